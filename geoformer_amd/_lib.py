@@ -1,0 +1,80 @@
+"""ctypes binding of libgeoformer_hip.so (the C ABI declared in include/geoformer_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails this module raises.
+PyTorch is only used by callers for device memory and streams; pointers cross the boundary
+as plain integers.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+from ._build import LIB_PATH
+
+_lib = None
+
+
+class GeoFormerHipError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    P, I, F = c_void_p, c_int, c_float
+    sig = {
+        "gf_abi_version": (I, []),
+        "gf_last_error": (c_char_p, []),
+        "gf_index_words": (c_size_t, [I, I, I, I]),
+        "gf_index_scratch_bytes": (c_size_t, [c_size_t]),
+        "gf_index_build": (I, [P, I, P, I, I, I, I, P, P, P, P, P]),
+        "gf_rules_subm3": (I, [P, I, P, I, I, I, P, P, P, P, I, P, P]),
+        "gf_rules_down2": (I, [P, I, P, I, I, I, I, P, P, P, P, P, P, I, P, P, P, I, P, P, P]),
+        "gf_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+EXPORTS = None
+
+
+def load():
+    """Load the shared library (after ``import torch`` so both share one HIP runtime)."""
+    global _lib, EXPORTS
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GeoFormerHipError(
+            f"{LIB_PATH} is missing: build it with `python -m geoformer_amd._build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the HIP operators."
+        )
+    import torch  # noqa: F401  (loads libamdhip64 first; our library binds to the same SONAME)
+
+    lib = ctypes.CDLL(LIB_PATH)
+    EXPORTS = _declare(lib)
+    if lib.gf_abi_version() != 1:
+        raise GeoFormerHipError("libgeoformer_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().gf_last_error()
+        raise GeoFormerHipError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,50 @@
+// Shared device/host helpers for the gfx950 kernels of libgeoformer_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "geoformer_hip.h"
+
+#define GF_WAVE 64
+
+// ---- error plumbing: every entry point returns 0 or a negative gf_status ----
+void gf_set_error(const char* fmt, ...);
+
+#define GF_CHECK_ARG(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            gf_set_error(__VA_ARGS__);   \
+            return GF_ERR_INVALID_ARG;   \
+        }                                \
+    } while (0)
+
+#define GF_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            gf_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return GF_ERR_LAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+
+static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- occupancy-bitmap rank index (see spconv_rules.hip) ----
+struct GfIndex {
+    const uint32_t* bitmap;  // one bit per cell of the [B,X,Y,Z] grid
+    const int32_t* prefix;   // exclusive popcount prefix per 32-bit word
+    const int32_t* perm;     // rank -> row, or nullptr when rows are already in rank order
+    int X, Y, Z;
+};
+
+__device__ __forceinline__ int gf_index_lookup(const GfIndex& ix, int b, int x, int y, int z) {
+    if ((unsigned)x >= (unsigned)ix.X || (unsigned)y >= (unsigned)ix.Y || (unsigned)z >= (unsigned)ix.Z) return -1;
+    unsigned long long lin = (((unsigned long long)b * ix.X + x) * ix.Y + y) * ix.Z + z;
+    unsigned long long w = lin >> 5;
+    unsigned bit = (unsigned)(lin & 31);
+    uint32_t word = ix.bitmap[w];
+    if (!((word >> bit) & 1u)) return -1;
+    int rank = ix.prefix[w] + __popc(word & ((1u << bit) - 1u));
+    return ix.perm ? ix.perm[rank] : rank;
+}

@@ -1,0 +1,161 @@
+"""Host side of the sparse-convolution path: rulebook objects and kernel launches.
+
+Thin Python over the C ABI (include/geoformer_hip.h).  PyTorch supplies device buffers and
+the current stream; all arithmetic happens in libgeoformer_hip.so.  The objects here play
+the role of spconv 1.0's ``indice_dict`` entries: one
+``SubmRules`` per ``indice_key="submL"`` and one ``DownRules`` per ``indice_key="spconvL"``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _round16(n: int) -> int:
+    return (int(n) + 15) // 16 * 16
+
+
+@dataclass
+class LevelIndex:
+    """Occupancy-bitmap rank index of one voxel set (see csrc/spconv_rules.hip)."""
+
+    bitmap: torch.Tensor  # uint32 words (stored as int32)
+    prefix: torch.Tensor  # int32
+    perm: Optional[torch.Tensor]  # rank -> row (None when rows are in rank order)
+    batch: int
+    shape: tuple  # (X, Y, Z)
+
+
+@dataclass
+class SubmRules:
+    nbr: torch.Tensor  # int32 [27, ld]
+    gmask: torch.Tensor  # int32 [ld/16]
+    ld: int
+    M: int
+    K: int = 27
+
+    def pairs(self):
+        """Canonical spconv pair lists: for each offset k the (in,out) pairs in ascending out."""
+        out = []
+        for k in range(self.K):
+            col = self.nbr[k, : self.M]
+            o = torch.nonzero(col >= 0).view(-1)
+            out.append(torch.stack([col[o].long(), o]))
+        return out
+
+
+@dataclass
+class DownRules:
+    out_coords: torch.Tensor  # int32 [M_out,4]
+    M_in: int
+    M_out: int
+    child: torch.Tensor  # int32 [8, ld]
+    ld: int
+    gmask_down: torch.Tensor
+    parent: torch.Tensor  # int32 [M_in]
+    koff: torch.Tensor  # int32 [M_in]
+    up: torch.Tensor  # int32 [8, ld_up]
+    ld_up: int
+    gmask_up: torch.Tensor
+    index_out: LevelIndex
+    out_shape: tuple
+
+
+def _scratch(words: int, device):
+    lib = _lib.load()
+    nbytes = lib.gf_index_scratch_bytes(words)
+    return torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=device)
+
+
+def build_index(coords: torch.Tensor, batch: int, shape) -> LevelIndex:
+    """coords int32 [M,4] (b,x,y,z) on the GPU, unique rows."""
+    lib = _lib.load()
+    assert coords.is_cuda and coords.dtype == torch.int32 and coords.is_contiguous()
+    X, Y, Z = (int(s) for s in shape)
+    M = coords.shape[0]
+    words = lib.gf_index_words(batch, X, Y, Z)
+    dev = coords.device
+    bitmap = torch.empty(words, dtype=torch.int32, device=dev)
+    prefix = torch.empty(words, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    scratch = _scratch(words, dev)
+    check(
+        lib.gf_index_build(ptr(coords), M, None, batch, X, Y, Z, ptr(bitmap), ptr(prefix), ptr(perm), ptr(scratch),
+                           stream_ptr()),
+        "gf_index_build",
+    )
+    return LevelIndex(bitmap, prefix, perm, batch, (X, Y, Z))
+
+
+def subm_rules(coords: torch.Tensor, index: LevelIndex) -> SubmRules:
+    lib = _lib.load()
+    M = coords.shape[0]
+    ld = max(_round16(M), 16)
+    dev = coords.device
+    nbr = torch.empty((27, ld), dtype=torch.int32, device=dev)
+    gmask = torch.empty(ld // 16, dtype=torch.int32, device=dev)
+    X, Y, Z = index.shape
+    check(
+        lib.gf_rules_subm3(ptr(coords), M, None, X, Y, Z, ptr(index.bitmap), ptr(index.prefix), ptr(index.perm),
+                           ptr(nbr), ld, ptr(gmask), stream_ptr()),
+        "gf_rules_subm3",
+    )
+    return SubmRules(nbr, gmask, ld, M)
+
+
+def down_rules(coords: torch.Tensor, batch: int, shape) -> DownRules:
+    """k=2, s=2 rulebook; one host sync to learn the number of output voxels."""
+    lib = _lib.load()
+    X, Y, Z = (int(s) for s in shape)
+    OX, OY, OZ = (X - 2) // 2 + 1, (Y - 2) // 2 + 1, (Z - 2) // 2 + 1
+    M = coords.shape[0]
+    dev = coords.device
+    words = lib.gf_index_words(batch, OX, OY, OZ)
+    bitmap = torch.empty(words, dtype=torch.int32, device=dev)
+    prefix = torch.empty(words, dtype=torch.int32, device=dev)
+    scratch = _scratch(words, dev)
+    ld = max(_round16(M), 16)  # capacity: M_out <= M_in
+    ld_up = ld
+    out_coords = torch.empty((ld, 4), dtype=torch.int32, device=dev)
+    d_M_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    child = torch.empty((8, ld), dtype=torch.int32, device=dev)
+    parent = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    koff = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    up = torch.empty((8, ld_up), dtype=torch.int32, device=dev)
+    gmask_down = torch.empty(ld // 16, dtype=torch.int32, device=dev)
+    gmask_up = torch.empty(ld_up // 16, dtype=torch.int32, device=dev)
+    check(
+        lib.gf_rules_down2(ptr(coords), M, None, batch, X, Y, Z, ptr(bitmap), ptr(prefix), ptr(scratch),
+                           ptr(out_coords), ptr(d_M_out), ptr(child), ld, ptr(parent), ptr(koff), ptr(up), ld_up,
+                           ptr(gmask_down), ptr(gmask_up), stream_ptr()),
+        "gf_rules_down2",
+    )
+    M_out = int(d_M_out.item())
+    index_out = LevelIndex(bitmap, prefix, None, batch, (OX, OY, OZ))
+    return DownRules(out_coords[:M_out], M, M_out, child, ld, gmask_down, parent[:M], koff[:M], up, ld_up, gmask_up,
+                     index_out, (OX, OY, OZ))
+
+
+def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], gmask: Optional[torch.Tensor],
+             K: int, M_out: int, ld: int, in_scale=None, in_shift=None, residual=None, out=None) -> torch.Tensor:
+    """out[o] = sum_k act(feats[nbr[k,o]]) @ weight[k] (+ residual).  weight is [K,Cin,Cout] fp32."""
+    lib = _lib.load()
+    assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
+    assert weight.dtype == torch.float32 and weight.is_contiguous()
+    Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
+    assert feats.shape[1] == Cin, (feats.shape, weight.shape)
+    if out is None:
+        out = torch.empty((M_out, Cout), dtype=torch.float32, device=feats.device)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.shape == (M_out, Cout)
+    check(
+        lib.gf_conv_fwd(ptr(feats), ptr(weight), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
+                        ptr(in_shift), ptr(residual), ptr(out), stream_ptr()),
+        "gf_conv_fwd",
+    )
+    return out

@@ -1,0 +1,98 @@
+/*
+ * geoformer_hip.h -- C ABI of libgeoformer_hip.so, the MI355X (gfx950) native layer under
+ * GeoFormer's per-scene forward/backward hot path.
+ *
+ * Boundary rules
+ *   - plain pointers and sizes only (no torch types); every pointer is a DEVICE pointer
+ *     unless the parameter name starts with h_;
+ *   - every call is asynchronous on the hipStream_t passed as `stream` (void*), allocates
+ *     nothing and keeps no global state: the caller owns outputs and scratch;
+ *   - return value 0 = ok, negative = gf_status; gf_last_error() gives the message of the
+ *     calling thread's last failure.
+ *
+ * Each entry point names the reference interface it stands in for.  Reference paths are
+ * relative to the VinAIResearch/GeoFormer checkout; "spconv" is llijiang/spconv@740a5b7
+ * (un-vendored dependency of the reference, docs/INSTALL.md:27-47) and "faiss" the
+ * faiss-gpu package (docs/INSTALL.md:69-73).
+ */
+#ifndef GEOFORMER_HIP_H
+#define GEOFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_ABI_VERSION 1
+
+typedef enum {
+    GF_OK = 0,
+    GF_ERR_INVALID_ARG = -1,
+    GF_ERR_LAUNCH = -2,
+    GF_ERR_UNSUPPORTED = -3,
+} gf_status;
+
+int gf_abi_version(void);
+const char* gf_last_error(void);
+
+/* ===================================================================================
+ * Sparse convolution (stands in for spconv.ops.get_indice_pairs / indice_conv /
+ * indice_subm_conv / indice_inverse_conv, reached from geoformer.py:42-53 and
+ * geoformer_modules.py:15-35,63-105 through SubMConv3d / SparseConv3d /
+ * SparseInverseConv3d).
+ *
+ * Rulebooks are OUTPUT-STATIONARY neighbour tables: nbr[k*ld + o] = input row feeding
+ * output row o through kernel offset k (k = (kx*K+ky)*K+kz), or -1.  The canonical
+ * (in,out) pair lists of spconv are the non-negative entries of row k in ascending o.
+ * =================================================================================== */
+
+/* Number of 32-bit words in the occupancy bitmap of a [B,X,Y,Z] grid. */
+size_t gf_index_words(int B, int X, int Y, int Z);
+/* Scratch bytes gf_index_build / gf_rules_down2 need for a bitmap of `words` words. */
+size_t gf_index_scratch_bytes(size_t words);
+
+/* Build the occupancy-bitmap rank index of a voxel set.
+ *   coords  int32 [M,4] (batch,x,y,z), unique rows          (SparseConvTensor.indices)
+ *   bitmap  uint32[words]  out      prefix int32[words] out
+ *   perm    int32 [M] out: rank (ascending linear index) -> row
+ *   d_M     optional device int32 overriding M (M is then a capacity) */
+int gf_index_build(const int32_t* coords, int M, const int32_t* d_M, int B, int X, int Y, int Z, uint32_t* bitmap,
+                   int32_t* prefix, int32_t* perm, void* scratch, void* stream);
+
+/* Submanifold 3x3x3 (padding 1) neighbour table from an index.
+ *   perm may be NULL when rows are already in ascending linear order (levels >= 2).
+ *   nbr    int32 [27*ld] out, ld >= M rounded up to 16
+ *   gmask  uint32[ceil(M/16)] out: OR of the offsets present in each 16-row group */
+int gf_rules_subm3(const int32_t* coords, int M, const int32_t* d_M, int X, int Y, int Z, const uint32_t* bitmap,
+                   const int32_t* prefix, const int32_t* perm, int32_t* nbr, int ld, uint32_t* gmask, void* stream);
+
+/* Strided 2x2x2 / stride 2 rulebook: builds the OUTPUT level's index and tables.
+ *   in shape (X,Y,Z) -> out shape (X/2,Y/2,Z/2) (floor; inputs mapping outside are dropped)
+ *   bitmap_out/prefix_out: index of the output voxel set (rows in ascending linear order)
+ *   out_coords int32 [cap,4] out      d_M_out device int32 out (number of output voxels)
+ *   child  int32 [8*ld] out: child[k*ld + o] = input row under offset k, or -1
+ *   parent int32 [M] out (output row or -1)      koff int32 [M] out (kernel offset 0..7)
+ *   up     int32 [8*ld_up] out: one-hot table of the inverse conv (up[k*ld_up+i] = parent[i] iff k==koff[i])
+ *   gmask_down uint32[ceil(cap/16)], gmask_up uint32[ceil(M/16)] out */
+int gf_rules_down2(const int32_t* coords, int M, const int32_t* d_M, int B, int X, int Y, int Z,
+                   uint32_t* bitmap_out, int32_t* prefix_out, void* scratch, int32_t* out_coords,
+                   int32_t* d_M_out, int32_t* child, int ld, int32_t* parent, int32_t* koff, int32_t* up, int ld_up,
+                   uint32_t* gmask_down, uint32_t* gmask_up, void* stream);
+
+/* Forward gather-GEMM (output-stationary): out[o,:] = sum_k act(in[nbr[k][o],:]) @ W[k] (+ residual[o,:])
+ *   in fp32 [M_in,Cin]   W fp32 [K,Cin,Cout]   out fp32 [M_out,Cout]
+ *   nbr may be NULL with K == 1 (identity map: plain GEMM, the k=1 "i_branch" conv)
+ *   in_scale/in_shift  optional fp32 [Cin]: act(x) = max(x*scale + shift, 0) fused on the
+ *                      gathered rows (eval-mode BatchNorm1d + ReLU, geoformer_modules.py:19-26)
+ *   residual           optional fp32 [M_out,Cout] added in the epilogue (geoformer_modules.py:33)
+ *   Cout <= 128. */
+int gf_conv_fwd(const float* in, const float* W, const int32_t* nbr, const uint32_t* gmask, int K, int M_out, int ld,
+                int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, float* out,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOFORMER_HIP_H */

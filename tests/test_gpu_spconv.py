@@ -1,0 +1,124 @@
+"""GPU parity: HIP rulebooks (bit-exact) and gather-MFMA convolution (<=1e-4 abs) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import random_voxels
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("M,shape,B,surface", [(5000, (64, 48, 40), 2, True), (300, (12, 10, 9), 1, False),
+                                               (17, (128, 128, 128), 1, False), (1, (128, 128, 128), 1, False)])
+def test_subm_rules_bit_exact(hip, oracle, M, shape, B, surface):
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(M)
+    coords = random_voxels(rng, M, shape, B, surface)
+    M = coords.shape[0]
+    ref = oracle.rules_subm3(coords, shape)
+    c = _dev(coords)
+    ix = sparse.build_index(c, B, shape)
+    rules = sparse.subm_rules(c, ix)
+    got = rules.nbr.cpu().numpy()
+    assert got.shape == ref.shape
+    assert (got == ref).all()
+    # group masks = OR of the offsets present in each 16-row group
+    gm = rules.gmask.cpu().numpy().view(np.uint32)
+    present = (ref >= 0).reshape(27, -1, 16).any(2)
+    expect = (present * (1 << np.arange(27))[:, None]).sum(0).astype(np.uint32)
+    assert (gm == expect).all()
+    # canonical pair lists: ascending output row inside every offset
+    for k, p in enumerate(rules.pairs()):
+        p = p.cpu().numpy()
+        assert (np.diff(p[1]) > 0).all()
+        assert (ref[k, p[1]] == p[0]).all()
+
+
+@pytest.mark.parametrize("M,shape,B", [(6000, (65, 47, 41), 2), (200, (11, 8, 13), 2), (3, (128, 128, 128), 1)])
+def test_down_rules_bit_exact(hip, oracle, M, shape, B):
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(M + 1)
+    coords = random_voxels(rng, M, shape, B, surface=M > 1000)
+    M = coords.shape[0]
+    oc, child, parent, koff = oracle.rules_down2(coords, shape)
+    r = sparse.down_rules(_dev(coords), B, shape)
+    assert r.M_out == oc.shape[0]
+    assert (r.out_coords.cpu().numpy() == oc).all()
+    assert (r.child.cpu().numpy()[:, : child.shape[1]] == child).all()
+    assert (r.parent.cpu().numpy() == parent).all()
+    assert (r.koff.cpu().numpy() == koff).all()
+    assert (r.up.cpu().numpy() == oracle.up_table(parent, koff, r.ld_up)).all()
+    # the output index answers subm lookups of the next level without a permutation
+    nxt = sparse.subm_rules(r.out_coords.contiguous(), r.index_out)
+    assert (nxt.nbr.cpu().numpy() == oracle.rules_subm3(oc, r.out_shape)).all()
+
+
+@pytest.mark.parametrize("Cin,Cout", [(6, 16), (16, 16), (32, 16), (32, 32), (48, 64), (112, 112), (19, 21)])
+def test_subm_conv_parity(hip, oracle, Cin, Cout):
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(Cin * 131 + Cout)
+    shape, B = (40, 36, 30), 2
+    coords = random_voxels(rng, 3000, shape, B, surface=True)
+    M = coords.shape[0]
+    feats = rng.standard_normal((M, Cin)).astype(np.float32)
+    W = (rng.standard_normal((27, Cin, Cout)) / np.sqrt(27 * Cin)).astype(np.float32)
+    nbr = oracle.rules_subm3(coords, shape)
+    ref = oracle.conv_fwd(feats, W, nbr, M)
+    c = _dev(coords)
+    rules = sparse.subm_rules(c, sparse.build_index(c, B, shape))
+    out = sparse.conv_fwd(_dev(feats), _dev(W), rules.nbr, rules.gmask, 27, M, rules.ld)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4  # tolerance of BASELINE.json north_star
+
+
+def test_conv_fused_bn_relu_residual_and_identity(hip, oracle):
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(5)
+    shape, B, Cin, Cout = (30, 30, 30), 1, 32, 16
+    coords = random_voxels(rng, 2000, shape, B, surface=True)
+    M = coords.shape[0]
+    feats = rng.standard_normal((M, Cin)).astype(np.float32)
+    W = (rng.standard_normal((27, Cin, Cout)) / np.sqrt(27 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cin).astype(np.float32)
+    shift = rng.standard_normal(Cin).astype(np.float32)
+    res = rng.standard_normal((M, Cout)).astype(np.float32)
+    nbr = oracle.rules_subm3(coords, shape)
+    act = np.maximum(feats * scale + shift, 0).astype(np.float32)
+    ref = oracle.conv_fwd(act, W, nbr, M) + res
+    c = _dev(coords)
+    rules = sparse.subm_rules(c, sparse.build_index(c, B, shape))
+    out = sparse.conv_fwd(_dev(feats), _dev(W), rules.nbr, rules.gmask, 27, M, rules.ld, in_scale=_dev(scale),
+                          in_shift=_dev(shift), residual=_dev(res))
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+    # K == 1 identity map (the 1x1x1 i_branch conv, geoformer_modules.py:17-19) == plain GEMM
+    W1 = (rng.standard_normal((1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+    out1 = sparse.conv_fwd(_dev(feats), _dev(W1), None, None, 1, M, 0)
+    assert np.abs(out1.cpu().numpy() - feats @ W1[0]).max() < 1e-4
+
+
+def test_down_up_conv_parity(hip, oracle):
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(9)
+    shape, B, C0, C1 = (41, 36, 31), 2, 16, 32
+    coords = random_voxels(rng, 4000, shape, B, surface=True)
+    M = coords.shape[0]
+    feats = rng.standard_normal((M, C0)).astype(np.float32)
+    Wd = (rng.standard_normal((8, C0, C1)) / np.sqrt(8 * C0)).astype(np.float32)
+    Wu = (rng.standard_normal((8, C1, C0)) / np.sqrt(C1)).astype(np.float32)
+    oc, child, parent, koff = oracle.rules_down2(coords, shape)
+    ref_d = oracle.conv_fwd(feats, Wd, child, oc.shape[0])
+    ref_u = oracle.conv_fwd(ref_d, Wu, oracle.up_table(parent, koff), M)
+    r = sparse.down_rules(_dev(coords), B, shape)
+    d = sparse.conv_fwd(_dev(feats), _dev(Wd), r.child, r.gmask_down, 8, r.M_out, r.ld)
+    u = sparse.conv_fwd(d, _dev(Wu), r.up, r.gmask_up, 8, M, r.ld_up)
+    assert np.abs(d.cpu().numpy() - ref_d).max() < 1e-4
+    assert np.abs(u.cpu().numpy() - ref_u).max() < 1e-4
