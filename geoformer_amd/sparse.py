@@ -141,6 +141,32 @@ def down_rules(coords: torch.Tensor, batch: int, shape) -> DownRules:
                      index_out, (OX, OY, OZ))
 
 
+import weakref
+
+_PACK_CACHE = {}  # id(weight tensor) -> (weakref, (ptr, version, ...), packed)
+
+
+def pack_weights(weight: torch.Tensor) -> torch.Tensor:
+    """[K,Cin,Cout] (or spconv's [k,k,k,Cin,Cout]) fp32 -> MFMA B-operand stream order.
+
+    Cached per (storage, version) so eval-mode weights are packed once; a training step
+    that updates the parameter in place bumps ``_version`` and triggers a re-pack."""
+    lib = _lib.load()
+    Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
+    K = weight.numel() // (Cin * Cout)
+    key = (weight.data_ptr(), weight._version, K, Cin, Cout)
+    hit = _PACK_CACHE.get(id(weight))
+    if hit is not None and hit[0]() is weight and hit[1] == key:
+        return hit[2]
+    w = weight.detach()
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    wp = torch.empty(lib.gf_conv_packed_floats(K, Cin, Cout), dtype=torch.float32, device=w.device)
+    check(lib.gf_conv_pack_weights(ptr(w), K, Cin, Cout, ptr(wp), stream_ptr()), "gf_conv_pack_weights")
+    wid = id(weight)
+    _PACK_CACHE[wid] = (weakref.ref(weight, lambda _r, wid=wid: _PACK_CACHE.pop(wid, None)), key, wp)
+    return wp
+
+
 def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], gmask: Optional[torch.Tensor],
              K: int, M_out: int, ld: int, in_scale=None, in_shift=None, residual=None, out=None) -> torch.Tensor:
     """out[o] = sum_k act(feats[nbr[k,o]]) @ weight[k] (+ residual).  weight is [K,Cin,Cout] fp32."""
@@ -154,7 +180,7 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == (M_out, Cout)
     check(
-        lib.gf_conv_fwd(ptr(feats), ptr(weight), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
+        lib.gf_conv_fwd(ptr(feats), ptr(pack_weights(weight)), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
                         ptr(in_shift), ptr(residual), ptr(out), stream_ptr()),
         "gf_conv_fwd",
     )

@@ -81,14 +81,21 @@ int gf_rules_down2(const int32_t* coords, int M, const int32_t* d_M, int B, int 
                    int32_t* d_M_out, int32_t* child, int ld, int32_t* parent, int32_t* koff, int32_t* up, int ld_up,
                    uint32_t* gmask_down, uint32_t* gmask_up, void* stream);
 
+/* Weight pre-packing: spconv's parameter layout [k,k,k,Cin,Cout] (= [K,Cin,Cout], kept as the
+ * state-dict layout, checkpoint.py:47-49) -> the per-lane MFMA B-operand order the conv kernel
+ * streams with one 16-byte load per lane.  Wp holds gf_conv_packed_floats(K,Cin,Cout) floats
+ * (channels zero-padded to multiples of 16). */
+size_t gf_conv_packed_floats(int K, int Cin, int Cout);
+int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
+
 /* Forward gather-GEMM (output-stationary): out[o,:] = sum_k act(in[nbr[k][o],:]) @ W[k] (+ residual[o,:])
- *   in fp32 [M_in,Cin]   W fp32 [K,Cin,Cout]   out fp32 [M_out,Cout]
+ *   in fp32 [M_in,Cin]   Wp = packed W (gf_conv_pack_weights)   out fp32 [M_out,Cout]
  *   nbr may be NULL with K == 1 (identity map: plain GEMM, the k=1 "i_branch" conv)
  *   in_scale/in_shift  optional fp32 [Cin]: act(x) = max(x*scale + shift, 0) fused on the
  *                      gathered rows (eval-mode BatchNorm1d + ReLU, geoformer_modules.py:19-26)
  *   residual           optional fp32 [M_out,Cout] added in the epilogue (geoformer_modules.py:33)
  *   Cout <= 128. */
-int gf_conv_fwd(const float* in, const float* W, const int32_t* nbr, const uint32_t* gmask, int K, int M_out, int ld,
+int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_out, int ld,
                 int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, float* out,
                 void* stream);
 
