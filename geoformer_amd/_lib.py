@@ -32,6 +32,19 @@ def _declare(lib):
         "gf_conv_packed_floats": (c_size_t, [I, I, I]),
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P]),
+        "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
+        "gf_voxelize_bp": (I, [P, P, I, I, I, I, P, P]),
+        "gf_gather_points": (I, [P, P, I, I, I, I, P, P]),
+        "gf_gather_points_grad": (I, [P, P, I, I, I, I, P, P]),
+        "gf_group_points": (I, [P, P, I, I, I, I, I, P, P]),
+        "gf_group_points_grad": (I, [P, P, I, I, I, I, I, P, P]),
+        "gf_ball_query": (I, [P, P, I, I, I, F, I, P, P]),
+        "gf_fps_scratch_bytes": (c_size_t, [I]),
+        "gf_furthest_point_sampling": (I, [P, I, I, I, P, P, P]),
+        "gf_knn_scratch_bytes": (c_size_t, [I]),
+        "gf_knn_radius": (I, [P, I, I, F, I, P, P, P, P, P]),
+        "gf_knn_error_flag": (P, [P, I]),
+        "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

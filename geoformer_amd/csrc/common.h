@@ -48,3 +48,35 @@ __device__ __forceinline__ int gf_index_lookup(const GfIndex& ix, int b, int x, 
     int rank = ix.prefix[w] + __popc(word & ((1u << bit) - 1u));
     return ix.perm ? ix.perm[rank] : rank;
 }
+
+// ---- block-wide exclusive scan (256 threads), shared by the rulebook and kNN-grid builders ----
+#define SCAN_THREADS 256
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a 256-thread block; returns the exclusive prefix, *total gets the block sum
+__device__ __forceinline__ int block_excl_scan(int v, int* total) {
+    __shared__ int wsum[SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = wave_incl_scan(v);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; w++) {
+        int s = wsum[w];
+        if (w < wid) off += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return off + inc - v;
+}
+

@@ -1,0 +1,319 @@
+// Geodesic stage on gfx950: radius-limited kNN graph + hop-synchronous frontier BFS.
+//
+//   reference: model/geoformer/geodesic_utils.py:11-24 (find_knn over faiss GpuIndexFlatL2)
+//              model/geoformer/geodesic_utils.py:91-164 (cal_geodesic_vectorize)
+//
+// kNN.  The BFS only ever follows edges with sqrt(d2) <= radius (geodesic_utils.py:123,152), and
+// "the k nearest, then keep those within the radius" equals "the k nearest among those within the
+// radius" because the test is monotone in d2.  So instead of faiss' O(N^2) brute force the graph is
+// built from a spatial-hash grid with cell >= radius: 27 buckets per query point, exact fp32
+// d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)), neighbours ordered by (d2, index) -- the oracle's order
+// (oracle/gf_oracle.c orc_knn).  Rows are padded with (inf, -1).  One wave per point; candidates
+// inside the radius are compacted into LDS and ranked by counting (typical count ~15).
+//
+// BFS.  One workgroup per query walks its own frontier; per hop (a) every frontier vertex pushes
+// (parent<<6 | rank)+1 to its unvisited in-radius neighbours with atomicMin -- the minimum is the
+// lowest-index parent, then the lowest neighbour rank, which is exactly the entry the reference's
+// sort-based de-duplication keeps -- and the first toucher appends the vertex to the next frontier;
+// (b) after a barrier the new frontier commits geo[v] = geo[parent] + D[parent][rank].  Distances
+// are fp32 sums along that parent chain, so results are bit-identical to the reference's.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------
+// spatial hash grid
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int3 cell_of(float x, float y, float z, float inv_cell) {
+    return make_int3((int)floorf(x * inv_cell), (int)floorf(y * inv_cell), (int)floorf(z * inv_cell));
+}
+__device__ __forceinline__ unsigned bucket_of(int cx, int cy, int cz, unsigned tmask) {
+    return (((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u) ^ ((unsigned)cz * 83492791u)) & tmask;
+}
+
+__global__ void k_grid_count(const float* __restrict__ xyz, int n, float inv_cell, unsigned tmask,
+                             int32_t* __restrict__ counts) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int3 c = cell_of(xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], inv_cell);
+    atomicAdd(&counts[bucket_of(c.x, c.y, c.z, tmask)], 1);
+}
+
+#define ISCAN_IPT 4
+#define ISCAN_IPB (SCAN_THREADS * ISCAN_IPT)
+__global__ void k_iscan_block_sums(const int32_t* __restrict__ v, int n, int32_t* __restrict__ block_sums) {
+    int base = blockIdx.x * ISCAN_IPB + threadIdx.x * ISCAN_IPT;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < ISCAN_IPT; j++)
+        if (base + j < n) s += v[base + j];
+    int tot;
+    block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+__global__ void k_iscan_top(const int32_t* __restrict__ block_sums, int nblocks, int32_t* __restrict__ block_off) {
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += SCAN_THREADS) {
+        int i = base + threadIdx.x;
+        int val = i < nblocks ? block_sums[i] : 0;
+        int tot;
+        int ex = block_excl_scan(val, &tot);
+        int carry = carry_s;
+        if (i < nblocks) block_off[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+}
+// start[i] = exclusive prefix of counts; start[n] = total; cursor[i] = start[i]
+__global__ void k_iscan_apply(const int32_t* __restrict__ v, int n, const int32_t* __restrict__ block_off,
+                              int32_t* __restrict__ start, int32_t* __restrict__ cursor) {
+    int base = blockIdx.x * ISCAN_IPB + threadIdx.x * ISCAN_IPT;
+    int c[ISCAN_IPT];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < ISCAN_IPT; j++) {
+        c[j] = (base + j < n) ? v[base + j] : 0;
+        s += c[j];
+    }
+    int tot;
+    int ex = block_excl_scan(s, &tot) + block_off[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < ISCAN_IPT; j++) {
+        if (base + j < n) {
+            start[base + j] = ex;
+            cursor[base + j] = ex;
+        }
+        ex += c[j];
+        if (base + j == n - 1) start[n] = ex;
+    }
+}
+
+__global__ void k_grid_fill(const float* __restrict__ xyz, int n, float inv_cell, unsigned tmask,
+                            int32_t* __restrict__ cursor, float4* __restrict__ sorted) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = xyz[i * 3 + 0], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+    int3 c = cell_of(x, y, z, inv_cell);
+    int pos = atomicAdd(&cursor[bucket_of(c.x, c.y, c.z, tmask)], 1);
+    sorted[pos] = make_float4(x, y, z, __int_as_float(i));
+}
+
+#define KNN_WAVES 4
+#define KNN_CAP 512  // in-radius candidates per query point held in LDS
+__global__ __launch_bounds__(KNN_WAVES * 64) void k_knn_radius(const float* __restrict__ xyz, int n, int k,
+                                                               float radius, float inv_cell, unsigned tmask,
+                                                               const int32_t* __restrict__ start,
+                                                               const float4* __restrict__ sorted, int sqrt_out,
+                                                               float* __restrict__ D, int32_t* __restrict__ I,
+                                                               int32_t* __restrict__ deg, int* __restrict__ err) {
+    __shared__ unsigned long long s_keys[KNN_WAVES][KNN_CAP];
+    __shared__ int s_off[KNN_WAVES][28];
+    __shared__ int s_beg[KNN_WAVES][27];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i = blockIdx.x * KNN_WAVES + wid;
+    if (i >= n) return;  // whole wave exits together (no block-level barrier below)
+    const float qx = xyz[i * 3 + 0], qy = xyz[i * 3 + 1], qz = xyz[i * 3 + 2];
+    const int3 qc = cell_of(qx, qy, qz, inv_cell);
+    // lanes 0..26 fetch the 27 bucket ranges
+    int beg = 0, cnt = 0;
+    int ncx = 0, ncy = 0, ncz = 0;
+    if (lane < 27) {
+        ncx = qc.x + lane / 9 - 1;
+        ncy = qc.y + (lane / 3) % 3 - 1;
+        ncz = qc.z + lane % 3 - 1;
+        const unsigned h = bucket_of(ncx, ncy, ncz, tmask);
+        beg = start[h];
+        cnt = start[h + 1] - beg;
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane < 27) {
+        s_off[wid][lane + 1] = inc;
+        s_beg[wid][lane] = beg;
+    }
+    if (lane == 0) s_off[wid][0] = 0;
+    const int total = __shfl(inc, 26, 64);
+    __builtin_amdgcn_wave_barrier();
+    // sweep the concatenated candidate ranges with all 64 lanes
+    int nin = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        bool hit = false;
+        unsigned long long key = 0;
+        if (t < total) {
+            int c = 0;
+#pragma unroll
+            for (int s = 1; s < 27; s++) c += (s_off[wid][s] <= t) ? 1 : 0;
+            const float4 p = sorted[s_beg[wid][c] + (t - s_off[wid][c])];
+            // a bucket may hold several cells (hash collisions) and several of the 27 cells may share a
+            // bucket: keep the candidate only when it really lies in the cell this slot stands for
+            const int3 pc = cell_of(p.x, p.y, p.z, inv_cell);
+            const int ex = qc.x + c / 9 - 1, ey = qc.y + (c / 3) % 3 - 1, ez = qc.z + c % 3 - 1;
+            if (pc.x == ex && pc.y == ey && pc.z == ez) {
+                const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                if (sqrtf(d2) <= radius) {
+                    hit = true;
+                    key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p.w);
+                }
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        const int pos = nin + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < KNN_CAP) s_keys[wid][pos] = key;
+        nin += __popcll(bal);
+    }
+    if (nin > KNN_CAP) {
+        if (lane == 0) *err = 1;  // more in-radius points than the LDS list holds: reported to the host
+        nin = KNN_CAP;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rank by counting: keys are unique (index in the low word), so ranks are a permutation
+    for (int t = lane; t < nin; t += 64) {
+        const unsigned long long key = s_keys[wid][t];
+        int rank = 0;
+        for (int j = 0; j < nin; j++) rank += (s_keys[wid][j] < key) ? 1 : 0;
+        if (rank < k) {
+            const float d2 = __uint_as_float((unsigned)(key >> 32));
+            D[(size_t)i * k + rank] = sqrt_out ? sqrtf(d2) : d2;
+            I[(size_t)i * k + rank] = (int)(unsigned)(key & 0xffffffffu);
+        }
+    }
+    for (int t = nin + lane; t < k; t += 64) {
+        D[(size_t)i * k + t] = __builtin_inff();
+        I[(size_t)i * k + t] = -1;
+    }
+    if (lane == 0 && deg) deg[i] = (nin < k ? nin : k) - 1;
+}
+
+static unsigned knn_table_size(int n) {
+    unsigned t = 1024;
+    while (t < 4u * (unsigned)n && t < (1u << 26)) t <<= 1;
+    return t;
+}
+extern "C" size_t gf_knn_scratch_bytes(int n) {
+    const size_t T = knn_table_size(n);
+    const size_t nb = (T + ISCAN_IPB - 1) / ISCAN_IPB;
+    // counts[T] start[T+1] cursor[T] block_sums[nb] block_off[nb] err[4] sorted[n] float4
+    return (3 * T + 8 + 2 * nb + 8) * sizeof(int32_t) + (size_t)(n + 1) * sizeof(float4) + 64;
+}
+
+extern "C" int gf_knn_radius(const float* xyz, int n, int k, float radius, int sqrt_out, float* D, int32_t* I,
+                             int32_t* deg, void* scratch, void* stream) {
+    GF_CHECK_ARG(n >= 0 && k >= 1 && k <= 64 && radius > 0.f, "gf_knn_radius: bad arguments n=%d k=%d r=%g", n, k,
+                 radius);
+    if (n == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned T = knn_table_size(n);
+    const int nb = (int)((T + ISCAN_IPB - 1) / ISCAN_IPB);
+    int32_t* counts = (int32_t*)scratch;
+    int32_t* start = counts + T;
+    int32_t* cursor = start + T + 1;
+    int32_t* block_sums = cursor + T;
+    int32_t* block_off = block_sums + nb;
+    int* err = (int*)(block_off + nb);
+    uintptr_t sp = ((uintptr_t)(err + 8) + 63) & ~(uintptr_t)63;
+    float4* sorted = (float4*)sp;
+    const float cell = radius * 1.001f;
+    const float inv_cell = 1.0f / cell;
+    hipMemsetAsync(counts, 0, (size_t)T * sizeof(int32_t), st);
+    hipMemsetAsync(err, 0, sizeof(int), st);
+    hipLaunchKernelGGL(k_grid_count, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, n, inv_cell, T - 1, counts);
+    hipLaunchKernelGGL(k_iscan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, counts, (int)T, block_sums);
+    hipLaunchKernelGGL(k_iscan_top, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, block_off);
+    hipLaunchKernelGGL(k_iscan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, counts, (int)T, block_off, start, cursor);
+    hipLaunchKernelGGL(k_grid_fill, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, n, inv_cell, T - 1, cursor, sorted);
+    hipLaunchKernelGGL(k_knn_radius, dim3(gf_div_up(n, KNN_WAVES)), dim3(KNN_WAVES * 64), 0, st, xyz, n, k, radius,
+                       inv_cell, T - 1, start, sorted, sqrt_out, D, I, deg, err);
+    GF_CHECK_LAUNCH("gf_knn_radius");
+    return GF_OK;
+}
+// device flag set when a point had more than KNN_CAP in-radius neighbours (result rows truncated)
+extern "C" const int32_t* gf_knn_error_flag(void* scratch, int n) {
+    const unsigned T = knn_table_size(n);
+    const int nb = (int)((T + ISCAN_IPB - 1) / ISCAN_IPB);
+    return (const int32_t*)scratch + 3 * (size_t)T + 1 + 2 * (size_t)nb;
+}
+
+// ------------------------------------------------------------------------------------
+// frontier BFS
+// ------------------------------------------------------------------------------------
+#define BFS_THREADS 512
+__global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __restrict__ D, const int32_t* __restrict__ I,
+                                                              const int32_t* __restrict__ deg, int n, int K,
+                                                              const int32_t* __restrict__ src, float radius,
+                                                              int max_step, float* __restrict__ geo,
+                                                              unsigned* __restrict__ keys,
+                                                              int32_t* __restrict__ queues) {
+    __shared__ int s_cnt;
+    const int q = blockIdx.x;
+    float* g = geo + (size_t)q * n;
+    unsigned* key = keys + (size_t)q * n;
+    int32_t* cur = queues + (size_t)q * 2 * n;
+    int32_t* nxt = cur + n;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < n; t += BFS_THREADS) {
+        g[t] = -1.0f;
+        key[t] = 0xffffffffu;
+    }
+    const int s = src[q];
+    __syncthreads();
+    if (tid == 0) {
+        g[s] = 0.0f;
+        cur[0] = s;
+        s_cnt = 0;
+    }
+    __syncthreads();
+    int ncur = 1;
+    const int sub = tid >> 4, sl = tid & 15;  // one frontier vertex per 16-lane sub-group
+    for (int step = 0; step < max_step && ncur > 0; step++) {
+        for (int f = sub; f < ncur; f += BFS_THREADS / 16) {
+            const int u = cur[f];
+            const int du = deg ? deg[u] : K - 1;
+            for (int r = 1 + sl; r <= du; r += 16) {
+                const int v = I[(size_t)u * K + r];
+                const float d = D[(size_t)u * K + r];
+                if (v >= 0 && d <= radius && g[v] < 0.0f) {
+                    const unsigned cand = (((unsigned)u << 6) | (unsigned)r) + 1u;
+                    const unsigned old = atomicMin(&key[v], cand);
+                    if (old == 0xffffffffu) {
+                        const int pos = atomicAdd(&s_cnt, 1);
+                        nxt[pos] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nn = s_cnt;
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+        for (int t = tid; t < nn; t += BFS_THREADS) {
+            const int v = nxt[t];
+            const unsigned kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+            const int u = (int)(kk >> 6), r = (int)(kk & 63u);
+            g[v] = D[(size_t)u * K + r] + g[u];
+        }
+        __syncthreads();
+        int32_t* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+        ncur = nn;
+    }
+}
+
+extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src,
+                               int nq, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
+                               void* stream) {
+    GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs: bad arguments");
+    GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs: n=%d exceeds the 26-bit parent field", n);
+    if (nq == 0) return GF_OK;
+    hipLaunchKernelGGL(k_geodesic_bfs, dim3(nq), dim3(BFS_THREADS), 0, (hipStream_t)stream, D, I, deg, n, K, src,
+                       radius, max_step, geo, (unsigned*)keys_ws, (int32_t*)queue_ws);
+    GF_CHECK_LAUNCH("gf_geodesic_bfs");
+    return GF_OK;
+}

@@ -30,7 +30,6 @@ extern "C" int gf_abi_version(void) { return GF_ABI_VERSION; }
 // ------------------------------------------------------------------------------------
 // bitmap + scan
 // ------------------------------------------------------------------------------------
-#define SCAN_THREADS 256
 #define SCAN_WPT 4  // words per thread
 #define SCAN_WPB (SCAN_THREADS * SCAN_WPT)
 
@@ -40,35 +39,6 @@ extern "C" size_t gf_index_words(int B, int X, int Y, int Z) {
 }
 static size_t scan_blocks(size_t words) { return (words + SCAN_WPB - 1) / SCAN_WPB; }
 extern "C" size_t gf_index_scratch_bytes(size_t words) { return (2 * scan_blocks(words) + 64) * sizeof(int32_t); }
-
-__device__ __forceinline__ int wave_incl_scan(int v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-// exclusive scan over a 256-thread block; returns the exclusive prefix, *total gets the block sum
-__device__ __forceinline__ int block_excl_scan(int v, int* total) {
-    __shared__ int wsum[SCAN_THREADS / 64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int inc = wave_incl_scan(v);
-    if (lane == 63) wsum[wid] = inc;
-    __syncthreads();
-    int off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < SCAN_THREADS / 64; w++) {
-        int s = wsum[w];
-        if (w < wid) off += s;
-        tot += s;
-    }
-    __syncthreads();
-    *total = tot;
-    return off + inc - v;
-}
 
 __global__ void k_set_bits(const int32_t* __restrict__ coords, int Mcap, const int32_t* __restrict__ d_M, int X,
                            int Y, int Z, uint32_t* __restrict__ bitmap) {

@@ -1,0 +1,138 @@
+"""Host side of the point-set operators (PG_OP / pointnet2._ext / geodesic stage).
+
+Plain functions over device tensors; every one launches a kernel of libgeoformer_hip.so on
+the current stream.  The module-shaped mirrors of the reference bindings live in
+``geoformer_amd.dropin``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _f32c(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected a contiguous float32 tensor on the GPU")
+    return t
+
+
+def _i32c(t, name):
+    if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected a contiguous int32 tensor on the GPU")
+    return t
+
+
+# ---- PG_OP ---------------------------------------------------------------------------
+def voxelize_fp(feats, rules, mode=4, out=None):
+    _f32c(feats, "feats"); _i32c(rules, "rules")
+    M, C = rules.shape[0], feats.shape[1]
+    if out is None:
+        out = torch.empty((M, C), dtype=torch.float32, device=feats.device)
+    check(_lib.load().gf_voxelize_fp(ptr(feats), ptr(rules), M, rules.shape[1] - 1, C, int(mode == 4), ptr(out),
+                                     stream_ptr()), "gf_voxelize_fp")
+    return out
+
+
+def voxelize_bp(d_out, rules, mode, d_feats):
+    """d_feats [N,C] must be zero-initialised by the caller (accumulated into)."""
+    _f32c(d_out, "d_out"); _i32c(rules, "rules"); _f32c(d_feats, "d_feats")
+    M, C = d_out.shape
+    check(_lib.load().gf_voxelize_bp(ptr(d_out), ptr(rules), M, rules.shape[1] - 1, C, int(mode == 4), ptr(d_feats),
+                                     stream_ptr()), "gf_voxelize_bp")
+    return d_feats
+
+
+# ---- pointnet2._ext --------------------------------------------------------------------
+def gather_points(points, idx):
+    _f32c(points, "points"); _i32c(idx, "idx")
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    check(_lib.load().gf_gather_points(ptr(points), ptr(idx), b, c, n, m, ptr(out), stream_ptr()), "gf_gather_points")
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    _f32c(grad_out, "grad_out"); _i32c(idx, "idx")
+    b, c, m = grad_out.shape
+    out = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+    check(_lib.load().gf_gather_points_grad(ptr(grad_out), ptr(idx), b, c, n, m, ptr(out), stream_ptr()),
+          "gf_gather_points_grad")
+    return out
+
+
+def group_points(points, idx):
+    _f32c(points, "points"); _i32c(idx, "idx")
+    b, c, n = points.shape
+    _, npoints, nsample = idx.shape
+    out = torch.empty((b, c, npoints, nsample), dtype=torch.float32, device=points.device)
+    check(_lib.load().gf_group_points(ptr(points), ptr(idx), b, c, n, npoints, nsample, ptr(out), stream_ptr()),
+          "gf_group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    _f32c(grad_out, "grad_out"); _i32c(idx, "idx")
+    b, c, npoints, nsample = grad_out.shape
+    out = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+    check(_lib.load().gf_group_points_grad(ptr(grad_out), ptr(idx), b, c, n, npoints, nsample, ptr(out),
+                                           stream_ptr()), "gf_group_points_grad")
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    _f32c(new_xyz, "new_xyz"); _f32c(xyz, "xyz")
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz.device)
+    check(_lib.load().gf_ball_query(ptr(new_xyz), ptr(xyz), b, n, m, float(radius), nsample, ptr(idx), stream_ptr()),
+          "gf_ball_query")
+    return idx
+
+
+def furthest_point_sampling(xyz, m):
+    _f32c(xyz, "xyz")
+    b, n, _ = xyz.shape
+    lib = _lib.load()
+    idx = torch.empty((b, m), dtype=torch.int32, device=xyz.device)
+    scratch = torch.empty(lib.gf_fps_scratch_bytes(b) // 8 + 1, dtype=torch.int64, device=xyz.device)
+    check(lib.gf_furthest_point_sampling(ptr(xyz), b, n, m, ptr(idx), ptr(scratch), stream_ptr()),
+          "gf_furthest_point_sampling")
+    return idx
+
+
+# ---- geodesic stage --------------------------------------------------------------------
+def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False):
+    """Radius-limited kNN graph of one scene.  Returns D [n,k] fp32, I [n,k] int32, deg [n] int32."""
+    _f32c(xyz, "xyz")
+    n = xyz.shape[0]
+    lib = _lib.load()
+    dev = xyz.device
+    D = torch.empty((n, k), dtype=torch.float32, device=dev)
+    I = torch.empty((n, k), dtype=torch.int32, device=dev)
+    deg = torch.empty(n, dtype=torch.int32, device=dev)
+    scratch = torch.empty(lib.gf_knn_scratch_bytes(n) // 4 + 16, dtype=torch.int32, device=dev)
+    check(lib.gf_knn_radius(ptr(xyz), n, k, float(radius), int(sqrt_out), ptr(D), ptr(I), ptr(deg), ptr(scratch),
+                            stream_ptr()), "gf_knn_radius")
+    if check_overflow:
+        off = (lib.gf_knn_error_flag(ptr(scratch), n) - scratch.data_ptr()) // 4
+        if int(scratch[off].item()) != 0:
+            raise _lib.GeoFormerHipError("gf_knn_radius: a point has more in-radius neighbours than the kernel's "
+                                         "candidate list holds (rows truncated)")
+    return D, I, deg
+
+
+def geodesic_bfs(D, I, deg, src, radius, max_step):
+    """geo [nq,n] fp32 for the sources `src` (int32 [nq]) over the kNN rows D/I (column 0 skipped)."""
+    _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
+    n, K = D.shape
+    nq = src.shape[0]
+    dev = D.device
+    geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
+    keys = torch.empty((nq, n), dtype=torch.int32, device=dev)
+    queues = torch.empty((nq, 2, n), dtype=torch.int32, device=dev)
+    check(_lib.load().gf_geodesic_bfs(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
+                                      ptr(geo), ptr(keys), ptr(queues), stream_ptr()), "gf_geodesic_bfs")
+    return geo

@@ -99,6 +99,67 @@ int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint
                 int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, float* out,
                 void* stream);
 
+/* ===================================================================================
+ * PG_OP (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-23)
+ * =================================================================================== */
+
+/* PG_OP.voxelize_fp (voxelize.cu:9-31): out[row,:] = sum_i mult * feats[rules[row,i],:], i in rule
+ * order, mult = 1/count when average (mode 4).  rules int32 [M, 1+maxActive].  out fp32 [M,C]. */
+int gf_voxelize_fp(const float* feats, const int32_t* rules, int M, int maxActive, int C, int average, float* out,
+                   void* stream);
+/* PG_OP.voxelize_bp / point_recover_fp (voxelize.cu:34-53): d_feats[rules[row,i],:] += mult*d_out[row,:];
+ * d_feats must be zeroed by the caller (pointgroup_ops.py:69). */
+int gf_voxelize_bp(const float* d_out, const int32_t* rules, int M, int maxActive, int C, int average, float* d_feats,
+                   void* stream);
+
+/* ===================================================================================
+ * pointnet2._ext (lib/pointnet2/_ext_src/src/bindings.cpp:8-21)
+ * =================================================================================== */
+
+/* gather_points (sampling_gpu.cu:11-33): out[b,c,j] = points[b,c,idx[b,j]] */
+int gf_gather_points(const float* points, const int32_t* idx, int b, int c, int n, int m, float* out, void* stream);
+/* gather_points_grad (sampling_gpu.cu:37-60): grad_points[b,c,idx[b,j]] += grad_out[b,c,j] (zeroed by caller) */
+int gf_gather_points_grad(const float* grad_out, const int32_t* idx, int b, int c, int n, int m, float* grad_points,
+                          void* stream);
+/* group_points (group_points_gpu.cu:11-42): out[b,c,j,s] = points[b,c,idx[b,j,s]] */
+int gf_group_points(const float* points, const int32_t* idx, int b, int c, int n, int npoints, int nsample, float* out,
+                    void* stream);
+/* group_points_grad (group_points_gpu.cu:46-78) */
+int gf_group_points_grad(const float* grad_out, const int32_t* idx, int b, int c, int n, int npoints, int nsample,
+                         float* grad_points, void* stream);
+/* ball_query (ball_query_gpu.cu:12-57): first nsample indices in ascending order with d2 < radius^2,
+ * padded with the first hit; rows without a hit are all zero.  idx int32 [b,m,nsample] (fully written). */
+int gf_ball_query(const float* new_xyz, const float* xyz, int b, int n, int m, float radius, int nsample, int32_t* idx,
+                  void* stream);
+/* furthest_point_sampling (sampling_gpu.cu:72-232) incl. the |p|^2 <= 1e-3 skip, the m > n padding
+ * and the launch-geometry tie-break of the reference.  xyz fp32 [b,n,3] -> idxs int32 [b,m].
+ * scratch: gf_fps_scratch_bytes(b) bytes (zeroed by the call). */
+size_t gf_fps_scratch_bytes(int b);
+int gf_furthest_point_sampling(const float* xyz, int b, int n, int m, int32_t* idxs, void* scratch, void* stream);
+
+/* ===================================================================================
+ * Geodesic stage (model/geoformer/geodesic_utils.py)
+ * =================================================================================== */
+
+/* Radius-limited kNN graph (stands in for find_knn, geodesic_utils.py:11-24, on the geodesic path):
+ * for every point the k nearest points with sqrt(d2) <= radius, ordered by (d2, index), itself
+ * included (normally column 0); missing entries are (inf, -1).
+ *   D fp32 [n,k] (sqrt(d2) when sqrt_out, else squared like faiss)   I int32 [n,k]
+ *   deg int32 [n] optional: number of valid entries after column 0
+ *   scratch: gf_knn_scratch_bytes(n); gf_knn_error_flag() points at a device int set to 1 when some
+ *   point had more in-radius neighbours than the kernel's list capacity (rows then truncated). */
+size_t gf_knn_scratch_bytes(int n);
+int gf_knn_radius(const float* xyz, int n, int k, float radius, int sqrt_out, float* D, int32_t* I, int32_t* deg,
+                  void* scratch, void* stream);
+const int32_t* gf_knn_error_flag(void* scratch, int n);
+
+/* Hop-synchronous geodesic BFS (cal_geodesic_vectorize, geodesic_utils.py:91-164) for nq sources of
+ * one scene.  D/I are kNN rows INCLUDING column 0 (which is skipped, :110-111), D already sqrt'ed.
+ *   geo fp32 [nq,n] out (-1 = not reached within max_step hops)
+ *   keys_ws: nq*n uint32, queue_ws: nq*2*n int32 (scratch). */
+int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
+                    float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

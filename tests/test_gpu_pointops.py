@@ -1,0 +1,94 @@
+"""GPU parity of the point-set operators against the oracle (bit-exact indices, exact copies)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _scene_points(n, seed):
+    from geoformer_amd import scene
+
+    sc = scene.make_scene(max(n, 64), seed)
+    p = sc["xyz"]
+    rng = np.random.default_rng(seed)
+    sel = rng.permutation(p.shape[0])[:n]
+    return np.ascontiguousarray(p[sel])
+
+
+def test_voxelize_fp_bp(hip, oracle):
+    from geoformer_amd import pointops, scene
+
+    sc = scene.make_small_scene(8192, 3)
+    batch = scene.make_batch([sc])
+    feats = np.concatenate([sc["rgb"], sc["xyz"]], 1).astype(np.float32)
+    rules = batch["v2p_map"].numpy()
+    ref = oracle.voxelize_fp(feats, rules, True)
+    out = pointops.voxelize_fp(_dev(feats), _dev(rules), 4)
+    assert (out.cpu().numpy() == ref).all()  # same rounding sequence -> bit-exact
+    g = np.random.default_rng(0).standard_normal(ref.shape).astype(np.float32)
+    refb = oracle.voxelize_bp(g, rules, feats.shape[0], True)
+    d = torch.zeros(feats.shape, device="cuda")
+    pointops.voxelize_bp(_dev(g), _dev(rules), 4, d)
+    assert (d.cpu().numpy() == refb).all()
+
+
+@pytest.mark.parametrize("n,m", [(20000, 2048), (50000, 2048), (3000, 32), (700, 2048), (5, 16), (513, 64)])
+def test_fps_bit_exact(hip, oracle, n, m):
+    from geoformer_amd import pointops
+
+    xyz = _scene_points(n, n)[None]
+    ref = oracle.fps(xyz, m)
+    got = pointops.furthest_point_sampling(_dev(xyz), m).cpu().numpy()
+    assert (got == ref).all()
+
+
+def test_fps_ties_skip_and_batch(hip, oracle):
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(11)
+    a = _scene_points(4000, 5)
+    a[100:140] = a[7]  # exact duplicates -> exact distance ties
+    a[200] = 0.0  # |p|^2 <= 1e-3 is never selected (sampling_gpu.cu:104)
+    a[201] = [0.02, 0.01, 0.0]
+    b = np.round(rng.uniform(-1, 1, (4000, 3)) * 4) / 4  # lattice: many exact ties
+    xyz = np.stack([a, b.astype(np.float32)])
+    ref = oracle.fps(xyz, 300)
+    got = pointops.furthest_point_sampling(_dev(xyz), 300).cpu().numpy()
+    assert (got == ref).all()
+    assert 200 not in got[0, 1:] and 201 not in got[0, 1:]
+
+
+@pytest.mark.parametrize("n,m,ns", [(20000, 2048, 64), (50000, 2048, 64), (900, 37, 16)])
+def test_ball_query_bit_exact(hip, oracle, n, m, ns):
+    from geoformer_amd import pointops
+
+    xyz = _scene_points(n, n + 1)[None]
+    centers = xyz[:, oracle.fps(xyz, m)[0]]
+    centers[0, -1] = 50.0  # a centre with no neighbour: row stays all-zero (ball_query.cpp:22-24)
+    ref = oracle.ball_query(centers, xyz, 0.2, ns)
+    got = pointops.ball_query(_dev(centers), _dev(xyz), 0.2, ns).cpu().numpy()
+    assert (got == ref).all()
+    assert (got[0, -1] == 0).all()
+
+
+def test_gather_group_and_grads(hip, oracle):
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(3)
+    b, c, n, m, ns = 2, 16, 5000, 256, 64
+    pts = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m)).astype(np.int32)
+    gidx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    assert (pointops.gather_points(_dev(pts), _dev(idx)).cpu().numpy() == oracle.gather_points(pts, idx)).all()
+    assert (pointops.group_points(_dev(pts), _dev(gidx)).cpu().numpy() == oracle.group_points(pts, gidx)).all()
+    go = rng.standard_normal((b, c, m)).astype(np.float32)
+    ggo = rng.standard_normal((b, c, m, ns)).astype(np.float32)
+    r1 = oracle.gather_points_grad(go, idx, n)
+    r2 = oracle.group_points_grad(ggo, gidx, n)
+    assert np.abs(pointops.gather_points_grad(_dev(go), _dev(idx), n).cpu().numpy() - r1).max() < 1e-5
+    assert np.abs(pointops.group_points_grad(_dev(ggo), _dev(gidx), n).cpu().numpy() - r2).max() < 1e-4
