@@ -258,3 +258,64 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     GF_CHECK_LAUNCH("gf_conv_fwd");
     return GF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// weight gradient: dW[k] = sum_o in[nbr[k][o],:]^T dOut[o,:]
+// One wave per (offset k, 16-channel input block, 16-channel output block, slice of rows).
+// MFMA orientation: M = input channel, N = output channel, K = rows (4 per instruction), so
+// both operands are 64-byte row segments; partial tiles are combined with fp32 atomics
+// (K*Cin*Cout words only -- far below the atomic-rate ceiling).
+// ------------------------------------------------------------------------------------
+#define WG_ROWS 2048
+__global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ in, const float* __restrict__ dout,
+                                                    const int32_t* __restrict__ nbr, int K, int M_out, int ld,
+                                                    int Cin, int Cout, int NCI, int NCO, int nslices,
+                                                    float* __restrict__ dW) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    long long item = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nitems = (long long)K * NCI * NCO * nslices;
+    if (item >= nitems) return;
+    const int sl = (int)(item % nslices);
+    item /= nslices;
+    const int cob = (int)(item % NCO);
+    item /= NCO;
+    const int cib = (int)(item % NCI);
+    const int k = (int)(item / NCI);
+    const int ci = cib * 16 + r, co = cob * 16 + r;
+    const int row0 = sl * WG_ROWS, row1 = min(M_out, row0 + WG_ROWS);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int base = row0; base < row1; base += 4) {
+        const int row = base + q;
+        float a = 0.f, b = 0.f;
+        if (row < row1) {
+            const int idx = nbr ? nbr[(size_t)k * ld + row] : row;
+            if (idx >= 0) {
+                if (ci < Cin) a = in[(size_t)idx * Cin + ci];
+                if (co < Cout) b = dout[(size_t)row * Cout + co];
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    // D layout: col (output channel) = lane&15, row (input channel) = 4*(lane>>4) + j
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int cii = cib * 16 + q * 4 + j;
+        if (cii < Cin && co < Cout && acc[j] != 0.f) atomicAdd(&dW[((size_t)k * Cin + cii) * Cout + co], acc[j]);
+    }
+}
+
+extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K, int M_out, int ld, int Cin,
+                             int Cout, float* dW, void* stream) {
+    GF_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1, "gf_conv_wgrad: bad sizes");
+    GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_wgrad: nbr==NULL requires K==1");
+    hipStream_t st = (hipStream_t)stream;
+    hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st);
+    if (M_out <= 0) return GF_OK;
+    const int nci = (Cin + 15) / 16, nco = (Cout + 15) / 16;
+    const int nslices = (M_out + WG_ROWS - 1) / WG_ROWS;
+    const long long nitems = (long long)K * nci * nco * nslices;
+    hipLaunchKernelGGL(k_conv_wgrad, dim3(gf_div_up(nitems, 4)), dim3(256), 0, st, in, dout, nbr, K, M_out, ld, Cin,
+                       Cout, nci, nco, nslices, dW);
+    GF_CHECK_LAUNCH("gf_conv_wgrad");
+    return GF_OK;
+}

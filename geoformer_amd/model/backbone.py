@@ -1,0 +1,107 @@
+"""Sparse-voxel U-Net blocks (geoformer_modules.py:10-35, 52-129) over the drop-in ``spconv``."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import spconv
+from ..spconv.modules import SparseModule
+from .layers import BackboneTransformer
+
+
+class ResidualBlock(SparseModule):
+    """out = conv_branch(x) + i_branch(x); i_branch is Identity or a 1x1x1 conv when the widths differ.
+    conv_branch = [BN, ReLU, SubM3, BN, ReLU, SubM3] (pre-activation)."""
+
+    def __init__(self, in_channels, out_channels, norm_fn, indice_key=None):
+        super().__init__()
+        if in_channels == out_channels:
+            self.i_branch = spconv.SparseSequential(nn.Identity())
+        else:
+            self.i_branch = spconv.SparseSequential(
+                spconv.SubMConv3d(in_channels, out_channels, kernel_size=1, bias=False))
+        self.conv_branch = spconv.SparseSequential(
+            norm_fn(in_channels), nn.ReLU(),
+            spconv.SubMConv3d(in_channels, out_channels, kernel_size=3, padding=1, bias=False, indice_key=indice_key),
+            norm_fn(out_channels), nn.ReLU(),
+            spconv.SubMConv3d(out_channels, out_channels, kernel_size=3, padding=1, bias=False, indice_key=indice_key),
+        )
+
+    def forward(self, input):
+        # snapshot BEFORE conv_branch: SparseSequential replaces input.features in place
+        identity = spconv.SparseConvTensor(input.features, input.indices, input.spatial_shape, input.batch_size)
+        output = self.conv_branch(input)
+        output.features = output.features + self.i_branch(identity).features
+        return output
+
+
+class UBlock(nn.Module):
+    """Recursive U-Net level: blocks -> [down conv -> UBlock -> inverse conv -> concat -> blocks_tail];
+    the two deepest levels add a dense per-scene transformer (geoformer_modules.py:64-68,120-127)."""
+
+    def __init__(self, nPlanes, norm_fn, block_reps, block, use_backbone_transformer=False, indice_key_id=1):
+        super().__init__()
+        self.nPlanes = nPlanes
+        c = nPlanes[0]
+        self.blocks = spconv.SparseSequential(OrderedDict(
+            (f"block{i}", block(c, c, norm_fn, indice_key=f"subm{indice_key_id}")) for i in range(block_reps)))
+        if len(nPlanes) <= 2 and use_backbone_transformer:
+            self.before_transformer_linear = nn.Linear(c, 128)
+            self.transformer = BackboneTransformer(d_model=128, N=2, heads=4, d_ff=64)
+            self.after_transformer_linear = nn.Linear(128, c)
+        else:
+            self.before_transformer_linear = self.transformer = self.after_transformer_linear = None
+        if len(nPlanes) > 1:
+            key = f"spconv{indice_key_id}"
+            self.conv = spconv.SparseSequential(
+                norm_fn(c), nn.ReLU(),
+                spconv.SparseConv3d(c, nPlanes[1], kernel_size=2, stride=2, bias=False, indice_key=key))
+            self.u = UBlock(nPlanes[1:], norm_fn, block_reps, block, use_backbone_transformer,
+                            indice_key_id=indice_key_id + 1)
+            self.deconv = spconv.SparseSequential(
+                norm_fn(nPlanes[1]), nn.ReLU(),
+                spconv.SparseInverseConv3d(nPlanes[1], c, kernel_size=2, bias=False, indice_key=key))
+            self.blocks_tail = spconv.SparseSequential(OrderedDict(
+                (f"block{i}", block(c * (2 - i), c, norm_fn, indice_key=f"subm{indice_key_id}"))
+                for i in range(block_reps)))
+
+    def forward(self, input):
+        output = self.blocks(input)
+        identity = spconv.SparseConvTensor(output.features, output.indices, output.spatial_shape, output.batch_size)
+        if len(self.nPlanes) > 1:
+            dec = self.deconv(self.u(self.conv(output)))
+            output.features = torch.cat((identity.features, dec.features), dim=1)
+            output = self.blocks_tail(output)
+        if self.before_transformer_linear is not None:
+            feats = self.before_transformer_linear(output.features)
+            feats = self.transformer(xyz=output.indices[:, 1:].float(), features=feats, batch_ids=output.indices[:, 0])
+            output.features = self.after_transformer_linear(feats)
+        return output
+
+
+def conv1d_bn_relu(in_channels, out_channels):
+    """conv_with_kaiming_uniform("BN", activation=True) (geoformer_modules.py:132-161):
+    Conv1d(k=1, no bias, kaiming_uniform a=1) + BatchNorm1d + ReLU."""
+    conv = nn.Conv1d(in_channels, out_channels, kernel_size=1, bias=False)
+    nn.init.kaiming_uniform_(conv.weight, a=1)
+    return nn.Sequential(conv, nn.BatchNorm1d(out_channels), nn.ReLU(inplace=True))
+
+
+def random_downsample(batch_offsets, batch_size, n_subsample=30000):
+    """Host-RNG subsampling of the mask-head points (geoformer_modules.py:165-186); consumes
+    np.random exactly like the reference (one np.random.choice per over-full scene)."""
+    idxs, raw = [], []
+    for b in range(batch_size):
+        start, end = batch_offsets[b], batch_offsets[b + 1]
+        n_b = int(end - start)
+        if n_subsample == -1 or n_subsample >= n_b:
+            new = torch.arange(n_b, dtype=torch.long, device=batch_offsets.device)
+        else:
+            new = torch.tensor(np.random.choice(n_b, n_subsample, replace=False), dtype=torch.long,
+                               device=batch_offsets.device)
+        raw.append(new)
+        idxs.append(new + start)
+    return torch.cat(idxs), raw

@@ -1,0 +1,352 @@
+"""GeoFormer on MI355X: the build's counterpart of ``model/geoformer/geoformer.py``.
+
+Same class name, ``forward(batch_input, epoch, training=True)`` signature, output-dict keys,
+``state_dict`` names/shapes and yaml keys as the reference (geoformer.py:23-662), so its drivers
+(train.py:63, test.py:56) and checkpoints can be pointed at this class unchanged.  The native
+work runs in libgeoformer_hip.so: voxel mean, rulebooks + gather-MFMA sparse convolutions, FPS,
+ball query, grouping, the kNN graph and the frontier BFS.  The reference's index-space quirk
+(FPS indices taken on the permuted points but applied to the un-permuted ones)
+and its host-RNG draws are reproduced deliberately.
+"""
+from __future__ import annotations
+
+import functools
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from .. import pointops, spconv
+from . import config as _config
+from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
+from .layers import GenericMLP, PositionEmbeddingCoordsSine, TransformerDecoder, TransformerDecoderLayer
+from .set_abstraction import PointnetSAModuleVotesSeparate
+
+
+class _Voxelization(torch.autograd.Function):
+    """pointgroup_ops.voxelization (lib/pointgroup_ops/functions/pointgroup_ops.py:42-72)."""
+
+    @staticmethod
+    def forward(ctx, feats, map_rule, mode=4):
+        ctx.rule, ctx.mode, ctx.N = map_rule, mode, feats.shape[0]
+        return pointops.voxelize_fp(feats.contiguous(), map_rule, mode)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d_feats = torch.zeros((ctx.N, d_out.shape[1]), dtype=torch.float32, device=d_out.device)
+        pointops.voxelize_bp(d_out.contiguous(), ctx.rule, ctx.mode, d_feats)
+        return d_feats, None, None
+
+
+voxelization = _Voxelization.apply
+
+
+def get_batch_offsets(batch_idxs, bs):
+    """offsets[i+1] = offsets[i] + count(batch_idxs == i)  (util/utils.py:132-142), one device op."""
+    counts = torch.bincount(batch_idxs.long(), minlength=bs)[:bs]
+    return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
+
+
+@torch.no_grad()
+def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighbor=64, radius=0.05, n_queries=128):
+    """cal_geodesic_vectorize (geodesic_utils.py:91-164): per scene a kNN graph (k=neighbor, edges
+    within `radius`) and a hop-synchronous BFS from the first n_queries FPS indices -- interpreted,
+    like the reference does, as indices into the scene's un-permuted foreground points."""
+    offs = batch_offsets_.tolist()
+    out = []
+    for b in range(pre_enc_inds.shape[0]):
+        pts = locs_float_[offs[b]:offs[b + 1]].contiguous()
+        D, I, deg = pointops.knn_radius(pts, neighbor, radius, sqrt_out=True)
+        src = pre_enc_inds[b][:n_queries].int().contiguous()
+        out.append(pointops.geodesic_bfs(D, I, deg, src, radius, max_step))
+    return out
+
+
+class GeoFormer(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg if cfg is not None else _config.cfg
+        self.cfg = cfg
+        input_c = cfg.input_channel + (3 if cfg.use_coords else 0)
+        m, classes = cfg.m, cfg.classes
+        self.prepare_epochs = cfg.prepare_epochs
+        self.fix_module = list(cfg.fix_module)
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+
+        # sparse-voxel U-Net
+        self.input_conv = spconv.SparseSequential(
+            spconv.SubMConv3d(input_c, m, kernel_size=3, padding=1, bias=False, indice_key="subm1"))
+        self.unet = UBlock([m * (i + 1) for i in range(7)], norm_fn, 2, ResidualBlock,
+                           use_backbone_transformer=True, indice_key_id=1)
+        self.output_layer = spconv.SparseSequential(norm_fn(m), nn.ReLU())
+
+        # semantic head
+        self.semantic = nn.Sequential(nn.Linear(m, m, bias=True), norm_fn(m), nn.ReLU(),
+                                      nn.Linear(m, m, bias=True), norm_fn(m), nn.ReLU())
+        self.semantic_linear = nn.Linear(m, classes, bias=True)
+
+        # mask features, controller of the dynamic convolution
+        self.output_dim = m
+        self.mask_conv_num = 3
+        tower = [conv1d_bn_relu(m, m) for _ in range(self.mask_conv_num)]
+        tower.append(nn.Conv1d(m, self.output_dim, 1))
+        self.add_module("mask_tower", nn.Sequential(*tower))
+        self.add_module("before_embedding_tower", nn.Sequential(conv1d_bn_relu(cfg.dec_dim, self.output_dim)))
+        self.use_coords = True
+        self.embedding_conv_num = 2
+        od = self.output_dim
+        self.weight_nums = [(od + 3) * od, od]
+        self.bias_nums = [od, 1]
+        self.num_gen_params = sum(self.weight_nums) + sum(self.bias_nums)
+        self.controller = nn.Conv1d(od, self.num_gen_params, kernel_size=1)
+        nn.init.normal_(self.controller.weight, std=0.01)
+        nn.init.constant_(self.controller.bias, 0)
+
+        # set aggregation, positional embedding, decoder
+        self.set_aggregator = PointnetSAModuleVotesSeparate(radius=0.2, nsample=64, npoint=cfg.n_decode_point,
+                                                            mlp=[m, 2 * m, 2 * m, 2 * m], normalize_xyz=True)
+        self.pos_embedding = PositionEmbeddingCoordsSine(d_pos=cfg.dec_dim, pos_type="fourier", normalize=True)
+        layer = TransformerDecoderLayer(d_model=cfg.dec_dim, nhead=cfg.dec_nhead, dim_feedforward=cfg.dec_ffn_dim,
+                                        dropout=cfg.dec_dropout, normalize_before=True, use_rel=True)
+        self.decoder = TransformerDecoder(layer, num_layers=cfg.dec_nlayers, return_intermediate=True)
+        self.query_projection = GenericMLP(input_dim=cfg.dec_dim, hidden_dims=[cfg.dec_dim], output_dim=cfg.dec_dim,
+                                           use_conv=True, output_use_activation=True, hidden_use_bias=True)
+        self.encoder_to_decoder_projection = GenericMLP(
+            input_dim=2 * m, hidden_dims=[2 * m], output_dim=cfg.dec_dim, norm_fn_name="bn1d", activation="relu",
+            use_conv=True, output_use_activation=True, output_use_norm=True, output_use_bias=False)
+        self.detr_sem_head = GenericMLP(input_dim=cfg.dec_dim, hidden_dims=[cfg.dec_dim, cfg.dec_dim],
+                                        norm_fn_name="bn1d", activation="relu", use_conv=True, output_dim=classes)
+
+        self.apply(self.set_bn_init)
+        for name in self.fix_module:
+            for p in getattr(self, name).parameters():
+                p.requires_grad = False
+
+    # -- reference quirks kept on purpose -----------------------------------------------------
+    def train(self, mode=True):
+        """Frozen sub-modules stay in eval mode; returns None like the reference (geoformer.py:179-184)."""
+        super().train(mode)
+        for name in self.fix_module:
+            for mod in getattr(self, name).modules():
+                mod.eval()
+
+    @staticmethod
+    def set_bn_init(mod):
+        if mod.__class__.__name__.find("BatchNorm1d") != -1:
+            mod.weight.data.fill_(1.0)
+            mod.bias.data.fill_(0.0)
+
+    # -- backbone ---------------------------------------------------------------------------
+    def preprocess_input(self, batch_input, batch_size):
+        feats = batch_input["feats"]
+        if self.cfg.use_coords:
+            feats = torch.cat((feats, batch_input["locs_float"]), 1).float()
+        voxel_feats = voxelization(feats, batch_input["v2p_map"], self.cfg.mode)
+        return spconv.SparseConvTensor(voxel_feats, batch_input["voxel_locs"].int(), batch_input["spatial_shape"],
+                                       batch_size)
+
+    def forward_backbone(self, batch_input, batch_size):
+        ctx = torch.no_grad if "unet" in self.fix_module else torch.enable_grad
+        with ctx():
+            x = self.preprocess_input(batch_input, batch_size)
+            x = self.output_layer(self.unet(self.input_conv(x)))
+            output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
+            semantic_scores = self.semantic_linear(self.semantic(output_feats))
+            semantic_preds = semantic_scores.max(1)[1]
+            return output_feats, semantic_scores, semantic_preds
+
+    # -- set aggregation ------------------------------------------------------------------------
+    def forward_aggregator(self, locs_float_, output_feats_, batch_offsets_, batch_size):
+        ctx = torch.no_grad if "set_aggregator" in self.fix_module else torch.enable_grad
+        offs = batch_offsets_.tolist()
+        with ctx():
+            locs, gfeat, gxyz, inds = [], [], [], []
+            for b in range(batch_size):
+                n_b = offs[b + 1] - offs[b]
+                if n_b == 0:
+                    return None
+                npoint = min(n_b, self.cfg.n_downsampling)
+                # host RNG, consumed exactly like the reference (geoformer.py:575-577): a random
+                # permutation (and truncation) of the scene's foreground points
+                sampling_indices = torch.tensor(np.random.choice(n_b, npoint, replace=False), dtype=torch.long,
+                                                device=locs_float_.device)
+                self.last_sampling_indices = sampling_indices
+                xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0)
+                feat_b = output_feats_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0)
+                l, gf, gx, idx = self.set_aggregator.group_points(xyz_b.contiguous(),
+                                                                  feat_b.transpose(1, 2).contiguous())
+                locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
+            context_locs, pre_enc_inds = torch.cat(locs), torch.cat(inds)
+            context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
+            return context_locs, context_feats, pre_enc_inds
+
+    # -- decoder ------------------------------------------------------------------------------
+    def relative_position_embedding(self, context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds):
+        """[nq, nc, B, d] Fourier embedding of the query->context geodesic distances; unreachable
+        pairs get max_geo(query) + |dxyz| per axis (geoformer.py:619-651)."""
+        B = context_locs.shape[0]
+        rel = torch.abs(query_locs[:, :, None, :] - context_locs[:, None, :, :])
+        nq, nc = rel.shape[1], rel.shape[2]
+        geo = torch.stack([geo_dists[b][:, pre_enc_inds[b].long()] for b in range(B)], dim=0)  # B x nq x nc
+        max_geo = torch.max(geo, dim=2)[0]
+        max_all = torch.max(max_geo)
+        max_geo = torch.where(max_geo < 0, max_all, max_geo)
+        geo3 = geo[:, :, :, None].repeat(1, 1, 1, 3)
+        geo3 = torch.where(geo3 < 0, max_geo[:, :, None, None] + rel, geo3)
+        emb = self.pos_embedding(geo3.reshape(B, nq * nc, -1), input_range=pc_dims).reshape(B, -1, nq, nc)
+        return emb.permute(2, 3, 0, 1)
+
+    def forward_decoder(self, context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds):
+        nq = self.cfg.n_query_points
+        context_embedding_pos = self.pos_embedding(context_locs, input_range=pc_dims)
+        context_feats = self.encoder_to_decoder_projection(context_feats.permute(0, 2, 1))  # B x C x nc
+        query_embedding_pos = self.query_projection(self.pos_embedding(query_locs, input_range=pc_dims).float())
+        dec_inputs = context_feats[:, :, :nq].permute(2, 0, 1)
+        relative_embedding_pos = self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists,
+                                                                  pre_enc_inds)
+        return self.decoder(tgt=dec_inputs, memory=context_feats.permute(2, 0, 1),
+                            pos=context_embedding_pos.permute(2, 0, 1), query_pos=query_embedding_pos.permute(2, 0, 1),
+                            relative_pos=relative_embedding_pos)
+
+    # -- dynamic-convolution mask head ------------------------------------------------------------
+    def parse_dynamic_params(self, params, out_channels):
+        n = params.size(0)
+        w1, w2, b1, b2 = torch.split_with_sizes(params, self.weight_nums + self.bias_nums, dim=1)
+        return ([w1.reshape(n * out_channels, -1, 1), w2.reshape(n, -1, 1)],
+                [b1.reshape(n * out_channels), b2.reshape(n)])
+
+    def mask_heads_forward(self, geo_dist, mask_features, weights, biases, num_insts, coords_, fps_sampling_coords,
+                           use_geo=True):
+        """logits[q, p] = W2_q relu(W1_q [rel_xyz(q,p); f_p] + b1_q) + b2_q with rel = q_xyz - p_xyz and,
+        where p is geodesically unreachable from q, rel += sqrt(max_geo_q) * sign(rel) (geoformer.py:286-324)."""
+        n_mask = mask_features.size(0)
+        rel = fps_sampling_coords.reshape(-1, 1, 3) - coords_.reshape(1, -1, 3)  # nq x N x 3
+        if use_geo:
+            mx = torch.max(geo_dist, dim=1)[0]
+            mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx))
+            rel = torch.where((geo_dist < 0).unsqueeze(-1), rel + mx[:, None, None] * torch.sign(rel), rel)
+        w1, w2 = weights[0].reshape(num_insts, self.output_dim, -1), weights[1].reshape(num_insts, 1, -1)
+        b1, b2 = biases[0].reshape(num_insts, self.output_dim, 1), biases[1].reshape(num_insts, 1, 1)
+        feat = mask_features.reshape(n_mask, -1)  # N x C
+        # first layer split into its coordinate part (per query) and its feature part (shared input)
+        h = torch.matmul(w1[:, :, :3], rel.permute(0, 2, 1)) + torch.matmul(w1[:, :, 3:], feat.t().unsqueeze(0)) + b1
+        x = torch.matmul(w2, F.relu(h)) + b2  # nq x 1 x N
+        return x.reshape(1, num_insts, n_mask)
+
+    def get_mask_prediction(self, geo_dists, param_kernels, mask_features, locs_float_, fps_sampling_locs,
+                            batch_offsets_):
+        num_layers, n_queries, batch = param_kernels.shape[:3]
+        offs = batch_offsets_.tolist()
+        outputs = []
+        for l in range(num_layers):
+            pk = param_kernels[l]  # nq x B x C
+            cls_logits = self.detr_sem_head(pk.permute(1, 2, 0)).transpose(1, 2)  # B x nq x classes
+            pk2 = pk.transpose(0, 1).flatten(0, 1)
+            controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
+            controllers = controllers.reshape(batch, n_queries, -1)
+            mask_logits_list = []
+            for b in range(batch):
+                s, e = offs[b], offs[b + 1]
+                if e - s == 0:
+                    mask_logits_list.append(None)
+                    continue
+                weights, biases = self.parse_dynamic_params(controllers[b], self.output_dim)
+                ml = self.mask_heads_forward(geo_dists[b], mask_features[s:e], weights, biases, n_queries,
+                                             locs_float_[s:e], fps_sampling_locs[b], use_geo=self.use_coords)
+                mask_logits_list.append(ml.squeeze(0))
+            outputs.append({"cls_logits": cls_logits, "mask_logits": mask_logits_list})
+        return outputs
+
+    def generate_proposal(self, mask_logits, cls_logits, fg_idxs, batch_offsets, batch_offsets_,
+                          semantic_scores_=None, logit_thresh=0.5, score_thresh=0.5, npoint_thresh=100):
+        """Batch-1 proposal extraction (geoformer.py:193-262): score = mean mask prob * sqrt(cls prob) *
+        mean semantic prob of the predicted class over the mask."""
+        sem = F.softmax(semantic_scores_, dim=1)
+        b = 0
+        num_points = int(batch_offsets[b + 1] - batch_offsets[b])
+        mask_prob = mask_logits[b].sigmoid()
+        cls_prob = F.softmax(cls_logits[b], dim=-1)
+        cls_pred = torch.argmax(cls_logits[b], dim=-1)
+        sem_b = sem[int(batch_offsets_[b]):int(batch_offsets_[b + 1])]
+        mask_bool = mask_prob >= logit_thresh
+        npts = torch.sum(mask_bool, dim=1)
+        mask_scores = torch.sum(mask_prob * mask_bool.int(), dim=1) / (npts + 1e-6)
+        cls_scores = torch.gather(cls_prob, 1, cls_pred.unsqueeze(-1)).squeeze(-1)
+        sem_scores = torch.matmul(mask_bool.float(), sem_b) / (npts[:, None] + 1e-6)  # nq x classes
+        sem_scores = torch.gather(sem_scores, 1, cls_pred.unsqueeze(-1)).squeeze(-1)
+        scores = mask_scores * torch.pow(cls_scores, 0.5) * sem_scores
+        final = (cls_pred >= 4) & (npts >= npoint_thresh) & (mask_scores >= score_thresh)
+        if torch.count_nonzero(final) == 0:
+            return [], [], []
+        masks_final = mask_bool[final]
+        proposals = torch.zeros((masks_final.shape[0], num_points), dtype=torch.int, device=mask_prob.device)
+        inst, pts = torch.nonzero(masks_final, as_tuple=True)
+        proposals[inst, fg_idxs[pts]] = 1
+        return cls_pred[final], scores[final], proposals
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, batch_input, epoch, training=True):
+        cfg = self.cfg
+        outputs = {}
+        batch_idxs = batch_input["locs"][:, 0].int()
+        locs_float = batch_input["locs_float"]
+        batch_offsets = batch_input["offsets"]
+        batch_size = len(batch_offsets) - 1
+        assert batch_size > 0
+        pc_dims = [batch_input["pc_maxs"], batch_input["pc_mins"]]  # swapped on purpose (geoformer.py:412-415)
+
+        output_feats, semantic_scores, semantic_preds = self.forward_backbone(batch_input, batch_size)
+        outputs["semantic_scores"] = semantic_scores
+        if epoch <= self.prepare_epochs:
+            return outputs
+
+        fg = semantic_preds >= 4 if cfg.train_fold == cfg.cvfold else semantic_preds == 3
+        fg_idxs = torch.nonzero(fg).view(-1)
+        if len(fg_idxs) == 0:
+            outputs["mask_predictions"] = None
+            return outputs
+        batch_idxs_ = batch_idxs[fg_idxs]
+        batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size)
+        locs_float_ = locs_float[fg_idxs]
+        output_feats_ = output_feats[fg_idxs]
+        semantic_scores_ = semantic_scores[fg_idxs]
+        mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
+
+        contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
+        if contexts is None:
+            outputs["mask_predictions"] = None
+            return outputs
+        context_locs, context_feats, pre_enc_inds = contexts
+        query_locs = context_locs[:, :cfg.n_query_points, :]
+
+        geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128 if self.training else 256,
+                                 neighbor=64, radius=0.05, n_queries=cfg.n_query_points)
+        dec_outputs = self.forward_decoder(context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds)
+
+        if training:
+            idxs_sub, idxs_sub_raw = random_downsample(batch_offsets_, batch_size, n_subsample=30000)
+            geo_sub = [geo_dists[b][:, idxs_sub_raw[b]] for b in range(batch_size)]
+            del geo_dists
+            batch_idxs_sub = batch_idxs_[idxs_sub]
+            # the reference calls an undefined self.get_batch_offsets here (geoformer.py:482); intended
+            # semantics = utils.get_batch_offsets
+            offsets_sub = get_batch_offsets(batch_idxs_sub, batch_size)
+            outputs["fg_idxs"] = fg_idxs[idxs_sub]
+            outputs["num_insts"] = cfg.n_query_points * batch_size
+            outputs["batch_idxs"] = batch_idxs_sub
+            outputs["mask_predictions"] = self.get_mask_prediction(geo_sub, dec_outputs, mask_features_[idxs_sub],
+                                                                   locs_float_[idxs_sub], query_locs, offsets_sub)
+        else:
+            dec_outputs = dec_outputs[-1:, ...]
+            outputs["fg_idxs"] = fg_idxs
+            outputs["num_insts"] = cfg.n_query_points * batch_size
+            outputs["batch_idxs"] = batch_idxs_
+            preds = self.get_mask_prediction(geo_dists, dec_outputs, mask_features_, locs_float_, query_locs,
+                                             batch_offsets_)
+            outputs["mask_predictions"] = preds
+            outputs["proposal_scores"] = self.generate_proposal(
+                preds[-1]["mask_logits"], preds[-1]["cls_logits"], fg_idxs, batch_offsets, batch_offsets_,
+                semantic_scores_=semantic_scores_, logit_thresh=0.5, score_thresh=cfg.TEST_SCORE_THRESH,
+                npoint_thresh=cfg.TEST_NPOINT_THRESH)
+        return outputs

@@ -1,0 +1,268 @@
+"""Pure-PyTorch building blocks of GeoFormer with the reference's parameter names.
+
+Written from the reference's behaviour (cited per class) so that its checkpoints load by
+name; everything here is stock PyTorch-ROCm plumbing around the HIP operators.
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------
+# model/helper.py:43-112  GenericMLP  (children live in ``self.layers``)
+# ------------------------------------------------------------------------------------------
+class GenericMLP(nn.Module):
+    def __init__(self, input_dim, hidden_dims, output_dim, norm_fn_name=None, activation="relu", use_conv=False,
+                 dropout=None, hidden_use_bias=False, output_use_bias=True, output_use_activation=False,
+                 output_use_norm=False, weight_init_name=None):
+        super().__init__()
+        act = {"relu": nn.ReLU, "gelu": nn.GELU}[activation]
+        norm = None
+        if norm_fn_name == "bn1d":
+            norm = nn.BatchNorm1d
+        elif norm_fn_name == "ln":
+            norm = (lambda c: nn.GroupNorm(1, c)) if use_conv else nn.LayerNorm
+        elif norm_fn_name == "id":
+            norm = lambda c: nn.Identity()  # noqa: E731
+        elif norm_fn_name is not None:
+            raise ValueError(norm_fn_name)
+        if dropout is not None and not isinstance(dropout, list):
+            dropout = [dropout] * len(hidden_dims)
+
+        def lin(i, o, bias):
+            return nn.Conv1d(i, o, 1, bias=bias) if use_conv else nn.Linear(i, o, bias=bias)
+
+        mods, prev = [], input_dim
+        for i, h in enumerate(hidden_dims):
+            mods.append(lin(prev, h, hidden_use_bias))
+            if norm:
+                mods.append(norm(h))
+            mods.append(act())
+            if dropout is not None:
+                mods.append(nn.Dropout(p=dropout[i]))
+            prev = h
+        mods.append(lin(prev, output_dim, output_use_bias))
+        if output_use_norm:
+            mods.append(norm(output_dim))
+        if output_use_activation:
+            mods.append(act())
+        self.layers = nn.Sequential(*mods)
+        if weight_init_name == "xavier_uniform":
+            for p in self.parameters():
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p)
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+# ------------------------------------------------------------------------------------------
+# model/pos_embedding.py:88-115 (fourier branch) + util/utils_pc.py:35-61 (shift_scale_points)
+# ------------------------------------------------------------------------------------------
+def shift_scale_points(xyz, src_range):
+    """Map src_range=[lo,hi] to the unit cube: ((x - lo) * 1) / (hi - lo) + 0 in the reference; the
+    multiplication by one and the addition of zero are exact, so this is bit-identical."""
+    lo, hi = src_range[0][:, None, :], src_range[1][:, None, :]
+    return (xyz - lo) / (hi - lo)
+
+
+class PositionEmbeddingCoordsSine(nn.Module):
+    """Fourier features with a frozen Gaussian projection ``gauss_B`` [3, d_pos/2]."""
+
+    def __init__(self, temperature=10000, normalize=False, scale=None, pos_type="fourier", d_pos=None, d_in=3,
+                 gauss_scale=1.0):
+        super().__init__()
+        if pos_type != "fourier":
+            raise NotImplementedError("only the fourier embedding is used by GeoFormer (geoformer.py:119)")
+        assert d_pos is not None and d_pos % 2 == 0
+        self.normalize, self.pos_type, self.d_pos = normalize, pos_type, d_pos
+        self.register_buffer("gauss_B", torch.empty((d_in, d_pos // 2)).normal_() * gauss_scale)
+
+    @torch.no_grad()
+    def forward(self, xyz, num_channels=None, input_range=None):
+        assert xyz.ndim == 3
+        d_out = (num_channels or self.d_pos) // 2
+        b, n = xyz.shape[0], xyz.shape[1]
+        x = xyz.clone()
+        if self.normalize:
+            x = shift_scale_points(x, input_range)
+        x = (x * (2 * np.pi)).float()
+        proj = torch.mm(x.view(-1, x.shape[-1]), self.gauss_B[:, :d_out]).view(b, n, d_out)
+        return torch.cat([proj.sin(), proj.cos()], dim=2).permute(0, 2, 1)  # batch x d_pos x n
+
+
+# ------------------------------------------------------------------------------------------
+# model/transformer.py:153-188  backbone TransformerEncoder (levels 6 and 7 of the U-Net)
+# ------------------------------------------------------------------------------------------
+class Norm(nn.Module):
+    """alpha * (x - mean) / (std_unbiased + eps) + bias   (transformer.py:62-76)"""
+
+    def __init__(self, d_model, eps=1e-6):
+        super().__init__()
+        self.alpha = nn.Parameter(torch.ones(d_model))
+        self.bias = nn.Parameter(torch.zeros(d_model))
+        self.eps = eps
+
+    def forward(self, x):
+        mu = x.mean(dim=-1, keepdim=True)
+        return self.alpha * (x - mu) / (x.std(dim=-1, keepdim=True) + self.eps) + self.bias
+
+
+class _MHA(nn.Module):
+    def __init__(self, heads, d_model, dropout=0.1):
+        super().__init__()
+        self.h, self.d_k, self.d_model = heads, d_model // heads, d_model
+        self.q_linear = nn.Linear(d_model, d_model)
+        self.v_linear = nn.Linear(d_model, d_model)
+        self.k_linear = nn.Linear(d_model, d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.out = nn.Linear(d_model, d_model)
+
+    def forward(self, q, k, v, mask=None):
+        bs = q.size(0)
+        k = self.k_linear(k).view(bs, -1, self.h, self.d_k).transpose(1, 2)
+        q = self.q_linear(q).view(bs, -1, self.h, self.d_k).transpose(1, 2)
+        v = self.v_linear(v).view(bs, -1, self.h, self.d_k).transpose(1, 2)
+        s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(self.d_k)
+        if mask is not None:
+            s = s.masked_fill(mask.unsqueeze(1) == 0, -1e9)
+        s = self.dropout(F.softmax(s, dim=-1))
+        o = torch.matmul(s, v).transpose(1, 2).contiguous().view(bs, -1, self.d_model)
+        return self.out(o)
+
+
+class _FF(nn.Module):
+    def __init__(self, d_model, d_ff=64, dropout=0.1):
+        super().__init__()
+        self.linear_1 = nn.Linear(d_model, d_ff)
+        self.dropout = nn.Dropout(dropout)
+        self.linear_2 = nn.Linear(d_ff, d_model)
+
+    def forward(self, x):
+        return self.linear_2(self.dropout(F.relu(self.linear_1(x))))
+
+
+class _EncLayer(nn.Module):
+    def __init__(self, d_model, heads, d_ff, dropout=0.1):
+        super().__init__()
+        self.norm_1, self.norm_2 = Norm(d_model), Norm(d_model)
+        self.attn_1 = _MHA(heads, d_model)
+        self.ff = _FF(d_model, d_ff=d_ff)
+        self.dropout_1, self.dropout_2 = nn.Dropout(dropout), nn.Dropout(dropout)
+
+    def forward(self, x, mask=None):
+        x2 = self.norm_1(x)
+        x = x + self.dropout_1(self.attn_1(x2, x2, x2, mask))
+        x2 = self.norm_2(x)
+        return x + self.dropout_2(self.ff(x2))
+
+
+class BackboneTransformer(nn.Module):
+    """Per scene: x = features + Linear3->d(mean_j(xyz_i - xyz_j)); N pre-norm layers; Norm."""
+
+    def __init__(self, d_model, N, heads, d_ff):
+        super().__init__()
+        self.d_model, self.N = d_model, N
+        self.layers = nn.ModuleList([copy.deepcopy(_EncLayer(d_model, heads, d_ff)) for _ in range(N)])
+        self.norm = Norm(d_model)
+        self.position_linear = nn.Linear(3, d_model)
+
+    def forward(self, xyz, features, batch_ids):
+        out = torch.zeros_like(features)
+        nb = int(batch_ids.max().item()) + 1
+        for b in range(nb):
+            rows = torch.nonzero(batch_ids == b).squeeze(1)
+            if rows.numel() == 0:
+                continue
+            s, e = int(rows.min().item()), int(rows.max().item()) + 1  # rows of a scene are contiguous
+            pts = xyz[s:e].view(-1, 3)
+            rel = (pts.unsqueeze(1) - pts.unsqueeze(0)).float().mean(dim=1)
+            x = (features[s:e].view(-1, self.d_model) + self.position_linear(rel)).unsqueeze(0)
+            for layer in self.layers:
+                x = layer(x, mask=None)
+            out[rows] = self.norm(x).squeeze(0)
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# model/transformer_detr.py:91-166, 345-463  DETR-style decoder with relative vector attention
+# ------------------------------------------------------------------------------------------
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead=4, dim_feedforward=256, dropout=0.1, dropout_attn=None, activation="relu",
+                 normalize_before=True, use_rel=False, norm_fn_name="ln"):
+        super().__init__()
+        if not use_rel or not normalize_before or norm_fn_name != "ln":
+            raise NotImplementedError("GeoFormer uses the pre-norm relative-position layer (geoformer.py:122-129)")
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d_model), nn.LayerNorm(d_model), nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout, inplace=True)
+        self.dropout2 = nn.Dropout(dropout, inplace=True)
+        self.dropout3 = nn.Dropout(dropout, inplace=True)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout, inplace=True)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.activation = {"relu": nn.ReLU, "gelu": nn.GELU}[activation]()
+        self.nhead, self.use_rel, self.normalize_before = nhead, use_rel, normalize_before
+        self.attn_mlp = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, d_model))
+        self.v_mlp = nn.Sequential(nn.Linear(d_model, d_model))
+        self.out_mlp = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU())
+
+    def cross_attention(self, tgt2, memory, relative_pos):
+        """Vector attention (transformer_detr.py:443-454): per-channel softmax over the contexts of
+        MLP(q_i - k_j + r_ij) / sqrt(d), values Linear(k_j + r_ij).  tgt2 [nq,B,d], memory [nc,B,d],
+        relative_pos [nq,nc,B,d] -> [nq,B,d]."""
+        sim = self.attn_mlp(tgt2[:, None] - memory[None] + relative_pos)
+        attn = F.softmax(sim / np.sqrt(sim.shape[-1]), dim=1)
+        v2 = self.v_mlp(memory[None] + relative_pos)
+        return (attn * v2).sum(dim=1)
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None, relative_pos=None,
+                return_attn_weights=False):
+        tgt2 = self.norm1(tgt)
+        q = k = tgt2 if query_pos is None else tgt2 + query_pos
+        tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        tgt = tgt + self.dropout1(tgt2)
+        tgt2 = self.norm2(tgt)
+        tgt = self.out_mlp(self.cross_attention(tgt2, memory, relative_pos))
+        tgt = tgt + self.dropout2(tgt2)  # the residual is the NORMED query (transformer_detr.py:457)
+        tgt2 = self.norm3(tgt)
+        tgt2 = self.linear2(self.dropout(self.activation(self.linear1(tgt2))))
+        tgt = tgt + self.dropout3(tgt2)
+        return tgt, None
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm_fn_name="ln", return_intermediate=False,
+                 weight_init_name="xavier_uniform"):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(decoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = nn.LayerNorm(self.layers[0].linear2.out_features) if norm_fn_name == "ln" else None
+        self.return_intermediate = return_intermediate
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None, relative_pos=None, transpose_swap=False,
+                return_attn_weights=False):
+        output, inter = tgt, []
+        for layer in self.layers:
+            output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                              tgt_key_padding_mask=tgt_key_padding_mask,
+                              memory_key_padding_mask=memory_key_padding_mask, pos=pos, query_pos=query_pos,
+                              relative_pos=relative_pos)
+            if self.return_intermediate:
+                inter.append(self.norm(output))
+        if self.norm is not None:
+            output = self.norm(output)
+            if self.return_intermediate:
+                inter[-1] = output
+        return torch.stack(inter) if self.return_intermediate else output

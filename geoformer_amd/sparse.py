@@ -185,3 +185,26 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
         "gf_conv_fwd",
     )
     return out
+
+
+def conv_dgrad(grad_out: torch.Tensor, weight: torch.Tensor, bwd, M_in: int) -> torch.Tensor:
+    """Input gradient = the forward kernel over the transposed relation.
+    bwd = ("subm", (nbr, gmask, 27, M, ld)): same table, weights W[26-k]^T (the submanifold
+    relation is symmetric: nbr[k][o] = i  <=>  nbr[26-k][i] = o);
+    bwd = ("table", (tbl, gmask, K, M_in, ld)): explicit transposed table, weights W[k]^T."""
+    kind, (tbl, gmask, K, M, ld) = bwd
+    Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
+    w = weight.detach().reshape(K, Cin, Cout)
+    if kind == "subm":
+        w = w.flip(0)
+    wt = w.transpose(1, 2).contiguous()
+    return conv_fwd(grad_out, wt, tbl, gmask, K, M, ld)
+
+
+def conv_wgrad(feats: torch.Tensor, grad_out: torch.Tensor, nbr, K: int, M_out: int, ld: int) -> torch.Tensor:
+    lib = _lib.load()
+    Cin, Cout = feats.shape[1], grad_out.shape[1]
+    dW = torch.empty((K, Cin, Cout), dtype=torch.float32, device=feats.device)
+    check(lib.gf_conv_wgrad(ptr(feats), ptr(grad_out), ptr(nbr), K, M_out, ld, Cin, Cout, ptr(dW), stream_ptr()),
+          "gf_conv_wgrad")
+    return dW

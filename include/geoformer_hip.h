@@ -99,6 +99,13 @@ int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint
                 int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, float* out,
                 void* stream);
 
+/* Weight gradient of the same operator: dW[k] = sum_o in[nbr[k][o],:]^T dOut[o,:]  (dW fp32
+ * [K,Cin,Cout], zeroed by the call).  The input gradient needs no entry point of its own: it is
+ * gf_conv_fwd over the transposed table with per-offset transposed weights
+ * (submanifold: same table, weights W[K-1-k]^T; strided/inverse: child <-> up tables). */
+int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K, int M_out, int ld, int Cin, int Cout,
+                  float* dW, void* stream);
+
 /* ===================================================================================
  * PG_OP (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-23)
  * =================================================================================== */

@@ -1,0 +1,150 @@
+"""Generates the golden fixtures by running the REFERENCE's own Python on CPU.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py
+The reference model code is imported, never copied; its native dependencies are replaced by the
+CPU oracle through tests/golden/ref_shims.py.  Outputs (committed, small):
+    geoformer_state_dict_keys.json   parameter/buffer names and shapes of GeoFormer
+    geoformer_s8k_eval.npz           S8k scene, test yaml (nq=256, nc=2048), eval forward: stage outputs
+    geodesic_vectorize.npz           cal_geodesic_vectorize on a 3k-point cloud (pins the BFS oracle)
+    decoder_layer.npz                one TransformerDecoderLayer + fourier embedding on random inputs
+Weights are NOT stored: both sides call tests.util.synthetic_state_dict (deterministic by name).
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+_WHICH = [a for a in sys.argv[1:] if a in ("geodesic", "decoder", "model")]
+sys.argv = ["make_golden", "--config", os.path.join(REF, "config/test_geoformer_scannet.yaml")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from tests.golden import ref_shims  # noqa: E402
+
+ref_shims.install(REF)
+os.chdir(REF)  # util/config.py and friends use relative paths
+
+from model.geoformer.geoformer import GeoFormer  # noqa: E402  (reference class)
+from model.geoformer import geodesic_utils  # noqa: E402
+from model.transformer_detr import TransformerDecoderLayer  # noqa: E402
+from model.pos_embedding import PositionEmbeddingCoordsSine  # noqa: E402
+
+from geoformer_amd import scene  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from tests.util import synthetic_state_dict  # noqa: E402
+
+
+def sub(a, rs=8, cs=4):
+    return np.ascontiguousarray(a[::rs, ::cs])
+
+
+def golden_model():
+    torch.manual_seed(0)
+    m = GeoFormer()
+    sd = m.state_dict()
+    json.dump({k: list(v.shape) for k, v in sd.items()}, open(os.path.join(HERE, "geoformer_state_dict_keys.json"), "w"),
+              indent=0)
+    m.load_state_dict(synthetic_state_dict(sd, 0))
+    m.eval()
+    sc = scene.make_small_scene(8192, 7)
+    batch = scene.make_batch([sc])
+    cap = {}
+    # capture intermediate stages by wrapping the reference's own methods
+    orig_agg, orig_dec, orig_geo = m.forward_aggregator, m.forward_decoder, geodesic_utils.cal_geodesic_vectorize
+
+    def agg(*a, **k):
+        r = orig_agg(*a, **k)
+        cap["context_locs"], cap["context_feats"], cap["pre_enc_inds"] = [t.detach().numpy().copy() for t in r]
+        return r
+
+    def dec(context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds):
+        cap["geo"] = geo_dists[0].numpy().copy()
+        r = orig_dec(context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds)
+        cap["dec_outputs"] = r.detach().numpy().copy()
+        return r
+
+    m.forward_aggregator, m.forward_decoder = agg, dec
+    np.random.seed(5)
+    rs = np.random.get_state()
+    with torch.no_grad():
+        out = m(batch, 300, training=False)
+    np.random.set_state(rs)
+    n_fg = int(out["fg_idxs"].shape[0])
+    sampling_indices = np.random.choice(n_fg, min(n_fg, 50000), replace=False)  # what forward_aggregator drew
+    mp = out["mask_predictions"][-1]
+    geo = cap["geo"]
+    ml = mp["mask_logits"][0].numpy()
+    cls_final, scores_final, masks_final = out["proposal_scores"]
+    np.savez_compressed(
+        os.path.join(HERE, "geoformer_s8k_eval.npz"),
+        scene_seed=7, scene_points=8192, numpy_seed=5, weight_seed=0,
+        semantic_scores=out["semantic_scores"].numpy(), fg_idxs=out["fg_idxs"].numpy(),
+        sampling_indices=sampling_indices, pre_enc_inds=cap["pre_enc_inds"],
+        context_locs=cap["context_locs"], context_feats=cap["context_feats"],
+        geo_sub=sub(geo), geo_rowsum=np.where(geo >= 0, geo, 0).astype(np.float64).sum(1),
+        geo_reached=(geo >= 0).sum(1), dec_outputs=cap["dec_outputs"],
+        cls_logits=mp["cls_logits"].numpy(), mask_logits_sub=sub(ml),
+        mask_logits_rowsum=ml.astype(np.float64).sum(1),
+        proposal_cls=np.asarray(cls_final), proposal_scores=np.asarray(scores_final),
+        proposal_npoints=np.asarray(masks_final).sum(1) if len(cls_final) else np.zeros(0),
+    )
+    print("model golden: N", batch["locs"].shape[0], "N_fg", n_fg, "proposals", len(cls_final))
+
+
+def golden_geodesic():
+    sc = scene.make_small_scene(3000, 21)  # ~4 cm spacing: radius 0.12 links ~25 neighbours
+    rng = np.random.default_rng(3)
+    pts = np.ascontiguousarray(sc["xyz"][rng.permutation(sc["xyz"].shape[0])[:3000]])
+    pts[40:44] = pts[5]  # exact duplicates: ties and the "self is not rank 0" case
+    nq = 16
+    n = pts.shape[0]
+    pre_enc = torch.from_numpy(np.concatenate([[5, 41], rng.permutation(n)[:62]]).astype(np.int64))[None]
+    idx = ref_shims._FaissIndex(None, 3, None)
+    geo = geodesic_utils.cal_geodesic_vectorize(idx, pre_enc, torch.from_numpy(pts), torch.tensor([0, n]),
+                                                max_step=256, neighbor=64, radius=0.12, n_queries=nq)[0].numpy()
+    geo5 = geodesic_utils.cal_geodesic_vectorize(idx, pre_enc, torch.from_numpy(pts), torch.tensor([0, n]),
+                                                 max_step=5, neighbor=64, radius=0.12, n_queries=nq)[0].numpy()
+    np.savez_compressed(os.path.join(HERE, "geodesic_vectorize.npz"), points=pts, pre_enc_inds=pre_enc.numpy(),
+                        radius=0.12, neighbor=64, n_queries=nq, geo_max256=geo, geo_max5=geo5)
+    print("geodesic golden: reached", (geo >= 0).mean(), "max", geo.max())
+
+
+def golden_decoder_layer():
+    torch.manual_seed(1)
+    d, nq, nc, B = 64, 24, 96, 2
+    layer = TransformerDecoderLayer(d_model=d, nhead=4, dim_feedforward=64, dropout=0.1, normalize_before=True,
+                                    use_rel=True)
+    sd = synthetic_state_dict(layer.state_dict(), 3)
+    layer.load_state_dict(sd)
+    layer.eval()
+    pe = PositionEmbeddingCoordsSine(d_pos=d, pos_type="fourier", normalize=True)
+    pe.load_state_dict(synthetic_state_dict(pe.state_dict(), 3))
+    rng = np.random.default_rng(4)
+    tgt = torch.from_numpy(rng.standard_normal((nq, B, d)).astype(np.float32))
+    mem = torch.from_numpy(rng.standard_normal((nc, B, d)).astype(np.float32))
+    qpos = torch.from_numpy(rng.standard_normal((nq, B, d)).astype(np.float32))
+    g = torch.from_numpy(rng.uniform(0, 6, (B, nq * nc, 3)).astype(np.float32))
+    lo = torch.from_numpy(rng.uniform(-3, -2, (B, 3)).astype(np.float32))
+    hi = torch.from_numpy(rng.uniform(2, 3, (B, 3)).astype(np.float32))
+    rel = pe(g, input_range=[hi, lo]).reshape(B, -1, nq, nc).permute(2, 3, 0, 1)
+    with torch.no_grad():
+        out, _ = layer(tgt, mem, query_pos=qpos, relative_pos=rel)
+    np.savez_compressed(os.path.join(HERE, "decoder_layer.npz"), tgt=tgt.numpy(), memory=mem.numpy(),
+                        query_pos=qpos.numpy(), geo=g.numpy(), lo=lo.numpy(), hi=hi.numpy(),
+                        relative_pos_sub=rel.numpy()[::4, ::8], out=out.numpy())
+    print("decoder golden ok", out.abs().mean().item())
+
+
+if __name__ == "__main__":
+    which = _WHICH or ["geodesic", "decoder", "model"]
+    if "geodesic" in which:
+        golden_geodesic()
+    if "decoder" in which:
+        golden_decoder_layer()
+    if "model" in which:
+        golden_model()

@@ -24,3 +24,37 @@ def random_voxels(rng, M, shape, batch=1, surface=True):
         p = p[: max(M // batch, 1)]
         rows.append(np.concatenate([np.full((p.shape[0], 1), b), p], 1))
     return np.concatenate(rows).astype(np.int32)
+
+
+def synthetic_state_dict(ref_sd, seed=0):
+    """Deterministic weights keyed by parameter NAME (not by construction order), so the reference
+    model (golden generator) and the build's model (GPU test) get identical values without a 32 MB
+    checkpoint in the repo.  BatchNorm statistics are randomised so the BN path is exercised."""
+    import zlib
+
+    import torch
+
+    out = {}
+    for name, t in ref_sd.items():
+        rng = np.random.default_rng((zlib.crc32(name.encode()) + seed * 7919) % (2**32))
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            v = np.array(100, dtype=np.int64)
+        elif name.endswith("running_mean"):
+            v = rng.normal(0, 0.1, shape)
+        elif name.endswith("running_var"):
+            v = rng.uniform(0.5, 1.5, shape)
+        elif name.endswith("gauss_B"):
+            v = rng.normal(0, 1.0, shape)
+        elif name.endswith(".alpha") or (t.dim() == 1 and name.endswith("weight")):
+            v = rng.uniform(0.5, 1.5, shape)  # norm scales
+        elif t.dim() == 1:
+            v = rng.normal(0, 0.1, shape)  # biases
+        else:
+            if t.dim() == 5:  # sparse conv [k,k,k,Cin,Cout]: every tap contributes
+                fan_in = shape[3] * max(shape[0] * shape[1] * shape[2] // 3, 1)
+            else:
+                fan_in = int(np.prod(shape[1:]))
+            v = rng.normal(0, 1.0 / np.sqrt(max(fan_in, 1)), shape)
+        out[name] = torch.from_numpy(np.asarray(v)).to(t.dtype)
+    return out
