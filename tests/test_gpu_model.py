@@ -1,0 +1,105 @@
+"""GPU: the build's GeoFormer (HIP operators) against fixtures produced by the REFERENCE's own
+forward() on the same scene, weights and numpy RNG state (tests/golden/make_golden.py).
+
+Integer outputs (foreground set, FPS indices, reach sets) are compared bit-exactly; floats to
+1e-4 abs (BASELINE.json north_star), a few accumulated quantities relative to their magnitude.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _to_dev(batch):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+@pytest.fixture(scope="module")
+def run(hip):
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    z = np.load(os.path.join(G, "geoformer_s8k_eval.npz"))
+    cfg = load_config("test_geoformer_scannet.yaml")
+    torch.manual_seed(0)
+    m = GeoFormer(cfg)
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), int(z["weight_seed"])))
+    m.cuda()
+    m.eval()
+    batch = _to_dev(scene.make_batch([scene.make_small_scene(int(z["scene_points"]), int(z["scene_seed"]))]))
+    cap = {}
+    agg, dec = m.forward_aggregator, m.forward_decoder
+
+    def agg_w(*a, **k):
+        r = agg(*a, **k)
+        cap["context_locs"], cap["context_feats"], cap["pre_enc_inds"] = [t.detach() for t in r]
+        return r
+
+    def dec_w(cl, cf, ql, pc, geo, pei):
+        cap["geo"] = geo[0]
+        r = dec(cl, cf, ql, pc, geo, pei)
+        cap["dec_outputs"] = r.detach()
+        return r
+
+    m.forward_aggregator, m.forward_decoder = agg_w, dec_w
+    np.random.seed(int(z["numpy_seed"]))
+    with torch.no_grad():
+        out = m(batch, 300, training=False)
+    torch.cuda.synchronize()
+    return z, out, cap, m
+
+
+def test_backbone_semantic_scores(run):
+    z, out, cap, m = run
+    got = out["semantic_scores"].cpu().numpy()
+    assert np.abs(got - z["semantic_scores"]).max() < 1e-4
+    assert (out["fg_idxs"].cpu().numpy() == z["fg_idxs"]).all()  # identical foreground set
+
+
+def test_aggregator_indices_and_features(run):
+    z, out, cap, m = run
+    assert (m.last_sampling_indices.cpu().numpy() == z["sampling_indices"]).all()  # same host RNG draw
+    assert (cap["pre_enc_inds"].cpu().numpy() == z["pre_enc_inds"]).all()  # FPS bit-exact
+    assert np.abs(cap["context_locs"].cpu().numpy() - z["context_locs"]).max() == 0
+    assert np.abs(cap["context_feats"].cpu().numpy() - z["context_feats"]).max() < 1e-4
+
+
+def test_geodesic_distances(run):
+    z, out, cap, m = run
+    geo = cap["geo"].cpu().numpy()
+    assert ((geo >= 0).sum(1) == z["geo_reached"]).all()  # reach sets
+    assert (geo[::8, ::4] == z["geo_sub"]).all()  # bit-exact fp32 path sums
+    assert np.abs(np.where(geo >= 0, geo, 0).astype(np.float64).sum(1) - z["geo_rowsum"]).max() < 1e-6
+
+
+def test_decoder_and_mask_head(run):
+    z, out, cap, m = run
+    assert np.abs(cap["dec_outputs"].cpu().numpy() - z["dec_outputs"]).max() < 1e-4
+    mp = out["mask_predictions"][-1]
+    assert np.abs(mp["cls_logits"].cpu().numpy() - z["cls_logits"]).max() < 1e-4
+    ml = mp["mask_logits"][0].cpu().numpy()
+    assert np.abs(ml[::8, ::4] - z["mask_logits_sub"]).max() < 1e-4
+    n = ml.shape[1]
+    assert np.abs(ml.astype(np.float64).sum(1) - z["mask_logits_rowsum"]).max() < 1e-4 * n
+
+
+def test_proposals(run):
+    z, out, cap, m = run
+    cls_final, scores_final, masks_final = out["proposal_scores"]
+    assert (cls_final.cpu().numpy() == z["proposal_cls"]).all()
+    assert np.abs(scores_final.cpu().numpy() - z["proposal_scores"]).max() < 1e-4
+    # mask sizes may differ by the few points whose logit lies within the 1e-4 tolerance of the 0.5 cut
+    d = np.abs(masks_final.sum(1).cpu().numpy() - z["proposal_npoints"])
+    assert d.max() <= 3 and (d > 0).mean() < 0.1
+
+
+def test_output_schema(run):
+    z, out, cap, m = run
+    assert set(out) == {"semantic_scores", "fg_idxs", "num_insts", "batch_idxs", "mask_predictions",
+                        "proposal_scores"}  # geoformer.py:402-528
+    assert out["num_insts"] == 256
