@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: scenes/sec of the GeoFormer eval forward on a ScanNet-like scene.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full ``GeoFormer.forward(batch, epoch, training=False)`` over one ~150k-point
+synthetic scene (BASELINE.json configs[1]; test yaml: nq=256, nc=2048, batch 1) with the batch
+dict already resident in HBM: voxel mean, 13 rulebooks, 71 sparse convs, semantic head, FPS, ball
+query, grouping, kNN graph + geodesic BFS, 4 decoder layers, dynamic-conv mask head, proposals.
+Weights are random-init of the real architecture (no checkpoints offline); the semantic head's
+bias is shifted so ~40 % of the points are foreground like a real scene.
+Scenes are independent, so N ranks run N replicas (no data-path collective; scaling "weak").
+
+The JSON line also carries
+  roofline     -- the level-1 (C=16) gather-MFMA sparse-conv launches, HBM-bound: algorithmic bytes
+                  4*(R*Cin + M*Cout + K*Cin*Cout) + 8*R per launch / mean launch time from HIP events
+                  recorded around those launches inside the timed region;
+  cpu_baseline -- the same forward through the build's model on the host cores with the oracle's
+                  scalar C operators ("port"), on the 8k-point scene (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_model(device, nfg_frac=0.4, probe_batch=None):
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    cfg = load_config("test_geoformer_scannet.yaml")
+    m = GeoFormer(cfg)
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 0))
+    m.to(device)
+    m.eval()
+    if probe_batch is not None:
+        # shift the background logits so that ~nfg_frac of the points come out as object classes
+        with torch.no_grad():
+            s = m(probe_batch, 0, training=False)["semantic_scores"]
+            margin = s[:, 4:].max(1)[0] - s[:, :4].max(1)[0]
+            m.semantic_linear.bias.data[:4] += torch.quantile(margin.float().cpu(), 1.0 - nfg_frac).to(device)
+    return m
+
+
+def to_device(batch, device):
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+class ConvProbe:
+    """HIP events around the level-1 16->16 submanifold conv launches (same stream as the kernel)."""
+
+    def __init__(self, M):
+        from geoformer_amd import sparse
+
+        self.sparse, self.orig, self.M, self.events, self.on = sparse, sparse.conv_fwd, M, [], False
+        self.R = None
+
+        def probe(feats, weight, nbr, gmask, K, M_out, ld, **kw):
+            hit = self.on and K == 27 and M_out == self.M and weight.shape[-2] == 16 and weight.shape[-1] == 16
+            if hit:
+                if self.R is None:
+                    self.tbl = nbr
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = self.orig(feats, weight, nbr, gmask, K, M_out, ld, **kw)
+                e.record()
+                self.events.append((s, e))
+                return out
+            return self.orig(feats, weight, nbr, gmask, K, M_out, ld, **kw)
+
+        sparse.conv_fwd = probe
+
+    def result(self):
+        if not self.events:
+            return None
+        R = int((self.tbl[:, : self.M] >= 0).sum().item())
+        ms = [s.elapsed_time(e) for s, e in self.events]
+        us = float(np.mean(ms)) * 1e3
+        Cin = Cout = 16
+        byt = 4 * (R * Cin + self.M * Cout + 27 * Cin * Cout) + 8 * R
+        ach = byt / (us * 1e-6) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "k_conv_os<1,true> (subm 3x3x3, 16->16, level 1)", "launches": len(ms),
+                "us_per_launch": round(us, 2), "algorithmic_bytes": byt, "rules": R, "voxels": self.M}
+
+
+def cpu_baseline():
+    """The build's model on the host through the oracle's scalar C operators, 8k-point scene."""
+    from geoformer_amd import scene
+    from oracle import cpu_backend
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    sc = scene.make_small_scene(8192, 7)
+    batch = scene.make_batch([sc])
+    with cpu_backend.installed(), torch.no_grad():
+        m = build_model("cpu", probe_batch=batch)
+        np.random.seed(0)
+        t = time.perf_counter()
+        out = m(batch, 300, training=False)
+        dt = time.perf_counter() - t
+    n = int(batch["locs"].shape[0])
+    return {"value": round(1.0 / dt, 5), "unit": "scenes/s", "cores": 1, "kind": "port",
+            "sample": f"one eval forward of an {n}-point scene at ScanNet density (N_fg={int(out['fg_idxs'].shape[0])}); "
+                      f"native operators = oracle scalar C on 1 core, torch modules on {torch.get_num_threads()} threads; "
+                      f"{dt:.1f} s; a 150k-point scene is ~18x the points",
+            "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=150_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP operators have no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from geoformer_amd import scene
+
+    # every rank gets its own scene (seed + rank): replicas of the same workload
+    sc = scene.make_scene(args.points, 1234 + rank)
+    batch = to_device(scene.make_batch([sc]), dev)
+    model = build_model(dev, probe_batch=batch)
+    M = int(batch["voxel_locs"].shape[0])
+    probe = ConvProbe(M)
+
+    def step(i):
+        np.random.seed(1000 + i)
+        with torch.no_grad():
+            return model(batch, 300, training=False)
+
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    probe.on = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    probe.on = False
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_fg = int(out["fg_idxs"].shape[0])
+        res = {
+            "metric": "scenes/sec forward (ScanNetV2 ~150k pts)",
+            "value": round(world * args.steps / elapsed, 3),
+            "unit": "scenes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "S150k eval forward, batch=1 per GPU, config/test_geoformer_scannet.yaml "
+                                   "(nq=256, nc=2048, 4 decoder layers), random-init weights",
+                       "points": int(batch["locs"].shape[0]), "voxels": M, "n_fg": n_fg,
+                       "parallelism": f"replicas x{world}"},
+            "roofline": probe.result(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+"""CPU stand-ins for the product's operator layer, built on the oracle.
+
+TEST INFRASTRUCTURE ONLY (see gf_oracle.c).  ``install()`` monkey-patches the functions of
+``geoformer_amd.sparse`` and ``geoformer_amd.pointops`` with numpy/oracle equivalents working on CPU
+tensors, so that the build's own model classes (host logic, index handling, RNG consumption) can
+be exercised without a GPU:
+  * ``-m "not gpu"`` tests run the build's GeoFormer on CPU against the reference-generated golden;
+  * bench.py's ``cpu_baseline`` leg times that same path on the GPU box's host cores.
+Nothing in ``geoformer_amd`` imports this module; the product path has no CPU fallback.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import numpy as np
+import torch
+
+from . import oracle as orc
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _r16(n):
+    return max((int(n) + 15) // 16 * 16, 16)
+
+
+def _gmask(tbl):
+    K = tbl.shape[0]
+    present = (tbl >= 0).reshape(K, -1, 16).any(2)
+    return (present * (1 << np.arange(K, dtype=np.int64))[:, None]).sum(0).astype(np.uint32).view(np.int32)
+
+
+def install():
+    """Patch the operator functions in place; returns a callable that restores them."""
+    from geoformer_amd import pointops, sparse
+
+    saved = {(mod, n): getattr(mod, n) for mod, names in (
+        (sparse, ["build_index", "subm_rules", "down_rules", "conv_fwd", "conv_dgrad", "conv_wgrad"]),
+        (pointops, ["voxelize_fp", "voxelize_bp", "gather_points", "gather_points_grad", "group_points",
+                    "group_points_grad", "ball_query", "furthest_point_sampling", "knn_radius", "geodesic_bfs"]),
+    ) for n in names}
+
+    def build_index(coords, batch, shape):
+        return sparse.LevelIndex(None, None, None, batch, tuple(int(s) for s in shape))
+
+    def subm_rules(coords, index):
+        M = coords.shape[0]
+        nbr = orc.rules_subm3(_np(coords), index.shape)
+        return sparse.SubmRules(_t(nbr), _t(_gmask(nbr)), nbr.shape[1], M)
+
+    def down_rules(coords, batch, shape):
+        shape = tuple(int(s) for s in shape)
+        M = coords.shape[0]
+        ld = _r16(M)
+        oc, child, parent, koff = orc.rules_down2(_np(coords), shape, ld)
+        up = orc.up_table(parent, koff, ld)
+        oshape = tuple((s - 2) // 2 + 1 for s in shape)
+        return sparse.DownRules(_t(oc), M, oc.shape[0], _t(child), ld, _t(_gmask(child)), _t(parent), _t(koff), _t(up),
+                                ld, _t(_gmask(up)), sparse.LevelIndex(None, None, None, batch, oshape), oshape)
+
+    def conv_fwd(feats, weight, nbr, gmask, K, M_out, ld, in_scale=None, in_shift=None, residual=None, out=None):
+        Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
+        W = _np(weight).reshape(K, Cin, Cout)
+        x = _np(feats)
+        if in_scale is not None:
+            x = np.maximum(x * _np(in_scale) + _np(in_shift), 0).astype(np.float32)
+        if nbr is None:
+            tbl = np.full((1, _r16(M_out)), -1, np.int32)
+            tbl[0, :M_out] = np.arange(M_out)
+        else:
+            tbl = _np(nbr)
+        y = orc.conv_fwd(x, W, tbl, M_out)
+        if residual is not None:
+            y = y + _np(residual)
+        return _t(y)
+
+    def conv_dgrad(grad_out, weight, bwd, M_in):
+        kind, (tbl, gmask, K, M, ld) = bwd
+        Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
+        w = weight.detach().reshape(K, Cin, Cout)
+        if kind == "subm":
+            w = w.flip(0)
+        return conv_fwd(grad_out, w.transpose(1, 2).contiguous(), tbl, gmask, K, M, ld)
+
+    def conv_wgrad(feats, grad_out, nbr, K, M_out, ld):
+        return _t(orc.conv_wgrad(_np(feats), _np(grad_out), _np(nbr), K))
+
+    def voxelize_fp(feats, rules, mode=4, out=None):
+        return _t(orc.voxelize_fp(_np(feats), _np(rules), mode == 4))
+
+    def voxelize_bp(d_out, rules, mode, d_feats):
+        d_feats += _t(orc.voxelize_bp(_np(d_out), _np(rules), d_feats.shape[0], mode == 4))
+        return d_feats
+
+    def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False):
+        p = _np(xyz)
+        D2, I = orc.knn(p, p, k)
+        D = np.sqrt(D2)
+        inr = D <= np.float32(radius)
+        Dm = np.where(inr, D if sqrt_out else D2, np.inf).astype(np.float32)
+        return _t(Dm), _t(np.where(inr, I, -1).astype(np.int32)), _t((inr.sum(1) - 1).astype(np.int32))
+
+    def geodesic_bfs(D, I, deg, src, radius, max_step):
+        return _t(orc.geodesic(_np(D)[:, 1:], _np(I)[:, 1:].astype(np.int64), _np(src).astype(np.int64), radius,
+                               max_step))
+
+    patch = {
+        (sparse, "build_index"): build_index, (sparse, "subm_rules"): subm_rules, (sparse, "down_rules"): down_rules,
+        (sparse, "conv_fwd"): conv_fwd, (sparse, "conv_dgrad"): conv_dgrad, (sparse, "conv_wgrad"): conv_wgrad,
+        (pointops, "voxelize_fp"): voxelize_fp, (pointops, "voxelize_bp"): voxelize_bp,
+        (pointops, "gather_points"): lambda p, i: _t(orc.gather_points(_np(p), _np(i))),
+        (pointops, "gather_points_grad"): lambda g, i, n: _t(orc.gather_points_grad(_np(g), _np(i), n)),
+        (pointops, "group_points"): lambda p, i: _t(orc.group_points(_np(p), _np(i))),
+        (pointops, "group_points_grad"): lambda g, i, n: _t(orc.group_points_grad(_np(g), _np(i), n)),
+        (pointops, "ball_query"): lambda q, p, r, ns: _t(orc.ball_query(_np(q), _np(p), r, ns)),
+        (pointops, "furthest_point_sampling"): lambda p, m: _t(orc.fps(_np(p), m)),
+        (pointops, "knn_radius"): knn_radius, (pointops, "geodesic_bfs"): geodesic_bfs,
+    }
+    for (mod, name), fn in patch.items():
+        setattr(mod, name, fn)
+
+    def restore():
+        for (mod, name), fn in saved.items():
+            setattr(mod, name, fn)
+
+    return restore
+
+
+@contextlib.contextmanager
+def installed():
+    restore = install()
+    try:
+        yield
+    finally:
+        restore()
