@@ -243,7 +243,12 @@ extern "C" const int32_t* gf_knn_error_flag(void* scratch, int n) {
 // ------------------------------------------------------------------------------------
 // frontier BFS
 // ------------------------------------------------------------------------------------
-#define BFS_THREADS 512
+#define BFS_THREADS 1024
+// One thread per frontier vertex: its row segment (<= 16 entries per pass, typical in-radius degree ~14)
+// is fetched with 16-byte loads issued together, then the visited probes of all its neighbours are
+// issued together, then the atomics -- so a hop costs a handful of dependent memory latencies for up to
+// 1024 vertices at once instead of one vertex per 16-lane group.  Queue entries carry the vertex degree
+// (fetched during the commit of the previous hop) to take one more load off the chain.
 __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __restrict__ D, const int32_t* __restrict__ I,
                                                               const int32_t* __restrict__ deg, int n, int K,
                                                               const int32_t* __restrict__ src, float radius,
@@ -254,8 +259,8 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
     const int q = blockIdx.x;
     float* g = geo + (size_t)q * n;
     unsigned* key = keys + (size_t)q * n;
-    int32_t* cur = queues + (size_t)q * 2 * n;
-    int32_t* nxt = cur + n;
+    int2* cur = reinterpret_cast<int2*>(queues + (size_t)q * 4 * n);
+    int2* nxt = cur + n;
     const int tid = threadIdx.x;
     for (int t = tid; t < n; t += BFS_THREADS) {
         g[t] = -1.0f;
@@ -265,25 +270,55 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
     __syncthreads();
     if (tid == 0) {
         g[s] = 0.0f;
-        cur[0] = s;
+        cur[0] = make_int2(s, deg ? deg[s] : K - 1);
         s_cnt = 0;
     }
     __syncthreads();
     int ncur = 1;
-    const int sub = tid >> 4, sl = tid & 15;  // one frontier vertex per 16-lane sub-group
+    const bool vec = (K & 3) == 0;
     for (int step = 0; step < max_step && ncur > 0; step++) {
-        for (int f = sub; f < ncur; f += BFS_THREADS / 16) {
-            const int u = cur[f];
-            const int du = deg ? deg[u] : K - 1;
-            for (int r = 1 + sl; r <= du; r += 16) {
-                const int v = I[(size_t)u * K + r];
-                const float d = D[(size_t)u * K + r];
-                if (v >= 0 && d <= radius && g[v] < 0.0f) {
-                    const unsigned cand = (((unsigned)u << 6) | (unsigned)r) + 1u;
-                    const unsigned old = atomicMin(&key[v], cand);
-                    if (old == 0xffffffffu) {
-                        const int pos = atomicAdd(&s_cnt, 1);
-                        nxt[pos] = v;
+        for (int f = tid; f < ncur; f += BFS_THREADS) {
+            const int2 e = cur[f];
+            const int u = e.x, du = e.y;
+            const int32_t* Iu = I + (size_t)u * K;
+            const float* Du = D + (size_t)u * K;
+            for (int r0 = 0; r0 <= du; r0 += 16) {  // entries r0 .. r0+15 (column 0 = self is skipped)
+                int v[16];
+                float d[16];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int rb = r0 + 4 * c;
+                    if (rb <= du && vec) {
+                        const int4 vi = *reinterpret_cast<const int4*>(Iu + rb);
+                        const float4 di = *reinterpret_cast<const float4*>(Du + rb);
+                        v[4 * c + 0] = vi.x; v[4 * c + 1] = vi.y; v[4 * c + 2] = vi.z; v[4 * c + 3] = vi.w;
+                        d[4 * c + 0] = di.x; d[4 * c + 1] = di.y; d[4 * c + 2] = di.z; d[4 * c + 3] = di.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int rr = rb + j;
+                            const bool ok = rr <= du && rr < K;
+                            v[4 * c + j] = ok ? Iu[rr] : -1;
+                            d[4 * c + j] = ok ? Du[rr] : 0.f;
+                        }
+                    }
+                }
+                float gv[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int rr = r0 + j;
+                    const bool ok = rr >= 1 && rr <= du && v[j] >= 0 && d[j] <= radius;
+                    gv[j] = ok ? g[v[j]] : 0.0f;  // 0 = "visited": nothing to do
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (gv[j] < 0.0f) {
+                        const unsigned cand = (((unsigned)u << 6) | (unsigned)(r0 + j)) + 1u;
+                        const unsigned old = atomicMin(&key[v[j]], cand);
+                        if (old == 0xffffffffu) {
+                            const int pos = atomicAdd(&s_cnt, 1);
+                            nxt[pos].x = v[j];
+                        }
                     }
                 }
             }
@@ -293,15 +328,134 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
         __syncthreads();
         if (tid == 0) s_cnt = 0;
         for (int t = tid; t < nn; t += BFS_THREADS) {
-            const int v = nxt[t];
+            const int v = nxt[t].x;
             const unsigned kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
             const int u = (int)(kk >> 6), r = (int)(kk & 63u);
+            const int dv = deg ? deg[v] : K - 1;
             g[v] = D[(size_t)u * K + r] + g[u];
+            nxt[t].y = dv;
         }
         __syncthreads();
-        int32_t* tmp = cur;
+        int2* tmp = cur;
         cur = nxt;
         nxt = tmp;
+        ncur = nn;
+    }
+}
+
+// LDS-resident variant (n <= BFS_LDS_MAX_N): the per-query "visited" and "touched" sets are bitmaps in
+// LDS and the frontier queues (vertex, distance) live in LDS too (spilling to global memory past the
+// LDS capacity), so a hop's dependent chain is: row fetch -> fire-and-forget 64-bit atomicMin carrying
+// (parent<<6|rank, distance) -> barrier -> one load of the winning pair -> store.  The 64-bit minimum
+// orders by (parent, rank) first, so the distance that rides in the low word is the winner's.
+#define BFS_LDS_MAX_N (1 << 19)
+#define BFS_LDS_BYTES (150 * 1024)
+__global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs_lds(const float* __restrict__ D,
+                                                                  const int32_t* __restrict__ I, int n, int K,
+                                                                  const int32_t* __restrict__ src, float radius,
+                                                                  int max_step, float* __restrict__ geo,
+                                                                  unsigned long long* __restrict__ keys,
+                                                                  int2* __restrict__ queues, int qcap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_cnt;
+    const int nw = (n + 31) >> 5;
+    unsigned* visited = reinterpret_cast<unsigned*>(smem);
+    unsigned* touched = visited + nw;
+    int2* q0 = reinterpret_cast<int2*>(touched + nw + ((2 * nw) & 1));
+    int2* q1 = q0 + qcap;
+    const int q = blockIdx.x;
+    float* g = geo + (size_t)q * n;
+    unsigned long long* key = keys + (size_t)q * n;
+    int2* gq0 = queues + (size_t)q * 2 * n;  // overflow space of the two queues
+    int2* gq1 = gq0 + n;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < n; t += BFS_THREADS) {
+        g[t] = -1.0f;
+        key[t] = ~0ull;
+    }
+    for (int t = tid; t < nw; t += BFS_THREADS) {
+        visited[t] = 0u;
+        touched[t] = 0u;
+    }
+    const int s = src[q];
+    __syncthreads();
+    if (tid == 0) {
+        g[s] = 0.0f;
+        visited[s >> 5] = 1u << (s & 31);
+        touched[s >> 5] = 1u << (s & 31);
+        q0[0] = make_int2(s, __float_as_int(0.0f));
+        s_cnt = 0;
+    }
+    __syncthreads();
+    int ncur = 1;
+    int2 *cl = q0, *cg = gq0, *nl = q1, *ng = gq1;
+    for (int step = 0; step < max_step && ncur > 0; step++) {
+        for (int f = tid; f < ncur; f += BFS_THREADS) {
+            const int2 e = f < qcap ? cl[f] : cg[f - qcap];
+            const int u = e.x;
+            const float gu = __int_as_float(e.y);
+            const int32_t* Iu = I + (size_t)u * K;
+            const float* Du = D + (size_t)u * K;
+            bool more = true;
+            for (int r0 = 0; r0 < K && more; r0 += 16) {
+                int v[16];
+                float d[16];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int rb = r0 + 4 * c;
+                    if (rb + 3 < K) {
+                        const int4 vi = *reinterpret_cast<const int4*>(Iu + rb);
+                        const float4 di = *reinterpret_cast<const float4*>(Du + rb);
+                        v[4 * c + 0] = vi.x; v[4 * c + 1] = vi.y; v[4 * c + 2] = vi.z; v[4 * c + 3] = vi.w;
+                        d[4 * c + 0] = di.x; d[4 * c + 1] = di.y; d[4 * c + 2] = di.z; d[4 * c + 3] = di.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            v[4 * c + j] = (rb + j < K) ? Iu[rb + j] : -1;
+                            d[4 * c + j] = (rb + j < K) ? Du[rb + j] : 0.f;
+                        }
+                    }
+                }
+                // rows are sorted by distance and padded with (inf,-1): stop after the first pad / out-of-radius
+                more = v[15] >= 0 && d[15] <= radius;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int rr = r0 + j;
+                    const int vv = v[j];
+                    if (rr >= 1 && vv >= 0 && d[j] <= radius) {
+                        const unsigned bit = 1u << (vv & 31);
+                        if (!(visited[vv >> 5] & bit)) {
+                            const unsigned cand = (((unsigned)u << 6) | (unsigned)rr) + 1u;
+                            const float nd = d[j] + gu;
+                            atomicMin(&key[vv], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(nd));
+                            const unsigned old = atomicOr(&touched[vv >> 5], bit);
+                            if (!(old & bit)) {
+                                const int pos = atomicAdd(&s_cnt, 1);
+                                if (pos < qcap) nl[pos].x = vv;
+                                else ng[pos - qcap].x = vv;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every atomicMin of this wave has been performed at L2
+        __syncthreads();
+        const int nn = s_cnt;
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+        for (int t = tid; t < nn; t += BFS_THREADS) {
+            int2* slot = t < qcap ? &nl[t] : &ng[t - qcap];
+            const int v = slot->x;
+            const unsigned long long kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int di = (int)(unsigned)(kk & 0xffffffffull);
+            g[v] = __int_as_float(di);
+            slot->y = di;
+            atomicOr(&visited[v >> 5], 1u << (v & 31));
+        }
+        __syncthreads();
+        int2* t1 = cl; cl = nl; nl = t1;
+        int2* t2 = cg; cg = ng; ng = t2;
         ncur = nn;
     }
 }
@@ -312,6 +466,25 @@ extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* 
     GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs: bad arguments");
     GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs: n=%d exceeds the 26-bit parent field", n);
     if (nq == 0) return GF_OK;
+    if (n <= BFS_LDS_MAX_N && (K & 3) == 0) {
+        // rows must be distance-sorted and padded with (inf,-1) (gf_knn_radius / faiss order): the
+        // LDS variant relies on that to stop scanning a row early
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_geodesic_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                BFS_LDS_BYTES);
+            attr_set = true;
+        }
+        const int nw = (n + 31) / 32;
+        const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
+        int qcap = (int)((BFS_LDS_BYTES - bm) / (2 * sizeof(int2)));
+        if (qcap > n) qcap = n;
+        const size_t lds = bm + (size_t)qcap * 2 * sizeof(int2);
+        hipLaunchKernelGGL(k_geodesic_bfs_lds, dim3(nq), dim3(BFS_THREADS), lds, (hipStream_t)stream, D, I, n, K, src,
+                           radius, max_step, geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
+        GF_CHECK_LAUNCH("gf_geodesic_bfs");
+        return GF_OK;
+    }
     hipLaunchKernelGGL(k_geodesic_bfs, dim3(nq), dim3(BFS_THREADS), 0, (hipStream_t)stream, D, I, deg, n, K, src,
                        radius, max_step, geo, (unsigned*)keys_ws, (int32_t*)queue_ws);
     GF_CHECK_LAUNCH("gf_geodesic_bfs");

@@ -91,21 +91,66 @@ __device__ __forceinline__ float4 load_a(const float* __restrict__ in, int idx, 
     return a;
 }
 
-template <int NCBW, bool VEC>
+// Per-wave schedule.  A "step" is one (kernel offset k, 16-channel chunk c) pair of the group; the
+// steps of a group are the present offsets (gmask) x NCH chunks.  The wave first stages the group's
+// neighbour indices in LDS (only the present offsets), then walks its steps in batches of PF: all
+// gathers and weight loads of a batch are issued back to back (PF x 1 KiB gathered rows in flight per
+// wave), then the batch's MFMAs run.  With SPLIT the four waves of the workgroup share one item and
+// take the steps round-robin (small levels: 4x more waves, 4x shorter dependent chains), and the
+// partial accumulators are summed through LDS.
+template <int NCBW>
+struct ConvPF {
+    static constexpr int value = NCBW == 1 ? 8 : (NCBW == 2 ? 6 : 4);
+};
+
+struct StepIter {
+    uint32_t m;  // offsets not yet visited
+    int k, c, nch;
+    __device__ __forceinline__ void init(uint32_t mask, int nch_) {
+        nch = nch_;
+        c = 0;
+        if (mask) {
+            k = __builtin_ctz(mask);
+            m = mask & (mask - 1);
+        } else {
+            k = -1;
+            m = 0;
+        }
+    }
+    __device__ __forceinline__ void next() {
+        if (k < 0) return;
+        if (++c == nch) {
+            c = 0;
+            if (m) {
+                k = __builtin_ctz(m);
+                m &= m - 1;
+            } else {
+                k = -1;
+            }
+        }
+    }
+};
+
+template <int NCBW, bool SPLIT, bool VEC>
 __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                  const int32_t* __restrict__ nbr, const uint32_t* __restrict__ gmask,
                                                  int K, int M_out, int ld, int Cin, int Cout, int NCH, int NCB,
                                                  int nsplit, const float* __restrict__ in_scale,
                                                  const float* __restrict__ in_shift,
                                                  const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int PF = ConvPF<NCBW>::value;
+    __shared__ int s_idx[4][32 * 16];
+    __shared__ float4 s_red[SPLIT ? 4 * NCBW * 64 : 1];
     const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int ngroups = (M_out + 15) >> 4;
     const int nitems = ngroups * nsplit;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int first = SPLIT ? blockIdx.x : ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int stride = SPLIT ? gridDim.x : ((gridDim.x * blockDim.x) >> 6);
+    int* idx_l = s_idx[w];
 
-    for (int item = wave; item < nitems; item += nwaves) {
+    for (int item = first; item < nitems; item += stride) {
         const int g = item / nsplit;
         const int cb0 = (item - g * nsplit) * NCBW;
         const int o = g * 16 + r;
@@ -116,79 +161,81 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
 
         uint32_t mask = nbr ? (gmask ? gmask[g] : ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u))) : 1u;
         mask = __builtin_amdgcn_readfirstlane(mask);
-        if (mask) {
-            // (k, idx) of the current offset and of the next one (index loaded one offset ahead)
-            int k = __builtin_ctz(mask);
-            mask &= mask - 1;
-            int idx = row_ok ? (nbr ? nbr[(size_t)k * ld + o] : o) : -1;
-            int k2 = -1, idx2 = -1;
-            if (mask) {
-                k2 = __builtin_ctz(mask);
-                mask &= mask - 1;
-                idx2 = row_ok ? nbr[(size_t)k2 * ld + o] : -1;
-            }
-            int c = 0;
-            float4 a = load_a<VEC>(in, idx, Cin, 4 * q, in_scale, in_shift);
-            float4 b[NCBW];
+        // stage the neighbour indices of the present offsets (lane (r,q) fetches offsets q, q+4, ...)
 #pragma unroll
-            for (int cb = 0; cb < NCBW; cb++)
-                b[cb] = (cb0 + cb < NCB) ? Wp[(((size_t)k * NCH + 0) * NCB + cb0 + cb) * 64 + lane]
-                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-            while (true) {
-                // ---- issue the loads of the next step ----
-                int nc = c + 1;
-                bool more = true;
-                if (nc == NCH) {
-                    nc = 0;
-                    if (k2 >= 0) {
-                        k = k2;
-                        idx = idx2;
-                        if (mask) {
-                            k2 = __builtin_ctz(mask);
-                            mask &= mask - 1;
-                            idx2 = row_ok ? nbr[(size_t)k2 * ld + o] : -1;
-                        } else {
-                            k2 = -1;
-                        }
-                    } else {
-                        more = false;
-                    }
-                }
-                float4 an = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 bn[NCBW];
-                if (more) {
-                    an = load_a<VEC>(in, idx, Cin, nc * 16 + 4 * q, in_scale, in_shift);
+        for (int i = 0; i < 8; i++) {
+            const int k = q + 4 * i;
+            if (k < K && ((mask >> k) & 1u)) idx_l[k * 16 + r] = row_ok ? (nbr ? nbr[(size_t)k * ld + o] : o) : -1;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        StepIter it;
+        it.init(mask, NCH);
+        if (SPLIT)
+            for (int j = 0; j < w; j++) it.next();
+        while (it.k >= 0) {
+            float4 a[PF];
+            float4 b[PF][NCBW];
+            bool valid[PF];
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                valid[j] = it.k >= 0;
+                if (valid[j]) {
+                    const int idx = idx_l[it.k * 16 + r];
+                    a[j] = load_a<VEC>(in, idx, Cin, it.c * 16 + 4 * q, in_scale, in_shift);
 #pragma unroll
                     for (int cb = 0; cb < NCBW; cb++)
-                        bn[cb] = (cb0 + cb < NCB) ? Wp[(((size_t)k * NCH + nc) * NCB + cb0 + cb) * 64 + lane]
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                        b[j][cb] = (cb0 + cb < NCB) ? Wp[(((size_t)it.k * NCH + it.c) * NCB + cb0 + cb) * 64 + lane]
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                // ---- MFMAs of the current step ----
-#pragma unroll
-                for (int cb = 0; cb < NCBW; cb++) {
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[cb].x, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[cb].y, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[cb].z, acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[cb].w, acc[cb], 0, 0, 0);
+                it.next();
+                if (SPLIT) {
+                    it.next();
+                    it.next();
+                    it.next();
                 }
-                if (!more) break;
-                a = an;
+            }
 #pragma unroll
-                for (int cb = 0; cb < NCBW; cb++) b[cb] = bn[cb];
-                c = nc;
+            for (int j = 0; j < PF; j++) {
+                if (valid[j]) {
+#pragma unroll
+                    for (int cb = 0; cb < NCBW; cb++) {
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j][cb].x, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j][cb].y, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j][cb].z, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j][cb].w, acc[cb], 0, 0, 0);
+                    }
+                }
             }
         }
-        // C/D layout: col = lane&15, row = (lane>>4)*4 + j
+        if (SPLIT) {
+            __syncthreads();  // previous item's reduction reads are done
+#pragma unroll
+            for (int cb = 0; cb < NCBW; cb++)
+                s_red[(w * NCBW + cb) * 64 + lane] = make_float4(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]);
+            __syncthreads();
+        }
+        // C/D layout: col = lane&15, row = (lane>>4)*4 + j.  SPLIT: wave w sums column blocks w, w+4.
 #pragma unroll
         for (int cb = 0; cb < NCBW; cb++) {
+            float v[4] = {acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]};
+            if (SPLIT) {
+                if ((cb & 3) != w) continue;
+                const float4 p0 = s_red[(0 * NCBW + cb) * 64 + lane], p1 = s_red[(1 * NCBW + cb) * 64 + lane];
+                const float4 p2 = s_red[(2 * NCBW + cb) * 64 + lane], p3 = s_red[(3 * NCBW + cb) * 64 + lane];
+                v[0] = (p0.x + p1.x) + (p2.x + p3.x);
+                v[1] = (p0.y + p1.y) + (p2.y + p3.y);
+                v[2] = (p0.z + p1.z) + (p2.z + p3.z);
+                v[3] = (p0.w + p1.w) + (p2.w + p3.w);
+            }
             const int col = (cb0 + cb) * 16 + r;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = g * 16 + q * 4 + j;
                 if (row < M_out && col < Cout) {
-                    float v = acc[cb][j];
-                    if (residual) v += residual[(size_t)row * Cout + col];
-                    out[(size_t)row * Cout + col] = v;
+                    float x = v[j];
+                    if (residual) x += residual[(size_t)row * Cout + col];
+                    out[(size_t)row * Cout + col] = x;
                 }
             }
         }
@@ -205,14 +252,28 @@ struct ConvArgs {
     float* out;
 };
 
-template <int NCBW>
+template <int NCBW, bool SPLIT>
 static void launch_conv(bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
     if (vec)
-        hipLaunchKernelGGL((k_conv_os<NCBW, true>), grid, dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K, a.M_out,
-                           a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
+        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, true>), grid, dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
     else
-        hipLaunchKernelGGL((k_conv_os<NCBW, false>), grid, dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K, a.M_out,
-                           a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
+        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, false>), grid, dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
+}
+
+template <bool SPLIT>
+static void dispatch_conv(int ncbw, bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
+    switch (ncbw) {
+        case 1: launch_conv<1, SPLIT>(vec, grid, st, a); break;
+        case 2: launch_conv<2, SPLIT>(vec, grid, st, a); break;
+        case 3: launch_conv<3, SPLIT>(vec, grid, st, a); break;
+        case 4: launch_conv<4, SPLIT>(vec, grid, st, a); break;
+        case 5: launch_conv<5, SPLIT>(vec, grid, st, a); break;
+        case 6: launch_conv<6, SPLIT>(vec, grid, st, a); break;
+        case 7: launch_conv<7, SPLIT>(vec, grid, st, a); break;
+        default: launch_conv<8, SPLIT>(vec, grid, st, a); break;
+    }
 }
 
 extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
@@ -228,33 +289,23 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     const int ncb = (Cout + 15) / 16, nch = (Cin + 15) / 16;
     const bool vec = (Cin % 16) == 0 && (((uintptr_t)in) % 16) == 0 &&
                      (in_scale == nullptr || ((((uintptr_t)in_scale) | ((uintptr_t)in_shift)) % 16) == 0);
-    // column blocks per wave: as many as possible while the launch still has >= 2048 waves
-    int ncbw = 1;
-    for (int cand = ncb; cand >= 1; cand--) {
-        const int split = (ncb + cand - 1) / cand;
-        if ((long long)ngroups * split >= 2048) {
-            ncbw = cand;
-            break;
-        }
-    }
+    // Big levels: one wave per 16-row group owning every column block.  Small levels (not enough groups
+    // to fill 1024 SIMDs with several waves each): a workgroup per (group, <=2 column blocks), steps split
+    // over its four waves.
+    const bool split = ngroups < 6000;
+    const int ncbw = split ? (ncb >= 2 && ngroups >= 2048 ? 2 : 1) : ncb;
     const int nsplit = (ncb + ncbw - 1) / ncbw;
-    long long nitems = (long long)ngroups * nsplit;
-    int blocks = (int)((nitems + 3) / 4);  // 4 waves per 256-thread block, one item per wave
+    const long long nitems = (long long)ngroups * nsplit;
+    long long blocks = split ? nitems : (nitems + 3) / 4;
     if (blocks > 256 * 64) blocks = 256 * 64;
     ConvArgs a{in, reinterpret_cast<const float4*>(Wp), nbr, gmask, K, M_out, ld, Cin, Cout, nch, ncb, nsplit,
                in_scale, in_shift, residual, out};
-    dim3 grid(blocks);
+    dim3 grid((unsigned)blocks);
     hipStream_t st = (hipStream_t)stream;
-    switch (ncbw) {
-        case 1: launch_conv<1>(vec, grid, st, a); break;
-        case 2: launch_conv<2>(vec, grid, st, a); break;
-        case 3: launch_conv<3>(vec, grid, st, a); break;
-        case 4: launch_conv<4>(vec, grid, st, a); break;
-        case 5: launch_conv<5>(vec, grid, st, a); break;
-        case 6: launch_conv<6>(vec, grid, st, a); break;
-        case 7: launch_conv<7>(vec, grid, st, a); break;
-        default: launch_conv<8>(vec, grid, st, a); break;
-    }
+    if (split)
+        dispatch_conv<true>(ncbw, vec, grid, st, a);
+    else
+        dispatch_conv<false>(ncbw, vec, grid, st, a);
     GF_CHECK_LAUNCH("gf_conv_fwd");
     return GF_OK;
 }

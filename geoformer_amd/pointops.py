@@ -131,8 +131,8 @@ def geodesic_bfs(D, I, deg, src, radius, max_step):
     nq = src.shape[0]
     dev = D.device
     geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
-    keys = torch.empty((nq, n), dtype=torch.int32, device=dev)
-    queues = torch.empty((nq, 2, n), dtype=torch.int32, device=dev)
+    keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
+    queues = torch.empty((nq, 4, n), dtype=torch.int32, device=dev)
     check(_lib.load().gf_geodesic_bfs(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
                                       ptr(geo), ptr(keys), ptr(queues), stream_ptr()), "gf_geodesic_bfs")
     return geo
