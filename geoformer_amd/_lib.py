@@ -46,6 +46,7 @@ def _declare(lib):
         "gf_knn_radius": (I, [P, I, I, F, I, P, P, P, P, P]),
         "gf_knn_error_flag": (P, [P, I]),
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
+        "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -1,0 +1,156 @@
+// Dynamic-convolution mask head, fused (gfx950).
+//
+//   reference: GeoFormer.mask_heads_forward (model/geoformer/geoformer.py:286-324) -- per query q and
+//   foreground point p:   rel = q_xyz - p_xyz;  if geo[q,p] < 0: rel += sqrt(max_geo_q) * sign(rel)
+//                         h   = relu(W1_q [rel ; f_p] + b1_q)        (W1_q: 16 x 19, generated per query)
+//                         out = W2_q h + b2_q                        (W2_q: 1 x 16)
+//   The reference materialises x.repeat(nq,1,1) (nq*19*N floats, 1.17 GB at 256 x 60k) and runs a
+//   grouped conv1d; here nothing but geo (read once) and the logits (written once) touches HBM.
+//
+// Mapping.  One wave owns MH_Q queries (their generated parameters live in registers) and streams
+// blocks of 64 points.  For a 16-point tile the feature part W1f_q[16x16] . F^T[16x16] is four
+// v_mfma_f32_16x16x4_f32 with the point on the column (lane&15): lane (g = lane>>4, j = lane&15) supplies
+// f_p[4g..4g+3] -- one 16-byte load per lane, reused by every query -- and the matching weight columns
+// 4g+s (the MFMA k index is only a summation index).  The 3 coordinate taps, bias, ReLU and the 16->1
+// contraction run on the accumulator layout (rows 4g..4g+3 per lane); the four row groups of the four
+// tiles are combined with a two-step butterfly so lane (g,j) ends up with the logit of point 16g+j and
+// a wave stores 256 contiguous bytes per query.  Roofline: 4*(2*nq*N) bytes of geo/logit traffic
+// against 2*nq*N*(19*16+16) flops -> 80 flop/B: MFMA/VALU-bound, ~10 GFLOP per 150k-point scene.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MH_Q 4
+
+template <bool USE_GEO>
+__global__ __launch_bounds__(256, 2) void k_mask_head(const float* __restrict__ feat, const float* __restrict__ coords,
+                                                      const float* __restrict__ geo, const float* __restrict__ qxyz,
+                                                      const float* __restrict__ mx, const float* __restrict__ w1,
+                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                      const float* __restrict__ b2, int N, int nq, int chunks,
+                                                      float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int qgroups = (nq + MH_Q - 1) / MH_Q;
+    const int qg = wave % qgroups, chunk = wave / qgroups;
+    if (chunk >= chunks) return;
+    const int nblocks = (N + 63) >> 6;
+    const int per = (nblocks + chunks - 1) / chunks;
+    const int blk0 = chunk * per, blk1 = min(nblocks, blk0 + per);
+
+    // per-query parameters in registers
+    float wf[MH_Q][4];      // A operand: W1[q][c=j][3 + 4g + s]
+    float wc[MH_Q][4][3];   // coordinate taps of rows c = 4g + r
+    float bb[MH_Q][4], ww[MH_Q][4], b2q[MH_Q], qx[MH_Q], qy[MH_Q], qz[MH_Q], mq[MH_Q];
+#pragma unroll
+    for (int t = 0; t < MH_Q; t++) {
+        const int q = min(qg * MH_Q + t, nq - 1);
+        const float* W = w1 + (size_t)q * 16 * 19;
+#pragma unroll
+        for (int s = 0; s < 4; s++) wf[t][s] = W[j * 19 + 3 + 4 * g + s];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c = 4 * g + r;
+            wc[t][r][0] = W[c * 19 + 0];
+            wc[t][r][1] = W[c * 19 + 1];
+            wc[t][r][2] = W[c * 19 + 2];
+            bb[t][r] = b1[(size_t)q * 16 + c];
+            ww[t][r] = w2[(size_t)q * 16 + c];
+        }
+        b2q[t] = b2[q];
+        qx[t] = qxyz[q * 3 + 0];
+        qy[t] = qxyz[q * 3 + 1];
+        qz[t] = qxyz[q * 3 + 2];
+        mq[t] = USE_GEO ? mx[q] : 0.f;
+    }
+
+    for (int blk = blk0; blk < blk1; blk++) {
+        const int p0 = blk * 64;
+        // operands of the four 16-point tiles: features (B operand) and coordinates of column j
+        float4 f[4];
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int p = p0 + 16 * t + j;
+            const int pc = min(p, N - 1);
+            f[t] = *reinterpret_cast<const float4*>(feat + (size_t)pc * 16 + 4 * g);
+            px[t] = coords[(size_t)pc * 3 + 0];
+            py[t] = coords[(size_t)pc * 3 + 1];
+            pz[t] = coords[(size_t)pc * 3 + 2];
+        }
+#pragma unroll
+        for (int t = 0; t < MH_Q; t++) {
+            const int q = qg * MH_Q + t;
+            float part[4];
+#pragma unroll
+            for (int tl = 0; tl < 4; tl++) {
+                const int p = p0 + 16 * tl + j;
+                f32x4 acc = (f32x4){bb[t][0], bb[t][1], bb[t][2], bb[t][3]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][0], f[tl].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][1], f[tl].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][2], f[tl].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][3], f[tl].w, acc, 0, 0, 0);
+                float rx = qx[t] - px[tl], ry = qy[t] - py[tl], rz = qz[t] - pz[tl];
+                if (USE_GEO) {
+                    const float gd = (p < N && q < nq) ? geo[(size_t)q * N + p] : 0.f;
+                    if (gd < 0.f) {
+                        rx = rx + mq[t] * (float)((rx > 0.f) - (rx < 0.f));
+                        ry = ry + mq[t] * (float)((ry > 0.f) - (ry < 0.f));
+                        rz = rz + mq[t] * (float)((rz > 0.f) - (rz < 0.f));
+                    }
+                }
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float h = acc[r];
+                    h = fmaf(wc[t][r][0], rx, h);
+                    h = fmaf(wc[t][r][1], ry, h);
+                    h = fmaf(wc[t][r][2], rz, h);
+                    s = fmaf(ww[t][r], fmaxf(h, 0.f), s);
+                }
+                part[tl] = s;
+            }
+            // butterfly over the four row groups: afterwards lane (g,j) holds the full sum of tile g
+            {
+                // step 1 (xor 32): groups {0,1} keep tiles {0,1}, groups {2,3} keep tiles {2,3}
+                const bool hi = g >= 2;
+                const float send0 = hi ? part[0] : part[2], send1 = hi ? part[1] : part[3];
+                const float r0 = __shfl_xor(send0, 32, 64), r1 = __shfl_xor(send1, 32, 64);
+                const float k0 = (hi ? part[2] : part[0]) + r0, k1 = (hi ? part[3] : part[1]) + r1;
+                // step 2 (xor 16): even group keeps the first of its pair, odd group the second
+                const bool odd = g & 1;
+                const float send = odd ? k0 : k1;
+                const float r = __shfl_xor(send, 16, 64);
+                const float tot = (odd ? k1 : k0) + r + b2q[t];
+                const int p = p0 + 16 * g + j;
+                if (p < N && q < nq) out[(size_t)q * N + p] = tot;
+            }
+        }
+    }
+}
+
+extern "C" int gf_mask_head(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                            const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                            const float* b2, int N, int nq, int C, float* out, void* stream) {
+    GF_CHECK_ARG(C == 16, "gf_mask_head: only the 16-channel mask head (m=16) is implemented, got C=%d", C);
+    GF_CHECK_ARG(N >= 0 && nq >= 0, "gf_mask_head: bad sizes");
+    GF_CHECK_ARG((geo == nullptr) == (sqrt_max_geo == nullptr), "gf_mask_head: geo and sqrt_max_geo come together");
+    if (N == 0 || nq == 0) return GF_OK;
+    const int qgroups = (nq + MH_Q - 1) / MH_Q;
+    const int nblocks = (N + 63) / 64;
+    // enough waves for ~8 per SIMD; every wave sweeps a contiguous range of 64-point blocks
+    int chunks = (256 * 4 * 8 + qgroups - 1) / qgroups;
+    if (chunks > nblocks) chunks = nblocks;
+    if (chunks < 1) chunks = 1;
+    const long long waves = (long long)qgroups * chunks;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (geo)
+        hipLaunchKernelGGL((k_mask_head<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1, b1,
+                           w2, b2, N, nq, chunks, out);
+    else
+        hipLaunchKernelGGL((k_mask_head<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1, b1,
+                           w2, b2, N, nq, chunks, out);
+    GF_CHECK_LAUNCH("gf_mask_head");
+    return GF_OK;
+}

@@ -221,6 +221,19 @@ class GeoFormer(nn.Module):
         """logits[q, p] = W2_q relu(W1_q [rel_xyz(q,p); f_p] + b1_q) + b2_q with rel = q_xyz - p_xyz and,
         where p is geodesically unreachable from q, rel += sqrt(max_geo_q) * sign(rel) (geoformer.py:286-324)."""
         n_mask = mask_features.size(0)
+        if (mask_features.is_cuda and self.output_dim == 16 and not torch.is_grad_enabled()):
+            # inference: one fused HIP kernel (no nq x 19 x N intermediate)
+            mx = None
+            if use_geo:
+                mx = torch.max(geo_dist, dim=1)[0]
+                mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+            od = self.output_dim
+            logits = pointops.mask_head(
+                mask_features.reshape(n_mask, od).contiguous(), coords_.contiguous(),
+                geo_dist.contiguous() if use_geo else None, fps_sampling_coords.reshape(-1, 3).contiguous(), mx,
+                weights[0].reshape(num_insts, od, od + 3).contiguous(), biases[0].reshape(num_insts, od).contiguous(),
+                weights[1].reshape(num_insts, od).contiguous(), biases[1].reshape(num_insts).contiguous())
+            return logits.reshape(1, num_insts, n_mask)
         rel = fps_sampling_coords.reshape(-1, 1, 3) - coords_.reshape(1, -1, 3)  # nq x N x 3
         if use_geo:
             mx = torch.max(geo_dist, dim=1)[0]

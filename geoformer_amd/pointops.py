@@ -136,3 +136,17 @@ def geodesic_bfs(D, I, deg, src, radius, max_step):
     check(_lib.load().gf_geodesic_bfs(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
                                       ptr(geo), ptr(keys), ptr(queues), stream_ptr()), "gf_geodesic_bfs")
     return geo
+
+
+# ---- fused heads -------------------------------------------------------------------------
+def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
+    """Fused dynamic-conv mask head: logits [nq,N].  feat [N,16], coords [N,3], geo [nq,N] or None,
+    qxyz [nq,3], sqrt_max_geo [nq] or None, w1 [nq,16,19], b1 [nq,16], w2 [nq,16], b2 [nq]."""
+    for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+        _f32c(t, name)
+    N, C = feat.shape
+    nq = qxyz.shape[0]
+    out = torch.empty((nq, N), dtype=torch.float32, device=feat.device)
+    check(_lib.load().gf_mask_head(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), ptr(w1), ptr(b1),
+                                   ptr(w2), ptr(b2), N, nq, C, ptr(out), stream_ptr()), "gf_mask_head")
+    return out

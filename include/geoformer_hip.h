@@ -168,6 +168,21 @@ const int32_t* gf_knn_error_flag(void* scratch, int n);
 int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
                     float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, void* stream);
 
+/* ===================================================================================
+ * Mask head (GeoFormer.mask_heads_forward, model/geoformer/geoformer.py:286-324), fused
+ * =================================================================================== */
+
+/* logits[q,p] = W2_q relu(W1_q [rel(q,p) ; feat_p] + b1_q) + b2_q,  rel = qxyz_q - coords_p and, where
+ * geo[q,p] < 0, rel += sqrt_max_geo[q] * sign(rel).
+ *   feat fp32 [N,C] (C = 16), coords fp32 [N,3], geo fp32 [nq,N] or NULL (then no fix-up),
+ *   qxyz fp32 [nq,3], sqrt_max_geo fp32 [nq] (NULL iff geo NULL),
+ *   w1 fp32 [nq,C,3+C] (row c = [3 coordinate taps, C feature taps], the layout
+ *   parse_dynamic_params produces, geoformer.py:264-284), b1 [nq,C], w2 [nq,C], b2 [nq]
+ *   out fp32 [nq,N]. */
+int gf_mask_head(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                 const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2, int N,
+                 int nq, int C, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
