@@ -20,7 +20,8 @@ from torch.nn import functional as F
 from .. import pointops, spconv
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
-from .layers import GenericMLP, PositionEmbeddingCoordsSine, TransformerDecoder, TransformerDecoderLayer
+from .layers import (GenericMLP, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
+                     TransformerDecoderLayer)
 from .set_abstraction import PointnetSAModuleVotesSeparate
 
 
@@ -186,6 +187,14 @@ class GeoFormer(nn.Module):
         """[nq, nc, B, d] Fourier embedding of the query->context geodesic distances; unreachable
         pairs get max_geo(query) + |dxyz| per axis (geoformer.py:619-651)."""
         B = context_locs.shape[0]
+        if context_locs.is_cuda and self.cfg.dec_dim == 64 and not torch.is_grad_enabled():
+            # inference: hand the fused cross-attention kernel the ingredients instead of the 134 MB tensor
+            geo = torch.stack([geo_dists[b][:, pre_enc_inds[b].long()] for b in range(B)], dim=0).contiguous()
+            max_geo = torch.max(geo, dim=2)[0]
+            max_geo = torch.where(max_geo < 0, torch.max(max_geo), max_geo).contiguous()
+            return RelPosSpec(geo, max_geo, query_locs.contiguous(), context_locs.contiguous(),
+                              pc_dims[0].float().contiguous(), pc_dims[1].float().contiguous(),
+                              self.pos_embedding.gauss_B.contiguous())
         rel = torch.abs(query_locs[:, :, None, :] - context_locs[:, None, :, :])
         nq, nc = rel.shape[1], rel.shape[2]
         geo = torch.stack([geo_dists[b][:, pre_enc_inds[b].long()] for b in range(B)], dim=0)  # B x nq x nc

@@ -193,6 +193,15 @@ class BackboneTransformer(nn.Module):
 # ------------------------------------------------------------------------------------------
 # model/transformer_detr.py:91-166, 345-463  DETR-style decoder with relative vector attention
 # ------------------------------------------------------------------------------------------
+class RelPosSpec:
+    """What the fused cross-attention kernel needs instead of the materialised [nq,nc,B,d] relative
+    embedding: the gathered geodesic distances and the ingredients of the fourier map."""
+
+    def __init__(self, geo_ctx, max_geo, query_locs, context_locs, lo, hi, gauss_B):
+        self.geo_ctx, self.max_geo, self.query_locs, self.context_locs = geo_ctx, max_geo, query_locs, context_locs
+        self.lo, self.hi, self.gauss_B = lo, hi, gauss_B
+
+
 class TransformerDecoderLayer(nn.Module):
     def __init__(self, d_model, nhead=4, dim_feedforward=256, dropout=0.1, dropout_attn=None, activation="relu",
                  normalize_before=True, use_rel=False, norm_fn_name="ln"):
@@ -217,10 +226,30 @@ class TransformerDecoderLayer(nn.Module):
         """Vector attention (transformer_detr.py:443-454): per-channel softmax over the contexts of
         MLP(q_i - k_j + r_ij) / sqrt(d), values Linear(k_j + r_ij).  tgt2 [nq,B,d], memory [nc,B,d],
         relative_pos [nq,nc,B,d] -> [nq,B,d]."""
+        if isinstance(relative_pos, RelPosSpec):
+            return self._cross_attention_fused(tgt2, memory, relative_pos)
         sim = self.attn_mlp(tgt2[:, None] - memory[None] + relative_pos)
         attn = F.softmax(sim / np.sqrt(sim.shape[-1]), dim=1)
         v2 = self.v_mlp(memory[None] + relative_pos)
         return (attn * v2).sum(dim=1)
+
+    def _cross_attention_fused(self, tgt2, memory, rp):
+        """Inference path on the GPU: one HIP kernel per layer (csrc/decoder_attn.hip); the parts of the two
+        MLPs that do not depend on the (query, context) pair are hoisted out as small GEMMs."""
+        from .. import pointops
+
+        w1, w2, wv = self.attn_mlp[0], self.attn_mlp[2], self.v_mlp[0]
+        key = (w1.weight._version, w2.weight._version, wv.weight._version, w1.weight.data_ptr())
+        if getattr(self, "_wpack_key", None) != key:
+            self._wpack = pointops.decoder_pack_weights(w1.weight.detach().contiguous(), w2.weight.detach().contiguous(),
+                                                        wv.weight.detach().contiguous())
+            self._wpack_key = key
+        Q1 = w1(tgt2).permute(1, 0, 2).contiguous()  # B x nq x d
+        K1 = F.linear(memory, w1.weight).permute(1, 0, 2).contiguous()  # B x nc x d
+        Kv = wv(memory).permute(1, 0, 2).contiguous()
+        out = pointops.decoder_cross_attn(rp.geo_ctx, rp.max_geo, rp.query_locs, rp.context_locs, rp.lo, rp.hi,
+                                          rp.gauss_B, Q1, K1, Kv, self._wpack, w2.bias.detach().contiguous())
+        return out.permute(1, 0, 2)  # nq x B x d
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None, relative_pos=None,

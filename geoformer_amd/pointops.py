@@ -150,3 +150,25 @@ def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
     check(_lib.load().gf_mask_head(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), ptr(w1), ptr(b1),
                                    ptr(w2), ptr(b2), N, nq, C, ptr(out), stream_ptr()), "gf_mask_head")
     return out
+
+
+def decoder_pack_weights(W1, W2, Wv):
+    lib = _lib.load()
+    wp = torch.empty(lib.gf_decoder_wpack_floats(), dtype=torch.float32, device=W1.device)
+    check(lib.gf_decoder_pack_weights(ptr(_f32c(W1, "W1")), ptr(_f32c(W2, "W2")), ptr(_f32c(Wv, "Wv")), ptr(wp),
+                                      stream_ptr()), "gf_decoder_pack_weights")
+    return wp
+
+
+def decoder_cross_attn(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, wpack, b2):
+    """Fused vector cross-attention; shapes as in include/geoformer_hip.h.  Returns [B,nq,64]."""
+    for t, name in ((geo_ctx, "geo_ctx"), (max_geo, "max_geo"), (qloc, "qloc"), (cloc, "cloc"), (lo, "lo"), (hi, "hi"),
+                    (gaussB, "gaussB"), (Q1, "Q1"), (K1, "K1"), (Kv, "Kv"), (wpack, "wpack"), (b2, "b2")):
+        _f32c(t, name)
+    B, nq, nc = geo_ctx.shape
+    d = Q1.shape[-1]
+    out = torch.empty((B, nq, d), dtype=torch.float32, device=Q1.device)
+    check(_lib.load().gf_decoder_cross_attn(ptr(geo_ctx), ptr(max_geo), ptr(qloc), ptr(cloc), ptr(lo), ptr(hi),
+                                            ptr(gaussB), ptr(Q1), ptr(K1), ptr(Kv), ptr(wpack), ptr(b2), B, nq, nc, d,
+                                            ptr(out), stream_ptr()), "gf_decoder_cross_attn")
+    return out

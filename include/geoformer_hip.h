@@ -183,6 +183,27 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
                  const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2, int N,
                  int nq, int C, float* out, void* stream);
 
+/* ===================================================================================
+ * Decoder cross-attention (TransformerDecoderLayer.forward_pre_rel, model/transformer_detr.py:443-454
+ * with the relative embedding of GeoFormer.forward_decoder, model/geoformer/geoformer.py:619-651), fused
+ * =================================================================================== */
+
+/* Packs attn_mlp.0.weight (W1), attn_mlp.2.weight (W2) and v_mlp.0.weight (Wv), each [64,64] (out,in),
+ * into MFMA A-operand lane order; Wpack holds gf_decoder_wpack_floats() floats. */
+size_t gf_decoder_wpack_floats(void);
+int gf_decoder_pack_weights(const float* W1, const float* W2, const float* Wv, float* Wpack, void* stream);
+
+/* out[b,i,:] = sum_j softmax_j(sim_ij / 8) * (Kv[b,j,:] + Wv r_ij),   sim_ij = W2 relu(Q1[b,i,:] - K1[b,j,:] + W1 r_ij) + b2,
+ * r_ij = [sin(P), cos(P)], P = 2*pi*((g3 - lo)/(hi - lo)) . gaussB,  g3 = geo_ctx[b,i,j] on all three axes, or
+ * max_geo[b,i] + |qloc[b,i] - cloc[b,j]| per axis where geo_ctx < 0.
+ *   geo_ctx [B,nq,nc], max_geo [B,nq], qloc [B,nq,3], cloc [B,nc,3], lo/hi [B,3] (the pc_dims pair as the
+ *   caller passes it -- GeoFormer passes [maxs, mins]), gaussB [3,32],
+ *   Q1 = W1 q + b1 [B,nq,64], K1 = W1 k [B,nc,64], Kv = Wv k + bv [B,nc,64], b2 [64];  out [B,nq,64]. */
+int gf_decoder_cross_attn(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
+                          const float* lo, const float* hi, const float* gaussB, const float* Q1, const float* K1,
+                          const float* Kv, const float* Wpack, const float* b2, int B, int nq, int nc, int d, float* out,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
