@@ -70,10 +70,9 @@ class ConvProbe:
             if hit:
                 if self.R is None:
                     self.tbl = nbr
+                # events recorded in native code right around the launch, on the kernel's stream
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s.record()
-                out = self.orig(feats, weight, nbr, gmask, K, M_out, ld, **kw)
-                e.record()
+                out = self.orig(feats, weight, nbr, gmask, K, M_out, ld, events=(s, e), **kw)
                 self.events.append((s, e))
                 return out
             return self.orig(feats, weight, nbr, gmask, K, M_out, ld, **kw)
@@ -91,7 +90,7 @@ class ConvProbe:
         ach = byt / (us * 1e-6) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "k_conv_os<1,true> (subm 3x3x3, 16->16, level 1)", "launches": len(ms),
+                "kernel": "k_conv_os<1,false,true> (subm 3x3x3, 16->16, level 1)", "launches": len(ms),
                 "us_per_launch": round(us, 2), "algorithmic_bytes": byt, "rules": R, "voxels": self.M}
 
 
@@ -100,7 +99,7 @@ def cpu_baseline():
     from geoformer_amd import scene
     from oracle import cpu_backend
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     sc = scene.make_small_scene(8192, 7)
     batch = scene.make_batch([sc])
     with cpu_backend.installed(), torch.no_grad():

@@ -100,7 +100,7 @@ __global__ void k_grid_fill(const float* __restrict__ xyz, int n, float inv_cell
 }
 
 #define KNN_WAVES 4
-#define KNN_CAP 512  // in-radius candidates per query point held in LDS
+#define KNN_CAP 1024  // in-radius candidates per query point held in LDS
 __global__ __launch_bounds__(KNN_WAVES * 64) void k_knn_radius(const float* __restrict__ xyz, int n, int k,
                                                                float radius, float inv_cell, unsigned tmask,
                                                                const int32_t* __restrict__ start,

@@ -310,6 +310,17 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     return GF_OK;
 }
 
+// Same launch bracketed by two caller-owned hipEvent_t recorded back to back with the kernel on the
+// same stream (bench.py's roofline probe: the kernel's own duration, not the host's launch gaps).
+extern "C" int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
+                                 int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
+                                 const float* residual, float* out, void* ev_start, void* ev_stop, void* stream) {
+    hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream);
+    const int rc = gf_conv_fwd(in, Wp, nbr, gmask, K, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out, stream);
+    hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream);
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------
 // weight gradient: dW[k] = sum_o in[nbr[k][o],:]^T dOut[o,:]
 // One wave per (offset k, 16-channel input block, 16-channel output block, slice of rows).

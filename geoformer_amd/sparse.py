@@ -168,7 +168,8 @@ def pack_weights(weight: torch.Tensor) -> torch.Tensor:
 
 
 def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], gmask: Optional[torch.Tensor],
-             K: int, M_out: int, ld: int, in_scale=None, in_shift=None, residual=None, out=None) -> torch.Tensor:
+             K: int, M_out: int, ld: int, in_scale=None, in_shift=None, residual=None, out=None,
+             events=None) -> torch.Tensor:
     """out[o] = sum_k act(feats[nbr[k,o]]) @ weight[k] (+ residual).  weight is [K,Cin,Cout] fp32."""
     lib = _lib.load()
     assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
@@ -179,8 +180,22 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
         out = torch.empty((M_out, Cout), dtype=torch.float32, device=feats.device)
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == (M_out, Cout)
+    wp = pack_weights(weight)
+    if events is not None:  # (start, stop) torch.cuda.Event pair recorded around the launch in native code
+        from ctypes import c_void_p
+
+        for e in events:
+            if not e.cuda_event:
+                e.record()  # materialise the hipEvent_t handle
+        check(
+            lib.gf_conv_fwd_timed(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
+                                  ptr(in_shift), ptr(residual), ptr(out), c_void_p(events[0].cuda_event),
+                                  c_void_p(events[1].cuda_event), stream_ptr()),
+            "gf_conv_fwd_timed",
+        )
+        return out
     check(
-        lib.gf_conv_fwd(ptr(feats), ptr(pack_weights(weight)), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
+        lib.gf_conv_fwd(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
                         ptr(in_shift), ptr(residual), ptr(out), stream_ptr()),
         "gf_conv_fwd",
     )

@@ -99,6 +99,12 @@ int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint
                 int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, float* out,
                 void* stream);
 
+/* gf_conv_fwd with two caller-owned hipEvent_t recorded immediately before/after the launch on `stream`
+ * (profiling aid used by bench.py's roofline probe). */
+int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_out,
+                      int ld, int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual,
+                      float* out, void* ev_start, void* ev_stop, void* stream);
+
 /* Weight gradient of the same operator: dW[k] = sum_o in[nbr[k][o],:]^T dOut[o,:]  (dW fp32
  * [K,Cin,Cout], zeroed by the call).  The input gradient needs no entry point of its own: it is
  * gf_conv_fwd over the transposed table with per-offset transposed weights

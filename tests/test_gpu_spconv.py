@@ -122,3 +122,49 @@ def test_down_up_conv_parity(hip, oracle):
     u = sparse.conv_fwd(d, _dev(Wu), r.up, r.gmask_up, 8, M, r.ld_up)
     assert np.abs(d.cpu().numpy() - ref_d).max() < 1e-4
     assert np.abs(u.cpu().numpy() - ref_u).max() < 1e-4
+
+
+def test_spconv_modules_forward_backward(hip, oracle):
+    """The drop-in spconv modules with autograd: subm -> down -> subm -> inverse, gradients of the input
+    features and of every weight against the oracle's dgrad/wgrad restatement."""
+    from geoformer_amd import spconv
+
+    rng = np.random.default_rng(21)
+    shape, B, C0, C1 = (37, 33, 30), 2, 16, 32
+    coords = random_voxels(rng, 3000, shape, B, surface=True)
+    M = coords.shape[0]
+    feats = rng.standard_normal((M, C0)).astype(np.float32)
+    mods = [spconv.SubMConv3d(C0, C0, 3, padding=1, bias=False, indice_key="subm1"),
+            spconv.SparseConv3d(C0, C1, kernel_size=2, stride=2, bias=False, indice_key="spconv1"),
+            spconv.SubMConv3d(C1, C1, 3, padding=1, bias=False, indice_key="subm2"),
+            spconv.SparseInverseConv3d(C1, C0, kernel_size=2, bias=False, indice_key="spconv1")]
+    for m in mods:
+        m.cuda()
+    x = torch.from_numpy(feats).cuda().requires_grad_()
+    t = spconv.SparseConvTensor(x, _dev(coords), shape, B)
+    for m in mods:
+        t = m(t)
+    gout = rng.standard_normal((M, C0)).astype(np.float32)
+    t.features.backward(_dev(gout))
+
+    W = [m.weight.detach().cpu().numpy().reshape(-1, m.in_channels, m.out_channels) for m in mods]
+    nbr1 = oracle.rules_subm3(coords, shape)
+    oc, child, parent, koff = oracle.rules_down2(coords, shape)
+    up = oracle.up_table(parent, koff)
+    nbr2 = oracle.rules_subm3(oc, tuple((s - 2) // 2 + 1 for s in shape))
+    y1 = oracle.conv_fwd(feats, W[0], nbr1, M)
+    y2 = oracle.conv_fwd(y1, W[1], child, oc.shape[0])
+    y3 = oracle.conv_fwd(y2, W[2], nbr2, oc.shape[0])
+    y4 = oracle.conv_fwd(y3, W[3], up, M)
+    assert np.abs(t.features.detach().cpu().numpy() - y4).max() < 1e-4
+    g3 = oracle.conv_dgrad(gout, W[3], up, oc.shape[0])
+    g2 = oracle.conv_dgrad(g3, W[2], nbr2, oc.shape[0])
+    g1 = oracle.conv_dgrad(g2, W[1], child, M)
+    g0 = oracle.conv_dgrad(g1, W[0], nbr1, M)
+    scale = max(1.0, float(np.abs(g0).max()))
+    assert np.abs(x.grad.cpu().numpy() - g0).max() < 1e-4 * scale
+    dWs = [oracle.conv_wgrad(feats, g1, nbr1, 27), oracle.conv_wgrad(y1, g2, child, 8),
+           oracle.conv_wgrad(y2, g3, nbr2, 27), oracle.conv_wgrad(y3, gout, up, 8)]
+    for m, dW in zip(mods, dWs):
+        got = m.weight.grad.cpu().numpy().reshape(dW.shape)
+        assert np.abs(got - dW).max() < 2e-4 * max(1.0, float(np.abs(dW).max()))
