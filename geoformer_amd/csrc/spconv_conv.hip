@@ -280,8 +280,7 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
                            int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
                            const float* residual, float* out, void* stream) {
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_fwd: K=%d out of range [1,32]", K);
-    GF_CHECK_ARG(Cin >= 1 && Cout >= 1 && Cout <= 128, "gf_conv_fwd: Cin=%d Cout=%d unsupported (Cout<=128)", Cin,
-                 Cout);
+    GF_CHECK_ARG(Cin >= 1 && Cout >= 1, "gf_conv_fwd: Cin=%d Cout=%d", Cin, Cout);
     GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_fwd: nbr==NULL requires K==1");
     GF_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gf_conv_fwd: in_scale/in_shift must come together");
     if (M_out <= 0) return GF_OK;
@@ -293,7 +292,7 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     // to fill 1024 SIMDs with several waves each): a workgroup per (group, <=2 column blocks), steps split
     // over its four waves.
     const bool split = ngroups < 6000;
-    const int ncbw = split ? (ncb >= 2 && ngroups >= 2048 ? 2 : 1) : ncb;
+    const int ncbw = split ? (ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
     const int nsplit = (ncb + ncbw - 1) / ncbw;
     const long long nitems = (long long)ngroups * nsplit;
     long long blocks = split ? nitems : (nitems + 3) / 4;

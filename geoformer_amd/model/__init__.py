@@ -1,3 +1,4 @@
 """The build's ``model/geoformer`` counterpart (same class names and forward() signatures)."""
 from .config import cfg, load_config, set_config  # noqa: F401
 from .geoformer import GeoFormer, cal_geodesic, get_batch_offsets  # noqa: F401
+from .criterion import InstSetCriterion  # noqa: F401,E402

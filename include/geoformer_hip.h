@@ -94,7 +94,7 @@ int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, vo
  *   in_scale/in_shift  optional fp32 [Cin]: act(x) = max(x*scale + shift, 0) fused on the
  *                      gathered rows (eval-mode BatchNorm1d + ReLU, geoformer_modules.py:19-26)
  *   residual           optional fp32 [M_out,Cout] added in the epilogue (geoformer_modules.py:33)
- *   Cout <= 128. */
+ */
 int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_out, int ld,
                 int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, float* out,
                 void* stream);

@@ -59,7 +59,7 @@ def test_down_rules_bit_exact(hip, oracle, M, shape, B):
     assert (nxt.nbr.cpu().numpy() == oracle.rules_subm3(oc, r.out_shape)).all()
 
 
-@pytest.mark.parametrize("Cin,Cout", [(6, 16), (16, 16), (32, 16), (32, 32), (48, 64), (112, 112), (19, 21)])
+@pytest.mark.parametrize("Cin,Cout", [(6, 16), (16, 16), (32, 16), (32, 32), (48, 64), (112, 112), (19, 21), (80, 160)])
 def test_subm_conv_parity(hip, oracle, Cin, Cout):
     from geoformer_amd import sparse
 

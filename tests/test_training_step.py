@@ -1,0 +1,81 @@
+"""Training step (BASELINE config 3 shape: rulebook + forward + criterion + backward + Adam).
+
+CPU: the build's model/criterion through the oracle-backed operators (host logic, autograd plumbing).
+GPU: the same step through the HIP forward/backward kernels; loss and per-module gradient norms must agree
+with the CPU/oracle run (dropout 0 as SURVEY.md section 7 prescribes for training parity)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _setup(device):
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormer, InstSetCriterion, load_config
+    from tests.util import synthetic_state_dict
+
+    cfg = load_config("geoformer_scannet.yaml", batch_size=2, dec_dropout=0.0, n_decode_point=128, n_query_points=16,
+                      prepare_epochs=1)
+    torch.manual_seed(0)
+    m = GeoFormer(cfg)
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 1))
+    for mod in m.modules():  # backbone-transformer dropouts off as well
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.to(device)
+    m.train()
+    batch = scene.make_batch([scene.make_small_scene(2500, 31), scene.make_small_scene(2000, 32)])
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    return cfg, m, InstSetCriterion(cfg), batch
+
+
+def _step(m, crit, batch, epoch):
+    np.random.seed(3)
+    out = m(batch, epoch)
+    loss, info = crit(out, batch, epoch)
+    m.zero_grad()
+    loss.backward()
+    norms = {n: float(p.grad.norm()) for n, p in m.named_parameters() if p.grad is not None}
+    return float(loss), info, norms
+
+
+def _summ(norms):
+    groups = {}
+    for n, v in norms.items():
+        groups.setdefault(n.split(".")[0], 0.0)
+        groups[n.split(".")[0]] += v * v
+    return {k: v ** 0.5 for k, v in groups.items()}
+
+
+def test_training_step_cpu_oracle_backend(oracle):
+    from oracle import cpu_backend
+
+    with cpu_backend.installed():
+        cfg, m, crit, batch = _setup("cpu")
+        loss0, info0, n0 = _step(m, crit, batch, 1)  # epoch <= prepare_epochs: backbone + semantic head only
+        assert np.isfinite(loss0) and set(info0) == {"sem_loss", "loss"}
+        assert any(k.startswith("unet") for k in n0) and not any(k.startswith("decoder") for k in n0)
+        loss1, info1, n1 = _step(m, crit, batch, 5)
+        assert np.isfinite(loss1) and {"focal_loss", "dice_loss", "cls_loss"} <= set(info1)
+        g = _summ(n1)
+        for k in ("unet", "input_conv", "set_aggregator", "decoder", "controller", "mask_tower"):
+            assert g[k] > 0 and np.isfinite(g[k]), k
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        opt.step()
+        loss2, _, _ = _step(m, crit, batch, 5)
+        assert np.isfinite(loss2)
+
+
+@pytest.mark.gpu
+def test_training_step_gpu_matches_oracle_backend(hip, oracle):
+    from oracle import cpu_backend
+
+    with cpu_backend.installed():
+        cfg, m, crit, batch = _setup("cpu")
+        loss_c, _, n_c = _step(m, crit, batch, 5)
+    cfg, mg, critg, batchg = _setup("cuda")
+    loss_g, _, n_g = _step(mg, critg, batchg, 5)
+    assert abs(loss_g - loss_c) < 1e-3 * max(1.0, abs(loss_c))
+    gc, gg = _summ(n_c), _summ(n_g)
+    for k in gc:
+        assert abs(gg[k] - gc[k]) <= 2e-3 * max(gc[k], 1e-3), (k, gc[k], gg[k])
+    torch.optim.Adam(mg.parameters(), lr=1e-3).step()
