@@ -121,16 +121,18 @@ class GeoFormer(nn.Module):
 
         self.apply(self.set_bn_init)
         for name in self.fix_module:
-            for p in getattr(self, name).parameters():
-                p.requires_grad = False
+            if hasattr(self, name):  # subclasses add modules and repeat the freeze
+                for p in getattr(self, name).parameters():
+                    p.requires_grad = False
 
     # -- reference quirks kept on purpose -----------------------------------------------------
     def train(self, mode=True):
         """Frozen sub-modules stay in eval mode; returns None like the reference (geoformer.py:179-184)."""
         super().train(mode)
         for name in self.fix_module:
-            for mod in getattr(self, name).modules():
-                mod.eval()
+            if hasattr(self, name):
+                for mod in getattr(self, name).modules():
+                    mod.eval()
 
     @staticmethod
     def set_bn_init(mod):

@@ -1,0 +1,203 @@
+"""GeoFormerFS (few-shot) on MI355X: counterpart of ``model/geoformer/geoformer_fs.py:21-793``.
+
+Same pipeline as GeoFormer plus the support branch: ``process_support`` (backbone under no_grad ->
+masked points -> FPS to 32 -> SA-MLP with average pooling -> mean embedding, :377-422), the
+support (x) query fusion ``cat(ctx*s, ctx-s, ctx)`` (:532-538), ``similarity_net`` (:151-159,572) and the
+result cache ``remember`` (:439-455,508-523).  Differences from GeoFormer kept on purpose: ``pc_dims`` is
+[mins, maxs] (:434-437), the aggregator does not subsample (:619-660), there is no per-query class head,
+proposals are scored by mask score * sqrt(similarity) (:191-239).  The reference evaluates the decoder
+and mask head under ``autocast`` (fp16 on a GPU); this build evaluates them in fp32 (its fused kernels are
+fp32), i.e. with strictly more precision.
+"""
+from __future__ import annotations
+
+import functools
+
+import torch
+import torch.nn as nn
+
+from . import config as _config
+from .backbone import random_downsample
+from .geoformer import GeoFormer, cal_geodesic, get_batch_offsets
+from .layers import GenericMLP
+
+
+class GeoFormerFS(GeoFormer):
+    def __init__(self, cfg=None):
+        cfg = cfg if cfg is not None else _config.cfg
+        super().__init__(cfg)
+        m = cfg.m
+        agg = 2 * m
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        del self.detr_sem_head
+        self.encoder_to_decoder_projection = GenericMLP(
+            input_dim=agg * 3, hidden_dims=[agg * 3], output_dim=cfg.dec_dim, norm_fn_name="bn1d", activation="relu",
+            use_conv=True, output_use_activation=True, output_use_norm=True, output_use_bias=False)
+        self.similarity_net = nn.Sequential(
+            nn.Linear(3 * agg, 3 * agg, bias=True), norm_fn(3 * agg), nn.ReLU(),
+            nn.Linear(3 * agg, 3 * agg, bias=True), norm_fn(3 * agg), nn.ReLU(),
+            nn.Linear(3 * agg, 1, bias=True))
+        self.apply(self.set_bn_init)
+        for name in self.fix_module:
+            for p in getattr(self, name).parameters():
+                p.requires_grad = False
+        self.cache_data = None
+
+    # -- support branch ---------------------------------------------------------------------------
+    def process_support(self, batch_input, training=True):
+        batch_idxs = batch_input["locs"][:, 0].int()
+        locs_float = batch_input["locs_float"]
+        batch_size = len(batch_input["batch_offsets"]) - 1
+        assert batch_size > 0
+        with torch.no_grad():
+            x = self.preprocess_input(batch_input, batch_size)
+            x = self.output_layer(self.unet(self.input_conv(x)))
+            output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
+            mask_indices = torch.nonzero(batch_input["support_masks"] == 1).view(-1)
+            feats_, locs_ = output_feats[mask_indices], locs_float[mask_indices]
+            offs = get_batch_offsets(batch_idxs[mask_indices], batch_size).tolist()
+            embs = []
+            for b in range(batch_size):
+                xyz_b = locs_[offs[b]:offs[b + 1]].unsqueeze(0)
+                f_b = feats_[offs[b]:offs[b + 1]].unsqueeze(0)
+                _, gfeat, gxyz, _ = self.set_aggregator.group_points(xyz_b.contiguous(),
+                                                                      f_b.transpose(1, 2).contiguous(), npoint_new=32)
+                ctx = self.set_aggregator.mlp(gfeat, gxyz, pooling="avg").transpose(1, 2)  # 1 x 32 x C
+                embs.append(torch.mean(ctx, dim=1))
+            return torch.cat(embs)  # batch x channel
+
+    # -- overrides ----------------------------------------------------------------------------------
+    def forward_backbone(self, batch_input, batch_size):
+        ctx = torch.enable_grad if self.training and "unet" not in self.fix_module else torch.no_grad
+        with ctx():
+            x = self.preprocess_input(batch_input, batch_size)
+            x = self.output_layer(self.unet(self.input_conv(x)))
+            output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
+            semantic_scores = self.semantic_linear(self.semantic(output_feats))
+            return output_feats, semantic_scores, semantic_scores.max(1)[1]
+
+    def forward_aggregator(self, locs_float_, output_feats_, batch_offsets_, batch_size):
+        ctx = torch.enable_grad if self.training and "set_aggregator" not in self.fix_module else torch.no_grad
+        offs = batch_offsets_.tolist()
+        with ctx():
+            locs, gfeat, gxyz, inds = [], [], [], []
+            for b in range(batch_size):
+                if offs[b + 1] - offs[b] == 0:
+                    return None
+                xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0)
+                f_b = output_feats_[offs[b]:offs[b + 1]].unsqueeze(0)
+                l, gf, gx, idx = self.set_aggregator.group_points(xyz_b.contiguous(), f_b.transpose(1, 2).contiguous())
+                locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
+            context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
+            return torch.cat(locs), context_feats, torch.cat(inds)
+
+    def get_mask_prediction(self, geo_dists, param_kernels, mask_features, locs_float_, fps_sampling_locs,
+                            batch_offsets_):
+        num_layers, n_queries, batch = param_kernels.shape[:3]
+        offs = batch_offsets_.tolist()
+        outputs = []
+        for l in range(num_layers):
+            pk2 = param_kernels[l].transpose(0, 1).flatten(0, 1)
+            controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
+            controllers = controllers.reshape(batch, n_queries, -1)
+            mask_logits_list = []
+            for b in range(batch):
+                s, e = offs[b], offs[b + 1]
+                if e - s == 0:
+                    mask_logits_list.append(None)
+                    continue
+                weights, biases = self.parse_dynamic_params(controllers[b], self.output_dim)
+                ml = self.mask_heads_forward(geo_dists[b], mask_features[s:e], weights, biases, n_queries,
+                                             locs_float_[s:e], fps_sampling_locs[b], use_geo=True)
+                mask_logits_list.append(ml.float().squeeze(0))
+            outputs.append({"mask_logits": mask_logits_list})
+        return outputs
+
+    def generate_proposal(self, mask_logits, similarity_score, fg_idxs, batch_offsets, logit_thresh=0.5,
+                          score_thresh=0.5, npoint_thresh=100, sim_score_thresh=0.5):
+        b = 0
+        num_points = int(batch_offsets[b + 1] - batch_offsets[b])
+        prob = mask_logits[b].sigmoid()
+        sim = similarity_score[b]
+        mask_bool = prob >= logit_thresh
+        npts = torch.sum(mask_bool, dim=1)
+        mask_scores = torch.sum(prob * mask_bool.int(), dim=1) / (npts + 1e-6)
+        scores = mask_scores * torch.pow(sim, 0.5)
+        final = (sim >= sim_score_thresh) & (npts >= npoint_thresh) & (mask_scores >= score_thresh)
+        if torch.count_nonzero(final) == 0:
+            return [], []
+        masks_final = mask_bool[final]
+        proposals = torch.zeros((masks_final.shape[0], num_points), dtype=torch.int, device=prob.device)
+        inst, pts = torch.nonzero(masks_final, as_tuple=True)
+        proposals[inst, fg_idxs[pts]] = 1
+        return scores[final], proposals
+
+    def forward(self, support_dict, scene_dict, training=True, remember=False, support_embeddings=None):
+        cfg = self.cfg
+        outputs = {}
+        batch_idxs = scene_dict["locs"][:, 0].int()
+        locs_float = scene_dict["locs_float"]
+        batch_offsets = scene_dict["batch_offsets"]
+        batch_size = len(batch_offsets) - 1
+        assert batch_size > 0
+        pc_dims = [scene_dict["pc_mins"], scene_dict["pc_maxs"]]
+
+        if remember:
+            (context_locs, context_feats, pre_enc_inds, fg_idxs, batch_offsets, output_feats_, batch_idxs_, locs_float_,
+             batch_offsets_, semantic_preds_, semantic_scores, query_locs, mask_features_, geo_dists) = self.cache_data
+            outputs["semantic_scores"] = semantic_scores
+        else:
+            output_feats, semantic_scores, semantic_preds = self.forward_backbone(scene_dict, batch_size)
+            outputs["semantic_scores"] = semantic_scores
+            fg = semantic_preds >= 4 if cfg.train_fold == cfg.cvfold else semantic_preds == 3
+            fg_idxs = torch.nonzero(fg).view(-1)
+            batch_idxs_ = batch_idxs[fg_idxs]
+            batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size)
+            locs_float_, output_feats_ = locs_float[fg_idxs], output_feats[fg_idxs]
+            semantic_preds_ = semantic_preds[fg_idxs]
+            ctx = torch.enable_grad if self.training and "mask_tower" not in self.fix_module else torch.no_grad
+            with ctx():
+                mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
+            contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
+            if contexts is None:
+                outputs["mask_predictions"] = None
+                return outputs
+            context_locs, context_feats, pre_enc_inds = contexts
+            query_locs = context_locs[:, :cfg.n_query_points, :]
+            geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_,
+                                     max_step=128 if self.training else 256, neighbor=64, radius=0.05,
+                                     n_queries=cfg.n_query_points)
+            self.cache_data = (context_locs, context_feats, pre_enc_inds, fg_idxs, batch_offsets, output_feats_,
+                               batch_idxs_, locs_float_, batch_offsets_, semantic_preds_, semantic_scores, query_locs,
+                               mask_features_, geo_dists)
+
+        if len(fg_idxs) == 0:
+            outputs["proposal_scores"] = None
+            return outputs
+        if support_embeddings is None:
+            support_embeddings = self.process_support(support_dict, training)  # batch x channel
+
+        s = support_embeddings.unsqueeze(1).repeat(1, cfg.n_decode_point, 1)
+        aggregation = torch.cat([context_feats * s, context_feats - s, context_feats], dim=2)  # B x nc x 3C
+        dec_outputs = self.forward_decoder(context_locs, aggregation, query_locs, pc_dims, geo_dists, pre_enc_inds)
+        if not training:
+            dec_outputs = dec_outputs[-1:, ...]
+        else:
+            idxs_sub, idxs_sub_raw = random_downsample(batch_offsets_, batch_size, n_subsample=30000)
+            geo_dists = [geo_dists[b][:, idxs_sub_raw[b]] for b in range(batch_size)]
+            fg_idxs = fg_idxs[idxs_sub]
+            mask_features_, locs_float_, batch_idxs_ = mask_features_[idxs_sub], locs_float_[idxs_sub], batch_idxs_[idxs_sub]
+            batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size)
+        mask_predictions = self.get_mask_prediction(geo_dists, dec_outputs, mask_features_, locs_float_, query_locs,
+                                                    batch_offsets_)
+        similarity = self.similarity_net(aggregation[:, :cfg.n_query_points, :].flatten(0, 1)).squeeze(-1)
+        similarity = similarity.reshape(batch_size, cfg.n_query_points)
+        if training:
+            outputs.update(fg_idxs=fg_idxs, num_insts=cfg.n_query_points * batch_size, batch_idxs=batch_idxs_,
+                           simnet=similarity, mask_predictions=mask_predictions)
+            return outputs
+        outputs["proposal_scores"] = self.generate_proposal(
+            mask_predictions[-1]["mask_logits"], similarity.detach().sigmoid(), fg_idxs, batch_offsets,
+            logit_thresh=0.2, score_thresh=cfg.TEST_SCORE_THRESH, npoint_thresh=cfg.TEST_NPOINT_THRESH,
+            sim_score_thresh=cfg.similarity_thresh)
+        return outputs

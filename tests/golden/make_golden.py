@@ -18,8 +18,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
-_WHICH = [a for a in sys.argv[1:] if a in ("geodesic", "decoder", "model")]
-sys.argv = ["make_golden", "--config", os.path.join(REF, "config/test_geoformer_scannet.yaml")]
+_WHICH = [a for a in sys.argv[1:] if a in ("geodesic", "decoder", "model", "fs")]
+_YAML = "config/test_geoformer_fs_scannet.yaml" if _WHICH == ["fs"] else "config/test_geoformer_scannet.yaml"
+sys.argv = ["make_golden", "--config", os.path.join(REF, _YAML)]  # util/config.py parses argv at import: one yaml per process
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -29,7 +30,10 @@ from tests.golden import ref_shims  # noqa: E402
 ref_shims.install(REF)
 os.chdir(REF)  # util/config.py and friends use relative paths
 
-from model.geoformer.geoformer import GeoFormer  # noqa: E402  (reference class)
+if _WHICH == ["fs"]:
+    from model.geoformer.geoformer_fs import GeoFormerFS  # noqa: E402  (reference class)
+else:
+    from model.geoformer.geoformer import GeoFormer  # noqa: E402  (reference class)
 from model.geoformer import geodesic_utils  # noqa: E402
 from model.transformer_detr import TransformerDecoderLayer  # noqa: E402
 from model.pos_embedding import PositionEmbeddingCoordsSine  # noqa: E402
@@ -140,8 +144,60 @@ def golden_decoder_layer():
     print("decoder golden ok", out.abs().mean().item())
 
 
+def fs_dicts():
+    """Query scene + one full support scene with one labelled cuboid as support mask."""
+    q = scene.make_batch([scene.make_small_scene(8192, 7)])
+    sup_sc = scene.make_small_scene(6000, 8)
+    sup = scene.make_batch([sup_sc])
+    for d in (q, sup):
+        d["batch_offsets"] = d["offsets"]
+    sup["support_masks"] = (sup["instance_labels"] >= 0).long()
+    return sup, q
+
+
+def golden_fs():
+    torch.manual_seed(0)
+    m = GeoFormerFS()
+    sd = m.state_dict()
+    json.dump({k: list(v.shape) for k, v in sd.items()},
+              open(os.path.join(HERE, "geoformer_fs_state_dict_keys.json"), "w"), indent=0)
+    m.load_state_dict(synthetic_state_dict(sd, 2))
+    m.semantic_linear.bias.data[3] += 1.5  # random head: lift class 3 (the test-fold foreground, geoformer_fs.py:466-469)
+    m.eval()
+    sup, q = fs_dicts()
+    cap = {}
+    orig_gmp = m.get_mask_prediction
+
+    def gmp(*a, **k):
+        r = orig_gmp(*a, **k)
+        cap.setdefault("mask_logits", []).append(r[-1]["mask_logits"][0].detach().numpy().copy())
+        return r
+
+    m.get_mask_prediction = gmp
+    orig_sim = m.similarity_net.forward
+    with torch.no_grad():
+        emb = m.process_support(sup, training=False)
+        out = m(sup, q, training=False, remember=False, support_embeddings=None)
+        out2 = m(sup, q, training=False, remember=True, support_embeddings=emb * 0.5)  # cached query side
+    ctx = m.cache_data
+    ml = None
+    scores, props = out["proposal_scores"]
+    scores2, props2 = out2["proposal_scores"]
+    np.savez_compressed(
+        os.path.join(HERE, "geoformer_fs_s8k_eval.npz"), weight_seed=2, semantic_bias3_shift=1.5,
+        mask_logits_sub=sub(cap["mask_logits"][0]), mask_logits_half_sub=sub(cap["mask_logits"][1]),
+        support_embeddings=emb.numpy(), semantic_scores=out["semantic_scores"].numpy(), fg_idxs=ctx[3].numpy(),
+        pre_enc_inds=ctx[2].numpy(), context_feats=ctx[1].numpy(),
+        proposal_scores=np.asarray(scores), proposal_npoints=np.asarray(props).sum(1) if len(scores) else np.zeros(0),
+        proposal_scores_half=np.asarray(scores2),
+        proposal_npoints_half=np.asarray(props2).sum(1) if len(scores2) else np.zeros(0))
+    print("fs golden: N_fg", ctx[3].shape[0], "proposals", len(scores), len(scores2), "emb", emb.shape)
+
+
 if __name__ == "__main__":
     which = _WHICH or ["geodesic", "decoder", "model"]
+    if "fs" in which:
+        golden_fs()
     if "geodesic" in which:
         golden_geodesic()
     if "decoder" in which:

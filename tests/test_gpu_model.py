@@ -103,3 +103,10 @@ def test_output_schema(run):
     assert set(out) == {"semantic_scores", "fg_idxs", "num_insts", "batch_idxs", "mask_predictions",
                         "proposal_scores"}  # geoformer.py:402-528
     assert out["num_insts"] == 256
+
+
+def test_geoformer_fs_episode_gpu(hip):
+    """Few-shot episode (BASELINE config 4 shape, 1-shot) through the HIP operators vs the reference golden."""
+    from tests.util import check_fs_episode, run_fs_episode
+
+    check_fs_episode(*run_fs_episode("cuda"))

@@ -40,3 +40,22 @@ def test_geoformer_forward_cpu_matches_reference_golden(oracle):
         m.semantic_linear.bias.data[:4] += 1e4  # nothing is predicted as an object class
         empty = m(batch, 300, training=False)
     assert empty["mask_predictions"] is None
+
+
+def test_geoformer_fs_state_dict_and_episode_cpu(oracle):
+    """GeoFormerFS: parameter names/shapes and a 1-shot episode (support branch, fusion, similarity net,
+    `remember` cache) against the reference's GeoFormerFS run on CPU."""
+    import json
+
+    from geoformer_amd.model import GeoFormerFS, load_config
+    from oracle import cpu_backend
+    from tests.util import check_fs_episode, run_fs_episode
+
+    ref = json.load(open(os.path.join(G, "geoformer_fs_state_dict_keys.json")))
+    m = GeoFormerFS(load_config("geoformer_fs_scannet.yaml"))
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref or (set(mine) == set(ref) and all(mine[k] == ref[k] for k in ref))
+    assert sum(p.numel() for p in m.parameters()) == 8142687
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 42706  # SURVEY.md section 2 row 2
+    with cpu_backend.installed():
+        check_fs_episode(*run_fs_episode("cpu"))

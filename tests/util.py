@@ -58,3 +58,65 @@ def synthetic_state_dict(ref_sd, seed=0):
             v = rng.normal(0, 1.0 / np.sqrt(max(fan_in, 1)), shape)
         out[name] = torch.from_numpy(np.asarray(v)).to(t.dtype)
     return out
+
+
+def fs_dicts():
+    """Few-shot episode inputs used by the FS golden: query scene + one full support scene whose labelled
+    cuboid is the support mask.  Same construction as tests/golden/make_golden.py."""
+    from geoformer_amd import scene
+
+    q = scene.make_batch([scene.make_small_scene(8192, 7)])
+    sup = scene.make_batch([scene.make_small_scene(6000, 8)])
+    for d in (q, sup):
+        d["batch_offsets"] = d["offsets"]
+    sup["support_masks"] = (sup["instance_labels"] >= 0).long()
+    return sup, q
+
+
+def run_fs_episode(device):
+    """Build GeoFormerFS with the golden's weights and run: process_support, a fresh forward, a cached forward."""
+    import os
+
+    import torch
+    from geoformer_amd.model import GeoFormerFS, load_config
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geoformer_fs_s8k_eval.npz"))
+    m = GeoFormerFS(load_config("test_geoformer_fs_scannet.yaml"))
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), int(z["weight_seed"])))
+    m.semantic_linear.bias.data[3] += float(z["semantic_bias3_shift"])
+    m.to(device)
+    m.eval()
+    sup, q = fs_dicts()
+    mv = lambda d: {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}  # noqa: E731
+    sup, q = mv(sup), mv(q)
+    cap = []
+    orig = m.get_mask_prediction
+
+    def gmp(*a, **k):
+        r = orig(*a, **k)
+        cap.append(r[-1]["mask_logits"][0].detach().cpu().numpy())
+        return r
+
+    m.get_mask_prediction = gmp
+    with torch.no_grad():
+        emb = m.process_support(sup, training=False)
+        out = m(sup, q, training=False, remember=False, support_embeddings=None)
+        out2 = m(sup, q, training=False, remember=True, support_embeddings=emb * 0.5)
+    return z, m, emb, out, out2, cap
+
+
+def check_fs_episode(z, m, emb, out, out2, cap):
+    c = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    assert np.abs(c(emb) - z["support_embeddings"]).max() < 1e-4
+    assert np.abs(c(out["semantic_scores"]) - z["semantic_scores"]).max() < 1e-4
+    assert (c(m.cache_data[3]) == z["fg_idxs"]).all()
+    assert (c(m.cache_data[2]) == z["pre_enc_inds"]).all()  # FPS over ALL foreground points (no subsampling)
+    assert np.abs(c(m.cache_data[1]) - z["context_feats"]).max() < 1e-4
+    assert np.abs(cap[0][::8, ::4] - z["mask_logits_sub"]).max() < 1e-4
+    assert np.abs(cap[1][::8, ::4] - z["mask_logits_half_sub"]).max() < 1e-4
+    for o, ks, kn in ((out, "proposal_scores", "proposal_npoints"), (out2, "proposal_scores_half", "proposal_npoints_half")):
+        scores, props = o["proposal_scores"]
+        assert len(scores) == len(z[ks])
+        if len(scores):
+            assert np.abs(c(scores) - z[ks]).max() < 1e-4
+            assert np.abs(c(props.sum(1)) - z[kn]).max() <= 3
