@@ -51,6 +51,16 @@ def _declare(lib):
         "gf_decoder_wpack_floats": (c_size_t, []),
         "gf_decoder_pack_weights": (I, [P, P, P, P, P]),
         "gf_decoder_cross_attn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+        "gf_sec_op": (I, [I, P, P, I, I, P, P]),
+        "gf_roipool_fp": (I, [P, P, I, I, P, P, P]),
+        "gf_roipool_bp": (I, [P, P, I, I, P, P]),
+        "gf_get_iou": (I, [P, P, P, P, I, I, P, P]),
+        "gf_ballquery_batch_p_scratch_bytes": (c_size_t, [I]),
+        "gf_ballquery_batch_p": (I, [P, P, P, I, I, F, P, P, P, P, P]),
+        "gf_bfs_cluster_host": (I, [P, P, P, I, I, P, P, P, P]),
+        "gf_three_nn": (I, [P, P, I, I, I, P, P, P]),
+        "gf_three_interpolate": (I, [P, P, P, I, I, I, I, P, P]),
+        "gf_three_interpolate_grad": (I, [P, P, P, I, I, I, I, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -490,3 +490,78 @@ extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* 
     GF_CHECK_LAUNCH("gf_geodesic_bfs");
     return GF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// ballquery_batch_p (lib/pointgroup_ops/src/bfs_cluster/bfs_cluster.cu:15-89): per point, the indices of the
+// points of its own batch segment with d2 < r^2 (at most 1000, ascending), packed CSR-like into idx with
+// (start, len) per point; entries beyond n*meanActive are dropped and the caller retries with a larger
+// buffer (pointgroup_ops.py:136-143).  The reference hands out `start` with an atomic cursor (arbitrary
+// order); here a count pass + exclusive scan gives starts in point order -- a canonical instance of it.
+// ------------------------------------------------------------------------------------
+__global__ void k_bqb_count(const float* __restrict__ xyz, const int32_t* __restrict__ batch_idxs,
+                            const int32_t* __restrict__ batch_offsets, int n, float radius2, int32_t* __restrict__ cnt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ox = xyz[i * 3 + 0], oy = xyz[i * 3 + 1], oz = xyz[i * 3 + 2];
+    const int b = batch_idxs[i];
+    int c = 0;
+    for (int k = batch_offsets[b]; k < batch_offsets[b + 1]; k++) {
+        const float dx = ox - xyz[k * 3 + 0], dy = oy - xyz[k * 3 + 1], dz = oz - xyz[k * 3 + 2];
+        if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < radius2) {
+            if (c >= 1000) break;
+            c++;
+        }
+    }
+    cnt[i] = c;
+}
+__global__ void k_bqb_fill(const float* __restrict__ xyz, const int32_t* __restrict__ batch_idxs,
+                           const int32_t* __restrict__ batch_offsets, int n, float radius2,
+                           const int32_t* __restrict__ start, const int32_t* __restrict__ cnt, long long thre,
+                           int32_t* __restrict__ idx, int32_t* __restrict__ start_len) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = start[i];
+    int c = cnt[i];
+    start_len[i * 2 + 0] = s;
+    start_len[i * 2 + 1] = c;
+    if (s >= thre) return;
+    if ((long long)s + c >= thre) c = (int)(thre - s);
+    const float ox = xyz[i * 3 + 0], oy = xyz[i * 3 + 1], oz = xyz[i * 3 + 2];
+    const int b = batch_idxs[i];
+    int w = 0;
+    for (int k = batch_offsets[b]; k < batch_offsets[b + 1] && w < c; k++) {
+        const float dx = ox - xyz[k * 3 + 0], dy = oy - xyz[k * 3 + 1], dz = oz - xyz[k * 3 + 2];
+        if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < radius2) idx[s + w++] = k;
+    }
+}
+extern "C" size_t gf_ballquery_batch_p_scratch_bytes(int n) {
+    const size_t nb = ((size_t)n + ISCAN_IPB - 1) / ISCAN_IPB;
+    return (2 * (size_t)n + 4 + 2 * nb + 16) * sizeof(int32_t);
+}
+// d_cumsum (device int32) receives the total number of (point, neighbour) pairs (the reference's return value)
+extern "C" int gf_ballquery_batch_p(const float* xyz, const int32_t* batch_idxs, const int32_t* batch_offsets, int n,
+                                    int meanActive, float radius, int32_t* idx, int32_t* start_len, int32_t* d_cumsum,
+                                    void* scratch, void* stream) {
+    GF_CHECK_ARG(n >= 0 && meanActive >= 1, "gf_ballquery_batch_p: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        hipMemsetAsync(d_cumsum, 0, sizeof(int32_t), st);
+        return GF_OK;
+    }
+    const int nb = (n + ISCAN_IPB - 1) / ISCAN_IPB;
+    int32_t* cnt = (int32_t*)scratch;
+    int32_t* start = cnt + n;          // n + 1 entries
+    int32_t* block_sums = start + n + 2;
+    int32_t* block_off = block_sums + nb;
+    const float r2 = radius * radius;
+    hipLaunchKernelGGL(k_bqb_count, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, batch_idxs, batch_offsets, n, r2, cnt);
+    hipLaunchKernelGGL(k_iscan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, cnt, n, block_sums);
+    hipLaunchKernelGGL(k_iscan_top, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, block_off);
+    // start[] and a throw-away cursor copy (idx is large enough to take it: it is overwritten by the fill)
+    hipLaunchKernelGGL(k_iscan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, cnt, n, block_off, start, start_len);
+    hipMemcpyAsync(d_cumsum, start + n, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(k_bqb_fill, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, batch_idxs, batch_offsets, n, r2,
+                       start, cnt, (long long)n * meanActive, idx, start_len);
+    GF_CHECK_LAUNCH("gf_ballquery_batch_p");
+    return GF_OK;
+}

@@ -10,8 +10,8 @@
 Same function names, argument order and in-place/return conventions as the pybind modules, so
 ``lib/pointgroup_ops/functions/pointgroup_ops.py`` and ``lib/pointnet2/pointnet2_utils.py`` work on top
 unchanged.  Bad inputs raise ``RuntimeError`` (the reference's natives ``assert``/``exit(-1)``).
-Operators GeoFormer never executes raise ``NotImplementedError`` naming the
-reference kernel they stand for.
+Operators GeoFormer never executes (sec_*, roipool, get_iou, ballquery_batch_p,
+bfs_cluster, three_nn / three_interpolate) are bound as well, with the native argument orders.
 """
 from __future__ import annotations
 
@@ -61,6 +61,102 @@ def point_recover_fp(feats, output_feats, idx_map, nActive, maxActive, nPlane):
 
 def point_recover_bp(d_output_feats, d_feats, idx_map, nActive, maxActive, nPlane):
     pointops.voxelize_fp(d_output_feats, idx_map, 3, out=d_feats)
+
+
+def _lib_call(name, *args):
+    from . import _lib
+
+    _lib.check(getattr(_lib.load(), name)(*args), name)
+
+
+def _p(t):
+    from ._lib import ptr
+
+    return ptr(t)
+
+
+def _s():
+    from ._lib import stream_ptr
+
+    return stream_ptr()
+
+
+def sec_mean(inp, offsets, out, nProposal, C):
+    _lib_call("gf_sec_op", 0, _p(inp), _p(offsets), nProposal, C, _p(out), _s())
+
+
+def sec_min(inp, offsets, out, nProposal, C):
+    _lib_call("gf_sec_op", 1, _p(inp), _p(offsets), nProposal, C, _p(out), _s())
+
+
+def sec_max(inp, offsets, out, nProposal, C):
+    _lib_call("gf_sec_op", 2, _p(inp), _p(offsets), nProposal, C, _p(out), _s())
+
+
+def roipool_fp(feats, proposals_offset, output_feats, output_maxidx, nProposal, C):
+    _lib_call("gf_roipool_fp", _p(feats), _p(proposals_offset), nProposal, C, _p(output_feats), _p(output_maxidx), _s())
+
+
+def roipool_bp(d_feats, proposals_offset, output_maxidx, d_output_feats, nProposal, C):
+    _lib_call("gf_roipool_bp", _p(d_output_feats), _p(output_maxidx), nProposal, C, _p(d_feats), _s())
+
+
+def get_iou(proposals_idx, proposals_offset, instance_labels, instance_pointnum, proposals_iou, nInstance, nProposal):
+    _lib_call("gf_get_iou", _p(proposals_idx), _p(proposals_offset), _p(instance_labels), _p(instance_pointnum),
+              nInstance, nProposal, _p(proposals_iou), _s())
+
+
+def ballquery_batch_p(xyz, batch_idxs, batch_offsets, idx, start_len, n, meanActive, radius):
+    """Returns the total pair count like the native (one host sync, bfs_cluster.cu:88)."""
+    from . import _lib
+
+    lib = _lib.load()
+    scratch = torch.empty(lib.gf_ballquery_batch_p_scratch_bytes(n) // 4 + 4, dtype=torch.int32, device=xyz.device)
+    cum = torch.zeros(1, dtype=torch.int32, device=xyz.device)
+    _lib_call("gf_ballquery_batch_p", _p(xyz), _p(batch_idxs), _p(batch_offsets), n, meanActive, float(radius), _p(idx),
+              _p(start_len), _p(cum), _p(scratch), _s())
+    return int(cum.item())
+
+
+def bfs_cluster(semantic_label, ball_query_idxs, start_len, cluster_idxs, cluster_offsets, N, threshold):
+    """CPU tensors in, outputs resized (bfs_cluster.cpp:103-106)."""
+    import ctypes
+
+    if semantic_label.is_cuda or ball_query_idxs.is_cuda or start_len.is_cuda:
+        raise RuntimeError("bfs_cluster expects CPU tensors")
+    ci = torch.zeros((max(N, 1), 2), dtype=torch.int32)
+    co = torch.zeros(N + 1, dtype=torch.int32)
+    nc, sm = ctypes.c_int32(), ctypes.c_int32()
+    _lib_call("gf_bfs_cluster_host", _p(semantic_label.contiguous()), _p(ball_query_idxs.contiguous()),
+              _p(start_len.contiguous()), N, threshold, _p(ci), _p(co), ctypes.byref(nc), ctypes.byref(sm))
+    cluster_idxs.resize_((sm.value, 2)).copy_(ci[: sm.value])
+    cluster_offsets.resize_((nc.value + 1,)).copy_(co[: nc.value + 1])
+
+
+def three_nn(unknown, known):
+    _chk(unknown, torch.float32, "unknown"); _chk(known, torch.float32, "known")
+    b, n, _ = unknown.shape
+    dist2 = torch.zeros((b, n, 3), dtype=torch.float32, device=unknown.device)
+    idx = torch.zeros((b, n, 3), dtype=torch.int32, device=unknown.device)
+    _lib_call("gf_three_nn", _p(unknown), _p(known), b, n, known.shape[1], _p(dist2), _p(idx), _s())
+    return dist2, idx
+
+
+def three_interpolate(points, idx, weight):
+    _chk(points, torch.float32, "points"); _chk(idx, torch.int32, "idx"); _chk(weight, torch.float32, "weight")
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = torch.zeros((b, c, n), dtype=torch.float32, device=points.device)
+    _lib_call("gf_three_interpolate", _p(points), _p(idx), _p(weight), b, c, m, n, _p(out), _s())
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    _chk(grad_out, torch.float32, "grad_out"); _chk(idx, torch.int32, "idx"); _chk(weight, torch.float32, "weight")
+    b, c, n = grad_out.shape
+    out = torch.zeros((b, c, m), dtype=torch.float32, device=grad_out.device)
+    _lib_call("gf_three_interpolate_grad", _p(grad_out), _p(idx), _p(weight), b, c, n, m, _p(out), _s())
+    return out
 
 
 # ------------------------------------------------------------------------------------------
@@ -161,23 +257,16 @@ def install():
     sys.modules["spconv.modules"] = sp.modules
 
     pg = types.ModuleType("PG_OP")
-    for fn in (voxelize_idx, voxelize_fp, voxelize_bp, point_recover_fp, point_recover_bp):
+    for fn in (voxelize_idx, voxelize_fp, voxelize_bp, point_recover_fp, point_recover_bp, ballquery_batch_p,
+               bfs_cluster, roipool_fp, roipool_bp, get_iou, sec_mean, sec_min, sec_max):
         setattr(pg, fn.__name__, fn)
-    for name, where in (("ballquery_batch_p", "bfs_cluster.cu:15-89"), ("bfs_cluster", "bfs_cluster.cpp:28-111"),
-                        ("roipool_fp", "roipool.cu:12-39"), ("roipool_bp", "roipool.cu:42-57"),
-                        ("get_iou", "get_iou.cu:12-38"), ("sec_mean", "sec_mean.cu:12-34"),
-                        ("sec_min", "sec_mean.cu:38-60"), ("sec_max", "sec_mean.cu:64-86")):
-        setattr(pg, name, _dormant(name, where))
     sys.modules["PG_OP"] = pg
 
     p2 = types.ModuleType("pointnet2")
     ext = types.ModuleType("pointnet2._ext")
     for fn in (gather_points, gather_points_grad, furthest_point_sampling, ball_query, group_points,
-               group_points_grad):
+               group_points_grad, three_nn, three_interpolate, three_interpolate_grad):
         setattr(ext, fn.__name__, fn)
-    for name, where in (("three_nn", "interpolate_gpu.cu:12-71"), ("three_interpolate", "interpolate_gpu.cu:75-114"),
-                        ("three_interpolate_grad", "interpolate_gpu.cu:119-157")):
-        setattr(ext, name, _dormant(name, where))
     p2._ext = ext
     sys.modules["pointnet2"], sys.modules["pointnet2._ext"] = p2, ext
 

@@ -210,6 +210,36 @@ int gf_decoder_cross_attn(const float* geo_ctx, const float* max_geo, const floa
                           const float* Kv, const float* Wpack, const float* b2, int B, int nq, int nc, int d, float* out,
                           void* stream);
 
+/* ===================================================================================
+ * Natives GeoFormer inherits but never executes -- binding completeness
+ * =================================================================================== */
+
+/* PG_OP.sec_mean / sec_min / sec_max (sec_mean.cu:12-86): kind 0/1/2; offsets int32 [nProposal+1]; out [nProposal,C] */
+int gf_sec_op(int kind, const float* inp, const int32_t* offsets, int nProposal, int C, float* out, void* stream);
+/* PG_OP.roipool_fp/bp (roipool.cu:12-57): segment max + arg-max; bp adds d_out to d_feats[argmax] (caller zeroes) */
+int gf_roipool_fp(const float* feats, const int32_t* offsets, int nProposal, int C, float* out, int32_t* maxidx,
+                  void* stream);
+int gf_roipool_bp(const float* d_out, const int32_t* maxidx, int nProposal, int C, float* d_feats, void* stream);
+/* PG_OP.get_iou (get_iou.cu:12-38): iou [nProposal,nInstance]; instance_labels int64 [N] */
+int gf_get_iou(const int32_t* proposals_idx, const int32_t* proposals_offset, const long long* instance_labels,
+               const int32_t* instance_pointnum, int nInstance, int nProposal, float* iou, void* stream);
+/* PG_OP.ballquery_batch_p (bfs_cluster.cu:15-89): idx int32 [n*meanActive], start_len int32 [n,2], starts in point
+ * order; d_cumsum (device int32) = total pair count (the reference's return value). */
+size_t gf_ballquery_batch_p_scratch_bytes(int n);
+int gf_ballquery_batch_p(const float* xyz, const int32_t* batch_idxs, const int32_t* batch_offsets, int n, int meanActive,
+                         float radius, int32_t* idx, int32_t* start_len, int32_t* d_cumsum, void* scratch, void* stream);
+/* PG_OP.bfs_cluster (bfs_cluster.cpp:28-111): HOST pointers (the reference runs it on CPU tensors).
+ * h_cluster_idxs capacity [N,2], h_cluster_offsets capacity [N+1]. */
+int gf_bfs_cluster_host(const int32_t* h_semantic_label, const int32_t* h_ball_query_idxs, const int32_t* h_start_len,
+                        int N, int threshold, int32_t* h_cluster_idxs, int32_t* h_cluster_offsets, int32_t* h_nCluster,
+                        int32_t* h_sumNPoint);
+/* pointnet2._ext.three_nn / three_interpolate / three_interpolate_grad (interpolate_gpu.cu:12-157) */
+int gf_three_nn(const float* unknown, const float* known, int b, int n, int m, float* dist2, int32_t* idx, void* stream);
+int gf_three_interpolate(const float* points, const int32_t* idx, const float* weight, int b, int c, int m, int n,
+                         float* out, void* stream);
+int gf_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight, int b, int c, int n, int m,
+                              float* grad_points, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -570,3 +570,75 @@ ORC_API void orc_sec_max(const float *inp, const int32_t *offsets, int32_t nP, i
         out[(size_t)p * C + c] = v;
     }
 }
+
+/* roipool_fp  (lib/pointgroup_ops/src/roipool/roipool.cu:12-31): segment max + arg-max (first max wins) */
+ORC_API void orc_roipool_fp(const float *feats, const int32_t *offsets, int32_t nP, int32_t C, float *out,
+                            int32_t *maxidx) {
+    for (int32_t p = 0; p < nP; p++) for (int32_t c = 0; c < C; c++) {
+        int32_t arg = -1; float v = -INFINITY;
+        for (int32_t i = offsets[p]; i < offsets[p + 1]; i++)
+            if (feats[(size_t)i * C + c] > v) { v = feats[(size_t)i * C + c]; arg = i; }
+        out[(size_t)p * C + c] = v; maxidx[(size_t)p * C + c] = arg;
+    }
+}
+/* get_iou  (lib/pointgroup_ops/src/get_iou/get_iou.cu:12-29) */
+ORC_API void orc_get_iou(const int32_t *pidx, const int32_t *poff, const int64_t *inst_labels,
+                         const int32_t *inst_pointnum, int32_t nInst, int32_t nP, float *iou) {
+    for (int32_t p = 0; p < nP; p++) for (int32_t k = 0; k < nInst; k++) {
+        int32_t inter = 0;
+        for (int32_t i = poff[p]; i < poff[p + 1]; i++) if ((int32_t)inst_labels[pidx[i]] == k) inter++;
+        float denom = (float)((poff[p + 1] - poff[p]) + inst_pointnum[k] - inter) + 1e-5f;
+        iou[(size_t)p * nInst + k] = (float)inter / denom;
+    }
+}
+/* ballquery_batch_p  (bfs_cluster.cu:15-60) in canonical order: starts assigned in point order (the CUDA code
+ * hands them out with an atomic cursor).  Returns the total pair count; idx holds at most n*meanActive. */
+ORC_API int32_t orc_ballquery_batch_p(const float *xyz, const int32_t *batch_idxs, const int32_t *batch_offsets,
+                                      int32_t n, int32_t meanActive, float radius, int32_t *idx, int32_t *start_len) {
+    float r2 = radius * radius;
+    int64_t thre = (int64_t)n * meanActive;
+    int32_t cum = 0;
+    for (int32_t i = 0; i < n; i++) {
+        int32_t b = batch_idxs[i], cnt = 0;
+        start_len[i * 2] = cum;
+        for (int32_t k = batch_offsets[b]; k < batch_offsets[b + 1]; k++) {
+            float dx = xyz[i * 3] - xyz[k * 3], dy = xyz[i * 3 + 1] - xyz[k * 3 + 1], dz = xyz[i * 3 + 2] - xyz[k * 3 + 2];
+            if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2) {
+                if (cnt >= 1000) break;
+                if ((int64_t)cum + cnt < thre) idx[cum + cnt] = k;
+                cnt++;
+            }
+        }
+        start_len[i * 2 + 1] = cnt;
+        cum += cnt;
+    }
+    return cum;
+}
+/* bfs_cluster  (bfs_cluster.cpp:28-111): scan order + FIFO BFS over same-label ball-query edges */
+ORC_API void orc_bfs_cluster(const int32_t *sem, const int32_t *bq_idx, const int32_t *start_len, int32_t N,
+                             int32_t threshold, int32_t *cluster_idxs /*[N,2]*/, int32_t *cluster_offsets /*[N+1]*/,
+                             int32_t *nCluster, int32_t *sumNPoint) {
+    uint8_t *vis = (uint8_t *)calloc((size_t)N + 1, 1);
+    int32_t *cc = (int32_t *)malloc(sizeof(int32_t) * ((size_t)N + 1));
+    int32_t nc = 0, sum = 0;
+    cluster_offsets[0] = 0;
+    for (int32_t i = 0; i < N; i++) {
+        if (vis[i]) continue;
+        int32_t head = 0, tail = 0;
+        cc[tail++] = i; vis[i] = 1;
+        while (head < tail) {
+            int32_t cur = cc[head++];
+            for (int32_t j = start_len[cur * 2]; j < start_len[cur * 2] + start_len[cur * 2 + 1]; j++) {
+                int32_t v = bq_idx[j];
+                if (sem[v] != sem[cur] || vis[v]) continue;
+                cc[tail++] = v; vis[v] = 1;
+            }
+        }
+        if (tail >= threshold) {
+            for (int32_t j = 0; j < tail; j++) { cluster_idxs[(size_t)(sum + j) * 2] = nc; cluster_idxs[(size_t)(sum + j) * 2 + 1] = cc[j]; }
+            sum += tail; nc++; cluster_offsets[nc] = sum;
+        }
+    }
+    free(vis); free(cc);
+    *nCluster = nc; *sumNPoint = sum;
+}

@@ -261,3 +261,43 @@ def sec_op(kind, inp, offsets):
     out = np.zeros((nP, C), np.float32)
     getattr(lib(), f"orc_sec_{kind}")(_p(inp), _p(offsets), c_int32(nP), c_int32(C), _p(out))
     return out
+
+
+def roipool_fp(feats, offsets):
+    feats, offsets = _f32(feats), _i32(offsets)
+    nP, C = offsets.shape[0] - 1, feats.shape[1]
+    out = np.zeros((nP, C), np.float32)
+    arg = np.zeros((nP, C), np.int32)
+    lib().orc_roipool_fp(_p(feats), _p(offsets), c_int32(nP), c_int32(C), _p(out), _p(arg))
+    return out, arg
+
+
+def get_iou(pidx, poff, inst_labels, inst_pointnum):
+    pidx, poff, inst_labels, inst_pointnum = _i32(pidx), _i32(poff), _i64(inst_labels), _i32(inst_pointnum)
+    nP, nI = poff.shape[0] - 1, inst_pointnum.shape[0]
+    iou = np.zeros((nP, nI), np.float32)
+    lib().orc_get_iou(_p(pidx), _p(poff), _p(inst_labels), _p(inst_pointnum), c_int32(nI), c_int32(nP), _p(iou))
+    return iou
+
+
+def ballquery_batch_p(xyz, batch_idxs, batch_offsets, mean_active, radius):
+    xyz, batch_idxs, batch_offsets = _f32(xyz), _i32(batch_idxs), _i32(batch_offsets)
+    n = xyz.shape[0]
+    idx = np.zeros(n * mean_active, np.int32)
+    start_len = np.zeros((n, 2), np.int32)
+    L = lib()
+    L.orc_ballquery_batch_p.restype = c_int32
+    cum = L.orc_ballquery_batch_p(_p(xyz), _p(batch_idxs), _p(batch_offsets), c_int32(n), c_int32(mean_active),
+                                  c_float(radius), _p(idx), _p(start_len))
+    return cum, idx, start_len
+
+
+def bfs_cluster(sem, bq_idx, start_len, threshold):
+    sem, bq_idx, start_len = _i32(sem), _i32(bq_idx), _i32(start_len)
+    N = sem.shape[0]
+    ci = np.zeros((N, 2), np.int32)
+    co = np.zeros(N + 1, np.int32)
+    nc, sm = c_int32(), c_int32()
+    lib().orc_bfs_cluster(_p(sem), _p(bq_idx), _p(start_len), c_int32(N), c_int32(threshold), _p(ci), _p(co), byref(nc),
+                          byref(sm))
+    return ci[: sm.value].copy(), co[: nc.value + 1].copy()

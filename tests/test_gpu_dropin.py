@@ -33,6 +33,8 @@ def test_install_registers_reference_import_names(hip):
         assert hasattr(_ext, name)  # bindings.cpp:8-21
     with pytest.raises(RuntimeError):
         _ext.furthest_point_sampling(torch.zeros(1, 8, 3), 4)  # "CPU not supported"
+    with pytest.raises(RuntimeError):
+        _ext.gather_points(torch.zeros(1, 3, 8).cuda().transpose(1, 2), torch.zeros(1, 4, dtype=torch.int32).cuda())
     assert faiss.GpuIndexFlatConfig().device == 0
 
 

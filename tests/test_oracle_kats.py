@@ -83,3 +83,20 @@ def test_sec_ops(oracle):
     assert oracle.sec_op("mean", x, off)[:2].tolist() == [[2.0, np.float32(5 / 3 + 1 / 3 + 2 / 3)], [7.0, 0.0]]
     assert oracle.sec_op("max", x, off)[0].tolist() == [3.0, 5.0] and oracle.sec_op("min", x, off)[0].tolist() == [1.0, 1.0]
     assert np.isinf(oracle.sec_op("min", x, off)[2]).all()  # empty segment keeps the 1e50 -> +inf initialiser
+
+
+def test_dormant_pg_ops_kats(oracle):
+    # bfs_cluster.cpp:28-54,60-75: scan order + FIFO BFS restricted to equal semantic label, size threshold
+    xyz = np.array([[0, 0, 0], [0.05, 0, 0], [0.1, 0, 0], [5, 0, 0], [5.05, 0, 0], [0.15, 0, 0]], np.float32)
+    bidx = np.zeros(6, np.int32)
+    cum, idx, sl = oracle.ballquery_batch_p(xyz, bidx, np.array([0, 6], np.int32), 6, 0.06)
+    assert sl[:, 1].tolist() == [2, 3, 3, 2, 2, 2] and sl[:, 0].tolist() == [0, 2, 5, 8, 10, 12] and cum == 14
+    assert idx[:5].tolist() == [0, 1, 0, 1, 2]
+    sem = np.array([1, 1, 1, 1, 1, 2], np.int32)
+    ci, co = oracle.bfs_cluster(sem, idx[:cum], sl, 2)
+    assert co.tolist() == [0, 3, 5] and ci[:, 1].tolist() == [0, 1, 2, 3, 4]  # point 5 differs in label: own size-1 cluster dropped
+    out, arg = oracle.roipool_fp(np.array([[1, 9], [3, 2], [3, 5]], np.float32), np.array([0, 3], np.int32))
+    assert out.tolist() == [[3.0, 9.0]] and arg.tolist() == [[1, 0]]  # strict '>' keeps the first maximum
+    iou = oracle.get_iou(np.array([0, 1, 2], np.int32), np.array([0, 3], np.int32), np.array([0, 0, 1, 1], np.int64),
+                         np.array([2, 2], np.int32))
+    assert np.allclose(iou, [[2 / (3 + 2 - 2 + 1e-5), 1 / (3 + 2 - 1 + 1e-5)]])
