@@ -73,7 +73,7 @@ class ConvProbe:
                 # events recorded in native code right around the launch, on the kernel's stream
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 out = self.orig(feats, weight, nbr, gmask, K, M_out, ld, events=(s, e), **kw)
-                self.events.append((s, e))
+                self.events.append((s, e, kw.get("residual") is not None))
                 return out
             return self.orig(feats, weight, nbr, gmask, K, M_out, ld, **kw)
 
@@ -83,14 +83,16 @@ class ConvProbe:
         if not self.events:
             return None
         R = int((self.tbl[:, : self.M] >= 0).sum().item())
-        ms = [s.elapsed_time(e) for s, e in self.events]
+        ms = [s.elapsed_time(e) for s, e, _ in self.events]
         us = float(np.mean(ms)) * 1e3
         Cin = Cout = 16
-        byt = 4 * (R * Cin + self.M * Cout + 27 * Cin * Cout) + 8 * R
+        base = 4 * (R * Cin + self.M * Cout + 27 * Cin * Cout) + 8 * R
+        # launches whose epilogue adds the residual read one more [M, Cout] operand
+        byt = int(np.mean([base + (4 * self.M * Cout if r else 0) for _, _, r in self.events]))
         ach = byt / (us * 1e-6) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "k_conv_os<1,false,true> (subm 3x3x3, 16->16, level 1)", "launches": len(ms),
+                "kernel": "k_conv_os<1,false,true> (subm 3x3x3, 16->16, level 1, BN+ReLU prologue, residual epilogue on half)", "launches": len(ms),
                 "us_per_launch": round(us, 2), "algorithmic_bytes": byt, "rules": R, "voxels": self.M}
 
 

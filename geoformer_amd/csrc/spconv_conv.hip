@@ -21,6 +21,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CONV_MAX_CIN 512
 
 extern "C" size_t gf_conv_packed_floats(int K, int Cin, int Cout) {
     const size_t nch = (Cin + 15) / 16, ncb = (Cout + 15) / 16;
@@ -61,32 +62,35 @@ extern "C" int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, fl
     return GF_OK;
 }
 
+// Raw gather of this lane's 4 channels of row idx (zeros for a missing neighbour).  The fused
+// BatchNorm+ReLU is applied later (activate_a), next to the MFMAs, so that the gathers of a batch
+// are issued back to back instead of each waiting for its own data.
 template <bool VEC>
-__device__ __forceinline__ float4 load_a(const float* __restrict__ in, int idx, int Cin, int ch,
-                                         const float* __restrict__ sc, const float* __restrict__ sh) {
+__device__ __forceinline__ float4 load_a(const float* __restrict__ in, int idx, int Cin, int ch) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx >= 0) {
         const float* src = in + (size_t)idx * Cin + ch;
         if (VEC) {
             a = *reinterpret_cast<const float4*>(src);
-            if (sc) {
-                const float4 s = *reinterpret_cast<const float4*>(sc + ch);
-                const float4 t = *reinterpret_cast<const float4*>(sh + ch);
-                a.x = fmaxf(fmaf(a.x, s.x, t.x), 0.f);
-                a.y = fmaxf(fmaf(a.y, s.y, t.y), 0.f);
-                a.z = fmaxf(fmaf(a.z, s.z, t.z), 0.f);
-                a.w = fmaxf(fmaf(a.w, s.w, t.w), 0.f);
-            }
         } else {
             float* pa = reinterpret_cast<float*>(&a);
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (ch + j < Cin) {
-                    float v = src[j];
-                    if (sc) v = fmaxf(fmaf(v, sc[ch + j], sh[ch + j]), 0.f);
-                    pa[j] = v;
-                }
+                if (ch + j < Cin) pa[j] = src[j];
         }
+    }
+    return a;
+}
+
+// act(x) = max(x*scale + shift, 0) on a present row; sc/sh live in LDS, padded with zeros past Cin
+__device__ __forceinline__ float4 activate_a(float4 a, bool present, const float* sc, const float* sh, int ch) {
+    if (present) {
+        const float4 s = *reinterpret_cast<const float4*>(sc + ch);
+        const float4 t = *reinterpret_cast<const float4*>(sh + ch);
+        a.x = fmaxf(fmaf(a.x, s.x, t.x), 0.f);
+        a.y = fmaxf(fmaf(a.y, s.y, t.y), 0.f);
+        a.z = fmaxf(fmaf(a.z, s.z, t.z), 0.f);
+        a.w = fmaxf(fmaf(a.w, s.w, t.w), 0.f);
     }
     return a;
 }
@@ -141,6 +145,7 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
     constexpr int PF = ConvPF<NCBW>::value;
     __shared__ int s_idx[4][32 * 16];
     __shared__ float4 s_red[SPLIT ? 4 * NCBW * 64 : 1];
+    __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];  // fused BN scale / shift
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -149,6 +154,17 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
     const int first = SPLIT ? blockIdx.x : ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int stride = SPLIT ? gridDim.x : ((gridDim.x * blockDim.x) >> 6);
     int* idx_l = s_idx[w];
+    const float* sc_l = nullptr;
+    const float* sh_l = nullptr;
+    if (in_scale) {  // workgroup-uniform
+        for (int c = threadIdx.x; c < NCH * 16; c += blockDim.x) {
+            s_aff[0][c] = c < Cin ? in_scale[c] : 0.f;
+            s_aff[1][c] = c < Cin ? in_shift[c] : 0.f;
+        }
+        __syncthreads();
+        sc_l = s_aff[0];
+        sh_l = s_aff[1];
+    }
 
     for (int item = first; item < nitems; item += stride) {
         const int g = item / nsplit;
@@ -159,6 +175,18 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
 #pragma unroll
         for (int cb = 0; cb < NCBW; cb++) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // residual rows of this lane's accumulator elements, requested up front (epilogue add)
+        float res[NCBW <= 2 ? NCBW : 1][4];
+        if (NCBW <= 2 && residual) {
+#pragma unroll
+            for (int cb = 0; cb < (NCBW <= 2 ? NCBW : 1); cb++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int row = g * 16 + q * 4 + j, col = (cb0 + cb) * 16 + r;
+                    res[cb][j] = (row < M_out && col < Cout && (!SPLIT || (cb & 3) == w))
+                                     ? residual[(size_t)row * Cout + col] : 0.f;
+                }
+        }
         uint32_t mask = nbr ? (gmask ? gmask[g] : ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u))) : 1u;
         mask = __builtin_amdgcn_readfirstlane(mask);
         // stage the neighbour indices of the present offsets (lane (r,q) fetches offsets q, q+4, ...)
@@ -177,12 +205,18 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
             float4 a[PF];
             float4 b[PF][NCBW];
             bool valid[PF];
+            bool present[PF];
+            int chv[PF];
 #pragma unroll
             for (int j = 0; j < PF; j++) {
                 valid[j] = it.k >= 0;
+                present[j] = false;
+                chv[j] = 0;
                 if (valid[j]) {
                     const int idx = idx_l[it.k * 16 + r];
-                    a[j] = load_a<VEC>(in, idx, Cin, it.c * 16 + 4 * q, in_scale, in_shift);
+                    present[j] = idx >= 0;
+                    chv[j] = it.c * 16 + 4 * q;
+                    a[j] = load_a<VEC>(in, idx, Cin, chv[j]);
 #pragma unroll
                     for (int cb = 0; cb < NCBW; cb++)
                         b[j][cb] = (cb0 + cb < NCB) ? Wp[(((size_t)it.k * NCH + it.c) * NCB + cb0 + cb) * 64 + lane]
@@ -198,6 +232,7 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
 #pragma unroll
             for (int j = 0; j < PF; j++) {
                 if (valid[j]) {
+                    if (sc_l) a[j] = activate_a(a[j], present[j], sc_l, sh_l, chv[j]);
 #pragma unroll
                     for (int cb = 0; cb < NCBW; cb++) {
                         acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j][cb].x, acc[cb], 0, 0, 0);
@@ -234,7 +269,7 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
                 const int row = g * 16 + q * 4 + j;
                 if (row < M_out && col < Cout) {
                     float x = v[j];
-                    if (residual) x += residual[(size_t)row * Cout + col];
+                    if (residual) x += (NCBW <= 2) ? res[NCBW <= 2 ? cb : 0][j] : residual[(size_t)row * Cout + col];
                     out[(size_t)row * Cout + col] = x;
                 }
             }
@@ -281,6 +316,8 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
                            const float* residual, float* out, void* stream) {
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_fwd: K=%d out of range [1,32]", K);
     GF_CHECK_ARG(Cin >= 1 && Cout >= 1, "gf_conv_fwd: Cin=%d Cout=%d", Cin, Cout);
+    GF_CHECK_ARG(in_scale == nullptr || Cin <= CONV_MAX_CIN - 16, "gf_conv_fwd: fused prologue supports Cin <= %d",
+                 CONV_MAX_CIN - 16);
     GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_fwd: nbr==NULL requires K==1");
     GF_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gf_conv_fwd: in_scale/in_shift must come together");
     if (M_out <= 0) return GF_OK;

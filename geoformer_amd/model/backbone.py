@@ -12,6 +12,27 @@ from ..spconv.modules import SparseModule
 from .layers import BackboneTransformer
 
 
+def bn_affine(bn):
+    """Eval-mode BatchNorm1d as y = x * scale + shift (cached until a parameter or statistic changes)."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr())
+    hit = getattr(bn, "_gf_affine", None)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float().contiguous()
+            shift = (bn.bias - bn.running_mean * scale).float().contiguous()
+        hit = (key, scale, shift)
+        bn._gf_affine = hit
+    return hit[1], hit[2]
+
+
+def _fusable(t, *bns):
+    """Inference on the GPU with frozen statistics: BN+ReLU ride in the conv kernel's prologue and the
+    residual add in its epilogue (csrc/spconv_conv.hip) instead of costing HBM round trips and launches."""
+    return (not torch.is_grad_enabled()) and t.features.is_cuda and t.indices.shape[0] > 0 and \
+        all(not bn.training for bn in bns)
+
+
 class ResidualBlock(SparseModule):
     """out = conv_branch(x) + i_branch(x); i_branch is Identity or a 1x1x1 conv when the widths differ.
     conv_branch = [BN, ReLU, SubM3, BN, ReLU, SubM3] (pre-activation)."""
@@ -30,7 +51,28 @@ class ResidualBlock(SparseModule):
             spconv.SubMConv3d(out_channels, out_channels, kernel_size=3, padding=1, bias=False, indice_key=indice_key),
         )
 
+    def _forward_fused(self, input):
+        from .. import sparse
+
+        bn0, _, conv0, bn1, _, conv1 = list(self.conv_branch._modules.values())
+        rules = conv0.get_rules(input)
+        M = input.indices.shape[0]
+        x = input.features.contiguous()
+        s0, t0 = bn_affine(bn0)
+        y = sparse.conv_fwd(x, conv0.weight, rules.nbr, rules.gmask, 27, M, rules.ld, in_scale=s0, in_shift=t0)
+        ib = self.i_branch[0]
+        idn = x if isinstance(ib, nn.Identity) else torch.mm(x, ib.weight.view(ib.in_channels, ib.out_channels))
+        s1, t1 = bn_affine(bn1)
+        out = conv1._new_like(input)
+        out._index = input._index
+        out.features = sparse.conv_fwd(y, conv1.weight, rules.nbr, rules.gmask, 27, M, rules.ld, in_scale=s1,
+                                       in_shift=t1, residual=idn.contiguous())
+        return out
+
     def forward(self, input):
+        mods = list(self.conv_branch._modules.values())
+        if _fusable(input, mods[0], mods[3]):
+            return self._forward_fused(input)
         # snapshot BEFORE conv_branch: SparseSequential replaces input.features in place
         identity = spconv.SparseConvTensor(input.features, input.indices, input.spatial_shape, input.batch_size)
         output = self.conv_branch(input)
@@ -71,7 +113,22 @@ class UBlock(nn.Module):
     def forward(self, input):
         output = self.blocks(input)
         identity = spconv.SparseConvTensor(output.features, output.indices, output.spatial_shape, output.batch_size)
-        if len(self.nPlanes) > 1:
+        if len(self.nPlanes) > 1 and _fusable(output, self.conv[0], self.deconv[0]):
+            from .. import sparse
+
+            down, up = self.conv[2], self.deconv[2]
+            r = down.get_rules(output)
+            s, t = bn_affine(self.conv[0])
+            coarse = down.output_tensor(output, r)
+            coarse.features = sparse.conv_fwd(output.features.contiguous(), down.weight, r.child, r.gmask_down, 8,
+                                              r.M_out, r.ld, in_scale=s, in_shift=t)
+            coarse = self.u(coarse)
+            s, t = bn_affine(self.deconv[0])
+            dec_feats = sparse.conv_fwd(coarse.features.contiguous(), up.weight, r.up, r.gmask_up, 8, r.M_in, r.ld_up,
+                                        in_scale=s, in_shift=t)
+            output.features = torch.cat((identity.features, dec_feats), dim=1)
+            output = self.blocks_tail(output)
+        elif len(self.nPlanes) > 1:
             dec = self.deconv(self.u(self.conv(output)))
             output.features = torch.cat((identity.features, dec.features), dim=1)
             output = self.blocks_tail(output)

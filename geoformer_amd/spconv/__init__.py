@@ -184,6 +184,15 @@ class SubMConv3d(_SparseConvBase):
         if ks not in (1, 3) or (ks == 3 and pad != 1) or stride != 1 or dilation != 1 or groups != 1:
             raise NotImplementedError("SubMConv3d: implemented for k=1 and k=3/padding=1, stride 1 (what GeoFormer uses)")
 
+    def get_rules(self, input):
+        """The 27-offset neighbour table of this tensor's voxel set, cached under ``indice_key``."""
+        rules = input.find_indice_pair(self.indice_key)
+        if rules is None:
+            rules = sparse.subm_rules(input._coords(), input._level_index())
+            if self.indice_key is not None:
+                input.indice_dict[self.indice_key] = rules
+        return rules
+
     def forward(self, input):
         out = self._new_like(input)
         out._index = input._index
@@ -192,12 +201,8 @@ class SubMConv3d(_SparseConvBase):
             return self._finish(out, torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels)))
         if M == 0:
             return self._finish(out, input.features.new_zeros((0, self.out_channels)))
-        rules = input.find_indice_pair(self.indice_key)
-        if rules is None:
-            rules = sparse.subm_rules(input._coords(), input._level_index())
-            out._index = input._index
-            if self.indice_key is not None:
-                input.indice_dict[self.indice_key] = rules
+        rules = self.get_rules(input)
+        out._index = input._index
         spec = (rules.nbr, rules.gmask, 27, M, rules.ld)
         return self._finish(out, _GatherConv.apply(input.features, self.weight, spec, ("subm", spec)))
 
@@ -214,13 +219,21 @@ class SparseConv3d(_SparseConvBase):
         if self.kernel_size[0] != 2 or st != 2 or pad != 0 or dilation != 1 or groups != 1:
             raise NotImplementedError("SparseConv3d: implemented for kernel_size=2, stride=2, padding=0")
 
-    def forward(self, input):
+    def get_rules(self, input):
         rules = sparse.down_rules(input._coords(), input.batch_size, input.spatial_shape)
         rules.in_coords, rules.in_shape, rules.in_index = input.indices, list(input.spatial_shape), input._index
         if self.indice_key is not None:
             input.indice_dict[self.indice_key] = rules
+        return rules
+
+    def output_tensor(self, input, rules):
         out = self._new_like(input, rules.out_coords, list(rules.out_shape))
         out._index = rules.index_out
+        return out
+
+    def forward(self, input):
+        rules = self.get_rules(input)
+        out = self.output_tensor(input, rules)
         fwd = (rules.child, rules.gmask_down, 8, rules.M_out, rules.ld)
         bwd = ("table", (rules.up, rules.gmask_up, 8, rules.M_in, rules.ld_up))
         return self._finish(out, _GatherConv.apply(input.features, self.weight, fwd, bwd))
@@ -235,12 +248,20 @@ class SparseInverseConv3d(_SparseConvBase):
         if self.kernel_size[0] != 2:
             raise NotImplementedError("SparseInverseConv3d: implemented for kernel_size=2")
 
-    def forward(self, input):
+    def get_rules(self, input):
         rules = input.find_indice_pair(self.indice_key)
         if rules is None or not isinstance(rules, sparse.DownRules):
             raise RuntimeError(f"SparseInverseConv3d: no SparseConv3d rules under indice_key={self.indice_key!r}")
+        return rules
+
+    def output_tensor(self, input, rules):
         out = self._new_like(input, rules.in_coords, rules.in_shape)
         out._index = rules.in_index
+        return out
+
+    def forward(self, input):
+        rules = self.get_rules(input)
+        out = self.output_tensor(input, rules)
         fwd = (rules.up, rules.gmask_up, 8, rules.M_in, rules.ld_up)
         bwd = ("table", (rules.child, rules.gmask_down, 8, rules.M_out, rules.ld))
         return self._finish(out, _GatherConv.apply(input.features, self.weight, fwd, bwd))

@@ -44,3 +44,12 @@ for L, (c, s, r, m) in enumerate(levels):
     byt = 4 * (Rl * C + m * C + 27 * C * C) + 8 * Rl
     fl = 2 * Rl * C * C
     print(f"level {L+1} M {m} C {C} R {Rl}: {us:.1f} us  alg {byt/us/1e6:.2f} TB/s  {fl/us/1e6:.2f} TFLOP/s")
+# fused-variant experiment on level 1
+c, s, r, m = levels[0]
+x = torch.randn(m, 16, device="cuda"); W = torch.randn(27, 16, 16, device="cuda") * 0.05
+sc = torch.rand(16, device="cuda") + 0.5; sh = torch.randn(16, device="cuda"); res = torch.randn(m, 16, device="cuda")
+for name, kw in (("plain", {}), ("scale", dict(in_scale=sc, in_shift=sh)), ("resid", dict(residual=res)),
+                 ("both", dict(in_scale=sc, in_shift=sh, residual=res))):
+    print("L1", name, round(timeit(lambda: sparse.conv_fwd(x, W, r.nbr, r.gmask, 27, m, r.ld, **kw)), 1), "us")
+xr = torch.relu(x)
+print("L1 plain on relu'd input", round(timeit(lambda: sparse.conv_fwd(xr, W, r.nbr, r.gmask, 27, m, r.ld)), 1), "us")
