@@ -18,6 +18,8 @@
 //
 // Roofline: HBM-bound for C <= 80.  Algorithmic bytes per launch are
 // 4*(R*Cin + M_out*Cout + K*Cin*Cout) + 8*R with R = number of non-negative table entries.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -135,15 +137,15 @@ struct StepIter {
     }
 };
 
-template <int NCBW, bool SPLIT, bool VEC>
-__global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
+template <int NCBW, bool SPLIT, bool VEC, bool LDSW>
+__global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                  const int32_t* __restrict__ nbr, const uint32_t* __restrict__ gmask,
                                                  int K, int M_out, int ld, int Cin, int Cout, int NCH, int NCB,
                                                  int nsplit, const float* __restrict__ in_scale,
                                                  const float* __restrict__ in_shift,
                                                  const float* __restrict__ residual, float* __restrict__ out) {
     constexpr int PF = ConvPF<NCBW>::value;
-    __shared__ int s_idx[4][32 * 16];
+    __shared__ int s_idx[SPLIT ? 4 : 8][32 * 16];
     __shared__ float4 s_red[SPLIT ? 4 * NCBW * 64 : 1];
     __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];  // fused BN scale / shift
     const int lane = threadIdx.x & 63;
@@ -154,6 +156,14 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
     const int first = SPLIT ? blockIdx.x : ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int stride = SPLIT ? gridDim.x : ((gridDim.x * blockDim.x) >> 6);
     int* idx_l = s_idx[w];
+    // LDSW: the whole packed weight tensor (K*NCH*NCB KiB, <= 64 KiB) is staged once per workgroup; B
+    // operands then come from conflict-free ds_read_b128 instead of one more stream through L1/TA
+    extern __shared__ __attribute__((aligned(16))) float4 s_wp[];
+    if (LDSW) {
+        const int total = K * NCH * NCB * 64;
+        for (int t = threadIdx.x; t < total; t += blockDim.x) s_wp[t] = Wp[t];
+        __syncthreads();
+    }
     const float* sc_l = nullptr;
     const float* sh_l = nullptr;
     if (in_scale) {  // workgroup-uniform
@@ -166,7 +176,8 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
         sh_l = s_aff[1];
     }
 
-    for (int item = first; item < nitems; item += stride) {
+    for (int item0 = first; item0 < nitems; item0 += stride) {
+        const int item = item0;
         const int g = item / nsplit;
         const int cb0 = (item - g * nsplit) * NCBW;
         const int o = g * 16 + r;
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
             for (int j = 0; j < w; j++) it.next();
         while (it.k >= 0) {
             float4 a[PF];
-            float4 b[PF][NCBW];
+            float4 b[LDSW ? 1 : PF][NCBW];
             bool valid[PF];
             bool present[PF];
             int chv[PF];
@@ -217,10 +228,15 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
                     present[j] = idx >= 0;
                     chv[j] = it.c * 16 + 4 * q;
                     a[j] = load_a<VEC>(in, idx, Cin, chv[j]);
+                    if (LDSW) {
+                        chv[j] |= ((it.k * NCH + it.c) * NCB) << 12;  // weight block of this step (uniform)
+                    } else {
 #pragma unroll
-                    for (int cb = 0; cb < NCBW; cb++)
-                        b[j][cb] = (cb0 + cb < NCB) ? Wp[(((size_t)it.k * NCH + it.c) * NCB + cb0 + cb) * 64 + lane]
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int cb = 0; cb < NCBW; cb++)
+                            b[j][cb] = (cb0 + cb < NCB)
+                                           ? Wp[(((size_t)it.k * NCH + it.c) * NCB + cb0 + cb) * 64 + lane]
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
                 it.next();
                 if (SPLIT) {
@@ -232,13 +248,19 @@ __global__ __launch_bounds__(256) void k_conv_os(const float* __restrict__ in, c
 #pragma unroll
             for (int j = 0; j < PF; j++) {
                 if (valid[j]) {
-                    if (sc_l) a[j] = activate_a(a[j], present[j], sc_l, sh_l, chv[j]);
+                    if (sc_l) a[j] = activate_a(a[j], present[j], sc_l, sh_l, chv[j] & 0xfff);
 #pragma unroll
                     for (int cb = 0; cb < NCBW; cb++) {
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, b[j][cb].x, acc[cb], 0, 0, 0);
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, b[j][cb].y, acc[cb], 0, 0, 0);
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, b[j][cb].z, acc[cb], 0, 0, 0);
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, b[j][cb].w, acc[cb], 0, 0, 0);
+                        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (LDSW) {
+                            if (cb0 + cb < NCB) bb = s_wp[((chv[j] >> 12) + cb0 + cb) * 64 + lane];
+                        } else {
+                            bb = b[j][cb];
+                        }
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, bb.x, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, bb.y, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, bb.z, acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].w, bb.w, acc[cb], 0, 0, 0);
                     }
                 }
             }
@@ -287,13 +309,26 @@ struct ConvArgs {
     float* out;
 };
 
+static int g_conv_block = 256;
+template <int NCBW>
+static void launch_conv_ldsw(dim3 grid, int bs, size_t lds, hipStream_t st, const ConvArgs& a) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)k_conv_os<NCBW, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            64 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv_os<NCBW, false, true, true>), grid, dim3(bs), lds, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+                       a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
+}
 template <int NCBW, bool SPLIT>
 static void launch_conv(bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
+    const int bs = SPLIT ? 256 : g_conv_block;
     if (vec)
-        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, true>), grid, dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, true, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                            a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
     else
-        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, false>), grid, dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, false, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                            a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
 }
 
@@ -328,17 +363,31 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     // Big levels: one wave per 16-row group owning every column block.  Small levels (not enough groups
     // to fill 1024 SIMDs with several waves each): a workgroup per (group, <=2 column blocks), steps split
     // over its four waves.
-    const bool split = ngroups < 6000;
+    bool split = ngroups < 6000;
+    if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
     const int ncbw = split ? (ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
     const int nsplit = (ncb + ncbw - 1) / ncbw;
     const long long nitems = (long long)ngroups * nsplit;
-    long long blocks = split ? nitems : (nitems + 3) / 4;
+    if (const char* e = getenv("GF_CONV_BLOCK")) g_conv_block = atoi(e);
+    const int wpb = g_conv_block / 64;
+    long long blocks = split ? nitems : (nitems + wpb - 1) / wpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
     ConvArgs a{in, reinterpret_cast<const float4*>(Wp), nbr, gmask, K, M_out, ld, Cin, Cout, nch, ncb, nsplit,
                in_scale, in_shift, residual, out};
     dim3 grid((unsigned)blocks);
     hipStream_t st = (hipStream_t)stream;
-    if (split)
+    const size_t wbytes = (size_t)K * nch * ncb * 1024;
+    // LDS-resident weights: measured 10 % SLOWER than streaming them through L1 at C=16 (33.4 vs 30.3 us,
+    // S150k level 1), so it is opt-in (GF_CONV_LDSW=1) until the staging cost is amortised differently
+    bool ldsw = false;
+    if (const char* e = getenv("GF_CONV_LDSW")) ldsw = atoi(e) != 0 && !split && vec && ncb <= 2 && wbytes <= 64 * 1024;
+    if (ldsw) {
+        // 512-thread workgroups share one weight image: 8 waves per 27-54 KiB
+        const int bs = 512;
+        dim3 g2((unsigned)((nitems + 7) / 8));
+        if (ncb == 1) launch_conv_ldsw<1>(g2, bs, wbytes, st, a);
+        else launch_conv_ldsw<2>(g2, bs, wbytes, st, a);
+    } else if (split)
         dispatch_conv<true>(ncbw, vec, grid, st, a);
     else
         dispatch_conv<false>(ncbw, vec, grid, st, a);
@@ -416,4 +465,10 @@ extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* 
                        Cout, nci, nco, nslices, dW);
     GF_CHECK_LAUNCH("gf_conv_wgrad");
     return GF_OK;
+}
+
+extern "C" int gf_debug_conv_occupancy(int block) {
+    int n = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_conv_os<1, false, true, true>, block, 27 * 1024);
+    return n;
 }
