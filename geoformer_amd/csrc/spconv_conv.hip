@@ -141,7 +141,7 @@ template <int NCBW, bool SPLIT, bool VEC, bool LDSW>
 __global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                  const int32_t* __restrict__ nbr, const uint32_t* __restrict__ gmask,
                                                  int K, int M_out, int ld, int Cin, int Cout, int NCH, int NCB,
-                                                 int nsplit, const float* __restrict__ in_scale,
+                                                 int nsplit, unsigned in_bytes, const float* __restrict__ in_scale,
                                                  const float* __restrict__ in_shift,
                                                  const float* __restrict__ residual, float* __restrict__ out) {
     constexpr int PF = ConvPF<NCBW>::value;
@@ -156,6 +156,14 @@ __global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, c
     const int first = SPLIT ? blockIdx.x : ((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int stride = SPLIT ? gridDim.x : ((gridDim.x * blockDim.x) >> 6);
     int* idx_l = s_idx[w];
+    // VEC path: gathers and weight loads go through buffer descriptors -- a 32-bit per-lane offset instead of
+    // 64-bit pointer arithmetic, a scalar offset for the (uniform) weight block, and the hardware range
+    // check turns "missing neighbour" (offset 0xffffffff) into zeros without a branch
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, K * NCH * NCB * 1024, 0x00020000);
+    const unsigned rowbytes = (unsigned)Cin * 4u;
     // LDSW: the whole packed weight tensor (K*NCH*NCB KiB, <= 64 KiB) is staged once per workgroup; B
     // operands then come from conflict-free ds_read_b128 instead of one more stream through L1/TA
     extern __shared__ __attribute__((aligned(16))) float4 s_wp[];
@@ -227,9 +235,26 @@ __global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, c
                     const int idx = idx_l[it.k * 16 + r];
                     present[j] = idx >= 0;
                     chv[j] = it.c * 16 + 4 * q;
-                    a[j] = load_a<VEC>(in, idx, Cin, chv[j]);
+                    if (VEC) {
+                        const unsigned voff = present[j] ? (unsigned)idx * rowbytes + (unsigned)chv[j] * 4u : 0xffffffffu;
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+                        a[j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                                           __uint_as_float(v[3]));
+                    } else {
+                        a[j] = load_a<VEC>(in, idx, Cin, chv[j]);
+                    }
                     if (LDSW) {
                         chv[j] |= ((it.k * NCH + it.c) * NCB) << 12;  // weight block of this step (uniform)
+                    } else if (VEC) {
+                        const unsigned wblk = (unsigned)((it.k * NCH + it.c) * NCB + cb0);
+#pragma unroll
+                        for (int cb = 0; cb < NCBW; cb++) {
+                            // blocks past NCB fall outside the descriptor range and read as zeros
+                            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                                rs_w, (unsigned)lane * 16u, (cb0 + cb < NCB) ? (wblk + cb) * 1024u : 0xfffffff0u, 0);
+                            b[j][cb] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                                                   __uint_as_float(v[3]));
+                        }
                     } else {
 #pragma unroll
                         for (int cb = 0; cb < NCBW; cb++)
@@ -305,6 +330,7 @@ struct ConvArgs {
     const int32_t* nbr;
     const uint32_t* gmask;
     int K, M_out, ld, Cin, Cout, NCH, NCB, nsplit;
+    unsigned in_bytes;
     const float *sc, *sh, *res;
     float* out;
 };
@@ -319,17 +345,17 @@ static void launch_conv_ldsw(dim3 grid, int bs, size_t lds, hipStream_t st, cons
         attr = true;
     }
     hipLaunchKernelGGL((k_conv_os<NCBW, false, true, true>), grid, dim3(bs), lds, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                       a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
+                       a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
 }
 template <int NCBW, bool SPLIT>
 static void launch_conv(bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
     const int bs = SPLIT ? 256 : g_conv_block;
     if (vec)
         hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, true, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
+                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
     else
         hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, false, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.sc, a.sh, a.res, a.out);
+                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
 }
 
 template <bool SPLIT>
@@ -347,8 +373,8 @@ static void dispatch_conv(int ncbw, bool vec, dim3 grid, hipStream_t st, const C
 }
 
 extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
-                           int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
-                           const float* residual, float* out, void* stream) {
+                           int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
+                           const float* in_shift, const float* residual, float* out, void* stream) {
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_fwd: K=%d out of range [1,32]", K);
     GF_CHECK_ARG(Cin >= 1 && Cout >= 1, "gf_conv_fwd: Cin=%d Cout=%d", Cin, Cout);
     GF_CHECK_ARG(in_scale == nullptr || Cin <= CONV_MAX_CIN - 16, "gf_conv_fwd: fused prologue supports Cin <= %d",
@@ -358,7 +384,8 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     if (M_out <= 0) return GF_OK;
     const int ngroups = (M_out + 15) / 16;
     const int ncb = (Cout + 15) / 16, nch = (Cin + 15) / 16;
-    const bool vec = (Cin % 16) == 0 && (((uintptr_t)in) % 16) == 0 &&
+    const unsigned long long in_bytes64 = (unsigned long long)M_in * Cin * 4ull;
+    const bool vec = (Cin % 16) == 0 && (((uintptr_t)in) % 16) == 0 && in_bytes64 < 0xfffffff0ull &&
                      (in_scale == nullptr || ((((uintptr_t)in_scale) | ((uintptr_t)in_shift)) % 16) == 0);
     // Big levels: one wave per 16-row group owning every column block.  Small levels (not enough groups
     // to fill 1024 SIMDs with several waves each): a workgroup per (group, <=2 column blocks), steps split
@@ -373,7 +400,7 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     long long blocks = split ? nitems : (nitems + wpb - 1) / wpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
     ConvArgs a{in, reinterpret_cast<const float4*>(Wp), nbr, gmask, K, M_out, ld, Cin, Cout, nch, ncb, nsplit,
-               in_scale, in_shift, residual, out};
+               (unsigned)(in_bytes64 < 0xfffffff0ull ? in_bytes64 : 0), in_scale, in_shift, residual, out};
     dim3 grid((unsigned)blocks);
     hipStream_t st = (hipStream_t)stream;
     const size_t wbytes = (size_t)K * nch * ncb * 1024;
@@ -398,10 +425,12 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
 // Same launch bracketed by two caller-owned hipEvent_t recorded back to back with the kernel on the
 // same stream (bench.py's roofline probe: the kernel's own duration, not the host's launch gaps).
 extern "C" int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
-                                 int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
-                                 const float* residual, float* out, void* ev_start, void* ev_stop, void* stream) {
+                                 int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
+                                 const float* in_shift, const float* residual, float* out, void* ev_start,
+                                 void* ev_stop, void* stream) {
     hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream);
-    const int rc = gf_conv_fwd(in, Wp, nbr, gmask, K, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out, stream);
+    const int rc =
+        gf_conv_fwd(in, Wp, nbr, gmask, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out, stream);
     hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream);
     return rc;
 }

@@ -188,14 +188,14 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
             if not e.cuda_event:
                 e.record()  # materialise the hipEvent_t handle
         check(
-            lib.gf_conv_fwd_timed(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
+            lib.gf_conv_fwd_timed(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
                                   ptr(in_shift), ptr(residual), ptr(out), c_void_p(events[0].cuda_event),
                                   c_void_p(events[1].cuda_event), stream_ptr()),
             "gf_conv_fwd_timed",
         )
         return out
     check(
-        lib.gf_conv_fwd(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(in_scale),
+        lib.gf_conv_fwd(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
                         ptr(in_shift), ptr(residual), ptr(out), stream_ptr()),
         "gf_conv_fwd",
     )

@@ -90,20 +90,21 @@ int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, vo
 
 /* Forward gather-GEMM (output-stationary): out[o,:] = sum_k act(in[nbr[k][o],:]) @ W[k] (+ residual[o,:])
  *   in fp32 [M_in,Cin]   Wp = packed W (gf_conv_pack_weights)   out fp32 [M_out,Cout]
+ *   (M_in bounds the buffer descriptor the gathers go through)
  *   nbr may be NULL with K == 1 (identity map: plain GEMM, the k=1 "i_branch" conv)
  *   in_scale/in_shift  optional fp32 [Cin]: act(x) = max(x*scale + shift, 0) fused on the
  *                      gathered rows (eval-mode BatchNorm1d + ReLU, geoformer_modules.py:19-26)
  *   residual           optional fp32 [M_out,Cout] added in the epilogue (geoformer_modules.py:33)
  */
-int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_out, int ld,
-                int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, float* out,
-                void* stream);
+int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in, int M_out,
+                int ld, int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual,
+                float* out, void* stream);
 
 /* gf_conv_fwd with two caller-owned hipEvent_t recorded immediately before/after the launch on `stream`
  * (profiling aid used by bench.py's roofline probe). */
-int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_out,
-                      int ld, int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual,
-                      float* out, void* ev_start, void* ev_stop, void* stream);
+int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in,
+                      int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
+                      const float* residual, float* out, void* ev_start, void* ev_stop, void* stream);
 
 /* Weight gradient of the same operator: dW[k] = sum_o in[nbr[k][o],:]^T dOut[o,:]  (dW fp32
  * [K,Cin,Cout], zeroed by the call).  The input gradient needs no entry point of its own: it is
