@@ -134,7 +134,8 @@ class UBlock(nn.Module):
             output = self.blocks_tail(output)
         if self.before_transformer_linear is not None:
             feats = self.before_transformer_linear(output.features)
-            feats = self.transformer(xyz=output.indices[:, 1:].float(), features=feats, batch_ids=output.indices[:, 0])
+            feats = self.transformer(xyz=output.indices[:, 1:].float(), features=feats, batch_ids=output.indices[:, 0],
+                                     batch_size=output.batch_size)
             output.features = self.after_transformer_linear(feats)
         return output
 

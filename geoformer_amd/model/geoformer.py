@@ -49,12 +49,22 @@ def get_batch_offsets(batch_idxs, bs):
     return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
 
 
+_OFFS_CACHE = [None, None]
+
+
+def _offsets_list(t):
+    """Host copy of a small offsets tensor, fetched once per tensor object (each fetch is a device sync)."""
+    if _OFFS_CACHE[0] is not t:
+        _OFFS_CACHE[0], _OFFS_CACHE[1] = t, t.tolist()
+    return _OFFS_CACHE[1]
+
+
 @torch.no_grad()
 def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighbor=64, radius=0.05, n_queries=128):
     """cal_geodesic_vectorize (geodesic_utils.py:91-164): per scene a kNN graph (k=neighbor, edges
     within `radius`) and a hop-synchronous BFS from the first n_queries FPS indices -- interpreted,
     like the reference does, as indices into the scene's un-permuted foreground points."""
-    offs = batch_offsets_.tolist()
+    offs = _offsets_list(batch_offsets_)
     out = []
     for b in range(pre_enc_inds.shape[0]):
         pts = locs_float_[offs[b]:offs[b + 1]].contiguous()
@@ -153,16 +163,33 @@ class GeoFormer(nn.Module):
         ctx = torch.no_grad if "unet" in self.fix_module else torch.enable_grad
         with ctx():
             x = self.preprocess_input(batch_input, batch_size)
+            self.prebuild_rulebooks(x)
             x = self.output_layer(self.unet(self.input_conv(x)))
             output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
             semantic_scores = self.semantic_linear(self.semantic(output_feats))
             semantic_preds = semantic_scores.max(1)[1]
             return output_feats, semantic_scores, semantic_preds
 
+    @staticmethod
+    def prebuild_rulebooks(x, nlevels=6):
+        """All six down-sampling rulebooks of the U-Net in one go (one host sync instead of six); the
+        SparseConv3d layers find them in the shared indice_dict under their ``spconvL`` keys."""
+        from .. import sparse
+
+        if not x.features.is_cuda or x.indices.shape[0] == 0:
+            return
+        coords = x._coords()
+        chain = sparse.down_rules_chain(coords, x.batch_size, x.spatial_shape, nlevels)
+        cur = coords
+        for l, r in enumerate(chain):
+            r.prebuilt_for = cur.data_ptr()
+            x.indice_dict[f"spconv{l + 1}"] = r
+            cur = r.out_coords
+
     # -- set aggregation ------------------------------------------------------------------------
     def forward_aggregator(self, locs_float_, output_feats_, batch_offsets_, batch_size):
         ctx = torch.no_grad if "set_aggregator" in self.fix_module else torch.enable_grad
-        offs = batch_offsets_.tolist()
+        offs = _offsets_list(batch_offsets_)
         with ctx():
             locs, gfeat, gxyz, inds = [], [], [], []
             for b in range(batch_size):
@@ -261,7 +288,7 @@ class GeoFormer(nn.Module):
     def get_mask_prediction(self, geo_dists, param_kernels, mask_features, locs_float_, fps_sampling_locs,
                             batch_offsets_):
         num_layers, n_queries, batch = param_kernels.shape[:3]
-        offs = batch_offsets_.tolist()
+        offs = _offsets_list(batch_offsets_)
         outputs = []
         for l in range(num_layers):
             pk = param_kernels[l]  # nq x B x C

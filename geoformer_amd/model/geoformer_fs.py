@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import config as _config
 from .backbone import random_downsample
-from .geoformer import GeoFormer, cal_geodesic, get_batch_offsets
+from .geoformer import GeoFormer, _offsets_list, cal_geodesic, get_batch_offsets
 from .layers import GenericMLP
 
 
@@ -78,7 +78,7 @@ class GeoFormerFS(GeoFormer):
 
     def forward_aggregator(self, locs_float_, output_feats_, batch_offsets_, batch_size):
         ctx = torch.enable_grad if self.training and "set_aggregator" not in self.fix_module else torch.no_grad
-        offs = batch_offsets_.tolist()
+        offs = _offsets_list(batch_offsets_)
         with ctx():
             locs, gfeat, gxyz, inds = [], [], [], []
             for b in range(batch_size):
@@ -94,7 +94,7 @@ class GeoFormerFS(GeoFormer):
     def get_mask_prediction(self, geo_dists, param_kernels, mask_features, locs_float_, fps_sampling_locs,
                             batch_offsets_):
         num_layers, n_queries, batch = param_kernels.shape[:3]
-        offs = batch_offsets_.tolist()
+        offs = _offsets_list(batch_offsets_)
         outputs = []
         for l in range(num_layers):
             pk2 = param_kernels[l].transpose(0, 1).flatten(0, 1)

@@ -173,14 +173,21 @@ class BackboneTransformer(nn.Module):
         self.norm = Norm(d_model)
         self.position_linear = nn.Linear(3, d_model)
 
-    def forward(self, xyz, features, batch_ids):
+    def forward(self, xyz, features, batch_ids, batch_size=None):
         out = torch.zeros_like(features)
-        nb = int(batch_ids.max().item()) + 1
+        if batch_size == 1 and features.shape[0] > 0:
+            # single scene: every row belongs to it -- no device round trip to find the row range
+            nb, single = 1, True
+        else:
+            nb, single = int(batch_ids.max().item()) + 1, False
         for b in range(nb):
-            rows = torch.nonzero(batch_ids == b).squeeze(1)
-            if rows.numel() == 0:
-                continue
-            s, e = int(rows.min().item()), int(rows.max().item()) + 1  # rows of a scene are contiguous
+            if single:
+                rows, s, e = slice(None), 0, features.shape[0]
+            else:
+                rows = torch.nonzero(batch_ids == b).squeeze(1)
+                if rows.numel() == 0:
+                    continue
+                s, e = int(rows.min().item()), int(rows.max().item()) + 1  # rows of a scene are contiguous
             pts = xyz[s:e].view(-1, 3)
             rel = (pts.unsqueeze(1) - pts.unsqueeze(0)).float().mean(dim=1)
             x = (features[s:e].view(-1, self.d_model) + self.position_linear(rel)).unsqueeze(0)

@@ -223,3 +223,52 @@ def conv_wgrad(feats: torch.Tensor, grad_out: torch.Tensor, nbr, K: int, M_out: 
     check(lib.gf_conv_wgrad(ptr(feats), ptr(grad_out), ptr(nbr), K, M_out, ld, Cin, Cout, ptr(dW), stream_ptr()),
           "gf_conv_wgrad")
     return dW
+
+
+def down_rules_chain(coords: torch.Tensor, batch: int, shape, nlevels: int):
+    """Rulebooks of `nlevels` successive k=2/s=2 down-samplings with ONE host sync.
+
+    Level l+1 is built from level l's output coordinates with the voxel count kept on the device
+    (`d_M`); all levels are allocated at the capacity of the first one, and the counts come back in a
+    single D2H copy at the end.  Returns a list of DownRules (tables keep the capacity as leading dim)."""
+    lib = _lib.load()
+    dev = coords.device
+    M0 = coords.shape[0]
+    cap = max(_round16(M0), 16)
+    counts = torch.zeros(nlevels + 1, dtype=torch.int32, device=dev)
+    counts[0] = M0
+    staged = []
+    cur, cur_shape = coords, tuple(int(s) for s in shape)
+    for l in range(nlevels):
+        X, Y, Z = cur_shape
+        if min(X, Y, Z) < 2:
+            break
+        oshape = ((X - 2) // 2 + 1, (Y - 2) // 2 + 1, (Z - 2) // 2 + 1)
+        words = lib.gf_index_words(batch, *oshape)
+        bitmap = torch.empty(words, dtype=torch.int32, device=dev)
+        prefix = torch.empty(words, dtype=torch.int32, device=dev)
+        scratch = _scratch(words, dev)
+        out_coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        child = torch.empty((8, cap), dtype=torch.int32, device=dev)
+        parent = torch.empty(cap, dtype=torch.int32, device=dev)
+        koff = torch.empty(cap, dtype=torch.int32, device=dev)
+        up = torch.empty((8, cap), dtype=torch.int32, device=dev)
+        gmask_down = torch.empty(cap // 16, dtype=torch.int32, device=dev)
+        gmask_up = torch.empty(cap // 16, dtype=torch.int32, device=dev)
+        check(
+            lib.gf_rules_down2(ptr(cur), cap if l else M0, ptr(counts[l:l + 1]) if l else None, batch, X, Y, Z,
+                               ptr(bitmap), ptr(prefix), ptr(scratch), ptr(out_coords), ptr(counts[l + 1:l + 2]),
+                               ptr(child), cap, ptr(parent), ptr(koff), ptr(up), cap, ptr(gmask_down), ptr(gmask_up),
+                               stream_ptr()),
+            "gf_rules_down2",
+        )
+        staged.append((cur, cur_shape, oshape, bitmap, prefix, out_coords, child, parent, koff, up, gmask_down, gmask_up))
+        cur, cur_shape = out_coords, oshape
+    n = counts.tolist()  # the only host sync
+    rules = []
+    for l, (cin, sin, oshape, bitmap, prefix, oc, child, parent, koff, up, gd, gu) in enumerate(staged):
+        r = DownRules(oc[: n[l + 1]], n[l], n[l + 1], child, cap, gd, parent[: n[l]], koff[: n[l]], up, cap, gu,
+                      LevelIndex(bitmap, prefix, None, batch, oshape), oshape)
+        r.in_coords, r.in_shape = cin[: n[l]], list(sin)
+        rules.append(r)
+    return rules

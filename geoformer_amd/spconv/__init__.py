@@ -220,6 +220,12 @@ class SparseConv3d(_SparseConvBase):
             raise NotImplementedError("SparseConv3d: implemented for kernel_size=2, stride=2, padding=0")
 
     def get_rules(self, input):
+        pre = input.find_indice_pair(self.indice_key)
+        if isinstance(pre, sparse.DownRules) and getattr(pre, "prebuilt_for", None) == input.indices.data_ptr() \
+                and pre.M_in == input.indices.shape[0]:
+            # rulebook chain prebuilt for exactly this voxel set (sparse.down_rules_chain): no host sync here
+            pre.in_coords, pre.in_shape, pre.in_index = input.indices, list(input.spatial_shape), input._index
+            return pre
         rules = sparse.down_rules(input._coords(), input.batch_size, input.spatial_shape)
         rules.in_coords, rules.in_shape, rules.in_index = input.indices, list(input.spatial_shape), input._index
         if self.indice_key is not None:

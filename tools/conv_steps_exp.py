@@ -25,3 +25,12 @@ for name, keep in (("none", 0), ("centre only", 1 << 13), ("3 offsets", (1 << 13
     print(f"{name:28s} mean steps {pop:5.2f}  {timeit(lambda: sparse.conv_fwd(x, W, rules.nbr, gm, 27, M, rules.ld)):6.1f} us")
 y = torch.empty(M, 16, device="cuda")
 print("copy M x 16 fp32", round(timeit(lambda: y.copy_(x)), 1), "us")
+gm0 = (full & 0).contiguous()
+for frac in (0.125, 0.25, 0.5, 1.0):
+    m = int(M * frac) // 16 * 16
+    print("none-mask, M_out", m, round(timeit(lambda: sparse.conv_fwd(x, W, rules.nbr, gm0, 27, m, rules.ld)), 1), "us")
+for frac in (0.125, 0.25, 0.5, 1.0):
+    m = int(M * frac) // 16 * 16
+    print("full-mask, M_out", m, round(timeit(lambda: sparse.conv_fwd(x, W, rules.nbr, full, 27, m, rules.ld)), 1), "us")
+z = torch.zeros(M, 16, device="cuda")
+print("zero_ M x16", round(timeit(lambda: z.zero_()), 1), "us")
