@@ -49,14 +49,16 @@ def get_batch_offsets(batch_idxs, bs):
     return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
 
 
-_OFFS_CACHE = [None, None]
+import threading
+
+_OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
 
 
 def _offsets_list(t):
     """Host copy of a small offsets tensor, fetched once per tensor object (each fetch is a device sync)."""
-    if _OFFS_CACHE[0] is not t:
-        _OFFS_CACHE[0], _OFFS_CACHE[1] = t, t.tolist()
-    return _OFFS_CACHE[1]
+    if getattr(_OFFS_CACHE, "key", None) is not t:
+        _OFFS_CACHE.key, _OFFS_CACHE.val = t, t.tolist()
+    return _OFFS_CACHE.val
 
 
 @torch.no_grad()

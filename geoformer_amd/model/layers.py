@@ -221,7 +221,9 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout, inplace=True)
         self.dropout3 = nn.Dropout(dropout, inplace=True)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
-        self.dropout = nn.Dropout(dropout, inplace=True)
+        # the reference builds this one in place too (transformer_detr.py:373), which current autograd rejects
+        # (it overwrites the ReLU output that ReLU's backward needs); out of place draws the same mask
+        self.dropout = nn.Dropout(dropout, inplace=False)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
         self.activation = {"relu": nn.ReLU, "gelu": nn.GELU}[activation]()
         self.nhead, self.use_rel, self.normalize_before = nhead, use_rel, normalize_before

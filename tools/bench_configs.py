@@ -1,0 +1,57 @@
+"""Dev tool: timings of the secondary BASELINE configs on one GPU.
+  config 3: training step, batch 4 (yaml copy with batch_size: 4), fwd + criterion + bwd + Adam
+  config 4: few-shot episode, 1 query scene + k full support scenes (k = 1 and 5), eval
+"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from geoformer_amd import scene
+from geoformer_amd.model import GeoFormer, GeoFormerFS, InstSetCriterion, load_config
+from tests.util import synthetic_state_dict
+
+dev = torch.device("cuda", 0)
+mv = lambda d: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+def sync_time(fn, n, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
+
+# ---- config 3 ----
+for epoch, tag in ((1, "epoch<=prepare_epochs (backbone+semantic)"), (200, "epoch>prepare_epochs (full)")):
+    cfg = load_config("geoformer_scannet.yaml", batch_size=4, prepare_epochs=120)
+    m = GeoFormer(cfg); m.load_state_dict(synthetic_state_dict(m.state_dict(), 0)); m.to(dev); m.train()
+    crit = InstSetCriterion(cfg)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=1e-3)
+    batch = mv(scene.make_batch([scene.make_scene(int(n), 50 + i) for i, n in enumerate((150_000, 120_000, 180_000, 100_000))]))
+    def step():
+        np.random.seed(0)
+        out = m(batch, epoch)
+        loss, _ = crit(out, batch, epoch)
+        opt.zero_grad(); loss.backward(); opt.step()
+    dt = sync_time(step, 5)
+    print(f"config 3 training step batch=4 ({int(batch['locs'].shape[0])} pts) {tag}: {dt*1e3:.1f} ms  max mem {torch.cuda.max_memory_allocated()/2**30:.1f} GB")
+    del m, opt
+
+# ---- config 4 ----
+cfg = load_config("test_geoformer_fs_scannet.yaml")
+m = GeoFormerFS(cfg); m.load_state_dict(synthetic_state_dict(m.state_dict(), 2)); m.semantic_linear.bias.data[3] += 1.0
+m.to(dev); m.eval()
+def fsd(sc):
+    d = scene.make_batch([sc]); d["batch_offsets"] = d["offsets"]; d["support_masks"] = (d["instance_labels"] >= 0).long(); return mv(d)
+q = fsd(scene.make_scene(150_000, 1234))
+sups = [fsd(scene.make_scene(130_000, 70 + i)) for i in range(5)]
+for k in (1, 5):
+    def episode():
+        with torch.no_grad():
+            emb = torch.stack([m.process_support(sups[i], training=False) for i in range(k)]).mean(0)
+            return m(None, q, training=False, remember=False, support_embeddings=emb)
+    dt = sync_time(episode, 5)
+    print(f"config 4 few-shot episode 1-way {k}-shot (query 150k + {k} full support scenes): {dt*1e3:.1f} ms")
+def cached():
+    with torch.no_grad():
+        return m(None, q, training=False, remember=True, support_embeddings=emb0)
+with torch.no_grad():
+    emb0 = m.process_support(sups[0], training=False)
+print(f"config 4 cached query side (remember=True, decoder+mask head only): {sync_time(cached, 10)*1e3:.1f} ms")
