@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import spconv
 from ..spconv.modules import SparseModule
-from .layers import BackboneTransformer
+from .layers import BackboneTransformer, BatchNorm1d, PointwiseConv1d
 
 
 def bn_affine(bn):
@@ -143,9 +143,9 @@ class UBlock(nn.Module):
 def conv1d_bn_relu(in_channels, out_channels):
     """conv_with_kaiming_uniform("BN", activation=True) (geoformer_modules.py:132-161):
     Conv1d(k=1, no bias, kaiming_uniform a=1) + BatchNorm1d + ReLU."""
-    conv = nn.Conv1d(in_channels, out_channels, kernel_size=1, bias=False)
+    conv = PointwiseConv1d(in_channels, out_channels, kernel_size=1, bias=False)
     nn.init.kaiming_uniform_(conv.weight, a=1)
-    return nn.Sequential(conv, nn.BatchNorm1d(out_channels), nn.ReLU(inplace=True))
+    return nn.Sequential(conv, BatchNorm1d(out_channels), nn.ReLU(inplace=True))
 
 
 def random_downsample(batch_offsets, batch_size, n_subsample=30000):

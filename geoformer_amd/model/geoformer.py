@@ -20,7 +20,7 @@ from torch.nn import functional as F
 from .. import pointops, spconv
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
-from .layers import (GenericMLP, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
+from .layers import (BatchNorm1d, GenericMLP, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
                      TransformerDecoderLayer)
 from .set_abstraction import PointnetSAModuleVotesSeparate
 
@@ -85,7 +85,7 @@ class GeoFormer(nn.Module):
         m, classes = cfg.m, cfg.classes
         self.prepare_epochs = cfg.prepare_epochs
         self.fix_module = list(cfg.fix_module)
-        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        norm_fn = functools.partial(BatchNorm1d, eps=1e-4, momentum=0.1)
 
         # sparse-voxel U-Net
         self.input_conv = spconv.SparseSequential(
@@ -103,7 +103,7 @@ class GeoFormer(nn.Module):
         self.output_dim = m
         self.mask_conv_num = 3
         tower = [conv1d_bn_relu(m, m) for _ in range(self.mask_conv_num)]
-        tower.append(nn.Conv1d(m, self.output_dim, 1))
+        tower.append(PointwiseConv1d(m, self.output_dim, 1))
         self.add_module("mask_tower", nn.Sequential(*tower))
         self.add_module("before_embedding_tower", nn.Sequential(conv1d_bn_relu(cfg.dec_dim, self.output_dim)))
         self.use_coords = True
@@ -112,7 +112,7 @@ class GeoFormer(nn.Module):
         self.weight_nums = [(od + 3) * od, od]
         self.bias_nums = [od, 1]
         self.num_gen_params = sum(self.weight_nums) + sum(self.bias_nums)
-        self.controller = nn.Conv1d(od, self.num_gen_params, kernel_size=1)
+        self.controller = PointwiseConv1d(od, self.num_gen_params, kernel_size=1)
         nn.init.normal_(self.controller.weight, std=0.01)
         nn.init.constant_(self.controller.bias, 0)
 

@@ -19,7 +19,7 @@ import torch.nn as nn
 from . import config as _config
 from .backbone import random_downsample
 from .geoformer import GeoFormer, _offsets_list, cal_geodesic, get_batch_offsets
-from .layers import GenericMLP
+from .layers import BatchNorm1d, GenericMLP
 
 
 class GeoFormerFS(GeoFormer):
@@ -28,7 +28,7 @@ class GeoFormerFS(GeoFormer):
         super().__init__(cfg)
         m = cfg.m
         agg = 2 * m
-        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        norm_fn = functools.partial(BatchNorm1d, eps=1e-4, momentum=0.1)
         del self.detr_sem_head
         self.encoder_to_decoder_projection = GenericMLP(
             input_dim=agg * 3, hidden_dims=[agg * 3], output_dim=cfg.dec_dim, norm_fn_name="bn1d", activation="relu",

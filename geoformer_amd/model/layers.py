@@ -14,6 +14,66 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _bn_train(mod, x, dims):
+    """Training-mode batch norm written with plain reductions (autograd-differentiable).  MIOpen's training
+    BN costs ~1.1 ms of HOST time per call on this stack (87 calls = 97 ms of a 180 ms training forward)."""
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    mean = x.mean(dims)
+    var = x.var(dims, unbiased=False)
+    if mod.track_running_stats:
+        with torch.no_grad():
+            n = x.numel() // x.shape[1]
+            mom = mod.momentum if mod.momentum is not None else 1.0 / float(mod.num_batches_tracked + 1)
+            mod.running_mean.mul_(1 - mom).add_(mean.detach(), alpha=mom)
+            mod.running_var.mul_(1 - mom).add_(var.detach() * (n / max(n - 1, 1)), alpha=mom)
+            mod.num_batches_tracked += 1
+    y = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + mod.eps)
+    if mod.affine:
+        y = y * mod.weight.view(shape) + mod.bias.view(shape)
+    return y
+
+
+class BatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters, buffers and eval behaviour) with a lean training forward."""
+
+    def forward(self, x):
+        # [M,C] inputs (the sparse backbone) keep the library kernel, which is fine for that shape (measured:
+        # 59.6 vs 73.5 ms for the backbone-only training step); the [B,C,L] ones go the lean way
+        if self.training and x.dim() == 3 and x.numel() > 0:
+            return _bn_train(self, x, [0, 2])
+        return super().forward(x)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def forward(self, x):
+        if self.training and x.numel() > 0:
+            return _bn_train(self, x, [0, 2, 3])
+        return super().forward(x)
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d(kernel_size=1) evaluated as a GEMM.  Same parameters / state-dict entries; MIOpen has no
+    tuned kernels for these shapes on gfx950 and falls back to naive convolutions (38 ms per weight gradient
+    of a [1,16,N] conv measured in the training step), rocBLAS does not."""
+
+    def forward(self, x):
+        if self.kernel_size != (1,) or self.stride != (1,) or self.padding != (0,) or self.groups != 1:
+            return super().forward(x)
+        y = torch.matmul(self.weight[:, :, 0], x)
+        return y if self.bias is None else y + self.bias[:, None]
+
+
+class PointwiseConv2d(nn.Conv2d):
+    """nn.Conv2d(kernel_size=1) as a GEMM (see PointwiseConv1d)."""
+
+    def forward(self, x):
+        if self.kernel_size != (1, 1) or self.stride != (1, 1) or self.padding != (0, 0) or self.groups != 1:
+            return super().forward(x)
+        b, c, h, w = x.shape
+        y = torch.matmul(self.weight[:, :, 0, 0], x.reshape(b, c, h * w)).reshape(b, -1, h, w)
+        return y if self.bias is None else y + self.bias[None, :, None, None]
+
+
 # ------------------------------------------------------------------------------------------
 # model/helper.py:43-112  GenericMLP  (children live in ``self.layers``)
 # ------------------------------------------------------------------------------------------
@@ -25,7 +85,7 @@ class GenericMLP(nn.Module):
         act = {"relu": nn.ReLU, "gelu": nn.GELU}[activation]
         norm = None
         if norm_fn_name == "bn1d":
-            norm = nn.BatchNorm1d
+            norm = BatchNorm1d
         elif norm_fn_name == "ln":
             norm = (lambda c: nn.GroupNorm(1, c)) if use_conv else nn.LayerNorm
         elif norm_fn_name == "id":
@@ -36,7 +96,7 @@ class GenericMLP(nn.Module):
             dropout = [dropout] * len(hidden_dims)
 
         def lin(i, o, bias):
-            return nn.Conv1d(i, o, 1, bias=bias) if use_conv else nn.Linear(i, o, bias=bias)
+            return PointwiseConv1d(i, o, 1, bias=bias) if use_conv else nn.Linear(i, o, bias=bias)
 
         mods, prev = [], input_dim
         for i, h in enumerate(hidden_dims):

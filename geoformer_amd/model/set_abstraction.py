@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import pointops
+from .layers import BatchNorm2d, PointwiseConv2d
 
 
 # ---- autograd wrappers (pointnet2_utils.py:40-68, 71-104, 190-236, 239-269) -------------------
@@ -97,7 +98,7 @@ class QueryAndGroup(nn.Module):
 class _BN2d(nn.Sequential):
     def __init__(self, c):
         super().__init__()
-        self.add_module("bn", nn.BatchNorm2d(c))
+        self.add_module("bn", BatchNorm2d(c))
         nn.init.constant_(self[0].weight, 1.0)
         nn.init.constant_(self[0].bias, 0)
 
@@ -105,7 +106,7 @@ class _BN2d(nn.Sequential):
 class _ConvBNReLU2d(nn.Sequential):
     def __init__(self, cin, cout, act):
         super().__init__()
-        conv = nn.Conv2d(cin, cout, kernel_size=(1, 1), bias=False)
+        conv = PointwiseConv2d(cin, cout, kernel_size=(1, 1), bias=False)
         nn.init.kaiming_normal_(conv.weight)
         self.add_module("conv", conv)
         self.add_module("bn", _BN2d(cout))
