@@ -110,6 +110,31 @@ class UBlock(nn.Module):
                 (f"block{i}", block(c * (2 - i), c, norm_fn, indice_key=f"subm{indice_key_id}"))
                 for i in range(block_reps)))
 
+    def _transformer_fused(self, t):
+        """Inference: before-linear, the per-scene transformer and after-linear as one HIP launch
+        (csrc/backbone_attn.hip) instead of ~75 small ones."""
+        from .. import pointops
+
+        key = (self.before_transformer_linear.weight.data_ptr(), self.after_transformer_linear.bias.data_ptr())
+        hit = getattr(self, "_gf_tr_params", None)
+        if hit is None or hit[0] != key:
+            table, nl = pointops.backbone_transformer_params(self.before_transformer_linear, self.transformer,
+                                                             self.after_transformer_linear)
+            hit = (key, table, nl)
+            self._gf_tr_params = hit
+        coords = t._coords()
+        M = coords.shape[0]
+        if t.batch_size == 1:
+            offs = getattr(self, "_gf_offs1", None)
+            if offs is None or offs[0] != M or offs[1].device != coords.device:
+                offs = (M, torch.tensor([0, M], dtype=torch.int32, device=coords.device))
+                self._gf_offs1 = offs
+            offs = offs[1]
+        else:
+            counts = torch.bincount(coords[:, 0].long(), minlength=t.batch_size)[:t.batch_size]
+            offs = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
+        return pointops.backbone_transformer(t.features.contiguous(), coords, offs, t.batch_size, hit[1], hit[2])
+
     def forward(self, input):
         output = self.blocks(input)
         identity = spconv.SparseConvTensor(output.features, output.indices, output.spatial_shape, output.batch_size)
@@ -132,7 +157,9 @@ class UBlock(nn.Module):
             dec = self.deconv(self.u(self.conv(output)))
             output.features = torch.cat((identity.features, dec.features), dim=1)
             output = self.blocks_tail(output)
-        if self.before_transformer_linear is not None:
+        if self.before_transformer_linear is not None and _fusable(output) and output.features.shape[1] % 16 == 0:
+            output.features = self._transformer_fused(output)
+        elif self.before_transformer_linear is not None:
             feats = self.before_transformer_linear(output.features)
             feats = self.transformer(xyz=output.indices[:, 1:].float(), features=feats, batch_ids=output.indices[:, 0],
                                      batch_size=output.batch_size)

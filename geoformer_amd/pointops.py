@@ -152,6 +152,37 @@ def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
     return out
 
 
+def backbone_transformer_params(before, transformer, after):
+    """Device-pointer table of gf_backbone_transformer in the order include/geoformer_hip.h documents."""
+    import ctypes
+
+    ts = [before.weight, before.bias, transformer.position_linear.weight, transformer.position_linear.bias]
+    for layer in transformer.layers:
+        a, ff = layer.attn_1, layer.ff
+        ts += [layer.norm_1.alpha, layer.norm_1.bias, a.q_linear.weight, a.q_linear.bias, a.k_linear.weight,
+               a.k_linear.bias, a.v_linear.weight, a.v_linear.bias, a.out.weight, a.out.bias, layer.norm_2.alpha,
+               layer.norm_2.bias, ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias]
+    ts += [transformer.norm.alpha, transformer.norm.bias, after.weight, after.bias]
+    for t in ts:
+        _f32c(t.data, "transformer parameter")
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), len(transformer.layers)
+
+
+def backbone_transformer(feats, coords, scene_offsets, n_scenes, params, n_layers):
+    """Fused before-linear -> per-scene voxel transformer -> after-linear: feats [M,c], coords int32 [M,4],
+    scene_offsets int32 [n_scenes+1] on the device.  Returns [M,c]."""
+    _f32c(feats, "feats")
+    if coords.dtype != torch.int32 or not coords.is_contiguous():
+        raise RuntimeError("coords must be contiguous int32 [M,4]")
+    lib = _lib.load()
+    M, c = feats.shape
+    out = torch.empty_like(feats)
+    scratch = torch.empty(lib.gf_backbone_transformer_scratch_bytes(M) // 4, dtype=torch.float32, device=feats.device)
+    check(lib.gf_backbone_transformer(ptr(feats), ptr(coords), ptr(scene_offsets), n_scenes, M, c, n_layers, params,
+                                      ptr(scratch), ptr(out), stream_ptr()), "gf_backbone_transformer")
+    return out
+
+
 def decoder_pack_weights(W1, W2, Wv):
     lib = _lib.load()
     wp = torch.empty(lib.gf_decoder_wpack_floats(), dtype=torch.float32, device=W1.device)

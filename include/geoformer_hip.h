@@ -191,6 +191,28 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
                  int nq, int C, float* out, void* stream);
 
 /* ===================================================================================
+ * Backbone voxel transformer of the two deepest U-Net levels, fused (inference)
+ * (UBlock: model/geoformer/geoformer_modules.py:64-68,120-127; TransformerEncoder(d_model=128, N,
+ *  heads=4, d_ff=64): model/transformer.py:62-188)
+ * =================================================================================== */
+
+/* out = after(TransformerEncoder(xyz, before(feats))) per scene, one launch, one workgroup per scene.
+ *   feats fp32 [M,c] (c % 16 == 0), coords int32 [M,4] (b,x,y,z) with the rows of a scene contiguous,
+ *   scene_offsets int32 [n_scenes+1] (device), out fp32 [M,c],
+ *   scratch: gf_backbone_transformer_scratch_bytes(M) bytes,
+ *   params: HOST array of gf_backbone_transformer_num_params(n_layers) DEVICE pointers, nn.Linear weights
+ *   row-major [out,in], in this order:
+ *     before.W[128,c] before.b | position.W[128,3] position.b |
+ *     per layer: norm1.alpha norm1.bias  q.W q.b  k.W k.b  v.W v.b  out.W out.b  norm2.alpha norm2.bias
+ *                ff1.W[64,128] ff1.b  ff2.W[128,64] ff2.b |
+ *     norm.alpha norm.bias | after.W[c,128] after.b */
+size_t gf_backbone_transformer_scratch_bytes(int M);
+int gf_backbone_transformer_num_params(int n_layers);
+int gf_backbone_transformer(const float* feats, const int* coords, const int* scene_offsets, int n_scenes, int M,
+                            int c, int n_layers, const float* const* params, void* scratch, float* out,
+                            void* stream);
+
+/* ===================================================================================
  * Decoder cross-attention (TransformerDecoderLayer.forward_pre_rel, model/transformer_detr.py:443-454
  * with the relative embedding of GeoFormer.forward_decoder, model/geoformer/geoformer.py:619-651), fused
  * =================================================================================== */

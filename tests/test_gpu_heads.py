@@ -79,3 +79,35 @@ def test_decoder_layer_fused_matches_reference_golden(hip):
         n3 = layer.norm3(x)
         out = x + layer.linear2(layer.activation(layer.linear1(n3)))
     assert np.abs(out.cpu().numpy() - z["out"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("c,counts", [(96, [100]), (112, [7]), (96, [1]), (112, [33, 150]), (96, [300, 16, 17]), (32, [64])])
+def test_backbone_transformer_fused(hip, c, counts):
+    """One-launch voxel transformer of the deepest U-Net levels vs the PyTorch formulation of the same
+    modules (geoformer_modules.py:120-127, transformer.py:62-188), fp32 on the CPU."""
+    from geoformer_amd import pointops
+    from geoformer_amd.model.layers import BackboneTransformer
+
+    torch.manual_seed(c + sum(counts))
+    before = torch.nn.Linear(c, 128)
+    tr = BackboneTransformer(d_model=128, N=2, heads=4, d_ff=64)
+    after = torch.nn.Linear(128, c)
+    for p in list(tr.parameters()):
+        if p.dim() == 1:  # Norm alpha/bias and Linear biases away from their 1/0 defaults
+            p.data.add_(torch.randn_like(p) * 0.2)
+    tr.eval()
+    M = sum(counts)
+    g = torch.Generator().manual_seed(3)
+    coords = torch.cat([torch.cat([torch.full((n, 1), b), torch.randint(0, 9, (n, 3), generator=g)], 1)
+                        for b, n in enumerate(counts)]).int()
+    feats = torch.randn(M, c, generator=g)
+    with torch.no_grad():
+        ref = after(tr(xyz=coords[:, 1:].float(), features=before(feats), batch_ids=coords[:, 0],
+                       batch_size=len(counts)))
+        for m in (before, tr, after):
+            m.cuda()
+        table, nl = pointops.backbone_transformer_params(before, tr, after)
+        offs = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32).cuda()
+        out = pointops.backbone_transformer(feats.cuda(), coords.cuda(), offs, len(counts), table, nl)
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - ref.numpy()).max() < 1e-4  # tolerance of BASELINE.json north_star
