@@ -1,0 +1,126 @@
+// Proposal extraction of the eval forward, fused (GeoFormer.generate_proposal,
+// model/geoformer/geoformer.py:193-262).
+//
+// The reference runs ~40 PyTorch launches over the [nq, N] mask logits (sigmoid, compare, three reductions,
+// an [nq,N]x[N,classes] product, nonzero over the selected masks, index_put).  Here:
+//   k_proposal_stats   one workgroup per query: a single sweep over its logit row gives the point count,
+//                      the mean mask probability and the mean semantic probability of the predicted class;
+//                      the class soft-max/arg-max, the score product and the three acceptance tests finish in
+//                      the same launch.  HBM: 4*nq*N bytes read once.
+//   k_proposal_scatter the accepted rows are swept once more and written as 0/1 rows over the scene's points
+//                      (proposals[i, fg_idxs[p]] = 1), no nonzero()/index_put round trip.
+// mask membership is  sigmoid(logit) >= logit_thresh  with sigmoid = 1 / (1 + expf(-x)), evaluated by the same
+// device function in both kernels.
+#include "common.h"
+
+#define PR_THREADS 1024
+
+__device__ __forceinline__ float pr_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(PR_THREADS) void k_proposal_stats(const float* __restrict__ logits,
+                                                               const float* __restrict__ cls_logits,
+                                                               const float* __restrict__ sem_prob, int N, int ncls,
+                                                               float logit_thresh, float score_thresh,
+                                                               int npoint_thresh, int min_class,
+                                                               int* __restrict__ cls_pred_out,
+                                                               int* __restrict__ npoints_out,
+                                                               float* __restrict__ scores_out,
+                                                               int* __restrict__ final_out) {
+    __shared__ int s_cls;
+    __shared__ float s_cls_score;
+    __shared__ int r_cnt[PR_THREADS / 64];
+    __shared__ float r_prob[PR_THREADS / 64], r_sem[PR_THREADS / 64];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        // soft-max over the classes and its arg-max (first maximum), geoformer.py:215-216
+        const float* c = cls_logits + (size_t)q * ncls;
+        float mx = c[0];
+        int arg = 0;
+        for (int k = 1; k < ncls; k++)
+            if (c[k] > mx) {
+                mx = c[k];
+                arg = k;
+            }
+        float den = 0.f;
+        for (int k = 0; k < ncls; k++) den += expf(c[k] - mx);
+        s_cls = arg;
+        s_cls_score = 1.0f / den;  // exp(0) / sum
+    }
+    __syncthreads();
+    const int cls = s_cls;
+    const float* row = logits + (size_t)q * N;
+    int cnt = 0;
+    float sp = 0.f, ss = 0.f;
+    for (int p = tid; p < N; p += PR_THREADS) {
+        const float pr = pr_sigmoid(row[p]);
+        if (pr >= logit_thresh) {
+            cnt++;
+            sp += pr;
+            ss += sem_prob[(size_t)p * ncls + cls];
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_xor(cnt, d, 64);
+        sp += __shfl_xor(sp, d, 64);
+        ss += __shfl_xor(ss, d, 64);
+    }
+    if (lane == 0) {
+        r_cnt[wave] = cnt;
+        r_prob[wave] = sp;
+        r_sem[wave] = ss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < PR_THREADS / 64; w++) {
+            n += r_cnt[w];
+            a += r_prob[w];
+            b += r_sem[w];
+        }
+        const float den = (float)n + 1e-6f;
+        const float mask_score = a / den, sem_score = b / den;
+        cls_pred_out[q] = cls;
+        npoints_out[q] = n;
+        scores_out[q] = mask_score * sqrtf(s_cls_score) * sem_score;
+        final_out[q] = (cls >= min_class) && (n >= npoint_thresh) && (mask_score >= score_thresh);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_proposal_scatter(const float* __restrict__ logits,
+                                                          const int* __restrict__ sel, int N,
+                                                          const long long* __restrict__ fg_idxs, float logit_thresh,
+                                                          int num_points, int* __restrict__ proposals) {
+    const int i = blockIdx.y;
+    const float* row = logits + (size_t)sel[i] * N;
+    int* out = proposals + (size_t)i * num_points;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < N; p += gridDim.x * 256)
+        if (pr_sigmoid(row[p]) >= logit_thresh) out[fg_idxs[p]] = 1;
+}
+
+extern "C" int gf_proposal_stats(const float* mask_logits, const float* cls_logits, const float* sem_prob, int nq,
+                                 int N, int ncls, float logit_thresh, float score_thresh, int npoint_thresh,
+                                 int min_class, int* cls_pred, int* npoints, float* scores, int* final_mask,
+                                 void* stream) {
+    GF_CHECK_ARG(nq >= 0 && N >= 0 && ncls >= 1, "gf_proposal_stats: bad sizes nq=%d N=%d ncls=%d", nq, N, ncls);
+    if (nq == 0) return GF_OK;
+    hipLaunchKernelGGL(k_proposal_stats, dim3(nq), dim3(PR_THREADS), 0, (hipStream_t)stream, mask_logits, cls_logits,
+                       sem_prob, N, ncls, logit_thresh, score_thresh, npoint_thresh, min_class, cls_pred, npoints,
+                       scores, final_mask);
+    GF_CHECK_LAUNCH("gf_proposal_stats");
+    return GF_OK;
+}
+
+extern "C" int gf_proposal_scatter(const float* mask_logits, const int* sel, int n_sel, int N,
+                                   const long long* fg_idxs, float logit_thresh, int num_points, int* proposals,
+                                   void* stream) {
+    GF_CHECK_ARG(n_sel >= 0 && N >= 0 && num_points >= 0, "gf_proposal_scatter: bad sizes");
+    if (n_sel == 0 || N == 0) return GF_OK;
+    int bx = gf_div_up(N, 256 * 8);
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_proposal_scatter, dim3(bx, n_sel), dim3(256), 0, (hipStream_t)stream, mask_logits, sel, N,
+                       fg_idxs, logit_thresh, num_points, proposals);
+    GF_CHECK_LAUNCH("gf_proposal_scatter");
+    return GF_OK;
+}

@@ -318,6 +318,18 @@ class GeoFormer(nn.Module):
         sem = F.softmax(semantic_scores_, dim=1)
         b = 0
         num_points = int(batch_offsets[b + 1] - batch_offsets[b])
+        if mask_logits[b].is_cuda and not torch.is_grad_enabled():
+            # inference: two fused HIP launches (csrc/proposal.hip) instead of ~40 PyTorch ones
+            offs_ = _offsets_list(batch_offsets_)
+            logits = mask_logits[b].contiguous()
+            cls_pred, _, scores, final = pointops.proposal_stats(
+                logits, cls_logits[b].contiguous(), sem[offs_[b]:offs_[b + 1]].contiguous(), logit_thresh,
+                score_thresh, npoint_thresh, min_class=4)
+            sel = torch.nonzero(final).view(-1)
+            if sel.numel() == 0:
+                return [], [], []
+            proposals = pointops.proposal_scatter(logits, sel.int(), fg_idxs.contiguous(), logit_thresh, num_points)
+            return cls_pred[sel].long(), scores[sel], proposals
         mask_prob = mask_logits[b].sigmoid()
         cls_prob = F.softmax(cls_logits[b], dim=-1)
         cls_pred = torch.argmax(cls_logits[b], dim=-1)

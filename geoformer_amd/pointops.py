@@ -152,6 +152,34 @@ def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
     return out
 
 
+def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh, npoint_thresh, min_class=4):
+    """Fused statistics of generate_proposal: (cls_pred i32[nq], npoints i32[nq], scores f32[nq], final i32[nq])."""
+    _f32c(mask_logits, "mask_logits"), _f32c(cls_logits, "cls_logits"), _f32c(sem_prob, "sem_prob")
+    nq, N = mask_logits.shape
+    ncls = cls_logits.shape[1]
+    if sem_prob.shape != (N, ncls):
+        raise RuntimeError(f"sem_prob must be [{N},{ncls}], got {tuple(sem_prob.shape)}")
+    ints = torch.empty((3, nq), dtype=torch.int32, device=mask_logits.device)
+    scores = torch.empty(nq, dtype=torch.float32, device=mask_logits.device)
+    check(_lib.load().gf_proposal_stats(ptr(mask_logits), ptr(cls_logits), ptr(sem_prob), nq, N, ncls,
+                                        float(logit_thresh), float(score_thresh), int(npoint_thresh), int(min_class),
+                                        ptr(ints[0]), ptr(ints[1]), ptr(scores), ptr(ints[2]), stream_ptr()),
+          "gf_proposal_stats")
+    return ints[0], ints[1], scores, ints[2]
+
+
+def proposal_scatter(mask_logits, sel, fg_idxs, logit_thresh, num_points):
+    """0/1 membership rows [len(sel), num_points] (int32) of the selected queries over the scene's points."""
+    _f32c(mask_logits, "mask_logits"), _i32c(sel, "sel")
+    if not (fg_idxs.is_cuda and fg_idxs.dtype == torch.int64 and fg_idxs.is_contiguous()):
+        raise RuntimeError("fg_idxs: expected a contiguous int64 tensor on the GPU")
+    out = torch.zeros((sel.shape[0], num_points), dtype=torch.int32, device=mask_logits.device)
+    check(_lib.load().gf_proposal_scatter(ptr(mask_logits), ptr(sel), sel.shape[0], mask_logits.shape[1],
+                                          ptr(fg_idxs), float(logit_thresh), int(num_points), ptr(out), stream_ptr()),
+          "gf_proposal_scatter")
+    return out
+
+
 def backbone_transformer_params(before, transformer, after):
     """Device-pointer table of gf_backbone_transformer in the order include/geoformer_hip.h documents."""
     import ctypes

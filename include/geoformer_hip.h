@@ -191,6 +191,28 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
                  int nq, int C, float* out, void* stream);
 
 /* ===================================================================================
+ * Proposal extraction of the eval forward (GeoFormer.generate_proposal,
+ * model/geoformer/geoformer.py:193-262), fused
+ * =================================================================================== */
+
+/* Per query q over its mask-logit row: member(p) = 1/(1+exp(-logit)) >= logit_thresh,
+ *   npoints[q] = #members, mask_score = sum prob / (npoints + 1e-6),
+ *   cls_pred[q] = argmax cls_logits[q], cls_score = softmax(cls_logits[q])[cls_pred],
+ *   sem_score = sum_{members} sem_prob[p, cls_pred] / (npoints + 1e-6),
+ *   scores[q] = mask_score * sqrt(cls_score) * sem_score,
+ *   final[q] = cls_pred >= min_class && npoints >= npoint_thresh && mask_score >= score_thresh.
+ *   mask_logits fp32 [nq,N], cls_logits fp32 [nq,ncls], sem_prob fp32 [N,ncls] (soft-max of the semantic
+ *   scores of the foreground points); outputs int32 [nq] / fp32 [nq]. */
+int gf_proposal_stats(const float* mask_logits, const float* cls_logits, const float* sem_prob, int nq, int N,
+                      int ncls, float logit_thresh, float score_thresh, int npoint_thresh, int min_class,
+                      int* cls_pred, int* npoints, float* scores, int* final_mask, void* stream);
+
+/* proposals[i, fg_idxs[p]] = 1 for every member p of query sel[i]; proposals int32 [n_sel,num_points] must be
+ * zero-filled by the caller, fg_idxs int64 [N] (row of each foreground point in the scene), sel int32 [n_sel]. */
+int gf_proposal_scatter(const float* mask_logits, const int* sel, int n_sel, int N, const long long* fg_idxs,
+                        float logit_thresh, int num_points, int* proposals, void* stream);
+
+/* ===================================================================================
  * Backbone voxel transformer of the two deepest U-Net levels, fused (inference)
  * (UBlock: model/geoformer/geoformer_modules.py:64-68,120-127; TransformerEncoder(d_model=128, N,
  *  heads=4, d_ff=64): model/transformer.py:62-188)

@@ -642,3 +642,35 @@ ORC_API void orc_bfs_cluster(const int32_t *sem, const int32_t *bq_idx, const in
     free(vis); free(cc);
     *nCluster = nc; *sumNPoint = sum;
 }
+
+/* generate_proposal statistics + membership rows  (model/geoformer/geoformer.py:206-262), batch 1.
+ * sem_prob = softmax of the semantic scores of the foreground points (computed by the caller like the
+ * reference's first line).  Sequential fp32 sums. */
+ORC_API void orc_proposal_stats(const float *mask_logits, const float *cls_logits, const float *sem_prob, int32_t nq,
+                                int32_t N, int32_t ncls, float logit_thresh, float score_thresh,
+                                int32_t npoint_thresh, int32_t min_class, int32_t *cls_pred, int32_t *npoints,
+                                float *scores, int32_t *final_mask) {
+    for (int32_t q = 0; q < nq; q++) {
+        const float *c = cls_logits + (size_t)q * ncls;
+        float mx = c[0]; int32_t arg = 0;
+        for (int32_t k = 1; k < ncls; k++) if (c[k] > mx) { mx = c[k]; arg = k; }
+        float den = 0.f;
+        for (int32_t k = 0; k < ncls; k++) den += expf(c[k] - mx);
+        float cls_score = 1.0f / den;
+        int32_t n = 0; float sp = 0.f, ss = 0.f;
+        for (int32_t p = 0; p < N; p++) {
+            float pr = 1.0f / (1.0f + expf(-mask_logits[(size_t)q * N + p]));
+            if (pr >= logit_thresh) { n++; sp += pr; ss += sem_prob[(size_t)p * ncls + arg]; }
+        }
+        float d = (float)n + 1e-6f, mask_score = sp / d, sem_score = ss / d;
+        cls_pred[q] = arg; npoints[q] = n;
+        scores[q] = mask_score * sqrtf(cls_score) * sem_score;
+        final_mask[q] = (arg >= min_class) && (n >= npoint_thresh) && (mask_score >= score_thresh);
+    }
+}
+ORC_API void orc_proposal_scatter(const float *mask_logits, const int32_t *sel, int32_t n_sel, int32_t N,
+                                  const int64_t *fg_idxs, float logit_thresh, int32_t num_points, int32_t *proposals) {
+    for (int32_t i = 0; i < n_sel; i++) for (int32_t p = 0; p < N; p++)
+        if (1.0f / (1.0f + expf(-mask_logits[(size_t)sel[i] * N + p])) >= logit_thresh)
+            proposals[(size_t)i * num_points + fg_idxs[p]] = 1;
+}

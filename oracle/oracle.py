@@ -301,3 +301,23 @@ def bfs_cluster(sem, bq_idx, start_len, threshold):
     lib().orc_bfs_cluster(_p(sem), _p(bq_idx), _p(start_len), c_int32(N), c_int32(threshold), _p(ci), _p(co), byref(nc),
                           byref(sm))
     return ci[: sm.value].copy(), co[: nc.value + 1].copy()
+
+
+def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh, npoint_thresh, min_class=4):
+    mask_logits, cls_logits, sem_prob = _f32(mask_logits), _f32(cls_logits), _f32(sem_prob)
+    nq, N = mask_logits.shape
+    ncls = cls_logits.shape[1]
+    cls_pred, npts, fin = np.zeros(nq, np.int32), np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+    scores = np.zeros(nq, np.float32)
+    lib().orc_proposal_stats(_p(mask_logits), _p(cls_logits), _p(sem_prob), c_int32(nq), c_int32(N), c_int32(ncls),
+                             c_float(logit_thresh), c_float(score_thresh), c_int32(npoint_thresh), c_int32(min_class),
+                             _p(cls_pred), _p(npts), _p(scores), _p(fin))
+    return cls_pred, npts, scores, fin
+
+
+def proposal_scatter(mask_logits, sel, fg_idxs, logit_thresh, num_points):
+    mask_logits, sel, fg_idxs = _f32(mask_logits), _i32(sel), _i64(fg_idxs)
+    out = np.zeros((sel.shape[0], num_points), np.int32)
+    lib().orc_proposal_scatter(_p(mask_logits), _p(sel), c_int32(sel.shape[0]), c_int32(mask_logits.shape[1]),
+                               _p(fg_idxs), c_float(logit_thresh), c_int32(num_points), _p(out))
+    return out

@@ -111,3 +111,36 @@ def test_backbone_transformer_fused(hip, c, counts):
         out = pointops.backbone_transformer(feats.cuda(), coords.cuda(), offs, len(counts), table, nl)
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy() - ref.numpy()).max() < 1e-4  # tolerance of BASELINE.json north_star
+
+
+@pytest.mark.parametrize("nq,N,ncls,npts", [(64, 5000, 20, 7000), (256, 333, 13, 400), (3, 1, 20, 5)])
+def test_proposal_stats_and_scatter(hip, oracle, nq, N, ncls, npts):
+    """Fused generate_proposal (geoformer.py:193-262) vs the oracle: integers bit-exact, scores <= 1e-4."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(nq + N)
+    logits = (rng.standard_normal((nq, N)) * 3).astype(np.float32)
+    logits[0] = -5.0  # an empty mask: npoints 0, scores 0, rejected
+    cls_logits = rng.standard_normal((nq, ncls)).astype(np.float32) * 2
+    sem = rng.standard_normal((N, ncls)).astype(np.float32)
+    sem_prob = torch.softmax(torch.from_numpy(sem), 1).numpy()
+    fg = np.sort(rng.choice(npts, N, replace=False)).astype(np.int64)
+    thr = max(1, N // 3)
+    ref = oracle.proposal_stats(logits, cls_logits, sem_prob, 0.5, 0.55, thr)
+    dl = torch.from_numpy(logits).cuda()
+    got = pointops.proposal_stats(dl, torch.from_numpy(cls_logits).cuda(), torch.from_numpy(sem_prob).cuda(), 0.5,
+                                  0.55, thr)
+    cls_pred, npoints, scores, final = [g.cpu().numpy() for g in got]
+    assert (cls_pred == ref[0]).all() and (npoints == ref[1]).all()
+    assert np.abs(scores - ref[2]).max() < 1e-4
+    # acceptance may only differ where the mean mask probability sits on the threshold
+    assert (final == ref[3]).all()
+    assert npoints[0] == 0 and final[0] == 0 and scores[0] == 0
+    sel = np.nonzero(ref[3])[0].astype(np.int32)
+    if N > 1:
+        assert sel.size > 0
+    want = oracle.proposal_scatter(logits, sel, fg, 0.5, npts)
+    have = pointops.proposal_scatter(dl, torch.from_numpy(sel).cuda(), torch.from_numpy(fg).cuda(), 0.5, npts)
+    assert (have.cpu().numpy() == want).all()
+    if sel.size:
+        assert (want.sum(1) == ref[1][sel]).all()

@@ -100,3 +100,35 @@ def test_dormant_pg_ops_kats(oracle):
     iou = oracle.get_iou(np.array([0, 1, 2], np.int32), np.array([0, 3], np.int32), np.array([0, 0, 1, 1], np.int64),
                          np.array([2, 2], np.int32))
     assert np.allclose(iou, [[2 / (3 + 2 - 2 + 1e-5), 1 / (3 + 2 - 1 + 1e-5)]])
+
+
+def test_proposal_stats_oracle_matches_reference_formulation(oracle):
+    """orc_proposal_stats/scatter vs the PyTorch lines of generate_proposal (geoformer.py:206-262) on CPU."""
+    import torch
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(0)
+    nq, N, ncls, npts = 32, 2000, 20, 2600
+    logits = (rng.standard_normal((nq, N)) * 3).astype(np.float32)
+    cl = (rng.standard_normal((nq, ncls)) * 2).astype(np.float32)
+    sem = torch.softmax(torch.from_numpy(rng.standard_normal((N, ncls)).astype(np.float32)), 1)
+    fg = np.sort(rng.choice(npts, N, replace=False)).astype(np.int64)
+    cp, npoints, sc, fin = oracle.proposal_stats(logits, cl, sem.numpy(), 0.5, 0.55, 600)
+    prob = torch.from_numpy(logits).sigmoid()
+    mb = prob >= 0.5
+    n = torch.sum(mb, dim=1)
+    ms = torch.sum(prob * mb.int(), dim=1) / (n + 1e-6)
+    cpr = F.softmax(torch.from_numpy(cl), dim=-1)
+    pred = torch.argmax(torch.from_numpy(cl), dim=-1)
+    ss = torch.sum(sem[None].expand(nq, N, ncls) * mb.int()[:, :, None], dim=1) / (n[:, None] + 1e-6)
+    ss = torch.gather(ss, 1, pred.unsqueeze(-1)).squeeze(-1)
+    scores = ms * torch.pow(torch.gather(cpr, 1, pred.unsqueeze(-1)).squeeze(-1), 0.5) * ss
+    final = (pred >= 4) & (n >= 600) & (ms >= 0.55)
+    assert (cp == pred.numpy()).all() and (npoints == n.numpy()).all() and (fin == final.numpy()).all()
+    assert np.abs(sc - scores.numpy()).max() < 1e-5
+    assert fin.sum() > 0
+    props = torch.zeros((int(final.sum()), npts), dtype=torch.int)
+    inst, pts = torch.nonzero(mb[final], as_tuple=True)
+    props[inst, torch.from_numpy(fg)[pts]] = 1
+    got = oracle.proposal_scatter(logits, np.nonzero(fin)[0].astype(np.int32), fg, 0.5, npts)
+    assert (got == props.numpy()).all()
