@@ -43,15 +43,22 @@ class _Voxelization(torch.autograd.Function):
 voxelization = _Voxelization.apply
 
 
-def get_batch_offsets(batch_idxs, bs):
-    """offsets[i+1] = offsets[i] + count(batch_idxs == i)  (util/utils.py:132-142), one device op."""
-    counts = torch.bincount(batch_idxs.long(), minlength=bs)[:bs]
-    return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
-
-
 import threading
 
 _OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
+
+
+def get_batch_offsets(batch_idxs, bs):
+    """offsets[i+1] = offsets[i] + count(batch_idxs == i)  (util/utils.py:132-142), one device op."""
+    if bs == 1:
+        # one scene: the offsets are known on the host, no device round trip when they are read back
+        n = int(batch_idxs.shape[0])
+        t = torch.tensor([0, n], dtype=torch.int32, device=batch_idxs.device)
+        _OFFS_CACHE.key, _OFFS_CACHE.val = t, [0, n]
+        return t
+    counts = torch.bincount(batch_idxs.long(), minlength=bs)[:bs]
+    return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
+
 
 
 def _offsets_list(t):
@@ -62,15 +69,26 @@ def _offsets_list(t):
 
 
 @torch.no_grad()
-def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighbor=64, radius=0.05, n_queries=128):
+def knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05):
+    """Per scene the radius-limited kNN graph of the foreground points (find_knn + the radius filter of
+    geodesic_utils.py:11-24,110-125).  Depends on the points only, so the forward issues it before the
+    host-side RNG draw and FPS."""
+    offs = _offsets_list(batch_offsets_)
+    return [pointops.knn_radius(locs_float_[offs[b]:offs[b + 1]].contiguous(), neighbor, radius, sqrt_out=True)
+            for b in range(batch_size)]
+
+
+@torch.no_grad()
+def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighbor=64, radius=0.05, n_queries=128,
+                 graphs=None):
     """cal_geodesic_vectorize (geodesic_utils.py:91-164): per scene a kNN graph (k=neighbor, edges
     within `radius`) and a hop-synchronous BFS from the first n_queries FPS indices -- interpreted,
     like the reference does, as indices into the scene's un-permuted foreground points."""
-    offs = _offsets_list(batch_offsets_)
+    if graphs is None:
+        graphs = knn_graphs(locs_float_, batch_offsets_, pre_enc_inds.shape[0], neighbor, radius)
     out = []
     for b in range(pre_enc_inds.shape[0]):
-        pts = locs_float_[offs[b]:offs[b + 1]].contiguous()
-        D, I, deg = pointops.knn_radius(pts, neighbor, radius, sqrt_out=True)
+        D, I, deg = graphs[b]
         src = pre_enc_inds[b][:n_queries].int().contiguous()
         out.append(pointops.geodesic_bfs(D, I, deg, src, radius, max_step))
     return out
@@ -376,7 +394,12 @@ class GeoFormer(nn.Module):
         locs_float_ = locs_float[fg_idxs]
         output_feats_ = output_feats[fg_idxs]
         semantic_scores_ = semantic_scores[fg_idxs]
+        offs_ = _offsets_list(batch_offsets_)  # the only read-back of this stretch, before the heavy launches
         mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
+        # the kNN graphs need the points only: on the device they run under the host's RNG draw
+        graphs = None
+        if locs_float_.is_cuda and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0:
+            graphs = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
 
         contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
         if contexts is None:
@@ -386,7 +409,7 @@ class GeoFormer(nn.Module):
         query_locs = context_locs[:, :cfg.n_query_points, :]
 
         geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128 if self.training else 256,
-                                 neighbor=64, radius=0.05, n_queries=cfg.n_query_points)
+                                 neighbor=64, radius=0.05, n_queries=cfg.n_query_points, graphs=graphs)
         dec_outputs = self.forward_decoder(context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds)
 
         if training:
