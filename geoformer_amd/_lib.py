@@ -12,6 +12,8 @@ from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
 
 from ._build import LIB_PATH
 
+LIB_PATH = os.environ.get("GF_LIB_PATH", LIB_PATH)  # dev knob: load an experimental build of the library
+
 _lib = None
 
 

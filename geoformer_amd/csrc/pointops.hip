@@ -240,50 +240,83 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return a > b ? a : b;
 }
 
-// arg-max over the wave of (dist desc, key asc); dist as non-negative float bits, "none" = (0, KEY_NONE)
+// arg-max over the wave of (dist desc, key asc); dist as non-negative float bits, "none" = (0, KEY_NONE).
+// The maximum distance usually has a single owner: its key then comes from one readlane instead of a
+// second reduction.
 __device__ __forceinline__ void wave_best(unsigned& dbits, unsigned& key) {
     const unsigned md = wave_max_u32(dbits);
-    const unsigned cand = dbits == md ? (FPS_KEY_NONE - key) : 0u;
-    const unsigned mk = wave_max_u32(cand);
+    const unsigned long long owners = __ballot(dbits == md);
+    if (__popcll(owners) == 1) {
+        key = (unsigned)__builtin_amdgcn_readlane((int)key, __builtin_ctzll(owners));
+    } else {
+        const unsigned cand = dbits == md ? (FPS_KEY_NONE - key) : 0u;
+        key = FPS_KEY_NONE - wave_max_u32(cand);
+    }
     dbits = md;
-    key = FPS_KEY_NONE - mk;
 }
 
-#define FPS_WAVES 16
-#define FPS_MAXG 16
-#define FPS_K 4  // candidates exchanged per round and workgroup
+#ifndef FPS_WAVES
+#define FPS_WAVES 16  // waves per workgroup
+#endif
+#ifndef FPS_MAXG
+#define FPS_MAXG 16   // cooperating workgroups per point set
+#endif
+#ifndef FPS_KPUB
+#define FPS_KPUB 4    // candidates a workgroup publishes per exchange
+#endif
+#define FPS_K 8       // picks validated per exchange (FPS_K * FPS_K == 64: one lane per pair check)
+#define FPS_NG (FPS_MAXG * FPS_KPUB / 64)  // granules a lane gathers
+#define FPS_TAG (1ull << 63)
 
-// 62-bit candidate code: [61:31] distance bits, [30:0] KEY_NONE - key; larger = better; 0 = none
+// 64-bit candidate code: [63] exchange tag, [62:32] distance bits (non-negative float), [31:1] KEY_NONE - key,
+// [0] "last entry its source forwards"; larger = better; 0 = none
 __device__ __forceinline__ unsigned long long fps_code(unsigned dbits, unsigned key) {
-    return ((unsigned long long)dbits << 31) | (unsigned long long)(FPS_KEY_NONE - key);
+    return ((unsigned long long)dbits << 32) | ((unsigned long long)(FPS_KEY_NONE - key) << 1);
 }
-__device__ __forceinline__ unsigned long long wave_max_u62(unsigned long long c) {
-    unsigned d = (unsigned)(c >> 31), k = FPS_KEY_NONE - (unsigned)(c & 0x7fffffffull);
-    wave_best(d, k);
-    return fps_code(d, k);
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long c) {
+    const unsigned hi = (unsigned)(c >> 32), md = wave_max_u32(hi);
+    const unsigned long long owners = __ballot(hi == md);
+    unsigned ml;
+    if (__popcll(owners) == 1) {
+        ml = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)c, __builtin_ctzll(owners));
+    } else {
+        ml = wave_max_u32(hi == md ? (unsigned)c : 0u);
+    }
+    return ((unsigned long long)md << 32) | ml;
+}
+__device__ __forceinline__ unsigned long long glt_lane_fix(const unsigned long long* g, int lane) {
+    unsigned long long v = g[0];
+#pragma unroll
+    for (int t = 1; t < 8; t++) v = lane == t ? g[t] : v;
+    return v;
+}
+__device__ __forceinline__ int fps_code_index(unsigned long long c) {
+    return c ? (int)((FPS_KEY_NONE - (unsigned)((c >> 1) & 0x7fffffffull)) & 0x3fffffu) : 0;
 }
 
 // Several picks per exchange.  After the distances have absorbed the picks of the previous exchange,
 // the best candidate c1 is the next pick by definition; the runner-up c2 is the pick after that iff
 // c1 does not lower its distance (d(c2,c1) >= tmp[c2]): nobody else can then overtake it, ties
 // included, because every other distance only decreases and c2 already preceded the rest in the
-// (distance desc, key asc) order.  The same argument chains to c3, c4.  FPS picks are far apart by
-// construction, so ~3.5 of 4 candidates are accepted on ScanNet-like scenes and the serial chain of
-// 2047 cross-CU exchanges shrinks to ~600.  Each level (lane -> wave -> workgroup -> grid) forwards
-// a sorted prefix of its candidates and merging stops after consuming the LAST entry a source
-// forwarded (its next one is unknown), which keeps the result exact.
+// (distance desc, key asc) order.  The same argument chains to c3, c4, ...  FPS picks are far apart by
+// construction, so ~5.5 of 8 candidates are accepted on ScanNet-like scenes and the serial chain of
+// 2047 cross-CU exchanges shrinks to ~370.  Each level (lane -> wave -> workgroup -> grid) forwards
+// a sorted prefix of its candidates with the last one flagged, and merging stops after consuming a
+// flagged entry (the source's next one is unknown), which keeps the result exact.
 template <int P>
 __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict__ xyz, int n, int m, int G,
                                                         int bs_log2, int batch0,
                                                         unsigned long long* __restrict__ slots,
                                                         int32_t* __restrict__ idxs, int* __restrict__ err) {
+    static_assert(FPS_K * FPS_K == 64 && FPS_NG >= 1 && FPS_NG * 64 == FPS_MAXG * FPS_KPUB && FPS_KPUB <= FPS_K &&
+                      FPS_WAVES * 2 <= 64, "lane mappings of the exchange");
     __shared__ unsigned long long s_part[2][FPS_WAVES * 2];
     __shared__ int s_pick[2][FPS_K + 1];
     __shared__ float s_xyz[2][FPS_K * 3];
     const int bi = batch0 + blockIdx.y, wg = blockIdx.x;
     xyz += (size_t)bi * n * 3;
     idxs += (size_t)bi * m;
-    slots += (size_t)bi * 2 * FPS_MAXG * FPS_K;
+    slots += (size_t)bi * 2 * FPS_MAXG * FPS_KPUB;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int gtid = wg * (FPS_WAVES * 64) + threadIdx.x;
     const int stride = G * FPS_WAVES * 64;
@@ -360,117 +393,149 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
         unsigned d2w = cd, k2w = ck;
         wave_best(d2w, k2w);
         if (lane == 0) {
-            s_part[par][wid * 2 + 0] = fps_code(d1, k1);
-            s_part[par][wid * 2 + 1] = fps_code(d2w, k2w);
+            unsigned long long c1 = fps_code(d1, k1), c2 = fps_code(d2w, k2w);
+            if (c2 != 0ull) c2 |= 1ull;  // the last entry this wave forwards
+            else if (c1 != 0ull) c1 |= 1ull;
+            s_part[par][wid * 2 + 0] = c1;
+            s_part[par][wid * 2 + 1] = c2;
         }
         __syncthreads();
-        // 3) wave 0: merge the 32 wave candidates into the workgroup's sorted prefix (<= FPS_K entries)
         if (wid == 0) {
+            // 3) merge the wave candidates into the workgroup's sorted prefix (<= FPS_KPUB entries)
             unsigned long long mine = lane < FPS_WAVES * 2 ? s_part[par][lane] : 0ull;
-            unsigned long long wgc[FPS_K];
+            unsigned long long wgc[FPS_KPUB];
             bool stop = false;
+            int cnt = 0;
 #pragma unroll
-            for (int t = 0; t < FPS_K; t++) {
-                unsigned long long best = stop ? 0ull : wave_max_u62(mine);
-                wgc[t] = best;
+            for (int t = 0; t < FPS_KPUB; t++) {
+                const unsigned long long best = stop ? 0ull : wave_max_u64(mine);
+                wgc[t] = best & ~1ull;
                 if (best != 0ull) {
-                    // owner lane retires its entry; consuming a wave's second (= last forwarded) entry, or a
-                    // first entry whose successor is empty, ends the prefix
-                    const bool own = mine == best;
-                    const unsigned long long bal = __ballot(own);
-                    const int ol = __builtin_ctzll(bal);
-                    const unsigned long long succ = __shfl(mine, ol | 1, 64);
-                    if (own) mine = 0ull;
-                    if ((ol & 1) || succ == 0ull) stop = true;
+                    if (mine == best) mine = 0ull;
+                    if (best & 1ull) stop = true;
+                    cnt = t + 1;
                 } else {
                     stop = true;
                 }
             }
-            // 4) grid level: publish FPS_K granules, gather everybody's, merge the same way
-            unsigned long long gl[FPS_K];
-            if (G > 1) {
-                unsigned long long* rs = slots + (size_t)par * FPS_MAXG * FPS_K;
-                const unsigned long long tag = (unsigned long long)(round & 3) << 62;
-                if (lane < FPS_K) {
-                    unsigned long long v = wgc[0];
 #pragma unroll
-                    for (int t = 1; t < FPS_K; t++) v = lane == t ? wgc[t] : v;
-                    __hip_atomic_store(rs + wg * FPS_K + lane, tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int t = 0; t < FPS_KPUB; t++)
+                if (t == cnt - 1) wgc[t] |= 1ull;  // ... and the last one this workgroup forwards
+            // 4) grid level: publish FPS_KPUB granules, gather everybody's (FPS_NG per lane)
+            unsigned long long v[FPS_NG];
+            v[0] = wgc[0];
+#pragma unroll
+            for (int t = 1; t < FPS_KPUB; t++) v[0] = lane == t ? wgc[t] : v[0];
+            if (lane >= FPS_KPUB) v[0] = 0ull;
+#pragma unroll
+            for (int j = 1; j < FPS_NG; j++) v[j] = 0ull;
+            if (G > 1) {
+                unsigned long long* rs = slots + (size_t)par * FPS_MAXG * FPS_KPUB;
+                const unsigned long long tag = ((unsigned long long)((round + 1) >> 1) & 1ull) << 63;
+                if (lane < FPS_KPUB)
+                    __hip_atomic_store(rs + wg * FPS_KPUB + lane, tag | v[0], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                bool ok[FPS_NG];
+                bool all = true;
+#pragma unroll
+                for (int j = 0; j < FPS_NG; j++) {
+                    ok[j] = !(lane + 64 * j < G * FPS_KPUB);
+                    all = all && ok[j];
+                    v[j] = 0ull;
                 }
-                unsigned long long v = 0ull;
-                if (lane < G * FPS_K) {
-                    int spins = 0;
-                    while (true) {
-                        v = __hip_atomic_load(rs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((v >> 62) == (tag >> 62)) break;
-                        if (++spins > FPS_SPIN_LIMIT) {
-                            *err = 1;
-                            break;
+                int spins = 0;
+                while (!all) {
+                    all = true;
+#pragma unroll
+                    for (int j = 0; j < FPS_NG; j++) {
+                        if (!ok[j]) {
+                            v[j] = __hip_atomic_load(rs + lane + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok[j] = (v[j] & FPS_TAG) == tag;
+                            all = all && ok[j];
                         }
                     }
-                    v &= (1ull << 62) - 1ull;
-                }
-                bool gstop = false;
-#pragma unroll
-                for (int t = 0; t < FPS_K; t++) {
-                    unsigned long long best = gstop ? 0ull : wave_max_u62(v);
-                    gl[t] = best;
-                    if (best != 0ull) {
-                        const bool own = v == best;
-                        const int ol = __builtin_ctzll(__ballot(own));
-                        const unsigned long long succ = __shfl(v, ol + 1, 64);
-                        if (own) v = 0ull;
-                        if ((ol % FPS_K) == FPS_K - 1 || succ == 0ull) gstop = true;
-                    } else {
-                        gstop = true;
+                    if (++spins > FPS_SPIN_LIMIT) {
+                        *err = 1;
+                        break;
                     }
                 }
-            } else {
 #pragma unroll
-                for (int t = 0; t < FPS_K; t++) gl[t] = wgc[t];
+                for (int j = 0; j < FPS_NG; j++) v[j] = (lane + 64 * j < G * FPS_KPUB) ? (v[j] & ~FPS_TAG) : 0ull;
             }
-            // 5) validate the chain c1, c2, ... (uniform): c_i is a pick iff no accepted c_a lowers its distance
-            int cidx[FPS_K];
-            float cx[FPS_K], cy[FPS_K], cz[FPS_K], ct[FPS_K];
-            int nacc = 0;
+            // coordinates of every gathered candidate, in flight while the merge runs
+            float vx[FPS_NG], vy[FPS_NG], vz[FPS_NG];
+#pragma unroll
+            for (int j = 0; j < FPS_NG; j++) {
+                const int ci = fps_code_index(v[j]);
+                vx[j] = xyz[(size_t)ci * 3 + 0];
+                vy[j] = xyz[(size_t)ci * 3 + 1];
+                vz[j] = xyz[(size_t)ci * 3 + 2];
+            }
+            unsigned long long gl[FPS_K];
+            bool gstop = false;
 #pragma unroll
             for (int t = 0; t < FPS_K; t++) {
-                const unsigned kk = FPS_KEY_NONE - (unsigned)(gl[t] & 0x7fffffffull);
-                const bool none = gl[t] == 0ull || kk == FPS_KEY_NONE;
-                cidx[t] = none ? 0 : (int)(kk & 0x3fffffu);
-                ct[t] = __uint_as_float((unsigned)(gl[t] >> 31));
-                const int ci = __builtin_amdgcn_readfirstlane(cidx[t]);
-                cx[t] = xyz[(size_t)ci * 3 + 0];
-                cy[t] = xyz[(size_t)ci * 3 + 1];
-                cz[t] = xyz[(size_t)ci * 3 + 2];
-                if (t == 0) {
-                    nacc = 1;  // c1 is always the next pick ("none" resolves to index 0 like the reference)
-                } else if (nacc == t && !none && done + t < m) {
-                    // the accepted picks drop to distance 0 themselves: a candidate at distance 0 can never
-                    // overtake them (they precede it in key order), e.g. in the m > n padding regime
-                    bool ok = ct[t] > 0.f;
+                unsigned long long mx = v[0];
 #pragma unroll
-                    for (int a = 0; a < FPS_K; a++) {
-                        if (a < t) {
-                            const float dx = cx[t] - cx[a], dy = cy[t] - cy[a], dz = cz[t] - cz[a];
-                            const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                            ok = ok && !(d < ct[t]);
+                for (int j = 1; j < FPS_NG; j++) mx = v[j] > mx ? v[j] : mx;
+                const unsigned long long best = gstop ? 0ull : wave_max_u64(mx);
+                gl[t] = best & ~1ull;
+                if (best != 0ull) {
+                    if (mx == best) {  // the owner lane hands the coordinates to everybody
+                        float ox = vx[0], oy = vy[0], oz = vz[0];
+#pragma unroll
+                        for (int j = 1; j < FPS_NG; j++) {
+                            if (v[j] == best) {
+                                ox = vx[j];
+                                oy = vy[j];
+                                oz = vz[j];
+                            }
                         }
+                        s_xyz[par][t * 3 + 0] = ox;
+                        s_xyz[par][t * 3 + 1] = oy;
+                        s_xyz[par][t * 3 + 2] = oz;
+#pragma unroll
+                        for (int j = 0; j < FPS_NG; j++)
+                            if (v[j] == best) v[j] = 0ull;
                     }
-                    if (ok) nacc = t + 1;
+                    if (best & 1ull) gstop = true;
+                } else {
+                    gstop = true;
+                    if (lane == 0) {  // "none" resolves to index 0 like the reference
+                        s_xyz[par][t * 3 + 0] = xyz[0];
+                        s_xyz[par][t * 3 + 1] = xyz[1];
+                        s_xyz[par][t * 3 + 2] = xyz[2];
+                    }
                 }
             }
-            if (lane == 0) {
-                s_pick[par][0] = nacc;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 5) validate the chain c1, c2, ...: c_t is a pick iff no accepted c_a (a < t) lowers its distance;
+            //    one lane per (t, a) pair, the verdicts come back as a ballot
+            const int vt = lane >> 3, va = lane & 7;
+            unsigned long long glt = gl[0];
 #pragma unroll
-                for (int t = 0; t < FPS_K; t++) {
-                    s_pick[par][1 + t] = cidx[t];
-                    s_xyz[par][t * 3 + 0] = cx[t];
-                    s_xyz[par][t * 3 + 1] = cy[t];
-                    s_xyz[par][t * 3 + 2] = cz[t];
-                }
-                if (wg == 0)
-                    for (int t = 0; t < nacc; t++) idxs[done + t] = cidx[t];
+            for (int t = 1; t < FPS_K; t++) glt = vt == t ? gl[t] : glt;
+            const float ctv = __uint_as_float((unsigned)(glt >> 32));
+            const float dx = s_xyz[par][vt * 3 + 0] - s_xyz[par][va * 3 + 0];
+            const float dy = s_xyz[par][vt * 3 + 1] - s_xyz[par][va * 3 + 1];
+            const float dz = s_xyz[par][vt * 3 + 2] - s_xyz[par][va * 3 + 2];
+            const bool viol = va < vt && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < ctv;
+            const unsigned long long bad = __ballot(viol);
+            int nacc = 1;  // c1 is always the next pick
+#pragma unroll
+            for (int t = 1; t < FPS_K; t++) {
+                // the accepted picks drop to distance 0 themselves: a candidate at distance 0 can never
+                // overtake them (they precede it in key order), e.g. in the m > n padding regime
+                const bool ok = nacc == t && gl[t] != 0ull && done + t < m && (gl[t] >> 32) != 0ull &&
+                                ((bad >> (8 * t)) & ((1ull << t) - 1ull)) == 0ull;
+                if (ok) nacc = t + 1;
+            }
+            if (lane == 0) s_pick[par][0] = nacc;
+            if (lane < FPS_K) {
+                const int ci = fps_code_index(glt_lane_fix(gl, lane));
+                s_pick[par][1 + lane] = ci;
+                if (wg == 0 && lane < nacc) idxs[done + lane] = ci;
             }
         }
         __syncthreads();
@@ -493,7 +558,7 @@ static void launch_fps(int G, int nb, hipStream_t st, const float* xyz, int n, i
 }
 
 extern "C" size_t gf_fps_scratch_bytes(int b) {
-    return ((size_t)b * 2 * FPS_MAXG * FPS_K + 8) * sizeof(unsigned long long);
+    return ((size_t)b * 2 * FPS_MAXG * FPS_KPUB + 8) * sizeof(unsigned long long);
 }
 
 extern "C" int gf_furthest_point_sampling(const float* xyz, int b, int n, int m, int32_t* idxs, void* scratch,
@@ -506,16 +571,16 @@ extern "C" int gf_furthest_point_sampling(const float* xyz, int b, int n, int m,
     int bs_log2 = 0;
     while ((2 << bs_log2) <= n && bs_log2 < 9) bs_log2++;
     const int per_wg = FPS_WAVES * 64;
-    int G = (n + per_wg * 3 - 1) / (per_wg * 3);
+    int G = (n + per_wg * 3 - 1) / (per_wg * 3);  // 3-4 points per lane
     if (const char* e = getenv("GF_FPS_G")) G = atoi(e);
     if (G < 1) G = 1;
     if (G > FPS_MAXG) G = FPS_MAXG;
     const int P = (n + G * per_wg - 1) / (G * per_wg);
     GF_CHECK_ARG(P <= 16, "gf_furthest_point_sampling: n=%d too large (max %d)", n, FPS_MAXG * per_wg * 16);
     unsigned long long* slots = (unsigned long long*)scratch;
-    int* err = (int*)(slots + (size_t)b * 2 * FPS_MAXG * FPS_K);
+    int* err = (int*)(slots + (size_t)b * 2 * FPS_MAXG * FPS_KPUB);
     hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), st);
-    const int per_launch = 128 / G > 0 ? 128 / G : 1;  // keep every cooperating workgroup resident
+    const int per_launch = 1024 / (G * FPS_WAVES) > 0 ? 1024 / (G * FPS_WAVES) : 1;  // all cooperating waves resident
     for (int b0 = 0; b0 < b; b0 += per_launch) {
         const int nb = (b - b0) < per_launch ? (b - b0) : per_launch;
         if (P <= 1) launch_fps<1>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
