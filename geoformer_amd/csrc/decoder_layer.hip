@@ -1,0 +1,289 @@
+// Token-side stages of the DETR-style decoder, fused (inference).
+//
+// Around the pairwise cross-attention (decoder_attn.hip) a decoder layer (TransformerDecoderLayer.forward_pre_rel,
+// model/transformer_detr.py:425-463) is ~30 small PyTorch launches over nq x 64 tokens: LayerNorm, the
+// nn.MultiheadAttention self-attention, residual adds, out_mlp, the FFN, and the hoisted W1 q + b1 product of the
+// next cross-attention.  One launch of this kernel runs everything BETWEEN two cross-attentions:
+//
+//   post (layer l):   tgt = relu(out_mlp(attn_out)) + tgt2;  tgt += linear2(relu(linear1(norm3(tgt))));
+//                     inter[l] = norm(tgt)                                    (TransformerDecoder.forward:155-164)
+//   pre  (layer l+1): t2 = norm1(tgt); q = k = t2 + query_pos; tgt += out_proj(MHA(q, k, t2));
+//                     tgt2 = norm2(tgt);  Q1 = W1 tgt2 + b1   (first half of attn_mlp[0] for the next cross-attention)
+//
+// as two launches: stage A is token-parallel (a workgroup per 16 tokens, intermediates in LDS) and ends with the
+// q/k/v projections; stage B is query-tile-parallel (a wave per head) and needs every token's K and V, which is why
+// the launch boundary sits there.  A 4-layer decoder is 4 cross-attention launches + 9 of these small ones
+// (~5 us each) instead of ~130.  All products are v_mfma_f32_16x16x4_f32 with operands loaded straight from
+// row-major activations (LDS tiles or global rows) and nn.Linear weights [out,in] (operand scheme of
+// backbone_attn.hip).  Self-attention: 4 heads x 16 channels, S^T = K Q^T keeps the query on the MFMA column so
+// the online soft-max state is per lane column and P^T feeds V^T P^T directly; one key tile of look-ahead.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DL_D 64
+#define DL_H 4
+#define DL_DK 16
+#define DL_THREADS 1024
+#define DL_MAXFF 256
+
+struct DlPost {
+    const float *omw, *omb, *n3w, *n3b, *l1w, *l1b, *l2w, *l2b, *fnw, *fnb;
+};
+struct DlPre {
+    const float *n1w, *n1b, *ipw, *ipb, *opw, *opb, *n2w, *n2b, *w1w, *w1b;
+};
+
+__device__ __forceinline__ f32x4 dl_mfma4(float4 a, float4 b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+#define DL_LD 68     // padded LDS row (floats): 16 rows x float4 reads without bank conflicts
+#define DL_LDH 260
+
+// one 16-row tile: out(r, col, act(sum_k A[r][k] W[col][k] + b[col])) for the column tiles ct = wave, wave+nw, ...
+// A may live in LDS or global memory (row stride lda); rows >= nvalid read as zero and are not emitted
+template <bool RELU, typename Epi>
+__device__ __forceinline__ void dl_tile_gemm(const float* A, int lda, int nvalid, int K, const float* __restrict__ W,
+                                             const float* __restrict__ bias, int N, int wave, int nwaves, int lane,
+                                             Epi epi) {
+    const int j = lane & 15, g = lane >> 4;
+    const int KC = K >> 4;
+    for (int ct = wave; ct < (N >> 4); ct += nwaves) {
+        const float* xa = A + (size_t)j * lda + 4 * g;
+        const float* wb = W + (size_t)(ct * 16 + j) * K + 4 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int kc = 0; kc < KC; kc++) {
+            float4 a = j < nvalid ? *reinterpret_cast<const float4*>(xa + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b = *reinterpret_cast<const float4*>(wb + kc * 16);
+            acc = dl_mfma4(a, b, acc);
+        }
+        const int col = ct * 16 + j;
+        const float bs = bias[col];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * g + i;
+            if (r >= nvalid) continue;
+            float v = acc[i] + bs;
+            if (RELU) v = fmaxf(v, 0.f);
+            epi(r, col, v);
+        }
+    }
+}
+
+// torch.nn.LayerNorm over 64 channels (biased variance, eps inside the root) of the rows of an LDS tile;
+// one wave per row, one channel per lane
+template <typename Out>
+__device__ __forceinline__ void dl_tile_layernorm(const float (*S)[DL_LD], int nvalid, const float* __restrict__ w,
+                                                  const float* __restrict__ b, int wave, int nwaves, int lane,
+                                                  Out out) {
+    const float wl = w[lane], bl = b[lane];
+    for (int r = wave; r < nvalid; r += nwaves) {
+        const float v = S[r][lane];
+        float s = v;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float mu = s / (float)DL_D;
+        const float dv = v - mu;
+        float q = dv * dv;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)DL_D + 1e-5f);
+        out(r, lane, dv * rstd * wl + bl);
+    }
+}
+
+#define DL_TILE_THREADS 256
+
+// Stage A, token-parallel (one workgroup per 16 tokens): the post part of a layer and the pre part of the next up
+// to the q/k/v projections of the self-attention.  State in global memory: X (running target), TGT2, QKV.
+__global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float* __restrict__ attn_out,
+                                                                     const float* __restrict__ tgt_in,
+                                                                     const float* __restrict__ query_pos, int T,
+                                                                     int B, int ff, int has_post, int has_pre,
+                                                                     DlPost po, DlPre pr, float* __restrict__ state,
+                                                                     float* __restrict__ inter_out) {
+    __shared__ float sX[16][DL_LD], sT[16][DL_LD], sQ[16][DL_LD], sH[16][DL_LDH];
+    const int b = blockIdx.y, t0 = blockIdx.x * 16;
+    const int nvalid = min(16, T - t0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = DL_TILE_THREADS / 64;
+    float* X = state + (size_t)b * T * (5 * DL_D);
+    float* TGT2 = X + (size_t)T * DL_D;
+    float* QKV = TGT2 + (size_t)T * DL_D;
+    const int lds = B * DL_D;  // row stride of the [T,B,64] tensors
+    if (has_post) {
+        // tgt = relu(out_mlp(attn)) + tgt2
+        const float* tg = TGT2 + (size_t)t0 * DL_D;
+        dl_tile_gemm<true>(attn_out + ((size_t)b * T + t0) * DL_D, DL_D, nvalid, DL_D, po.omw, po.omb, DL_D, wave, nw,
+                           lane, [&](int r, int c, float v) { sX[r][c] = v + tg[r * DL_D + c]; });
+        __syncthreads();
+        dl_tile_layernorm(sX, nvalid, po.n3w, po.n3b, wave, nw, lane, [&](int r, int c, float v) { sT[r][c] = v; });
+        __syncthreads();
+        dl_tile_gemm<true>(&sT[0][0], DL_LD, nvalid, DL_D, po.l1w, po.l1b, ff, wave, nw, lane,
+                           [&](int r, int c, float v) { sH[r][c] = v; });
+        __syncthreads();
+        dl_tile_gemm<false>(&sH[0][0], DL_LDH, nvalid, ff, po.l2w, po.l2b, DL_D, wave, nw, lane,
+                            [&](int r, int c, float v) { sX[r][c] += v; });
+        __syncthreads();
+        float* io = inter_out + (size_t)t0 * lds + b * DL_D;
+        dl_tile_layernorm(sX, nvalid, po.fnw, po.fnb, wave, nw, lane,
+                          [&](int r, int c, float v) { io[(size_t)r * lds + c] = v; });
+    } else {
+        for (int i = threadIdx.x; i < nvalid * DL_D; i += DL_TILE_THREADS)
+            sX[i >> 6][i & 63] = tgt_in[(size_t)(t0 + (i >> 6)) * lds + b * DL_D + (i & 63)];
+        __syncthreads();
+    }
+    if (!has_pre) return;
+    // t2 = norm1(tgt);  q = k = t2 + query_pos
+    const float* qp = query_pos + (size_t)t0 * lds + b * DL_D;
+    dl_tile_layernorm(sX, nvalid, pr.n1w, pr.n1b, wave, nw, lane, [&](int r, int c, float v) {
+        sT[r][c] = v;
+        sQ[r][c] = v + qp[(size_t)r * lds + c];
+    });
+    for (int i = threadIdx.x; i < nvalid * DL_D; i += DL_TILE_THREADS)
+        X[(size_t)(t0 + (i >> 6)) * DL_D + (i & 63)] = sX[i >> 6][i & 63];
+    __syncthreads();
+    // in_proj: rows 0..127 of the packed weight -> q, k (from t2 + pos), rows 128..191 -> v (from t2)
+    float* qkv = QKV + (size_t)t0 * (3 * DL_D);
+    dl_tile_gemm<false>(&sQ[0][0], DL_LD, nvalid, DL_D, pr.ipw, pr.ipb, 2 * DL_D, wave, nw, lane,
+                        [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + c] = v; });
+    dl_tile_gemm<false>(&sT[0][0], DL_LD, nvalid, DL_D, pr.ipw + 2 * DL_D * DL_D, pr.ipb + 2 * DL_D, DL_D, wave, nw, lane,
+                        [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + 2 * DL_D + c] = v; });
+}
+
+// Stage B, query-tile-parallel (one workgroup per 16 queries, one wave per head): self-attention over all
+// tokens, out_proj + residual, norm2, and the query half of the next cross-attention's first linear.
+__global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int B, DlPre pr,
+                                                                     float* __restrict__ state,
+                                                                     float* __restrict__ q1_out) {
+    __shared__ float sO[16][DL_LD], sX[16][DL_LD], sT[16][DL_LD];
+    const int b = blockIdx.y, t0 = blockIdx.x * 16;
+    const int nvalid = min(16, T - t0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = DL_TILE_THREADS / 64;
+    const int j = lane & 15, g = lane >> 4;
+    float* X = state + (size_t)b * T * (5 * DL_D);
+    float* TGT2 = X + (size_t)T * DL_D;
+    const float* QKV = TGT2 + (size_t)T * DL_D;
+    {
+        const int h = wave;  // 4 waves = 4 heads
+        const int QT = (T + 15) >> 4;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int qrow = t0 + j;
+        float4 bq = z4;
+        if (qrow < T) bq = *reinterpret_cast<const float4*>(QKV + (size_t)qrow * (3 * DL_D) + h * DL_DK + 4 * g);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, l = 0.f;
+        // operands of key tile 0, then one tile of look-ahead
+        float4 ak = z4;
+        float v[4];
+        {
+            if (j < T) ak = *reinterpret_cast<const float4*>(QKV + (size_t)j * (3 * DL_D) + DL_D + h * DL_DK + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int key = 4 * g + i;
+                v[i] = key < T ? QKV[(size_t)key * (3 * DL_D) + 2 * DL_D + h * DL_DK + j] : 0.f;
+            }
+        }
+        for (int kt = 0; kt < QT; kt++) {
+            float4 ak_n = z4;
+            float v_n[4] = {0.f, 0.f, 0.f, 0.f};
+            if (kt + 1 < QT) {
+                const int krow = (kt + 1) * 16 + j;
+                if (krow < T)
+                    ak_n = *reinterpret_cast<const float4*>(QKV + (size_t)krow * (3 * DL_D) + DL_D + h * DL_DK + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int key = (kt + 1) * 16 + 4 * g + i;
+                    v_n[i] = key < T ? QKV[(size_t)key * (3 * DL_D) + 2 * DL_D + h * DL_DK + j] : 0.f;
+                }
+            }
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            s = dl_mfma4(ak, bq, s);
+            float sc[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) sc[i] = (kt * 16 + 4 * g + i) < T ? s[i] * 0.25f : -INFINITY;  // 1/sqrt(16)
+            float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float corr = expf(m - mnew);
+            float p[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[i] = expf(sc[i] - mnew);
+            l = l * corr + ((p[0] + p[1]) + (p[2] + p[3]));
+            o *= corr;
+            m = mnew;
+#pragma unroll
+            for (int i = 0; i < 4; i++) o = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], p[i], o, 0, 0, 0);
+            ak = ak_n;
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = v_n[i];
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+#pragma unroll
+        for (int i = 0; i < 4; i++) sO[j][h * DL_DK + 4 * g + i] = o[i] / l;
+    }
+    __syncthreads();
+    // tgt += out_proj(O)
+    const float* xg = X + (size_t)t0 * DL_D;
+    dl_tile_gemm<false>(&sO[0][0], DL_LD, nvalid, DL_D, pr.opw, pr.opb, DL_D, wave, nw, lane,
+                        [&](int r, int c, float v) { sX[r][c] = xg[r * DL_D + c] + v; });
+    __syncthreads();
+    float* xo = X + (size_t)t0 * DL_D;
+    for (int i = threadIdx.x; i < nvalid * DL_D; i += DL_TILE_THREADS) xo[i] = sX[i >> 6][i & 63];
+    float* tg = TGT2 + (size_t)t0 * DL_D;
+    dl_tile_layernorm(sX, nvalid, pr.n2w, pr.n2b, wave, nw, lane, [&](int r, int c, float v) {
+        sT[r][c] = v;
+        tg[r * DL_D + c] = v;
+    });
+    __syncthreads();
+    float* q1 = q1_out + ((size_t)b * T + t0) * DL_D;
+    dl_tile_gemm<false>(&sT[0][0], DL_LD, nvalid, DL_D, pr.w1w, pr.w1b, DL_D, wave, nw, lane,
+                        [&](int r, int c, float v) { q1[r * DL_D + c] = v; });
+}
+
+extern "C" size_t gf_decoder_token_state_bytes(int nq, int B) {
+    return (size_t)(nq > 0 ? nq : 0) * (B > 0 ? B : 0) * (5 * DL_D) * sizeof(float);  // X, TGT2, QKV
+}
+
+extern "C" int gf_decoder_token_stage(const float* attn_out, const float* tgt_in, const float* query_pos, int nq, int B,
+                                      int d, int nhead, int ff, const float* const* post_params,
+                                      const float* const* pre_params, void* state, float* inter_out, float* q1_out,
+                                      void* stream) {
+    GF_CHECK_ARG(d == DL_D && nhead == DL_H, "gf_decoder_token_stage: built for d_model=64, 4 heads (got %d, %d)", d,
+                 nhead);
+    GF_CHECK_ARG(ff > 0 && ff % 16 == 0 && ff <= DL_MAXFF, "gf_decoder_token_stage: dim_feedforward %d not in 16..%d",
+                 ff, DL_MAXFF);
+    GF_CHECK_ARG(nq >= 0 && B >= 0, "gf_decoder_token_stage: bad sizes");
+    GF_CHECK_ARG(post_params || pre_params, "gf_decoder_token_stage: nothing to do");
+    GF_CHECK_ARG(post_params ? (attn_out && inter_out) : (tgt_in != nullptr),
+                 "gf_decoder_token_stage: post needs attn_out and inter_out, a first stage needs tgt_in");
+    GF_CHECK_ARG(!pre_params || (query_pos && q1_out), "gf_decoder_token_stage: pre needs query_pos and q1_out");
+    if (nq == 0 || B == 0) return GF_OK;
+    DlPost po = {};
+    DlPre pr = {};
+    if (post_params) {
+        for (int i = 0; i < 10; i++) GF_CHECK_ARG(post_params[i], "gf_decoder_token_stage: post_params[%d] is null", i);
+        po = {post_params[0], post_params[1], post_params[2], post_params[3], post_params[4],
+              post_params[5], post_params[6], post_params[7], post_params[8], post_params[9]};
+    }
+    if (pre_params) {
+        for (int i = 0; i < 10; i++) GF_CHECK_ARG(pre_params[i], "gf_decoder_token_stage: pre_params[%d] is null", i);
+        pr = {pre_params[0], pre_params[1], pre_params[2], pre_params[3], pre_params[4],
+              pre_params[5], pre_params[6], pre_params[7], pre_params[8], pre_params[9]};
+    }
+    const dim3 grid((nq + 15) / 16, B);
+    hipLaunchKernelGGL(k_decoder_stage_a, grid, dim3(DL_TILE_THREADS), 0, (hipStream_t)stream, attn_out, tgt_in,
+                       query_pos, nq, B, ff, post_params ? 1 : 0, pre_params ? 1 : 0, po, pr, (float*)state, inter_out);
+    if (pre_params)
+        hipLaunchKernelGGL(k_decoder_stage_b, grid, dim3(DL_TILE_THREADS), 0, (hipStream_t)stream, nq, B, pr,
+                           (float*)state, q1_out);
+    GF_CHECK_LAUNCH("gf_decoder_token_stage");
+    return GF_OK;
+}

@@ -336,6 +336,31 @@ class TransformerDecoderLayer(nn.Module):
         return tgt, None
 
 
+def _decoder_fused_cache(dec):
+    """Per-decoder constants of the fused inference path: pointer tables, stacked K-side weights of the
+    cross-attentions, packed pair weights; rebuilt when a parameter is replaced or updated in place."""
+    from .. import pointops
+
+    params = list(dec.parameters())
+    key = (params[0].data_ptr(), sum(p._version for p in params))
+    hit = getattr(dec, "_gf_fused", None)
+    if hit is not None and hit["key"] == key:
+        return hit
+    with torch.no_grad():
+        tables = [pointops.decoder_stage_tables(l, dec.norm) for l in dec.layers]
+        # K1_l = memory W1_l^T (no bias), Kv_l = memory Wv_l^T + bv_l: one batched product for all layers
+        wt = torch.stack([w for l in dec.layers for w in (l.attn_mlp[0].weight.t(), l.v_mlp[0].weight.t())]).contiguous()
+        bs = torch.stack([b for l in dec.layers
+                          for b in (torch.zeros_like(l.v_mlp[0].bias), l.v_mlp[0].bias)]).unsqueeze(1).contiguous()
+        packs = [pointops.decoder_pack_weights(l.attn_mlp[0].weight.detach().contiguous(),
+                                               l.attn_mlp[2].weight.detach().contiguous(),
+                                               l.v_mlp[0].weight.detach().contiguous()) for l in dec.layers]
+        b2 = [l.attn_mlp[2].bias.detach().contiguous() for l in dec.layers]
+    hit = {"key": key, "tables": tables, "wt": wt, "bs": bs, "packs": packs, "b2": b2}
+    dec._gf_fused = hit
+    return hit
+
+
 class TransformerDecoder(nn.Module):
     def __init__(self, decoder_layer, num_layers, norm_fn_name="ln", return_intermediate=False,
                  weight_init_name="xavier_uniform"):
@@ -348,9 +373,40 @@ class TransformerDecoder(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def _forward_fused(self, tgt, memory, query_pos, rp):
+        """Inference on the GPU: L cross-attention launches + L+1 token-stage launches + one batched product
+        (csrc/decoder_attn.hip, csrc/decoder_layer.hip) instead of ~35 launches per layer."""
+        from .. import pointops
+
+        c = _decoder_fused_cache(self)
+        nq, B, d = tgt.shape
+        nc = memory.shape[0]
+        L = len(self.layers)
+        ff = self.layers[0].linear1.out_features
+        mem = memory.permute(1, 0, 2).reshape(1, B * nc, d)
+        kk = torch.baddbmm(c["bs"], mem.expand(2 * L, B * nc, d), c["wt"])  # [2L, B*nc, d]
+        state = pointops.decoder_token_state(nq, B, tgt.device)
+        inter = torch.empty((L, nq, B, d), dtype=torch.float32, device=tgt.device)
+        q1 = torch.empty((B, nq, d), dtype=torch.float32, device=tgt.device)
+        tgt_c, qp = tgt.contiguous(), query_pos.contiguous()
+        pointops.decoder_token_stage(None, tgt_c, qp, nq, B, 4, ff, None, c["tables"][0][1], state, None, q1)
+        for l in range(L):
+            attn = pointops.decoder_cross_attn(rp.geo_ctx, rp.max_geo, rp.query_locs, rp.context_locs, rp.lo, rp.hi,
+                                               rp.gauss_B, q1, kk[2 * l].view(B, nc, d), kk[2 * l + 1].view(B, nc, d),
+                                               c["packs"][l], c["b2"][l])
+            pre = c["tables"][l + 1][1] if l + 1 < L else None
+            pointops.decoder_token_stage(attn, None, qp, nq, B, 4, ff, c["tables"][l][0], pre, state, inter[l],
+                                         q1 if pre is not None else None)
+        return inter
+
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None, relative_pos=None, transpose_swap=False,
                 return_attn_weights=False):
+        if (isinstance(relative_pos, RelPosSpec) and tgt_mask is None and tgt_key_padding_mask is None
+                and query_pos is not None and self.norm is not None and self.return_intermediate
+                and tgt.shape[-1] == 64 and self.layers[0].nhead == 4 and self.layers[0].linear1.out_features % 16 == 0
+                and self.layers[0].linear1.out_features <= 256 and not self.layers[0].self_attn.training):
+            return self._forward_fused(tgt, memory, query_pos, relative_pos)
         output, inter = tgt, []
         for layer in self.layers:
             output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,

@@ -152,6 +152,32 @@ def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
     return out
 
 
+def decoder_stage_tables(layer, final_norm):
+    """(post, pre) device-pointer tables of one decoder layer for gf_decoder_token_stage (header order)."""
+    import ctypes
+
+    sa = layer.self_attn
+    post = [layer.out_mlp[0].weight, layer.out_mlp[0].bias, layer.norm3.weight, layer.norm3.bias, layer.linear1.weight,
+            layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, final_norm.weight, final_norm.bias]
+    pre = [layer.norm1.weight, layer.norm1.bias, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight,
+           sa.out_proj.bias, layer.norm2.weight, layer.norm2.bias, layer.attn_mlp[0].weight, layer.attn_mlp[0].bias]
+    for t in post + pre:
+        _f32c(t.data, "decoder parameter")
+    mk = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])  # noqa: E731
+    return mk(post), mk(pre)
+
+
+def decoder_token_stage(attn_out, tgt_in, query_pos, nq, B, nhead, ff, post, pre, state, inter_out, q1_out):
+    """One fused token-side stage between two cross-attentions (include/geoformer_hip.h)."""
+    check(_lib.load().gf_decoder_token_stage(ptr(attn_out), ptr(tgt_in), ptr(query_pos), nq, B, 64, nhead, ff, post,
+                                             pre, ptr(state), ptr(inter_out), ptr(q1_out), stream_ptr()),
+          "gf_decoder_token_stage")
+
+
+def decoder_token_state(nq, B, device):
+    return torch.empty(_lib.load().gf_decoder_token_state_bytes(nq, B) // 4, dtype=torch.float32, device=device)
+
+
 def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh, npoint_thresh, min_class=4):
     """Fused statistics of generate_proposal: (cls_pred i32[nq], npoints i32[nq], scores f32[nq], final i32[nq])."""
     _f32c(mask_logits, "mask_logits"), _f32c(cls_logits, "cls_logits"), _f32c(sem_prob, "sem_prob")

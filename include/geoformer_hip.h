@@ -191,6 +191,28 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
                  int nq, int C, float* out, void* stream);
 
 /* ===================================================================================
+ * Token-side stages of the decoder between two cross-attentions, fused (inference)
+ * (TransformerDecoderLayer.forward_pre_rel, model/transformer_detr.py:425-463; TransformerDecoder.forward,
+ *  model/transformer_detr.py:130-166)
+ * =================================================================================== */
+
+/* One launch = [post part of layer l] + [pre part of layer l+1]; either half may be absent (NULL table).
+ *   post: tgt = relu(out_mlp(attn_out)) + tgt2; tgt += linear2(relu(linear1(norm3(tgt)))); inter_out = norm(tgt)
+ *   pre : t2 = norm1(tgt); q = k = t2 + query_pos; tgt += self_attn(q, k, t2); tgt2 = norm2(tgt);
+ *         q1_out = attn_mlp[0](tgt2)   (the query half of the next cross-attention's first linear)
+ *   attn_out fp32 [B,nq,64] (gf_decoder_cross_attn output), tgt_in fp32 [nq,B,64] (first stage only),
+ *   query_pos fp32 [nq,B,64], inter_out fp32 [nq,B,64], q1_out fp32 [B,nq,64],
+ *   state: gf_decoder_token_state_bytes(nq,B) bytes, carried unchanged from one stage to the next,
+ *   post_params (HOST array of 10 device pointers): out_mlp.W[64,64] .b | norm3.w .b | linear1.W[ff,64] .b |
+ *                linear2.W[64,ff] .b | decoder.norm.w .b
+ *   pre_params  (10): norm1.w .b | self_attn.in_proj_weight[192,64] in_proj_bias | out_proj.W .b | norm2.w .b |
+ *                attn_mlp[0].W[64,64] .b.       d = 64, nhead = 4, ff % 16 == 0, ff <= 256. */
+size_t gf_decoder_token_state_bytes(int nq, int B);
+int gf_decoder_token_stage(const float* attn_out, const float* tgt_in, const float* query_pos, int nq, int B, int d,
+                           int nhead, int ff, const float* const* post_params, const float* const* pre_params,
+                           void* state, float* inter_out, float* q1_out, void* stream);
+
+/* ===================================================================================
  * Proposal extraction of the eval forward (GeoFormer.generate_proposal,
  * model/geoformer/geoformer.py:193-262), fused
  * =================================================================================== */

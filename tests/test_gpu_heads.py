@@ -144,3 +144,37 @@ def test_proposal_stats_and_scatter(hip, oracle, nq, N, ncls, npts):
     assert (have.cpu().numpy() == want).all()
     if sel.size:
         assert (want.sum(1) == ref[1][sel]).all()
+
+
+@pytest.mark.parametrize("nq,nc,B,ff", [(256, 512, 1, 64), (100, 300, 2, 128), (16, 40, 1, 256)])
+def test_decoder_token_stages_fused(hip, nq, nc, B, ff):
+    """Whole fused decoder (token stages + cross-attention launches) vs the layer-by-layer PyTorch modules
+    (transformer_detr.py:130-166, 425-463) around the same cross-attention kernel."""
+    from geoformer_amd.model.layers import RelPosSpec, TransformerDecoder, TransformerDecoderLayer
+
+    torch.manual_seed(nq + ff)
+    layer = TransformerDecoderLayer(d_model=64, nhead=4, dim_feedforward=ff, dropout=0.1, normalize_before=True,
+                                    use_rel=True)
+    dec = TransformerDecoder(layer, num_layers=3, return_intermediate=True)
+    for p in dec.parameters():
+        if p.dim() == 1:
+            p.data.add_(torch.randn_like(p) * 0.2)
+    dec.cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
+    tgt, mem, qp = r(nq, B, 64), r(nc, B, 64), r(nq, B, 64)
+    geo = torch.rand(B, nq, nc, device="cuda", generator=g) * 3
+    geo[torch.rand(B, nq, nc, device="cuda", generator=g) < 0.3] = -1.0
+    mx = geo.max(2)[0].clamp_min(0).contiguous()
+    rp = RelPosSpec(geo.contiguous(), mx, torch.rand(B, nq, 3, device="cuda", generator=g).contiguous(),
+                    torch.rand(B, nc, 3, device="cuda", generator=g).contiguous(), torch.zeros(B, 3, device="cuda"),
+                    torch.ones(B, 3, device="cuda"), r(3, 32).contiguous())
+    with torch.no_grad():
+        fused = dec(tgt, mem, query_pos=qp, relative_pos=rp)
+        out, inter = tgt, []
+        for l in dec.layers:
+            out, _ = l(out, mem, query_pos=qp, relative_pos=rp)
+            inter.append(dec.norm(out))
+        ref = torch.stack(inter)
+    assert fused.shape == ref.shape
+    assert (fused - ref).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
