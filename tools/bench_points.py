@@ -33,3 +33,8 @@ src = idx[0, :256].contiguous()
 print("bfs nq=256 us", timeit(lambda: pointops.geodesic_bfs(D, I, deg, src, 0.05, 256)))
 geo = pointops.geodesic_bfs(D, I, deg, src, 0.05, 256)
 print("reached frac", (geo >= 0).float().mean().item(), "max geo", geo.max().item())
+if os.environ.get("BFS_STEPS"):
+    for ms in (0, 16, 64, 128, 192, 256, 512):
+        t = timeit(lambda: pointops.geodesic_bfs(D, I, deg, src, 0.05, ms))
+        gg = pointops.geodesic_bfs(D, I, deg, src, 0.05, ms)
+        print(f"bfs max_step={ms}: {t:.1f} us, reached {(gg >= 0).float().mean().item():.4f}")
