@@ -104,9 +104,27 @@ __device__ __forceinline__ float4 activate_a(float4 a, bool present, const float
 // wave), then the batch's MFMAs run.  With SPLIT the four waves of the workgroup share one item and
 // take the steps round-robin (small levels: 4x more waves, 4x shorter dependent chains), and the
 // partial accumulators are summed through LDS.
+// Steps in flight per wave.  The kernel is bound by dependent latency, and every resident wave helps to hide
+// the parts of a group's chain that prefetching cannot (mask -> indices -> first gathers, the epilogue):
+// PF 8/6/4 cost 135-150 VGPRs = 3 waves per SIMD; PF 4/2/3 fit 96-112 = 5/5/4 waves and measured 18-23 % faster
+// on every level (rocprofv3 kernel trace, S150k: level 1 31.9 -> 26.3 us, level 2 39.9 -> 30.8, level 3 30.3 -> 23.7).
+#ifndef CONV_PF1
+#define CONV_PF1 4
+#endif
+#ifndef CONV_PF2
+#define CONV_PF2 2
+#endif
+#ifndef CONV_PF3
+#define CONV_PF3 3
+#endif
+#ifndef CONV_WPE
+#define CONV_WPE_ATTR
+#else
+#define CONV_WPE_ATTR __attribute__((amdgpu_waves_per_eu(CONV_WPE, CONV_WPE)))
+#endif
 template <int NCBW>
 struct ConvPF {
-    static constexpr int value = NCBW == 1 ? 8 : (NCBW == 2 ? 6 : 4);
+    static constexpr int value = NCBW == 1 ? CONV_PF1 : (NCBW == 2 ? CONV_PF2 : CONV_PF3);
 };
 
 struct StepIter {
@@ -137,16 +155,18 @@ struct StepIter {
     }
 };
 
-template <int NCBW, bool SPLIT, bool VEC, bool LDSW>
-__global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
+template <int NCBW, int SW, bool VEC, bool LDSW>
+__global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                  const int32_t* __restrict__ nbr, const uint32_t* __restrict__ gmask,
                                                  int K, int M_out, int ld, int Cin, int Cout, int NCH, int NCB,
                                                  int nsplit, unsigned in_bytes, const float* __restrict__ in_scale,
                                                  const float* __restrict__ in_shift,
                                                  const float* __restrict__ residual, float* __restrict__ out) {
     constexpr int PF = ConvPF<NCBW>::value;
-    __shared__ int s_idx[SPLIT ? 4 : 8][32 * 16];
-    __shared__ float4 s_red[SPLIT ? 4 * NCBW * 64 : 1];
+    constexpr bool SPLIT = SW > 0;  // SW waves of the workgroup share one item
+    constexpr int NSW = SW > 0 ? SW : 1;
+    __shared__ int s_idx[SPLIT ? NSW : 8][32 * 16];
+    __shared__ float4 s_red[SPLIT ? NSW * NCBW * 64 : 1];
     __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];  // fused BN scale / shift
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, c
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int row = g * 16 + q * 4 + j, col = (cb0 + cb) * 16 + r;
-                    res[cb][j] = (row < M_out && col < Cout && (!SPLIT || (cb & 3) == w))
+                    res[cb][j] = (row < M_out && col < Cout && (!SPLIT || (cb % NSW) == w))
                                      ? residual[(size_t)row * Cout + col] : 0.f;
                 }
         }
@@ -265,9 +285,8 @@ __global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, c
                 }
                 it.next();
                 if (SPLIT) {
-                    it.next();
-                    it.next();
-                    it.next();
+#pragma unroll
+                    for (int e = 1; e < NSW; e++) it.next();
                 }
             }
 #pragma unroll
@@ -297,18 +316,30 @@ __global__ __launch_bounds__(512) void k_conv_os(const float* __restrict__ in, c
                 s_red[(w * NCBW + cb) * 64 + lane] = make_float4(acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]);
             __syncthreads();
         }
-        // C/D layout: col = lane&15, row = (lane>>4)*4 + j.  SPLIT: wave w sums column blocks w, w+4.
+        // C/D layout: col = lane&15, row = (lane>>4)*4 + j.  SPLIT: wave w sums column blocks w, w+SW, ...
 #pragma unroll
         for (int cb = 0; cb < NCBW; cb++) {
             float v[4] = {acc[cb][0], acc[cb][1], acc[cb][2], acc[cb][3]};
             if (SPLIT) {
-                if ((cb & 3) != w) continue;
-                const float4 p0 = s_red[(0 * NCBW + cb) * 64 + lane], p1 = s_red[(1 * NCBW + cb) * 64 + lane];
-                const float4 p2 = s_red[(2 * NCBW + cb) * 64 + lane], p3 = s_red[(3 * NCBW + cb) * 64 + lane];
-                v[0] = (p0.x + p1.x) + (p2.x + p3.x);
-                v[1] = (p0.y + p1.y) + (p2.y + p3.y);
-                v[2] = (p0.z + p1.z) + (p2.z + p3.z);
-                v[3] = (p0.w + p1.w) + (p2.w + p3.w);
+                if ((cb % NSW) != w) continue;
+                float4 t[NSW / 4 > 0 ? NSW / 4 : 1];
+#pragma unroll
+                for (int e = 0; e < NSW / 4; e++) {
+                    const float4 p0 = s_red[((4 * e + 0) * NCBW + cb) * 64 + lane];
+                    const float4 p1 = s_red[((4 * e + 1) * NCBW + cb) * 64 + lane];
+                    const float4 p2 = s_red[((4 * e + 2) * NCBW + cb) * 64 + lane];
+                    const float4 p3 = s_red[((4 * e + 3) * NCBW + cb) * 64 + lane];
+                    t[e] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y),
+                                       (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+                }
+                float4 sum = t[0];
+#pragma unroll
+                for (int e = 1; e < NSW / 4; e++)
+                    sum = make_float4(sum.x + t[e].x, sum.y + t[e].y, sum.z + t[e].z, sum.w + t[e].w);
+                v[0] = sum.x;
+                v[1] = sum.y;
+                v[2] = sum.z;
+                v[3] = sum.w;
             }
             const int col = (cb0 + cb) * 16 + r;
 #pragma unroll
@@ -340,35 +371,35 @@ template <int NCBW>
 static void launch_conv_ldsw(dim3 grid, int bs, size_t lds, hipStream_t st, const ConvArgs& a) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)k_conv_os<NCBW, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void*)k_conv_os<NCBW, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             64 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv_os<NCBW, false, true, true>), grid, dim3(bs), lds, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+    hipLaunchKernelGGL((k_conv_os<NCBW, 0, true, true>), grid, dim3(bs), lds, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                        a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
 }
-template <int NCBW, bool SPLIT>
+template <int NCBW, int SW>
 static void launch_conv(bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
-    const int bs = SPLIT ? 256 : g_conv_block;
+    const int bs = SW ? SW * 64 : g_conv_block;
     if (vec)
-        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, true, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+        hipLaunchKernelGGL((k_conv_os<NCBW, SW, true, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                            a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
     else
-        hipLaunchKernelGGL((k_conv_os<NCBW, SPLIT, false, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+        hipLaunchKernelGGL((k_conv_os<NCBW, SW, false, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                            a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
 }
 
-template <bool SPLIT>
+template <int SW>
 static void dispatch_conv(int ncbw, bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
     switch (ncbw) {
-        case 1: launch_conv<1, SPLIT>(vec, grid, st, a); break;
-        case 2: launch_conv<2, SPLIT>(vec, grid, st, a); break;
-        case 3: launch_conv<3, SPLIT>(vec, grid, st, a); break;
-        case 4: launch_conv<4, SPLIT>(vec, grid, st, a); break;
-        case 5: launch_conv<5, SPLIT>(vec, grid, st, a); break;
-        case 6: launch_conv<6, SPLIT>(vec, grid, st, a); break;
-        case 7: launch_conv<7, SPLIT>(vec, grid, st, a); break;
-        default: launch_conv<8, SPLIT>(vec, grid, st, a); break;
+        case 1: launch_conv<1, SW>(vec, grid, st, a); break;
+        case 2: launch_conv<2, SW>(vec, grid, st, a); break;
+        case 3: launch_conv<3, SW>(vec, grid, st, a); break;
+        case 4: launch_conv<4, SW>(vec, grid, st, a); break;
+        case 5: launch_conv<5, SW>(vec, grid, st, a); break;
+        case 6: launch_conv<6, SW>(vec, grid, st, a); break;
+        case 7: launch_conv<7, SW>(vec, grid, st, a); break;
+        default: launch_conv<8, SW>(vec, grid, st, a); break;
     }
 }
 
@@ -392,7 +423,10 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     // over its four waves.
     bool split = ngroups < 6000;
     if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
-    const int ncbw = split ? (ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
+    // tiny levels (all items resident at once with room to spare): 16 waves per item, 4x shorter chains again
+    bool wide = false;  // measured slower (register spills at 1024 threads), kept behind GF_CONV_WIDE
+    if (const char* e = getenv("GF_CONV_WIDE")) wide = split && atoi(e) != 0;
+    const int ncbw = split ? (!wide && ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
     const int nsplit = (ncb + ncbw - 1) / ncbw;
     const long long nitems = (long long)ngroups * nsplit;
     if (const char* e = getenv("GF_CONV_BLOCK")) g_conv_block = atoi(e);
@@ -414,10 +448,12 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
         dim3 g2((unsigned)((nitems + 7) / 8));
         if (ncb == 1) launch_conv_ldsw<1>(g2, bs, wbytes, st, a);
         else launch_conv_ldsw<2>(g2, bs, wbytes, st, a);
-    } else if (split)
-        dispatch_conv<true>(ncbw, vec, grid, st, a);
+    } else if (split && wide)
+        launch_conv<1, 16>(vec, grid, st, a);
+    else if (split)
+        dispatch_conv<4>(ncbw, vec, grid, st, a);
     else
-        dispatch_conv<false>(ncbw, vec, grid, st, a);
+        dispatch_conv<0>(ncbw, vec, grid, st, a);
     GF_CHECK_LAUNCH("gf_conv_fwd");
     return GF_OK;
 }
