@@ -11,7 +11,7 @@
 //   r_ij is recomputed on the fly and nothing of size nq*nc*64 ever exists.  Linear parts that do not
 //   depend on the pair are hoisted by the caller: Q1 = W1 q + b1, K1 = W1 k, Kv = Wv k + bv.
 //
-// Mapping.  One 512-thread workgroup per (query, batch); its 8 waves split the contexts in tiles of
+// Mapping.  One 1024-thread workgroup per (query, batch); its 16 waves split the contexts in tiles of
 // 16.  Everything is kept TRANSPOSED -- channels on the MFMA row index, contexts on the column
 // (lane&15) -- so the accumulator of one product is directly the B operand of the next
 // (v_mfma_f32_16x16x4_f32: lane (g = lane>>4, j = lane&15) holds rows 4g..4g+3 of a 16-row block, and
@@ -22,27 +22,52 @@
 // The weights sit in LDS pre-packed in A-operand lane order (one conflict-free ds_read_b128 per four
 // MFMAs).  Each lane computes the 16 embedding channels it feeds (8 projections -> sin and cos), and
 // carries an online-softmax state (max, sum, weighted sum) for its 16 channels over the contexts it
-// sees; the 8 x 16 partial states per channel are merged once at the end.  MFMA-bound: 3*2*64*64 flop
+// sees; the 16 x 16 partial states per channel are merged once at the end (channel maximum, rescale, row sums).  MFMA-bound: 3*2*64*64 flop
 // per pair = 12.9 GFLOP per layer at 256 x 2048, against ~1 MB of input.
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define DA_WAVES 8
+#define DA_WAVES 16
 #define DA_D 64
 
+// max / sum over the 16 lanes that share lane>>4 (one DPP row): quad xor 1, quad xor 2, half mirror, mirror
+__device__ __forceinline__ float da_row_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false)));
+    return v;
+}
+__device__ __forceinline__ float da_row_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false));
+    return v;
+}
+
+// 16 waves per (query, batch) = 4 per SIMD: the kernel has to fit 128 VGPRs, so only the online soft-max state
+// (48 values) stays in registers across tiles; the per-query constants (Q1 row, the lane's Fourier projections)
+// sit in LDS next to the weights.  b2 is not needed at all: the soft-max runs over the contexts separately for
+// every channel, and a per-channel constant cancels in it.
 __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
     const float* __restrict__ geo_ctx, const float* __restrict__ max_geo, const float* __restrict__ qloc,
     const float* __restrict__ cloc, const float* __restrict__ lo, const float* __restrict__ hi,
     const float* __restrict__ gaussB, const float* __restrict__ Q1, const float* __restrict__ K1,
-    const float* __restrict__ Kv, const float4* __restrict__ Wpack, const float* __restrict__ b2, int nq, int nc,
-    float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4* sW = reinterpret_cast<float4*>(smem);  // [3][4 rb][4 kb][64 lanes]
+    const float* __restrict__ Kv, const float4* __restrict__ Wpack, int nq, int nc, float* __restrict__ out) {
+    __shared__ float4 sW[3 * 16 * 64];       // [3][4 rb][4 kb][64 lanes]
+    __shared__ float4 sQ1[16];               // Q1 row of this query: channel rb*16 + 4g + r at [rb*4 + g]
+    __shared__ float4 sB[3][2][4];           // sB[axis][half][g] = gaussB[axis][half*16 + 4g .. +3]
+    __shared__ float sRed[3][DA_WAVES][DA_D];
     const int qi = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
     for (int t = tid; t < 3 * 16 * 64; t += DA_WAVES * 64) sW[t] = Wpack[t];
-
+    if (tid < 16) sQ1[tid] = *reinterpret_cast<const float4*>(Q1 + ((size_t)b * nq + qi) * DA_D + tid * 4);
+    if (tid >= 64 && tid < 64 + 24) {
+        const int e = tid - 64, axis = e >> 3, half = (e >> 2) & 1, gg = e & 3;
+        sB[axis][half][gg] = *reinterpret_cast<const float4*>(gaussB + axis * 32 + half * 16 + 4 * gg);
+    }
     geo_ctx += ((size_t)b * nq + qi) * nc;
     cloc += (size_t)b * nc * 3;
     K1 += (size_t)b * nc * DA_D;
@@ -52,24 +77,6 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
                 qz = qloc[((size_t)b * nq + qi) * 3 + 2];
     const float lx = lo[b * 3 + 0], ly = lo[b * 3 + 1], lz = lo[b * 3 + 2];
     const float sx = hi[b * 3 + 0] - lx, sy = hi[b * 3 + 1] - ly, sz = hi[b * 3 + 2] - lz;
-    // projections this lane evaluates: f = 4g+s and 16+4g+s
-    float B0[8], B1[8], B2[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int f = (e >> 2) * 16 + 4 * g + (e & 3);
-        B0[e] = gaussB[0 * 32 + f];
-        B1[e] = gaussB[1 * 32 + f];
-        B2[e] = gaussB[2 * 32 + f];
-    }
-    // per-query constants in accumulator layout: channel c = rb*16 + 4g + r
-    float q1[4][4], bias2[4][4];
-#pragma unroll
-    for (int rb = 0; rb < 4; rb++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            q1[rb][r] = Q1[((size_t)b * nq + qi) * DA_D + rb * 16 + 4 * g + r];
-            bias2[rb][r] = b2[rb * 16 + 4 * g + r];
-        }
     float sm[4][4], sl[4][4], sa[4][4];  // online softmax: running max, sum, weighted sum
 #pragma unroll
     for (int rb = 0; rb < 4; rb++)
@@ -98,12 +105,17 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
                     t2 = ((g2 - lz) / sz) * 6.2831855f;
         float R[4][4];  // R[kb][s]: channel kb*16 + 4g + s
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const float proj = fmaf(t2, B2[e], fmaf(t1, B1[e], t0 * B0[e]));
-            float sn, cs;
-            __sincosf(proj, &sn, &cs);
-            R[e >> 2][e & 3] = sn;
-            R[2 + (e >> 2)][e & 3] = cs;
+        for (int half = 0; half < 2; half++) {
+            const float4 b0 = sB[0][half][g], b1 = sB[1][half][g], b2v = sB[2][half][g];
+            const float p[4] = {fmaf(t2, b2v.x, fmaf(t1, b1.x, t0 * b0.x)), fmaf(t2, b2v.y, fmaf(t1, b1.y, t0 * b0.y)),
+                                fmaf(t2, b2v.z, fmaf(t1, b1.z, t0 * b0.z)), fmaf(t2, b2v.w, fmaf(t1, b1.w, t0 * b0.w))};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float sn, cs;
+                __sincosf(p[e], &sn, &cs);
+                R[half][e] = sn;
+                R[2 + half][e] = cs;
+            }
         }
         // --- H^T = W1 . R^T ---
         f32x4 H[4];
@@ -119,11 +131,13 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, R[kb][3], acc, 0, 0, 0);
             }
             const float4 k1 = *reinterpret_cast<const float4*>(K1 + (size_t)cc * DA_D + rb * 16 + 4 * g);
-            acc[0] = fmaxf(acc[0] + q1[rb][0] - k1.x, 0.f);
-            acc[1] = fmaxf(acc[1] + q1[rb][1] - k1.y, 0.f);
-            acc[2] = fmaxf(acc[2] + q1[rb][2] - k1.z, 0.f);
-            acc[3] = fmaxf(acc[3] + q1[rb][3] - k1.w, 0.f);
+            const float4 q1 = sQ1[rb * 4 + g];
+            acc[0] = fmaxf(acc[0] + q1.x - k1.x, 0.f);
+            acc[1] = fmaxf(acc[1] + q1.y - k1.y, 0.f);
+            acc[2] = fmaxf(acc[2] + q1.z - k1.z, 0.f);
+            acc[3] = fmaxf(acc[3] + q1.w - k1.w, 0.f);
             H[rb] = acc;
+            __builtin_amdgcn_sched_barrier(0);  // keep the next block's 4 weight reads from being hoisted (VGPRs)
         }
         // --- sim^T = W2 . H^T ,  v^T = Wv . R^T , online softmax ---
 #pragma unroll
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
             if (valid) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float x = (s[r] + bias2[rb][r]) * 0.125f;
+                    const float x = s[r] * 0.125f;
                     const float val = v[r] + kvv[r];
                     const float mn = fmaxf(sm[rb][r], x);
                     const float corr = __expf(sm[rb][r] - mn), p = __expf(x - mn);
@@ -156,45 +170,46 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
                     sm[rb][r] = mn;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // --- merge the 8 waves x 16 column slots of every channel ---
-    __syncthreads();  // weights no longer needed: reuse LDS
-    float* sS = reinterpret_cast<float*>(smem);  // [3][64 channels][128 slots]
+    // --- merge: channel maximum over all lanes, rescale, then plain sums ---
 #pragma unroll
     for (int rb = 0; rb < 4; rb++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int c = rb * 16 + 4 * g + r, slot = w * 16 + j;
-            sS[(0 * 64 + c) * 128 + slot] = sm[rb][r];
-            sS[(1 * 64 + c) * 128 + slot] = sl[rb][r];
-            sS[(2 * 64 + c) * 128 + slot] = sa[rb][r];
+            const float m = da_row_max(sm[rb][r]);
+            if (j == 0) sRed[0][w][rb * 16 + 4 * g + r] = m;
         }
     __syncthreads();
-    {
-        // 8 threads per channel, 16 slots each, then a shuffle merge
-        const int c = tid >> 3, part = tid & 7;
-        float M = -3.0e38f, L = 0.f, A = 0.f;
-        for (int u = 0; u < 16; u++) {
-            const int slot = part * 16 + u;
-            const float m2 = sS[(0 * 64 + c) * 128 + slot], l2 = sS[(1 * 64 + c) * 128 + slot],
-                        a2 = sS[(2 * 64 + c) * 128 + slot];
-            const float mn = fmaxf(M, m2);
-            const float c1 = __expf(M - mn), c2 = __expf(m2 - mn);
-            L = L * c1 + l2 * c2;
-            A = A * c1 + a2 * c2;
-            M = mn;
-        }
+    if (tid < DA_D) {
+        float m = sRed[0][0][tid];
 #pragma unroll
-        for (int off = 1; off < 8; off <<= 1) {
-            const float m2 = __shfl_xor(M, off, 64), l2 = __shfl_xor(L, off, 64), a2 = __shfl_xor(A, off, 64);
-            const float mn = fmaxf(M, m2);
-            const float c1 = __expf(M - mn), c2 = __expf(m2 - mn);
-            L = L * c1 + l2 * c2;
-            A = A * c1 + a2 * c2;
-            M = mn;
+        for (int u = 1; u < DA_WAVES; u++) m = fmaxf(m, sRed[0][u][tid]);
+        sRed[0][0][tid] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c = rb * 16 + 4 * g + r;
+            const float f = __expf(sm[rb][r] - sRed[0][0][c]);
+            const float l = da_row_sum(sl[rb][r] * f), a = da_row_sum(sa[rb][r] * f);
+            if (j == 0) {
+                sRed[1][w][c] = l;
+                sRed[2][w][c] = a;
+            }
         }
-        if (part == 0) out[((size_t)b * nq + qi) * DA_D + c] = A / L;
+    __syncthreads();
+    if (tid < DA_D) {
+        float L = 0.f, A = 0.f;
+#pragma unroll
+        for (int u = 0; u < DA_WAVES; u++) {
+            L += sRed[1][u][tid];
+            A += sRed[2][u][tid];
+        }
+        out[((size_t)b * nq + qi) * DA_D + tid] = A / L;
     }
 }
 
@@ -223,15 +238,9 @@ extern "C" int gf_decoder_cross_attn(const float* geo_ctx, const float* max_geo,
     GF_CHECK_ARG(d == DA_D, "gf_decoder_cross_attn: implemented for dec_dim = 64 (got %d)", d);
     GF_CHECK_ARG(B >= 0 && nq >= 0 && nc >= 1, "gf_decoder_cross_attn: bad sizes");
     if (B == 0 || nq == 0) return GF_OK;
-    const size_t lds = (size_t)3 * 64 * 128 * sizeof(float);  // 96 KB (>= the 48 KB weight image)
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_decoder_cross_attn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_decoder_cross_attn, dim3(nq, B), dim3(DA_WAVES * 64), lds, (hipStream_t)stream, geo_ctx,
-                       max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), b2, nq,
-                       nc, out);
+    (void)b2;  // a per-channel constant cancels in the per-channel soft-max over the contexts
+    hipLaunchKernelGGL(k_decoder_cross_attn, dim3(nq, B), dim3(DA_WAVES * 64), 0, (hipStream_t)stream, geo_ctx, max_geo,
+                       qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out);
     GF_CHECK_LAUNCH("gf_decoder_cross_attn");
     return GF_OK;
 }
