@@ -240,7 +240,7 @@ int gf_proposal_scatter(const float* mask_logits, const int* sel, int n_sel, int
  *  heads=4, d_ff=64): model/transformer.py:62-188)
  * =================================================================================== */
 
-/* out = after(TransformerEncoder(xyz, before(feats))) per scene, one launch, one workgroup per scene.
+/* out = after(TransformerEncoder(xyz, before(feats))) per scene in n_layers + 2 launches (n_scenes <= 4096).
  *   feats fp32 [M,c] (c % 16 == 0), coords int32 [M,4] (b,x,y,z) with the rows of a scene contiguous,
  *   scene_offsets int32 [n_scenes+1] (device), out fp32 [M,c],
  *   scratch: gf_backbone_transformer_scratch_bytes(M) bytes,
