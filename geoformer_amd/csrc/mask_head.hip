@@ -20,10 +20,15 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define MH_Q 4
+#ifndef MH_Q
+#define MH_Q 2   // queries per wave: 2 at 3 workgroups per CU measured 209 us vs 262 us for 4 at 2 (S150k, nq=256)
+#endif
+#ifndef MH_MINB
+#define MH_MINB 3
+#endif
 
 template <bool USE_GEO>
-__global__ __launch_bounds__(256, 2) void k_mask_head(const float* __restrict__ feat, const float* __restrict__ coords,
+__global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restrict__ feat, const float* __restrict__ coords,
                                                       const float* __restrict__ geo, const float* __restrict__ qxyz,
                                                       const float* __restrict__ mx, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
