@@ -97,7 +97,7 @@ class ConvProbe:
         ach = byt / (us * 1e-6) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES,
-                "kernel": "k_conv_os<1,false,true> (subm 3x3x3, 16->16, level 1, BN+ReLU prologue, residual epilogue on half)", "launches": len(ms),
+                "kernel": "k_conv_os<1,0,true,false> (subm 3x3x3, 16->16, level 1, BN+ReLU prologue, residual epilogue on half)", "launches": len(ms),
                 "us_per_launch": round(us, 2), "algorithmic_bytes": byt, "rules": R, "voxels": self.M}
 
 
