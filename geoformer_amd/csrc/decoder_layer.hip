@@ -13,7 +13,7 @@
 // as two launches: stage A is token-parallel (a workgroup per 16 tokens, intermediates in LDS) and ends with the
 // q/k/v projections; stage B is query-tile-parallel (a wave per head) and needs every token's K and V, which is why
 // the launch boundary sits there.  A 4-layer decoder is 4 cross-attention launches + 9 of these small ones
-// (~5 us each) instead of ~130.  All products are v_mfma_f32_16x16x4_f32 with operands loaded straight from
+// (~20 us each) instead of ~130.  All products are v_mfma_f32_16x16x4_f32 with operands loaded straight from
 // row-major activations (LDS tiles or global rows) and nn.Linear weights [out,in] (operand scheme of
 // backbone_attn.hip).  Self-attention: 4 heads x 16 channels, S^T = K Q^T keeps the query on the MFMA column so
 // the online soft-max state is per lane column and P^T feeds V^T P^T directly; one key tile of look-ahead.
