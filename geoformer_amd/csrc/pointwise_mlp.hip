@@ -1,0 +1,123 @@
+// Per-point MLP chains of the eval forward, fused: y = L_n(... relu(affine(L_1 x)) ...) over the rows of x[N,C].
+//
+// The reference runs them as Conv1d(k=1)/Linear + BatchNorm1d + ReLU launches over [1,C,N] / [N,C] tensors:
+//   mask_tower        geoformer.py:64-71    3 x (conv1d 16->16, BN, ReLU) + conv1d 16->16      over the fg points
+//   semantic head     geoformer.py:54-62    2 x (Linear 16->16, BN, ReLU) + Linear 16->classes  over all points
+// (~10 launches and 2*4*N*C bytes of HBM traffic each; at C = 16 a layer is 64 B in, 64 B out per point).  Here a
+// wave owns 16-point tiles and keeps the activations TRANSPOSED in MFMA accumulators (channel on the row, point on
+// the column): H^T = W . X^T -- the accumulator of one layer is directly the B operand of the next, so a point's
+// features are read once and its outputs written once.  Eval-mode BatchNorm and the bias are folded by the caller
+// into one per-channel (scale, shift) pair per layer.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PM_MAXL 4
+#define PM_MAXC 64  // channels per layer (4 tiles of 16)
+
+struct PmLayer {
+    const float *W, *scale, *shift;  // W row-major [cout, cin]
+    int cin, cout, relu;
+};
+struct PmArgs {
+    PmLayer L[PM_MAXL];
+    int nl;
+};
+
+__global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__ x, int N, PmArgs A,
+                                                       float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int ntiles = (N + 15) >> 4;
+    const int c0 = A.L[0].cin, cl = A.L[A.nl - 1].cout;
+    for (int t = wave; t < ntiles; t += nwaves) {
+        const int p = t * 16 + j;
+        const bool live = p < N;
+        // B operand of the first layer: channels kc*16 + 4g .. +3 of point j
+        float4 h[PM_MAXC / 16];
+#pragma unroll
+        for (int kc = 0; kc < PM_MAXC / 16; kc++) {
+            h[kc] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kc * 16 < c0 && live) h[kc] = *reinterpret_cast<const float4*>(x + (size_t)p * c0 + kc * 16 + 4 * g);
+        }
+#pragma unroll
+        for (int l = 0; l < PM_MAXL; l++) {
+            if (l >= A.nl) break;
+            const PmLayer& L = A.L[l];
+            float4 o[PM_MAXC / 16];
+#pragma unroll
+            for (int ct = 0; ct < PM_MAXC / 16; ct++) {
+                o[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ct * 16 >= L.cout) continue;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int row = ct * 16 + j;  // output channel this lane feeds as the A operand
+#pragma unroll
+                for (int kc = 0; kc < PM_MAXC / 16; kc++) {
+                    if (kc * 16 >= L.cin) continue;
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < L.cout) a = *reinterpret_cast<const float4*>(L.W + (size_t)row * L.cin + kc * 16 + 4 * g);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, h[kc].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, h[kc].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, h[kc].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, h[kc].w, acc, 0, 0, 0);
+                }
+                // accumulator: channels ct*16 + 4g + i of point j
+                float r[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int ch = ct * 16 + 4 * g + i;
+                    float v = 0.f;
+                    if (ch < L.cout) {
+                        v = fmaf(acc[i], L.scale[ch], L.shift[ch]);
+                        if (L.relu) v = fmaxf(v, 0.f);
+                    }
+                    r[i] = v;
+                }
+                o[ct] = make_float4(r[0], r[1], r[2], r[3]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < PM_MAXC / 16; ct++) h[ct] = o[ct];
+        }
+        if (live) {
+#pragma unroll
+            for (int ct = 0; ct < PM_MAXC / 16; ct++) {
+                const int ch = ct * 16 + 4 * g;
+                if (ch + 3 < cl) {
+                    *reinterpret_cast<float4*>(out + (size_t)p * cl + ch) = h[ct];
+                } else {
+                    const float v[4] = {h[ct].x, h[ct].y, h[ct].z, h[ct].w};
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (ch + i < cl) out[(size_t)p * cl + ch + i] = v[i];
+                }
+            }
+        }
+    }
+}
+
+extern "C" int gf_pointwise_mlp(const float* x, int N, int n_layers, const float* const* W, const float* const* scale,
+                                const float* const* shift, const int* channels, const int* relu, float* out,
+                                void* stream) {
+    GF_CHECK_ARG(n_layers >= 1 && n_layers <= PM_MAXL, "gf_pointwise_mlp: 1..%d layers, got %d", PM_MAXL, n_layers);
+    GF_CHECK_ARG(N >= 0, "gf_pointwise_mlp: bad N");
+    PmArgs A;
+    for (int l = 0; l < n_layers; l++) {
+        const int cin = channels[l], cout = channels[l + 1];
+        GF_CHECK_ARG(cin >= 16 && cin <= PM_MAXC && cin % 16 == 0,
+                     "gf_pointwise_mlp: input width %d of layer %d must be a multiple of 16 in 16..%d", cin, l, PM_MAXC);
+        GF_CHECK_ARG(cout >= 1 && cout <= PM_MAXC && (l == n_layers - 1 ? cout % 4 == 0 : cout % 16 == 0),
+                     "gf_pointwise_mlp: output width %d of layer %d (hidden: multiple of 16, last: multiple of 4, <= %d)",
+                     cout, l, PM_MAXC);
+        GF_CHECK_ARG(W[l] && scale[l] && shift[l], "gf_pointwise_mlp: null parameter of layer %d", l);
+        A.L[l] = {W[l], scale[l], shift[l], cin, cout, relu[l]};
+    }
+    for (int l = n_layers; l < PM_MAXL; l++) A.L[l] = A.L[0];
+    A.nl = n_layers;
+    if (N == 0) return GF_OK;
+    const int ntiles = (N + 15) / 16;
+    int blocks = (ntiles + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_pointwise_mlp, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, A, out);
+    GF_CHECK_LAUNCH("gf_pointwise_mlp");
+    return GF_OK;
+}

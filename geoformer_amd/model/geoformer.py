@@ -170,6 +170,24 @@ class GeoFormer(nn.Module):
             mod.weight.data.fill_(1.0)
             mod.bias.data.fill_(0.0)
 
+    def _pointwise_chain(self, name, mods, x):
+        """Inference on the GPU: the Conv1d(k=1)/Linear + BatchNorm1d + ReLU stack `mods` as one fused launch
+        (csrc/pointwise_mlp.hip); None when the PyTorch modules have to run (training, CPU, odd widths)."""
+        if torch.is_grad_enabled() or not x.is_cuda or x.shape[0] == 0:
+            return None
+        flat = [m for top in mods for m in top.modules() if len(list(m.children())) == 0]
+        if any(m.training for m in flat if "BatchNorm" in type(m).__name__):
+            return None
+        params = [p for m in flat for p in list(m.parameters()) + list(m.buffers())]
+        key = (params[0].data_ptr(), sum(p._version for p in params))
+        cache = self.__dict__.setdefault("_gf_chains", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            chain = pointops.PointwiseChain(flat) if pointops.PointwiseChain.supported(flat) else None
+            hit = (key, chain)
+            cache[name] = hit
+        return hit[1]
+
     # -- backbone ---------------------------------------------------------------------------
     def preprocess_input(self, batch_input, batch_size):
         feats = batch_input["feats"]
@@ -186,7 +204,11 @@ class GeoFormer(nn.Module):
             self.prebuild_rulebooks(x)
             x = self.output_layer(self.unet(self.input_conv(x)))
             output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
-            semantic_scores = self.semantic_linear(self.semantic(output_feats))
+            chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)
+            if chain is not None:
+                semantic_scores = pointops.pointwise_mlp(output_feats, chain)
+            else:
+                semantic_scores = self.semantic_linear(self.semantic(output_feats))
             semantic_preds = semantic_scores.max(1)[1]
             return output_feats, semantic_scores, semantic_preds
 
@@ -395,7 +417,11 @@ class GeoFormer(nn.Module):
         output_feats_ = output_feats[fg_idxs]
         semantic_scores_ = semantic_scores[fg_idxs]
         offs_ = _offsets_list(batch_offsets_)  # the only read-back of this stretch, before the heavy launches
-        mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
+        chain = self._pointwise_chain("mask_tower", [self.mask_tower], output_feats_)
+        if chain is not None:
+            mask_features_ = pointops.pointwise_mlp(output_feats_.contiguous(), chain).unsqueeze(2)
+        else:
+            mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
         # the kNN graphs need the points only: on the device they run under the host's RNG draw
         graphs = None
         if locs_float_.is_cuda and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0:

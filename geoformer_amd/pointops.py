@@ -152,6 +152,67 @@ def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
     return out
 
 
+class PointwiseChain:
+    """Folded parameters of a Conv1d(k=1)/Linear + eval BatchNorm1d + ReLU stack for gf_pointwise_mlp."""
+
+    def __init__(self, modules):
+        import ctypes
+
+        layers = []  # [W, scale, shift, relu]
+        for m in modules:
+            name = type(m).__name__
+            if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d)):
+                W = m.weight.detach()
+                W = (W[:, :, 0] if W.dim() == 3 else W).float().contiguous()
+                bias = m.bias.detach().float() if m.bias is not None else torch.zeros(W.shape[0], device=W.device)
+                layers.append([W, torch.ones_like(bias), bias.clone(), 0])
+            elif "BatchNorm" in name:
+                if m.training:
+                    raise RuntimeError("PointwiseChain folds eval-mode BatchNorm only")
+                s = (m.weight / torch.sqrt(m.running_var + m.eps)).detach().float()
+                layers[-1][2] = (layers[-1][2] - m.running_mean.detach()) * s + m.bias.detach()
+                layers[-1][1] = layers[-1][1] * s
+            elif isinstance(m, torch.nn.ReLU):
+                layers[-1][3] = 1
+            elif isinstance(m, (torch.nn.Identity, torch.nn.Dropout)):
+                continue
+            else:
+                raise RuntimeError(f"PointwiseChain: unsupported module {name}")
+        self.tensors = [[l[0], l[1].contiguous(), l[2].contiguous()] for l in layers]
+        n = len(layers)
+        self.n = n
+        self.channels = [layers[0][0].shape[1]] + [l[0].shape[0] for l in layers]
+        mk = lambda k: (ctypes.c_void_p * n)(*[t[k].data_ptr() for t in self.tensors])  # noqa: E731
+        self.W, self.scale, self.shift = mk(0), mk(1), mk(2)
+        self.ch = (ctypes.c_int * (n + 1))(*self.channels)
+        self.relu = (ctypes.c_int * n)(*[l[3] for l in layers])
+
+    @staticmethod
+    def supported(modules):
+        ch = []
+        for m in modules:
+            if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d)):
+                if isinstance(m, torch.nn.Conv1d) and (m.kernel_size != (1,) or m.groups != 1 or m.stride != (1,)):
+                    return False
+                ch.append((m.weight.shape[1], m.weight.shape[0]))
+        if not 1 <= len(ch) <= 4:
+            return False
+        ok = all(ci % 16 == 0 and 16 <= ci <= 64 for ci, _ in ch) and all(co % 16 == 0 and co <= 64 for _, co in ch[:-1])
+        return ok and ch[-1][1] % 4 == 0 and ch[-1][1] <= 64
+
+
+def pointwise_mlp(x, chain):
+    """Fused per-point MLP chain over the rows of x [N, C0] -> [N, C_last] (include/geoformer_hip.h)."""
+    _f32c(x, "x")
+    N = x.shape[0]
+    if x.shape[1] != chain.channels[0]:
+        raise RuntimeError(f"pointwise_mlp: x has {x.shape[1]} channels, the chain expects {chain.channels[0]}")
+    out = torch.empty((N, chain.channels[-1]), dtype=torch.float32, device=x.device)
+    check(_lib.load().gf_pointwise_mlp(ptr(x), N, chain.n, chain.W, chain.scale, chain.shift, chain.ch, chain.relu,
+                                       ptr(out), stream_ptr()), "gf_pointwise_mlp")
+    return out
+
+
 def decoder_stage_tables(layer, final_norm):
     """(post, pre) device-pointer tables of one decoder layer for gf_decoder_token_stage (header order)."""
     import ctypes

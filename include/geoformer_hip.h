@@ -191,6 +191,19 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
                  int nq, int C, float* out, void* stream);
 
 /* ===================================================================================
+ * Per-point MLP chains of the eval forward, fused: mask_tower (geoformer.py:64-71), semantic head
+ * (geoformer.py:54-62): Conv1d(k=1)/Linear + eval BatchNorm1d + ReLU stacks over the rows of x
+ * =================================================================================== */
+
+/* out[p,:] = L_n(... L_1(x[p,:])) with L_l(h) = act_l((W_l h) * scale_l + shift_l), act = ReLU where relu[l] != 0.
+ * The caller folds bias and eval-mode BatchNorm into (scale, shift).
+ *   x fp32 [N, channels[0]], out fp32 [N, channels[n_layers]], n_layers <= 4,
+ *   W / scale / shift: HOST arrays of n_layers DEVICE pointers (W_l row-major [channels[l+1], channels[l]]),
+ *   channels: HOST int[n_layers+1] (inputs multiples of 16, <= 64; last output a multiple of 4), relu: HOST int[n_layers]. */
+int gf_pointwise_mlp(const float* x, int N, int n_layers, const float* const* W, const float* const* scale,
+                     const float* const* shift, const int* channels, const int* relu, float* out, void* stream);
+
+/* ===================================================================================
  * Token-side stages of the decoder between two cross-attentions, fused (inference)
  * (TransformerDecoderLayer.forward_pre_rel, model/transformer_detr.py:425-463; TransformerDecoder.forward,
  *  model/transformer_detr.py:130-166)

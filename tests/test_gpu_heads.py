@@ -178,3 +178,35 @@ def test_decoder_token_stages_fused(hip, nq, nc, B, ff):
         ref = torch.stack(inter)
     assert fused.shape == ref.shape
     assert (fused - ref).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
+
+
+@pytest.mark.parametrize("N,chs,last_plain", [(5000, [16, 16, 16, 16, 16], True), (77, [16, 16, 16, 20], True),
+                                              (1234, [32, 64, 16], False), (1, [16, 16], True)])
+def test_pointwise_mlp_chain(hip, N, chs, last_plain):
+    """Fused Conv1d(k=1)/Linear + eval BatchNorm1d + ReLU stack (mask_tower geoformer.py:64-71, semantic head
+    :54-62) vs the PyTorch modules on the CPU."""
+    from geoformer_amd import pointops
+
+    torch.manual_seed(N)
+    mods = []
+    for l in range(len(chs) - 1):
+        last = l == len(chs) - 2
+        mods.append(torch.nn.Linear(chs[l], chs[l + 1], bias=(l % 2 == 0)) if l % 2 == 0 else
+                    torch.nn.Conv1d(chs[l], chs[l + 1], 1, bias=False))
+        if not (last and last_plain):
+            bn = torch.nn.BatchNorm1d(chs[l + 1], eps=1e-4)
+            bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2); bn.weight.data.normal_(1, 0.2); bn.bias.data.normal_()
+            mods += [bn, torch.nn.ReLU()]
+    for m in mods:
+        m.eval()
+    x = torch.randn(N, chs[0])
+    with torch.no_grad():
+        h = x
+        for m in mods:
+            h = m(h.t().unsqueeze(0)).squeeze(0).t() if isinstance(m, torch.nn.Conv1d) else m(h)
+        assert pointops.PointwiseChain.supported(mods)
+        for m in mods:
+            m.cuda()
+        out = pointops.pointwise_mlp(x.cuda(), pointops.PointwiseChain(mods))
+    assert out.shape == h.shape
+    assert (out.cpu() - h).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
