@@ -51,6 +51,7 @@ def _declare(lib):
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
         "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
         "gf_pointwise_mlp": (I, [P, I, I, P, P, P, P, P, P, P]),
+        "gf_group_mlp_max": (I, [P, I, I, I, I, P, P, P, P, P, P, P]),
         "gf_decoder_token_state_bytes": (c_size_t, [I, I]),
         "gf_decoder_token_stage": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),

@@ -121,3 +121,139 @@ extern "C" int gf_pointwise_mlp(const float* x, int N, int n_layers, const float
     GF_CHECK_LAUNCH("gf_pointwise_mlp");
     return GF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Set-abstraction MLP + max-pool, fused (PointnetSAModuleVotes: SharedMLP over the grouped features and
+// F.max_pool2d over the samples, lib/pointnet2/pointnet2_modules.py:335-349 with pytorch_utils.SharedMLP):
+//   out[b, :, i] = max_s  L_n(... L_1(grouped[b, :, i, s]))        L_l = ReLU(BN(Conv2d 1x1))
+// One wave per centre point: its nsample columns are the MFMA columns (16 per tile), activations stay transposed
+// in accumulators from layer to layer (see k_pointwise_mlp), the maximum over the samples is a DPP row reduction
+// plus a running maximum over the tiles.  The [B, C, npoint, nsample] intermediates of the reference never exist.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float pm_row_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false)));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__ grouped, int B, int np, int ns,
+                                                       PmArgs A, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int c0 = A.L[0].cin, cl = A.L[A.nl - 1].cout;
+    const size_t cstride = (size_t)np * ns;
+    for (int item = wave; item < B * np; item += nwaves) {
+        const int b = item / np, pt = item - b * np;
+        const float* gp = grouped + (size_t)b * c0 * cstride + (size_t)pt * ns;
+        float best[PM_MAXC / 16][4];
+#pragma unroll
+        for (int ct = 0; ct < PM_MAXC / 16; ct++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) best[ct][i] = -INFINITY;
+        for (int s0 = 0; s0 < ns; s0 += 16) {
+            const int smp = s0 + j;
+            const bool live = smp < ns;
+            float4 h[PM_MAXC / 16];
+#pragma unroll
+            for (int kc = 0; kc < PM_MAXC / 16; kc++) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (kc * 16 < c0 && live) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ch = kc * 16 + 4 * g + i;
+                        if (ch < c0) v[i] = gp[(size_t)ch * cstride + smp];
+                    }
+                }
+                h[kc] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int l = 0; l < PM_MAXL; l++) {
+                if (l >= A.nl) break;
+                const PmLayer& L = A.L[l];
+                float4 o[PM_MAXC / 16];
+#pragma unroll
+                for (int ct = 0; ct < PM_MAXC / 16; ct++) {
+                    o[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ct * 16 >= L.cout) continue;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const int row = ct * 16 + j;
+#pragma unroll
+                    for (int kc = 0; kc < PM_MAXC / 16; kc++) {
+                        if (kc * 16 >= L.cin) continue;
+                        float a[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (row < L.cout) {
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const int k = kc * 16 + 4 * g + i;
+                                if (k < L.cin) a[i] = L.W[(size_t)row * L.cin + k];
+                            }
+                        }
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], h[kc].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], h[kc].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], h[kc].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], h[kc].w, acc, 0, 0, 0);
+                    }
+                    float r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int ch = ct * 16 + 4 * g + i;
+                        float v = 0.f;
+                        if (ch < L.cout) {
+                            v = fmaf(acc[i], L.scale[ch], L.shift[ch]);
+                            if (L.relu) v = fmaxf(v, 0.f);
+                        }
+                        r[i] = v;
+                    }
+                    o[ct] = make_float4(r[0], r[1], r[2], r[3]);
+                }
+#pragma unroll
+                for (int ct = 0; ct < PM_MAXC / 16; ct++) h[ct] = o[ct];
+            }
+#pragma unroll
+            for (int ct = 0; ct < PM_MAXC / 16; ct++) {
+                if (ct * 16 >= cl) continue;
+                const float v[4] = {h[ct].x, h[ct].y, h[ct].z, h[ct].w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) best[ct][i] = fmaxf(best[ct][i], pm_row_max(live ? v[i] : -INFINITY));
+            }
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int ct = 0; ct < PM_MAXC / 16; ct++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int ch = ct * 16 + 4 * g + i;
+                    if (ch < cl) out[((size_t)b * cl + ch) * np + pt] = best[ct][i];
+                }
+        }
+    }
+}
+
+extern "C" int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsample, int n_layers,
+                                const float* const* W, const float* const* scale, const float* const* shift,
+                                const int* channels, const int* relu, float* out, void* stream) {
+    GF_CHECK_ARG(n_layers >= 1 && n_layers <= PM_MAXL, "gf_group_mlp_max: 1..%d layers, got %d", PM_MAXL, n_layers);
+    GF_CHECK_ARG(B >= 0 && npoint >= 0 && nsample >= 1, "gf_group_mlp_max: bad sizes");
+    PmArgs A;
+    for (int l = 0; l < n_layers; l++) {
+        const int cin = channels[l], cout = channels[l + 1];
+        GF_CHECK_ARG(cin >= 1 && cin <= PM_MAXC && (l == 0 || cin % 16 == 0) && cout >= 1 && cout <= PM_MAXC &&
+                         (l == n_layers - 1 || cout % 16 == 0),
+                     "gf_group_mlp_max: layer %d widths %d -> %d (hidden widths: multiples of 16, all <= %d)", l, cin,
+                     cout, PM_MAXC);
+        GF_CHECK_ARG(W[l] && scale[l] && shift[l], "gf_group_mlp_max: null parameter of layer %d", l);
+        A.L[l] = {W[l], scale[l], shift[l], cin, cout, relu[l]};
+    }
+    for (int l = n_layers; l < PM_MAXL; l++) A.L[l] = A.L[0];
+    A.nl = n_layers;
+    if (B == 0 || npoint == 0) return GF_OK;
+    long long items = (long long)B * npoint;
+    int blocks = (int)((items + 3) / 4);
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    hipLaunchKernelGGL(k_group_mlp_max, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grouped, B, npoint, nsample, A,
+                       out);
+    GF_CHECK_LAUNCH("gf_group_mlp_max");
+    return GF_OK;
+}

@@ -170,13 +170,19 @@ class GeoFormer(nn.Module):
             mod.weight.data.fill_(1.0)
             mod.bias.data.fill_(0.0)
 
+    def _grad_ctx(self, name):
+        """no_grad for frozen sub-modules (geoformer.py:497,566).  The reference re-enables autograd for the others
+        even when the caller runs under torch.no_grad() (eval); that only builds a graph nobody uses, so the
+        caller's mode is respected here and the fused inference kernels stay eligible."""
+        return torch.enable_grad if (name not in self.fix_module and torch.is_grad_enabled()) else torch.no_grad
+
     def _pointwise_chain(self, name, mods, x):
         """Inference on the GPU: the Conv1d(k=1)/Linear + BatchNorm1d + ReLU stack `mods` as one fused launch
         (csrc/pointwise_mlp.hip); None when the PyTorch modules have to run (training, CPU, odd widths)."""
         if torch.is_grad_enabled() or not x.is_cuda or x.shape[0] == 0:
             return None
-        flat = [m for top in mods for m in top.modules() if len(list(m.children())) == 0]
-        if any(m.training for m in flat if "BatchNorm" in type(m).__name__):
+        flat = [m for top in mods for _, m in top.named_modules(remove_duplicate=False) if len(list(m.children())) == 0]
+        if any(m.training for m in flat if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)):
             return None
         params = [p for m in flat for p in list(m.parameters()) + list(m.buffers())]
         key = (params[0].data_ptr(), sum(p._version for p in params))
@@ -198,7 +204,7 @@ class GeoFormer(nn.Module):
                                        batch_size)
 
     def forward_backbone(self, batch_input, batch_size):
-        ctx = torch.no_grad if "unet" in self.fix_module else torch.enable_grad
+        ctx = self._grad_ctx("unet")
         with ctx():
             x = self.preprocess_input(batch_input, batch_size)
             self.prebuild_rulebooks(x)
@@ -230,7 +236,7 @@ class GeoFormer(nn.Module):
 
     # -- set aggregation ------------------------------------------------------------------------
     def forward_aggregator(self, locs_float_, output_feats_, batch_offsets_, batch_size):
-        ctx = torch.no_grad if "set_aggregator" in self.fix_module else torch.enable_grad
+        ctx = self._grad_ctx("set_aggregator")
         offs = _offsets_list(batch_offsets_)
         with ctx():
             locs, gfeat, gxyz, inds = [], [], [], []

@@ -148,9 +148,34 @@ class PointnetSAModuleVotesSeparate(nn.Module):
         grouped_features, grouped_xyz = self.grouper(xyz, new_xyz, features)
         return new_xyz, grouped_features, grouped_xyz, inds
 
+    def _fused_chain(self):
+        """Folded Conv2d(1x1)+BN+ReLU stack for the fused inference kernel (csrc/pointwise_mlp.hip), cached."""
+        from .. import pointops
+
+        flat = [m for _, m in self.mlp_module.named_modules(remove_duplicate=False) if len(list(m.children())) == 0]
+        if any(m.training for m in flat if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)):
+            return None
+        convs = [m for m in flat if isinstance(m, nn.Conv2d)]
+        if not (1 <= len(convs) <= 4) or any(m.kernel_size != (1, 1) or m.groups != 1 for m in convs) or \
+                any(m.out_channels % 16 or m.out_channels > 64 for m in convs) or convs[0].in_channels > 64:
+            return None
+        params = [p for m in flat for p in list(m.parameters()) + list(m.buffers())]
+        key = (params[0].data_ptr(), sum(p._version for p in params))
+        hit = self.__dict__.get("_gf_chain")
+        if hit is None or hit[0] != key:
+            hit = (key, pointops.PointwiseChain(flat))
+            self.__dict__["_gf_chain"] = hit
+        return hit[1]
+
     def mlp(self, grouped_features, grouped_xyz, pooling=None):
-        x = self.mlp_module(grouped_features)  # (B, C, npoint, nsample)
         pooling = pooling or self.pooling
+        if pooling == "max" and grouped_features.is_cuda and not torch.is_grad_enabled():
+            chain = self._fused_chain()
+            if chain is not None:
+                from .. import pointops
+
+                return pointops.group_mlp_max(grouped_features.contiguous(), chain)
+        x = self.mlp_module(grouped_features)  # (B, C, npoint, nsample)
         if pooling == "max":
             x = F.max_pool2d(x, kernel_size=[1, x.size(3)])
         elif pooling == "avg":

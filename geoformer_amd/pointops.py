@@ -161,12 +161,12 @@ class PointwiseChain:
         layers = []  # [W, scale, shift, relu]
         for m in modules:
             name = type(m).__name__
-            if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d)):
+            if isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, torch.nn.Conv2d)):
                 W = m.weight.detach()
-                W = (W[:, :, 0] if W.dim() == 3 else W).float().contiguous()
+                W = W.reshape(W.shape[0], W.shape[1]).float().contiguous()
                 bias = m.bias.detach().float() if m.bias is not None else torch.zeros(W.shape[0], device=W.device)
                 layers.append([W, torch.ones_like(bias), bias.clone(), 0])
-            elif "BatchNorm" in name:
+            elif isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
                 if m.training:
                     raise RuntimeError("PointwiseChain folds eval-mode BatchNorm only")
                 s = (m.weight / torch.sqrt(m.running_var + m.eps)).detach().float()
@@ -210,6 +210,18 @@ def pointwise_mlp(x, chain):
     out = torch.empty((N, chain.channels[-1]), dtype=torch.float32, device=x.device)
     check(_lib.load().gf_pointwise_mlp(ptr(x), N, chain.n, chain.W, chain.scale, chain.shift, chain.ch, chain.relu,
                                        ptr(out), stream_ptr()), "gf_pointwise_mlp")
+    return out
+
+
+def group_mlp_max(grouped, chain):
+    """Fused SharedMLP + max over the samples: grouped [B,C0,npoint,nsample] -> [B,C_last,npoint]."""
+    _f32c(grouped, "grouped")
+    B, c0, npnt, ns = grouped.shape
+    if c0 != chain.channels[0]:
+        raise RuntimeError(f"group_mlp_max: grouped has {c0} channels, the chain expects {chain.channels[0]}")
+    out = torch.empty((B, chain.channels[-1], npnt), dtype=torch.float32, device=grouped.device)
+    check(_lib.load().gf_group_mlp_max(ptr(grouped), B, npnt, ns, chain.n, chain.W, chain.scale, chain.shift, chain.ch,
+                                       chain.relu, ptr(out), stream_ptr()), "gf_group_mlp_max")
     return out
 
 

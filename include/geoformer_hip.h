@@ -203,6 +203,15 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
 int gf_pointwise_mlp(const float* x, int N, int n_layers, const float* const* W, const float* const* scale,
                      const float* const* shift, const int* channels, const int* relu, float* out, void* stream);
 
+/* Set-abstraction MLP + max-pool, fused (PointnetSAModuleVotes: SharedMLP + max_pool2d over the samples,
+ * lib/pointnet2/pointnet2_modules.py:335-349):  out[b,:,i] = max_s L_n(...L_1(grouped[b,:,i,s])), layers as above
+ * (Conv2d 1x1 + eval BatchNorm2d + ReLU folded into W / scale / shift).
+ *   grouped fp32 [B, channels[0], npoint, nsample] (gf_group_points layout), out fp32 [B, channels[n], npoint];
+ *   channels[0] arbitrary <= 64 (e.g. 3 + 16), hidden widths multiples of 16, all <= 64. */
+int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsample, int n_layers, const float* const* W,
+                     const float* const* scale, const float* const* shift, const int* channels, const int* relu,
+                     float* out, void* stream);
+
 /* ===================================================================================
  * Token-side stages of the decoder between two cross-attentions, fused (inference)
  * (TransformerDecoderLayer.forward_pre_rel, model/transformer_detr.py:425-463; TransformerDecoder.forward,

@@ -210,3 +210,25 @@ def test_pointwise_mlp_chain(hip, N, chs, last_plain):
         out = pointops.pointwise_mlp(x.cuda(), pointops.PointwiseChain(mods))
     assert out.shape == h.shape
     assert (out.cpu() - h).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
+
+
+@pytest.mark.parametrize("B,npnt,ns,dims", [(1, 300, 64, [19, 32, 32, 32]), (2, 33, 20, [19, 32, 32, 32]), (1, 5, 64, [35, 64, 16])])
+def test_group_mlp_max_fused(hip, B, npnt, ns, dims):
+    """Fused SharedMLP + max-pool of the set-abstraction module (pointnet2_modules.py:335-349) vs its PyTorch
+    modules on the CPU."""
+    from geoformer_amd.model.set_abstraction import PointnetSAModuleVotesSeparate
+
+    torch.manual_seed(npnt)
+    sa = PointnetSAModuleVotesSeparate(radius=0.2, nsample=ns, npoint=npnt, mlp=[dims[0] - 3] + dims[1:],
+                                       normalize_xyz=True)
+    for m in sa.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(); m.running_var.uniform_(0.5, 2); m.weight.data.normal_(1, 0.2); m.bias.data.normal_()
+    sa.eval()
+    g = torch.randn(B, dims[0], npnt, ns)
+    with torch.no_grad():
+        ref = sa.mlp(g, None)
+        sa.cuda()
+        out = sa.mlp(g.cuda(), None)
+    assert out.shape == ref.shape
+    assert (out.cpu() - ref).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
