@@ -49,14 +49,27 @@ __global__ __launch_bounds__(PR_THREADS) void k_proposal_stats(const float* __re
     __syncthreads();
     const int cls = s_cls;
     const float* row = logits + (size_t)q * N;
+    const float* sem_row = sem_prob + (size_t)cls * N;  // class-major: the predicted class is one contiguous row
     int cnt = 0;
     float sp = 0.f, ss = 0.f;
-    for (int p = tid; p < N; p += PR_THREADS) {
-        const float pr = pr_sigmoid(row[p]);
-        if (pr >= logit_thresh) {
-            cnt++;
-            sp += pr;
-            ss += sem_prob[(size_t)p * ncls + cls];
+    // four independent points per thread and trip (loads of a trip go out together; the class probability is
+    // fetched for every point, from a clamped index, and selected afterwards)
+    for (int p0 = tid; p0 < N; p0 += 4 * PR_THREADS) {
+        float x[4], sv[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int p = p0 + e * PR_THREADS;
+            const int pc = p < N ? p : N - 1;
+            x[e] = row[pc];
+            sv[e] = sem_row[pc];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float pr = pr_sigmoid(x[e]);
+            const bool in = (p0 + e * PR_THREADS) < N && pr >= logit_thresh;
+            cnt += in ? 1 : 0;
+            sp += in ? pr : 0.f;
+            ss += in ? sv[e] : 0.f;
         }
     }
 #pragma unroll
@@ -95,8 +108,21 @@ __global__ __launch_bounds__(256) void k_proposal_scatter(const float* __restric
     const int i = blockIdx.y;
     const float* row = logits + (size_t)sel[i] * N;
     int* out = proposals + (size_t)i * num_points;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < N; p += gridDim.x * 256)
-        if (pr_sigmoid(row[p]) >= logit_thresh) out[fg_idxs[p]] = 1;
+    const int stride = gridDim.x * 256;
+    for (int p0 = blockIdx.x * 256 + threadIdx.x; p0 < N; p0 += 4 * stride) {
+        float x[4];
+        long long dst[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int p = p0 + e * stride;
+            const int pc = p < N ? p : N - 1;
+            x[e] = row[pc];
+            dst[e] = fg_idxs[pc];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if ((p0 + e * stride) < N && pr_sigmoid(x[e]) >= logit_thresh) out[dst[e]] = 1;
+    }
 }
 
 extern "C" int gf_proposal_stats(const float* mask_logits, const float* cls_logits, const float* sem_prob, int nq,
@@ -117,7 +143,7 @@ extern "C" int gf_proposal_scatter(const float* mask_logits, const int* sel, int
                                    void* stream) {
     GF_CHECK_ARG(n_sel >= 0 && N >= 0 && num_points >= 0, "gf_proposal_scatter: bad sizes");
     if (n_sel == 0 || N == 0) return GF_OK;
-    int bx = gf_div_up(N, 256 * 8);
+    int bx = gf_div_up(N, 256 * 4);
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(k_proposal_scatter, dim3(bx, n_sel), dim3(256), 0, (hipStream_t)stream, mask_logits, sel, N,
                        fg_idxs, logit_thresh, num_points, proposals);

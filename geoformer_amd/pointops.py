@@ -252,12 +252,14 @@ def decoder_token_state(nq, B, device):
 
 
 def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh, npoint_thresh, min_class=4):
-    """Fused statistics of generate_proposal: (cls_pred i32[nq], npoints i32[nq], scores f32[nq], final i32[nq])."""
-    _f32c(mask_logits, "mask_logits"), _f32c(cls_logits, "cls_logits"), _f32c(sem_prob, "sem_prob")
+    """Fused statistics of generate_proposal: (cls_pred i32[nq], npoints i32[nq], scores f32[nq], final i32[nq]).
+    sem_prob [N,ncls] is handed to the kernel class-major (one coalesced row per predicted class)."""
+    _f32c(mask_logits, "mask_logits"), _f32c(cls_logits, "cls_logits")
     nq, N = mask_logits.shape
     ncls = cls_logits.shape[1]
     if sem_prob.shape != (N, ncls):
         raise RuntimeError(f"sem_prob must be [{N},{ncls}], got {tuple(sem_prob.shape)}")
+    sem_prob = _f32c(sem_prob.t().contiguous(), "sem_prob")
     ints = torch.empty((3, nq), dtype=torch.int32, device=mask_logits.device)
     scores = torch.empty(nq, dtype=torch.float32, device=mask_logits.device)
     check(_lib.load().gf_proposal_stats(ptr(mask_logits), ptr(cls_logits), ptr(sem_prob), nq, N, ncls,

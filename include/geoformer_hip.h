@@ -245,8 +245,8 @@ int gf_decoder_token_stage(const float* attn_out, const float* tgt_in, const flo
  *   sem_score = sum_{members} sem_prob[p, cls_pred] / (npoints + 1e-6),
  *   scores[q] = mask_score * sqrt(cls_score) * sem_score,
  *   final[q] = cls_pred >= min_class && npoints >= npoint_thresh && mask_score >= score_thresh.
- *   mask_logits fp32 [nq,N], cls_logits fp32 [nq,ncls], sem_prob fp32 [N,ncls] (soft-max of the semantic
- *   scores of the foreground points); outputs int32 [nq] / fp32 [nq]. */
+ *   mask_logits fp32 [nq,N], cls_logits fp32 [nq,ncls], sem_prob fp32 [ncls,N] CLASS-MAJOR (soft-max of the
+ *   semantic scores of the foreground points, transposed); outputs int32 [nq] / fp32 [nq]. */
 int gf_proposal_stats(const float* mask_logits, const float* cls_logits, const float* sem_prob, int nq, int N,
                       int ncls, float logit_thresh, float score_thresh, int npoint_thresh, int min_class,
                       int* cls_pred, int* npoints, float* scores, int* final_mask, void* stream);
