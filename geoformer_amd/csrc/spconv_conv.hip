@@ -355,6 +355,146 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
     }
 }
 
+// Two 16-row groups per wave for the big 16-output-channel levels (level 1 of the U-Net: ~9000 groups).
+// Measured on the S150k level-1 launch (variants with parts compiled out, rocprofv3 kernel trace): index staging +
+// output 4.3 us, gathers 3.3 us, weight fetches 0.3 us, and 13.8 us for the loop WITHOUT any memory access, i.e. the
+// kernel is instruction-issue bound: ~6 us of MFMA (32 cycles each per SIMD) plus the per-step address / control
+// VALU work.  Hence: two groups share every step's control flow and weight fetch, the neighbour table is staged in
+// LDS as ready-made byte offsets (missing = out of the descriptor's range, which reads as zeros), and the presence
+// flags are only materialised for the fused BatchNorm prologue.  The steps walk the UNION of the two groups' offsets.
+#ifndef CONV_PAIR_PF
+#define CONV_PAIR_PF 2
+#endif
+#define CONV_PAIR_MISSING 0xfffff000u
+template <bool AFF>
+__global__ __launch_bounds__(256, 5) void k_conv_pair(const float* __restrict__ in, const float4* __restrict__ Wp,
+                                                      const int32_t* __restrict__ nbr,
+                                                      const uint32_t* __restrict__ gmask, int K, int M_out, int ld,
+                                                      int Cin, int Cout, int NCH, unsigned in_bytes,
+                                                      const float* __restrict__ in_scale,
+                                                      const float* __restrict__ in_shift,
+                                                      const float* __restrict__ residual, float* __restrict__ out) {
+    constexpr int PF = CONV_PAIR_PF;
+    __shared__ unsigned s_off[4][32 * 32];
+    __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int ngroups = (M_out + 15) >> 4;
+    const int npairs = (ngroups + 1) >> 1;
+    const int first = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int stride = (gridDim.x * blockDim.x) >> 6;
+    unsigned* off_l = s_off[w];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, K * NCH * 1024, 0x00020000);
+    const unsigned rowbytes = (unsigned)Cin * 4u;
+    const unsigned lane_ch = 16u * (unsigned)q;  // byte offset of this lane's 4 channels inside a 16-channel chunk
+    if (AFF) {
+        for (int c = threadIdx.x; c < NCH * 16; c += blockDim.x) {
+            s_aff[0][c] = c < Cin ? in_scale[c] : 0.f;
+            s_aff[1][c] = c < Cin ? in_shift[c] : 0.f;
+        }
+        __syncthreads();
+    }
+    for (int pr = first; pr < npairs; pr += stride) {
+        const int g0 = 2 * pr, g1 = g0 + 1;
+        const int o0 = g0 * 16 + r, o1 = g1 * 16 + r;
+        const bool ok0 = o0 < M_out, ok1 = o1 < M_out;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // residual rows of this lane's accumulator elements, requested up front (epilogue add)
+        float res0[4] = {0.f, 0.f, 0.f, 0.f}, res1[4] = {0.f, 0.f, 0.f, 0.f};
+        if (residual && r < Cout) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row0 = g0 * 16 + q * 4 + j, row1 = g1 * 16 + q * 4 + j;
+                if (row0 < M_out) res0[j] = residual[(size_t)row0 * Cout + r];
+                if (row1 < M_out) res1[j] = residual[(size_t)row1 * Cout + r];
+            }
+        }
+        const uint32_t full = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+        const uint32_t m0 = gmask ? gmask[g0] : full, m1 = g1 < ngroups ? (gmask ? gmask[g1] : full) : 0u;
+        const uint32_t mask = __builtin_amdgcn_readfirstlane(m0 | m1);
+        // byte offsets of the neighbour rows of the union offsets: lane (r,q) fetches offsets q, q+4, ... of both groups
+        {
+            // all loads first (one round trip), then the LDS writes
+            int i0[8], i1[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = q + 4 * i;
+                const bool want = k < K && ((mask >> k) & 1u);
+                i0[i] = (want && ok0) ? nbr[(size_t)k * ld + o0] : -1;
+                i1[i] = (want && ok1) ? nbr[(size_t)k * ld + o1] : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = q + 4 * i;
+                if (k < K) {
+                    off_l[k * 32 + r] = i0[i] >= 0 ? (unsigned)i0[i] * rowbytes : CONV_PAIR_MISSING;
+                    off_l[k * 32 + 16 + r] = i1[i] >= 0 ? (unsigned)i1[i] * rowbytes : CONV_PAIR_MISSING;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        StepIter it;
+        it.init(mask, NCH);
+        while (it.k >= 0) {
+            u32x4 x0[PF], x1[PF], wv[PF];
+            unsigned v0[PF], v1[PF];
+            int chn[PF];
+            int nv = 0;
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                if (it.k >= 0) {
+                    nv = j + 1;
+                    const unsigned cbyte = (unsigned)it.c * 64u + lane_ch;
+                    chn[j] = (int)(cbyte >> 2);
+                    v0[j] = off_l[it.k * 32 + r] + cbyte;
+                    v1[j] = off_l[it.k * 32 + 16 + r] + cbyte;
+                    x0[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, v0[j], 0, 0);
+                    x1[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, v1[j], 0, 0);
+                    wv[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)lane * 16u,
+                                                                  (unsigned)(it.k * NCH + it.c) * 1024u, 0);
+                }
+                it.next();
+            }
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                if (j < nv) {
+                    float4 a0 = make_float4(__uint_as_float(x0[j][0]), __uint_as_float(x0[j][1]),
+                                            __uint_as_float(x0[j][2]), __uint_as_float(x0[j][3]));
+                    float4 a1 = make_float4(__uint_as_float(x1[j][0]), __uint_as_float(x1[j][1]),
+                                            __uint_as_float(x1[j][2]), __uint_as_float(x1[j][3]));
+                    if (AFF) {
+                        a0 = activate_a(a0, v0[j] < CONV_PAIR_MISSING, s_aff[0], s_aff[1], chn[j]);
+                        a1 = activate_a(a1, v1[j] < CONV_PAIR_MISSING, s_aff[0], s_aff[1], chn[j]);
+                    }
+                    const float b0 = __uint_as_float(wv[j][0]), b1 = __uint_as_float(wv[j][1]),
+                                b2 = __uint_as_float(wv[j][2]), b3 = __uint_as_float(wv[j][3]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b0, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b1, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b2, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b2, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b3, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b3, acc1, 0, 0, 0);
+                }
+            }
+        }
+        // C/D layout: col = lane&15, row = (lane>>4)*4 + j
+        if (r < Cout) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row0 = g0 * 16 + q * 4 + j, row1 = g1 * 16 + q * 4 + j;
+                if (row0 < M_out) out[(size_t)row0 * Cout + r] = acc0[j] + res0[j];
+                if (row1 < M_out) out[(size_t)row1 * Cout + r] = acc1[j] + res1[j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // off_l is rewritten by the next pair
+    }
+}
+
 struct ConvArgs {
     const float* in;
     const float4* Wp;
@@ -442,7 +582,19 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     // S150k level 1), so it is opt-in (GF_CONV_LDSW=1) until the staging cost is amortised differently
     bool ldsw = false;
     if (const char* e = getenv("GF_CONV_LDSW")) ldsw = atoi(e) != 0 && !split && vec && ncb <= 2 && wbytes <= 64 * 1024;
-    if (ldsw) {
+    bool pair = !split && vec && ncb == 1 && nbr != nullptr && K <= 32 && nch <= 8 && in_bytes64 <= 0xfffff000ull - 4096ull;
+    if (const char* e = getenv("GF_CONV_PAIR")) pair = pair && atoi(e) != 0;
+    if (pair && !ldsw) {
+        const long long npairs = (ngroups + 1) / 2;
+        long long pb = (npairs + 3) / 4;
+        if (pb > 256 * 64) pb = 256 * 64;
+        if (a.sc)
+            hipLaunchKernelGGL(k_conv_pair<true>, dim3((unsigned)pb), dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+                               a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.out);
+        else
+            hipLaunchKernelGGL(k_conv_pair<false>, dim3((unsigned)pb), dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+                               a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.out);
+    } else if (ldsw) {
         // 512-thread workgroups share one weight image: 8 waves per 27-54 KiB
         const int bs = 512;
         dim3 g2((unsigned)((nitems + 7) / 8));
