@@ -33,10 +33,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM-side bytes per launch of that kernel from rocprofv3 PMC passes on this scene (profiles/r1_c_pmc_conv_l1.md):
-# FETCH_SIZE 17 160 KiB (raw; the guide's x2 correction for wide streaming reads is uncalibrated for 64-byte
-# gathers) + WRITE_SIZE 8 882 KiB.  Far below the 73 MB algorithmic figure: the ~6 re-reads of every input row
-# are served by L1/L2 (90 % L1 hit), i.e. the kernel is latency/L1-issue-bound, not HBM-bound.
-PMC_TRAFFIC_BYTES = (17160 + 8882) * 1024
+# FETCH_SIZE 14 998 KiB (raw; the guide's x2 correction for wide streaming reads is uncalibrated for 64-byte
+# gathers) + WRITE_SIZE 8 882 KiB (k_conv_pair, tools/pmc_conv_l1.sh; 17 160 + 8 882 KiB for the one-group-per-wave
+# kernel before it).  Far below the 73 MB algorithmic figure: the ~6 re-reads of every input row are served by
+# L1/L2, i.e. the kernel is bound by L1 throughput / dependent latency / issue, not by HBM.
+PMC_TRAFFIC_BYTES = (14998 + 8882) * 1024
 
 
 def build_model(device, nfg_frac=0.4, probe_batch=None):
@@ -97,7 +98,7 @@ class ConvProbe:
         ach = byt / (us * 1e-6) / 1e9
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES,
-                "kernel": "k_conv_os<1,0,true,false> (subm 3x3x3, 16->16, level 1, BN+ReLU prologue, residual epilogue on half)", "launches": len(ms),
+                "kernel": "k_conv_pair (subm 3x3x3, 16->16, level 1, BN+ReLU prologue, residual epilogue on half)", "launches": len(ms),
                 "us_per_launch": round(us, 2), "algorithmic_bytes": byt, "rules": R, "voxels": self.M}
 
 
