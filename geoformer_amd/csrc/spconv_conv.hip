@@ -228,11 +228,21 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
         }
         uint32_t mask = nbr ? (gmask ? gmask[g] : ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u))) : 1u;
         mask = __builtin_amdgcn_readfirstlane(mask);
-        // stage the neighbour indices of the present offsets (lane (r,q) fetches offsets q, q+4, ...)
+        // stage the neighbour indices of the present offsets (lane (r,q) fetches offsets q, q+4, ...): all loads
+        // first -- one memory round trip instead of up to eight dependent ones -- then the LDS writes
+        {
+            int iv[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int k = q + 4 * i;
-            if (k < K && ((mask >> k) & 1u)) idx_l[k * 16 + r] = row_ok ? (nbr ? nbr[(size_t)k * ld + o] : o) : -1;
+            for (int i = 0; i < 8; i++) {
+                const int k = q + 4 * i;
+                const bool want = k < K && ((mask >> k) & 1u) && row_ok;
+                iv[i] = want ? (nbr ? nbr[(size_t)k * ld + o] : o) : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int k = q + 4 * i;
+                if (k < K) idx_l[k * 16 + r] = iv[i];
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
