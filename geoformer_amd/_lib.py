@@ -54,6 +54,8 @@ def _declare(lib):
         "gf_group_mlp_max": (I, [P, I, I, I, I, P, P, P, P, P, P, P]),
         "gf_decoder_token_state_bytes": (c_size_t, [I, I]),
         "gf_decoder_token_stage": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
+        "gf_mask_intersections_scratch_bytes": (c_size_t, [I, I]),
+        "gf_mask_intersections": (I, [P, I, I, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),

@@ -281,6 +281,18 @@ def proposal_scatter(mask_logits, sel, fg_idxs, logit_thresh, num_points):
     return out
 
 
+def mask_intersections(masks):
+    """inter[i,j] = |mask_i AND mask_j| for 0/1 int32 masks [n,N] (bit-packed popcount kernel)."""
+    _i32c(masks, "masks")
+    n, N = masks.shape
+    lib = _lib.load()
+    scratch = torch.empty(lib.gf_mask_intersections_scratch_bytes(n, N) // 8 + 1, dtype=torch.int64,
+                          device=masks.device)
+    inter = torch.empty((n, n), dtype=torch.int32, device=masks.device)
+    check(lib.gf_mask_intersections(ptr(masks), n, N, ptr(scratch), ptr(inter), stream_ptr()), "gf_mask_intersections")
+    return inter
+
+
 def backbone_transformer_params(before, transformer, after):
     """Device-pointer table of gf_backbone_transformer in the order include/geoformer_hip.h documents."""
     import ctypes

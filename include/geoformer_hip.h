@@ -256,6 +256,12 @@ int gf_proposal_stats(const float* mask_logits, const float* cls_logits, const f
 int gf_proposal_scatter(const float* mask_logits, const int* sel, int n_sel, int N, const long long* fg_idxs,
                         float logit_thresh, int num_points, int* proposals, void* stream);
 
+/* inter[i,j] = number of points in both proposal i and proposal j (matrix NMS, util/utils_3d.py:95-141: the
+ * einsum over the [n,N] float masks; exact because the masks are 0/1).  masks int32 [n,N] (gf_proposal_scatter
+ * output), inter int32 [n,n], scratch: gf_mask_intersections_scratch_bytes(n, N). */
+size_t gf_mask_intersections_scratch_bytes(int n, int N);
+int gf_mask_intersections(const int32_t* masks, int n, int N, void* scratch, int32_t* inter, void* stream);
+
 /* ===================================================================================
  * Backbone voxel transformer of the two deepest U-Net levels, fused (inference)
  * (UBlock: model/geoformer/geoformer_modules.py:64-68,120-127; TransformerEncoder(d_model=128, N,

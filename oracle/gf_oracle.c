@@ -674,3 +674,13 @@ ORC_API void orc_proposal_scatter(const float *mask_logits, const int32_t *sel, 
         if (1.0f / (1.0f + expf(-mask_logits[(size_t)sel[i] * N + p])) >= logit_thresh)
             proposals[(size_t)i * num_points + fg_idxs[p]] = 1;
 }
+
+/* pairwise intersections of 0/1 proposal masks = the einsum("nc,mc->nm") of matrix_non_max_suppression
+ * (util/utils_3d.py:104) */
+ORC_API void orc_mask_intersections(const int32_t *masks, int32_t n, int32_t N, int32_t *inter) {
+    for (int32_t i = 0; i < n; i++) for (int32_t j = 0; j < n; j++) {
+        int32_t c = 0;
+        for (int32_t p = 0; p < N; p++) c += (masks[(size_t)i * N + p] != 0) && (masks[(size_t)j * N + p] != 0);
+        inter[(size_t)i * n + j] = c;
+    }
+}

@@ -321,3 +321,11 @@ def proposal_scatter(mask_logits, sel, fg_idxs, logit_thresh, num_points):
     lib().orc_proposal_scatter(_p(mask_logits), _p(sel), c_int32(sel.shape[0]), c_int32(mask_logits.shape[1]),
                                _p(fg_idxs), c_float(logit_thresh), c_int32(num_points), _p(out))
     return out
+
+
+def mask_intersections(masks):
+    masks = _i32(masks)
+    n, N = masks.shape
+    inter = np.zeros((n, n), np.int32)
+    lib().orc_mask_intersections(_p(masks), c_int32(n), c_int32(N), _p(inter))
+    return inter

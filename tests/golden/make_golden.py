@@ -8,6 +8,7 @@ CPU oracle through tests/golden/ref_shims.py.  Outputs (committed, small):
     geoformer_s8k_eval.npz           S8k scene, test yaml (nq=256, nc=2048), eval forward: stage outputs
     geodesic_vectorize.npz           cal_geodesic_vectorize on a 3k-point cloud (pins the BFS oracle)
     decoder_layer.npz                one TransformerDecoderLayer + fourier embedding on random inputs
+    matrix_nms.npz                   util.utils_3d.matrix_non_max_suppression on overlapping random proposals (`nms`)
 Weights are NOT stored: both sides call tests.util.synthetic_state_dict (deterministic by name).
 """
 import json
@@ -18,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
-_WHICH = [a for a in sys.argv[1:] if a in ("geodesic", "decoder", "model", "fs")]
+_WHICH = [a for a in sys.argv[1:] if a in ("geodesic", "decoder", "model", "fs", "nms")]
 _YAML = "config/test_geoformer_fs_scannet.yaml" if _WHICH == ["fs"] else "config/test_geoformer_scannet.yaml"
 sys.argv = ["make_golden", "--config", os.path.join(REF, _YAML)]  # util/config.py parses argv at import: one yaml per process
 
@@ -144,6 +145,31 @@ def golden_decoder_layer():
     print("decoder golden ok", out.abs().mean().item())
 
 
+def golden_matrix_nms():
+    """matrix_non_max_suppression (util/utils_3d.py:95-141) on overlapping random proposals, both kernels."""
+    from util.utils_3d import matrix_non_max_suppression
+
+    rng = np.random.default_rng(11)
+    n, N = 40, 3000
+    base = rng.integers(0, N - 400, 12)
+    masks = np.zeros((n, N), np.float32)
+    for i in range(n):
+        b = base[rng.integers(0, len(base))] + rng.integers(-60, 60)
+        w = rng.integers(150, 400)
+        masks[i, max(b, 0):b + w] = 1
+        masks[i, rng.integers(0, N, 30)] = 1
+    scores = rng.uniform(0.2, 1.0, n).astype(np.float32)
+    cats = rng.integers(4, 8, n).astype(np.int64)
+    out = {"masks": masks.astype(np.int32), "scores": scores, "categories": cats}
+    for kern in ("gaussian", "linear"):
+        for thr in (0.5, 0.05):
+            pick = matrix_non_max_suppression(torch.from_numpy(masks), torch.from_numpy(scores), torch.from_numpy(cats),
+                                              kernel=kern, final_score_thresh=thr)
+            out[f"pick_{kern}_{thr}"] = pick.numpy()
+    np.savez_compressed(os.path.join(HERE, "matrix_nms.npz"), **out)
+    print("matrix_nms.npz", {k: v.shape for k, v in out.items()})
+
+
 def fs_dicts():
     """Query scene + one full support scene with one labelled cuboid as support mask."""
     q = scene.make_batch([scene.make_small_scene(8192, 7)])
@@ -198,6 +224,8 @@ if __name__ == "__main__":
     which = _WHICH or ["geodesic", "decoder", "model"]
     if "fs" in which:
         golden_fs()
+    if "nms" in which:
+        golden_matrix_nms()
     if "geodesic" in which:
         golden_geodesic()
     if "decoder" in which:

@@ -232,3 +232,26 @@ def test_group_mlp_max_fused(hip, B, npnt, ns, dims):
         out = sa.mlp(g.cuda(), None)
     assert out.shape == ref.shape
     assert (out.cpu() - ref).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
+
+
+def test_matrix_nms_gpu(hip, oracle):
+    """Bit-packed intersection kernel vs the oracle (exact), and the GPU matrix NMS vs the reference golden."""
+    import os
+
+    from geoformer_amd import pointops
+    from geoformer_amd.postprocess import matrix_non_max_suppression
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "matrix_nms.npz"))
+    masks = torch.from_numpy(z["masks"]).cuda()
+    assert (pointops.mask_intersections(masks).cpu().numpy() == oracle.mask_intersections(z["masks"])).all()
+    for key in z.files:
+        if key.startswith("pick_"):
+            _, kern, thr = key.split("_")
+            pick = matrix_non_max_suppression(masks, torch.from_numpy(z["scores"]).cuda(),
+                                              torch.from_numpy(z["categories"]).cuda(), kernel=kern,
+                                              final_score_thresh=float(thr))
+            assert (pick.cpu().numpy() == z[key]).all(), key
+    rng = np.random.default_rng(3)
+    big = (rng.uniform(size=(70, 10007)) < 0.05).astype(np.int32)  # N not a multiple of 64, empty-ish rows
+    big[5] = 0
+    assert (pointops.mask_intersections(torch.from_numpy(big).cuda()).cpu().numpy() == oracle.mask_intersections(big)).all()

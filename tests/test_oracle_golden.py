@@ -58,3 +58,27 @@ def test_decoder_layer_and_fourier_match_reference():
     with torch.no_grad():
         out, _ = layer(t("tgt"), t("memory"), query_pos=t("query_pos"), relative_pos=rel)
     assert np.abs(out.numpy() - z["out"]).max() < 1e-4
+
+
+def test_matrix_nms_matches_reference_golden(oracle):
+    """geoformer_amd.postprocess.matrix_non_max_suppression (CPU path) and the oracle's intersection counts against
+    the picks of the reference's own util.utils_3d.matrix_non_max_suppression (tests/golden/matrix_nms.npz)."""
+    import os
+
+    import torch
+
+    from geoformer_amd.postprocess import matrix_non_max_suppression
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "matrix_nms.npz"))
+    masks = z["masks"]
+    inter = oracle.mask_intersections(masks)
+    f = masks.astype(np.float32)
+    assert (inter == (f @ f.T).astype(np.int32)).all()
+    for key in z.files:
+        if not key.startswith("pick_"):
+            continue
+        _, kern, thr = key.split("_")
+        pick = matrix_non_max_suppression(torch.from_numpy(f), torch.from_numpy(z["scores"]),
+                                          torch.from_numpy(z["categories"]), kernel=kern,
+                                          final_score_thresh=float(thr))
+        assert (pick.numpy() == z[key]).all(), key
