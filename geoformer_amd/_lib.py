@@ -35,6 +35,7 @@ def _declare(lib):
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P]),
         "gf_conv_fwd_timed": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_resblock_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
         "gf_voxelize_bp": (I, [P, P, I, I, I, I, P, P]),
@@ -112,13 +113,20 @@ def check(status: int, what: str = ""):
 
 
 def ptr(t):
-    """Device (or host) address of a tensor, None -> NULL."""
-    if t is None:
-        return None
-    return c_void_p(t.data_ptr())
+    """Device (or host) address of a tensor as a plain int (ctypes converts it for a c_void_p argtype), None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = None
 
 
 def stream_ptr():
+    """hipStream_t of PyTorch's current stream on the current device (plain int)."""
+    global _raw_stream
     import torch
 
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream

@@ -620,6 +620,27 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     return GF_OK;
 }
 
+// Pre-activation residual block of the U-Net in one call (ResidualBlock, geoformer_modules.py:10-35, eval):
+//   out = conv1(relu(bn1(conv0(relu(bn0(x)))))) + (Wi ? x . Wi : x)
+// Three (two) launches of the kernels above; exists because the host side of a 17-26 us launch matters: one
+// boundary crossing per block instead of three.
+extern "C" int gf_resblock_fwd(const float* x, const float* Wp0, const float* Wp1, const float* Wpi,
+                               const int32_t* nbr, const uint32_t* gmask, int K, int M, int ld, int Cin, int Cout,
+                               const float* s0, const float* t0, const float* s1, const float* t1, float* tmp,
+                               float* idn, float* out, void* stream) {
+    GF_CHECK_ARG(x && Wp0 && Wp1 && tmp && out, "gf_resblock_fwd: null argument");
+    GF_CHECK_ARG(Wpi != nullptr || Cin == Cout, "gf_resblock_fwd: identity branch needs Cin == Cout");
+    GF_CHECK_ARG((Wpi == nullptr) == (idn == nullptr), "gf_resblock_fwd: Wpi and idn come together");
+    int rc;
+    if (Wpi) {
+        rc = gf_conv_fwd(x, Wpi, nullptr, nullptr, 1, M, M, 0, Cin, Cout, nullptr, nullptr, nullptr, idn, stream);
+        if (rc != GF_OK) return rc;
+    }
+    rc = gf_conv_fwd(x, Wp0, nbr, gmask, K, M, M, ld, Cin, Cout, s0, t0, nullptr, tmp, stream);
+    if (rc != GF_OK) return rc;
+    return gf_conv_fwd(tmp, Wp1, nbr, gmask, K, M, M, ld, Cout, Cout, s1, t1, Wpi ? idn : x, out, stream);
+}
+
 // Same launch bracketed by two caller-owned hipEvent_t recorded back to back with the kernel on the
 // same stream (bench.py's roofline probe: the kernel's own duration, not the host's launch gaps).
 extern "C" int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,

@@ -51,22 +51,37 @@ class ResidualBlock(SparseModule):
             spconv.SubMConv3d(out_channels, out_channels, kernel_size=3, padding=1, bias=False, indice_key=indice_key),
         )
 
-    def _forward_fused(self, input):
+    def _fused_params(self):
+        """Packed weights and folded BatchNorm of the block, rebuilt when any of them changes (one combined key)."""
         from .. import sparse
 
         bn0, _, conv0, bn1, _, conv1 = list(self.conv_branch._modules.values())
+        ib = self.i_branch[0]
+        wi = None if isinstance(ib, nn.Identity) else ib.weight
+        key = (conv0.weight._version, conv1.weight._version, bn0.weight._version, bn0.bias._version,
+               bn0.running_mean._version, bn0.running_var._version, bn1.weight._version, bn1.bias._version,
+               bn1.running_mean._version, bn1.running_var._version, conv0.weight.data_ptr(),
+               -1 if wi is None else wi._version)
+        hit = self.__dict__.get("_gf_block")
+        if hit is None or hit[0] != key:
+            s0, t0 = bn_affine(bn0)
+            s1, t1 = bn_affine(bn1)
+            wpi = None if wi is None else sparse.pack_weights(wi.view(1, ib.in_channels, ib.out_channels))
+            hit = (key, sparse.pack_weights(conv0.weight), sparse.pack_weights(conv1.weight), wpi, s0, t0, s1, t1,
+                   conv0, conv1)
+            self.__dict__["_gf_block"] = hit
+        return hit
+
+    def _forward_fused(self, input):
+        from .. import sparse
+
+        _, wp0, wp1, wpi, s0, t0, s1, t1, conv0, conv1 = self._fused_params()
         rules = conv0.get_rules(input)
         M = input.indices.shape[0]
-        x = input.features.contiguous()
-        s0, t0 = bn_affine(bn0)
-        y = sparse.conv_fwd(x, conv0.weight, rules.nbr, rules.gmask, 27, M, rules.ld, in_scale=s0, in_shift=t0)
-        ib = self.i_branch[0]
-        idn = x if isinstance(ib, nn.Identity) else torch.mm(x, ib.weight.view(ib.in_channels, ib.out_channels))
-        s1, t1 = bn_affine(bn1)
         out = conv1._new_like(input)
         out._index = input._index
-        out.features = sparse.conv_fwd(y, conv1.weight, rules.nbr, rules.gmask, 27, M, rules.ld, in_scale=s1,
-                                       in_shift=t1, residual=idn.contiguous())
+        out.features = sparse.resblock_fwd(input.features.contiguous(), wp0, wp1, wpi, rules.nbr, rules.gmask, 27, M,
+                                           rules.ld, conv0.in_channels, conv0.out_channels, s0, t0, s1, t1)
         return out
 
     def forward(self, input):

@@ -106,6 +106,15 @@ int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, cons
                       int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
                       const float* residual, float* out, void* ev_start, void* ev_stop, void* stream);
 
+/* Pre-activation residual block (ResidualBlock, model/geoformer/geoformer_modules.py:10-35) in eval mode, one
+ * call:  out = conv1(relu(bn1(conv0(relu(bn0(x)))))) + (Wpi ? x . Wi : x).
+ *   x fp32 [M,Cin]; Wp0 (K,Cin,Cout), Wp1 (K,Cout,Cout), Wpi (1,Cin,Cout) or NULL: gf_conv_pack_weights output;
+ *   nbr/gmask/K/ld: the level's submanifold table; s0,t0 [Cin], s1,t1 [Cout]: folded BatchNorm (scale, shift);
+ *   tmp, idn (NULL iff Wpi NULL), out fp32 [M,Cout]. */
+int gf_resblock_fwd(const float* x, const float* Wp0, const float* Wp1, const float* Wpi, const int32_t* nbr,
+                    const uint32_t* gmask, int K, int M, int ld, int Cin, int Cout, const float* s0, const float* t0,
+                    const float* s1, const float* t1, float* tmp, float* idn, float* out, void* stream);
+
 /* Weight gradient of the same operator: dW[k] = sum_o in[nbr[k][o],:]^T dOut[o,:]  (dW fp32
  * [K,Cin,Cout], zeroed by the call).  The input gradient needs no entry point of its own: it is
  * gf_conv_fwd over the transposed table with per-offset transposed weights
