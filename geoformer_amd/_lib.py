@@ -46,6 +46,7 @@ def _declare(lib):
         "gf_ball_query": (I, [P, P, I, I, I, F, I, P, P]),
         "gf_fps_scratch_bytes": (c_size_t, [I]),
         "gf_furthest_point_sampling": (I, [P, I, I, I, P, P, P]),
+        "gf_furthest_point_sampling_resume": (I, [P, I, I, I, I, P, P, P]),
         "gf_knn_scratch_bytes": (c_size_t, [I]),
         "gf_knn_radius": (I, [P, I, I, F, I, P, P, P, P, P]),
         "gf_knn_error_flag": (P, [P, I]),

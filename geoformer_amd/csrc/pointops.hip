@@ -9,6 +9,8 @@
 // match oracle/gf_oracle.c term by term.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------
@@ -255,6 +257,16 @@ __device__ __forceinline__ void wave_best(unsigned& dbits, unsigned& key) {
     dbits = md;
 }
 
+// compile-time loop: the wave-wide reductions inside these bodies keep the optimiser from unrolling an ordinary
+// loop, and a runtime-indexed candidate array then lands in LDS (64 KB per workgroup) instead of registers
+template <int I, int N, typename F>
+__device__ __forceinline__ void fps_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        fps_static_for<I + 1, N>(f);
+    }
+}
+
 #ifndef FPS_WAVES
 #define FPS_WAVES 16  // waves per workgroup
 #endif
@@ -284,7 +296,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long c)
     }
     return ((unsigned long long)md << 32) | ml;
 }
-__device__ __forceinline__ unsigned long long glt_lane_fix(const unsigned long long* g, int lane) {
+__device__ __forceinline__ unsigned long long glt_lane_fix(const unsigned long long (&g)[8], int lane) {
     unsigned long long v = g[0];
 #pragma unroll
     for (int t = 1; t < 8; t++) v = lane == t ? g[t] : v;
@@ -304,7 +316,7 @@ __device__ __forceinline__ int fps_code_index(unsigned long long c) {
 // a sorted prefix of its candidates with the last one flagged, and merging stops after consuming a
 // flagged entry (the source's next one is unknown), which keeps the result exact.
 template <int P>
-__global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict__ xyz, int n, int m, int G,
+__global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict__ xyz, int n, int m, int m0, int G,
                                                         int bs_log2, int batch0,
                                                         unsigned long long* __restrict__ slots,
                                                         int32_t* __restrict__ idxs, int* __restrict__ err) {
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             key[i] = (rev << 22) | (unsigned)k;
         }
     }
-    if (wg == 0 && threadIdx.x == 0) idxs[0] = 0;
+    if (m0 <= 0 && wg == 0 && threadIdx.x == 0) idxs[0] = 0;
     // picks of the previous exchange (uniform): count + coordinates
     int nnew = 1;
     float nx[FPS_K], ny[FPS_K], nz[FPS_K];
@@ -349,6 +361,40 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
 #pragma unroll
     for (int a = 1; a < FPS_K; a++) nx[a] = ny[a] = nz[a] = 0.f;
     int done = 1;  // picks written so far
+    if (m0 > 1) {
+        // resume: idxs[0..m0) are the first m0 picks of this very sequence (an earlier launch); the state of the
+        // algorithm is a function of the pick SET, so absorbing them in any grouping reproduces it exactly
+        for (int base = 0; base < m0 - 1; base += FPS_K) {
+            const int cntk = min(FPS_K, m0 - 1 - base);
+#pragma unroll
+            for (int a = 0; a < FPS_K; a++) {
+                const int pi = a < cntk ? idxs[base + a] : 0;
+                nx[a] = xyz[(size_t)pi * 3 + 0];
+                ny[a] = xyz[(size_t)pi * 3 + 1];
+                nz[a] = xyz[(size_t)pi * 3 + 2];
+            }
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                if (elig & (1u << i)) {
+                    float d2 = tmp[i];
+#pragma unroll
+                    for (int a = 0; a < FPS_K; a++) {
+                        if (a < cntk) {
+                            const float dx = px[i] - nx[a], dy = py[i] - ny[a], dz = pz[i] - nz[a];
+                            d2 = fminf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), d2);
+                        }
+                    }
+                    tmp[i] = d2;
+                }
+            }
+        }
+        // the last known pick is absorbed by the first round like a fresh one
+        const int pl = idxs[m0 - 1];
+        nx[0] = xyz[(size_t)pl * 3 + 0];
+        ny[0] = xyz[(size_t)pl * 3 + 1];
+        nz[0] = xyz[(size_t)pl * 3 + 2];
+        done = m0;
+    }
     for (int round = 1; done < m; round++) {
         const int par = round & 1;
         // 1) absorb the new picks, track this lane's best
@@ -406,8 +452,8 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             unsigned long long wgc[FPS_KPUB];
             bool stop = false;
             int cnt = 0;
-#pragma unroll
-            for (int t = 0; t < FPS_KPUB; t++) {
+            fps_static_for<0, FPS_KPUB>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
                 const unsigned long long best = stop ? 0ull : wave_max_u64(mine);
                 wgc[t] = best & ~1ull;
                 if (best != 0ull) {
@@ -417,7 +463,7 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                 } else {
                     stop = true;
                 }
-            }
+            });
 #pragma unroll
             for (int t = 0; t < FPS_KPUB; t++)
                 if (t == cnt - 1) wgc[t] |= 1ull;  // ... and the last one this workgroup forwards
@@ -473,8 +519,8 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             }
             unsigned long long gl[FPS_K];
             bool gstop = false;
-#pragma unroll
-            for (int t = 0; t < FPS_K; t++) {
+            fps_static_for<0, FPS_K>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
                 unsigned long long mx = v[0];
 #pragma unroll
                 for (int j = 1; j < FPS_NG; j++) mx = v[j] > mx ? v[j] : mx;
@@ -507,7 +553,7 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                         s_xyz[par][t * 3 + 2] = xyz[2];
                     }
                 }
-            }
+            });
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // 5) validate the chain c1, c2, ...: c_t is a pick iff no accepted c_a (a < t) lowers its distance;
@@ -523,19 +569,21 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             const bool viol = va < vt && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < ctv;
             const unsigned long long bad = __ballot(viol);
             int nacc = 1;  // c1 is always the next pick
-#pragma unroll
-            for (int t = 1; t < FPS_K; t++) {
+            fps_static_for<1, FPS_K>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
                 // the accepted picks drop to distance 0 themselves: a candidate at distance 0 can never
                 // overtake them (they precede it in key order), e.g. in the m > n padding regime
                 const bool ok = nacc == t && gl[t] != 0ull && done + t < m && (gl[t] >> 32) != 0ull &&
                                 ((bad >> (8 * t)) & ((1ull << t) - 1ull)) == 0ull;
                 if (ok) nacc = t + 1;
-            }
-            if (lane == 0) s_pick[par][0] = nacc;
-            if (lane < FPS_K) {
-                const int ci = fps_code_index(glt_lane_fix(gl, lane));
-                s_pick[par][1 + lane] = ci;
-                if (wg == 0 && lane < nacc) idxs[done + lane] = ci;
+            });
+            if (lane == 0) {
+                s_pick[par][0] = nacc;
+                // (static indices only: a lane-indexed read of gl[] would make the compiler spill the array to LDS)
+                fps_static_for<0, FPS_K>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if (wg == 0 && t < nacc) idxs[done + t] = fps_code_index(gl[t]);
+                });
             }
         }
         __syncthreads();
@@ -551,9 +599,9 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
 }
 
 template <int P>
-static void launch_fps(int G, int nb, hipStream_t st, const float* xyz, int n, int m, int bs_log2, int batch0,
+static void launch_fps(int G, int nb, hipStream_t st, const float* xyz, int n, int m, int m0, int bs_log2, int batch0,
                        unsigned long long* slots, int32_t* idxs, int* err) {
-    hipLaunchKernelGGL((k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), 0, st, xyz, n, m, G, bs_log2, batch0, slots,
+    hipLaunchKernelGGL((k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), 0, st, xyz, n, m, m0, G, bs_log2, batch0, slots,
                        idxs, err);
 }
 
@@ -561,9 +609,20 @@ extern "C" size_t gf_fps_scratch_bytes(int b) {
     return ((size_t)b * 2 * FPS_MAXG * FPS_KPUB + 8) * sizeof(unsigned long long);
 }
 
+extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs,
+                                                 void* scratch, void* stream);
+
 extern "C" int gf_furthest_point_sampling(const float* xyz, int b, int n, int m, int32_t* idxs, void* scratch,
                                           void* stream) {
+    return gf_furthest_point_sampling_resume(xyz, b, n, m, 0, idxs, scratch, stream);
+}
+
+extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs,
+                                                 void* scratch, void* stream) {
     GF_CHECK_ARG(b >= 0 && n >= 1 && m >= 0, "gf_furthest_point_sampling: bad sizes b=%d n=%d m=%d", b, n, m);
+    GF_CHECK_ARG(m_known >= 0 && m_known <= m, "gf_furthest_point_sampling_resume: m_known=%d not in [0, m=%d]", m_known,
+                 m);
+    if (m_known == m && m > 0) return GF_OK;
     GF_CHECK_ARG(n < (1 << 22), "gf_furthest_point_sampling: n=%d exceeds the 22-bit index of the tie-break key", n);
     if (b == 0 || m == 0) return GF_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -583,13 +642,13 @@ extern "C" int gf_furthest_point_sampling(const float* xyz, int b, int n, int m,
     const int per_launch = 1024 / (G * FPS_WAVES) > 0 ? 1024 / (G * FPS_WAVES) : 1;  // all cooperating waves resident
     for (int b0 = 0; b0 < b; b0 += per_launch) {
         const int nb = (b - b0) < per_launch ? (b - b0) : per_launch;
-        if (P <= 1) launch_fps<1>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
-        else if (P <= 2) launch_fps<2>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
-        else if (P <= 4) launch_fps<4>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
-        else if (P <= 6) launch_fps<6>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
-        else if (P <= 8) launch_fps<8>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
-        else if (P <= 12) launch_fps<12>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
-        else launch_fps<16>(G, nb, st, xyz, n, m, bs_log2, b0, slots, idxs, err);
+        if (P <= 1) launch_fps<1>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 2) launch_fps<2>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 4) launch_fps<4>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 6) launch_fps<6>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 8) launch_fps<8>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 12) launch_fps<12>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else launch_fps<16>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
     }
     GF_CHECK_LAUNCH("gf_furthest_point_sampling");
     return GF_OK;

@@ -92,13 +92,20 @@ def ball_query(new_xyz, xyz, radius, nsample):
     return idx
 
 
-def furthest_point_sampling(xyz, m):
+def furthest_point_sampling(xyz, m, known=None):
+    """FPS indices [b,m] (int32).  known: the first picks [b,m0] of the same sequence from an earlier call with a
+    smaller m -- the draw continues from there (same result as one call with m)."""
     _f32c(xyz, "xyz")
     b, n, _ = xyz.shape
     lib = _lib.load()
     idx = torch.empty((b, m), dtype=torch.int32, device=xyz.device)
     scratch = torch.empty(lib.gf_fps_scratch_bytes(b) // 8 + 1, dtype=torch.int64, device=xyz.device)
-    check(lib.gf_furthest_point_sampling(ptr(xyz), b, n, m, ptr(idx), ptr(scratch), stream_ptr()),
+    m0 = 0
+    if known is not None:
+        _i32c(known, "known")
+        m0 = min(int(known.shape[1]), m)
+        idx[:, :m0] = known[:, :m0]
+    check(lib.gf_furthest_point_sampling_resume(ptr(xyz), b, n, m, m0, ptr(idx), ptr(scratch), stream_ptr()),
           "gf_furthest_point_sampling")
     return idx
 

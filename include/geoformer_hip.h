@@ -159,6 +159,11 @@ int gf_ball_query(const float* new_xyz, const float* xyz, int b, int n, int m, f
  * scratch: gf_fps_scratch_bytes(b) bytes (zeroed by the call). */
 size_t gf_fps_scratch_bytes(int b);
 int gf_furthest_point_sampling(const float* xyz, int b, int n, int m, int32_t* idxs, void* scratch, void* stream);
+/* Same sequence, continued: idxs[b, 0..m_known) already hold its first m_known picks (an earlier call with a
+ * smaller m on the same points); fills idxs[b, m_known..m).  Lets a consumer of the first picks (the geodesic BFS
+ * needs 256 of 2048) start while the rest is still being drawn. */
+int gf_furthest_point_sampling_resume(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs,
+                                      void* scratch, void* stream);
 
 /* ===================================================================================
  * Geodesic stage (model/geoformer/geodesic_utils.py)

@@ -92,3 +92,19 @@ def test_gather_group_and_grads(hip, oracle):
     r2 = oracle.group_points_grad(ggo, gidx, n)
     assert np.abs(pointops.gather_points_grad(_dev(go), _dev(idx), n).cpu().numpy() - r1).max() < 1e-5
     assert np.abs(pointops.group_points_grad(_dev(ggo), _dev(gidx), n).cpu().numpy() - r2).max() < 1e-4
+
+
+@pytest.mark.parametrize("n,m0,m", [(5000, 256, 2048), (700, 1, 64), (300, 100, 512), (4096, 33, 34)])
+def test_fps_resume_equals_single_call(hip, n, m0, m):
+    """gf_furthest_point_sampling_resume: continuing from the first m0 picks gives the sequence of one call."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(n + m0)
+    xyz = rng.uniform(-2, 2, (2, n, 3)).astype(np.float32)
+    xyz[0, 10:20] = xyz[0, 5]  # duplicates -> exact ties
+    x = torch.from_numpy(xyz).cuda()
+    full = pointops.furthest_point_sampling(x, m)
+    first = pointops.furthest_point_sampling(x, m0)
+    assert (first == full[:, :m0]).all()
+    cont = pointops.furthest_point_sampling(x, m, known=first)
+    assert (cont == full).all()
