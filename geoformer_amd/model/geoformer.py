@@ -11,6 +11,7 @@ and its host-RNG draws are reproduced deliberately.
 from __future__ import annotations
 
 import functools
+import os
 
 import numpy as np
 import torch
@@ -259,11 +260,60 @@ class GeoFormer(nn.Module):
             context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
             return context_locs, context_feats, pre_enc_inds
 
+    def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step):
+        """Inference on the GPU: once the furthest-point sequence is drawn, the geodesic BFS (a latency-bound launch
+        that leaves most of the chip idle) goes to a second HIP stream and runs beside ball query, grouping, the
+        shared MLP and the decoder's input projections; the main stream joins it where the decoder first needs
+        the distances (relative_position_embedding).  Same values as forward_aggregator + cal_geodesic, same
+        consumption of the host RNG.  (Starting the BFS after the first n_query_points picks, beside the rest of
+        FPS, was measured too: the cross-CU exchange of FPS slows down by more than the BFS saves.)"""
+        offs = _offsets_list(batch_offsets_)
+        nq = self.cfg.n_query_points
+        main = torch.cuda.current_stream()
+        side = self.__dict__.get("_gf_side_stream")
+        if side is None or side.device != locs_float_.device:
+            side = torch.cuda.Stream(device=locs_float_.device)
+            self.__dict__["_gf_side_stream"] = side
+        staged = []
+        for b in range(batch_size):
+            n_b = offs[b + 1] - offs[b]
+            if n_b == 0:
+                return None, None
+            npoint = min(n_b, self.cfg.n_downsampling)
+            sampling_indices = torch.tensor(np.random.choice(n_b, npoint, replace=False), dtype=torch.long,
+                                            device=locs_float_.device)
+            self.last_sampling_indices = sampling_indices
+            xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
+            feat_b = output_feats_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).transpose(1, 2).contiguous()
+            staged.append((xyz_b, feat_b, pointops.furthest_point_sampling(xyz_b, self.set_aggregator.npoint)))
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            geo = []
+            for b in range(batch_size):
+                D, I, deg = graphs[b]
+                g = pointops.geodesic_bfs(D, I, deg, staged[b][2][0, :nq].contiguous(), 0.05, max_step)
+                g.record_stream(main)
+                geo.append(g)
+        self.__dict__["_gf_pending_side"] = side
+        locs, gfeat, gxyz, inds = [], [], [], []
+        for xyz_b, feat_b, idx in staged:
+            l, gf, gx, idx = self.set_aggregator.group_points(xyz_b, feat_b, inds=idx)
+            locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
+        context_locs, pre_enc_inds = torch.cat(locs), torch.cat(inds)
+        context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
+        return (context_locs, context_feats, pre_enc_inds), geo
+
+    def _join_side_stream(self):
+        side = self.__dict__.pop("_gf_pending_side", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+
     # -- decoder ------------------------------------------------------------------------------
     def relative_position_embedding(self, context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds):
         """[nq, nc, B, d] Fourier embedding of the query->context geodesic distances; unreachable
         pairs get max_geo(query) + |dxyz| per axis (geoformer.py:619-651)."""
         B = context_locs.shape[0]
+        self._join_side_stream()  # the geodesic distances may still be in flight on the second stream
         if context_locs.is_cuda and self.cfg.dec_dim == 64 and not torch.is_grad_enabled():
             # inference: hand the fused cross-attention kernel the ingredients instead of the 134 MB tensor
             geo = torch.stack([geo_dists[b][:, pre_enc_inds[b].long()] for b in range(B)], dim=0).contiguous()
@@ -433,16 +483,24 @@ class GeoFormer(nn.Module):
         if locs_float_.is_cuda and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0:
             graphs = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
 
-        contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
+        max_step = 128 if self.training else 256
+        geo_dists = None
+        if graphs is not None and not torch.is_grad_enabled() and os.environ.get("GF_OVERLAP", "1") != "0":
+            contexts, geo_dists = self._aggregate_geodesic_overlapped(locs_float_, output_feats_, batch_offsets_,
+                                                                      batch_size, graphs, max_step)
+        else:
+            contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
         if contexts is None:
             outputs["mask_predictions"] = None
             return outputs
         context_locs, context_feats, pre_enc_inds = contexts
         query_locs = context_locs[:, :cfg.n_query_points, :]
 
-        geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128 if self.training else 256,
-                                 neighbor=64, radius=0.05, n_queries=cfg.n_query_points, graphs=graphs)
+        if geo_dists is None:
+            geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=max_step, neighbor=64,
+                                     radius=0.05, n_queries=cfg.n_query_points, graphs=graphs)
         dec_outputs = self.forward_decoder(context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds)
+        self._join_side_stream()  # no-op unless a subclass' decoder skipped relative_position_embedding
 
         if training:
             idxs_sub, idxs_sub_raw = random_downsample(batch_offsets_, batch_size, n_subsample=30000)

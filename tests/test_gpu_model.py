@@ -18,8 +18,9 @@ def _to_dev(batch):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
-@pytest.fixture(scope="module")
-def run(hip):
+@pytest.fixture(scope="module", params=["1", "0"], ids=["two-stream", "sequential"])
+def run(hip, request):
+    os.environ["GF_OVERLAP"] = request.param  # set aggregation || geodesic BFS on two streams, or one after the other
     from geoformer_amd import scene
     from geoformer_amd.model import GeoFormer, load_config
     from tests.util import synthetic_state_dict
@@ -33,24 +34,21 @@ def run(hip):
     m.eval()
     batch = _to_dev(scene.make_batch([scene.make_small_scene(int(z["scene_points"]), int(z["scene_seed"]))]))
     cap = {}
-    agg, dec = m.forward_aggregator, m.forward_decoder
-
-    def agg_w(*a, **k):
-        r = agg(*a, **k)
-        cap["context_locs"], cap["context_feats"], cap["pre_enc_inds"] = [t.detach() for t in r]
-        return r
+    dec = m.forward_decoder
 
     def dec_w(cl, cf, ql, pc, geo, pei):
+        cap["context_locs"], cap["context_feats"], cap["pre_enc_inds"] = cl.detach(), cf.detach(), pei.detach()
         cap["geo"] = geo[0]
         r = dec(cl, cf, ql, pc, geo, pei)
         cap["dec_outputs"] = r.detach()
         return r
 
-    m.forward_aggregator, m.forward_decoder = agg_w, dec_w
+    m.forward_decoder = dec_w
     np.random.seed(int(z["numpy_seed"]))
     with torch.no_grad():
         out = m(batch, 300, training=False)
     torch.cuda.synchronize()
+    os.environ.pop("GF_OVERLAP", None)
     return z, out, cap, m
 
 
