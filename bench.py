@@ -54,7 +54,9 @@ def build_model(device, nfg_frac=0.4, probe_batch=None):
         with torch.no_grad():
             s = m(probe_batch, 0, training=False)["semantic_scores"]
             margin = s[:, 4:].max(1)[0] - s[:, :4].max(1)[0]
-            m.semantic_linear.bias.data[:4] += torch.quantile(margin.float().cpu(), 1.0 - nfg_frac).to(device)
+            # in place on the parameter itself (bumps its version counter: the fused inference paths cache folded
+            # copies of the parameters and re-derive them when a version changes; writes through `.data` are invisible)
+            m.semantic_linear.bias[:4] += torch.quantile(margin.float().cpu(), 1.0 - nfg_frac).to(device)
     return m
 
 

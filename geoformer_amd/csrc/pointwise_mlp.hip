@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__
 #pragma unroll
             for (int ct = 0; ct < PM_MAXC / 16; ct++) {
                 const int ch = ct * 16 + 4 * g;
-                if (ch + 3 < cl) {
+                if (ch + 3 < cl && (cl & 3) == 0) {
                     *reinterpret_cast<float4*>(out + (size_t)p * cl + ch) = h[ct];
                 } else {
                     const float v[4] = {h[ct].x, h[ct].y, h[ct].z, h[ct].w};
@@ -105,8 +105,8 @@ extern "C" int gf_pointwise_mlp(const float* x, int N, int n_layers, const float
         const int cin = channels[l], cout = channels[l + 1];
         GF_CHECK_ARG(cin >= 16 && cin <= PM_MAXC && cin % 16 == 0,
                      "gf_pointwise_mlp: input width %d of layer %d must be a multiple of 16 in 16..%d", cin, l, PM_MAXC);
-        GF_CHECK_ARG(cout >= 1 && cout <= PM_MAXC && (l == n_layers - 1 ? cout % 4 == 0 : cout % 16 == 0),
-                     "gf_pointwise_mlp: output width %d of layer %d (hidden: multiple of 16, last: multiple of 4, <= %d)",
+        GF_CHECK_ARG(cout >= 1 && cout <= PM_MAXC && (l == n_layers - 1 || cout % 16 == 0),
+                     "gf_pointwise_mlp: output width %d of layer %d (hidden widths: multiples of 16, all <= %d)",
                      cout, l, PM_MAXC);
         GF_CHECK_ARG(W[l] && scale[l] && shift[l], "gf_pointwise_mlp: null parameter of layer %d", l);
         A.L[l] = {W[l], scale[l], shift[l], cin, cout, relu[l]};

@@ -171,6 +171,19 @@ class GeoFormer(nn.Module):
             mod.weight.data.fill_(1.0)
             mod.bias.data.fill_(0.0)
 
+    def invalidate_fused_caches(self):
+        """Drop every derived copy the fused inference paths keep (packed conv weights, folded BatchNorm, MLP chains,
+        pointer tables).  They are re-derived automatically when a parameter's version counter changes
+        (optimizer steps, load_state_dict, in-place ops); call this after editing parameters through ``.data``,
+        which leaves the counter untouched."""
+        from .. import sparse
+
+        sparse._PACK_CACHE.clear()
+        for mod in self.modules():
+            for key in ("_gf_chains", "_gf_block", "_gf_affine", "_gf_chain", "_gf_tr_params", "_gf_fused",
+                        "_wpack_key", "_wpack"):
+                mod.__dict__.pop(key, None)
+
     def _grad_ctx(self, name):
         """no_grad for frozen sub-modules (geoformer.py:497,566).  The reference re-enables autograd for the others
         even when the caller runs under torch.no_grad() (eval); that only builds a graph nobody uses, so the
@@ -335,6 +348,19 @@ class GeoFormer(nn.Module):
 
     def forward_decoder(self, context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds):
         nq = self.cfg.n_query_points
+        if context_locs.shape[0] == 1 and context_locs.is_cuda and not torch.is_grad_enabled():
+            # inference, one scene: the two projection stacks as fused launches over token rows; the context's
+            # positional embedding is skipped (the pre-norm relative layer never reads `pos`, transformer_detr.py:425-463)
+            e2d = self._pointwise_chain("e2d", [self.encoder_to_decoder_projection], context_feats)
+            qpr = self._pointwise_chain("qproj", [self.query_projection], context_feats)
+            if e2d is not None and qpr is not None:
+                ctx = pointops.pointwise_mlp(context_feats[0].contiguous(), e2d)  # [nc, dec_dim]
+                qpe = self.pos_embedding(query_locs, input_range=pc_dims).float()  # [1, dec_dim, nq]
+                qpos = pointops.pointwise_mlp(qpe[0].t().contiguous(), qpr)  # [nq, dec_dim]
+                rel = self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds)
+                memory = ctx.unsqueeze(1)  # [nc, 1, dec_dim]
+                return self.decoder(tgt=memory[:nq], memory=memory, pos=None, query_pos=qpos.unsqueeze(1),
+                                    relative_pos=rel)
         context_embedding_pos = self.pos_embedding(context_locs, input_range=pc_dims)
         context_feats = self.encoder_to_decoder_projection(context_feats.permute(0, 2, 1))  # B x C x nc
         query_embedding_pos = self.query_projection(self.pos_embedding(query_locs, input_range=pc_dims).float())
@@ -390,9 +416,18 @@ class GeoFormer(nn.Module):
         outputs = []
         for l in range(num_layers):
             pk = param_kernels[l]  # nq x B x C
-            cls_logits = self.detr_sem_head(pk.permute(1, 2, 0)).transpose(1, 2)  # B x nq x classes
-            pk2 = pk.transpose(0, 1).flatten(0, 1)
-            controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
+            pk2 = pk.transpose(0, 1).flatten(0, 1)  # [B*nq, C] token rows
+            sem_chain = self._pointwise_chain("detr_sem_head", [self.detr_sem_head], pk2)
+            tow_chain = self._pointwise_chain("before_embedding_tower", [self.before_embedding_tower], pk2)
+            if sem_chain is not None and tow_chain is not None:
+                # inference on the GPU: the two token MLPs as fused launches, the controller as one GEMM
+                rows = pk2.contiguous()
+                cls_logits = pointops.pointwise_mlp(rows, sem_chain).reshape(batch, n_queries, -1)
+                emb = pointops.pointwise_mlp(rows, tow_chain)
+                controllers = F.linear(emb, self.controller.weight[:, :, 0], self.controller.bias)
+            else:
+                cls_logits = self.detr_sem_head(pk.permute(1, 2, 0)).transpose(1, 2)  # B x nq x classes
+                controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
             controllers = controllers.reshape(batch, n_queries, -1)
             mask_logits_list = []
             for b in range(batch):

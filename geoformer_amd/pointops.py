@@ -205,7 +205,7 @@ class PointwiseChain:
         if not 1 <= len(ch) <= 4:
             return False
         ok = all(ci % 16 == 0 and 16 <= ci <= 64 for ci, _ in ch) and all(co % 16 == 0 and co <= 64 for _, co in ch[:-1])
-        return ok and ch[-1][1] % 4 == 0 and ch[-1][1] <= 64
+        return ok and 1 <= ch[-1][1] <= 64
 
 
 def pointwise_mlp(x, chain):

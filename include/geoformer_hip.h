@@ -213,7 +213,7 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
  * The caller folds bias and eval-mode BatchNorm into (scale, shift).
  *   x fp32 [N, channels[0]], out fp32 [N, channels[n_layers]], n_layers <= 4,
  *   W / scale / shift: HOST arrays of n_layers DEVICE pointers (W_l row-major [channels[l+1], channels[l]]),
- *   channels: HOST int[n_layers+1] (inputs multiples of 16, <= 64; last output a multiple of 4), relu: HOST int[n_layers]. */
+ *   channels: HOST int[n_layers+1] (inputs multiples of 16, all widths <= 64; the last output width is free), relu: HOST int[n_layers]. */
 int gf_pointwise_mlp(const float* x, int N, int n_layers, const float* const* W, const float* const* scale,
                      const float* const* shift, const int* channels, const int* relu, float* out, void* stream);
 

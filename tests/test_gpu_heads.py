@@ -181,6 +181,7 @@ def test_decoder_token_stages_fused(hip, nq, nc, B, ff):
 
 
 @pytest.mark.parametrize("N,chs,last_plain", [(5000, [16, 16, 16, 16, 16], True), (77, [16, 16, 16, 20], True),
+                                              (256, [64, 64, 64, 13], True),
                                               (1234, [32, 64, 16], False), (1, [16, 16], True)])
 def test_pointwise_mlp_chain(hip, N, chs, last_plain):
     """Fused Conv1d(k=1)/Linear + eval BatchNorm1d + ReLU stack (mask_tower geoformer.py:64-71, semantic head

@@ -108,3 +108,30 @@ def test_geoformer_fs_episode_gpu(hip):
     from tests.util import check_fs_episode, run_fs_episode
 
     check_fs_episode(*run_fs_episode("cuda"))
+
+
+def test_fused_caches_follow_parameter_updates(hip):
+    """The fused inference paths keep derived copies of parameters (folded BatchNorm, packed weights, MLP chains):
+    an in-place update (version bump) must be picked up by the next forward, a `.data` edit after
+    invalidate_fused_caches()."""
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    m = GeoFormer(load_config("test_geoformer_scannet.yaml"))
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 0))
+    m.cuda().eval()
+    batch = _to_dev(scene.make_batch([scene.make_small_scene(3000, 5)]))
+    with torch.no_grad():
+        s0 = m(batch, 0, training=False)["semantic_scores"].clone()
+        m.semantic_linear.bias[2] += 3.0
+        s1 = m(batch, 0, training=False)["semantic_scores"].clone()
+        assert torch.allclose(s1[:, 2] - s0[:, 2], torch.full_like(s0[:, 2], 3.0), atol=1e-4)
+        conv = m.unet.blocks.block0.conv_branch[2]
+        conv.weight.mul_(0.5)
+        s2 = m(batch, 0, training=False)["semantic_scores"].clone()
+        assert (s2 - s1).abs().max() > 1e-3
+        m.semantic_linear.bias.data[2] -= 3.0
+        m.invalidate_fused_caches()
+        s3 = m(batch, 0, training=False)["semantic_scores"]
+        assert torch.allclose(s3[:, 2] - s2[:, 2], torch.full_like(s0[:, 2], -3.0), atol=1e-4)
