@@ -221,7 +221,10 @@ class GeoFormer(nn.Module):
         ctx = self._grad_ctx("unet")
         with ctx():
             x = self.preprocess_input(batch_input, batch_size)
-            self.prebuild_rulebooks(x)
+            # built lazily by the first strided convolution (spconv.SparseConv3d.get_rules): the host then issues
+            # the chain's ~50 small launches while the GPU is busy with the level-1 blocks, and the one read-back
+            # of the voxel counts waits behind real work instead of an empty queue
+            x.indice_dict["_prebuild"] = self.prebuild_rulebooks
             x = self.output_layer(self.unet(self.input_conv(x)))
             output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
             chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)

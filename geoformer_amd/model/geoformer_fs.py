@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from . import config as _config
 from .backbone import random_downsample
+from .. import pointops
 from .geoformer import GeoFormer, _offsets_list, cal_geodesic, get_batch_offsets
 from .layers import BatchNorm1d, GenericMLP
 
@@ -71,9 +72,14 @@ class GeoFormerFS(GeoFormer):
         ctx = torch.enable_grad if self.training and "unet" not in self.fix_module else torch.no_grad
         with ctx():
             x = self.preprocess_input(batch_input, batch_size)
+            x.indice_dict["_prebuild"] = self.prebuild_rulebooks  # whole down-sampling chain, one host sync
             x = self.output_layer(self.unet(self.input_conv(x)))
             output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
-            semantic_scores = self.semantic_linear(self.semantic(output_feats))
+            chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)
+            if chain is not None:
+                semantic_scores = pointops.pointwise_mlp(output_feats, chain)
+            else:
+                semantic_scores = self.semantic_linear(self.semantic(output_feats))
             return output_feats, semantic_scores, semantic_scores.max(1)[1]
 
     def forward_aggregator(self, locs_float_, output_feats_, batch_offsets_, batch_size):

@@ -220,6 +220,9 @@ class SparseConv3d(_SparseConvBase):
             raise NotImplementedError("SparseConv3d: implemented for kernel_size=2, stride=2, padding=0")
 
     def get_rules(self, input):
+        hook = input.indice_dict.pop("_prebuild", None)
+        if hook is not None:
+            hook(input)  # a caller that knows the whole down-sampling chain builds it in one go (one host sync)
         pre = input.find_indice_pair(self.indice_key)
         if isinstance(pre, sparse.DownRules) and getattr(pre, "prebuilt_for", None) == input.indices.data_ptr() \
                 and pre.M_in == input.indices.shape[0]:
