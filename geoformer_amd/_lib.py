@@ -52,6 +52,8 @@ def _declare(lib):
         "gf_knn_error_flag": (P, [P, I]),
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
         "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+        "gf_softmax_dim1_fwd": (I, [P, I, I, I, F, P, P]),
+        "gf_softmax_dim1_bwd": (I, [P, P, I, I, I, F, P, P]),
         "gf_pointwise_mlp": (I, [P, I, I, P, P, P, P, P, P, P]),
         "gf_group_mlp_max": (I, [P, I, I, I, I, P, P, P, P, P, P, P]),
         "gf_decoder_token_state_bytes": (c_size_t, [I, I]),

@@ -298,7 +298,12 @@ class TransformerDecoderLayer(nn.Module):
         if isinstance(relative_pos, RelPosSpec):
             return self._cross_attention_fused(tgt2, memory, relative_pos)
         sim = self.attn_mlp(tgt2[:, None] - memory[None] + relative_pos)
-        attn = F.softmax(sim / np.sqrt(sim.shape[-1]), dim=1)
+        if sim.is_cuda and sim.dtype == torch.float32:
+            from .. import pointops
+
+            attn = pointops.softmax_dim1(sim, 1.0 / float(np.sqrt(sim.shape[-1])))  # streaming kernel, fwd + bwd
+        else:
+            attn = F.softmax(sim / np.sqrt(sim.shape[-1]), dim=1)
         v2 = self.v_mlp(memory[None] + relative_pos)
         return (attn * v2).sum(dim=1)
 

@@ -351,3 +351,34 @@ def decoder_cross_attn(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
                                             ptr(gaussB), ptr(Q1), ptr(K1), ptr(Kv), ptr(wpack), ptr(b2), B, nq, nc, d,
                                             ptr(out), stream_ptr()), "gf_decoder_cross_attn")
     return out
+
+
+class _SoftmaxDim1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        n0, n1 = x.shape[0], x.shape[1]
+        inner = x.numel() // max(n0 * n1, 1)
+        y = torch.empty_like(x)
+        check(_lib.load().gf_softmax_dim1_fwd(ptr(x), n0, n1, inner, float(scale), ptr(y), stream_ptr()),
+              "gf_softmax_dim1_fwd")
+        ctx.save_for_backward(y)
+        ctx.scale = float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        n0, n1 = y.shape[0], y.shape[1]
+        inner = y.numel() // max(n0 * n1, 1)
+        gx = torch.empty_like(y)
+        check(_lib.load().gf_softmax_dim1_bwd(ptr(y), ptr(gy), n0, n1, inner, ctx.scale, ptr(gx), stream_ptr()),
+              "gf_softmax_dim1_bwd")
+        return gx, None
+
+
+def softmax_dim1(x, scale=1.0):
+    """softmax(scale * x, dim=1) for a float32 GPU tensor with >= 2 dims, differentiable (streaming HIP kernels)."""
+    _f32c(x.detach() if x.is_contiguous() else x.detach().contiguous(), "x")
+    return _SoftmaxDim1.apply(x, scale)

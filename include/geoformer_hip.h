@@ -226,6 +226,13 @@ int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsample, int n
                      const float* const* scale, const float* const* shift, const int* channels, const int* relu,
                      float* out, void* stream);
 
+/* Soft-max over the middle dimension of x[n0,n1,inner] (training path of the decoder's vector cross-attention,
+ * model/transformer_detr.py:449: F.softmax(sim / sqrt(d), dim=1) on [nq,nc,B,d]):
+ *   y = softmax_{n1}(scale * x);   gx = scale * y * (gy - sum_{n1} gy * y). */
+int gf_softmax_dim1_fwd(const float* x, int n0, int n1, int inner, float scale, float* y, void* stream);
+int gf_softmax_dim1_bwd(const float* y, const float* gy, int n0, int n1, int inner, float scale, float* gx,
+                        void* stream);
+
 /* ===================================================================================
  * Token-side stages of the decoder between two cross-attentions, fused (inference)
  * (TransformerDecoderLayer.forward_pre_rel, model/transformer_detr.py:425-463; TransformerDecoder.forward,

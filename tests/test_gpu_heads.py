@@ -256,3 +256,22 @@ def test_matrix_nms_gpu(hip, oracle):
     big = (rng.uniform(size=(70, 10007)) < 0.05).astype(np.int32)  # N not a multiple of 64, empty-ish rows
     big[5] = 0
     assert (pointops.mask_intersections(torch.from_numpy(big).cuda()).cpu().numpy() == oracle.mask_intersections(big)).all()
+
+
+@pytest.mark.parametrize("shape", [(7, 300, 2, 64), (3, 17, 70), (128, 64, 1, 64), (2, 1, 5)])
+def test_softmax_dim1_forward_backward(hip, shape):
+    """Streaming soft-max over dim 1 (decoder cross-attention, transformer_detr.py:449) vs torch, values and grads."""
+    from geoformer_amd import pointops
+
+    torch.manual_seed(sum(shape))
+    x = (torch.randn(*shape) * 4).cuda().requires_grad_()
+    g = torch.randn(*shape).cuda()
+    scale = 0.125
+    y = pointops.softmax_dim1(x, scale)
+    y.backward(g)
+    gx = x.grad.clone()
+    x.grad = None
+    ref = torch.softmax(x.double() * scale, dim=1)
+    ref.backward(g.double())
+    assert (y.double() - ref).abs().max().item() < 1e-6
+    assert (gx.double() - x.grad.double()).abs().max().item() < 1e-5
