@@ -679,17 +679,25 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ in
     const int ci = cib * 16 + r, co = cob * 16 + r;
     const int row0 = sl * WG_ROWS, row1 = min(M_out, row0 + WG_ROWS);
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int base = row0; base < row1; base += 4) {
-        const int row = base + q;
-        float a = 0.f, b = 0.f;
-        if (row < row1) {
-            const int idx = nbr ? nbr[(size_t)k * ld + row] : row;
-            if (idx >= 0) {
-                if (ci < Cin) a = in[(size_t)idx * Cin + ci];
-                if (co < Cout) b = dout[(size_t)row * Cout + co];
-            }
+    // 8 MFMAs (32 rows) per trip: the neighbour rows, then both operand streams, go out back to back -- one
+    // dependent round trip per 32 rows instead of per 4 (the loop is pure memory latency otherwise)
+    constexpr int U = 8;
+    for (int base = row0; base < row1; base += 4 * U) {
+        int idx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int row = base + 4 * u + q;
+            idx[u] = row < row1 ? (nbr ? nbr[(size_t)k * ld + row] : row) : -1;
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int row = base + 4 * u + q;
+            a[u] = (idx[u] >= 0 && ci < Cin) ? in[(size_t)idx[u] * Cin + ci] : 0.f;
+            b[u] = (idx[u] >= 0 && co < Cout) ? dout[(size_t)row * Cout + co] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
     }
     // D layout: col (output channel) = lane&15, row (input channel) = 4*(lane>>4) + j
 #pragma unroll
