@@ -91,6 +91,37 @@ class BigLinear(nn.Linear):
         return super().forward(x)
 
 
+class _PointwiseSplitKFn(torch.autograd.Function):
+    """y[b] = W x[b] for x [B,Cin,L] with L ~ 10^5: the weight gradient sum_b gy[b] x[b]^T reduces over L into a
+    Cout x Cin tile, which the library runs on a single workgroup (0.6 ms at 16x16x240k); chunked into a batched
+    product it is bandwidth-bound."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.matmul(w, x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(w.t(), gy)
+        if ctx.needs_input_grad[1]:
+            B, Co, L = gy.shape
+            S = 128
+            Lc = L // S
+            main = S * Lc
+            gw = torch.zeros_like(w)
+            if Lc > 0:
+                a = gy[:, :, :main].reshape(B, Co, S, Lc).permute(0, 2, 1, 3).reshape(B * S, Co, Lc)
+                b = x[:, :, :main].reshape(B, x.shape[1], S, Lc).permute(0, 2, 3, 1).reshape(B * S, Lc, x.shape[1])
+                gw = torch.bmm(a, b).sum(0)
+            if main < L:
+                gw = gw + torch.einsum("bol,bil->oi", gy[:, :, main:], x[:, :, main:])
+        return gx, gw
+
+
 class PointwiseConv1d(nn.Conv1d):
     """nn.Conv1d(kernel_size=1) evaluated as a GEMM.  Same parameters / state-dict entries; MIOpen has no
     tuned kernels for these shapes on gfx950 and falls back to naive convolutions (38 ms per weight gradient
@@ -99,7 +130,10 @@ class PointwiseConv1d(nn.Conv1d):
     def forward(self, x):
         if self.kernel_size != (1,) or self.stride != (1,) or self.padding != (0,) or self.groups != 1:
             return super().forward(x)
-        y = torch.matmul(self.weight[:, :, 0], x)
+        if x.is_cuda and torch.is_grad_enabled() and x.dim() == 3 and x.shape[-1] >= (1 << 15):
+            y = _PointwiseSplitKFn.apply(x, self.weight[:, :, 0])
+        else:
+            y = torch.matmul(self.weight[:, :, 0], x)
         return y if self.bias is None else y + self.bias[:, None]
 
 
