@@ -60,6 +60,9 @@ def _declare(lib):
         "gf_decoder_token_stage": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
         "gf_mask_intersections_scratch_bytes": (c_size_t, [I, I]),
         "gf_mask_intersections": (I, [P, I, I, P, P, P]),
+        "gf_voxelize_idx_scratch_bytes": (c_size_t, [I]),
+        "gf_voxelize_idx_count": (I, [P, I, I, I, P, P, P, P]),
+        "gf_voxelize_idx_fill": (I, [P, I, I, I, P, P, I, I, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),

@@ -36,10 +36,16 @@ def _dormant(name, where):
 # PG_OP
 # ------------------------------------------------------------------------------------------
 def voxelize_idx(coords, output_coords, input_map, output_map, batch_size, mode):
-    """CPU, fork-safe (runs inside DataLoader workers, datasets/scannetv2_inst.py:369): no HIP context.
+    """CPU tensors: fork-safe host path (runs inside DataLoader workers, datasets/scannetv2_inst.py:369), no HIP
+    context.  CUDA tensors: the GPU kernels (csrc/voxelize_idx.hip).
     Resizes ``output_coords`` / ``output_map`` like voxelize.cpp:22-26."""
     if coords.is_cuda:
-        raise RuntimeError("voxelize_idx expects CPU tensors (it runs in the DataLoader workers)")
+        # device-resident pipeline (SURVEY row f2): same outputs from the GPU kernels, on the input's device
+        oc, p2v, v2p = pointops.voxelize_idx(coords.contiguous(), mode)
+        output_coords.resize_(oc.shape).copy_(oc)
+        input_map.copy_(p2v)
+        output_map.resize_(v2p.shape).copy_(v2p)
+        return
     oc, p2v, v2p = scene.voxelize_host(coords.numpy(), mode)
     output_coords.resize_(oc.shape).copy_(torch.from_numpy(np.ascontiguousarray(oc)))
     input_map.copy_(torch.from_numpy(p2v))

@@ -45,6 +45,31 @@ def voxelize_bp(d_out, rules, mode, d_feats):
 
 
 # ---- pointnet2._ext --------------------------------------------------------------------
+def voxelize_idx(coords, mode=4):
+    """GPU voxelisation with the semantics of PG_OP.voxelize_idx: coords int64 [N,3|4] on the device ->
+    (output_coords int64 [M,ncol], input_map int32 [N], output_map int32 [M,1+maxActive]).  One host read-back
+    (M, maxActive)."""
+    if not (coords.is_cuda and coords.dtype == torch.int64 and coords.is_contiguous() and coords.dim() == 2):
+        raise RuntimeError("coords: expected a contiguous int64 [N,3|4] tensor on the GPU")
+    lib = _lib.load()
+    N, ncol = coords.shape
+    dev = coords.device
+    scratch = torch.empty(lib.gf_voxelize_idx_scratch_bytes(N) // 8 + 1, dtype=torch.int64, device=dev)
+    input_map = torch.empty(N, dtype=torch.int32, device=dev)
+    head = torch.empty(3, dtype=torch.int32, device=dev)
+    check(lib.gf_voxelize_idx_count(ptr(coords), N, ncol, int(mode), ptr(scratch), ptr(input_map), ptr(head),
+                                    stream_ptr()), "gf_voxelize_idx_count")
+    M, max_active, err = head.tolist()
+    if err:
+        raise _lib.GeoFormerHipError("gf_voxelize_idx: a coordinate lies outside [0, 65535] (packed 16-bit key fields)")
+    max_active = max(max_active, 1)
+    out_coords = torch.empty((M, ncol), dtype=torch.int64, device=dev)
+    out_map = torch.empty((M, max_active + 1), dtype=torch.int32, device=dev)
+    check(lib.gf_voxelize_idx_fill(ptr(coords), N, ncol, int(mode), ptr(scratch), ptr(input_map), M, max_active,
+                                   ptr(out_coords), ptr(out_map), stream_ptr()), "gf_voxelize_idx_fill")
+    return out_coords, input_map, out_map
+
+
 def gather_points(points, idx):
     _f32c(points, "points"); _i32c(idx, "idx")
     b, c, n = points.shape

@@ -126,6 +126,19 @@ int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K,
  * PG_OP (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-23)
  * =================================================================================== */
 
+/* voxelize_idx on the GPU (reference: PG_OP.voxelize_idx, lib/pointgroup_ops/src/voxelize/voxelize.cpp:10-152, CPU):
+ * voxel ids in order of first occurrence, input_map[N] point -> voxel, rule rows [count, point ids ascending, 0 pad]
+ * (modes 3/4) or [1, front()/back()] (modes 0,1 / 2), output coords = coords of rule[1].
+ *   coords int64 [N,ncol] on the device (ncol 4 = (b,x,y,z) or 3), every field in [0, 65535];
+ *   _count: fills input_map int32 [N] and d_M_maxActive int32[3] = {M, maxActive, error flag} (device);
+ *   _fill (after the caller read M and maxActive): output_coords int64 [M,ncol], output_map int32 [M,1+maxActive];
+ *   the same scratch (gf_voxelize_idx_scratch_bytes(N)) must be handed to both calls. */
+size_t gf_voxelize_idx_scratch_bytes(int N);
+int gf_voxelize_idx_count(const long long* coords, int N, int ncol, int mode, void* scratch, int32_t* input_map,
+                          int32_t* d_M_maxActive, void* stream);
+int gf_voxelize_idx_fill(const long long* coords, int N, int ncol, int mode, void* scratch, const int32_t* input_map,
+                         int M, int maxActive, long long* out_coords, int32_t* out_map, void* stream);
+
 /* PG_OP.voxelize_fp (voxelize.cu:9-31): out[row,:] = sum_i mult * feats[rules[row,i],:], i in rule
  * order, mult = 1/count when average (mode 4).  rules int32 [M, 1+maxActive].  out fp32 [M,C]. */
 int gf_voxelize_fp(const float* feats, const int32_t* rules, int M, int maxActive, int C, int average, float* out,

@@ -108,3 +108,31 @@ def test_fps_resume_equals_single_call(hip, n, m0, m):
     assert (first == full[:, :m0]).all()
     cont = pointops.furthest_point_sampling(x, m, known=first)
     assert (cont == full).all()
+
+
+@pytest.mark.parametrize("N,ncol,mode,span", [(20000, 4, 4, 40), (5000, 4, 3, 12), (3000, 3, 4, 9), (4000, 4, 1, 10),
+                                              (4000, 4, 2, 10), (1, 4, 4, 3), (777, 4, 0, 2000)])
+def test_voxelize_idx_gpu_bit_exact(hip, oracle, N, ncol, mode, span):
+    """GPU voxelize_idx (row f2) vs the oracle's restatement of voxelize.cpp: voxel order, maps and rule rows."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(N + mode)
+    c = rng.integers(0, span, (N, ncol)).astype(np.int64)
+    if ncol == 4:
+        c[:, 0] = np.sort(rng.integers(0, 3, N))  # batch column, contiguous scenes
+    if mode == 0:
+        c = np.unique(c, axis=0)  # mode 0 = "guaranteed unique"
+        c = c[rng.permutation(c.shape[0])]
+    oc, p2v, v2p = oracle.voxelize_idx(c, mode)
+    goc, gp2v, gv2p = pointops.voxelize_idx(torch.from_numpy(c).cuda(), mode)
+    assert (gp2v.cpu().numpy() == p2v).all()
+    assert gv2p.shape == v2p.shape and (gv2p.cpu().numpy() == v2p).all()
+    assert (goc.cpu().numpy() == oc).all()
+
+
+def test_voxelize_idx_gpu_rejects_out_of_range(hip):
+    from geoformer_amd import _lib, pointops
+
+    c = torch.tensor([[0, 1, 2, 3], [0, 70000, 2, 3]], dtype=torch.int64).cuda()
+    with pytest.raises(_lib.GeoFormerHipError):
+        pointops.voxelize_idx(c, 4)
