@@ -276,7 +276,9 @@ __device__ __forceinline__ void fps_static_for(F&& f) {
 #ifndef FPS_KPUB
 #define FPS_KPUB 4    // candidates a workgroup publishes per exchange
 #endif
-#define FPS_K 8       // picks validated per exchange (FPS_K * FPS_K == 64: one lane per pair check)
+#ifndef FPS_K
+#define FPS_K 16      // upper bound of the picks one exchange can deliver
+#endif
 #define FPS_NG (FPS_MAXG * FPS_KPUB / 64)  // granules a lane gathers
 #define FPS_TAG (1ull << 63)
 
@@ -320,8 +322,8 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                                                         int bs_log2, int batch0,
                                                         unsigned long long* __restrict__ slots,
                                                         int32_t* __restrict__ idxs, int* __restrict__ err) {
-    static_assert(FPS_K * FPS_K == 64 && FPS_NG >= 1 && FPS_NG * 64 == FPS_MAXG * FPS_KPUB && FPS_KPUB <= FPS_K &&
-                      FPS_WAVES * 2 <= 64, "lane mappings of the exchange");
+    static_assert(FPS_NG >= 1 && FPS_NG * 64 == FPS_MAXG * FPS_KPUB && FPS_KPUB <= FPS_K && FPS_WAVES * 2 <= 64,
+                  "lane mappings of the exchange");
     __shared__ unsigned long long s_part[2][FPS_WAVES * 2];
     __shared__ int s_pick[2][FPS_K + 1];
     __shared__ float s_xyz[2][FPS_K * 3];
@@ -517,74 +519,58 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                 vy[j] = xyz[(size_t)ci * 3 + 1];
                 vz[j] = xyz[(size_t)ci * 3 + 2];
             }
-            unsigned long long gl[FPS_K];
-            bool gstop = false;
-            fps_static_for<0, FPS_K>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                unsigned long long mx = v[0];
-#pragma unroll
-                for (int j = 1; j < FPS_NG; j++) mx = v[j] > mx ? v[j] : mx;
-                const unsigned long long best = gstop ? 0ull : wave_max_u64(mx);
-                gl[t] = best & ~1ull;
-                if (best != 0ull) {
-                    if (mx == best) {  // the owner lane hands the coordinates to everybody
-                        float ox = vx[0], oy = vy[0], oz = vz[0];
-#pragma unroll
-                        for (int j = 1; j < FPS_NG; j++) {
-                            if (v[j] == best) {
-                                ox = vx[j];
-                                oy = vy[j];
-                                oz = vz[j];
-                            }
+            // 5) picks of this exchange.  Every lane holds one gathered candidate with its coordinates; B is the
+            //    best code any source may still be hiding (its last forwarded entry, original value: distances only
+            //    fall).  Repeatedly: the best candidate under its UPDATED distance is the next pick as long as its
+            //    code is >= B -- every hidden point is below B, every known one below the best -- then all lanes
+            //    lower their candidate's distance by the new pick.  A candidate that an accepted pick pulled down
+            //    is simply re-ranked, so the exchange keeps going where the prefix rule had to stop (simulated on
+            //    the S150k foreground: 174 exchanges for 2048 picks instead of 370).
+            static_assert(FPS_NG == 1, "one gathered candidate per lane");
+            const unsigned long long mine0 = v[0];
+            const unsigned long long Bcode = wave_max_u64((mine0 & 1ull) ? (mine0 & ~1ull) : 0ull);
+            unsigned ckey = (unsigned)((mine0 >> 1) & 0x7fffffffull);  // KEY_NONE - key
+            float cdist = __uint_as_float((unsigned)(mine0 >> 32));
+            bool alive = mine0 != 0ull;
+            int nacc = 0;
+#pragma unroll 1
+            for (int t = 0; t < FPS_K; t++) {
+                const unsigned long long my = alive ? (((unsigned long long)__float_as_uint(cdist) << 32) |
+                                                      ((unsigned long long)ckey << 1)) : 0ull;
+                const unsigned long long best = wave_max_u64(my);
+                if (t == 0) {
+                    if (best == 0ull) {  // nothing eligible anywhere: index 0 like the reference
+                        if (lane == 0) {
+                            s_xyz[par][0] = xyz[0];
+                            s_xyz[par][1] = xyz[1];
+                            s_xyz[par][2] = xyz[2];
+                            if (wg == 0) idxs[done] = 0;
                         }
-                        s_xyz[par][t * 3 + 0] = ox;
-                        s_xyz[par][t * 3 + 1] = oy;
-                        s_xyz[par][t * 3 + 2] = oz;
-#pragma unroll
-                        for (int j = 0; j < FPS_NG; j++)
-                            if (v[j] == best) v[j] = 0ull;
+                        nacc = 1;
+                        break;
                     }
-                    if (best & 1ull) gstop = true;
-                } else {
-                    gstop = true;
-                    if (lane == 0) {  // "none" resolves to index 0 like the reference
-                        s_xyz[par][t * 3 + 0] = xyz[0];
-                        s_xyz[par][t * 3 + 1] = xyz[1];
-                        s_xyz[par][t * 3 + 2] = xyz[2];
-                    }
+                } else if (best == 0ull || best < Bcode || (best >> 32) == 0ull || done + t >= m) {
+                    // (a candidate at distance 0 never overtakes the accepted picks, which sit at 0 with lower keys)
+                    break;
                 }
-            });
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // 5) validate the chain c1, c2, ...: c_t is a pick iff no accepted c_a (a < t) lowers its distance;
-            //    one lane per (t, a) pair, the verdicts come back as a ballot
-            const int vt = lane >> 3, va = lane & 7;
-            unsigned long long glt = gl[0];
-#pragma unroll
-            for (int t = 1; t < FPS_K; t++) glt = vt == t ? gl[t] : glt;
-            const float ctv = __uint_as_float((unsigned)(glt >> 32));
-            const float dx = s_xyz[par][vt * 3 + 0] - s_xyz[par][va * 3 + 0];
-            const float dy = s_xyz[par][vt * 3 + 1] - s_xyz[par][va * 3 + 1];
-            const float dz = s_xyz[par][vt * 3 + 2] - s_xyz[par][va * 3 + 2];
-            const bool viol = va < vt && fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < ctv;
-            const unsigned long long bad = __ballot(viol);
-            int nacc = 1;  // c1 is always the next pick
-            fps_static_for<1, FPS_K>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                // the accepted picks drop to distance 0 themselves: a candidate at distance 0 can never
-                // overtake them (they precede it in key order), e.g. in the m > n padding regime
-                const bool ok = nacc == t && gl[t] != 0ull && done + t < m && (gl[t] >> 32) != 0ull &&
-                                ((bad >> (8 * t)) & ((1ull << t) - 1ull)) == 0ull;
-                if (ok) nacc = t + 1;
-            });
-            if (lane == 0) {
-                s_pick[par][0] = nacc;
-                // (static indices only: a lane-indexed read of gl[] would make the compiler spill the array to LDS)
-                fps_static_for<0, FPS_K>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    if (wg == 0 && t < nacc) idxs[done + t] = fps_code_index(gl[t]);
-                });
+                const bool own = alive && my == best;
+                const int ol = __builtin_ctzll(__ballot(own));
+                const float bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx[0]), ol));
+                const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy[0]), ol));
+                const float bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz[0]), ol));
+                if (lane == 0) {
+                    s_xyz[par][t * 3 + 0] = bx;
+                    s_xyz[par][t * 3 + 1] = by;
+                    s_xyz[par][t * 3 + 2] = bz;
+                    if (wg == 0)
+                        idxs[done + t] = (int)((FPS_KEY_NONE - (unsigned)((best >> 1) & 0x7fffffffull)) & 0x3fffffu);
+                }
+                if (own) alive = false;
+                const float dx = vx[0] - bx, dy = vy[0] - by, dz = vz[0] - bz;
+                cdist = fminf(cdist, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+                nacc = t + 1;
             }
+            if (lane == 0) s_pick[par][0] = nacc;
         }
         __syncthreads();
         nnew = s_pick[par][0];
