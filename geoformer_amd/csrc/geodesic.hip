@@ -418,22 +418,25 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs_lds(const float* _
                 }
                 // rows are sorted by distance and padded with (inf,-1): stop after the first pad / out-of-radius
                 more = v[15] >= 0 && d[15] <= radius;
+                // all 16 probes of the visited bitmap first (branch-free, one LDS round trip), then the bids
+                unsigned wv[16];
+                bool open_[16];
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    const int rr = r0 + j;
-                    const int vv = v[j];
-                    if (rr >= 1 && vv >= 0 && d[j] <= radius) {
-                        const unsigned bit = 1u << (vv & 31);
-                        if (!(visited[vv >> 5] & bit)) {
-                            const unsigned cand = (((unsigned)u << 6) | (unsigned)rr) + 1u;
-                            const float nd = d[j] + gu;
-                            atomicMin(&key[vv], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(nd));
-                            const unsigned old = atomicOr(&touched[vv >> 5], bit);
-                            if (!(old & bit)) {
-                                const int pos = atomicAdd(&s_cnt, 1);
-                                if (pos < qcap) nl[pos].x = vv;
-                                else ng[pos - qcap].x = vv;
-                            }
+                    open_[j] = (r0 + j) >= 1 && v[j] >= 0 && d[j] <= radius;
+                    wv[j] = visited[open_[j] ? (v[j] >> 5) : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const unsigned bit = 1u << (v[j] & 31);
+                    if (open_[j] && !(wv[j] & bit)) {
+                        const unsigned cand = (((unsigned)u << 6) | (unsigned)(r0 + j)) + 1u;
+                        atomicMin(&key[v[j]], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(d[j] + gu));
+                        const unsigned old = atomicOr(&touched[v[j] >> 5], bit);
+                        if (!(old & bit)) {
+                            const int pos = atomicAdd(&s_cnt, 1);
+                            if (pos < qcap) nl[pos].x = v[j];
+                            else ng[pos - qcap].x = v[j];
                         }
                     }
                 }
