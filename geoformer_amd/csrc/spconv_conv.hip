@@ -166,6 +166,7 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
     constexpr bool SPLIT = SW > 0;  // SW waves of the workgroup share one item
     constexpr int NSW = SW > 0 ? SW : 1;
     __shared__ int s_idx[SPLIT ? NSW : 8][32 * 16];
+    __shared__ int s_kl[SPLIT ? NSW : 8][32];  // present offsets of the wave's item, ascending
     __shared__ float4 s_red[SPLIT ? NSW * NCBW * 64 : 1];
     __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];  // fused BN scale / shift
     const int lane = threadIdx.x & 63;
@@ -244,13 +245,15 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
                 if (k < K) idx_l[k * 16 + r] = iv[i];
             }
         }
+        // the steps of the item are (present offset i, chunk c), numbered s = i*NCH + c; a wave takes s = first, first +
+        // stride, ...  (plain index arithmetic: the earlier bit-scanning iterator cost ~20 scalar branches per
+        // step, 0.26 us per step and wave on the small levels -- more than the step's memory round trip)
+        if (lane < 32 && ((mask >> lane) & 1u)) s_kl[w][__popc(mask & ((1u << lane) - 1u))] = lane;
         __builtin_amdgcn_wave_barrier();
-
-        StepIter it;
-        it.init(mask, NCH);
-        if (SPLIT)
-            for (int j = 0; j < w; j++) it.next();
-        while (it.k >= 0) {
+        const int nsteps = __popc(mask) * NCH;
+        const int sstride = SPLIT ? NSW : 1;
+        const unsigned inv_nch = (65536u + (unsigned)NCH - 1u) / (unsigned)NCH;  // s / NCH for s < 4096, NCH <= 16
+        for (int s0 = SPLIT ? w : 0; s0 < nsteps; s0 += PF * sstride) {
             float4 a[PF];
             float4 b[LDSW ? 1 : PF][NCBW];
             bool valid[PF];
@@ -258,10 +261,15 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
             int chv[PF];
 #pragma unroll
             for (int j = 0; j < PF; j++) {
-                valid[j] = it.k >= 0;
+                const int sj = s0 + j * sstride;
+                valid[j] = sj < nsteps;
                 present[j] = false;
                 chv[j] = 0;
                 if (valid[j]) {
+                    const int ki = (int)(((unsigned)sj * inv_nch) >> 16);
+                    struct { int k, c; } it;
+                    it.k = __builtin_amdgcn_readfirstlane(s_kl[w][ki]);
+                    it.c = sj - ki * NCH;
                     const int idx = idx_l[it.k * 16 + r];
                     present[j] = idx >= 0;
                     chv[j] = it.c * 16 + 4 * q;
@@ -292,11 +300,6 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
                                            ? Wp[(((size_t)it.k * NCH + it.c) * NCB + cb0 + cb) * 64 + lane]
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                }
-                it.next();
-                if (SPLIT) {
-#pragma unroll
-                    for (int e = 1; e < NSW; e++) it.next();
                 }
             }
 #pragma unroll
@@ -574,7 +577,9 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     bool split = ngroups < 6000;
     if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
     // tiny levels (all items resident at once with room to spare): 16 waves per item, 4x shorter chains again
-    bool wide = false;  // measured slower (register spills at 1024 threads), kept behind GF_CONV_WIDE
+    // tiny levels (<= 256 workgroups of 16 waves, all resident at once): 16 waves share an item, each wave's chain
+    // of gather batches is 4x shorter again (S150k levels 5-7: 13.5/15.8/16.0 -> 10.6/11.4/11.5 us)
+    bool wide = split && (long long)ngroups * ncb <= 256;
     if (const char* e = getenv("GF_CONV_WIDE")) wide = split && atoi(e) != 0;
     const int ncbw = split ? (!wide && ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
     const int nsplit = (ncb + ncbw - 1) / ncbw;
