@@ -156,7 +156,7 @@ struct StepIter {
 };
 
 template <int NCBW, int SW, bool VEC, bool LDSW>
-__global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
+__global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW <= 2) ? 5 : 1) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                  const int32_t* __restrict__ nbr, const uint32_t* __restrict__ gmask,
                                                  int K, int M_out, int ld, int Cin, int Cout, int NCH, int NCB,
                                                  int nsplit, unsigned in_bytes, const float* __restrict__ in_scale,
@@ -259,6 +259,20 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
             bool valid[PF];
             bool present[PF];
             int chv[PF];
+            // offsets and neighbour rows of the whole batch first (independent LDS reads, one wait), then the loads
+            int kq[PF], cq[PF], iq[PF];
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const int sj = min(s0 + j * sstride, nsteps - 1);
+                const int ki = (int)(((unsigned)sj * inv_nch) >> 16);
+                kq[j] = s_kl[w][ki];
+                cq[j] = sj - ki * NCH;
+            }
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                kq[j] = __builtin_amdgcn_readfirstlane(kq[j]);
+                iq[j] = idx_l[kq[j] * 16 + r];
+            }
 #pragma unroll
             for (int j = 0; j < PF; j++) {
                 const int sj = s0 + j * sstride;
@@ -266,11 +280,10 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 512) void k_conv_os(c
                 present[j] = false;
                 chv[j] = 0;
                 if (valid[j]) {
-                    const int ki = (int)(((unsigned)sj * inv_nch) >> 16);
                     struct { int k, c; } it;
-                    it.k = __builtin_amdgcn_readfirstlane(s_kl[w][ki]);
-                    it.c = sj - ki * NCH;
-                    const int idx = idx_l[it.k * 16 + r];
+                    it.k = kq[j];
+                    it.c = cq[j];
+                    const int idx = iq[j];
                     present[j] = idx >= 0;
                     chv[j] = it.c * 16 + 4 * q;
                     if (VEC) {
@@ -584,7 +597,7 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     const int ncbw = split ? (!wide && ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
     const int nsplit = (ncb + ncbw - 1) / ncbw;
     const long long nitems = (long long)ngroups * nsplit;
-    if (const char* e = getenv("GF_CONV_BLOCK")) g_conv_block = atoi(e);
+    if (const char* e = getenv("GF_CONV_BLOCK")) g_conv_block = atoi(e) > 256 ? 256 : atoi(e);
     const int wpb = g_conv_block / 64;
     long long blocks = split ? nitems : (nitems + wpb - 1) / wpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
@@ -610,9 +623,9 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
             hipLaunchKernelGGL(k_conv_pair<false>, dim3((unsigned)pb), dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                                a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.out);
     } else if (ldsw) {
-        // 512-thread workgroups share one weight image: 8 waves per 27-54 KiB
-        const int bs = 512;
-        dim3 g2((unsigned)((nitems + 7) / 8));
+        // 256-thread workgroups share one weight image: 4 waves per 27-54 KiB
+        const int bs = 256;
+        dim3 g2((unsigned)((nitems + 3) / 4));
         if (ncb == 1) launch_conv_ldsw<1>(g2, bs, wbytes, st, a);
         else launch_conv_ldsw<2>(g2, bs, wbytes, st, a);
     } else if (split && wide)
