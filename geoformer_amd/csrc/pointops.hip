@@ -139,13 +139,19 @@ extern "C" int gf_group_points_grad(const float* grad_out, const int32_t* idx, i
 // 512-point tiles of xyz through LDS so 8 centres share every fetched tile; a wave stops as
 // soon as it holds nsample hits (ballot + popcount compaction keeps ascending order).
 // ------------------------------------------------------------------------------------
+// One wave per centre, 8 centres per workgroup sharing every tile of points.  The tile lives in LDS as three
+// coordinate planes so a lane tests four consecutive points per ds_read_b128 triple (256 points per wave trip), and
+// the next tile is already in flight in registers while this one is tested (one barrier per tile).  Hits are
+// appended in index order: the four compare masks give each lane the number of earlier hits.
 #define BQ_WAVES 8
-#define BQ_TILE 512
+#define BQ_TILE 1024
+#define BQ_PLANE (BQ_TILE + 12)  // plane stride: 16-byte aligned rows, x/y/z of one point in different banks
+#define BQ_LD (BQ_TILE * 3 / (BQ_WAVES * 64))
 __global__ __launch_bounds__(BQ_WAVES * 64) void k_ball_query(const float* __restrict__ new_xyz,
                                                                const float* __restrict__ xyz, int n, int m,
                                                                float radius2, int nsample, int32_t* __restrict__ idx) {
-    __shared__ float tile[BQ_TILE * 3];
-    __shared__ int done_count;
+    __shared__ __attribute__((aligned(16))) float tile[2][3 * BQ_PLANE];
+    __shared__ int s_done[2][BQ_WAVES];
     const int bi = blockIdx.y;
     xyz += (size_t)bi * n * 3;
     new_xyz += (size_t)bi * m * 3;
@@ -161,32 +167,81 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void k_ball_query(const float* __res
     }
     int cnt = valid ? 0 : nsample;  // invalid waves are "done"
     int first = -1;
-    for (int base = 0; base < n; base += BQ_TILE) {
-        if (threadIdx.x == 0) done_count = 0;
-        __syncthreads();
-        const int tn = min(BQ_TILE, n - base);
-        for (int t = threadIdx.x; t < tn * 3; t += BQ_WAVES * 64) tile[t] = xyz[(size_t)base * 3 + t];
-        if (lane == 0 && cnt >= nsample) atomicAdd(&done_count, 1);
-        __syncthreads();
-        if (done_count == BQ_WAVES) break;  // uniform: every wave of the block has its nsample hits
+    // this thread's slots of a tile: flat float f = threadIdx.x + 512 i  ->  plane f % 3, point f / 3
+    int slot[BQ_LD];
+#pragma unroll
+    for (int i = 0; i < BQ_LD; i++) {
+        const unsigned f = threadIdx.x + BQ_WAVES * 64 * i;
+        const unsigned p = __umulhi(f, 0xAAAAAAABu) >> 1;
+        slot[i] = (int)((f - 3u * p) * BQ_PLANE + p);
+    }
+    float nxt[BQ_LD];
+    const int ntiles = (n + BQ_TILE - 1) / BQ_TILE;
+    auto fetch = [&](int t) {
+        const int base3 = t * BQ_TILE * 3, lim = n * 3;
+#pragma unroll
+        for (int i = 0; i < BQ_LD; i++) {
+            const int f = base3 + (int)threadIdx.x + BQ_WAVES * 64 * i;
+            nxt[i] = f < lim ? xyz[f] : 1e30f;  // padding points are never inside a ball
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < BQ_LD; i++) tile[buf][slot[i]] = nxt[i];
+    };
+    if (ntiles > 0) {
+        fetch(0);
+        stage(0);
+    }
+    if (lane == 0) s_done[0][wid] = cnt >= nsample;
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int buf = t & 1;
+        int alldone = 1;
+#pragma unroll
+        for (int w = 0; w < BQ_WAVES; w++) alldone &= s_done[buf][w];
+        if (alldone) break;  // uniform: every wave of the block has its nsample hits
+        if (t + 1 < ntiles) fetch(t + 1);
         if (cnt < nsample) {
-            for (int s = 0; s < tn && cnt < nsample; s += 64) {
-                const int p = s + lane;
-                bool hit = false;
-                if (p < tn) {
-                    const float dx = nx - tile[p * 3 + 0], dy = ny - tile[p * 3 + 1], dz = nz - tile[p * 3 + 2];
-                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    hit = d2 < radius2;
+            const float* tx = tile[buf];
+            const int base = t * BQ_TILE;
+            for (int s = 0; s < BQ_TILE && cnt < nsample; s += 256) {
+                const float4 X = *reinterpret_cast<const float4*>(tx + s + 4 * lane);
+                const float4 Y = *reinterpret_cast<const float4*>(tx + BQ_PLANE + s + 4 * lane);
+                const float4 Z = *reinterpret_cast<const float4*>(tx + 2 * BQ_PLANE + s + 4 * lane);
+                const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+                bool hit[4];
+                unsigned long long bal[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float dx = nx - xs[u], dy = ny - ys[u], dz = nz - zs[u];
+                    hit[u] = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < radius2;
+                    bal[u] = __ballot(hit[u]);
                 }
-                const unsigned long long bal = __ballot(hit);
-                if (bal) {
-                    if (first < 0) first = base + s + __builtin_ctzll(bal);
-                    const int pos = cnt + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (hit && pos < nsample) idx[(size_t)j * nsample + pos] = base + p;
-                    cnt += __popcll(bal);
+                const unsigned long long any = bal[0] | bal[1] | bal[2] | bal[3];
+                if (any) {
+                    if (first < 0) {
+                        const int l0 = __builtin_ctzll(any);
+                        const int u0 = ((bal[0] >> l0) & 1) ? 0 : ((bal[1] >> l0) & 1) ? 1 : ((bal[2] >> l0) & 1) ? 2 : 3;
+                        first = base + s + 4 * l0 + u0;
+                    }
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    int pos = cnt + __popcll(bal[0] & below) + __popcll(bal[1] & below) + __popcll(bal[2] & below) +
+                              __popcll(bal[3] & below);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (hit[u]) {
+                            if (pos < nsample) idx[(size_t)j * nsample + pos] = base + s + 4 * lane + u;
+                            pos++;
+                        }
+                    }
+                    cnt += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
                 }
             }
         }
+        if (t + 1 < ntiles) stage(buf ^ 1);
+        if (lane == 0) s_done[buf ^ 1][wid] = cnt >= nsample;
+        __syncthreads();
     }
     if (valid) {
         const int filled = min(cnt, nsample);
