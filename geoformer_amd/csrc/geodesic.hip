@@ -17,6 +17,7 @@
 // sort-based de-duplication keeps -- and the first toucher appends the vertex to the next frontier;
 // (b) after a barrier the new frontier commits geo[v] = geo[parent] + D[parent][rank].  Distances
 // are fp32 sums along that parent chain, so results are bit-identical to the reference's.
+#include <cstdlib>
 #include "common.h"
 
 // ------------------------------------------------------------------------------------
@@ -480,7 +481,12 @@ extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* 
         }
         const int nw = (n + 31) / 32;
         const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
-        int qcap = (int)((BFS_LDS_BYTES - bm) / (2 * sizeof(int2)));
+        size_t budget = BFS_LDS_BYTES;
+        if (const char* e = getenv("GF_BFS_LDS_KB")) {
+            const long kb = atol(e);
+            if (kb > 0 && (size_t)kb * 1024 <= BFS_LDS_BYTES && (size_t)kb * 1024 > bm + 64) budget = (size_t)kb * 1024;
+        }
+        int qcap = (int)((budget - bm) / (2 * sizeof(int2)));
         if (qcap > n) qcap = n;
         const size_t lds = bm + (size_t)qcap * 2 * sizeof(int2);
         hipLaunchKernelGGL(k_geodesic_bfs_lds, dim3(nq), dim3(BFS_THREADS), lds, (hipStream_t)stream, D, I, n, K, src,

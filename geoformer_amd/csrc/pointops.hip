@@ -144,9 +144,11 @@ extern "C" int gf_group_points_grad(const float* grad_out, const int32_t* idx, i
 // the next tile is already in flight in registers while this one is tested (one barrier per tile).  Hits are
 // appended in index order: the four compare masks give each lane the number of earlier hits.
 #define BQ_WAVES 8
-#define BQ_TILE 1024
+#ifndef BQ_TILE
+#define BQ_TILE 256
+#endif
 #define BQ_PLANE (BQ_TILE + 12)  // plane stride: 16-byte aligned rows, x/y/z of one point in different banks
-#define BQ_LD (BQ_TILE * 3 / (BQ_WAVES * 64))
+#define BQ_LD ((BQ_TILE * 3 + BQ_WAVES * 64 - 1) / (BQ_WAVES * 64))
 __global__ __launch_bounds__(BQ_WAVES * 64) void k_ball_query(const float* __restrict__ new_xyz,
                                                                const float* __restrict__ xyz, int n, int m,
                                                                float radius2, int nsample, int32_t* __restrict__ idx) {
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void k_ball_query(const float* __res
     for (int i = 0; i < BQ_LD; i++) {
         const unsigned f = threadIdx.x + BQ_WAVES * 64 * i;
         const unsigned p = __umulhi(f, 0xAAAAAAABu) >> 1;
-        slot[i] = (int)((f - 3u * p) * BQ_PLANE + p);
+        slot[i] = f < BQ_TILE * 3 ? (int)((f - 3u * p) * BQ_PLANE + p) : -1;
     }
     float nxt[BQ_LD];
     const int ntiles = (n + BQ_TILE - 1) / BQ_TILE;
@@ -182,12 +184,13 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void k_ball_query(const float* __res
 #pragma unroll
         for (int i = 0; i < BQ_LD; i++) {
             const int f = base3 + (int)threadIdx.x + BQ_WAVES * 64 * i;
-            nxt[i] = f < lim ? xyz[f] : 1e30f;  // padding points are never inside a ball
+            nxt[i] = (f < lim && slot[i] >= 0) ? xyz[f] : 1e30f;  // padding points are never inside a ball
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < BQ_LD; i++) tile[buf][slot[i]] = nxt[i];
+        for (int i = 0; i < BQ_LD; i++)
+            if (slot[i] >= 0) tile[buf][slot[i]] = nxt[i];
     };
     if (ntiles > 0) {
         fetch(0);
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void k_ball_query(const float* __res
         if (cnt < nsample) {
             const float* tx = tile[buf];
             const int base = t * BQ_TILE;
-            for (int s = 0; s < BQ_TILE && cnt < nsample; s += 256) {
+            for (int s = 0; s < BQ_TILE && cnt < nsample; s += 256) {  // BQ_TILE is a multiple of 256
                 const float4 X = *reinterpret_cast<const float4*>(tx + s + 4 * lane);
                 const float4 Y = *reinterpret_cast<const float4*>(tx + BQ_PLANE + s + 4 * lane);
                 const float4 Z = *reinterpret_cast<const float4*>(tx + 2 * BQ_PLANE + s + 4 * lane);

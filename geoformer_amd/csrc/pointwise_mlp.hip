@@ -138,7 +138,10 @@ __device__ __forceinline__ float pm_row_max(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__ grouped, int B, int np, int ns,
+#ifndef GM_MINW
+#define GM_MINW 1
+#endif
+__global__ __launch_bounds__(256, GM_MINW) void k_group_mlp_max(const float* __restrict__ grouped, int B, int np, int ns,
                                                        PmArgs A, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
