@@ -51,6 +51,7 @@ def _declare(lib):
         "gf_knn_radius": (I, [P, I, I, F, I, P, P, P, P, P]),
         "gf_knn_error_flag": (P, [P, I]),
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
+        "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, I, P]),
         "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
         "gf_softmax_dim1_fwd": (I, [P, I, I, I, F, P, P]),
         "gf_softmax_dim1_bwd": (I, [P, P, I, I, I, F, P, P]),

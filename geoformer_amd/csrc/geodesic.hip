@@ -351,7 +351,8 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
 // orders by (parent, rank) first, so the distance that rides in the low word is the winner's.
 #define BFS_LDS_MAX_N (1 << 19)
 #define BFS_LDS_BYTES (150 * 1024)
-__global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs_lds(const float* __restrict__ D,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __restrict__ D,
                                                                   const int32_t* __restrict__ I, int n, int K,
                                                                   const int32_t* __restrict__ src, float radius,
                                                                   int max_step, float* __restrict__ geo,
@@ -370,11 +371,11 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs_lds(const float* _
     int2* gq0 = queues + (size_t)q * 2 * n;  // overflow space of the two queues
     int2* gq1 = gq0 + n;
     const int tid = threadIdx.x;
-    for (int t = tid; t < n; t += BFS_THREADS) {
+    for (int t = tid; t < n; t += THREADS) {
         g[t] = -1.0f;
         key[t] = ~0ull;
     }
-    for (int t = tid; t < nw; t += BFS_THREADS) {
+    for (int t = tid; t < nw; t += THREADS) {
         visited[t] = 0u;
         touched[t] = 0u;
     }
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs_lds(const float* _
     int ncur = 1;
     int2 *cl = q0, *cg = gq0, *nl = q1, *ng = gq1;
     for (int step = 0; step < max_step && ncur > 0; step++) {
-        for (int f = tid; f < ncur; f += BFS_THREADS) {
+        for (int f = tid; f < ncur; f += THREADS) {
             const int2 e = f < qcap ? cl[f] : cg[f - qcap];
             const int u = e.x;
             const float gu = __int_as_float(e.y);
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs_lds(const float* _
         const int nn = s_cnt;
         __syncthreads();
         if (tid == 0) s_cnt = 0;
-        for (int t = tid; t < nn; t += BFS_THREADS) {
+        for (int t = tid; t < nn; t += THREADS) {
             int2* slot = t < qcap ? &nl[t] : &ng[t - qcap];
             const int v = slot->x;
             const unsigned long long kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -464,33 +465,49 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs_lds(const float* _
     }
 }
 
-extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src,
-                               int nq, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
-                               void* stream) {
+template <int THREADS>
+static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, const int32_t* I, int n, int K,
+                           const int32_t* src, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
+                           int qcap) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_geodesic_bfs_lds<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  BFS_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_geodesic_bfs_lds<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
+                       geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
+}
+
+// wg_threads: threads (and, in proportion, LDS) per query.  1024 = one query per compute unit, the fastest when the
+// launch has the chip to itself; 256 lets four queries share a compute unit, which is what makes the launch overlap
+// with furthest point sampling (16 compute units busy for 1.3 ms): with one query per CU the 256 queries of the eval
+// forward need a second round on the remaining 240 CUs and the launch takes 2.2 ms instead of 1.3 ms; at 256 threads
+// it takes 1.45 ms alone and 1.65 ms beside the sampling kernel (S150k, tools/fps_bfs_overlap_exp.py).
+extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K,
+                                   const int32_t* src, int nq, float radius, int max_step, float* geo, void* keys_ws,
+                                   void* queue_ws, int wg_threads, void* stream) {
     GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs: bad arguments");
     GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs: n=%d exceeds the 26-bit parent field", n);
+    GF_CHECK_ARG(wg_threads == 1024 || wg_threads == 512 || wg_threads == 256,
+                 "gf_geodesic_bfs: wg_threads=%d (256, 512 or 1024)", wg_threads);
     if (nq == 0) return GF_OK;
-    if (n <= BFS_LDS_MAX_N && (K & 3) == 0) {
+    const int nw = (n + 31) / 32;
+    const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
+    const size_t budget = (size_t)BFS_LDS_BYTES * wg_threads / 1024;
+    if (n <= BFS_LDS_MAX_N && (K & 3) == 0 && bm + 64 * 2 * sizeof(int2) <= budget) {
         // rows must be distance-sorted and padded with (inf,-1) (gf_knn_radius / faiss order): the
         // LDS variant relies on that to stop scanning a row early
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipFuncSetAttribute((const void*)k_geodesic_bfs_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                BFS_LDS_BYTES);
-            attr_set = true;
-        }
-        const int nw = (n + 31) / 32;
-        const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
-        size_t budget = BFS_LDS_BYTES;
-        if (const char* e = getenv("GF_BFS_LDS_KB")) {
-            const long kb = atol(e);
-            if (kb > 0 && (size_t)kb * 1024 <= BFS_LDS_BYTES && (size_t)kb * 1024 > bm + 64) budget = (size_t)kb * 1024;
-        }
         int qcap = (int)((budget - bm) / (2 * sizeof(int2)));
         if (qcap > n) qcap = n;
         const size_t lds = bm + (size_t)qcap * 2 * sizeof(int2);
-        hipLaunchKernelGGL(k_geodesic_bfs_lds, dim3(nq), dim3(BFS_THREADS), lds, (hipStream_t)stream, D, I, n, K, src,
-                           radius, max_step, geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
+        hipStream_t st = (hipStream_t)stream;
+        if (wg_threads == 256)
+            launch_bfs_lds<256>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
+        else if (wg_threads == 512)
+            launch_bfs_lds<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
+        else
+            launch_bfs_lds<1024>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
         GF_CHECK_LAUNCH("gf_geodesic_bfs");
         return GF_OK;
     }
@@ -498,6 +515,12 @@ extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* 
                        radius, max_step, geo, (unsigned*)keys_ws, (int32_t*)queue_ws);
     GF_CHECK_LAUNCH("gf_geodesic_bfs");
     return GF_OK;
+}
+
+extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src,
+                               int nq, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
+                               void* stream) {
+    return gf_geodesic_bfs_cfg(D, I, deg, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, 1024, stream);
 }
 
 // ------------------------------------------------------------------------------------

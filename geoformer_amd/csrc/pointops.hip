@@ -145,7 +145,7 @@ extern "C" int gf_group_points_grad(const float* grad_out, const int32_t* idx, i
 // appended in index order: the four compare masks give each lane the number of earlier hits.
 #define BQ_WAVES 8
 #ifndef BQ_TILE
-#define BQ_TILE 256
+#define BQ_TILE 1024
 #endif
 #define BQ_PLANE (BQ_TILE + 12)  // plane stride: 16-byte aligned rows, x/y/z of one point in different banks
 #define BQ_LD ((BQ_TILE * 3 + BQ_WAVES * 64 - 1) / (BQ_WAVES * 64))

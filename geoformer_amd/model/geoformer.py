@@ -277,20 +277,24 @@ class GeoFormer(nn.Module):
             return context_locs, context_feats, pre_enc_inds
 
     def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step):
-        """Inference on the GPU: once the furthest-point sequence is drawn, the geodesic BFS (a latency-bound launch
-        that leaves most of the chip idle) goes to a second HIP stream and runs beside ball query, grouping, the
-        shared MLP and the decoder's input projections; the main stream joins it where the decoder first needs
-        the distances (relative_position_embedding).  Same values as forward_aggregator + cal_geodesic, same
-        consumption of the host RNG.  (Starting the BFS after the first n_query_points picks, beside the rest of
-        FPS, was measured too: the cross-CU exchange of FPS slows down by more than the BFS saves.)"""
+        """Inference on the GPU.  Furthest point sampling (2047 serial rounds on 16 compute units) and the geodesic
+        BFS (<= 256 serial hops, one workgroup per query) are the two long latency-bound launches of the forward, and
+        the BFS only needs the first n_query_points picks.  So the sampling is cut after those picks, the BFS goes
+        to a second HIP stream with four queries per compute unit (it then fits on the units the sampling leaves
+        free: gf_geodesic_bfs_cfg), and the rest of the sampling, ball query, grouping, the shared MLP and the
+        decoder's input projections run beside it on the main stream, which joins where the decoder first needs the
+        distances (relative_position_embedding).  Same values as forward_aggregator + cal_geodesic, same consumption
+        of the host RNG.  GF_OVERLAP=2 keeps the sampling in one piece and starts the BFS after it."""
         offs = _offsets_list(batch_offsets_)
         nq = self.cfg.n_query_points
+        npoint_sa = self.set_aggregator.npoint
+        split = os.environ.get("GF_OVERLAP", "1") != "2" and npoint_sa > nq
         main = torch.cuda.current_stream()
         side = self.__dict__.get("_gf_side_stream")
         if side is None or side.device != locs_float_.device:
             side = torch.cuda.Stream(device=locs_float_.device)  # (stream priorities made no difference: measured)
             self.__dict__["_gf_side_stream"] = side
-        staged = []
+        staged, geo = [], []
         for b in range(batch_size):
             n_b = offs[b + 1] - offs[b]
             if n_b == 0:
@@ -301,15 +305,17 @@ class GeoFormer(nn.Module):
             self.last_sampling_indices = sampling_indices
             xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
             feat_b = output_feats_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).transpose(1, 2).contiguous()
-            staged.append((xyz_b, feat_b, pointops.furthest_point_sampling(xyz_b, self.set_aggregator.npoint)))
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            geo = []
-            for b in range(batch_size):
+            first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
+            src = first[0, :nq].contiguous()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
                 D, I, deg = graphs[b]
-                g = pointops.geodesic_bfs(D, I, deg, staged[b][2][0, :nq].contiguous(), 0.05, max_step)
+                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=256 if split else 1024)
                 g.record_stream(main)
+                src.record_stream(side)
                 geo.append(g)
+            idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+            staged.append((xyz_b, feat_b, idx))
         self.__dict__["_gf_pending_side"] = side
         locs, gfeat, gxyz, inds = [], [], [], []
         for xyz_b, feat_b, idx in staged:

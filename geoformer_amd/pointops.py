@@ -156,8 +156,9 @@ def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False):
     return D, I, deg
 
 
-def geodesic_bfs(D, I, deg, src, radius, max_step):
-    """geo [nq,n] fp32 for the sources `src` (int32 [nq]) over the kNN rows D/I (column 0 skipped)."""
+def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
+    """geo [nq,n] fp32 for the sources `src` (int32 [nq]) over the kNN rows D/I (column 0 skipped).
+    wg_threads: 1024 = one query per compute unit; 256 / 512 = several per unit (to run beside another kernel)."""
     _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
     n, K = D.shape
     nq = src.shape[0]
@@ -165,8 +166,9 @@ def geodesic_bfs(D, I, deg, src, radius, max_step):
     geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
     keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
     queues = torch.empty((nq, 4, n), dtype=torch.int32, device=dev)
-    check(_lib.load().gf_geodesic_bfs(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
-                                      ptr(geo), ptr(keys), ptr(queues), stream_ptr()), "gf_geodesic_bfs")
+    check(_lib.load().gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
+                                          ptr(geo), ptr(keys), ptr(queues), int(wg_threads), stream_ptr()),
+          "gf_geodesic_bfs")
     return geo
 
 

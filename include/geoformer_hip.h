@@ -201,6 +201,12 @@ const int32_t* gf_knn_error_flag(void* scratch, int n);
  *   D/I rows must be sorted by distance with (inf,-1) padding (the order gf_knn_radius and faiss emit). */
 int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
                     float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, void* stream);
+/* Same, with the workgroup size per query chosen by the caller: wg_threads = 1024 (one query per compute unit,
+ * fastest when the launch has the device to itself), 512 or 256 (several queries share a compute unit, so the
+ * launch fits beside another resident kernel -- the host runs it next to furthest point sampling). */
+int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
+                        float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, int wg_threads,
+                        void* stream);
 
 /* ===================================================================================
  * Mask head (GeoFormer.mask_heads_forward, model/geoformer/geoformer.py:286-324), fused

@@ -59,3 +59,7 @@ def test_bfs_matches_oracle(hip, oracle, n, nq, max_step):
     geo2 = pointops.geodesic_bfs(_dev(D.astype(np.float32)), _dev(I.astype(np.int32)), None,
                                  _dev(src.astype(np.int32)), radius, max_step).cpu().numpy()
     assert (geo2 == ref).all()
+    # several queries per compute unit (the layout the forward uses beside furthest point sampling): same values
+    for wg in (256, 512):
+        geo3 = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), radius, max_step, wg_threads=wg)
+        assert (geo3.cpu().numpy() == ref).all()

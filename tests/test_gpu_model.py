@@ -18,9 +18,9 @@ def _to_dev(batch):
     return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
-@pytest.fixture(scope="module", params=["1", "0"], ids=["two-stream", "sequential"])
+@pytest.fixture(scope="module", params=["1", "2", "0"], ids=["split-sampling", "two-stream", "sequential"])
 def run(hip, request):
-    os.environ["GF_OVERLAP"] = request.param  # set aggregation || geodesic BFS on two streams, or one after the other
+    os.environ["GF_OVERLAP"] = request.param  # sampling cut after the query picks with the BFS beside the rest / BFS beside grouping only / one after the other
     from geoformer_amd import scene
     from geoformer_amd.model import GeoFormer, load_config
     from tests.util import synthetic_state_dict
