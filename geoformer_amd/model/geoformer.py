@@ -276,7 +276,8 @@ class GeoFormer(nn.Module):
             context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
             return context_locs, context_feats, pre_enc_inds
 
-    def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step):
+    def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step,
+                                       pc_dims=None):
         """Inference on the GPU.  Furthest point sampling (2047 serial rounds on 16 compute units) and the geodesic
         BFS (<= 256 serial hops, one workgroup per query) are the two long latency-bound launches of the forward, and
         the BFS only needs the first n_query_points picks.  So the sampling is cut after those picks, the BFS goes
@@ -314,6 +315,9 @@ class GeoFormer(nn.Module):
                 g.record_stream(main)
                 src.record_stream(side)
                 geo.append(g)
+                # small launches that only need the distances / the query picks ride in the BFS's shadow instead of
+                # sitting between the decoder and the mask head on the main stream
+                self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main)
             idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
             staged.append((xyz_b, feat_b, idx))
         self.__dict__["_gf_pending_side"] = side
@@ -324,6 +328,24 @@ class GeoFormer(nn.Module):
         context_locs, pre_enc_inds = torch.cat(locs), torch.cat(inds)
         context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
         return (context_locs, context_feats, pre_enc_inds), geo
+
+    def _side_epilogue(self, b, batch_size, g, xyz_b, src, pc_dims, main):
+        early = self.__dict__.setdefault("_gf_early", {})
+        if b == 0:
+            early.clear()
+        # sqrt of the per-query maximum geodesic distance (mask_heads_forward, geoformer.py:303-306)
+        mx = torch.max(g, dim=1)[0]
+        mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+        mx.record_stream(main)
+        early[("mx", b)] = (g, mx)
+        if batch_size == 1 and pc_dims is not None and self.cfg.dec_dim == 64:
+            qpr = self._pointwise_chain("qproj", [self.query_projection], xyz_b)
+            if qpr is not None:
+                q_locs = xyz_b[:, src.long()]  # the first picks = the query points (same gather as group_points)
+                qpe = self.pos_embedding(q_locs, input_range=pc_dims).float()
+                qpos = pointops.pointwise_mlp(qpe[0].t().contiguous(), qpr)
+                qpos.record_stream(main)
+                early["qpos"] = (q_locs, qpos)
 
     def _join_side_stream(self):
         side = self.__dict__.pop("_gf_pending_side", None)
@@ -364,9 +386,13 @@ class GeoFormer(nn.Module):
             qpr = self._pointwise_chain("qproj", [self.query_projection], context_feats)
             if e2d is not None and qpr is not None:
                 ctx = pointops.pointwise_mlp(context_feats[0].contiguous(), e2d)  # [nc, dec_dim]
-                qpe = self.pos_embedding(query_locs, input_range=pc_dims).float()  # [1, dec_dim, nq]
-                qpos = pointops.pointwise_mlp(qpe[0].t().contiguous(), qpr)  # [nq, dec_dim]
                 rel = self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds)
+                hit = self.__dict__.get("_gf_early", {}).pop("qpos", None)  # computed beside the BFS (joined above)
+                if hit is not None and hit[0].shape == query_locs.shape:
+                    qpos = hit[1]
+                else:
+                    qpe = self.pos_embedding(query_locs, input_range=pc_dims).float()  # [1, dec_dim, nq]
+                    qpos = pointops.pointwise_mlp(qpe[0].t().contiguous(), qpr)  # [nq, dec_dim]
                 memory = ctx.unsqueeze(1)  # [nc, 1, dec_dim]
                 return self.decoder(tgt=memory[:nq], memory=memory, pos=None, query_pos=qpos.unsqueeze(1),
                                     relative_pos=rel)
@@ -396,8 +422,13 @@ class GeoFormer(nn.Module):
             # inference: one fused HIP kernel (no nq x 19 x N intermediate)
             mx = None
             if use_geo:
-                mx = torch.max(geo_dist, dim=1)[0]
-                mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+                early = self.__dict__.get("_gf_early", {})
+                hit = next((early.pop(k) for k in list(early) if k[0] == "mx" and early[k][0] is geo_dist), None)
+                if hit is not None:
+                    mx = hit[1]  # computed beside the BFS
+                else:
+                    mx = torch.max(geo_dist, dim=1)[0]
+                    mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
             od = self.output_dim
             logits = pointops.mask_head(
                 mask_features.reshape(n_mask, od).contiguous(), coords_.contiguous(),
@@ -452,10 +483,10 @@ class GeoFormer(nn.Module):
         return outputs
 
     def generate_proposal(self, mask_logits, cls_logits, fg_idxs, batch_offsets, batch_offsets_,
-                          semantic_scores_=None, logit_thresh=0.5, score_thresh=0.5, npoint_thresh=100):
+                          semantic_scores_=None, logit_thresh=0.5, score_thresh=0.5, npoint_thresh=100, sem_prob=None):
         """Batch-1 proposal extraction (geoformer.py:193-262): score = mean mask prob * sqrt(cls prob) *
         mean semantic prob of the predicted class over the mask."""
-        sem = F.softmax(semantic_scores_, dim=1)
+        sem = sem_prob if sem_prob is not None else F.softmax(semantic_scores_, dim=1)
         b = 0
         num_points = int(batch_offsets[b + 1] - batch_offsets[b])
         if mask_logits[b].is_cuda and not torch.is_grad_enabled():
@@ -522,7 +553,9 @@ class GeoFormer(nn.Module):
             mask_features_ = pointops.pointwise_mlp(output_feats_.contiguous(), chain).unsqueeze(2)
         else:
             mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
-        # the kNN graphs need the points only: on the device they run under the host's RNG draw
+        # the kNN graphs need the points only: on the device they run under the host's RNG draw, and so does the
+        # class-probability table the proposal scores read at the very end
+        sem_prob = F.softmax(semantic_scores_, dim=1) if not training else None
         graphs = None
         if locs_float_.is_cuda and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0:
             graphs = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
@@ -531,7 +564,7 @@ class GeoFormer(nn.Module):
         geo_dists = None
         if graphs is not None and not torch.is_grad_enabled() and os.environ.get("GF_OVERLAP", "1") != "0":
             contexts, geo_dists = self._aggregate_geodesic_overlapped(locs_float_, output_feats_, batch_offsets_,
-                                                                      batch_size, graphs, max_step)
+                                                                      batch_size, graphs, max_step, pc_dims)
         else:
             contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
         if contexts is None:
@@ -570,5 +603,6 @@ class GeoFormer(nn.Module):
             outputs["proposal_scores"] = self.generate_proposal(
                 preds[-1]["mask_logits"], preds[-1]["cls_logits"], fg_idxs, batch_offsets, batch_offsets_,
                 semantic_scores_=semantic_scores_, logit_thresh=0.5, score_thresh=cfg.TEST_SCORE_THRESH,
-                npoint_thresh=cfg.TEST_NPOINT_THRESH)
+                npoint_thresh=cfg.TEST_NPOINT_THRESH, sem_prob=sem_prob)
+        self.__dict__.get("_gf_early", {}).clear()
         return outputs
