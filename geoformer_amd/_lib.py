@@ -57,6 +57,8 @@ def _declare(lib):
         "gf_softmax_dim1_bwd": (I, [P, P, I, I, I, F, P, P]),
         "gf_pointwise_mlp": (I, [P, I, I, P, P, P, P, P, P, P]),
         "gf_group_mlp_max": (I, [P, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_ball_query_centres": (I, [P, P, I, I, I, F, I, P, P, P]),
+        "gf_sa_group_mlp_max": (I, [P, P, P, I, I, I, I, F, I, I, I, I, P, P, P, P, P, P, P, P, P]),
         "gf_decoder_token_state_bytes": (c_size_t, [I, I]),
         "gf_decoder_token_stage": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
         "gf_mask_intersections_scratch_bytes": (c_size_t, [I, I]),

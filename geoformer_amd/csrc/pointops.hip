@@ -151,21 +151,25 @@ extern "C" int gf_group_points_grad(const float* grad_out, const int32_t* idx, i
 #define BQ_LD ((BQ_TILE * 3 + BQ_WAVES * 64 - 1) / (BQ_WAVES * 64))
 __global__ __launch_bounds__(BQ_WAVES * 64) void k_ball_query(const float* __restrict__ new_xyz,
                                                                const float* __restrict__ xyz, int n, int m,
-                                                               float radius2, int nsample, int32_t* __restrict__ idx) {
+                                                               float radius2, int nsample, int32_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ centre_idx,
+                                                               float* __restrict__ new_xyz_out) {
     __shared__ __attribute__((aligned(16))) float tile[2][3 * BQ_PLANE];
     __shared__ int s_done[2][BQ_WAVES];
     const int bi = blockIdx.y;
     xyz += (size_t)bi * n * 3;
-    new_xyz += (size_t)bi * m * 3;
     idx += (size_t)bi * m * nsample;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = blockIdx.x * BQ_WAVES + wid;
     const bool valid = j < m;
     float nx = 0.f, ny = 0.f, nz = 0.f;
     if (valid) {
-        nx = new_xyz[j * 3 + 0];
-        ny = new_xyz[j * 3 + 1];
-        nz = new_xyz[j * 3 + 2];
+        // centres given as coordinates, or as indices into xyz (then their coordinates are also written out)
+        const float* c = centre_idx ? xyz + (size_t)centre_idx[(size_t)bi * m + j] * 3 : new_xyz + ((size_t)bi * m + j) * 3;
+        nx = c[0];
+        ny = c[1];
+        nz = c[2];
+        if (centre_idx && lane < 3) new_xyz_out[((size_t)bi * m + j) * 3 + lane] = lane == 0 ? nx : lane == 1 ? ny : nz;
     }
     int cnt = valid ? 0 : nsample;  // invalid waves are "done"
     int first = -1;
@@ -259,8 +263,22 @@ extern "C" int gf_ball_query(const float* new_xyz, const float* xyz, int b, int 
     if (b == 0 || m == 0) return GF_OK;
     const float radius2 = radius * radius;  // fp32 like ball_query_gpu.cu:25
     hipLaunchKernelGGL(k_ball_query, dim3(gf_div_up(m, BQ_WAVES), b), dim3(BQ_WAVES * 64), 0, (hipStream_t)stream,
-                       new_xyz, xyz, n, m, radius2, nsample, idx);
+                       new_xyz, xyz, n, m, radius2, nsample, idx, nullptr, nullptr);
     GF_CHECK_LAUNCH("gf_ball_query");
+    return GF_OK;
+}
+
+// ball query around xyz[centre_idx] (the gather_operation + ball_query pair of PointnetSAModuleVotes with given
+// indices, pointnet2_modules.py:305-312); new_xyz [b,m,3] receives the centre coordinates.
+extern "C" int gf_ball_query_centres(const float* xyz, const int32_t* centre_idx, int b, int n, int m, float radius,
+                                     int nsample, float* new_xyz, int32_t* idx, void* stream) {
+    GF_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, "gf_ball_query_centres: bad sizes");
+    GF_CHECK_ARG(centre_idx && new_xyz, "gf_ball_query_centres: null argument");
+    if (b == 0 || m == 0) return GF_OK;
+    const float radius2 = radius * radius;
+    hipLaunchKernelGGL(k_ball_query, dim3(gf_div_up(m, BQ_WAVES), b), dim3(BQ_WAVES * 64), 0, (hipStream_t)stream,
+                       nullptr, xyz, n, m, radius2, nsample, idx, centre_idx, new_xyz);
+    GF_CHECK_LAUNCH("gf_ball_query_centres");
     return GF_OK;
 }
 

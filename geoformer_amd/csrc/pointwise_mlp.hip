@@ -138,18 +138,25 @@ __device__ __forceinline__ float pm_row_max(float v) {
     return v;
 }
 
-#ifndef GM_MINW
-#define GM_MINW 1
-#endif
-__global__ __launch_bounds__(256, GM_MINW) void k_group_mlp_max(const float* __restrict__ grouped, int B, int np, int ns,
-                                                       PmArgs A, float* __restrict__ out) {
+// GATHER: the grouped tensor is never materialised -- sample `smp` of centre `pt` is point idx[pt][smp], its input
+// channels are the centred (and radius-scaled) coordinates followed by the point's feature column
+// (QueryAndGroup.forward, pointnet2_utils.py:326-356).
+struct PmGather {
+    const float *xyz, *feats, *new_xyz;  // [B,n,3], [B,C,n], [B,np,3]
+    const int32_t* idx;                  // [B,np,ns]
+    int n, C, use_xyz;
+    float inv_radius;  // 1/radius with normalize_xyz (torch divides by a Python scalar as a * (1/b)), else 1
+};
+template <bool GATHER>
+__global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__ grouped, int B, int np, int ns,
+                                                       PmArgs A, PmGather Gx, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const int c0 = A.L[0].cin, cl = A.L[A.nl - 1].cout;
     const size_t cstride = (size_t)np * ns;
     for (int item = wave; item < B * np; item += nwaves) {
         const int b = item / np, pt = item - b * np;
-        const float* gp = grouped + (size_t)b * c0 * cstride + (size_t)pt * ns;
+        const float* gp = GATHER ? nullptr : grouped + (size_t)b * c0 * cstride + (size_t)pt * ns;
         float best[PM_MAXC / 16][4];
 #pragma unroll
         for (int ct = 0; ct < PM_MAXC / 16; ct++)
@@ -159,6 +166,8 @@ __global__ __launch_bounds__(256, GM_MINW) void k_group_mlp_max(const float* __r
             const int smp = s0 + j;
             const bool live = smp < ns;
             float4 h[PM_MAXC / 16];
+            int id = 0;
+            if (GATHER && live) id = Gx.idx[((size_t)b * np + pt) * ns + smp];
 #pragma unroll
             for (int kc = 0; kc < PM_MAXC / 16; kc++) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -166,7 +175,17 @@ __global__ __launch_bounds__(256, GM_MINW) void k_group_mlp_max(const float* __r
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int ch = kc * 16 + 4 * g + i;
-                        if (ch < c0) v[i] = gp[(size_t)ch * cstride + smp];
+                        if (ch < c0) {
+                            if (!GATHER) {
+                                v[i] = gp[(size_t)ch * cstride + smp];
+                            } else if (Gx.use_xyz && ch < 3) {
+                                v[i] = (Gx.xyz[((size_t)b * Gx.n + id) * 3 + ch] -
+                                        Gx.new_xyz[((size_t)b * np + pt) * 3 + ch]) * Gx.inv_radius;
+                            } else {
+                                const int fc = ch - (Gx.use_xyz ? 3 : 0);
+                                v[i] = Gx.feats[((size_t)b * Gx.C + fc) * Gx.n + id];
+                            }
+                        }
                     }
                 }
                 h[kc] = make_float4(v[0], v[1], v[2], v[3]);
@@ -234,29 +253,66 @@ __global__ __launch_bounds__(256, GM_MINW) void k_group_mlp_max(const float* __r
     }
 }
 
-extern "C" int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsample, int n_layers,
-                                const float* const* W, const float* const* scale, const float* const* shift,
-                                const int* channels, const int* relu, float* out, void* stream) {
-    GF_CHECK_ARG(n_layers >= 1 && n_layers <= PM_MAXL, "gf_group_mlp_max: 1..%d layers, got %d", PM_MAXL, n_layers);
-    GF_CHECK_ARG(B >= 0 && npoint >= 0 && nsample >= 1, "gf_group_mlp_max: bad sizes");
-    PmArgs A;
+static int pm_fill_args(const char* who, int n_layers, const float* const* W, const float* const* scale,
+                        const float* const* shift, const int* channels, const int* relu, PmArgs& A) {
+    GF_CHECK_ARG(n_layers >= 1 && n_layers <= PM_MAXL, "%s: 1..%d layers, got %d", who, PM_MAXL, n_layers);
     for (int l = 0; l < n_layers; l++) {
         const int cin = channels[l], cout = channels[l + 1];
         GF_CHECK_ARG(cin >= 1 && cin <= PM_MAXC && (l == 0 || cin % 16 == 0) && cout >= 1 && cout <= PM_MAXC &&
                          (l == n_layers - 1 || cout % 16 == 0),
-                     "gf_group_mlp_max: layer %d widths %d -> %d (hidden widths: multiples of 16, all <= %d)", l, cin,
-                     cout, PM_MAXC);
-        GF_CHECK_ARG(W[l] && scale[l] && shift[l], "gf_group_mlp_max: null parameter of layer %d", l);
+                     "%s: layer %d widths %d -> %d (hidden widths: multiples of 16, all <= %d)", who, l, cin, cout,
+                     PM_MAXC);
+        GF_CHECK_ARG(W[l] && scale[l] && shift[l], "%s: null parameter of layer %d", who, l);
         A.L[l] = {W[l], scale[l], shift[l], cin, cout, relu[l]};
     }
     for (int l = n_layers; l < PM_MAXL; l++) A.L[l] = A.L[0];
     A.nl = n_layers;
+    return GF_OK;
+}
+
+extern "C" int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsample, int n_layers,
+                                const float* const* W, const float* const* scale, const float* const* shift,
+                                const int* channels, const int* relu, float* out, void* stream) {
+    GF_CHECK_ARG(B >= 0 && npoint >= 0 && nsample >= 1, "gf_group_mlp_max: bad sizes");
+    PmArgs A;
+    if (int rc = pm_fill_args("gf_group_mlp_max", n_layers, W, scale, shift, channels, relu, A)) return rc;
     if (B == 0 || npoint == 0) return GF_OK;
     long long items = (long long)B * npoint;
     int blocks = (int)((items + 3) / 4);
     if (blocks > 256 * 4) blocks = 256 * 4;
-    hipLaunchKernelGGL(k_group_mlp_max, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grouped, B, npoint, nsample, A,
-                       out);
+    hipLaunchKernelGGL(k_group_mlp_max<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grouped, B, npoint,
+                       nsample, A, PmGather{}, out);
     GF_CHECK_LAUNCH("gf_group_mlp_max");
+    return GF_OK;
+}
+
+// The set-abstraction stage of the eval forward in two launches (PointnetSAModuleVotes with given sample indices,
+// pointnet2_modules.py:262-333): ball query around xyz[inds] (which also writes new_xyz), then the shared MLP + max
+// pool reading the neighbours through idx.  Replaces gather, ball query, two groupings, centring, scaling, the
+// concatenation and the [B, 3+C, np, ns] tensor they produce.
+extern "C" int gf_ball_query_centres(const float* xyz, const int32_t* centre_idx, int b, int n, int m, float radius,
+                                     int nsample, float* new_xyz, int32_t* idx, void* stream);
+extern "C" int gf_sa_group_mlp_max(const float* xyz, const float* feats, const int32_t* inds, int B, int n, int C,
+                                   int npoint, float radius, int nsample, int use_xyz, int normalize_xyz,
+                                   int n_layers, const float* const* W, const float* const* scale,
+                                   const float* const* shift, const int* channels, const int* relu, float* new_xyz,
+                                   int32_t* idx, float* out, void* stream) {
+    GF_CHECK_ARG(xyz && inds && new_xyz && idx && out && (feats || C == 0), "gf_sa_group_mlp_max: null argument");
+    GF_CHECK_ARG(B >= 0 && n >= 1 && C >= 0 && npoint >= 0 && nsample >= 1 && radius > 0.f,
+                 "gf_sa_group_mlp_max: bad sizes");
+    GF_CHECK_ARG(use_xyz || C > 0, "gf_sa_group_mlp_max: no input channels");
+    PmArgs A;
+    if (int rc = pm_fill_args("gf_sa_group_mlp_max", n_layers, W, scale, shift, channels, relu, A)) return rc;
+    GF_CHECK_ARG(channels[0] == C + (use_xyz ? 3 : 0), "gf_sa_group_mlp_max: first layer expects %d channels, got %d",
+                 channels[0], C + (use_xyz ? 3 : 0));
+    if (B == 0 || npoint == 0) return GF_OK;
+    if (int rc = gf_ball_query_centres(xyz, inds, B, n, npoint, radius, nsample, new_xyz, idx, stream)) return rc;
+    PmGather Gx{xyz, feats, new_xyz, idx, n, C, use_xyz, normalize_xyz ? 1.0f / radius : 1.0f};
+    long long items = (long long)B * npoint;
+    int blocks = (int)((items + 3) / 4);
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    hipLaunchKernelGGL(k_group_mlp_max<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, B, npoint,
+                       nsample, A, Gx, out);
+    GF_CHECK_LAUNCH("gf_sa_group_mlp_max");
     return GF_OK;
 }

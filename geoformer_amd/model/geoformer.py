@@ -321,12 +321,18 @@ class GeoFormer(nn.Module):
             idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
             staged.append((xyz_b, feat_b, idx))
         self.__dict__["_gf_pending_side"] = side
+        cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
+        fused = [self.set_aggregator.fused_forward(xyz_b, feat_b, idx) for xyz_b, feat_b, idx in staged]
+        if all(f is not None for f in fused):
+            context_locs, pre_enc_inds = cat([f[0] for f in fused]), cat([st[2] for st in staged])
+            context_feats = cat([f[1] for f in fused]).transpose(1, 2)
+            return (context_locs, context_feats, pre_enc_inds), geo
         locs, gfeat, gxyz, inds = [], [], [], []
         for xyz_b, feat_b, idx in staged:
             l, gf, gx, idx = self.set_aggregator.group_points(xyz_b, feat_b, inds=idx)
             locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
-        context_locs, pre_enc_inds = torch.cat(locs), torch.cat(inds)
-        context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
+        context_locs, pre_enc_inds = cat(locs), cat(inds)
+        context_feats = self.set_aggregator.mlp(cat(gfeat), cat(gxyz)).transpose(1, 2)
         return (context_locs, context_feats, pre_enc_inds), geo
 
     def _side_epilogue(self, b, batch_size, g, xyz_b, src, pc_dims, main):

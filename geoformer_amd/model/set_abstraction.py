@@ -167,6 +167,20 @@ class PointnetSAModuleVotesSeparate(nn.Module):
             self.__dict__["_gf_chain"] = hit
         return hit[1]
 
+    def fused_forward(self, xyz, features, inds):
+        """(new_xyz, pooled features [B,C,npoint]) of the whole stage in two launches -- inference with max pooling on
+        the GPU and given sample indices; None when that path does not apply (the caller then uses group_points + mlp)."""
+        if self.pooling != "max" or not xyz.is_cuda or torch.is_grad_enabled() or inds is None:
+            return None
+        chain = self._fused_chain()
+        if chain is None:
+            return None
+        from .. import pointops
+
+        new_xyz, _, pooled = pointops.sa_group_mlp_max(xyz.contiguous(), features.contiguous(), inds.contiguous(),
+                                                       self.radius, self.nsample, self.use_xyz, self.normalize_xyz, chain)
+        return new_xyz, pooled
+
     def mlp(self, grouped_features, grouped_xyz, pooling=None):
         pooling = pooling or self.pooling
         if pooling == "max" and grouped_features.is_cuda and not torch.is_grad_enabled():

@@ -259,6 +259,27 @@ def group_mlp_max(grouped, chain):
     return out
 
 
+def sa_group_mlp_max(xyz, feats, inds, radius, nsample, use_xyz, normalize_xyz, chain):
+    """Set-abstraction stage for given sample indices, fused: returns (new_xyz [B,np,3], idx [B,np,ns] int32,
+    pooled [B,C_last,np]).  xyz [B,n,3], feats [B,C,n] (or None), inds int32 [B,np]."""
+    _f32c(xyz, "xyz"); _i32c(inds, "inds")
+    B, n, _ = xyz.shape
+    C = 0
+    if feats is not None:
+        _f32c(feats, "feats")
+        C = feats.shape[1]
+    npnt = inds.shape[1]
+    dev = xyz.device
+    new_xyz = torch.empty((B, npnt, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, npnt, nsample), dtype=torch.int32, device=dev)
+    out = torch.empty((B, chain.channels[-1], npnt), dtype=torch.float32, device=dev)
+    check(_lib.load().gf_sa_group_mlp_max(ptr(xyz), ptr(feats) if feats is not None else None, ptr(inds), B, n, C, npnt,
+                                          float(radius), int(nsample), int(bool(use_xyz)), int(bool(normalize_xyz)),
+                                          chain.n, chain.W, chain.scale, chain.shift, chain.ch, chain.relu,
+                                          ptr(new_xyz), ptr(idx), ptr(out), stream_ptr()), "gf_sa_group_mlp_max")
+    return new_xyz, idx, out
+
+
 def decoder_stage_tables(layer, final_norm):
     """(post, pre) device-pointer tables of one decoder layer for gf_decoder_token_stage (header order)."""
     import ctypes

@@ -245,6 +245,21 @@ int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsample, int n
                      const float* const* scale, const float* const* shift, const int* channels, const int* relu,
                      float* out, void* stream);
 
+/* The whole set-abstraction stage for given sample indices in two launches (PointnetSAModuleVotes.forward with
+ * inds, lib/pointnet2/pointnet2_modules.py:305-349; QueryAndGroup, pointnet2_utils.py:326-356):
+ *   new_xyz[b,i] = xyz[b, inds[b,i]];  idx = ball_query(radius, nsample, xyz, new_xyz);
+ *   input channels of sample s of centre i: (xyz[idx] - new_xyz[i]) (* 1/radius with normalize_xyz) if use_xyz,
+ *   then feats[:, idx];  out[b,:,i] = max_s MLP(...)   -- without materialising the grouped tensor.
+ *   xyz fp32 [B,n,3], feats fp32 [B,C,n], inds int32 [B,npoint]; outputs new_xyz fp32 [B,npoint,3],
+ *   idx int32 [B,npoint,nsample] (the ball-query result), out fp32 [B,channels[n_layers],npoint];
+ *   channels[0] must equal C + 3*use_xyz. */
+int gf_ball_query_centres(const float* xyz, const int32_t* centre_idx, int b, int n, int m, float radius, int nsample,
+                          float* new_xyz, int32_t* idx, void* stream);
+int gf_sa_group_mlp_max(const float* xyz, const float* feats, const int32_t* inds, int B, int n, int C, int npoint,
+                        float radius, int nsample, int use_xyz, int normalize_xyz, int n_layers,
+                        const float* const* W, const float* const* scale, const float* const* shift,
+                        const int* channels, const int* relu, float* new_xyz, int32_t* idx, float* out, void* stream);
+
 /* Soft-max over the middle dimension of x[n0,n1,inner] (training path of the decoder's vector cross-attention,
  * model/transformer_detr.py:449: F.softmax(sim / sqrt(d), dim=1) on [nq,nc,B,d]):
  *   y = softmax_{n1}(scale * x);   gx = scale * y * (gy - sum_{n1} gy * y). */

@@ -235,6 +235,41 @@ def test_group_mlp_max_fused(hip, B, npnt, ns, dims):
     assert (out.cpu() - ref).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
 
 
+@pytest.mark.parametrize("B,n,npnt,ns,C", [(1, 6000, 256, 32, 16), (2, 3000, 77, 16, 29)])
+def test_sa_stage_fused(hip, oracle, B, n, npnt, ns, C):
+    """gf_sa_group_mlp_max (gather + ball query + grouping + SharedMLP + max in two launches) vs the module's
+    separate operators: centre coordinates and ball-query indices bit-exact, pooled features within 1e-4 of the
+    PyTorch modules on the CPU fed by the oracle's ball query / grouping."""
+    from geoformer_amd import pointops
+    from geoformer_amd.model.set_abstraction import PointnetSAModuleVotesSeparate
+
+    torch.manual_seed(n)
+    sa = PointnetSAModuleVotesSeparate(radius=0.2, nsample=ns, npoint=npnt, mlp=[C, 32, 32, 48], normalize_xyz=True)
+    for m in sa.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(); m.running_var.uniform_(0.5, 2); m.weight.data.normal_(1, 0.2); m.bias.data.normal_()
+    sa.eval()
+    xyz = torch.rand(B, n, 3) * torch.tensor([2.0, 2.0, 0.5])
+    feats = torch.randn(B, C, n)
+    inds = torch.stack([torch.randperm(n)[:npnt] for _ in range(B)]).int()
+    # CPU reference: oracle operators + the PyTorch modules
+    new_xyz_ref = torch.stack([xyz[b, inds[b].long()] for b in range(B)])
+    idx_ref = oracle.ball_query(new_xyz_ref.numpy(), xyz.numpy(), 0.2, ns)
+    gx = torch.from_numpy(oracle.group_points(xyz.transpose(1, 2).contiguous().numpy(), idx_ref))
+    gx = (gx - new_xyz_ref.transpose(1, 2).unsqueeze(-1)) / 0.2
+    gf = torch.from_numpy(oracle.group_points(feats.numpy(), idx_ref))
+    with torch.no_grad():
+        ref = sa.mlp(torch.cat([gx, gf], dim=1), None)
+        sa.cuda()
+        chain = sa._fused_chain()
+        new_xyz, idx, pooled = pointops.sa_group_mlp_max(xyz.cuda(), feats.cuda(), inds.cuda(), 0.2, ns, True, True, chain)
+        got = sa.fused_forward(xyz.cuda(), feats.cuda(), inds.cuda())
+    assert (new_xyz.cpu() == new_xyz_ref).all()
+    assert (idx.cpu().numpy() == idx_ref).all()
+    assert (pooled.cpu() - ref).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
+    assert torch.equal(got[0], new_xyz) and torch.equal(got[1], pooled)
+
+
 def test_matrix_nms_gpu(hip, oracle):
     """Bit-packed intersection kernel vs the oracle (exact), and the GPU matrix NMS vs the reference golden."""
     import os
