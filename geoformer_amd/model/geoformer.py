@@ -315,11 +315,13 @@ class GeoFormer(nn.Module):
                 g.record_stream(main)
                 src.record_stream(side)
                 geo.append(g)
+            # the rest of the sampling is on the critical path: issue it before anything else
+            idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+            staged.append((xyz_b, feat_b, idx))
+            with torch.cuda.stream(side):
                 # small launches that only need the distances / the query picks ride in the BFS's shadow instead of
                 # sitting between the decoder and the mask head on the main stream
                 self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main)
-            idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
-            staged.append((xyz_b, feat_b, idx))
         self.__dict__["_gf_pending_side"] = side
         cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
         fused = [self.set_aggregator.fused_forward(xyz_b, feat_b, idx) for xyz_b, feat_b, idx in staged]
