@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 from ._build import LIB_PATH
 
@@ -66,6 +66,7 @@ def _declare(lib):
         "gf_voxelize_idx_scratch_bytes": (c_size_t, [I]),
         "gf_voxelize_idx_count": (I, [P, I, I, I, P, P, P, P]),
         "gf_voxelize_idx_fill": (I, [P, I, I, I, P, P, I, I, P, P, P]),
+        "gf_host_legacy_choice": (I, [P, P, c_longlong, c_longlong, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),

@@ -1,0 +1,102 @@
+// Host-side helper (no device code): numpy's legacy sampling draw, bit for bit, at half the host time.
+//
+//   reference: geoformer.py:575-577 draws `np.random.choice(n_b, npoint, replace=False)` once per scene.  With the
+//   legacy global generator that is `permutation(n_b)[:npoint]`: arange(n) shuffled by Fisher-Yates from the top,
+//   `j = random_interval(i)` = 32-bit MT19937 outputs masked to the bit length of i and rejected while > i
+//   (numpy/random/mtrand.pyx: RandomState.choice / permutation / _shuffle_raw; _legacy/legacy-distributions +
+//   src/mt19937/mt19937.c for the generator).  The forward cannot start sampling before this draw and the device
+//   idles meanwhile (0.43 ms for 60k points), so it is worth restating natively:
+//     * the generator advances a whole 624-word block at a time and tempers it in one vectorisable pass;
+//     * rejection is branch-free (the candidate is stored every time, the index only moves on acceptance) --
+//       numpy's loop mispredicts on every fourth draw;
+//     * the swap indices are known before the swaps start, so the swap pass prefetches its targets.
+//   The caller moves the generator state in and out (np.random.get_state / set_state), so the stream of random
+//   numbers stays the one the reference consumes.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+constexpr int MT_N = 624, MT_M = 397;
+
+inline void mt_advance(uint32_t* key) {
+    constexpr uint32_t A = 0x9908b0dfu, UP = 0x80000000u, LO = 0x7fffffffu;
+    int i = 0;
+    for (; i < MT_N - MT_M; i++) {
+        const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+        key[i] = key[i + MT_M] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    for (; i < MT_N - 1; i++) {
+        const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+        key[i] = key[i + (MT_M - MT_N)] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+    }
+    const uint32_t y = (key[MT_N - 1] & UP) | (key[0] & LO);
+    key[MT_N - 1] = key[MT_M - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
+}
+
+inline void mt_temper_block(const uint32_t* __restrict__ key, uint32_t* __restrict__ out) {
+    for (int i = 0; i < MT_N; i++) {
+        uint32_t y = key[i];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        out[i] = y;
+    }
+}
+}  // namespace
+
+// key[624], *pos: numpy's MT19937 state (pos == 624: the block is used up).  out[k] = permutation(n)[:k].
+extern "C" int gf_host_legacy_choice(uint32_t* key, int32_t* pos_io, long long n, long long k, long long* out) {
+    GF_CHECK_ARG(key && pos_io && out, "gf_host_legacy_choice: null argument");
+    GF_CHECK_ARG(n >= 1 && n <= 0x7fffffffLL && k >= 0 && k <= n, "gf_host_legacy_choice: n=%lld k=%lld", n, k);
+    GF_CHECK_ARG(*pos_io >= 0 && *pos_io <= MT_N, "gf_host_legacy_choice: generator position %d", (int)*pos_io);
+    int pos = *pos_io;
+    uint32_t block[MT_N];
+    if (pos < MT_N) mt_temper_block(key, block);
+    uint32_t* J = (uint32_t*)malloc((size_t)(n + 1) * sizeof(uint32_t));
+    uint32_t* x = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));  // 32-bit working set: half the cache footprint
+    if (!J || !x) {
+        free(J);
+        free(x);
+        gf_set_error("gf_host_legacy_choice: out of memory");
+        return GF_ERR_LAUNCH;
+    }
+    // pass 1: the swap partner of every position, top down
+    uint32_t i = (uint32_t)(n - 1);
+    while (i >= 1) {
+        uint32_t mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        const uint32_t lo = (mask >> 1) + 1;  // the mask serves positions lo..mask
+        while (i >= lo) {
+            if (pos == MT_N) {
+                mt_advance(key);
+                mt_temper_block(key, block);
+                pos = 0;
+            }
+            int t = pos;
+            for (; t < MT_N && i >= lo; t++) {
+                const uint32_t v = block[t] & mask;
+                J[i] = v;
+                i -= (v <= i);
+            }
+            pos = t;
+        }
+    }
+    // pass 2: the swaps
+    for (long long t = 0; t < n; t++) x[t] = (uint32_t)t;
+    for (long long p = n - 1; p >= 1; p--) {
+        if (p >= 24) __builtin_prefetch(&x[J[p - 24]], 1, 1);
+        const uint32_t j = J[p];
+        const uint32_t tmp = x[j];
+        x[j] = x[p];
+        x[p] = tmp;
+    }
+    for (long long t = 0; t < k; t++) out[t] = (long long)x[t];
+    free(J);
+    free(x);
+    *pos_io = pos;
+    return GF_OK;
+}

@@ -264,8 +264,9 @@ class GeoFormer(nn.Module):
                 npoint = min(n_b, self.cfg.n_downsampling)
                 # host RNG, consumed exactly like the reference (geoformer.py:575-577): a random
                 # permutation (and truncation) of the scene's foreground points
-                sampling_indices = torch.tensor(np.random.choice(n_b, npoint, replace=False), dtype=torch.long,
-                                                device=locs_float_.device)
+                draw = pointops.legacy_choice(n_b, npoint) if locs_float_.is_cuda else \
+                    np.random.choice(n_b, npoint, replace=False)
+                sampling_indices = torch.tensor(draw, dtype=torch.long, device=locs_float_.device)
                 self.last_sampling_indices = sampling_indices
                 xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0)
                 feat_b = output_feats_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0)
@@ -301,7 +302,8 @@ class GeoFormer(nn.Module):
             if n_b == 0:
                 return None, None
             npoint = min(n_b, self.cfg.n_downsampling)
-            sampling_indices = torch.tensor(np.random.choice(n_b, npoint, replace=False), dtype=torch.long,
+            # the reference's host draw (same values, same generator state), restated natively: the device idles on it
+            sampling_indices = torch.tensor(pointops.legacy_choice(n_b, npoint), dtype=torch.long,
                                             device=locs_float_.device)
             self.last_sampling_indices = sampling_indices
             xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()

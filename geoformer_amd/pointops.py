@@ -135,6 +135,26 @@ def furthest_point_sampling(xyz, m, known=None):
     return idx
 
 
+def legacy_choice(n, k):
+    """``np.random.choice(n, k, replace=False)`` on numpy's global legacy generator -- same values, same generator
+    state afterwards -- through the native restatement (csrc/host_draw.hip; about half the host time)."""
+    import ctypes
+
+    import numpy as np
+
+    n, k = int(n), int(k)
+    st = np.random.get_state()
+    if st[0] != "MT19937" or not (1 <= k <= n <= 0x7fffffff):
+        return np.random.choice(n, k, replace=False)  # numpy's own argument errors / exotic sizes
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    out = np.empty(k, dtype=np.int64)
+    check(_lib.load().gf_host_legacy_choice(key.ctypes.data, ctypes.addressof(pos), n, k, out.ctypes.data),
+          "gf_host_legacy_choice")
+    np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    return out
+
+
 # ---- geodesic stage --------------------------------------------------------------------
 def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False):
     """Radius-limited kNN graph of one scene.  Returns D [n,k] fp32, I [n,k] int32, deg [n] int32."""

@@ -38,6 +38,14 @@ int gf_abi_version(void);
 const char* gf_last_error(void);
 
 /* ===================================================================================
+ * Host helper (CPU code, no launch): the reference's per-scene sampling draw
+ * np.random.choice(n, k, replace=False) (geoformer.py:575-577) on numpy's legacy MT19937 state, bit for bit.
+ *   key uint32[624], *pos: the state as np.random.get_state() returns it (updated in place, hand it back with
+ *   set_state);  out int64[k] = permutation(n)[:k].
+ * =================================================================================== */
+int gf_host_legacy_choice(uint32_t* key, int32_t* pos, long long n, long long k, long long* out);
+
+/* ===================================================================================
  * Sparse convolution (stands in for spconv.ops.get_indice_pairs / indice_conv /
  * indice_subm_conv / indice_inverse_conv, reached from geoformer.py:42-53 and
  * geoformer_modules.py:15-35,63-105 through SubMConv3d / SparseConv3d /
