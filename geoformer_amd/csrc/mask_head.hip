@@ -69,40 +69,52 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
         mq[t] = USE_GEO ? mx[q] : 0.f;
     }
 
-    for (int blk = blk0; blk < blk1; blk++) {
-        const int p0 = blk * 64;
-        // operands of the four 16-point tiles: features (B operand) and coordinates of column j
+    // Operands of one 64-point block: features (B operand) and coordinates of column j for the four 16-point tiles,
+    // and the block's geodesic distances for this wave's queries.  Everything a block needs is requested in one go,
+    // one block ahead of the arithmetic (a load inside the per-tile code would expose one HBM round trip per tile
+    // and query: the first version of this loop spent most of its time there).
+    struct Block {
         float4 f[4];
         float px[4], py[4], pz[4];
+        float gd[MH_Q][4];
+    };
+    auto fetch = [&](int blk, Block& B) {
+        const int p0 = blk * 64;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int p = p0 + 16 * t + j;
-            const int pc = min(p, N - 1);
-            f[t] = *reinterpret_cast<const float4*>(feat + (size_t)pc * 16 + 4 * g);
-            px[t] = coords[(size_t)pc * 3 + 0];
-            py[t] = coords[(size_t)pc * 3 + 1];
-            pz[t] = coords[(size_t)pc * 3 + 2];
+            const int pc = min(p0 + 16 * t + j, N - 1);
+            B.f[t] = *reinterpret_cast<const float4*>(feat + (size_t)pc * 16 + 4 * g);
+            B.px[t] = coords[(size_t)pc * 3 + 0];
+            B.py[t] = coords[(size_t)pc * 3 + 1];
+            B.pz[t] = coords[(size_t)pc * 3 + 2];
+#pragma unroll
+            for (int u = 0; u < MH_Q; u++)
+                B.gd[u][t] = USE_GEO ? geo[(size_t)min(qg * MH_Q + u, nq - 1) * N + pc] : 0.f;
         }
+    };
+    Block cur, nxt;
+    if (blk0 < blk1) fetch(blk0, cur);
+    for (int blk = blk0; blk < blk1; blk++) {
+        const int p0 = blk * 64;
+        if (blk + 1 < blk1) fetch(blk + 1, nxt);
 #pragma unroll
         for (int t = 0; t < MH_Q; t++) {
             const int q = qg * MH_Q + t;
             float part[4];
 #pragma unroll
             for (int tl = 0; tl < 4; tl++) {
-                const int p = p0 + 16 * tl + j;
                 f32x4 acc = (f32x4){bb[t][0], bb[t][1], bb[t][2], bb[t][3]};
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][0], f[tl].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][1], f[tl].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][2], f[tl].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][3], f[tl].w, acc, 0, 0, 0);
-                float rx = qx[t] - px[tl], ry = qy[t] - py[tl], rz = qz[t] - pz[tl];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][0], cur.f[tl].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][1], cur.f[tl].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][2], cur.f[tl].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][3], cur.f[tl].w, acc, 0, 0, 0);
+                float rx = qx[t] - cur.px[tl], ry = qy[t] - cur.py[tl], rz = qz[t] - cur.pz[tl];
                 if (USE_GEO) {
-                    const float gd = (p < N && q < nq) ? geo[(size_t)q * N + p] : 0.f;
-                    if (gd < 0.f) {
-                        rx = rx + mq[t] * (float)((rx > 0.f) - (rx < 0.f));
-                        ry = ry + mq[t] * (float)((ry > 0.f) - (ry < 0.f));
-                        rz = rz + mq[t] * (float)((rz > 0.f) - (rz < 0.f));
-                    }
+                    // unreachable point: rel += sqrt(max_geo_q) * sign(rel), sign(0) = 0  (branch-free)
+                    const float m = cur.gd[t][tl] < 0.f ? mq[t] : 0.f;
+                    rx = rx + m * (rx > 0.f ? 1.f : (rx < 0.f ? -1.f : 0.f));
+                    ry = ry + m * (ry > 0.f ? 1.f : (ry < 0.f ? -1.f : 0.f));
+                    rz = rz + m * (rz > 0.f ? 1.f : (rz < 0.f ? -1.f : 0.f));
                 }
                 float s = 0.f;
 #pragma unroll
@@ -131,6 +143,7 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
                 if (p < N && q < nq) out[(size_t)q * N + p] = tot;
             }
         }
+        cur = nxt;
     }
 }
 
