@@ -55,13 +55,18 @@ class ResidualBlock(SparseModule):
         """Packed weights and folded BatchNorm of the block, rebuilt when any of them changes (one combined key)."""
         from .. import sparse
 
-        bn0, _, conv0, bn1, _, conv1 = list(self.conv_branch._modules.values())
-        ib = self.i_branch[0]
-        wi = None if isinstance(ib, nn.Identity) else ib.weight
-        key = (conv0.weight._version, conv1.weight._version, bn0.weight._version, bn0.bias._version,
-               bn0.running_mean._version, bn0.running_var._version, bn1.weight._version, bn1.bias._version,
-               bn1.running_mean._version, bn1.running_var._version, conv0.weight.data_ptr(),
-               -1 if wi is None else wi._version)
+        # the tensors the derived copies depend on, looked up once (attribute access on a Module goes through
+        # __getattr__; 26 blocks x a dozen lookups per forward is measurable in the launch-bound U-Net)
+        cached = self.__dict__.get("_gf_block_t")
+        if cached is None or cached[1]._parameters["weight"] is not cached[0][0]:
+            bn0, _, conv0, bn1, _, conv1 = list(self.conv_branch._modules.values())
+            ib = self.i_branch[0]
+            wi = None if isinstance(ib, nn.Identity) else ib.weight
+            tensors = [conv0.weight, conv1.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var, bn1.weight,
+                       bn1.bias, bn1.running_mean, bn1.running_var] + ([] if wi is None else [wi])
+            cached = self.__dict__["_gf_block_t"] = (tensors, conv0, (bn0, conv0, bn1, conv1, ib, wi))
+        tensors, _, (bn0, conv0, bn1, conv1, ib, wi) = cached
+        key = (tensors[0].data_ptr(), [t._version for t in tensors])
         hit = self.__dict__.get("_gf_block")
         if hit is None or hit[0] != key:
             s0, t0 = bn_affine(bn0)

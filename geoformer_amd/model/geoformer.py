@@ -180,8 +180,8 @@ class GeoFormer(nn.Module):
 
         sparse._PACK_CACHE.clear()
         for mod in self.modules():
-            for key in ("_gf_chains", "_gf_block", "_gf_affine", "_gf_chain", "_gf_tr_params", "_gf_fused",
-                        "_wpack_key", "_wpack"):
+            for key in ("_gf_chains", "_gf_chain_walks", "_gf_block", "_gf_block_t", "_gf_affine", "_gf_chain",
+                        "_gf_chain_walk", "_gf_tr_params", "_gf_fused", "_gf_fused_params", "_wpack_key", "_wpack"):
                 mod.__dict__.pop(key, None)
 
     def _grad_ctx(self, name):
@@ -195,11 +195,20 @@ class GeoFormer(nn.Module):
         (csrc/pointwise_mlp.hip); None when the PyTorch modules have to run (training, CPU, odd widths)."""
         if torch.is_grad_enabled() or not x.is_cuda or x.shape[0] == 0:
             return None
-        flat = [m for top in mods for _, m in top.named_modules(remove_duplicate=False) if len(list(m.children())) == 0]
-        if any(m.training for m in flat if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)):
+        # the walk over the module tree is done once per stack (this runs in launch-bound stretches of the forward);
+        # per call only the cheap part: BatchNorm modes and the parameters' version counters
+        walks = self.__dict__.setdefault("_gf_chain_walks", {})
+        walk = walks.get(name)
+        if walk is None or any(a is not b for a, b in zip(walk[0], mods)):
+            flat = [m for top in mods for _, m in top.named_modules(remove_duplicate=False)
+                    if len(list(m.children())) == 0]
+            walk = walks[name] = (list(mods), flat,
+                                  [m for m in flat if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)],
+                                  [p for m in flat for p in list(m.parameters()) + list(m.buffers())])
+        _, flat, bns, params = walk
+        if any(m.training for m in bns):
             return None
-        params = [p for m in flat for p in list(m.parameters()) + list(m.buffers())]
-        key = (params[0].data_ptr(), sum(p._version for p in params))
+        key = (params[0].data_ptr(), sum([p._version for p in params]))
         cache = self.__dict__.setdefault("_gf_chains", {})
         hit = cache.get(name)
         if hit is None or hit[0] != key:

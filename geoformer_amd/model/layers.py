@@ -420,9 +420,11 @@ def _decoder_fused_cache(dec):
     cross-attentions, packed pair weights; rebuilt when a parameter is replaced or updated in place."""
     from .. import pointops
 
-    params = list(dec.parameters())
-    key = (params[0].data_ptr(), sum(p._version for p in params))
-    hit = getattr(dec, "_gf_fused", None)
+    params = dec.__dict__.get("_gf_fused_params")
+    if params is None:
+        params = dec.__dict__["_gf_fused_params"] = list(dec.parameters())
+    key = (params[0].data_ptr(), sum([p._version for p in params]))
+    hit = dec.__dict__.get("_gf_fused")
     if hit is not None and hit["key"] == key:
         return hit
     with torch.no_grad():
@@ -436,7 +438,7 @@ def _decoder_fused_cache(dec):
                                                l.v_mlp[0].weight.detach().contiguous()) for l in dec.layers]
         b2 = [l.attn_mlp[2].bias.detach().contiguous() for l in dec.layers]
     hit = {"key": key, "tables": tables, "wt": wt, "bs": bs, "packs": packs, "b2": b2}
-    dec._gf_fused = hit
+    dec.__dict__["_gf_fused"] = hit
     return hit
 
 

@@ -152,15 +152,19 @@ class PointnetSAModuleVotesSeparate(nn.Module):
         """Folded Conv2d(1x1)+BN+ReLU stack for the fused inference kernel (csrc/pointwise_mlp.hip), cached."""
         from .. import pointops
 
-        flat = [m for _, m in self.mlp_module.named_modules(remove_duplicate=False) if len(list(m.children())) == 0]
-        if any(m.training for m in flat if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)):
+        walk = self.__dict__.get("_gf_chain_walk")
+        if walk is None:  # the module tree is walked once; per call only BatchNorm modes and version counters
+            flat = [m for _, m in self.mlp_module.named_modules(remove_duplicate=False) if len(list(m.children())) == 0]
+            convs = [m for m in flat if isinstance(m, nn.Conv2d)]
+            ok = (1 <= len(convs) <= 4) and not any(m.kernel_size != (1, 1) or m.groups != 1 for m in convs) and \
+                not any(m.out_channels % 16 or m.out_channels > 64 for m in convs) and convs[0].in_channels <= 64
+            walk = self.__dict__["_gf_chain_walk"] = (
+                flat, [m for m in flat if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)],
+                [p for m in flat for p in list(m.parameters()) + list(m.buffers())], ok)
+        flat, bns, params, ok = walk
+        if not ok or any(m.training for m in bns):
             return None
-        convs = [m for m in flat if isinstance(m, nn.Conv2d)]
-        if not (1 <= len(convs) <= 4) or any(m.kernel_size != (1, 1) or m.groups != 1 for m in convs) or \
-                any(m.out_channels % 16 or m.out_channels > 64 for m in convs) or convs[0].in_channels > 64:
-            return None
-        params = [p for m in flat for p in list(m.parameters()) + list(m.buffers())]
-        key = (params[0].data_ptr(), sum(p._version for p in params))
+        key = (params[0].data_ptr(), sum([p._version for p in params]))
         hit = self.__dict__.get("_gf_chain")
         if hit is None or hit[0] != key:
             hit = (key, pointops.PointwiseChain(flat))
