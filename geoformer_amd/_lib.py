@@ -31,6 +31,8 @@ def _declare(lib):
         "gf_index_build": (I, [P, I, P, I, I, I, I, P, P, P, P, P]),
         "gf_rules_subm3": (I, [P, I, P, I, I, I, P, P, P, P, I, P, P]),
         "gf_rules_down2": (I, [P, I, P, I, I, I, I, P, P, P, P, P, P, I, P, P, P, I, P, P, P]),
+        "gf_rules_down2_chain_plan": (I, [I, I, I, I, I, I, P, P, P, P, P]),
+        "gf_rules_down2_chain": (I, [P, I, I, I, I, I, I, P, P, P]),
         "gf_conv_packed_floats": (c_size_t, [I, I, I]),
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P]),

@@ -40,14 +40,39 @@ extern "C" size_t gf_index_words(int B, int X, int Y, int Z) {
 static size_t scan_blocks(size_t words) { return (words + SCAN_WPB - 1) / SCAN_WPB; }
 extern "C" size_t gf_index_scratch_bytes(size_t words) { return (2 * scan_blocks(words) + 64) * sizeof(int32_t); }
 
+// Set bit `lin` of a bitmap from every active lane of a wave.  Rows arrive in a spatially coherent order, so
+// neighbouring lanes mostly hit the same 32-bit word (a z-run of cells, or the eight children of one coarse voxel):
+// the bits of each run of equal word indices are OR-ed together across the lanes and only the last lane of a run
+// issues the atomic -- a wave-wide atomic whose lanes share an address is serialised lane by lane otherwise
+// (k_down_bits on 142k voxels: 32 us before).  Lanes without work pass valid = false.
+__device__ __forceinline__ void bitmap_set_coalesced(uint32_t* __restrict__ bitmap, unsigned long long lin, bool valid) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long word = valid ? (lin >> 5) : ~0ull;
+    uint32_t bits = valid ? (1u << (lin & 31)) : 0u;
+    const unsigned lo = (unsigned)word, hi = (unsigned)(word >> 32);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned plo = __shfl_up(lo, d, 64), phi = __shfl_up(hi, d, 64);
+        const uint32_t pb = __shfl_up(bits, d, 64);
+        // inside a run of equal words the partial ORs double their reach each step (segmented scan)
+        if (lane >= d && plo == lo && phi == hi) bits |= pb;
+    }
+    const unsigned nlo = __shfl_down(lo, 1, 64), nhi = __shfl_down(hi, 1, 64);
+    const bool last = lane == 63 || nlo != lo || nhi != hi;
+    if (valid && last) atomicOr(&bitmap[word], bits);
+}
+
 __global__ void k_set_bits(const int32_t* __restrict__ coords, int Mcap, const int32_t* __restrict__ d_M, int X,
                            int Y, int Z, uint32_t* __restrict__ bitmap) {
     const int M = d_M ? *d_M : Mcap;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    int4 c = reinterpret_cast<const int4*>(coords)[i];
-    unsigned long long lin = (((unsigned long long)c.x * X + c.y) * Y + c.z) * Z + c.w;
-    atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+    const bool valid = i < M;
+    unsigned long long lin = 0;
+    if (valid) {
+        int4 c = reinterpret_cast<const int4*>(coords)[i];
+        lin = (((unsigned long long)c.x * X + c.y) * Y + c.z) * Z + c.w;
+    }
+    bitmap_set_coalesced(bitmap, lin, valid);
 }
 
 __global__ void k_block_popc(const uint32_t* __restrict__ bitmap, size_t words, int32_t* __restrict__ block_sums) {
@@ -193,12 +218,15 @@ __global__ void k_down_bits(const int32_t* __restrict__ coords, int Mcap, const 
                             int OY, int OZ, uint32_t* __restrict__ bitmap) {
     const int M = d_M ? *d_M : Mcap;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    int4 c = reinterpret_cast<const int4*>(coords)[i];
-    int ox = c.y >> 1, oy = c.z >> 1, oz = c.w >> 1;
-    if (ox >= OX || oy >= OY || oz >= OZ) return;  // dropped: candidate output outside out_shape
-    unsigned long long lin = (((unsigned long long)c.x * OX + ox) * OY + oy) * OZ + oz;
-    atomicOr(&bitmap[lin >> 5], 1u << (lin & 31));
+    bool valid = i < M;
+    unsigned long long lin = 0;
+    if (valid) {
+        int4 c = reinterpret_cast<const int4*>(coords)[i];
+        int ox = c.y >> 1, oy = c.z >> 1, oz = c.w >> 1;
+        valid = ox < OX && oy < OY && oz < OZ;  // dropped otherwise: candidate output outside out_shape
+        lin = (((unsigned long long)c.x * OX + ox) * OY + oy) * OZ + oz;
+    }
+    bitmap_set_coalesced(bitmap, lin, valid);
 }
 
 __global__ void k_down_fill(const int32_t* __restrict__ coords, int Mcap, const int32_t* __restrict__ d_M, GfIndex ox_,
@@ -268,5 +296,119 @@ extern "C" int gf_rules_down2(const int32_t* coords, int M, const int32_t* d_M, 
     if (ld > 0)
         hipLaunchKernelGGL(k_table_gmask, dim3(gf_div_up(ld, 256)), dim3(256), 0, st, child, 8, ld, gmask_down);
     GF_CHECK_LAUNCH("gf_rules_down2");
+    return GF_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// The whole chain of k=2/s=2 down-sampling rulebooks of the U-Net in one call.
+//
+// All tables live in one caller-provided workspace (bitmaps first, child tables next, so two memsets clear them for
+// every level at once instead of two per level), and a level's tables are sized by a host-known bound of its voxel
+// count: min(bound of the level above, grid cells).  (Walking the tail of small levels in ONE single-workgroup
+// kernel, with workgroup barriers in place of kernel boundaries, was tried: 165 us against ~50 us for the two dozen
+// 1-3 us launches it replaces -- a lone workgroup pays a memory round trip per loop iteration.)
+// ------------------------------------------------------------------------------------
+#define DOWN_MAX_LEVELS 8
+#define DOWN_FIELDS 10  // bitmap prefix scratch out_coords child parent koff up gmask_down gmask_up
+
+struct DownPlan {
+    int nl;
+    int shape[DOWN_MAX_LEVELS + 1][3];
+    int cap[DOWN_MAX_LEVELS + 1];
+    size_t words[DOWN_MAX_LEVELS];
+    long long off[DOWN_MAX_LEVELS][DOWN_FIELDS];  // int32-element offsets into the workspace
+    long long bitmaps_begin, bitmaps_end, child_begin, child_end, total;
+};
+
+static inline long long pad64(long long n) { return (n + 63) / 64 * 64; }
+
+static int plan_down_chain(int M0, int B, int X, int Y, int Z, int nlevels, DownPlan& P) {
+    P.nl = 0;
+    P.shape[0][0] = X; P.shape[0][1] = Y; P.shape[0][2] = Z;
+    P.cap[0] = M0 < 16 ? 16 : (M0 + 15) / 16 * 16;
+    for (int l = 0; l < nlevels && l < DOWN_MAX_LEVELS; l++) {
+        const int x = P.shape[l][0], y = P.shape[l][1], z = P.shape[l][2];
+        if (x < 2 || y < 2 || z < 2) break;
+        const int ox = (x - 2) / 2 + 1, oy = (y - 2) / 2 + 1, oz = (z - 2) / 2 + 1;
+        P.shape[l + 1][0] = ox; P.shape[l + 1][1] = oy; P.shape[l + 1][2] = oz;
+        const unsigned long long cells = (unsigned long long)B * ox * oy * oz;
+        unsigned long long c = (cells + 15) / 16 * 16;
+        if (c > (unsigned long long)P.cap[l]) c = P.cap[l];
+        if (c < 16) c = 16;
+        P.cap[l + 1] = (int)c;
+        P.words[l] = gf_index_words(B, ox, oy, oz);
+        if (P.words[l] >= (1ull << 31)) return -1;
+        P.nl = l + 1;
+    }
+    long long cur = 0;
+    P.bitmaps_begin = cur;
+    for (int l = 0; l < P.nl; l++) { P.off[l][0] = cur; cur += pad64((long long)P.words[l]); }
+    P.bitmaps_end = cur;
+    P.child_begin = cur;
+    for (int l = 0; l < P.nl; l++) { P.off[l][4] = cur; cur += pad64(8ll * P.cap[l + 1]); }
+    P.child_end = cur;
+    for (int l = 0; l < P.nl; l++) {
+        const long long ci = P.cap[l], co = P.cap[l + 1];
+        const long long sz[DOWN_FIELDS] = {0, (long long)P.words[l], (long long)(gf_index_scratch_bytes(P.words[l]) + 3) / 4,
+                                           4 * co, 0, ci, ci, 8 * ci, co / 16, ci / 16};
+        for (int f = 0; f < DOWN_FIELDS; f++) {
+            if (f == 0 || f == 4) continue;
+            P.off[l][f] = cur;
+            cur += pad64(sz[f]);
+        }
+    }
+    P.total = cur;
+    return 0;
+}
+
+extern "C" int gf_rules_down2_chain_plan(int M0, int B, int X, int Y, int Z, int nlevels, long long* offsets,
+                                         int* caps, int* shapes, long long* ws_elems, int* nlevels_out) {
+    GF_CHECK_ARG(offsets && caps && shapes && ws_elems && nlevels_out, "gf_rules_down2_chain_plan: null argument");
+    GF_CHECK_ARG(M0 >= 0 && B > 0 && nlevels >= 0 && nlevels <= DOWN_MAX_LEVELS,
+                 "gf_rules_down2_chain_plan: M0=%d B=%d nlevels=%d (at most %d levels)", M0, B, nlevels, DOWN_MAX_LEVELS);
+    DownPlan P;
+    GF_CHECK_ARG(plan_down_chain(M0, B, X, Y, Z, nlevels, P) == 0, "gf_rules_down2_chain_plan: grid too large");
+    for (int l = 0; l <= P.nl; l++) {
+        caps[l] = P.cap[l];
+        for (int a = 0; a < 3; a++) shapes[3 * l + a] = P.shape[l][a];
+    }
+    for (int l = 0; l < P.nl; l++)
+        for (int f = 0; f < DOWN_FIELDS; f++) offsets[l * DOWN_FIELDS + f] = P.off[l][f];
+    *ws_elems = P.total;
+    *nlevels_out = P.nl;
+    return GF_OK;
+}
+
+extern "C" int gf_rules_down2_chain(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels,
+                                    int32_t* ws, int32_t* counts, void* stream) {
+    GF_CHECK_ARG(coords && ws && counts, "gf_rules_down2_chain: null argument");
+    GF_CHECK_ARG(M0 >= 0 && B > 0 && nlevels >= 0 && nlevels <= DOWN_MAX_LEVELS, "gf_rules_down2_chain: bad sizes");
+    DownPlan P;
+    GF_CHECK_ARG(plan_down_chain(M0, B, X, Y, Z, nlevels, P) == 0, "gf_rules_down2_chain: grid too large");
+    if (P.nl == 0 || M0 == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(ws + P.bitmaps_begin, 0, (size_t)(P.bitmaps_end - P.bitmaps_begin) * 4, st);
+    (void)hipMemsetAsync(ws + P.child_begin, 0xff, (size_t)(P.child_end - P.child_begin) * 4, st);
+    const int32_t* cur = coords;
+    for (int l = 0; l < P.nl; l++) {
+        int32_t* F[DOWN_FIELDS];
+        for (int f = 0; f < DOWN_FIELDS; f++) F[f] = ws + P.off[l][f];
+        const int Mcap = l ? P.cap[l] : M0;
+        const int32_t* d_M = l ? counts + l : nullptr;
+        const int OX = P.shape[l + 1][0], OY = P.shape[l + 1][1], OZ = P.shape[l + 1][2];
+        const int ld = P.cap[l + 1], ld_up = P.cap[l];
+        {
+            if (Mcap > 0)
+                hipLaunchKernelGGL(k_down_bits, dim3(gf_div_up(Mcap, 256)), dim3(256), 0, st, cur, Mcap, d_M, OX, OY, OZ,
+                                   (uint32_t*)F[0]);
+            run_scan((uint32_t*)F[0], P.words[l], F[1], F[2], counts + l + 1, st);
+            GfIndex oix{(uint32_t*)F[0], F[1], nullptr, OX, OY, OZ};
+            hipLaunchKernelGGL(k_down_fill, dim3(gf_div_up(ld_up, 256)), dim3(256), 0, st, cur, Mcap, d_M, oix, F[3], F[4],
+                               ld, F[5], F[6], F[7], ld_up, (uint32_t*)F[9]);
+            hipLaunchKernelGGL(k_table_gmask, dim3(gf_div_up(ld, 256)), dim3(256), 0, st, F[4], 8, ld, (uint32_t*)F[8]);
+        }
+        cur = F[3];
+    }
+    GF_CHECK_LAUNCH("gf_rules_down2_chain");
     return GF_OK;
 }

@@ -258,50 +258,61 @@ def conv_wgrad(feats: torch.Tensor, grad_out: torch.Tensor, nbr, K: int, M_out: 
     return dW
 
 
-def down_rules_chain(coords: torch.Tensor, batch: int, shape, nlevels: int):
-    """Rulebooks of `nlevels` successive k=2/s=2 down-samplings with ONE host sync.
+_PLAN_CACHE = {}
 
-    Level l+1 is built from level l's output coordinates with the voxel count kept on the device
-    (`d_M`); all levels are allocated at the capacity of the first one, and the counts come back in a
-    single D2H copy at the end.  Returns a list of DownRules (tables keep the capacity as leading dim)."""
+
+def _down_chain_plan(M0: int, batch: int, shape, nlevels: int):
+    import ctypes
+
+    key = (M0, batch, tuple(shape), nlevels)
+    hit = _PLAN_CACHE.get(key)
+    if hit is None:
+        lib = _lib.load()
+        offs = (ctypes.c_longlong * (nlevels * 10))()
+        caps = (ctypes.c_int * (nlevels + 1))()
+        shapes = (ctypes.c_int * (3 * (nlevels + 1)))()
+        total, nl = ctypes.c_longlong(0), ctypes.c_int(0)
+        check(lib.gf_rules_down2_chain_plan(M0, batch, shape[0], shape[1], shape[2], nlevels,
+                                            ctypes.cast(offs, ctypes.c_void_p), ctypes.cast(caps, ctypes.c_void_p),
+                                            ctypes.cast(shapes, ctypes.c_void_p), ctypes.addressof(total),
+                                            ctypes.addressof(nl)), "gf_rules_down2_chain_plan")
+        n = nl.value
+        hit = (n, [list(offs[l * 10:(l + 1) * 10]) for l in range(n)], list(caps[: n + 1]),
+               [tuple(shapes[3 * l:3 * l + 3]) for l in range(n + 1)], int(total.value))
+        if len(_PLAN_CACHE) > 64:
+            _PLAN_CACHE.clear()
+        _PLAN_CACHE[key] = hit
+    return hit
+
+
+def down_rules_chain(coords: torch.Tensor, batch: int, shape, nlevels: int):
+    """Rulebooks of `nlevels` successive k=2/s=2 down-samplings: one native call, one workspace, one host sync
+    (include/geoformer_hip.h: gf_rules_down2_chain).  Level l+1 is built from level l's output coordinates with the
+    voxel count kept on the device; tables are sized by a host-known bound of the level's voxel count and keep that
+    capacity as leading dimension; the counts come back in a single D2H copy.  Returns a list of DownRules."""
     lib = _lib.load()
     dev = coords.device
     M0 = coords.shape[0]
-    cap = max(_round16(M0), 16)
-    counts = torch.zeros(nlevels + 1, dtype=torch.int32, device=dev)
-    counts[0] = M0
-    staged = []
-    cur, cur_shape = coords, tuple(int(s) for s in shape)
-    for l in range(nlevels):
-        X, Y, Z = cur_shape
-        if min(X, Y, Z) < 2:
-            break
-        oshape = ((X - 2) // 2 + 1, (Y - 2) // 2 + 1, (Z - 2) // 2 + 1)
-        words = lib.gf_index_words(batch, *oshape)
-        bitmap = torch.empty(words, dtype=torch.int32, device=dev)
-        prefix = torch.empty(words, dtype=torch.int32, device=dev)
-        scratch = _scratch(words, dev)
-        out_coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-        child = torch.empty((8, cap), dtype=torch.int32, device=dev)
-        parent = torch.empty(cap, dtype=torch.int32, device=dev)
-        koff = torch.empty(cap, dtype=torch.int32, device=dev)
-        up = torch.empty((8, cap), dtype=torch.int32, device=dev)
-        gmask_down = torch.empty(cap // 16, dtype=torch.int32, device=dev)
-        gmask_up = torch.empty(cap // 16, dtype=torch.int32, device=dev)
-        check(
-            lib.gf_rules_down2(ptr(cur), cap if l else M0, ptr(counts[l:l + 1]) if l else None, batch, X, Y, Z,
-                               ptr(bitmap), ptr(prefix), ptr(scratch), ptr(out_coords), ptr(counts[l + 1:l + 2]),
-                               ptr(child), cap, ptr(parent), ptr(koff), ptr(up), cap, ptr(gmask_down), ptr(gmask_up),
-                               stream_ptr()),
-            "gf_rules_down2",
-        )
-        staged.append((cur, cur_shape, oshape, bitmap, prefix, out_coords, child, parent, koff, up, gmask_down, gmask_up))
-        cur, cur_shape = out_coords, oshape
-    n = counts.tolist()  # the only host sync
+    shape = tuple(int(s) for s in shape)
+    nl, offs, caps, shapes, total = _down_chain_plan(M0, batch, shape, nlevels)
+    if nl == 0:
+        return []
+    ws = torch.empty(total, dtype=torch.int32, device=dev)
+    counts = torch.empty(nl + 1, dtype=torch.int32, device=dev)
+    check(lib.gf_rules_down2_chain(coords.data_ptr(), M0, batch, shape[0], shape[1], shape[2], nl, ws.data_ptr(),
+                                   counts.data_ptr(), stream_ptr()), "gf_rules_down2_chain")
+    n = [M0] + (counts[1:].tolist() if M0 > 0 else [0] * nl)  # the only host sync
     rules = []
-    for l, (cin, sin, oshape, bitmap, prefix, oc, child, parent, koff, up, gd, gu) in enumerate(staged):
-        r = DownRules(oc[: n[l + 1]], n[l], n[l + 1], child, cap, gd, parent[: n[l]], koff[: n[l]], up, cap, gu,
-                      LevelIndex(bitmap, prefix, None, batch, oshape), oshape)
-        r.in_coords, r.in_shape = cin[: n[l]], list(sin)
+    cin = coords
+    for l in range(nl):
+        o, cap_in, cap_out, oshape = offs[l], caps[l], caps[l + 1], shapes[l + 1]
+        words = lib.gf_index_words(batch, *oshape)
+        oc = ws[o[3]:o[3] + 4 * cap_out].view(cap_out, 4)
+        r = DownRules(oc[: n[l + 1]], n[l], n[l + 1], ws[o[4]:o[4] + 8 * cap_out].view(8, cap_out), cap_out,
+                      ws[o[8]:o[8] + cap_out // 16], ws[o[5]:o[5] + n[l]], ws[o[6]:o[6] + n[l]],
+                      ws[o[7]:o[7] + 8 * cap_in].view(8, cap_in), cap_in, ws[o[9]:o[9] + cap_in // 16],
+                      LevelIndex(ws[o[0]:o[0] + words], ws[o[1]:o[1] + words], None, batch, oshape), oshape)
+        r.in_coords, r.in_shape = cin[: n[l]], list(shapes[l])
         rules.append(r)
+        cin = oc
     return rules

@@ -89,6 +89,19 @@ int gf_rules_down2(const int32_t* coords, int M, const int32_t* d_M, int B, int 
                    int32_t* d_M_out, int32_t* child, int ld, int32_t* parent, int32_t* koff, int32_t* up, int ld_up,
                    uint32_t* gmask_down, uint32_t* gmask_up, void* stream);
 
+/* The chain of `nlevels` successive down-sampling rulebooks (the six SparseConv3d(k=2,s=2) of the U-Net,
+ * geoformer_modules.py:83-96) in one call and one workspace; the tail of small levels runs in a single launch.
+ *   plan (host only): offsets[l*10 + f] = int32-element offset into the workspace of field f of level l, f in
+ *     (bitmap, prefix, scratch, out_coords[cap_{l+1},4], child[8,cap_{l+1}], parent[cap_l], koff[cap_l],
+ *      up[8,cap_l], gmask_down[cap_{l+1}/16], gmask_up[cap_l/16]);  caps[l] = capacity (leading dimension) of
+ *     level l (caps[0] = M0 rounded up to 16), shapes[3*l..] = grid of level l; *ws_elems = workspace size in
+ *     int32 elements; *nlevels_out = levels actually built (stops when a grid side drops below 2).
+ *   chain: counts[l+1] (device) = number of voxels of level l+1; tables as gf_rules_down2 writes them. */
+int gf_rules_down2_chain_plan(int M0, int B, int X, int Y, int Z, int nlevels, long long* offsets, int* caps, int* shapes,
+                              long long* ws_elems, int* nlevels_out);
+int gf_rules_down2_chain(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels, int32_t* ws,
+                         int32_t* counts, void* stream);
+
 /* Weight pre-packing: spconv's parameter layout [k,k,k,Cin,Cout] (= [K,Cin,Cout], kept as the
  * state-dict layout, checkpoint.py:47-49) -> the per-lane MFMA B-operand order the conv kernel
  * streams with one 16-byte load per lane.  Wp holds gf_conv_packed_floats(K,Cin,Cout) floats
