@@ -316,7 +316,6 @@ class GeoFormer(nn.Module):
                                             device=locs_float_.device)
             self.last_sampling_indices = sampling_indices
             xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
-            feat_b = output_feats_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).transpose(1, 2).contiguous()
             first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
             src = first[0, :nq].contiguous()
             side.wait_stream(main)
@@ -328,6 +327,8 @@ class GeoFormer(nn.Module):
                 geo.append(g)
             # the rest of the sampling is on the critical path: issue it before anything else
             idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+            # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
+            feat_b = output_feats_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).transpose(1, 2).contiguous()
             staged.append((xyz_b, feat_b, idx))
             with torch.cuda.stream(side):
                 # small launches that only need the distances / the query picks ride in the BFS's shadow instead of
