@@ -16,8 +16,8 @@ The JSON line also carries
   roofline     -- the level-1 (C=16) gather-MFMA sparse-conv launches, HBM-bound: algorithmic bytes
                   4*(R*Cin + M*Cout + K*Cin*Cout) + 8*R per launch / mean launch time from HIP events
                   recorded around those launches inside the timed region;
-  cpu_baseline -- the same forward through the build's model on the host cores with the oracle's
-                  scalar C operators ("port"), on the 8k-point scene (rank 0, N=1 only).
+  cpu_baseline -- the same forward of the same scene through the build's model on the host cores with the
+                  oracle's scalar C operators ("port"; rank 0, N=1 only; ~20 s).
 """
 import argparse
 import json
@@ -104,13 +104,16 @@ class ConvProbe:
                 "us_per_launch": round(us, 2), "algorithmic_bytes": byt, "rules": R, "voxels": self.M}
 
 
-def cpu_baseline():
-    """The build's model on the host through the oracle's scalar C operators, 8k-point scene."""
+def cpu_baseline(points):
+    """The build's model on the host through the oracle's scalar C operators: one eval forward of the benchmark scene
+    itself (about 20 s on the GPU box's host; GF_CPU_BASELINE_POINTS bounds the sample to a smaller scene of the same
+    density when that is too long)."""
     from geoformer_amd import scene
     from oracle import cpu_backend
 
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    sc = scene.make_small_scene(8192, 7)
+    sample = int(os.environ.get("GF_CPU_BASELINE_POINTS", "0"))
+    sc = scene.make_small_scene(sample, 7) if sample else scene.make_scene(points, 1234)
     batch = scene.make_batch([sc])
     with cpu_backend.installed(), torch.no_grad():
         m = build_model("cpu", probe_batch=batch)
@@ -119,10 +122,12 @@ def cpu_baseline():
         out = m(batch, 300, training=False)
         dt = time.perf_counter() - t
     n = int(batch["locs"].shape[0])
+    what = f"a {n}-point scene of the same density ({points / n:.1f}x fewer points)" if sample else \
+        f"the benchmark scene itself ({n} points)"
     return {"value": round(1.0 / dt, 5), "unit": "scenes/s", "cores": 1, "kind": "port",
-            "sample": f"one eval forward of an {n}-point scene at ScanNet density (N_fg={int(out['fg_idxs'].shape[0])}); "
+            "sample": f"one eval forward of {what}, N_fg={int(out['fg_idxs'].shape[0])}; "
                       f"native operators = oracle scalar C on 1 core, torch modules on {torch.get_num_threads()} threads; "
-                      f"{dt:.1f} s; a 150k-point scene is ~18x the points",
+                      f"{dt:.1f} s",
             "seconds": round(dt, 2)}
 
 
@@ -206,7 +211,7 @@ def main():
             "roofline": probe.result(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(args.points)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
