@@ -143,9 +143,11 @@ extern "C" int gf_group_points_grad(const float* grad_out, const int32_t* idx, i
 // coordinate planes so a lane tests four consecutive points per ds_read_b128 triple (256 points per wave trip), and
 // the next tile is already in flight in registers while this one is tested (one barrier per tile).  Hits are
 // appended in index order: the four compare masks give each lane the number of earlier hits.
+#ifndef BQ_WAVES
 #define BQ_WAVES 8
+#endif
 #ifndef BQ_TILE
-#define BQ_TILE 1024
+#define BQ_TILE 2048  // 49 KB of LDS per workgroup; 1024: 88 us, 2048: 78 us on the S150k stage
 #endif
 #define BQ_PLANE (BQ_TILE + 12)  // plane stride: 16-byte aligned rows, x/y/z of one point in different banks
 #define BQ_LD ((BQ_TILE * 3 + BQ_WAVES * 64 - 1) / (BQ_WAVES * 64))
