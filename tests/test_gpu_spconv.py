@@ -59,6 +59,55 @@ def test_down_rules_bit_exact(hip, oracle, M, shape, B):
     assert (nxt.nbr.cpu().numpy() == oracle.rules_subm3(oc, r.out_shape)).all()
 
 
+@pytest.mark.parametrize("M,shape,B,nl", [(20000, (150, 90, 64), 1, 6), (3000, (65, 47, 41), 2, 4), (5, (128, 128, 128), 1, 6)])
+def test_down_rules_chain_bit_exact(hip, oracle, M, shape, B, nl):
+    """gf_rules_down2_chain (all levels in one call, one workspace, device-side voxel counts) level by level against
+    the oracle: coarse coordinates, child / parent / up tables, group masks, and the index each level hands to the
+    submanifold rulebook of the next."""
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(M + 7)
+    coords = random_voxels(rng, M, shape, B, surface=M > 1000)
+    chain = sparse.down_rules_chain(_dev(coords), B, shape, nl)
+    cur, cur_shape = coords, tuple(shape)
+    assert len(chain) >= 1
+    for r in chain:
+        oc, child, parent, koff = oracle.rules_down2(cur, cur_shape)
+        assert r.M_in == cur.shape[0] and r.M_out == oc.shape[0]
+        assert (r.out_coords.cpu().numpy() == oc).all()
+        got_child = r.child.cpu().numpy()
+        mo = oc.shape[0]  # the tables keep their capacity as leading dimension: rows beyond M_out stay empty
+        assert (got_child[:, :mo] == child[:, :mo]).all() and (got_child[:, mo:] == -1).all() and (child[:, mo:] == -1).all()
+        assert (r.parent.cpu().numpy() == parent).all() and (r.koff.cpu().numpy() == koff).all()
+        assert (r.up.cpu().numpy() == oracle.up_table(parent, koff, r.ld_up)).all()
+        for tbl, gm in ((got_child, r.gmask_down), (r.up.cpu().numpy(), r.gmask_up)):
+            present = (tbl >= 0).reshape(8, -1, 16).any(2)
+            expect = (present * (1 << np.arange(8))[:, None]).sum(0).astype(np.uint32)
+            assert (gm.cpu().numpy().view(np.uint32) == expect).all()
+        nxt = sparse.subm_rules(r.out_coords.contiguous(), r.index_out)
+        assert (nxt.nbr.cpu().numpy() == oracle.rules_subm3(oc, r.out_shape)).all()
+        cur, cur_shape = oc, tuple(r.out_shape)
+
+
+def test_index_build_any_row_order(hip, oracle):
+    """The bitmap bits are OR-ed across runs of lanes before the atomic: rows in raster order (long runs inside a
+    word), shuffled (no runs) and with every word boundary crossed must give the same index."""
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(5)
+    shape = (40, 33, 70)
+    dense = np.stack(np.meshgrid(np.arange(8, 20), np.arange(5, 25), np.arange(0, 70), indexing="ij"), -1).reshape(-1, 3)
+    coords = np.concatenate([np.zeros((dense.shape[0], 1), np.int64), dense], 1).astype(np.int32)
+    ref = oracle.rules_subm3(coords, shape)
+    for order in (np.arange(coords.shape[0]), rng.permutation(coords.shape[0])):
+        c = _dev(coords[order])
+        rules = sparse.subm_rules(c, sparse.build_index(c, 1, shape))
+        got = rules.nbr.cpu().numpy()[:, : coords.shape[0]]
+        inv = np.empty_like(order); inv[order] = np.arange(order.size)
+        expect = np.where(ref[:, order] >= 0, inv[np.clip(ref[:, order], 0, None)], -1)
+        assert (got == expect).all()
+
+
 @pytest.mark.parametrize("Cin,Cout", [(6, 16), (16, 16), (32, 16), (32, 32), (48, 64), (112, 112), (19, 21), (80, 160)])
 def test_subm_conv_parity(hip, oracle, Cin, Cout):
     from geoformer_amd import sparse
