@@ -69,6 +69,8 @@ def _declare(lib):
         "gf_voxelize_idx_count": (I, [P, I, I, I, P, P, P, P]),
         "gf_voxelize_idx_fill": (I, [P, I, I, I, P, P, I, I, P, P, P]),
         "gf_host_legacy_choice": (I, [P, P, c_longlong, c_longlong, P]),
+        "gf_fg_scratch_bytes": (c_size_t, [I]),
+        "gf_fg_select": (I, [P, I, I, I, I, P, P, P, I, P, P, P, P, P, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),

@@ -226,7 +226,7 @@ class GeoFormer(nn.Module):
         return spconv.SparseConvTensor(voxel_feats, batch_input["voxel_locs"].int(), batch_input["spatial_shape"],
                                        batch_size)
 
-    def forward_backbone(self, batch_input, batch_size):
+    def forward_backbone(self, batch_input, batch_size, want_preds=True):
         ctx = self._grad_ctx("unet")
         with ctx():
             x = self.preprocess_input(batch_input, batch_size)
@@ -241,7 +241,7 @@ class GeoFormer(nn.Module):
                 semantic_scores = pointops.pointwise_mlp(output_feats, chain)
             else:
                 semantic_scores = self.semantic_linear(self.semantic(output_feats))
-            semantic_preds = semantic_scores.max(1)[1]
+            semantic_preds = semantic_scores.max(1)[1] if want_preds else None
             return output_feats, semantic_scores, semantic_preds
 
     @staticmethod
@@ -552,21 +552,33 @@ class GeoFormer(nn.Module):
         assert batch_size > 0
         pc_dims = [batch_input["pc_maxs"], batch_input["pc_mins"]]  # swapped on purpose (geoformer.py:412-415)
 
-        output_feats, semantic_scores, semantic_preds = self.forward_backbone(batch_input, batch_size)
+        # inference on the GPU: arg-max, foreground test, index list and the four gathers in three launches before
+        # the one read-back (csrc/foreground.hip) instead of max / compare / nonzero() / four gathers around it
+        fused_fg = (locs_float.is_cuda and not torch.is_grad_enabled() and epoch > self.prepare_epochs
+                    and locs_float.dtype == torch.float32)
+        output_feats, semantic_scores, semantic_preds = self.forward_backbone(batch_input, batch_size,
+                                                                              want_preds=not fused_fg)
         outputs["semantic_scores"] = semantic_scores
         if epoch <= self.prepare_epochs:
             return outputs
 
-        fg = semantic_preds >= 4 if cfg.train_fold == cfg.cvfold else semantic_preds == 3
-        fg_idxs = torch.nonzero(fg).view(-1)
+        same_fold = cfg.train_fold == cfg.cvfold
+        if fused_fg:
+            fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = pointops.select_foreground(
+                semantic_scores.contiguous(), 4 if same_fold else 3, not same_fold, locs_float.contiguous(),
+                batch_idxs.contiguous(), output_feats.contiguous())
+        else:
+            fg = semantic_preds >= 4 if same_fold else semantic_preds == 3
+            fg_idxs = torch.nonzero(fg).view(-1)
         if len(fg_idxs) == 0:
             outputs["mask_predictions"] = None
             return outputs
-        batch_idxs_ = batch_idxs[fg_idxs]
+        if not fused_fg:
+            batch_idxs_ = batch_idxs[fg_idxs]
+            locs_float_ = locs_float[fg_idxs]
+            output_feats_ = output_feats[fg_idxs]
+            semantic_scores_ = semantic_scores[fg_idxs]
         batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size)
-        locs_float_ = locs_float[fg_idxs]
-        output_feats_ = output_feats[fg_idxs]
-        semantic_scores_ = semantic_scores[fg_idxs]
         offs_ = _offsets_list(batch_offsets_)  # the only read-back of this stretch, before the heavy launches
         chain = self._pointwise_chain("mask_tower", [self.mask_tower], output_feats_)
         if chain is not None:

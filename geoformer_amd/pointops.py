@@ -135,6 +135,29 @@ def furthest_point_sampling(xyz, m, known=None):
     return idx
 
 
+def select_foreground(scores, cls, equal, locs, batch_idxs, feats):
+    """Fused foreground selection (csrc/foreground.hip): points whose arg-max class is >= cls (== cls with `equal`).
+    Returns (fg_idxs int64 [n], locs_ [n,3], batch_idxs_ int32 [n], feats_ [n,F], scores_ [n,C]) -- views of
+    capacity-N buffers -- after ONE read-back (the count)."""
+    _f32c(scores, "scores"); _f32c(locs, "locs"); _i32c(batch_idxs, "batch_idxs"); _f32c(feats, "feats")
+    N, C = scores.shape
+    F = feats.shape[1]
+    dev = scores.device
+    lib = _lib.load()
+    scratch = torch.empty(lib.gf_fg_scratch_bytes(N) // 4 + 1, dtype=torch.int32, device=dev)
+    fg = torch.empty(N, dtype=torch.int64, device=dev)
+    locs_o = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    bidx_o = torch.empty(N, dtype=torch.int32, device=dev)
+    feats_o = torch.empty((N, F), dtype=torch.float32, device=dev)
+    scores_o = torch.empty((N, C), dtype=torch.float32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    check(lib.gf_fg_select(ptr(scores), N, C, int(cls), int(bool(equal)), ptr(locs), ptr(batch_idxs), ptr(feats), F,
+                           ptr(scratch), ptr(fg), ptr(locs_o), ptr(bidx_o), ptr(feats_o), ptr(scores_o), ptr(cnt),
+                           stream_ptr()), "gf_fg_select")
+    n = int(cnt.item())
+    return fg[:n], locs_o[:n], bidx_o[:n], feats_o[:n], scores_o[:n]
+
+
 def legacy_choice(n, k):
     """``np.random.choice(n, k, replace=False)`` on numpy's global legacy generator -- same values, same generator
     state afterwards -- through the native restatement (csrc/host_draw.hip; about half the host time)."""

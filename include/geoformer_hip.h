@@ -38,6 +38,19 @@ int gf_abi_version(void);
 const char* gf_last_error(void);
 
 /* ===================================================================================
+ * Foreground selection of the forward, fused (geoformer.py:423-439): arg-max over the class scores, the
+ * foreground test (mode 0: class >= cls, mode 1: class == cls), the ascending index list of the foreground points
+ * and the gathered rows of the per-point tensors, all before the one read-back of the count.
+ *   scores fp32 [N,C]; locs fp32 [N,3]; batch_idxs int32 [N]; feats fp32 [N,F]  (sources, any may be NULL
+ *   together with its output);  fg_idxs int64 [N], locs_out [N,3], bidx_out [N], feats_out [N,F],
+ *   scores_out [N,C]: capacity N, the first *d_count rows are valid;  scratch: gf_fg_scratch_bytes(N).
+ * =================================================================================== */
+size_t gf_fg_scratch_bytes(int N);
+int gf_fg_select(const float* scores, int N, int C, int cls, int mode, const float* locs, const int32_t* batch_idxs,
+                 const float* feats, int F, void* scratch, long long* fg_idxs, float* locs_out, int32_t* bidx_out,
+                 float* feats_out, float* scores_out, int32_t* d_count, void* stream);
+
+/* ===================================================================================
  * Host helper (CPU code, no launch): the reference's per-scene sampling draw
  * np.random.choice(n, k, replace=False) (geoformer.py:575-577) on numpy's legacy MT19937 state, bit for bit.
  *   key uint32[624], *pos: the state as np.random.get_state() returns it (updated in place, hand it back with

@@ -270,6 +270,30 @@ def test_sa_stage_fused(hip, oracle, B, n, npnt, ns, C):
     assert torch.equal(got[0], new_xyz) and torch.equal(got[1], pooled)
 
 
+@pytest.mark.parametrize("N,equal", [(150_003, False), (5000, True), (1, False), (1024, False), (1025, True)])
+def test_select_foreground_fused(hip, N, equal):
+    """gf_fg_select vs the PyTorch sequence it replaces (geoformer.py:423-439): index list and gathered integers
+    bit-exact, gathered floats bit-exact copies."""
+    from geoformer_amd import pointops
+
+    g = torch.Generator().manual_seed(N)
+    scores = torch.randn(N, 13, generator=g)
+    scores[::7, 2] = 9.0  # a block of background winners
+    locs, feats = torch.randn(N, 3, generator=g), torch.randn(N, 16, generator=g)
+    bidx = torch.randint(0, 3, (N,), generator=g).int()
+    preds = scores.max(1)[1]
+    ref = torch.nonzero(preds == 3 if equal else preds >= 4).view(-1)
+    fg, l, b, f, sc = pointops.select_foreground(scores.cuda(), 3 if equal else 4, equal, locs.cuda(), bidx.cuda(),
+                                                 feats.cuda())
+    assert fg.dtype == torch.int64 and torch.equal(fg.cpu(), ref)
+    assert torch.equal(l.cpu(), locs[ref]) and torch.equal(b.cpu(), bidx[ref])
+    assert torch.equal(f.cpu(), feats[ref]) and torch.equal(sc.cpu(), scores[ref])
+    # nothing selected
+    none = pointops.select_foreground(torch.zeros(300, 13).cuda() - torch.arange(13.0).cuda(), 4, False,
+                                      locs[:300].cuda(), bidx[:300].cuda(), feats[:300].cuda())
+    assert none[0].numel() == 0 and none[3].shape == (0, 16)
+
+
 def test_matrix_nms_gpu(hip, oracle):
     """Bit-packed intersection kernel vs the oracle (exact), and the GPU matrix NMS vs the reference golden."""
     import os
