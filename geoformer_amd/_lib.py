@@ -58,6 +58,7 @@ def _declare(lib):
         "gf_softmax_dim1_fwd": (I, [P, I, I, I, F, P, P]),
         "gf_softmax_dim1_bwd": (I, [P, P, I, I, I, F, P, P]),
         "gf_pointwise_mlp": (I, [P, I, I, P, P, P, P, P, P, P]),
+        "gf_pointwise_mlp_rows": (I, [P, P, I, I, P, P, P, P, P, P, P]),
         "gf_group_mlp_max": (I, [P, I, I, I, I, P, P, P, P, P, P, P]),
         "gf_ball_query_centres": (I, [P, P, I, I, I, F, I, P, P, P]),
         "gf_sa_group_mlp_max": (I, [P, P, P, I, I, I, I, F, I, I, I, I, P, P, P, P, P, P, P, P, P]),
@@ -70,7 +71,7 @@ def _declare(lib):
         "gf_voxelize_idx_fill": (I, [P, I, I, I, P, P, I, I, P, P, P]),
         "gf_host_legacy_choice": (I, [P, P, c_longlong, c_longlong, P]),
         "gf_fg_scratch_bytes": (c_size_t, [I]),
-        "gf_fg_select": (I, [P, I, I, I, I, P, P, P, I, P, P, P, P, P, P, P, P]),
+        "gf_fg_select": (I, [P, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),

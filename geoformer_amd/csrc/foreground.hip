@@ -76,7 +76,8 @@ __global__ __launch_bounds__(FG_THREADS) void k_fg_compact(const unsigned char* 
                                                           const float* __restrict__ scores, int C,
                                                           const float* __restrict__ locs,
                                                           const int32_t* __restrict__ batch_idxs,
-                                                          const float* __restrict__ feats, int F,
+                                                          const float* __restrict__ feats,
+                                                          const int32_t* __restrict__ feat_rows, int F,
                                                           long long* __restrict__ fg_idxs, float* __restrict__ locs_out,
                                                           int32_t* __restrict__ bidx_out, float* __restrict__ feats_out,
                                                           float* __restrict__ scores_out) {
@@ -109,12 +110,13 @@ __global__ __launch_bounds__(FG_THREADS) void k_fg_compact(const unsigned char* 
             if (scores_out)
                 for (int k = 0; k < C; k++) scores_out[pos * C + k] = scores[(size_t)p * C + k];
             if (feats_out) {
+                const size_t fr = feat_rows ? (size_t)feat_rows[p] : (size_t)p;  // feats_[i] = feats[feat_rows[fg_idxs[i]]]
                 if ((F & 3) == 0) {
-                    const float4* src = reinterpret_cast<const float4*>(feats + (size_t)p * F);
+                    const float4* src = reinterpret_cast<const float4*>(feats + fr * F);
                     float4* dst = reinterpret_cast<float4*>(feats_out + pos * F);
                     for (int k = 0; k < (F >> 2); k++) dst[k] = src[k];
                 } else {
-                    for (int k = 0; k < F; k++) feats_out[pos * F + k] = feats[(size_t)p * F + k];
+                    for (int k = 0; k < F; k++) feats_out[pos * F + k] = feats[fr * F + k];
                 }
             }
         }
@@ -131,7 +133,8 @@ extern "C" size_t gf_fg_scratch_bytes(int N) {
 }
 
 extern "C" int gf_fg_select(const float* scores, int N, int C, int cls, int mode, const float* locs,
-                            const int32_t* batch_idxs, const float* feats, int F, void* scratch, long long* fg_idxs,
+                            const int32_t* batch_idxs, const float* feats, const int32_t* feat_rows, int F,
+                            void* scratch, long long* fg_idxs,
                             float* locs_out, int32_t* bidx_out, float* feats_out, float* scores_out, int32_t* d_count,
                             void* stream) {
     GF_CHECK_ARG(scores && scratch && fg_idxs && d_count, "gf_fg_select: null argument");
@@ -152,7 +155,7 @@ extern "C" int gf_fg_select(const float* scores, int N, int C, int cls, int mode
     hipLaunchKernelGGL(k_fg_flags, dim3(nb), dim3(FG_THREADS), 0, st, scores, N, C, cls, mode, flags, block_counts);
     hipLaunchKernelGGL(k_fg_scan, dim3(1), dim3(SCAN_THREADS), 0, st, block_counts, nb, block_offs, d_count);
     hipLaunchKernelGGL(k_fg_compact, dim3(nb), dim3(FG_THREADS), 0, st, flags, N, block_offs, scores, C, locs, batch_idxs,
-                       feats, F, fg_idxs, locs_out, bidx_out, feats_out, scores_out);
+                       feats, feat_rows, F, fg_idxs, locs_out, bidx_out, feats_out, scores_out);
     GF_CHECK_LAUNCH("gf_fg_select");
     return GF_OK;
 }

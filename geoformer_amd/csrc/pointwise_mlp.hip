@@ -24,8 +24,10 @@ struct PmArgs {
     int nl;
 };
 
-__global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__ x, int N, PmArgs A,
-                                                       float* __restrict__ out) {
+// rows: optional int32 [N] row indirection of the input (out[p] = MLP(x[rows[p]])): the p2v gather of the semantic
+// head rides in the first layer's operand load instead of materialising feats[p2v_map]
+__global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__ x, const int32_t* __restrict__ rows,
+                                                       int N, PmArgs A, float* __restrict__ out) {
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const int ntiles = (N + 15) >> 4;
@@ -33,12 +35,13 @@ __global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__
     for (int t = wave; t < ntiles; t += nwaves) {
         const int p = t * 16 + j;
         const bool live = p < N;
+        const int src = (rows && live) ? rows[p] : p;
         // B operand of the first layer: channels kc*16 + 4g .. +3 of point j
         float4 h[PM_MAXC / 16];
 #pragma unroll
         for (int kc = 0; kc < PM_MAXC / 16; kc++) {
             h[kc] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kc * 16 < c0 && live) h[kc] = *reinterpret_cast<const float4*>(x + (size_t)p * c0 + kc * 16 + 4 * g);
+            if (kc * 16 < c0 && live) h[kc] = *reinterpret_cast<const float4*>(x + (size_t)src * c0 + kc * 16 + 4 * g);
         }
 #pragma unroll
         for (int l = 0; l < PM_MAXL; l++) {
@@ -95,9 +98,18 @@ __global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__
     }
 }
 
+extern "C" int gf_pointwise_mlp_rows(const float* x, const int32_t* rows, int N, int n_layers, const float* const* W,
+                                     const float* const* scale, const float* const* shift, const int* channels,
+                                     const int* relu, float* out, void* stream);
 extern "C" int gf_pointwise_mlp(const float* x, int N, int n_layers, const float* const* W, const float* const* scale,
                                 const float* const* shift, const int* channels, const int* relu, float* out,
                                 void* stream) {
+    return gf_pointwise_mlp_rows(x, nullptr, N, n_layers, W, scale, shift, channels, relu, out, stream);
+}
+
+extern "C" int gf_pointwise_mlp_rows(const float* x, const int32_t* rows, int N, int n_layers, const float* const* W,
+                                     const float* const* scale, const float* const* shift, const int* channels,
+                                     const int* relu, float* out, void* stream) {
     GF_CHECK_ARG(n_layers >= 1 && n_layers <= PM_MAXL, "gf_pointwise_mlp: 1..%d layers, got %d", PM_MAXL, n_layers);
     GF_CHECK_ARG(N >= 0, "gf_pointwise_mlp: bad N");
     PmArgs A;
@@ -117,7 +129,7 @@ extern "C" int gf_pointwise_mlp(const float* x, int N, int n_layers, const float
     const int ntiles = (N + 15) / 16;
     int blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(k_pointwise_mlp, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, N, A, out);
+    hipLaunchKernelGGL(k_pointwise_mlp, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, N, A, out);
     GF_CHECK_LAUNCH("gf_pointwise_mlp");
     return GF_OK;
 }

@@ -235,7 +235,15 @@ class GeoFormer(nn.Module):
             # of the voxel counts waits behind real work instead of an empty queue
             x.indice_dict["_prebuild"] = self.prebuild_rulebooks
             x = self.output_layer(self.unet(self.input_conv(x)))
-            output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
+            p2v = batch_input["p2v_map"]
+            if not want_preds and p2v.dtype == torch.int32 and p2v.is_contiguous():
+                # fused inference: nobody needs feats[p2v_map] as a tensor -- the semantic head and the foreground
+                # compaction read the voxel rows through the map (returned as (voxel features, map))
+                vox = x.features.contiguous()
+                chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], vox)
+                if chain is not None:
+                    return (vox, p2v), pointops.pointwise_mlp(vox, chain, rows=p2v), None
+            output_feats = x.features[p2v.long()].contiguous()
             chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)
             if chain is not None:
                 semantic_scores = pointops.pointwise_mlp(output_feats, chain)
@@ -564,9 +572,10 @@ class GeoFormer(nn.Module):
 
         same_fold = cfg.train_fold == cfg.cvfold
         if fused_fg:
+            feats_src, feat_rows = output_feats if isinstance(output_feats, tuple) else (output_feats.contiguous(), None)
             fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = pointops.select_foreground(
                 semantic_scores.contiguous(), 4 if same_fold else 3, not same_fold, locs_float.contiguous(),
-                batch_idxs.contiguous(), output_feats.contiguous())
+                batch_idxs.contiguous(), feats_src, feat_rows)
         else:
             fg = semantic_preds >= 4 if same_fold else semantic_preds == 3
             fg_idxs = torch.nonzero(fg).view(-1)

@@ -135,11 +135,13 @@ def furthest_point_sampling(xyz, m, known=None):
     return idx
 
 
-def select_foreground(scores, cls, equal, locs, batch_idxs, feats):
+def select_foreground(scores, cls, equal, locs, batch_idxs, feats, feat_rows=None):
     """Fused foreground selection (csrc/foreground.hip): points whose arg-max class is >= cls (== cls with `equal`).
     Returns (fg_idxs int64 [n], locs_ [n,3], batch_idxs_ int32 [n], feats_ [n,F], scores_ [n,C]) -- views of
     capacity-N buffers -- after ONE read-back (the count)."""
     _f32c(scores, "scores"); _f32c(locs, "locs"); _i32c(batch_idxs, "batch_idxs"); _f32c(feats, "feats")
+    if feat_rows is not None:
+        _i32c(feat_rows, "feat_rows")  # feats are rows of another table (voxels), read as feats[feat_rows[p]]
     N, C = scores.shape
     F = feats.shape[1]
     dev = scores.device
@@ -151,7 +153,8 @@ def select_foreground(scores, cls, equal, locs, batch_idxs, feats):
     feats_o = torch.empty((N, F), dtype=torch.float32, device=dev)
     scores_o = torch.empty((N, C), dtype=torch.float32, device=dev)
     cnt = torch.empty(1, dtype=torch.int32, device=dev)
-    check(lib.gf_fg_select(ptr(scores), N, C, int(cls), int(bool(equal)), ptr(locs), ptr(batch_idxs), ptr(feats), F,
+    check(lib.gf_fg_select(ptr(scores), N, C, int(cls), int(bool(equal)), ptr(locs), ptr(batch_idxs), ptr(feats),
+                           ptr(feat_rows), F,
                            ptr(scratch), ptr(fg), ptr(locs_o), ptr(bidx_o), ptr(feats_o), ptr(scores_o), ptr(cnt),
                            stream_ptr()), "gf_fg_select")
     n = int(cnt.item())
@@ -278,15 +281,19 @@ class PointwiseChain:
         return ok and 1 <= ch[-1][1] <= 64
 
 
-def pointwise_mlp(x, chain):
-    """Fused per-point MLP chain over the rows of x [N, C0] -> [N, C_last] (include/geoformer_hip.h)."""
+def pointwise_mlp(x, chain, rows=None):
+    """Fused per-point MLP chain over the rows of x [N, C0] -> [N, C_last] (include/geoformer_hip.h); with
+    rows (int32 [N]) over x[rows] without materialising the gather."""
     _f32c(x, "x")
     N = x.shape[0]
+    if rows is not None:
+        _i32c(rows, "rows")
+        N = rows.shape[0]
     if x.shape[1] != chain.channels[0]:
         raise RuntimeError(f"pointwise_mlp: x has {x.shape[1]} channels, the chain expects {chain.channels[0]}")
     out = torch.empty((N, chain.channels[-1]), dtype=torch.float32, device=x.device)
-    check(_lib.load().gf_pointwise_mlp(ptr(x), N, chain.n, chain.W, chain.scale, chain.shift, chain.ch, chain.relu,
-                                       ptr(out), stream_ptr()), "gf_pointwise_mlp")
+    check(_lib.load().gf_pointwise_mlp_rows(ptr(x), ptr(rows), N, chain.n, chain.W, chain.scale, chain.shift, chain.ch,
+                                            chain.relu, ptr(out), stream_ptr()), "gf_pointwise_mlp")
     return out
 
 

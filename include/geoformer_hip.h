@@ -41,14 +41,15 @@ const char* gf_last_error(void);
  * Foreground selection of the forward, fused (geoformer.py:423-439): arg-max over the class scores, the
  * foreground test (mode 0: class >= cls, mode 1: class == cls), the ascending index list of the foreground points
  * and the gathered rows of the per-point tensors, all before the one read-back of the count.
- *   scores fp32 [N,C]; locs fp32 [N,3]; batch_idxs int32 [N]; feats fp32 [N,F]  (sources, any may be NULL
- *   together with its output);  fg_idxs int64 [N], locs_out [N,3], bidx_out [N], feats_out [N,F],
+ *   scores fp32 [N,C]; locs fp32 [N,3]; batch_idxs int32 [N]; feats fp32 [N,F] or, with feat_rows int32 [N]
+ *   (the p2v map), fp32 [M,F] voxel rows read as feats[feat_rows[p]]  (sources, any may be NULL together with its
+ *   output);  fg_idxs int64 [N], locs_out [N,3], bidx_out [N], feats_out [N,F],
  *   scores_out [N,C]: capacity N, the first *d_count rows are valid;  scratch: gf_fg_scratch_bytes(N).
  * =================================================================================== */
 size_t gf_fg_scratch_bytes(int N);
 int gf_fg_select(const float* scores, int N, int C, int cls, int mode, const float* locs, const int32_t* batch_idxs,
-                 const float* feats, int F, void* scratch, long long* fg_idxs, float* locs_out, int32_t* bidx_out,
-                 float* feats_out, float* scores_out, int32_t* d_count, void* stream);
+                 const float* feats, const int32_t* feat_rows, int F, void* scratch, long long* fg_idxs, float* locs_out,
+                 int32_t* bidx_out, float* feats_out, float* scores_out, int32_t* d_count, void* stream);
 
 /* ===================================================================================
  * Host helper (CPU code, no launch): the reference's per-scene sampling draw
@@ -269,6 +270,11 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
  *   channels: HOST int[n_layers+1] (inputs multiples of 16, all widths <= 64; the last output width is free), relu: HOST int[n_layers]. */
 int gf_pointwise_mlp(const float* x, int N, int n_layers, const float* const* W, const float* const* scale,
                      const float* const* shift, const int* channels, const int* relu, float* out, void* stream);
+/* Same with a row indirection of the input: out[p] = MLP(x[rows[p]]), rows int32 [N] (the semantic head reading the
+ * voxel features through p2v_map, geoformer.py:541-547, without materialising the gathered tensor). */
+int gf_pointwise_mlp_rows(const float* x, const int32_t* rows, int N, int n_layers, const float* const* W,
+                          const float* const* scale, const float* const* shift, const int* channels, const int* relu,
+                          float* out, void* stream);
 
 /* Set-abstraction MLP + max-pool, fused (PointnetSAModuleVotes: SharedMLP + max_pool2d over the samples,
  * lib/pointnet2/pointnet2_modules.py:335-349):  out[b,:,i] = max_s L_n(...L_1(grouped[b,:,i,s])), layers as above

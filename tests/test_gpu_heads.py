@@ -213,6 +213,23 @@ def test_pointwise_mlp_chain(hip, N, chs, last_plain):
     assert (out.cpu() - h).abs().max().item() < 1e-4  # tolerance of BASELINE.json north_star
 
 
+def test_pointwise_mlp_row_indirection(hip):
+    """gf_pointwise_mlp_rows: MLP(x[rows]) equals the chain over the gathered tensor, bit for bit."""
+    from geoformer_amd import pointops
+
+    torch.manual_seed(3)
+    lin = [torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 13)]
+    mods = torch.nn.Sequential(*lin).cuda().eval()
+    flat = [m for _, m in mods.named_modules(remove_duplicate=False) if len(list(m.children())) == 0]
+    assert pointops.PointwiseChain.supported(flat)
+    chain = pointops.PointwiseChain(flat)
+    x = torch.randn(5000, 16, device="cuda")
+    rows = torch.randint(0, 5000, (12345,), device="cuda").int()
+    a = pointops.pointwise_mlp(x, chain, rows=rows)
+    b = pointops.pointwise_mlp(x[rows.long()].contiguous(), chain)
+    assert a.shape == (12345, 13) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,npnt,ns,dims", [(1, 300, 64, [19, 32, 32, 32]), (2, 33, 20, [19, 32, 32, 32]), (1, 5, 64, [35, 64, 16])])
 def test_group_mlp_max_fused(hip, B, npnt, ns, dims):
     """Fused SharedMLP + max-pool of the set-abstraction module (pointnet2_modules.py:335-349) vs its PyTorch
@@ -288,6 +305,13 @@ def test_select_foreground_fused(hip, N, equal):
     assert fg.dtype == torch.int64 and torch.equal(fg.cpu(), ref)
     assert torch.equal(l.cpu(), locs[ref]) and torch.equal(b.cpu(), bidx[ref])
     assert torch.equal(f.cpu(), feats[ref]) and torch.equal(sc.cpu(), scores[ref])
+    # features read through a row map (voxel rows via p2v_map)
+    M = max(1, N // 3)
+    vox = torch.randn(M, 16, generator=g)
+    rows = torch.randint(0, M, (N,), generator=g).int()
+    f2 = pointops.select_foreground(scores.cuda(), 3 if equal else 4, equal, locs.cuda(), bidx.cuda(), vox.cuda(),
+                                    rows.cuda())[3]
+    assert torch.equal(f2.cpu(), vox[rows.long()][ref])
     # nothing selected
     none = pointops.select_foreground(torch.zeros(300, 13).cuda() - torch.arange(13.0).cuda(), 4, False,
                                       locs[:300].cuda(), bidx[:300].cuda(), feats[:300].cuda())
