@@ -301,18 +301,24 @@ def down_rules_chain(coords: torch.Tensor, batch: int, shape, nlevels: int):
     counts = torch.empty(nl + 1, dtype=torch.int32, device=dev)
     check(lib.gf_rules_down2_chain(coords.data_ptr(), M0, batch, shape[0], shape[1], shape[2], nl, ws.data_ptr(),
                                    counts.data_ptr(), stream_ptr()), "gf_rules_down2_chain")
+    # every view that does not depend on the voxel counts is made while the chain is still running on the device;
+    # after the read-back only three slices per level are left (the stretch behind the sync is launch-bound)
+    pre = []
+    for l in range(nl):
+        o, cap_in, cap_out, oshape = offs[l], caps[l], caps[l + 1], shapes[l + 1]
+        words = lib.gf_index_words(batch, *oshape)
+        pre.append((ws[o[3]:o[3] + 4 * cap_out].view(cap_out, 4), ws[o[4]:o[4] + 8 * cap_out].view(8, cap_out),
+                    ws[o[8]:o[8] + cap_out // 16], ws[o[5]:o[5] + cap_in], ws[o[6]:o[6] + cap_in],
+                    ws[o[7]:o[7] + 8 * cap_in].view(8, cap_in), ws[o[9]:o[9] + cap_in // 16],
+                    LevelIndex(ws[o[0]:o[0] + words], ws[o[1]:o[1] + words], None, batch, oshape)))
     n = [M0] + (counts[1:].tolist() if M0 > 0 else [0] * nl)  # the only host sync
     rules = []
     cin = coords
     for l in range(nl):
-        o, cap_in, cap_out, oshape = offs[l], caps[l], caps[l + 1], shapes[l + 1]
-        words = lib.gf_index_words(batch, *oshape)
-        oc = ws[o[3]:o[3] + 4 * cap_out].view(cap_out, 4)
-        r = DownRules(oc[: n[l + 1]], n[l], n[l + 1], ws[o[4]:o[4] + 8 * cap_out].view(8, cap_out), cap_out,
-                      ws[o[8]:o[8] + cap_out // 16], ws[o[5]:o[5] + n[l]], ws[o[6]:o[6] + n[l]],
-                      ws[o[7]:o[7] + 8 * cap_in].view(8, cap_in), cap_in, ws[o[9]:o[9] + cap_in // 16],
-                      LevelIndex(ws[o[0]:o[0] + words], ws[o[1]:o[1] + words], None, batch, oshape), oshape)
-        r.in_coords, r.in_shape = cin[: n[l]], list(shapes[l])
+        oc, child, gd, parent, koff, up, gu, index = pre[l]
+        r = DownRules(oc[: n[l + 1]], n[l], n[l + 1], child, caps[l + 1], gd, parent[: n[l]], koff[: n[l]], up, caps[l],
+                      gu, index, shapes[l + 1])
+        r.in_coords, r.in_shape = cin[: n[l]] if l else coords, list(shapes[l])
         rules.append(r)
         cin = oc
     return rules
