@@ -695,7 +695,8 @@ extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n,
     while ((2 << bs_log2) <= n && bs_log2 < 9) bs_log2++;
     const int per_wg = FPS_WAVES * 64;
     int G = (n + per_wg * 3 - 1) / (per_wg * 3);  // 3-4 points per lane
-    if (const char* e = getenv("GF_FPS_G")) G = atoi(e);
+    static const int g_env = [] { const char* e = getenv("GF_FPS_G"); return e ? atoi(e) : 0; }();  // read once
+    if (g_env > 0) G = g_env;
     if (G < 1) G = 1;
     if (G > FPS_MAXG) G = FPS_MAXG;
     const int P = (n + G * per_wg - 1) / (G * per_wg);

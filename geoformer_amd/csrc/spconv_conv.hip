@@ -569,6 +569,23 @@ static void dispatch_conv(int ncbw, bool vec, dim3 grid, hipStream_t st, const C
     }
 }
 
+// Dev knobs, read from the environment ONCE: a getenv() walks the whole environment block, and five of them per
+// launch cost the host ~10 us -- more than a small conv kernel runs -- in the launch-bound U-Net (71 convs per scene).
+struct ConvKnobs {
+    int split = -1, wide = -1, block = 0, ldsw = 0, pair = -1;  // -1 / 0: not set
+    ConvKnobs() {
+        if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
+        if (const char* e = getenv("GF_CONV_WIDE")) wide = atoi(e) != 0;
+        if (const char* e = getenv("GF_CONV_BLOCK")) block = atoi(e) > 256 ? 256 : atoi(e);
+        if (const char* e = getenv("GF_CONV_LDSW")) ldsw = atoi(e) != 0;
+        if (const char* e = getenv("GF_CONV_PAIR")) pair = atoi(e) != 0;
+    }
+};
+static const ConvKnobs& conv_knobs() {
+    static const ConvKnobs k;
+    return k;
+}
+
 extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
                            int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
                            const float* in_shift, const float* residual, float* out, void* stream) {
@@ -588,16 +605,17 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     // to fill 1024 SIMDs with several waves each): a workgroup per (group, <=2 column blocks), steps split
     // over its four waves.
     bool split = ngroups < 6000;
-    if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
+    const ConvKnobs& knobs = conv_knobs();
+    if (knobs.split >= 0) split = knobs.split != 0;
     // tiny levels (all items resident at once with room to spare): 16 waves per item, 4x shorter chains again
     // tiny levels (<= 256 workgroups of 16 waves, all resident at once): 16 waves share an item, each wave's chain
     // of gather batches is 4x shorter again (S150k levels 5-7: 13.5/15.8/16.0 -> 10.6/11.4/11.5 us)
     bool wide = split && (long long)ngroups * ncb <= 256;
-    if (const char* e = getenv("GF_CONV_WIDE")) wide = split && atoi(e) != 0;
+    if (knobs.wide >= 0) wide = split && knobs.wide != 0;
     const int ncbw = split ? (!wide && ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
     const int nsplit = (ncb + ncbw - 1) / ncbw;
     const long long nitems = (long long)ngroups * nsplit;
-    if (const char* e = getenv("GF_CONV_BLOCK")) g_conv_block = atoi(e) > 256 ? 256 : atoi(e);
+    if (knobs.block > 0) g_conv_block = knobs.block;
     const int wpb = g_conv_block / 64;
     long long blocks = split ? nitems : (nitems + wpb - 1) / wpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
@@ -609,9 +627,9 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     // LDS-resident weights: measured 10 % SLOWER than streaming them through L1 at C=16 (33.4 vs 30.3 us,
     // S150k level 1), so it is opt-in (GF_CONV_LDSW=1) until the staging cost is amortised differently
     bool ldsw = false;
-    if (const char* e = getenv("GF_CONV_LDSW")) ldsw = atoi(e) != 0 && !split && vec && ncb <= 2 && wbytes <= 64 * 1024;
+    if (knobs.ldsw) ldsw = !split && vec && ncb <= 2 && wbytes <= 64 * 1024;
     bool pair = !split && vec && ncb == 1 && nbr != nullptr && K <= 32 && nch <= 8 && in_bytes64 <= 0xfffff000ull - 4096ull;
-    if (const char* e = getenv("GF_CONV_PAIR")) pair = pair && atoi(e) != 0;
+    if (knobs.pair >= 0) pair = pair && knobs.pair != 0;
     if (pair && !ldsw) {
         const long long npairs = (ngroups + 1) / 2;
         long long pb = (npairs + 3) / 4;
