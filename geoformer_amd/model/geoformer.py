@@ -514,21 +514,31 @@ class GeoFormer(nn.Module):
                           semantic_scores_=None, logit_thresh=0.5, score_thresh=0.5, npoint_thresh=100, sem_prob=None):
         """Batch-1 proposal extraction (geoformer.py:193-262): score = mean mask prob * sqrt(cls prob) *
         mean semantic prob of the predicted class over the mask."""
-        sem = sem_prob if sem_prob is not None else F.softmax(semantic_scores_, dim=1)
         b = 0
-        num_points = int(batch_offsets[b + 1] - batch_offsets[b])
         if mask_logits[b].is_cuda and not torch.is_grad_enabled():
-            # inference: two fused HIP launches (csrc/proposal.hip) instead of ~40 PyTorch ones
-            offs_ = _offsets_list(batch_offsets_)
+            # inference: two fused HIP launches (csrc/proposal.hip) instead of ~40 PyTorch ones; the acceptance flags
+            # come back in one small copy and the row selection is made on the host (nonzero() on the device is six
+            # launches around its own read-back)
+            offs, offs_ = _offsets_list(batch_offsets), _offsets_list(batch_offsets_)
+            num_points = int(offs[b + 1] - offs[b])
             logits = mask_logits[b].contiguous()
+            if sem_prob is not None and isinstance(sem_prob, tuple):
+                sem_t = sem_prob[1][:, offs_[b]:offs_[b + 1]]  # class-major copy made early, off the critical path
+            else:
+                sem = sem_prob if sem_prob is not None else F.softmax(semantic_scores_, dim=1)
+                sem_t = sem[offs_[b]:offs_[b + 1]].t()
             cls_pred, _, scores, final = pointops.proposal_stats(
-                logits, cls_logits[b].contiguous(), sem[offs_[b]:offs_[b + 1]].contiguous(), logit_thresh,
-                score_thresh, npoint_thresh, min_class=4)
-            sel = torch.nonzero(final).view(-1)
-            if sel.numel() == 0:
+                logits, cls_logits[b].contiguous(), sem_t.contiguous(), logit_thresh, score_thresh, npoint_thresh,
+                min_class=4, class_major=True)
+            keep = np.flatnonzero(final.cpu().numpy())
+            if keep.size == 0:
                 return [], [], []
-            proposals = pointops.proposal_scatter(logits, sel.int(), fg_idxs.contiguous(), logit_thresh, num_points)
+            sel = torch.from_numpy(keep.astype(np.int32)).to(logits.device)
+            proposals = pointops.proposal_scatter(logits, sel, fg_idxs.contiguous(), logit_thresh, num_points)
+            sel = sel.long()
             return cls_pred[sel].long(), scores[sel], proposals
+        sem = sem_prob if sem_prob is not None and not isinstance(sem_prob, tuple) else F.softmax(semantic_scores_, dim=1)
+        num_points = int(batch_offsets[b + 1] - batch_offsets[b])
         mask_prob = mask_logits[b].sigmoid()
         cls_prob = F.softmax(cls_logits[b], dim=-1)
         cls_pred = torch.argmax(cls_logits[b], dim=-1)
@@ -596,7 +606,11 @@ class GeoFormer(nn.Module):
             mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
         # the kNN graphs need the points only: on the device they run under the host's RNG draw, and so does the
         # class-probability table the proposal scores read at the very end
-        sem_prob = F.softmax(semantic_scores_, dim=1) if not training else None
+        sem_prob = None
+        if not training:
+            sem_prob = F.softmax(semantic_scores_, dim=1)
+            if sem_prob.is_cuda:
+                sem_prob = (sem_prob, sem_prob.t().contiguous())  # + the class-major copy the proposal kernel reads
         graphs = None
         if locs_float_.is_cuda and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0:
             graphs = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)

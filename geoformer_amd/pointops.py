@@ -356,15 +356,17 @@ def decoder_token_state(nq, B, device):
     return torch.empty(_lib.load().gf_decoder_token_state_bytes(nq, B) // 4, dtype=torch.float32, device=device)
 
 
-def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh, npoint_thresh, min_class=4):
+def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh, npoint_thresh, min_class=4,
+                   class_major=False):
     """Fused statistics of generate_proposal: (cls_pred i32[nq], npoints i32[nq], scores f32[nq], final i32[nq]).
-    sem_prob [N,ncls] is handed to the kernel class-major (one coalesced row per predicted class)."""
+    sem_prob [N,ncls] is handed to the kernel class-major (one coalesced row per predicted class); pass it as
+    [ncls,N] with class_major=True when the caller already has that copy."""
     _f32c(mask_logits, "mask_logits"), _f32c(cls_logits, "cls_logits")
     nq, N = mask_logits.shape
     ncls = cls_logits.shape[1]
-    if sem_prob.shape != (N, ncls):
-        raise RuntimeError(f"sem_prob must be [{N},{ncls}], got {tuple(sem_prob.shape)}")
-    sem_prob = _f32c(sem_prob.t().contiguous(), "sem_prob")
+    if sem_prob.shape != ((ncls, N) if class_major else (N, ncls)):
+        raise RuntimeError(f"sem_prob must be [{N},{ncls}] ([{ncls},{N}] class-major), got {tuple(sem_prob.shape)}")
+    sem_prob = _f32c(sem_prob if class_major else sem_prob.t().contiguous(), "sem_prob")
     ints = torch.empty((3, nq), dtype=torch.int32, device=mask_logits.device)
     scores = torch.empty(nq, dtype=torch.float32, device=mask_logits.device)
     check(_lib.load().gf_proposal_stats(ptr(mask_logits), ptr(cls_logits), ptr(sem_prob), nq, N, ncls,
