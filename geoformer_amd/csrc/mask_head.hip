@@ -11,8 +11,8 @@
 // blocks of 64 points.  For a 16-point tile the feature part W1f_q[16x16] . F^T[16x16] is four
 // v_mfma_f32_16x16x4_f32 with the point on the column (lane&15): lane (g = lane>>4, j = lane&15) supplies
 // f_p[4g..4g+3] -- one 16-byte load per lane, reused by every query -- and the matching weight columns
-// 4g+s (the MFMA k index is only a summation index).  The 3 coordinate taps, bias, ReLU and the 16->1
-// contraction run on the accumulator layout (rows 4g..4g+3 per lane); the four row groups of the four
+// 4g+s (the MFMA k index is only a summation index).  The 3 coordinate taps and the bias are a fifth MFMA over
+// k = (rel_x, rel_y, rel_z, 1); ReLU and the 16->1 contraction run on the accumulator layout (rows 4g..4g+3 per lane); the four row groups of the four
 // tiles are combined with a two-step butterfly so lane (g,j) ends up with the logit of point 16g+j and
 // a wave stores 256 contiguous bytes per query.  Roofline: 4*(2*nq*N) bytes of geo/logit traffic
 // against 2*nq*N*(19*16+16) flops -> 80 flop/B: MFMA/VALU-bound, ~10 GFLOP per 150k-point scene.
@@ -43,39 +43,35 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
     const int per = (nblocks + chunks - 1) / chunks;
     const int blk0 = chunk * per, blk1 = min(nblocks, blk0 + per);
 
-    // per-query parameters in registers
-    float wf[MH_Q][4];      // A operand: W1[q][c=j][3 + 4g + s]
-    float wc[MH_Q][4][3];   // coordinate taps of rows c = 4g + r
-    float bb[MH_Q][4], ww[MH_Q][4], b2q[MH_Q], qx[MH_Q], qy[MH_Q], qz[MH_Q], mq[MH_Q];
+    // per-query parameters in registers.  The three coordinate taps and the bias ride in a FIFTH MFMA whose k index
+    // runs over (rel_x, rel_y, rel_z, 1): lane group g supplies component g of the relative position of point j (its
+    // own coordinate of the point only -- one load, one subtract, one select) and the matching weight column
+    // W1[q][j][g] (g = 3: the bias b1[q][j]).  The first version applied the taps to the accumulator rows on the VALU
+    // (twelve fma per lane and tile): 42 VALU instructions per tile and query against 20 MFMA passes.
+    float wf[MH_Q][4];  // A operand of the feature part: W1[q][c=j][3 + 4g + s]
+    float w5[MH_Q];     // A operand of the coordinate part: W1[q][j][g] (g < 3), b1[q][j] (g = 3)
+    float ww[MH_Q][4], b2q[MH_Q], qc[MH_Q], mq[MH_Q];
 #pragma unroll
     for (int t = 0; t < MH_Q; t++) {
         const int q = min(qg * MH_Q + t, nq - 1);
         const float* W = w1 + (size_t)q * 16 * 19;
 #pragma unroll
         for (int s = 0; s < 4; s++) wf[t][s] = W[j * 19 + 3 + 4 * g + s];
+        w5[t] = g < 3 ? W[j * 19 + g] : b1[(size_t)q * 16 + j];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int c = 4 * g + r;
-            wc[t][r][0] = W[c * 19 + 0];
-            wc[t][r][1] = W[c * 19 + 1];
-            wc[t][r][2] = W[c * 19 + 2];
-            bb[t][r] = b1[(size_t)q * 16 + c];
-            ww[t][r] = w2[(size_t)q * 16 + c];
-        }
+        for (int r = 0; r < 4; r++) ww[t][r] = w2[(size_t)q * 16 + 4 * g + r];
         b2q[t] = b2[q];
-        qx[t] = qxyz[q * 3 + 0];
-        qy[t] = qxyz[q * 3 + 1];
-        qz[t] = qxyz[q * 3 + 2];
+        qc[t] = g < 3 ? qxyz[q * 3 + g] : 0.f;
         mq[t] = USE_GEO ? mx[q] : 0.f;
     }
 
-    // Operands of one 64-point block: features (B operand) and coordinates of column j for the four 16-point tiles,
-    // and the block's geodesic distances for this wave's queries.  Everything a block needs is requested in one go,
-    // one block ahead of the arithmetic (a load inside the per-tile code would expose one HBM round trip per tile
-    // and query: the first version of this loop spent most of its time there).
+    // Operands of one 64-point block: features (B operand) and this lane group's coordinate of column j for the four
+    // 16-point tiles, and the block's geodesic distances for this wave's queries.  Everything a block needs is
+    // requested in one go, one block ahead of the arithmetic (a load inside the per-tile code would expose one HBM
+    // round trip per tile and query: an earlier version of this loop spent most of its time there).
     struct Block {
         float4 f[4];
-        float px[4], py[4], pz[4];
+        float pc[4];
         float gd[MH_Q][4];
     };
     auto fetch = [&](int blk, Block& B) {
@@ -84,9 +80,7 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
         for (int t = 0; t < 4; t++) {
             const int pc = min(p0 + 16 * t + j, N - 1);
             B.f[t] = *reinterpret_cast<const float4*>(feat + (size_t)pc * 16 + 4 * g);
-            B.px[t] = coords[(size_t)pc * 3 + 0];
-            B.py[t] = coords[(size_t)pc * 3 + 1];
-            B.pz[t] = coords[(size_t)pc * 3 + 2];
+            B.pc[t] = coords[(size_t)pc * 3 + min(g, 2)];
 #pragma unroll
             for (int u = 0; u < MH_Q; u++)
                 B.gd[u][t] = USE_GEO ? geo[(size_t)min(qg * MH_Q + u, nq - 1) * N + pc] : 0.f;
@@ -103,28 +97,22 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
             float part[4];
 #pragma unroll
             for (int tl = 0; tl < 4; tl++) {
-                f32x4 acc = (f32x4){bb[t][0], bb[t][1], bb[t][2], bb[t][3]};
+                float rel = qc[t] - cur.pc[tl];
+                if (USE_GEO) {
+                    // unreachable point: rel += sqrt(max_geo_q) * sign(rel), sign(0) = 0  (branch-free)
+                    const float m = cur.gd[t][tl] < 0.f ? mq[t] : 0.f;
+                    rel = rel + m * (rel > 0.f ? 1.f : (rel < 0.f ? -1.f : 0.f));
+                }
+                if (g == 3) rel = 1.0f;  // the bias row
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w5[t], rel, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][0], cur.f[tl].x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][1], cur.f[tl].y, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][2], cur.f[tl].z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][3], cur.f[tl].w, acc, 0, 0, 0);
-                float rx = qx[t] - cur.px[tl], ry = qy[t] - cur.py[tl], rz = qz[t] - cur.pz[tl];
-                if (USE_GEO) {
-                    // unreachable point: rel += sqrt(max_geo_q) * sign(rel), sign(0) = 0  (branch-free)
-                    const float m = cur.gd[t][tl] < 0.f ? mq[t] : 0.f;
-                    rx = rx + m * (rx > 0.f ? 1.f : (rx < 0.f ? -1.f : 0.f));
-                    ry = ry + m * (ry > 0.f ? 1.f : (ry < 0.f ? -1.f : 0.f));
-                    rz = rz + m * (rz > 0.f ? 1.f : (rz < 0.f ? -1.f : 0.f));
-                }
                 float s = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float h = acc[r];
-                    h = fmaf(wc[t][r][0], rx, h);
-                    h = fmaf(wc[t][r][1], ry, h);
-                    h = fmaf(wc[t][r][2], rz, h);
-                    s = fmaf(ww[t][r], fmaxf(h, 0.f), s);
-                }
+                for (int r = 0; r < 4; r++) s = fmaf(ww[t][r], fmaxf(acc[r], 0.f), s);
                 part[tl] = s;
             }
             // butterfly over the four row groups: afterwards lane (g,j) holds the full sum of tile g
