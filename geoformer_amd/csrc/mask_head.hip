@@ -27,6 +27,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MH_MINB 3
 #endif
 
+// value of lane (i ^ 32) / (i ^ 16): one v_permlane{32,16}_swap (VALU) instead of a trip through the LDS crossbar
+__device__ __forceinline__ float mh_xor32(float v, int lane) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(lane < 32 ? r[1] : r[0]);
+}
+__device__ __forceinline__ float mh_xor16(float v, int lane) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float((lane & 16) ? r[0] : r[1]);
+}
+
 template <bool USE_GEO>
 __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restrict__ feat, const float* __restrict__ coords,
                                                       const float* __restrict__ geo, const float* __restrict__ qxyz,
@@ -120,12 +130,12 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
                 // step 1 (xor 32): groups {0,1} keep tiles {0,1}, groups {2,3} keep tiles {2,3}
                 const bool hi = g >= 2;
                 const float send0 = hi ? part[0] : part[2], send1 = hi ? part[1] : part[3];
-                const float r0 = __shfl_xor(send0, 32, 64), r1 = __shfl_xor(send1, 32, 64);
+                const float r0 = mh_xor32(send0, lane), r1 = mh_xor32(send1, lane);
                 const float k0 = (hi ? part[2] : part[0]) + r0, k1 = (hi ? part[3] : part[1]) + r1;
                 // step 2 (xor 16): even group keeps the first of its pair, odd group the second
                 const bool odd = g & 1;
                 const float send = odd ? k0 : k1;
-                const float r = __shfl_xor(send, 16, 64);
+                const float r = mh_xor16(send, lane);
                 const float tot = (odd ? k1 : k0) + r + b2q[t];
                 const int p = p0 + 16 * g + j;
                 if (p < N && q < nq) out[(size_t)q * N + p] = tot;
