@@ -295,7 +295,7 @@ class GeoFormer(nn.Module):
             return context_locs, context_feats, pre_enc_inds
 
     def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step,
-                                       pc_dims=None):
+                                       pc_dims=None, sample=True, epilogue=True):
         """Inference on the GPU.  Furthest point sampling (2047 serial rounds on 16 compute units) and the geodesic
         BFS (<= 256 serial hops, one workgroup per query) are the two long latency-bound launches of the forward, and
         the BFS only needs the first n_query_points picks.  So the sampling is cut after those picks, the BFS goes
@@ -303,7 +303,9 @@ class GeoFormer(nn.Module):
         free: gf_geodesic_bfs_cfg), and the rest of the sampling, ball query, grouping, the shared MLP and the
         decoder's input projections run beside it on the main stream, which joins where the decoder first needs the
         distances (relative_position_embedding).  Same values as forward_aggregator + cal_geodesic, same consumption
-        of the host RNG.  GF_OVERLAP=2 keeps the sampling in one piece and starts the BFS after it."""
+        of the host RNG.  GF_OVERLAP=2 keeps the sampling in one piece and starts the BFS after it.
+        sample=False: no random sub-sampling of the scene's points first (GeoFormerFS, geoformer_fs.py:300-318);
+        epilogue=False: none of the small side-stream launches whose results GeoFormer.forward picks up later."""
         offs = _offsets_list(batch_offsets_)
         nq = self.cfg.n_query_points
         npoint_sa = self.set_aggregator.npoint
@@ -318,12 +320,16 @@ class GeoFormer(nn.Module):
             n_b = offs[b + 1] - offs[b]
             if n_b == 0:
                 return None, None
-            npoint = min(n_b, self.cfg.n_downsampling)
-            # the reference's host draw (same values, same generator state), restated natively: the device idles on it
-            sampling_indices = torch.tensor(pointops.legacy_choice(n_b, npoint), dtype=torch.long,
-                                            device=locs_float_.device)
-            self.last_sampling_indices = sampling_indices
-            xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
+            if sample:
+                npoint = min(n_b, self.cfg.n_downsampling)
+                # the reference's host draw (same values, same generator state), restated natively: the device idles on it
+                sampling_indices = torch.tensor(pointops.legacy_choice(n_b, npoint), dtype=torch.long,
+                                                device=locs_float_.device)
+                self.last_sampling_indices = sampling_indices
+                xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
+            else:
+                sampling_indices = None
+                xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
             first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
             src = first[0, :nq].contiguous()
             side.wait_stream(main)
@@ -336,8 +342,13 @@ class GeoFormer(nn.Module):
             # the rest of the sampling is on the critical path: issue it before anything else
             idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
             # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
-            feat_b = output_feats_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).transpose(1, 2).contiguous()
+            feat_b = output_feats_[offs[b]:offs[b + 1]]
+            if sampling_indices is not None:
+                feat_b = feat_b[sampling_indices]
+            feat_b = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
             staged.append((xyz_b, feat_b, idx))
+            if not epilogue:
+                continue
             with torch.cuda.stream(side):
                 # small launches that only need the distances / the query picks ride in the BFS's shadow instead of
                 # sitting between the decoder and the mask head on the main stream

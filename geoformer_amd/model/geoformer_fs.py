@@ -13,13 +13,15 @@ from __future__ import annotations
 
 import functools
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import config as _config
 from .backbone import random_downsample
 from .. import pointops
-from .geoformer import GeoFormer, _offsets_list, cal_geodesic, get_batch_offsets
+from .geoformer import GeoFormer, _offsets_list, cal_geodesic, get_batch_offsets, knn_graphs
 from .layers import BatchNorm1d, GenericMLP
 
 
@@ -164,15 +166,27 @@ class GeoFormerFS(GeoFormer):
             ctx = torch.enable_grad if self.training and "mask_tower" not in self.fix_module else torch.no_grad
             with ctx():
                 mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
-            contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
+            max_step = 128 if self.training else 256
+            geo_dists = None
+            offs_ = _offsets_list(batch_offsets_)
+            if (locs_float_.is_cuda and not torch.is_grad_enabled() and os.environ.get("GF_OVERLAP", "1") != "0"
+                    and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0):
+                # inference on the GPU: sampling cut after the query picks, BFS beside the rest of it (GeoFormer)
+                graphs = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
+                contexts, geo_dists = self._aggregate_geodesic_overlapped(
+                    locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step, sample=False,
+                    epilogue=False)
+                self._join_side_stream()
+            else:
+                contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
             if contexts is None:
                 outputs["mask_predictions"] = None
                 return outputs
             context_locs, context_feats, pre_enc_inds = contexts
             query_locs = context_locs[:, :cfg.n_query_points, :]
-            geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_,
-                                     max_step=128 if self.training else 256, neighbor=64, radius=0.05,
-                                     n_queries=cfg.n_query_points)
+            if geo_dists is None:
+                geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=max_step, neighbor=64,
+                                         radius=0.05, n_queries=cfg.n_query_points)
             self.cache_data = (context_locs, context_feats, pre_enc_inds, fg_idxs, batch_offsets, output_feats_,
                                batch_idxs_, locs_float_, batch_offsets_, semantic_preds_, semantic_scores, query_locs,
                                mask_features_, geo_dists)
