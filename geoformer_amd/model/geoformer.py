@@ -307,6 +307,7 @@ class GeoFormer(nn.Module):
         sample=False: no random sub-sampling of the scene's points first (GeoFormerFS, geoformer_fs.py:300-318);
         epilogue=False: none of the small side-stream launches whose results GeoFormer.forward picks up later."""
         offs = _offsets_list(batch_offsets_)
+        grad_ctx = self._grad_ctx("set_aggregator")  # like forward_aggregator: no graph through a frozen aggregator
         nq = self.cfg.n_query_points
         npoint_sa = self.set_aggregator.npoint
         split = os.environ.get("GF_OVERLAP", "1") != "2" and npoint_sa > nq
@@ -342,10 +343,11 @@ class GeoFormer(nn.Module):
             # the rest of the sampling is on the critical path: issue it before anything else
             idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
             # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
-            feat_b = output_feats_[offs[b]:offs[b + 1]]
-            if sampling_indices is not None:
-                feat_b = feat_b[sampling_indices]
-            feat_b = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
+            with grad_ctx():
+                feat_b = output_feats_[offs[b]:offs[b + 1]]
+                if sampling_indices is not None:
+                    feat_b = feat_b[sampling_indices]
+                feat_b = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
             staged.append((xyz_b, feat_b, idx))
             if not epilogue:
                 continue
@@ -355,17 +357,18 @@ class GeoFormer(nn.Module):
                 self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main)
         self.__dict__["_gf_pending_side"] = side
         cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
-        fused = [self.set_aggregator.fused_forward(xyz_b, feat_b, idx) for xyz_b, feat_b, idx in staged]
-        if all(f is not None for f in fused):
-            context_locs, pre_enc_inds = cat([f[0] for f in fused]), cat([st[2] for st in staged])
-            context_feats = cat([f[1] for f in fused]).transpose(1, 2)
-            return (context_locs, context_feats, pre_enc_inds), geo
-        locs, gfeat, gxyz, inds = [], [], [], []
-        for xyz_b, feat_b, idx in staged:
-            l, gf, gx, idx = self.set_aggregator.group_points(xyz_b, feat_b, inds=idx)
-            locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
-        context_locs, pre_enc_inds = cat(locs), cat(inds)
-        context_feats = self.set_aggregator.mlp(cat(gfeat), cat(gxyz)).transpose(1, 2)
+        with grad_ctx():
+            fused = [self.set_aggregator.fused_forward(xyz_b, feat_b, idx) for xyz_b, feat_b, idx in staged]
+            if all(f is not None for f in fused):
+                context_locs, pre_enc_inds = cat([f[0] for f in fused]), cat([st[2] for st in staged])
+                context_feats = cat([f[1] for f in fused]).transpose(1, 2)
+                return (context_locs, context_feats, pre_enc_inds), geo
+            locs, gfeat, gxyz, inds = [], [], [], []
+            for xyz_b, feat_b, idx in staged:
+                l, gf, gx, idx = self.set_aggregator.group_points(xyz_b, feat_b, inds=idx)
+                locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
+            context_locs, pre_enc_inds = cat(locs), cat(inds)
+            context_feats = self.set_aggregator.mlp(cat(gfeat), cat(gxyz)).transpose(1, 2)
         return (context_locs, context_feats, pre_enc_inds), geo
 
     def _side_epilogue(self, b, batch_size, g, xyz_b, src, pc_dims, main):
@@ -628,9 +631,11 @@ class GeoFormer(nn.Module):
 
         max_step = 128 if self.training else 256
         geo_dists = None
-        if graphs is not None and not torch.is_grad_enabled() and os.environ.get("GF_OVERLAP", "1") != "0":
+        if graphs is not None and os.environ.get("GF_OVERLAP", "1") != "0":
+            # (training too: sampling and BFS carry no gradient; grouping and the shared MLP stay PyTorch autograd)
             contexts, geo_dists = self._aggregate_geodesic_overlapped(locs_float_, output_feats_, batch_offsets_,
-                                                                      batch_size, graphs, max_step, pc_dims)
+                                                                      batch_size, graphs, max_step, pc_dims,
+                                                                      epilogue=not torch.is_grad_enabled())
         else:
             contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
         if contexts is None:
