@@ -159,13 +159,47 @@ struct PmGather {
     int n, C, use_xyz;
     float inv_radius;  // 1/radius with normalize_xyz (torch divides by a Python scalar as a * (1/b)), else 1
 };
+// The layers' weights are staged once per workgroup in LDS, zero-padded to multiples of 16 in both dimensions with a
+// row stride of cin_padded + 4 floats: the A operand of four MFMAs is then ONE aligned ds_read_b128 without predicates.
+// Reading them in place (row-major [cout, cin] with cin = 3 + C = 35 for the set-abstraction MLP: unaligned rows)
+// took four predicated scalar loads per operand, 72 per 16-sample tile and lane -- the kernel spent its time there.
+#define GM_WSTRIDE(cinp) ((cinp) + 4)
 template <bool GATHER>
 __global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__ grouped, int B, int np, int ns,
                                                        PmArgs A, PmGather Gx, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];  // per layer: W [coutp][cinp + 4], scale, shift [coutp]
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const int c0 = A.L[0].cin, cl = A.L[A.nl - 1].cout;
     const size_t cstride = (size_t)np * ns;
+    int woff[PM_MAXL], soff[PM_MAXL];
+    {
+        int cur = 0;
+#pragma unroll
+        for (int l = 0; l < PM_MAXL; l++) {
+            if (l >= A.nl) break;
+            const int cinp = (A.L[l].cin + 15) & ~15, coutp = (A.L[l].cout + 15) & ~15;
+            woff[l] = cur;
+            cur += coutp * GM_WSTRIDE(cinp);
+            soff[l] = cur;
+            cur += 2 * coutp;
+        }
+#pragma unroll
+        for (int l = 0; l < PM_MAXL; l++) {
+            if (l >= A.nl) break;
+            const PmLayer& L = A.L[l];
+            const int cinp = (L.cin + 15) & ~15, coutp = (L.cout + 15) & ~15, ws = GM_WSTRIDE(cinp);
+            for (int t = threadIdx.x; t < coutp * cinp; t += blockDim.x) {
+                const int r = t / cinp, c = t - r * cinp;
+                s_w[woff[l] + r * ws + c] = (r < L.cout && c < L.cin) ? L.W[(size_t)r * L.cin + c] : 0.f;
+            }
+            for (int t = threadIdx.x; t < coutp; t += blockDim.x) {
+                s_w[soff[l] + t] = t < L.cout ? L.scale[t] : 0.f;
+                s_w[soff[l] + coutp + t] = t < L.cout ? L.shift[t] : 0.f;
+            }
+        }
+        __syncthreads();
+    }
     for (int item = wave; item < B * np; item += nwaves) {
         const int b = item / np, pt = item - b * np;
         const float* gp = GATHER ? nullptr : grouped + (size_t)b * c0 * cstride + (size_t)pt * ns;
@@ -206,39 +240,33 @@ __global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__
             for (int l = 0; l < PM_MAXL; l++) {
                 if (l >= A.nl) break;
                 const PmLayer& L = A.L[l];
+                const int cinp = (L.cin + 15) & ~15, coutp = (L.cout + 15) & ~15, ws = GM_WSTRIDE(cinp);
+                const float* Wl = s_w + woff[l];
+                const float* Sl = s_w + soff[l];
                 float4 o[PM_MAXC / 16];
 #pragma unroll
                 for (int ct = 0; ct < PM_MAXC / 16; ct++) {
                     o[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (ct * 16 >= L.cout) continue;
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    const int row = ct * 16 + j;
+                    const float* wrow = Wl + (ct * 16 + j) * ws + 4 * g;
 #pragma unroll
                     for (int kc = 0; kc < PM_MAXC / 16; kc++) {
                         if (kc * 16 >= L.cin) continue;
-                        float a[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (row < L.cout) {
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const int k = kc * 16 + 4 * g + i;
-                                if (k < L.cin) a[i] = L.W[(size_t)row * L.cin + k];
-                            }
-                        }
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], h[kc].x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], h[kc].y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], h[kc].z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], h[kc].w, acc, 0, 0, 0);
+                        const float4 a = *reinterpret_cast<const float4*>(wrow + kc * 16);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, h[kc].x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, h[kc].y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, h[kc].z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, h[kc].w, acc, 0, 0, 0);
                     }
-                    float r[4];
+                    // padded channels: scale = shift = 0 -> 0 (also after the ReLU)
+                    const float4 sc = *reinterpret_cast<const float4*>(Sl + ct * 16 + 4 * g);
+                    const float4 sh = *reinterpret_cast<const float4*>(Sl + coutp + ct * 16 + 4 * g);
+                    float r[4] = {fmaf(acc[0], sc.x, sh.x), fmaf(acc[1], sc.y, sh.y), fmaf(acc[2], sc.z, sh.z),
+                                  fmaf(acc[3], sc.w, sh.w)};
+                    if (L.relu) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int ch = ct * 16 + 4 * g + i;
-                        float v = 0.f;
-                        if (ch < L.cout) {
-                            v = fmaf(acc[i], L.scale[ch], L.shift[ch]);
-                            if (L.relu) v = fmaxf(v, 0.f);
-                        }
-                        r[i] = v;
+                        for (int i = 0; i < 4; i++) r[i] = fmaxf(r[i], 0.f);
                     }
                     o[ct] = make_float4(r[0], r[1], r[2], r[3]);
                 }
@@ -262,6 +290,24 @@ __global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__
                     if (ch < cl) out[((size_t)b * cl + ch) * np + pt] = best[ct][i];
                 }
         }
+    }
+}
+
+static size_t gm_lds_bytes(const PmArgs& A) {
+    size_t n = 0;
+    for (int l = 0; l < A.nl; l++) {
+        const size_t cinp = (A.L[l].cin + 15) & ~15, coutp = (A.L[l].cout + 15) & ~15;
+        n += coutp * GM_WSTRIDE(cinp) + 2 * coutp;
+    }
+    return n * sizeof(float);  // <= 4 * (64 * 68 + 128) * 4 = 71 KB worst case, ~20 KB for the set-abstraction MLP
+}
+template <bool GATHER>
+static void gm_allow_lds() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute((const void*)k_group_mlp_max<GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  96 * 1024);
+        done = true;
     }
 }
 
@@ -291,9 +337,10 @@ extern "C" int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsa
     if (B == 0 || npoint == 0) return GF_OK;
     long long items = (long long)B * npoint;
     int blocks = (int)((items + 3) / 4);
-    if (blocks > 256 * 4) blocks = 256 * 4;
-    hipLaunchKernelGGL(k_group_mlp_max<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grouped, B, npoint,
-                       nsample, A, PmGather{}, out);
+    if (blocks > 256 * 2) blocks = 256 * 2;  // the weight image is staged once per workgroup
+    gm_allow_lds<false>();
+    hipLaunchKernelGGL(k_group_mlp_max<false>, dim3(blocks), dim3(256), gm_lds_bytes(A), (hipStream_t)stream, grouped, B,
+                       npoint, nsample, A, PmGather{}, out);
     GF_CHECK_LAUNCH("gf_group_mlp_max");
     return GF_OK;
 }
@@ -322,9 +369,10 @@ extern "C" int gf_sa_group_mlp_max(const float* xyz, const float* feats, const i
     PmGather Gx{xyz, feats, new_xyz, idx, n, C, use_xyz, normalize_xyz ? 1.0f / radius : 1.0f};
     long long items = (long long)B * npoint;
     int blocks = (int)((items + 3) / 4);
-    if (blocks > 256 * 4) blocks = 256 * 4;
-    hipLaunchKernelGGL(k_group_mlp_max<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, nullptr, B, npoint,
-                       nsample, A, Gx, out);
+    if (blocks > 256 * 2) blocks = 256 * 2;
+    gm_allow_lds<true>();
+    hipLaunchKernelGGL(k_group_mlp_max<true>, dim3(blocks), dim3(256), gm_lds_bytes(A), (hipStream_t)stream, nullptr, B,
+                       npoint, nsample, A, Gx, out);
     GF_CHECK_LAUNCH("gf_sa_group_mlp_max");
     return GF_OK;
 }
