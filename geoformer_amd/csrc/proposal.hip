@@ -208,3 +208,56 @@ extern "C" int gf_mask_intersections(const int32_t* masks, int n, int N, void* s
     GF_CHECK_LAUNCH("gf_mask_intersections");
     return GF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Ingredients of the decoder's relative position embedding (GeoFormer.forward_decoder, geoformer.py:619-651), for
+// one scene:  geo_ctx[q, j] = geo[q, inds[j]]  (geodesic distance from query q to context point j) and
+// max_geo[q] = max_j geo_ctx[q, j], replaced by the largest row maximum where a row is entirely unreachable (< 0).
+// PyTorch: index, copy, max, max, compare, where, copy -- seven launches between the set abstraction and the first
+// cross-attention; here one launch per step of the dependency (row maxima, then the fix-up over nq values).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relpos_gather(const float* __restrict__ geo, const int32_t* __restrict__ inds,
+                                                       int n, int nc, float* __restrict__ geo_ctx,
+                                                       float* __restrict__ row_max) {
+    __shared__ float s_m[4];
+    const int q = blockIdx.x;
+    const float* g = geo + (size_t)q * n;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < nc; j += 256) {
+        const float v = g[inds[j]];
+        geo_ctx[(size_t)q * nc + j] = v;
+        m = fmaxf(m, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) row_max[q] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
+__global__ __launch_bounds__(1024) void k_relpos_fix(float* __restrict__ row_max, int nq) {
+    __shared__ float s_m[16];
+    float m = -INFINITY;
+    for (int q = threadIdx.x; q < nq; q += 1024) m = fmaxf(m, row_max[q]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float all = s_m[0];
+#pragma unroll
+    for (int w = 1; w < 16; w++) all = fmaxf(all, s_m[w]);
+    for (int q = threadIdx.x; q < nq; q += 1024)
+        if (row_max[q] < 0.f) row_max[q] = all;
+}
+
+extern "C" int gf_relpos_prepare(const float* geo, const int32_t* inds, int nq, int n, int nc, float* geo_ctx,
+                                 float* max_geo, void* stream) {
+    GF_CHECK_ARG(geo && inds && geo_ctx && max_geo, "gf_relpos_prepare: null argument");
+    GF_CHECK_ARG(nq >= 0 && n >= 1 && nc >= 1, "gf_relpos_prepare: bad sizes");
+    if (nq == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_relpos_gather, dim3(nq), dim3(256), 0, st, geo, inds, n, nc, geo_ctx, max_geo);
+    hipLaunchKernelGGL(k_relpos_fix, dim3(1), dim3(1024), 0, st, max_geo, nq);
+    GF_CHECK_LAUNCH("gf_relpos_prepare");
+    return GF_OK;
+}

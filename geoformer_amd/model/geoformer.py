@@ -402,9 +402,13 @@ class GeoFormer(nn.Module):
         self._join_side_stream()  # the geodesic distances may still be in flight on the second stream
         if context_locs.is_cuda and self.cfg.dec_dim == 64 and not torch.is_grad_enabled():
             # inference: hand the fused cross-attention kernel the ingredients instead of the 134 MB tensor
-            geo = torch.stack([geo_dists[b][:, pre_enc_inds[b].long()] for b in range(B)], dim=0).contiguous()
-            max_geo = torch.max(geo, dim=2)[0]
-            max_geo = torch.where(max_geo < 0, torch.max(max_geo), max_geo).contiguous()
+            if B == 1 and pre_enc_inds.dtype == torch.int32:
+                g1, m1 = pointops.relpos_prepare(geo_dists[0].contiguous(), pre_enc_inds[0].contiguous())
+                geo, max_geo = g1.unsqueeze(0), m1.unsqueeze(0)
+            else:
+                geo = torch.stack([geo_dists[b][:, pre_enc_inds[b].long()] for b in range(B)], dim=0).contiguous()
+                max_geo = torch.max(geo, dim=2)[0]
+                max_geo = torch.where(max_geo < 0, torch.max(max_geo), max_geo).contiguous()
             return RelPosSpec(geo, max_geo, query_locs.contiguous(), context_locs.contiguous(),
                               pc_dims[0].float().contiguous(), pc_dims[1].float().contiguous(),
                               self.pos_embedding.gauss_B.contiguous())

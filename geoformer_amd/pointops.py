@@ -388,6 +388,19 @@ def proposal_scatter(mask_logits, sel, fg_idxs, logit_thresh, num_points):
     return out
 
 
+def relpos_prepare(geo, inds):
+    """(geo_ctx [nq,nc], max_geo [nq]) of one scene: geo[:, inds] and its row maxima with all-unreachable rows set to
+    the largest maximum (ingredients of the relative position embedding, csrc/proposal.hip)."""
+    _f32c(geo, "geo"); _i32c(inds, "inds")
+    nq, n = geo.shape
+    nc = inds.shape[0]
+    geo_ctx = torch.empty((nq, nc), dtype=torch.float32, device=geo.device)
+    max_geo = torch.empty(nq, dtype=torch.float32, device=geo.device)
+    check(_lib.load().gf_relpos_prepare(ptr(geo), ptr(inds), nq, n, nc, ptr(geo_ctx), ptr(max_geo), stream_ptr()),
+          "gf_relpos_prepare")
+    return geo_ctx, max_geo
+
+
 def mask_intersections(masks):
     """inter[i,j] = |mask_i AND mask_j| for 0/1 int32 masks [n,N] (bit-packed popcount kernel)."""
     _i32c(masks, "masks")

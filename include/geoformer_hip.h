@@ -351,6 +351,12 @@ int gf_proposal_stats(const float* mask_logits, const float* cls_logits, const f
 int gf_proposal_scatter(const float* mask_logits, const int* sel, int n_sel, int N, const long long* fg_idxs,
                         float logit_thresh, int num_points, int* proposals, void* stream);
 
+/* Ingredients of the decoder's relative position embedding for one scene (geoformer.py:619-651):
+ *   geo_ctx[q,j] = geo[q, inds[j]]   (geo fp32 [nq,n], inds int32 [nc] = the context points' FPS indices),
+ *   max_geo[q]   = max_j geo_ctx[q,j], or the largest such maximum where row q is entirely unreachable (< 0). */
+int gf_relpos_prepare(const float* geo, const int32_t* inds, int nq, int n, int nc, float* geo_ctx, float* max_geo,
+                      void* stream);
+
 /* inter[i,j] = number of points in both proposal i and proposal j (matrix NMS, util/utils_3d.py:95-141: the
  * einsum over the [n,N] float masks; exact because the masks are 0/1).  masks int32 [n,N] (gf_proposal_scatter
  * output), inter int32 [n,n], scratch: gf_mask_intersections_scratch_bytes(n, N). */

@@ -318,6 +318,26 @@ def test_select_foreground_fused(hip, N, equal):
     assert none[0].numel() == 0 and none[3].shape == (0, 16)
 
 
+def test_relpos_prepare(hip):
+    """gf_relpos_prepare vs the PyTorch sequence of relative_position_embedding (geoformer.py:619-651)."""
+    from geoformer_amd import pointops
+
+    g = torch.Generator().manual_seed(9)
+    nq, n, nc = 37, 5001, 777
+    geo = torch.rand(nq, n, generator=g)
+    geo[geo < 0.4] = -1.0
+    geo[5] = -1.0  # a query that reaches nothing: gets the largest row maximum
+    inds = torch.randint(0, n, (nc,), generator=g).int()
+    ref = geo[:, inds.long()]
+    mx = ref.max(1)[0]
+    mx = torch.where(mx < 0, mx.max(), mx)
+    got, gm = pointops.relpos_prepare(geo.cuda(), inds.cuda())
+    assert torch.equal(got.cpu(), ref) and torch.equal(gm.cpu(), mx)
+    allneg = -torch.ones(4, 50)
+    _, gm2 = pointops.relpos_prepare(allneg.cuda(), torch.arange(20).int().cuda())
+    assert (gm2.cpu() == -1).all()
+
+
 def test_matrix_nms_gpu(hip, oracle):
     """Bit-packed intersection kernel vs the oracle (exact), and the GPU matrix NMS vs the reference golden."""
     import os
