@@ -19,6 +19,16 @@ void gf_set_error(const char* fmt, ...);
         }                                \
     } while (0)
 
+// a HIP runtime call whose failure must not pass silently (memsets / copies queued next to the launches)
+#define GF_TRY(call)                                                             \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess) {                                                 \
+            gf_set_error("%s failed: %s", #call, hipGetErrorString(e__));        \
+            return GF_ERR_LAUNCH;                                                \
+        }                                                                        \
+    } while (0)
+
 #define GF_CHECK_LAUNCH(name)                                                        \
     do {                                                                             \
         hipError_t e__ = hipGetLastError();                                          \

@@ -149,7 +149,7 @@ extern "C" int gf_fg_select(const float* scores, int N, int C, int cls, int mode
     int32_t* block_counts = (int32_t*)(flags + ((size_t)N + 63) / 64 * 64);
     int32_t* block_offs = block_counts + nb;
     if (N == 0) {
-        (void)hipMemsetAsync(d_count, 0, sizeof(int32_t), st);
+        GF_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t), st));
         return GF_OK;
     }
     hipLaunchKernelGGL(k_fg_flags, dim3(nb), dim3(FG_THREADS), 0, st, scores, N, C, cls, mode, flags, block_counts);

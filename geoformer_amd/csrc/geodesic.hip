@@ -222,8 +222,8 @@ extern "C" int gf_knn_radius(const float* xyz, int n, int k, float radius, int s
     float4* sorted = (float4*)sp;
     const float cell = radius * 1.001f;
     const float inv_cell = 1.0f / cell;
-    hipMemsetAsync(counts, 0, (size_t)T * sizeof(int32_t), st);
-    hipMemsetAsync(err, 0, sizeof(int), st);
+    GF_TRY(hipMemsetAsync(counts, 0, (size_t)T * sizeof(int32_t), st));
+    GF_TRY(hipMemsetAsync(err, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_grid_count, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, n, inv_cell, T - 1, counts);
     hipLaunchKernelGGL(k_iscan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, counts, (int)T, block_sums);
     hipLaunchKernelGGL(k_iscan_top, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, block_off);
@@ -577,7 +577,7 @@ extern "C" int gf_ballquery_batch_p(const float* xyz, const int32_t* batch_idxs,
     GF_CHECK_ARG(n >= 0 && meanActive >= 1, "gf_ballquery_batch_p: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
-        hipMemsetAsync(d_cumsum, 0, sizeof(int32_t), st);
+        GF_TRY(hipMemsetAsync(d_cumsum, 0, sizeof(int32_t), st));
         return GF_OK;
     }
     const int nb = (n + ISCAN_IPB - 1) / ISCAN_IPB;
@@ -591,7 +591,7 @@ extern "C" int gf_ballquery_batch_p(const float* xyz, const int32_t* batch_idxs,
     hipLaunchKernelGGL(k_iscan_top, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, block_off);
     // start[] and a throw-away cursor copy (idx is large enough to take it: it is overwritten by the fill)
     hipLaunchKernelGGL(k_iscan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, cnt, n, block_off, start, start_len);
-    hipMemcpyAsync(d_cumsum, start + n, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    GF_TRY(hipMemcpyAsync(d_cumsum, start + n, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_bqb_fill, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, batch_idxs, batch_offsets, n, r2,
                        start, cnt, (long long)n * meanActive, idx, start_len);
     GF_CHECK_LAUNCH("gf_ballquery_batch_p");

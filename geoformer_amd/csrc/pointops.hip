@@ -703,7 +703,7 @@ extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n,
     GF_CHECK_ARG(P <= 16, "gf_furthest_point_sampling: n=%d too large (max %d)", n, FPS_MAXG * per_wg * 16);
     unsigned long long* slots = (unsigned long long*)scratch;
     int* err = (int*)(slots + (size_t)b * 2 * FPS_MAXG * FPS_KPUB);
-    hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), st);
+    GF_TRY(hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), st));
     const int per_launch = 1024 / (G * FPS_WAVES) > 0 ? 1024 / (G * FPS_WAVES) : 1;  // all cooperating waves resident
     for (int b0 = 0; b0 < b; b0 += per_launch) {
         const int nb = (b - b0) < per_launch ? (b - b0) : per_launch;

@@ -537,8 +537,8 @@ template <int NCBW>
 static void launch_conv_ldsw(dim3 grid, int bs, size_t lds, hipStream_t st, const ConvArgs& a) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void*)k_conv_os<NCBW, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            64 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_conv_os<NCBW, 0, true, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);  // a failure shows at the launch
         attr = true;
     }
     hipLaunchKernelGGL((k_conv_os<NCBW, 0, true, true>), grid, dim3(bs), lds, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
@@ -683,10 +683,10 @@ extern "C" int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t
                                  int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
                                  const float* in_shift, const float* residual, float* out, void* ev_start,
                                  void* ev_stop, void* stream) {
-    hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream);
+    GF_TRY(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
     const int rc =
         gf_conv_fwd(in, Wp, nbr, gmask, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out, stream);
-    hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream);
+    GF_TRY(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
     return rc;
 }
 
@@ -748,7 +748,7 @@ extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* 
     GF_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1, "gf_conv_wgrad: bad sizes");
     GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_wgrad: nbr==NULL requires K==1");
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st);
+    GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
     if (M_out <= 0) return GF_OK;
     const int nci = (Cin + 15) / 16, nco = (Cout + 15) / 16;
     const int nslices = (M_out + WG_ROWS - 1) / WG_ROWS;
@@ -761,6 +761,8 @@ extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* 
 
 extern "C" int gf_debug_conv_occupancy(int block) {
     int n = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_conv_os<1, false, true, true>, block, 27 * 1024);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_conv_os<1, false, true, true>, block,
+                                                     27 * 1024) != hipSuccess)
+        return -1;
     return n;
 }

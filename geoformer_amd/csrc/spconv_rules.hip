@@ -160,7 +160,7 @@ extern "C" int gf_index_build(const int32_t* coords, int M, const int32_t* d_M, 
     size_t words = gf_index_words(B, X, Y, Z);
     GF_CHECK_ARG(words < (1ull << 31), "gf_index_build: grid of %zu words is too large for the bitmap index", words);
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(bitmap, 0, words * sizeof(uint32_t), st);
+    GF_TRY(hipMemsetAsync(bitmap, 0, words * sizeof(uint32_t), st));
     if (M > 0)
         hipLaunchKernelGGL(k_set_bits, dim3(gf_div_up(M, 256)), dim3(256), 0, st, coords, M, d_M, X, Y, Z, bitmap);
     run_scan(bitmap, words, prefix, scratch, nullptr, st);
@@ -282,8 +282,8 @@ extern "C" int gf_rules_down2(const int32_t* coords, int M, const int32_t* d_M, 
     size_t words = gf_index_words(B, OX, OY, OZ);
     GF_CHECK_ARG(words < (1ull << 31), "gf_rules_down2: output grid too large");
     hipStream_t st = (hipStream_t)stream;
-    hipMemsetAsync(bitmap_out, 0, words * sizeof(uint32_t), st);
-    hipMemsetAsync(child, 0xff, (size_t)8 * ld * sizeof(int32_t), st);
+    GF_TRY(hipMemsetAsync(bitmap_out, 0, words * sizeof(uint32_t), st));
+    GF_TRY(hipMemsetAsync(child, 0xff, (size_t)8 * ld * sizeof(int32_t), st));
     if (M > 0)
         hipLaunchKernelGGL(k_down_bits, dim3(gf_div_up(M, 256)), dim3(256), 0, st, coords, M, d_M, OX, OY, OZ,
                            bitmap_out);
@@ -387,8 +387,8 @@ extern "C" int gf_rules_down2_chain(const int32_t* coords, int M0, int B, int X,
     GF_CHECK_ARG(plan_down_chain(M0, B, X, Y, Z, nlevels, P) == 0, "gf_rules_down2_chain: grid too large");
     if (P.nl == 0 || M0 == 0) return GF_OK;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(ws + P.bitmaps_begin, 0, (size_t)(P.bitmaps_end - P.bitmaps_begin) * 4, st);
-    (void)hipMemsetAsync(ws + P.child_begin, 0xff, (size_t)(P.child_end - P.child_begin) * 4, st);
+    GF_TRY(hipMemsetAsync(ws + P.bitmaps_begin, 0, (size_t)(P.bitmaps_end - P.bitmaps_begin) * 4, st));
+    GF_TRY(hipMemsetAsync(ws + P.child_begin, 0xff, (size_t)(P.child_end - P.child_begin) * 4, st));
     const int32_t* cur = coords;
     for (int l = 0; l < P.nl; l++) {
         int32_t* F[DOWN_FIELDS];

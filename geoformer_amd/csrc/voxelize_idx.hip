@@ -192,11 +192,11 @@ extern "C" int gf_voxelize_idx_count(const long long* coords, int N, int ncol, i
     hipStream_t st = (hipStream_t)stream;
     VxScratch s = vx_carve(scratch, N);
     const size_t n1 = (size_t)N + 1;
-    hipMemsetAsync(s.keys, 0xff, (size_t)s.T * 8, st);
-    hipMemsetAsync(s.first, 0x7f, (size_t)s.T * 4, st);
-    hipMemsetAsync(s.cnt, 0, n1 * 4, st);
-    hipMemsetAsync(s.cursor, 0, n1 * 4, st);
-    hipMemsetAsync(s.err, 0, 4 * 4, st);
+    GF_TRY(hipMemsetAsync(s.keys, 0xff, (size_t)s.T * 8, st));
+    GF_TRY(hipMemsetAsync(s.first, 0x7f, (size_t)s.T * 4, st));
+    GF_TRY(hipMemsetAsync(s.cnt, 0, n1 * 4, st));
+    GF_TRY(hipMemsetAsync(s.cursor, 0, n1 * 4, st));
+    GF_TRY(hipMemsetAsync(s.err, 0, 4 * 4, st));
     if (N > 0) {
         const int nb = gf_div_up(N, SCAN_THREADS);
         hipLaunchKernelGGL(k_vx_insert, dim3(gf_div_up(N, VX_THREADS)), dim3(VX_THREADS), 0, st, coords, N, ncol, s);
@@ -211,9 +211,9 @@ extern "C" int gf_voxelize_idx_count(const long long* coords, int N, int ncol, i
         hipLaunchKernelGGL(k_vx_max, dim3(64), dim3(256), 0, st, s, mode);
     }
     // d_M_maxActive[0] = M, [1] = maxActive, [2] = error flag (coordinate outside the packed key's range)
-    hipMemcpyAsync(d_M_maxActive, s.err + 1, 4, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(d_M_maxActive + 1, s.err + 3, 4, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(d_M_maxActive + 2, s.err, 4, hipMemcpyDeviceToDevice, st);
+    GF_TRY(hipMemcpyAsync(d_M_maxActive, s.err + 1, 4, hipMemcpyDeviceToDevice, st));
+    GF_TRY(hipMemcpyAsync(d_M_maxActive + 1, s.err + 3, 4, hipMemcpyDeviceToDevice, st));
+    GF_TRY(hipMemcpyAsync(d_M_maxActive + 2, s.err, 4, hipMemcpyDeviceToDevice, st));
     GF_CHECK_LAUNCH("gf_voxelize_idx_count");
     return GF_OK;
 }
