@@ -95,6 +95,43 @@ def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighb
     return out
 
 
+class PendingProposals:
+    """The tail of generate_proposal (geoformer.py:236-262) behind the forward's last device->host read-back: the
+    acceptance flags of the queries are on their way to a pinned host buffer; ``get()`` waits for them, selects the
+    accepted queries on the host and queues the membership scatter on the stream the forward ran on."""
+
+    _pinned = {}
+
+    def __init__(self, final, cls_pred, scores, logits, fg_idxs, logit_thresh, num_points):
+        self.args = (cls_pred, scores, logits, fg_idxs, logit_thresh, num_points)
+        self.stream = torch.cuda.current_stream(logits.device)
+        self.pool = PendingProposals._pinned.setdefault(int(final.numel()), [])  # free landing buffers of this size
+        buf = self.pool.pop() if self.pool else torch.empty(final.numel(), dtype=torch.int32).pin_memory()
+        buf.copy_(final, non_blocking=True)
+        self.host = buf
+        self.done = torch.cuda.Event()
+        self.done.record(self.stream)
+        self.value = None
+
+    def get(self):
+        if self.value is None:
+            cls_pred, scores, logits, fg_idxs, logit_thresh, num_points = self.args
+            self.done.synchronize()
+            keep = np.flatnonzero(self.host.numpy())
+            self.pool.append(self.host)
+            self.host = None
+            if keep.size == 0:
+                self.value = ([], [], [])
+            else:
+                with torch.cuda.stream(self.stream):
+                    sel = torch.from_numpy(keep.astype(np.int32)).to(logits.device)
+                    proposals = pointops.proposal_scatter(logits, sel, fg_idxs, logit_thresh, num_points)
+                    sel = sel.long()
+                    self.value = (cls_pred[sel].long(), scores[sel], proposals)
+            self.args = None
+        return self.value
+
+
 class GeoFormer(nn.Module):
     def __init__(self, cfg=None):
         super().__init__()
@@ -312,10 +349,11 @@ class GeoFormer(nn.Module):
         npoint_sa = self.set_aggregator.npoint
         split = os.environ.get("GF_OVERLAP", "1") != "2" and npoint_sa > nq
         main = torch.cuda.current_stream()
-        side = self.__dict__.get("_gf_side_stream")
-        if side is None or side.device != locs_float_.device:
+        sides = self.__dict__.setdefault("_gf_side_streams", {})  # one per caller stream: scenes in flight on
+        side = sides.get((locs_float_.device, main.cuda_stream))   # different streams do not queue behind each other
+        if side is None:
             side = torch.cuda.Stream(device=locs_float_.device)  # (stream priorities made no difference: measured)
-            self.__dict__["_gf_side_stream"] = side
+            sides[(locs_float_.device, main.cuda_stream)] = side
         staged, geo = [], []
         for b in range(batch_size):
             n_b = offs[b + 1] - offs[b]
@@ -529,9 +567,11 @@ class GeoFormer(nn.Module):
         return outputs
 
     def generate_proposal(self, mask_logits, cls_logits, fg_idxs, batch_offsets, batch_offsets_,
-                          semantic_scores_=None, logit_thresh=0.5, score_thresh=0.5, npoint_thresh=100, sem_prob=None):
+                          semantic_scores_=None, logit_thresh=0.5, score_thresh=0.5, npoint_thresh=100, sem_prob=None,
+                          defer=False):
         """Batch-1 proposal extraction (geoformer.py:193-262): score = mean mask prob * sqrt(cls prob) *
-        mean semantic prob of the predicted class over the mask."""
+        mean semantic prob of the predicted class over the mask.  defer: return a PendingProposals instead of
+        waiting for the device (GPU inference only)."""
         b = 0
         if mask_logits[b].is_cuda and not torch.is_grad_enabled():
             # inference: two fused HIP launches (csrc/proposal.hip) instead of ~40 PyTorch ones; the acceptance flags
@@ -548,13 +588,8 @@ class GeoFormer(nn.Module):
             cls_pred, _, scores, final = pointops.proposal_stats(
                 logits, cls_logits[b].contiguous(), sem_t.contiguous(), logit_thresh, score_thresh, npoint_thresh,
                 min_class=4, class_major=True)
-            keep = np.flatnonzero(final.cpu().numpy())
-            if keep.size == 0:
-                return [], [], []
-            sel = torch.from_numpy(keep.astype(np.int32)).to(logits.device)
-            proposals = pointops.proposal_scatter(logits, sel, fg_idxs.contiguous(), logit_thresh, num_points)
-            sel = sel.long()
-            return cls_pred[sel].long(), scores[sel], proposals
+            pending = PendingProposals(final, cls_pred, scores, logits, fg_idxs.contiguous(), logit_thresh, num_points)
+            return pending if defer else pending.get()
         sem = sem_prob if sem_prob is not None and not isinstance(sem_prob, tuple) else F.softmax(semantic_scores_, dim=1)
         num_points = int(batch_offsets[b + 1] - batch_offsets[b])
         mask_prob = mask_logits[b].sigmoid()
@@ -578,7 +613,10 @@ class GeoFormer(nn.Module):
         return cls_pred[final], scores[final], proposals
 
     # -- forward --------------------------------------------------------------------------------
-    def forward(self, batch_input, epoch, training=True):
+    def forward(self, batch_input, epoch, training=True, defer_proposals=False):
+        """defer_proposals (GPU inference): everything is queued on the current stream and
+        ``outputs["proposal_scores"]`` is a PendingProposals whose ``get()`` makes the forward's last read-back -- a
+        serving loop can queue the next scene on another stream before it collects this one (bench.py does)."""
         cfg = self.cfg
         outputs = {}
         batch_idxs = batch_input["locs"][:, 0].int()
@@ -678,6 +716,6 @@ class GeoFormer(nn.Module):
             outputs["proposal_scores"] = self.generate_proposal(
                 preds[-1]["mask_logits"], preds[-1]["cls_logits"], fg_idxs, batch_offsets, batch_offsets_,
                 semantic_scores_=semantic_scores_, logit_thresh=0.5, score_thresh=cfg.TEST_SCORE_THRESH,
-                npoint_thresh=cfg.TEST_NPOINT_THRESH, sem_prob=sem_prob)
+                npoint_thresh=cfg.TEST_NPOINT_THRESH, sem_prob=sem_prob, defer=defer_proposals)
         self.__dict__.get("_gf_early", {}).clear()
         return outputs
