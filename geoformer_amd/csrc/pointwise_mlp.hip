@@ -24,14 +24,50 @@ struct PmArgs {
     int nl;
 };
 
+// The layers' weights are staged once per workgroup in LDS, zero-padded to multiples of 16 in both dimensions with a
+// row stride of cin_padded + 4 floats: the A operand of four MFMAs is then ONE aligned ds_read_b128 without predicates.
+// Reading them in place (row-major [cout, cin] with cin = 3 + C = 35 for the set-abstraction MLP: unaligned rows)
+// took four predicated scalar loads per operand, 72 per 16-sample tile and lane -- the kernel spent its time there.
+#define GM_WSTRIDE(cinp) ((cinp) + 4)
+__device__ __forceinline__ void pm_stage_weights(const PmArgs& A, float* __restrict__ s_w, int* woff, int* soff) {
+    int cur = 0;
+#pragma unroll
+    for (int l = 0; l < PM_MAXL; l++) {
+        if (l >= A.nl) break;
+        const int cinp = (A.L[l].cin + 15) & ~15, coutp = (A.L[l].cout + 15) & ~15;
+        woff[l] = cur;
+        cur += coutp * GM_WSTRIDE(cinp);
+        soff[l] = cur;
+        cur += 2 * coutp;
+    }
+#pragma unroll
+    for (int l = 0; l < PM_MAXL; l++) {
+        if (l >= A.nl) break;
+        const PmLayer& L = A.L[l];
+        const int cinp = (L.cin + 15) & ~15, coutp = (L.cout + 15) & ~15, ws = GM_WSTRIDE(cinp);
+        for (int t = threadIdx.x; t < coutp * cinp; t += blockDim.x) {
+            const int r = t / cinp, c = t - r * cinp;
+            s_w[woff[l] + r * ws + c] = (r < L.cout && c < L.cin) ? L.W[(size_t)r * L.cin + c] : 0.f;
+        }
+        for (int t = threadIdx.x; t < coutp; t += blockDim.x) {
+            s_w[soff[l] + t] = t < L.cout ? L.scale[t] : 0.f;
+            s_w[soff[l] + coutp + t] = t < L.cout ? L.shift[t] : 0.f;
+        }
+    }
+    __syncthreads();
+}
+
 // rows: optional int32 [N] row indirection of the input (out[p] = MLP(x[rows[p]])): the p2v gather of the semantic
 // head rides in the first layer's operand load instead of materialising feats[p2v_map]
 __global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__ x, const int32_t* __restrict__ rows,
                                                        int N, PmArgs A, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const int ntiles = (N + 15) >> 4;
     const int c0 = A.L[0].cin, cl = A.L[A.nl - 1].cout;
+    int woff[PM_MAXL], soff[PM_MAXL];
+    pm_stage_weights(A, s_w, woff, soff);
     for (int t = wave; t < ntiles; t += nwaves) {
         const int p = t * 16 + j;
         const bool live = p < N;
@@ -47,34 +83,33 @@ __global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__
         for (int l = 0; l < PM_MAXL; l++) {
             if (l >= A.nl) break;
             const PmLayer& L = A.L[l];
+            const int cinp = (L.cin + 15) & ~15, coutp = (L.cout + 15) & ~15, ws = GM_WSTRIDE(cinp);
+            const float* Wl = s_w + woff[l];
+            const float* Sl = s_w + soff[l];
             float4 o[PM_MAXC / 16];
 #pragma unroll
             for (int ct = 0; ct < PM_MAXC / 16; ct++) {
                 o[ct] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ct * 16 >= L.cout) continue;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const int row = ct * 16 + j;  // output channel this lane feeds as the A operand
+                const float* wrow = Wl + (ct * 16 + j) * ws + 4 * g;  // output channel ct*16 + j is this lane's A row
 #pragma unroll
                 for (int kc = 0; kc < PM_MAXC / 16; kc++) {
                     if (kc * 16 >= L.cin) continue;
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row < L.cout) a = *reinterpret_cast<const float4*>(L.W + (size_t)row * L.cin + kc * 16 + 4 * g);
+                    const float4 a = *reinterpret_cast<const float4*>(wrow + kc * 16);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, h[kc].x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, h[kc].y, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, h[kc].z, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, h[kc].w, acc, 0, 0, 0);
                 }
-                // accumulator: channels ct*16 + 4g + i of point j
-                float r[4];
+                // accumulator: channels ct*16 + 4g + i of point j; padded channels come out as 0 (scale = shift = 0)
+                const float4 sc = *reinterpret_cast<const float4*>(Sl + ct * 16 + 4 * g);
+                const float4 sh = *reinterpret_cast<const float4*>(Sl + coutp + ct * 16 + 4 * g);
+                float r[4] = {fmaf(acc[0], sc.x, sh.x), fmaf(acc[1], sc.y, sh.y), fmaf(acc[2], sc.z, sh.z),
+                              fmaf(acc[3], sc.w, sh.w)};
+                if (L.relu) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int ch = ct * 16 + 4 * g + i;
-                    float v = 0.f;
-                    if (ch < L.cout) {
-                        v = fmaf(acc[i], L.scale[ch], L.shift[ch]);
-                        if (L.relu) v = fmaxf(v, 0.f);
-                    }
-                    r[i] = v;
+                    for (int i = 0; i < 4; i++) r[i] = fmaxf(r[i], 0.f);
                 }
                 o[ct] = make_float4(r[0], r[1], r[2], r[3]);
             }
@@ -96,6 +131,15 @@ __global__ __launch_bounds__(256) void k_pointwise_mlp(const float* __restrict__
             }
         }
     }
+}
+
+static size_t gm_lds_bytes(const PmArgs& A) {
+    size_t n = 0;
+    for (int l = 0; l < A.nl; l++) {
+        const size_t cinp = (A.L[l].cin + 15) & ~15, coutp = (A.L[l].cout + 15) & ~15;
+        n += coutp * GM_WSTRIDE(cinp) + 2 * coutp;
+    }
+    return n * sizeof(float);  // <= 4 * (64 * 68 + 128) * 4 = 71 KB worst case, ~20 KB for the set-abstraction MLP
 }
 
 extern "C" int gf_pointwise_mlp_rows(const float* x, const int32_t* rows, int N, int n_layers, const float* const* W,
@@ -129,7 +173,12 @@ extern "C" int gf_pointwise_mlp_rows(const float* x, const int32_t* rows, int N,
     const int ntiles = (N + 15) / 16;
     int blocks = (ntiles + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(k_pointwise_mlp, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, rows, N, A, out);
+    static bool lds_ok = false;
+    if (!lds_ok) {
+        (void)hipFuncSetAttribute((const void*)k_pointwise_mlp, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        lds_ok = true;
+    }
+    hipLaunchKernelGGL(k_pointwise_mlp, dim3(blocks), dim3(256), gm_lds_bytes(A), (hipStream_t)stream, x, rows, N, A, out);
     GF_CHECK_LAUNCH("gf_pointwise_mlp");
     return GF_OK;
 }
@@ -159,11 +208,6 @@ struct PmGather {
     int n, C, use_xyz;
     float inv_radius;  // 1/radius with normalize_xyz (torch divides by a Python scalar as a * (1/b)), else 1
 };
-// The layers' weights are staged once per workgroup in LDS, zero-padded to multiples of 16 in both dimensions with a
-// row stride of cin_padded + 4 floats: the A operand of four MFMAs is then ONE aligned ds_read_b128 without predicates.
-// Reading them in place (row-major [cout, cin] with cin = 3 + C = 35 for the set-abstraction MLP: unaligned rows)
-// took four predicated scalar loads per operand, 72 per 16-sample tile and lane -- the kernel spent its time there.
-#define GM_WSTRIDE(cinp) ((cinp) + 4)
 template <bool GATHER>
 __global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__ grouped, int B, int np, int ns,
                                                        PmArgs A, PmGather Gx, float* __restrict__ out) {
@@ -173,33 +217,7 @@ __global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__
     const int c0 = A.L[0].cin, cl = A.L[A.nl - 1].cout;
     const size_t cstride = (size_t)np * ns;
     int woff[PM_MAXL], soff[PM_MAXL];
-    {
-        int cur = 0;
-#pragma unroll
-        for (int l = 0; l < PM_MAXL; l++) {
-            if (l >= A.nl) break;
-            const int cinp = (A.L[l].cin + 15) & ~15, coutp = (A.L[l].cout + 15) & ~15;
-            woff[l] = cur;
-            cur += coutp * GM_WSTRIDE(cinp);
-            soff[l] = cur;
-            cur += 2 * coutp;
-        }
-#pragma unroll
-        for (int l = 0; l < PM_MAXL; l++) {
-            if (l >= A.nl) break;
-            const PmLayer& L = A.L[l];
-            const int cinp = (L.cin + 15) & ~15, coutp = (L.cout + 15) & ~15, ws = GM_WSTRIDE(cinp);
-            for (int t = threadIdx.x; t < coutp * cinp; t += blockDim.x) {
-                const int r = t / cinp, c = t - r * cinp;
-                s_w[woff[l] + r * ws + c] = (r < L.cout && c < L.cin) ? L.W[(size_t)r * L.cin + c] : 0.f;
-            }
-            for (int t = threadIdx.x; t < coutp; t += blockDim.x) {
-                s_w[soff[l] + t] = t < L.cout ? L.scale[t] : 0.f;
-                s_w[soff[l] + coutp + t] = t < L.cout ? L.shift[t] : 0.f;
-            }
-        }
-        __syncthreads();
-    }
+    pm_stage_weights(A, s_w, woff, soff);
     for (int item = wave; item < B * np; item += nwaves) {
         const int b = item / np, pt = item - b * np;
         const float* gp = GATHER ? nullptr : grouped + (size_t)b * c0 * cstride + (size_t)pt * ns;
@@ -293,14 +311,6 @@ __global__ __launch_bounds__(256) void k_group_mlp_max(const float* __restrict__
     }
 }
 
-static size_t gm_lds_bytes(const PmArgs& A) {
-    size_t n = 0;
-    for (int l = 0; l < A.nl; l++) {
-        const size_t cinp = (A.L[l].cin + 15) & ~15, coutp = (A.L[l].cout + 15) & ~15;
-        n += coutp * GM_WSTRIDE(cinp) + 2 * coutp;
-    }
-    return n * sizeof(float);  // <= 4 * (64 * 68 + 128) * 4 = 71 KB worst case, ~20 KB for the set-abstraction MLP
-}
 template <bool GATHER>
 static void gm_allow_lds() {
     static bool done = false;
