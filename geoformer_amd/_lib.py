@@ -61,7 +61,9 @@ def _declare(lib):
         "gf_pointwise_mlp_rows": (I, [P, P, I, I, P, P, P, P, P, P, P]),
         "gf_group_mlp_max": (I, [P, I, I, I, I, P, P, P, P, P, P, P]),
         "gf_ball_query_centres": (I, [P, P, I, I, I, F, I, P, P, P]),
-        "gf_sa_group_mlp_max": (I, [P, P, P, I, I, I, I, F, I, I, I, I, P, P, P, P, P, P, P, P, P]),
+        "gf_sa_group_mlp_max": (I, [P, P, P, I, I, I, I, F, I, I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
+        "gf_ball_query_grid": (I, [P, I, P, P, I, F, I, P, I, P, P, P]),
+        "gf_point_grid_build": (I, [P, I, F, P, P]),
         "gf_decoder_token_state_bytes": (c_size_t, [I, I]),
         "gf_decoder_token_stage": (I, [P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
         "gf_mask_intersections_scratch_bytes": (c_size_t, [I, I]),

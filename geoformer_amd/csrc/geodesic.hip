@@ -204,12 +204,18 @@ extern "C" size_t gf_knn_scratch_bytes(int n) {
     return (3 * T + 8 + 2 * nb + 8) * sizeof(int32_t) + (size_t)(n + 1) * sizeof(float4) + 64;
 }
 
-extern "C" int gf_knn_radius(const float* xyz, int n, int k, float radius, int sqrt_out, float* D, int32_t* I,
-                             int32_t* deg, void* scratch, void* stream) {
-    GF_CHECK_ARG(n >= 0 && k >= 1 && k <= 64 && radius > 0.f, "gf_knn_radius: bad arguments n=%d k=%d r=%g", n, k,
-                 radius);
-    if (n == 0) return GF_OK;
-    hipStream_t st = (hipStream_t)stream;
+struct PointGrid {
+    const int32_t* start;
+    const float4* sorted;
+    int* err;
+    unsigned tmask;
+    float inv_cell;
+};
+
+// hash grid of one point set with cells of `radius` (x 1.001): counts -> exclusive scan -> (xyz, index) records
+// sorted by bucket.  scratch: gf_knn_scratch_bytes(n).
+static int build_point_grid(const float* xyz, int n, float radius, void* scratch, hipStream_t st, PointGrid* G,
+                            bool ready = false) {
     const unsigned T = knn_table_size(n);
     const int nb = (int)((T + ISCAN_IPB - 1) / ISCAN_IPB);
     int32_t* counts = (int32_t*)scratch;
@@ -222,6 +228,8 @@ extern "C" int gf_knn_radius(const float* xyz, int n, int k, float radius, int s
     float4* sorted = (float4*)sp;
     const float cell = radius * 1.001f;
     const float inv_cell = 1.0f / cell;
+    *G = {start, sorted, err, T - 1, inv_cell};
+    if (ready) return GF_OK;  // built by an earlier gf_point_grid_build over the same points and radius
     GF_TRY(hipMemsetAsync(counts, 0, (size_t)T * sizeof(int32_t), st));
     GF_TRY(hipMemsetAsync(err, 0, sizeof(int), st));
     hipLaunchKernelGGL(k_grid_count, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, n, inv_cell, T - 1, counts);
@@ -229,11 +237,173 @@ extern "C" int gf_knn_radius(const float* xyz, int n, int k, float radius, int s
     hipLaunchKernelGGL(k_iscan_top, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, block_off);
     hipLaunchKernelGGL(k_iscan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, counts, (int)T, block_off, start, cursor);
     hipLaunchKernelGGL(k_grid_fill, dim3(gf_div_up(n, 256)), dim3(256), 0, st, xyz, n, inv_cell, T - 1, cursor, sorted);
+    return GF_OK;
+}
+
+// the grid alone (five small launches that only need the points): a caller with something else on the critical
+// path builds it early, on another stream, and hands gf_ball_query_grid the scratch with grid_ready = 1
+extern "C" int gf_point_grid_build(const float* xyz, int n, float radius, void* scratch, void* stream) {
+    GF_CHECK_ARG(xyz && scratch && n >= 1 && radius > 0.f, "gf_point_grid_build: bad arguments");
+    PointGrid G;
+    if (int rc = build_point_grid(xyz, n, radius, scratch, (hipStream_t)stream, &G)) return rc;
+    GF_CHECK_LAUNCH("gf_point_grid_build");
+    return GF_OK;
+}
+
+extern "C" int gf_knn_radius(const float* xyz, int n, int k, float radius, int sqrt_out, float* D, int32_t* I,
+                             int32_t* deg, void* scratch, void* stream) {
+    GF_CHECK_ARG(n >= 0 && k >= 1 && k <= 64 && radius > 0.f, "gf_knn_radius: bad arguments n=%d k=%d r=%g", n, k,
+                 radius);
+    if (n == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    PointGrid G;
+    if (int rc = build_point_grid(xyz, n, radius, scratch, st, &G)) return rc;
     hipLaunchKernelGGL(k_knn_radius, dim3(gf_div_up(n, KNN_WAVES)), dim3(KNN_WAVES * 64), 0, st, xyz, n, k, radius,
-                       inv_cell, T - 1, start, sorted, sqrt_out, D, I, deg, err);
+                       G.inv_cell, G.tmask, G.start, G.sorted, sqrt_out, D, I, deg, G.err);
     GF_CHECK_LAUNCH("gf_knn_radius");
     return GF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// ball query over the hash grid (pointnet2 ball_query, ball_query_gpu.cu:10-46: the first `nsample` points in
+// INDEX order with d2 < r^2, the rest of the row padded with the first hit, all zeros without any).
+// The brute-force kernel (pointops.hip) tests every centre against every point: 10^8 tests for the eval forward's
+// 2048 x 50 000, 78 us.  Here a wave walks the 27 buckets around its centre (~270 candidates), keeps the hits'
+// indices in LDS and ranks them by counting -- the rank of an index among the hits IS its output column.  A centre
+// with more than BQG_CAP hits (never seen at 2 cm voxels and r = 0.2) falls back to the linear scan inside the same
+// wave, so the result never depends on the capacity.
+// ------------------------------------------------------------------------------------
+#define BQG_WAVES 4
+#define BQG_CAP 1024
+__global__ __launch_bounds__(BQG_WAVES * 64) void k_ball_query_grid(const float* __restrict__ xyz, int n,
+                                                                    const int32_t* __restrict__ centre_idx,
+                                                                    const float* __restrict__ centres, int m,
+                                                                    float radius2, int nsample, PointGrid G,
+                                                                    float* __restrict__ new_xyz_out,
+                                                                    int32_t* __restrict__ idx) {
+    __shared__ __attribute__((aligned(16))) unsigned s_hit[BQG_WAVES][BQG_CAP + 16];
+    __shared__ int s_off[BQG_WAVES][28];
+    __shared__ int s_beg[BQG_WAVES][27];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int j = blockIdx.x * BQG_WAVES + wid;
+    if (j >= m) return;  // whole wave exits together (no block-level barrier below)
+    const float* c = centre_idx ? xyz + (size_t)centre_idx[j] * 3 : centres + (size_t)j * 3;
+    const float qx = c[0], qy = c[1], qz = c[2];
+    if (new_xyz_out && lane < 3) new_xyz_out[(size_t)j * 3 + lane] = lane == 0 ? qx : lane == 1 ? qy : qz;
+    const int3 qc = cell_of(qx, qy, qz, G.inv_cell);
+    int beg = 0, cnt = 0;
+    if (lane < 27) {
+        const unsigned h = bucket_of(qc.x + lane / 9 - 1, qc.y + (lane / 3) % 3 - 1, qc.z + lane % 3 - 1, G.tmask);
+        beg = G.start[h];
+        cnt = G.start[h + 1] - beg;
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane < 27) {
+        s_off[wid][lane + 1] = inc;
+        s_beg[wid][lane] = beg;
+    }
+    if (lane == 0) s_off[wid][0] = 0;
+    const int total = __shfl(inc, 26, 64);
+    __builtin_amdgcn_wave_barrier();
+    int nin = 0;
+    for (int t0 = 0; t0 < total; t0 += 64) {
+        const int t = t0 + lane;
+        bool hit = false;
+        unsigned pid = 0;
+        if (t < total) {
+            int cc = 0;
+#pragma unroll
+            for (int s = 1; s < 27; s++) cc += (s_off[wid][s] <= t) ? 1 : 0;
+            const float4 p = G.sorted[s_beg[wid][cc] + (t - s_off[wid][cc])];
+            // several cells may share a bucket and several of the 27 cells may hash alike: count a point only in the
+            // slot of the cell it really lies in
+            const int3 pc = cell_of(p.x, p.y, p.z, G.inv_cell);
+            if (pc.x == qc.x + cc / 9 - 1 && pc.y == qc.y + (cc / 3) % 3 - 1 && pc.z == qc.z + cc % 3 - 1) {
+                const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+                hit = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < radius2;
+                pid = (unsigned)__float_as_int(p.w);
+            }
+        }
+        const unsigned long long bal = __ballot(hit);
+        const int pos = nin + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < BQG_CAP) s_hit[wid][pos] = pid;
+        nin += __popcll(bal);
+    }
+    int32_t* row = idx + (size_t)j * nsample;
+    if (nin > BQG_CAP) {
+        // more hits than the list holds: the linear scan in index order (same result, just slower)
+        int got = 0, first = -1;
+        for (int s = 0; s < n && got < nsample; s += 64) {
+            const int p = s + lane;
+            bool hit = false;
+            if (p < n) {
+                const float dx = qx - xyz[(size_t)p * 3 + 0], dy = qy - xyz[(size_t)p * 3 + 1],
+                            dz = qz - xyz[(size_t)p * 3 + 2];
+                hit = fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < radius2;
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (bal) {
+                if (first < 0) first = s + __builtin_ctzll(bal);
+                const int pos = got + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && pos < nsample) row[pos] = p;
+                got += __popcll(bal);
+            }
+        }
+        for (int l = min(got, nsample) + lane; l < nsample; l += 64) row[l] = first < 0 ? 0 : first;
+        return;
+    }
+    // pad the list to a multiple of 16 with a value no index is below: the counting loop reads it 16 at a time
+    {
+        const int padded = (nin + 15) & ~15;
+        if (nin + lane < padded) s_hit[wid][nin + lane] = 0xffffffffu;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rank by counting: indices are unique, so the ranks are a permutation of 0..nin-1.  Four ds_read_b128 per
+    // step, issued together (one key at a time with a dependent LDS read each was 60 us for a centre with 300 hits)
+    unsigned lowest = 0xffffffffu;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* list = reinterpret_cast<const u32x4*>(s_hit[wid]);
+    const int n16 = (nin + 15) >> 4;
+    for (int t = lane; t < nin; t += 64) {
+        const unsigned key = s_hit[wid][t];
+        int rank = 0;
+        for (int u = 0; u < n16; u++) {
+            const u32x4 a = list[4 * u + 0], b = list[4 * u + 1], c2 = list[4 * u + 2], d = list[4 * u + 3];
+            rank += (a[0] < key) + (a[1] < key) + (a[2] < key) + (a[3] < key) + (b[0] < key) + (b[1] < key) +
+                    (b[2] < key) + (b[3] < key) + (c2[0] < key) + (c2[1] < key) + (c2[2] < key) + (c2[3] < key) +
+                    (d[0] < key) + (d[1] < key) + (d[2] < key) + (d[3] < key);
+        }
+        if (rank < nsample) row[rank] = (int)key;
+        lowest = min(lowest, key);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lowest = min(lowest, (unsigned)__shfl_xor((int)lowest, d, 64));
+    const int pad = nin > 0 ? (int)lowest : 0;
+    for (int l = min(nin, nsample) + lane; l < nsample; l += 64) row[l] = pad;
+}
+
+// one point set (b = 1): xyz fp32 [n,3]; centres given as indices into xyz (new_xyz [m,3] then receives their
+// coordinates) or as coordinates.  scratch: gf_knn_scratch_bytes(n).
+extern "C" int gf_ball_query_grid(const float* xyz, int n, const int32_t* centre_idx, const float* centres, int m,
+                                  float radius, int nsample, void* scratch, int grid_ready, float* new_xyz,
+                                  int32_t* idx, void* stream) {
+    GF_CHECK_ARG(xyz && scratch && idx && (centre_idx || centres), "gf_ball_query_grid: null argument");
+    GF_CHECK_ARG(n >= 1 && m >= 0 && nsample >= 1 && radius > 0.f, "gf_ball_query_grid: bad sizes");
+    if (m == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    PointGrid G;
+    if (int rc = build_point_grid(xyz, n, radius, scratch, st, &G, grid_ready != 0)) return rc;
+    hipLaunchKernelGGL(k_ball_query_grid, dim3(gf_div_up(m, BQG_WAVES)), dim3(BQG_WAVES * 64), 0, st, xyz, n, centre_idx,
+                       centres, m, radius * radius, nsample, G, new_xyz, idx);
+    GF_CHECK_LAUNCH("gf_ball_query_grid");
+    return GF_OK;
+}
+
 // device flag set when a point had more than KNN_CAP in-radius neighbours (result rows truncated)
 extern "C" const int32_t* gf_knn_error_flag(void* scratch, int n) {
     const unsigned T = knn_table_size(n);

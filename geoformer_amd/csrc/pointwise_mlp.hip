@@ -361,11 +361,14 @@ extern "C" int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsa
 // concatenation and the [B, 3+C, np, ns] tensor they produce.
 extern "C" int gf_ball_query_centres(const float* xyz, const int32_t* centre_idx, int b, int n, int m, float radius,
                                      int nsample, float* new_xyz, int32_t* idx, void* stream);
+extern "C" int gf_ball_query_grid(const float* xyz, int n, const int32_t* centre_idx, const float* centres, int m,
+                                  float radius, int nsample, void* scratch, int grid_ready, float* new_xyz,
+                                  int32_t* idx, void* stream);
 extern "C" int gf_sa_group_mlp_max(const float* xyz, const float* feats, const int32_t* inds, int B, int n, int C,
                                    int npoint, float radius, int nsample, int use_xyz, int normalize_xyz,
                                    int n_layers, const float* const* W, const float* const* scale,
                                    const float* const* shift, const int* channels, const int* relu, float* new_xyz,
-                                   int32_t* idx, float* out, void* stream) {
+                                   int32_t* idx, float* out, void* scratch, int grid_ready, void* stream) {
     GF_CHECK_ARG(xyz && inds && new_xyz && idx && out && (feats || C == 0), "gf_sa_group_mlp_max: null argument");
     GF_CHECK_ARG(B >= 0 && n >= 1 && C >= 0 && npoint >= 0 && nsample >= 1 && radius > 0.f,
                  "gf_sa_group_mlp_max: bad sizes");
@@ -375,7 +378,14 @@ extern "C" int gf_sa_group_mlp_max(const float* xyz, const float* feats, const i
     GF_CHECK_ARG(channels[0] == C + (use_xyz ? 3 : 0), "gf_sa_group_mlp_max: first layer expects %d channels, got %d",
                  channels[0], C + (use_xyz ? 3 : 0));
     if (B == 0 || npoint == 0) return GF_OK;
-    if (int rc = gf_ball_query_centres(xyz, inds, B, n, npoint, radius, nsample, new_xyz, idx, stream)) return rc;
+    // a grid pays once the linear scan is long: 27 buckets per centre against every point
+    if (scratch && B == 1 && n >= 4096) {
+        if (int rc = gf_ball_query_grid(xyz, n, inds, nullptr, npoint, radius, nsample, scratch, grid_ready, new_xyz, idx,
+                                        stream))
+            return rc;
+    } else if (int rc = gf_ball_query_centres(xyz, inds, B, n, npoint, radius, nsample, new_xyz, idx, stream)) {
+        return rc;
+    }
     PmGather Gx{xyz, feats, new_xyz, idx, n, C, use_xyz, normalize_xyz ? 1.0f / radius : 1.0f};
     long long items = (long long)B * npoint;
     int blocks = (int)((items + 3) / 4);

@@ -369,8 +369,21 @@ class GeoFormer(nn.Module):
             else:
                 sampling_indices = None
                 xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
+            xyz_ready = torch.cuda.Event()
+            xyz_ready.record(main)
             first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
             src = first[0, :nq].contiguous()
+            grid = None
+            if xyz_b.shape[1] >= 4096 and not torch.is_grad_enabled():
+                # the ball query's point grid needs the points only: built on the side stream under the first picks
+                # (issued after their launch -- nothing may delay that one)
+                side.wait_event(xyz_ready)
+                with torch.cuda.stream(side):
+                    grid = pointops.point_grid_build(xyz_b, self.set_aggregator.radius)
+                    grid.record_stream(main)
+                    grid_done = torch.cuda.Event()
+                    grid_done.record(side)
+                grid = (grid, grid_done)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 D, I, deg = graphs[b]
@@ -386,7 +399,7 @@ class GeoFormer(nn.Module):
                 if sampling_indices is not None:
                     feat_b = feat_b[sampling_indices]
                 feat_b = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
-            staged.append((xyz_b, feat_b, idx))
+            staged.append((xyz_b, feat_b, idx, grid))
             if not epilogue:
                 continue
             with torch.cuda.stream(side):
@@ -396,13 +409,17 @@ class GeoFormer(nn.Module):
         self.__dict__["_gf_pending_side"] = side
         cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
         with grad_ctx():
-            fused = [self.set_aggregator.fused_forward(xyz_b, feat_b, idx) for xyz_b, feat_b, idx in staged]
+            fused = []
+            for xyz_b, feat_b, idx, grid in staged:
+                if grid is not None:
+                    main.wait_event(grid[1])
+                fused.append(self.set_aggregator.fused_forward(xyz_b, feat_b, idx, grid=None if grid is None else grid[0]))
             if all(f is not None for f in fused):
                 context_locs, pre_enc_inds = cat([f[0] for f in fused]), cat([st[2] for st in staged])
                 context_feats = cat([f[1] for f in fused]).transpose(1, 2)
                 return (context_locs, context_feats, pre_enc_inds), geo
             locs, gfeat, gxyz, inds = [], [], [], []
-            for xyz_b, feat_b, idx in staged:
+            for xyz_b, feat_b, idx, _ in staged:
                 l, gf, gx, idx = self.set_aggregator.group_points(xyz_b, feat_b, inds=idx)
                 locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
             context_locs, pre_enc_inds = cat(locs), cat(inds)

@@ -171,7 +171,7 @@ class PointnetSAModuleVotesSeparate(nn.Module):
             self.__dict__["_gf_chain"] = hit
         return hit[1]
 
-    def fused_forward(self, xyz, features, inds):
+    def fused_forward(self, xyz, features, inds, grid=None):
         """(new_xyz, pooled features [B,C,npoint]) of the whole stage in two launches -- inference with max pooling on
         the GPU and given sample indices; None when that path does not apply (the caller then uses group_points + mlp)."""
         if self.pooling != "max" or not xyz.is_cuda or torch.is_grad_enabled() or inds is None:
@@ -182,7 +182,8 @@ class PointnetSAModuleVotesSeparate(nn.Module):
         from .. import pointops
 
         new_xyz, _, pooled = pointops.sa_group_mlp_max(xyz.contiguous(), features.contiguous(), inds.contiguous(),
-                                                       self.radius, self.nsample, self.use_xyz, self.normalize_xyz, chain)
+                                                       self.radius, self.nsample, self.use_xyz, self.normalize_xyz, chain,
+                                                       grid=grid)
         return new_xyz, pooled
 
     def mlp(self, grouped_features, grouped_xyz, pooling=None):

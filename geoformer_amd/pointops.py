@@ -107,12 +107,21 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
-def ball_query(new_xyz, xyz, radius, nsample):
+def ball_query(new_xyz, xyz, radius, nsample, grid=None):
+    """pointnet2 ball_query.  grid: use the hash-grid kernel (same rows; default: for one point set of >= 4096 points)."""
     _f32c(new_xyz, "new_xyz"); _f32c(xyz, "xyz")
     b, m, _ = new_xyz.shape
     n = xyz.shape[1]
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz.device)
-    check(_lib.load().gf_ball_query(ptr(new_xyz), ptr(xyz), b, n, m, float(radius), nsample, ptr(idx), stream_ptr()),
+    lib = _lib.load()
+    if grid is None:
+        grid = b == 1 and n >= 4096
+    if grid and b == 1 and n >= 1:
+        scratch = torch.empty(lib.gf_knn_scratch_bytes(n) // 4 + 16, dtype=torch.int32, device=xyz.device)
+        check(lib.gf_ball_query_grid(ptr(xyz), n, None, ptr(new_xyz), m, float(radius), nsample, ptr(scratch), 0, None,
+                                     ptr(idx), stream_ptr()), "gf_ball_query_grid")
+        return idx
+    check(lib.gf_ball_query(ptr(new_xyz), ptr(xyz), b, n, m, float(radius), nsample, ptr(idx), stream_ptr()),
           "gf_ball_query")
     return idx
 
@@ -309,7 +318,18 @@ def group_mlp_max(grouped, chain):
     return out
 
 
-def sa_group_mlp_max(xyz, feats, inds, radius, nsample, use_xyz, normalize_xyz, chain):
+def point_grid_build(xyz, radius):
+    """Hash grid of one point set [1,n,3] with cells of `radius` for the grid ball query (returns the scratch tensor
+    to hand to sa_group_mlp_max(grid=...)); runs on the current stream."""
+    _f32c(xyz, "xyz")
+    n = xyz.shape[1]
+    lib = _lib.load()
+    scratch = torch.empty(lib.gf_knn_scratch_bytes(n) // 4 + 16, dtype=torch.int32, device=xyz.device)
+    check(lib.gf_point_grid_build(ptr(xyz), n, float(radius), ptr(scratch), stream_ptr()), "gf_point_grid_build")
+    return scratch
+
+
+def sa_group_mlp_max(xyz, feats, inds, radius, nsample, use_xyz, normalize_xyz, chain, grid=None):
     """Set-abstraction stage for given sample indices, fused: returns (new_xyz [B,np,3], idx [B,np,ns] int32,
     pooled [B,C_last,np]).  xyz [B,n,3], feats [B,C,n] (or None), inds int32 [B,np]."""
     _f32c(xyz, "xyz"); _i32c(inds, "inds")
@@ -323,10 +343,15 @@ def sa_group_mlp_max(xyz, feats, inds, radius, nsample, use_xyz, normalize_xyz, 
     new_xyz = torch.empty((B, npnt, 3), dtype=torch.float32, device=dev)
     idx = torch.empty((B, npnt, nsample), dtype=torch.int32, device=dev)
     out = torch.empty((B, chain.channels[-1], npnt), dtype=torch.float32, device=dev)
-    check(_lib.load().gf_sa_group_mlp_max(ptr(xyz), ptr(feats) if feats is not None else None, ptr(inds), B, n, C, npnt,
-                                          float(radius), int(nsample), int(bool(use_xyz)), int(bool(normalize_xyz)),
-                                          chain.n, chain.W, chain.scale, chain.shift, chain.ch, chain.relu,
-                                          ptr(new_xyz), ptr(idx), ptr(out), stream_ptr()), "gf_sa_group_mlp_max")
+    lib = _lib.load()
+    scratch, ready = grid, grid is not None
+    if scratch is None and B == 1 and n >= 4096:  # hash grid for the ball query, built here
+        scratch = torch.empty(lib.gf_knn_scratch_bytes(n) // 4 + 16, dtype=torch.int32, device=dev)
+    check(lib.gf_sa_group_mlp_max(ptr(xyz), ptr(feats) if feats is not None else None, ptr(inds), B, n, C, npnt,
+                                  float(radius), int(nsample), int(bool(use_xyz)), int(bool(normalize_xyz)),
+                                  chain.n, chain.W, chain.scale, chain.shift, chain.ch, chain.relu,
+                                  ptr(new_xyz), ptr(idx), ptr(out), ptr(scratch), int(ready), stream_ptr()),
+          "gf_sa_group_mlp_max")
     return new_xyz, idx, out
 
 

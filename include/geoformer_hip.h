@@ -295,10 +295,21 @@ int gf_group_mlp_max(const float* grouped, int B, int npoint, int nsample, int n
  *   channels[0] must equal C + 3*use_xyz. */
 int gf_ball_query_centres(const float* xyz, const int32_t* centre_idx, int b, int n, int m, float radius, int nsample,
                           float* new_xyz, int32_t* idx, void* stream);
+/* The same query for ONE point set through a hash grid with cells of `radius` (27 buckets around each centre instead
+ * of every point): identical rows, ~8x less work at 2048 centres x 50 000 points.  Centres as indices into xyz
+ * (centre_idx, new_xyz then receives their coordinates) or as coordinates (centres fp32 [m,3], new_xyz may be NULL).
+ *   scratch: gf_knn_scratch_bytes(n). */
+int gf_point_grid_build(const float* xyz, int n, float radius, void* scratch, void* stream);
+int gf_ball_query_grid(const float* xyz, int n, const int32_t* centre_idx, const float* centres, int m, float radius,
+                       int nsample, void* scratch, int grid_ready, float* new_xyz, int32_t* idx, void* stream);
+/* gf_point_grid_build: the grid alone (same points, radius and scratch), e.g. early on another stream; the query is
+ * then called with grid_ready = 1 and launches nothing but itself. */
 int gf_sa_group_mlp_max(const float* xyz, const float* feats, const int32_t* inds, int B, int n, int C, int npoint,
                         float radius, int nsample, int use_xyz, int normalize_xyz, int n_layers,
                         const float* const* W, const float* const* scale, const float* const* shift,
-                        const int* channels, const int* relu, float* new_xyz, int32_t* idx, float* out, void* stream);
+                        const int* channels, const int* relu, float* new_xyz, int32_t* idx, float* out, void* scratch,
+                        int grid_ready, void* stream);
+/* scratch: NULL, or gf_knn_scratch_bytes(n) bytes -> grid ball query (B = 1; grid_ready as above) */
 
 /* Soft-max over the middle dimension of x[n0,n1,inner] (training path of the decoder's vector cross-attention,
  * model/transformer_detr.py:449: F.softmax(sim / sqrt(d), dim=1) on [nq,nc,B,d]):

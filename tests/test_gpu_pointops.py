@@ -71,9 +71,14 @@ def test_ball_query_bit_exact(hip, oracle, n, m, ns):
     centers = xyz[:, oracle.fps(xyz, m)[0]]
     centers[0, -1] = 50.0  # a centre with no neighbour: row stays all-zero (ball_query.cpp:22-24)
     ref = oracle.ball_query(centers, xyz, 0.2, ns)
-    got = pointops.ball_query(_dev(centers), _dev(xyz), 0.2, ns).cpu().numpy()
-    assert (got == ref).all()
-    assert (got[0, -1] == 0).all()
+    for grid in (False, True):  # linear scan and hash-grid kernels: the same rows
+        got = pointops.ball_query(_dev(centers), _dev(xyz), 0.2, ns, grid=grid).cpu().numpy()
+        assert (got == ref).all(), grid
+        assert (got[0, -1] == 0).all()
+    # a radius with more hits than the grid kernel's candidate list holds: it falls back to the scan per centre
+    big = oracle.ball_query(centers[:, :40], xyz, 1.5, ns)
+    got = pointops.ball_query(_dev(centers[:, :40].copy()), _dev(xyz), 1.5, ns, grid=True).cpu().numpy()
+    assert (got == big).all()
 
 
 def test_gather_group_and_grads(hip, oracle):
