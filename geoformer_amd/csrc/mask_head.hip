@@ -42,8 +42,11 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
                                                       const float* __restrict__ geo, const float* __restrict__ qxyz,
                                                       const float* __restrict__ mx, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, int N, int nq, int chunks,
+                                                      const float* __restrict__ b2, int ldp, int N, int nq, int chunks,
                                                       float* __restrict__ out) {
+    // ldp: 0 = four dense arrays (w1 [nq,16,19], b1 [nq,16], w2 [nq,16], b2 [nq]); else the row stride of ONE packed
+    // parameter matrix the four pointers point into (the controller's output, geoformer.py:264-284)
+    const int ld_w1 = ldp ? ldp : 16 * 19, ld_v = ldp ? ldp : 16, ld_s = ldp ? ldp : 1;
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int qgroups = (nq + MH_Q - 1) / MH_Q;
@@ -64,13 +67,13 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
 #pragma unroll
     for (int t = 0; t < MH_Q; t++) {
         const int q = min(qg * MH_Q + t, nq - 1);
-        const float* W = w1 + (size_t)q * 16 * 19;
+        const float* W = w1 + (size_t)q * ld_w1;
 #pragma unroll
         for (int s = 0; s < 4; s++) wf[t][s] = W[j * 19 + 3 + 4 * g + s];
-        w5[t] = g < 3 ? W[j * 19 + g] : b1[(size_t)q * 16 + j];
+        w5[t] = g < 3 ? W[j * 19 + g] : b1[(size_t)q * ld_v + j];
 #pragma unroll
-        for (int r = 0; r < 4; r++) ww[t][r] = w2[(size_t)q * 16 + 4 * g + r];
-        b2q[t] = b2[q];
+        for (int r = 0; r < 4; r++) ww[t][r] = w2[(size_t)q * ld_v + 4 * g + r];
+        b2q[t] = b2[(size_t)q * ld_s];
         qc[t] = g < 3 ? qxyz[q * 3 + g] : 0.f;
         mq[t] = USE_GEO ? mx[q] : 0.f;
     }
@@ -145,9 +148,21 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
     }
 }
 
+extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                                   const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                                   const float* b2, int ldp, int N, int nq, int C, float* out, void* stream);
 extern "C" int gf_mask_head(const float* feat, const float* coords, const float* geo, const float* qxyz,
                             const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
                             const float* b2, int N, int nq, int C, float* out, void* stream) {
+    return gf_mask_head_packed(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2, 0, N, nq, C, out, stream);
+}
+
+// the four per-query parameter blocks as pointers INTO one matrix with row stride ldp (floats): the controller's
+// [nq, 16*19 + 16 + 16 + 1] output read in place, no split / reshape / contiguous copies in front of the launch
+extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                                   const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                                   const float* b2, int ldp, int N, int nq, int C, float* out, void* stream) {
+    GF_CHECK_ARG(ldp >= 0, "gf_mask_head: negative parameter stride");
     GF_CHECK_ARG(C == 16, "gf_mask_head: only the 16-channel mask head (m=16) is implemented, got C=%d", C);
     GF_CHECK_ARG(N >= 0 && nq >= 0, "gf_mask_head: bad sizes");
     GF_CHECK_ARG((geo == nullptr) == (sqrt_max_geo == nullptr), "gf_mask_head: geo and sqrt_max_geo come together");
@@ -163,10 +178,10 @@ extern "C" int gf_mask_head(const float* feat, const float* coords, const float*
     hipStream_t st = (hipStream_t)stream;
     if (geo)
         hipLaunchKernelGGL((k_mask_head<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1, b1,
-                           w2, b2, N, nq, chunks, out);
+                           w2, b2, ldp, N, nq, chunks, out);
     else
         hipLaunchKernelGGL((k_mask_head<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1, b1,
-                           w2, b2, N, nq, chunks, out);
+                           w2, b2, ldp, N, nq, chunks, out);
     GF_CHECK_LAUNCH("gf_mask_head");
     return GF_OK;
 }

@@ -550,6 +550,21 @@ class GeoFormer(nn.Module):
         x = torch.matmul(w2, F.relu(h)) + b2  # nq x 1 x N
         return x.reshape(1, num_insts, n_mask)
 
+    def _mask_head_packed(self, geo_dist, mask_features, params, num_insts, coords_, fps_sampling_coords):
+        """mask_heads_forward (geoformer.py:286-324) with the generated parameters read from `params` in place."""
+        n_mask = mask_features.size(0)
+        early = self.__dict__.get("_gf_early", {})
+        hit = next((early.pop(k) for k in list(early) if k[0] == "mx" and early[k][0] is geo_dist), None)
+        if hit is not None:
+            mx = hit[1]  # computed beside the BFS
+        else:
+            mx = torch.max(geo_dist, dim=1)[0]
+            mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+        logits = pointops.mask_head_packed(mask_features.reshape(n_mask, self.output_dim).contiguous(),
+                                           coords_.contiguous(), geo_dist.contiguous(),
+                                           fps_sampling_coords.reshape(-1, 3).contiguous(), mx, params.contiguous())
+        return logits.reshape(1, num_insts, n_mask)
+
     def get_mask_prediction(self, geo_dists, param_kernels, mask_features, locs_float_, fps_sampling_locs,
                             batch_offsets_):
         num_layers, n_queries, batch = param_kernels.shape[:3]
@@ -560,13 +575,16 @@ class GeoFormer(nn.Module):
             pk2 = pk.transpose(0, 1).flatten(0, 1)  # [B*nq, C] token rows
             sem_chain = self._pointwise_chain("detr_sem_head", [self.detr_sem_head], pk2)
             tow_chain = self._pointwise_chain("before_embedding_tower", [self.before_embedding_tower], pk2)
+            packed = False
             if sem_chain is not None and tow_chain is not None:
-                # inference on the GPU: the two token MLPs as fused launches, the controller as one GEMM
+                # inference on the GPU: the two token MLPs as fused launches, the controller as one GEMM.  (Running
+                # the class head on the second stream beside the mask head was measured with tools/ab_inprocess.py:
+                # no difference -- back-to-back small kernels cost ~1.5 us each, not the ~5 us a profiler shows.)
                 rows = pk2.contiguous()
                 cls_logits = pointops.pointwise_mlp(rows, sem_chain).reshape(batch, n_queries, -1)
                 emb = pointops.pointwise_mlp(rows, tow_chain)
                 controllers = F.linear(emb, self.controller.weight[:, :, 0], self.controller.bias)
-            else:
+                packed = self.output_dim == 16 and self.use_coords
                 cls_logits = self.detr_sem_head(pk.permute(1, 2, 0)).transpose(1, 2)  # B x nq x classes
                 controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
             controllers = controllers.reshape(batch, n_queries, -1)
@@ -576,9 +594,14 @@ class GeoFormer(nn.Module):
                 if e - s == 0:
                     mask_logits_list.append(None)
                     continue
-                weights, biases = self.parse_dynamic_params(controllers[b], self.output_dim)
-                ml = self.mask_heads_forward(geo_dists[b], mask_features[s:e], weights, biases, n_queries,
-                                             locs_float_[s:e], fps_sampling_locs[b], use_geo=self.use_coords)
+                if packed and mask_features.is_cuda and not torch.is_grad_enabled():
+                    # the controller's output read in place by the kernel (no split / reshape / contiguous copies)
+                    ml = self._mask_head_packed(geo_dists[b], mask_features[s:e], controllers[b], n_queries,
+                                                locs_float_[s:e], fps_sampling_locs[b])
+                else:
+                    weights, biases = self.parse_dynamic_params(controllers[b], self.output_dim)
+                    ml = self.mask_heads_forward(geo_dists[b], mask_features[s:e], weights, biases, n_queries,
+                                                 locs_float_[s:e], fps_sampling_locs[b], use_geo=self.use_coords)
                 mask_logits_list.append(ml.squeeze(0))
             outputs.append({"cls_logits": cls_logits, "mask_logits": mask_logits_list})
         return outputs

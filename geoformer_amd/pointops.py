@@ -241,6 +241,24 @@ def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
     return out
 
 
+def mask_head_packed(feat, coords, geo, qxyz, sqrt_max_geo, params):
+    """mask_head with the per-query parameters read in place from the controller's output params [nq, 16*19+16+16+1]
+    (column blocks w1 | w2 | b1 | b2, parse_dynamic_params of geoformer.py:264-284)."""
+    for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (params, "params")):
+        _f32c(t, name)
+    N, C = feat.shape
+    nq, ld = params.shape
+    if ld != C * (C + 3) + C + C + 1:
+        raise RuntimeError(f"mask_head_packed: params has {ld} columns, expected {C * (C + 3) + 2 * C + 1}")
+    base = params.data_ptr()
+    o_w2, o_b1, o_b2 = C * (C + 3), C * (C + 3) + C, C * (C + 3) + 2 * C
+    out = torch.empty((nq, N), dtype=torch.float32, device=feat.device)
+    check(_lib.load().gf_mask_head_packed(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), base,
+                                          base + 4 * o_b1, base + 4 * o_w2, base + 4 * o_b2, ld, N, nq, C, ptr(out),
+                                          stream_ptr()), "gf_mask_head")
+    return out
+
+
 class PointwiseChain:
     """Folded parameters of a Conv1d(k=1)/Linear + eval BatchNorm1d + ReLU stack for gf_pointwise_mlp."""
 

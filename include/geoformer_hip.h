@@ -257,6 +257,11 @@ int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, in
 int gf_mask_head(const float* feat, const float* coords, const float* geo, const float* qxyz,
                  const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2, int N,
                  int nq, int C, float* out, void* stream);
+/* Same, with w1 / b1 / w2 / b2 pointing INTO one parameter matrix of row stride ldp floats (the controller's
+ * [nq, 16*19+16+16+1] output, split as geoformer.py:264-284 does: w1 | w2 | b1 | b2), read in place; ldp = 0: dense. */
+int gf_mask_head_packed(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                        const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2,
+                        int ldp, int N, int nq, int C, float* out, void* stream);
 
 /* ===================================================================================
  * Per-point MLP chains of the eval forward, fused: mask_tower (geoformer.py:64-71), semantic head
