@@ -585,6 +585,7 @@ class GeoFormer(nn.Module):
                 emb = pointops.pointwise_mlp(rows, tow_chain)
                 controllers = F.linear(emb, self.controller.weight[:, :, 0], self.controller.bias)
                 packed = self.output_dim == 16 and self.use_coords
+            else:
                 cls_logits = self.detr_sem_head(pk.permute(1, 2, 0)).transpose(1, 2)  # B x nq x classes
                 controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
             controllers = controllers.reshape(batch, n_queries, -1)
