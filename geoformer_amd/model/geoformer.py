@@ -354,6 +354,12 @@ class GeoFormer(nn.Module):
         if side is None:
             side = torch.cuda.Stream(device=locs_float_.device)  # (stream priorities made no difference: measured)
             sides[(locs_float_.device, main.cuda_stream)] = side
+        # a third stream for small work that needs neither the BFS nor the rest of the sampling (the ball query's
+        # point grid, the query positional embedding): behind the BFS on `side` it would gate the decoder
+        aux = sides.get((locs_float_.device, main.cuda_stream, "aux"))
+        if aux is None:
+            aux = sides[(locs_float_.device, main.cuda_stream, "aux")] = torch.cuda.Stream(device=locs_float_.device)
+        geo_ready = []
         staged, geo = [], []
         for b in range(batch_size):
             n_b = offs[b + 1] - offs[b]
@@ -373,16 +379,18 @@ class GeoFormer(nn.Module):
             xyz_ready.record(main)
             first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
             src = first[0, :nq].contiguous()
+            first_ready = torch.cuda.Event()
+            first_ready.record(main)
             grid = None
             if xyz_b.shape[1] >= 4096 and not torch.is_grad_enabled():
                 # the ball query's point grid needs the points only: built on the side stream under the first picks
                 # (issued after their launch -- nothing may delay that one)
-                side.wait_event(xyz_ready)
-                with torch.cuda.stream(side):
+                aux.wait_event(xyz_ready)
+                with torch.cuda.stream(aux):
                     grid = pointops.point_grid_build(xyz_b, self.set_aggregator.radius)
                     grid.record_stream(main)
                     grid_done = torch.cuda.Event()
-                    grid_done.record(side)
+                    grid_done.record(aux)
                 grid = (grid, grid_done)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -391,6 +399,9 @@ class GeoFormer(nn.Module):
                 g.record_stream(main)
                 src.record_stream(side)
                 geo.append(g)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                geo_ready.append(ev)
             # the rest of the sampling is on the critical path: issue it before anything else
             idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
             # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
@@ -402,11 +413,10 @@ class GeoFormer(nn.Module):
             staged.append((xyz_b, feat_b, idx, grid))
             if not epilogue:
                 continue
-            with torch.cuda.stream(side):
-                # small launches that only need the distances / the query picks ride in the BFS's shadow instead of
-                # sitting between the decoder and the mask head on the main stream
-                self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main)
-        self.__dict__["_gf_pending_side"] = side
+            # small launches that only need the distances / the query picks ride beside the sampling instead of
+            # sitting between the decoder and the mask head on the main stream
+            self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready)
+        self.__dict__["_gf_pending_side"] = geo_ready
         cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
         with grad_ctx():
             fused = []
@@ -426,28 +436,37 @@ class GeoFormer(nn.Module):
             context_feats = self.set_aggregator.mlp(cat(gfeat), cat(gxyz)).transpose(1, 2)
         return (context_locs, context_feats, pre_enc_inds), geo
 
-    def _side_epilogue(self, b, batch_size, g, xyz_b, src, pc_dims, main):
+    def _side_epilogue(self, b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready):
         early = self.__dict__.setdefault("_gf_early", {})
         if b == 0:
             early.clear()
-        # sqrt of the per-query maximum geodesic distance (mask_heads_forward, geoformer.py:303-306)
-        mx = torch.max(g, dim=1)[0]
-        mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
-        mx.record_stream(main)
-        early[("mx", b)] = (g, mx)
+        with torch.cuda.stream(side):
+            # behind the BFS: sqrt of the per-query maximum geodesic distance (mask_heads_forward, geoformer.py:303-306)
+            mx = torch.max(g, dim=1)[0]
+            mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+            mx.record_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            early[("mx", b)] = (g, mx, ev)
         if batch_size == 1 and pc_dims is not None and self.cfg.dec_dim == 64:
-            qpr = self._pointwise_chain("qproj", [self.query_projection], xyz_b)
-            if qpr is not None:
-                q_locs = xyz_b[:, src.long()]  # the first picks = the query points (same gather as group_points)
-                qpe = self.pos_embedding(q_locs, input_range=pc_dims).float()
-                qpos = pointops.pointwise_mlp(qpe[0].t().contiguous(), qpr)
-                qpos.record_stream(main)
-                early["qpos"] = (q_locs, qpos)
+            aux.wait_event(first_ready)
+            with torch.cuda.stream(aux):
+                # (the folded copy of the projection's parameters is derived on the stream that reads it)
+                qpr = self._pointwise_chain("qproj", [self.query_projection], xyz_b)
+                if qpr is not None:
+                    q_locs = xyz_b[:, src.long()]  # the first picks = the query points (same gather as group_points)
+                    qpe = self.pos_embedding(q_locs, input_range=pc_dims).float()
+                    qpos = pointops.pointwise_mlp(qpe[0].t().contiguous(), qpr)
+                    qpos.record_stream(main)
+                    src.record_stream(aux)
+                    ev = torch.cuda.Event()
+                    ev.record(aux)
+                    early["qpos"] = (q_locs, qpos, ev)
 
     def _join_side_stream(self):
-        side = self.__dict__.pop("_gf_pending_side", None)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+        """The calling stream waits for the geodesic distances (not for the small launches queued behind them)."""
+        for ev in self.__dict__.pop("_gf_pending_side", None) or ():
+            torch.cuda.current_stream().wait_event(ev)
 
     # -- decoder ------------------------------------------------------------------------------
     def relative_position_embedding(self, context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds):
@@ -490,6 +509,7 @@ class GeoFormer(nn.Module):
                 rel = self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds)
                 hit = self.__dict__.get("_gf_early", {}).pop("qpos", None)  # computed beside the BFS (joined above)
                 if hit is not None and hit[0].shape == query_locs.shape:
+                    torch.cuda.current_stream().wait_event(hit[2])
                     qpos = hit[1]
                 else:
                     qpe = self.pos_embedding(query_locs, input_range=pc_dims).float()  # [1, dec_dim, nq]
@@ -526,6 +546,7 @@ class GeoFormer(nn.Module):
                 early = self.__dict__.get("_gf_early", {})
                 hit = next((early.pop(k) for k in list(early) if k[0] == "mx" and early[k][0] is geo_dist), None)
                 if hit is not None:
+                    torch.cuda.current_stream().wait_event(hit[2])
                     mx = hit[1]  # computed beside the BFS
                 else:
                     mx = torch.max(geo_dist, dim=1)[0]
@@ -556,6 +577,7 @@ class GeoFormer(nn.Module):
         early = self.__dict__.get("_gf_early", {})
         hit = next((early.pop(k) for k in list(early) if k[0] == "mx" and early[k][0] is geo_dist), None)
         if hit is not None:
+            torch.cuda.current_stream().wait_event(hit[2])
             mx = hit[1]  # computed beside the BFS
         else:
             mx = torch.max(geo_dist, dim=1)[0]
