@@ -21,7 +21,7 @@
 namespace {
 constexpr int MT_N = 624, MT_M = 397;
 
-inline void mt_advance(uint32_t* key) {
+__attribute__((always_inline)) inline void mt_advance_body(uint32_t* key) {
     constexpr uint32_t A = 0x9908b0dfu, UP = 0x80000000u, LO = 0x7fffffffu;
     int i = 0;
     for (; i < MT_N - MT_M; i++) {
@@ -36,7 +36,7 @@ inline void mt_advance(uint32_t* key) {
     key[MT_N - 1] = key[MT_M - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & A);
 }
 
-inline void mt_temper_block(const uint32_t* __restrict__ key, uint32_t* __restrict__ out) {
+__attribute__((always_inline)) inline void mt_temper_body(const uint32_t* __restrict__ key, uint32_t* __restrict__ out) {
     for (int i = 0; i < MT_N; i++) {
         uint32_t y = key[i];
         y ^= y >> 11;
@@ -46,6 +46,23 @@ inline void mt_temper_block(const uint32_t* __restrict__ key, uint32_t* __restri
         out[i] = y;
     }
 }
+
+// the block update and the tempering are element-wise over 624 words: compiled once more for AVX2 (8 words per
+// instruction) and picked at run time
+__attribute__((target("avx2"))) void mt_next_block_avx2(uint32_t* key, uint32_t* out) {
+    mt_advance_body(key);
+    mt_temper_body(key, out);
+}
+void mt_next_block_base(uint32_t* key, uint32_t* out) {
+    mt_advance_body(key);
+    mt_temper_body(key, out);
+}
+inline void mt_next_block(uint32_t* key, uint32_t* out) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) mt_next_block_avx2(key, out);
+    else mt_next_block_base(key, out);
+}
+inline void mt_temper_block(const uint32_t* __restrict__ key, uint32_t* __restrict__ out) { mt_temper_body(key, out); }
 }  // namespace
 
 // key[624], *pos: numpy's MT19937 state (pos == 624: the block is used up).  out[k] = permutation(n)[:k].
@@ -72,17 +89,28 @@ extern "C" int gf_host_legacy_choice(uint32_t* key, int32_t* pos_io, long long n
         const uint32_t lo = (mask >> 1) + 1;  // the mask serves positions lo..mask
         while (i >= lo) {
             if (pos == MT_N) {
-                mt_advance(key);
-                mt_temper_block(key, block);
+                mt_next_block(key, block);
                 pos = 0;
             }
-            int t = pos;
-            for (; t < MT_N && i >= lo; t++) {
-                const uint32_t v = block[t] & mask;
+            // i drops by at most one per draw, so the next min(words left, i - lo + 1) draws cannot leave the mask's
+            // range: a check-free inner loop (the only loop-carried chain is compare -> subtract)
+            const int avail = MT_N - pos;
+            const uint32_t room = i - lo + 1;
+            const int m = room < (uint32_t)avail ? (int)room : avail;
+            const uint32_t* b = block + pos;
+            for (int t = 0; t < m; t++) {
+                const uint32_t v = b[t] & mask;
                 J[i] = v;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+                // i -= (v <= i) as compare + add-with-carry: two cycles of loop-carried latency instead of the four of
+                // the compare / set / extend / subtract sequence the compiler emits (this loop is 80k iterations of
+                // nothing else)
+                asm("cmp %1, %0\n\tadc $-1, %0" : "+r"(i) : "r"(v) : "cc");
+#else
                 i -= (v <= i);
+#endif
             }
-            pos = t;
+            pos += m;
         }
     }
     // pass 2: the swaps
