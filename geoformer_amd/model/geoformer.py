@@ -49,12 +49,14 @@ import threading
 _OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
 
 
-def get_batch_offsets(batch_idxs, bs):
-    """offsets[i+1] = offsets[i] + count(batch_idxs == i)  (util/utils.py:132-142), one device op."""
+def get_batch_offsets(batch_idxs, bs, host_only=False):
+    """offsets[i+1] = offsets[i] + count(batch_idxs == i)  (util/utils.py:132-142), one device op.
+    host_only (one scene): the offsets tensor stays on the host -- every reader of the eval forward wants host integers,
+    and creating a two-element device tensor is a synchronous 40 us copy in a launch-bound stretch."""
     if bs == 1:
         # one scene: the offsets are known on the host, no device round trip when they are read back
         n = int(batch_idxs.shape[0])
-        t = torch.tensor([0, n], dtype=torch.int32, device=batch_idxs.device)
+        t = torch.tensor([0, n], dtype=torch.int32, device="cpu" if host_only else batch_idxs.device)
         _OFFS_CACHE.key, _OFFS_CACHE.val = t, [0, n]
         return t
     counts = torch.bincount(batch_idxs.long(), minlength=bs)[:bs]
@@ -368,8 +370,7 @@ class GeoFormer(nn.Module):
             if sample:
                 npoint = min(n_b, self.cfg.n_downsampling)
                 # the reference's host draw (same values, same generator state), restated natively: the device idles on it
-                sampling_indices = torch.tensor(pointops.legacy_choice(n_b, npoint), dtype=torch.long,
-                                                device=locs_float_.device)
+                sampling_indices = torch.from_numpy(pointops.legacy_choice(n_b, npoint)).to(locs_float_.device)
                 self.last_sampling_indices = sampling_indices
                 xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
             else:
@@ -716,7 +717,7 @@ class GeoFormer(nn.Module):
             locs_float_ = locs_float[fg_idxs]
             output_feats_ = output_feats[fg_idxs]
             semantic_scores_ = semantic_scores[fg_idxs]
-        batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size)
+        batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size, host_only=fused_fg and not training)
         offs_ = _offsets_list(batch_offsets_)  # the only read-back of this stretch, before the heavy launches
         chain = self._pointwise_chain("mask_tower", [self.mask_tower], output_feats_)
         if chain is not None:
