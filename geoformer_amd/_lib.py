@@ -78,6 +78,7 @@ def _declare(lib):
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),
         "gf_relpos_prepare": (I, [P, P, I, I, I, P, P, P]),
+        "gf_proposal_select": (I, [P, P, P, I, P, P, P, P, P]),
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),
         "gf_backbone_transformer_num_params": (I, [I]),
         "gf_backbone_transformer": (I, [P, P, P, I, I, I, I, P, P, P, P]),

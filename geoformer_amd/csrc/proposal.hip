@@ -261,3 +261,54 @@ extern "C" int gf_relpos_prepare(const float* geo, const int32_t* inds, int nq, 
     GF_CHECK_LAUNCH("gf_relpos_prepare");
     return GF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Accepted queries in ascending order, with their classes and scores, on the device (generate_proposal,
+// geoformer.py:236-243: `final = ...; cls_final = cls_pred[final]; scores_final = scores[final]`): the host then
+// reads back ONE integer (how many) instead of the flags, and the membership scatter takes the list as it is.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_proposal_select(const int32_t* __restrict__ final_, const int32_t* __restrict__ cls_pred,
+                                                          const float* __restrict__ scores, int nq,
+                                                          int32_t* __restrict__ sel, long long* __restrict__ cls_out,
+                                                          float* __restrict__ scores_out, int32_t* __restrict__ count) {
+    __shared__ int s_w[16];
+    __shared__ int s_run;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += 1024) {
+        const int q = base + threadIdx.x;
+        const bool f = q < nq && final_[q] != 0;
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0) s_w[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int c = s_w[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        const int run = s_run;
+        if (f) {
+            const int pos = run + before + __popcll(bal & ((1ull << lane) - 1ull));
+            sel[pos] = q;
+            cls_out[pos] = cls_pred[q];
+            scores_out[pos] = scores[q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = s_run;
+}
+
+extern "C" int gf_proposal_select(const int32_t* final_, const int32_t* cls_pred, const float* scores, int nq,
+                                  int32_t* sel, long long* cls_out, float* scores_out, int32_t* d_count, void* stream) {
+    GF_CHECK_ARG(final_ && cls_pred && scores && sel && cls_out && scores_out && d_count && nq >= 0,
+                 "gf_proposal_select: bad arguments");
+    hipLaunchKernelGGL(k_proposal_select, dim3(1), dim3(1024), 0, (hipStream_t)stream, final_, cls_pred, scores, nq, sel,
+                       cls_out, scores_out, d_count);
+    GF_CHECK_LAUNCH("gf_proposal_select");
+    return GF_OK;
+}

@@ -98,18 +98,18 @@ def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighb
 
 
 class PendingProposals:
-    """The tail of generate_proposal (geoformer.py:236-262) behind the forward's last device->host read-back: the
-    acceptance flags of the queries are on their way to a pinned host buffer; ``get()`` waits for them, selects the
-    accepted queries on the host and queues the membership scatter on the stream the forward ran on."""
+    """The tail of generate_proposal (geoformer.py:236-262) behind the forward's last device->host read-back.  The
+    accepted queries are compacted on the device (indices, classes, scores); only their NUMBER travels to a pinned
+    host word.  ``get()`` waits for it and queues the membership scatter on the stream the forward ran on."""
 
-    _pinned = {}
+    _pinned = []
 
     def __init__(self, final, cls_pred, scores, logits, fg_idxs, logit_thresh, num_points):
-        self.args = (cls_pred, scores, logits, fg_idxs, logit_thresh, num_points)
         self.stream = torch.cuda.current_stream(logits.device)
-        self.pool = PendingProposals._pinned.setdefault(int(final.numel()), [])  # free landing buffers of this size
-        buf = self.pool.pop() if self.pool else torch.empty(final.numel(), dtype=torch.int32).pin_memory()
-        buf.copy_(final, non_blocking=True)
+        sel, cls, sc, cnt = pointops.proposal_select(final.contiguous(), cls_pred.contiguous(), scores.contiguous())
+        self.args = (sel, cls, sc, logits, fg_idxs, logit_thresh, num_points)
+        buf = PendingProposals._pinned.pop() if PendingProposals._pinned else torch.empty(1, dtype=torch.int32).pin_memory()
+        buf.copy_(cnt, non_blocking=True)
         self.host = buf
         self.done = torch.cuda.Event()
         self.done.record(self.stream)
@@ -117,19 +117,17 @@ class PendingProposals:
 
     def get(self):
         if self.value is None:
-            cls_pred, scores, logits, fg_idxs, logit_thresh, num_points = self.args
+            sel, cls, sc, logits, fg_idxs, logit_thresh, num_points = self.args
             self.done.synchronize()
-            keep = np.flatnonzero(self.host.numpy())
-            self.pool.append(self.host)
+            n = int(self.host[0])
+            PendingProposals._pinned.append(self.host)
             self.host = None
-            if keep.size == 0:
+            if n == 0:
                 self.value = ([], [], [])
             else:
                 with torch.cuda.stream(self.stream):
-                    sel = torch.from_numpy(keep.astype(np.int32)).to(logits.device)
-                    proposals = pointops.proposal_scatter(logits, sel, fg_idxs, logit_thresh, num_points)
-                    sel = sel.long()
-                    self.value = (cls_pred[sel].long(), scores[sel], proposals)
+                    proposals = pointops.proposal_scatter(logits, sel[:n], fg_idxs, logit_thresh, num_points)
+                self.value = (cls[:n], sc[:n], proposals)
             self.args = None
         return self.value
 

@@ -419,6 +419,21 @@ def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh
     return ints[0], ints[1], scores, ints[2]
 
 
+def proposal_select(final, cls_pred, scores):
+    """Accepted queries compacted on the device: (sel i32[nq], cls i64[nq], scores f32[nq], count i32[1]); the first
+    `count` entries are valid."""
+    _i32c(final, "final"); _i32c(cls_pred, "cls_pred"); _f32c(scores, "scores")
+    nq = final.shape[0]
+    dev = final.device
+    sel = torch.empty(nq, dtype=torch.int32, device=dev)
+    cls = torch.empty(nq, dtype=torch.int64, device=dev)
+    sc = torch.empty(nq, dtype=torch.float32, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    check(_lib.load().gf_proposal_select(ptr(final), ptr(cls_pred), ptr(scores), nq, ptr(sel), ptr(cls), ptr(sc), ptr(cnt),
+                                         stream_ptr()), "gf_proposal_select")
+    return sel, cls, sc, cnt
+
+
 def proposal_scatter(mask_logits, sel, fg_idxs, logit_thresh, num_points):
     """0/1 membership rows [len(sel), num_points] (int32) of the selected queries over the scene's points."""
     _f32c(mask_logits, "mask_logits"), _i32c(sel, "sel")

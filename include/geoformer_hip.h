@@ -373,6 +373,11 @@ int gf_proposal_scatter(const float* mask_logits, const int* sel, int n_sel, int
 int gf_relpos_prepare(const float* geo, const int32_t* inds, int nq, int n, int nc, float* geo_ctx, float* max_geo,
                       void* stream);
 
+/* The accepted queries of gf_proposal_stats in ascending order with their classes / scores (geoformer.py:236-243),
+ * compacted on the device: sel int32 [nq], cls_out int64 [nq], scores_out fp32 [nq] (capacity nq), *d_count = how many. */
+int gf_proposal_select(const int32_t* final_, const int32_t* cls_pred, const float* scores, int nq, int32_t* sel,
+                       long long* cls_out, float* scores_out, int32_t* d_count, void* stream);
+
 /* inter[i,j] = number of points in both proposal i and proposal j (matrix NMS, util/utils_3d.py:95-141: the
  * einsum over the [n,N] float masks; exact because the masks are 0/1).  masks int32 [n,N] (gf_proposal_scatter
  * output), inter int32 [n,n], scratch: gf_mask_intersections_scratch_bytes(n, N). */

@@ -318,6 +318,23 @@ def test_select_foreground_fused(hip, N, equal):
     assert none[0].numel() == 0 and none[3].shape == (0, 16)
 
 
+@pytest.mark.parametrize("nq", [256, 1, 1500])
+def test_proposal_select(hip, nq):
+    """gf_proposal_select: accepted queries in ascending order with their classes / scores (geoformer.py:236-243)."""
+    from geoformer_amd import pointops
+
+    g = torch.Generator().manual_seed(nq)
+    final = (torch.rand(nq, generator=g) < 0.3).int()
+    cls = torch.randint(0, 13, (nq,), generator=g).int()
+    sc = torch.rand(nq, generator=g)
+    sel, c, s_, cnt = pointops.proposal_select(final.cuda(), cls.cuda(), sc.cuda())
+    n = int(cnt.item())
+    ref = torch.nonzero(final).view(-1)
+    assert n == ref.numel()
+    assert torch.equal(sel[:n].cpu().long(), ref) and c.dtype == torch.int64
+    assert torch.equal(c[:n].cpu(), cls[ref].long()) and torch.equal(s_[:n].cpu(), sc[ref])
+
+
 def test_relpos_prepare(hip):
     """gf_relpos_prepare vs the PyTorch sequence of relative_position_embedding (geoformer.py:619-651)."""
     from geoformer_amd import pointops
