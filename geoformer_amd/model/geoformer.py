@@ -71,6 +71,15 @@ def _offsets_list(t):
     return _OFFS_CACHE.val
 
 
+def _tensors_of(obj):
+    """All tensors inside nested tuples / lists (for record_stream)."""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            yield from _tensors_of(o)
+
+
 @torch.no_grad()
 def knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05):
     """Per scene the radius-limited kNN graph of the foreground points (find_knn + the radius filter of
@@ -332,7 +341,7 @@ class GeoFormer(nn.Module):
             return context_locs, context_feats, pre_enc_inds
 
     def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step,
-                                       pc_dims=None, sample=True, epilogue=True):
+                                       pc_dims=None, sample=True, epilogue=True, early=None):
         """Inference on the GPU.  Furthest point sampling (2047 serial rounds on 16 compute units) and the geodesic
         BFS (<= 256 serial hops, one workgroup per query) are the two long latency-bound launches of the forward, and
         the BFS only needs the first n_query_points picks.  So the sampling is cut after those picks, the BFS goes
@@ -380,6 +389,19 @@ class GeoFormer(nn.Module):
             src = first[0, :nq].contiguous()
             first_ready = torch.cuda.Event()
             first_ready.record(main)
+            if early is not None and b == 0:
+                # work of the caller that does not depend on the sampling (early() -> (.., .., kNN graphs)): queued on
+                # the third stream now that the first sampling launch is out
+                aux.wait_event(xyz_ready)
+                with torch.cuda.stream(aux):
+                    early_out = early()
+                    graphs = early_out[2]
+                    for t in _tensors_of(early_out):
+                        t.record_stream(main)
+                        t.record_stream(side)
+                    early_done = torch.cuda.Event()
+                    early_done.record(aux)
+                side.wait_event(early_done)
             grid = None
             if xyz_b.shape[1] >= 4096 and not torch.is_grad_enabled():
                 # the ball query's point grid needs the points only: built on the side stream under the first picks
@@ -403,6 +425,8 @@ class GeoFormer(nn.Module):
                 geo_ready.append(ev)
             # the rest of the sampling is on the critical path: issue it before anything else
             idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+            if early is not None and b == 0:
+                main.wait_event(early_done)
             # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
             with grad_ctx():
                 feat_b = output_feats_[offs[b]:offs[b + 1]]
@@ -426,14 +450,16 @@ class GeoFormer(nn.Module):
             if all(f is not None for f in fused):
                 context_locs, pre_enc_inds = cat([f[0] for f in fused]), cat([st[2] for st in staged])
                 context_feats = cat([f[1] for f in fused]).transpose(1, 2)
-                return (context_locs, context_feats, pre_enc_inds), geo
+                res = ((context_locs, context_feats, pre_enc_inds), geo)
+                return res + (early_out,) if early is not None else res
             locs, gfeat, gxyz, inds = [], [], [], []
             for xyz_b, feat_b, idx, _ in staged:
                 l, gf, gx, idx = self.set_aggregator.group_points(xyz_b, feat_b, inds=idx)
                 locs.append(l); gfeat.append(gf); gxyz.append(gx); inds.append(idx)
             context_locs, pre_enc_inds = cat(locs), cat(inds)
             context_feats = self.set_aggregator.mlp(cat(gfeat), cat(gxyz)).transpose(1, 2)
-        return (context_locs, context_feats, pre_enc_inds), geo
+        res = ((context_locs, context_feats, pre_enc_inds), geo)
+        return res + (early_out,) if early is not None else res
 
     def _side_epilogue(self, b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready):
         early = self.__dict__.setdefault("_gf_early", {})
@@ -717,31 +743,44 @@ class GeoFormer(nn.Module):
             semantic_scores_ = semantic_scores[fg_idxs]
         batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size, host_only=fused_fg and not training)
         offs_ = _offsets_list(batch_offsets_)  # the only read-back of this stretch, before the heavy launches
-        chain = self._pointwise_chain("mask_tower", [self.mask_tower], output_feats_)
-        if chain is not None:
-            mask_features_ = pointops.pointwise_mlp(output_feats_.contiguous(), chain).unsqueeze(2)
-        else:
-            mask_features_ = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
-        # the kNN graphs need the points only: on the device they run under the host's RNG draw, and so does the
-        # class-probability table the proposal scores read at the very end
-        sem_prob = None
-        if not training:
-            sem_prob = F.softmax(semantic_scores_, dim=1)
-            if sem_prob.is_cuda:
-                sem_prob = (sem_prob, sem_prob.t().contiguous())  # + the class-major copy the proposal kernel reads
-        graphs = None
-        if locs_float_.is_cuda and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0:
-            graphs = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
+        nonempty = min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0
+
+        def sampling_independent():
+            """Everything of this stretch that does not need the sampling: mask features, class probabilities (read
+            by the proposal scores at the very end), the kNN graphs."""
+            chain = self._pointwise_chain("mask_tower", [self.mask_tower], output_feats_)
+            if chain is not None:
+                mf = pointops.pointwise_mlp(output_feats_.contiguous(), chain).unsqueeze(2)
+            else:
+                mf = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
+            sp = None
+            if not training:
+                sp = F.softmax(semantic_scores_, dim=1)
+                if sp.is_cuda:
+                    sp = (sp, sp.t().contiguous())  # + the class-major copy the proposal kernel reads
+            gr = None
+            if locs_float_.is_cuda and nonempty:
+                gr = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
+            return mf, sp, gr
 
         max_step = 128 if self.training else 256
         geo_dists = None
-        if graphs is not None and os.environ.get("GF_OVERLAP", "1") != "0":
-            # (training too: sampling and BFS carry no gradient; grouping and the shared MLP stay PyTorch autograd)
-            contexts, geo_dists = self._aggregate_geodesic_overlapped(locs_float_, output_feats_, batch_offsets_,
-                                                                      batch_size, graphs, max_step, pc_dims,
-                                                                      epilogue=not torch.is_grad_enabled())
+        overlap = locs_float_.is_cuda and nonempty and os.environ.get("GF_OVERLAP", "1") != "0"
+        if overlap and fused_fg and not training:
+            # inference: the host goes straight to the sampling draw and the first sampling launch; the work above is
+            # issued behind that launch on the third stream and runs beside it (the sampler keeps 16 CUs busy)
+            contexts, geo_dists, (mask_features_, sem_prob, graphs) = self._aggregate_geodesic_overlapped(
+                locs_float_, output_feats_, batch_offsets_, batch_size, None, max_step, pc_dims, epilogue=True,
+                early=sampling_independent)
         else:
-            contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
+            mask_features_, sem_prob, graphs = sampling_independent()
+            if graphs is not None and overlap:
+                # (training too: sampling and BFS carry no gradient; grouping and the shared MLP stay PyTorch autograd)
+                contexts, geo_dists = self._aggregate_geodesic_overlapped(locs_float_, output_feats_, batch_offsets_,
+                                                                          batch_size, graphs, max_step, pc_dims,
+                                                                          epilogue=not torch.is_grad_enabled())
+            else:
+                contexts = self.forward_aggregator(locs_float_, output_feats_, batch_offsets_, batch_size)
         if contexts is None:
             outputs["mask_predictions"] = None
             return outputs
