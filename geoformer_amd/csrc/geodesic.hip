@@ -664,6 +664,9 @@ extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32
     if (nq == 0) return GF_OK;
     const int nw = (n + 31) / 32;
     const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
+    // the two bitmaps must fit the workgroup's LDS share: a large scene moves to the next larger workgroup (and
+    // share) before it gives up the LDS-resident kernel altogether
+    while (wg_threads < 1024 && bm + 256 * 2 * sizeof(int2) > (size_t)BFS_LDS_BYTES * wg_threads / 1024) wg_threads *= 2;
     const size_t budget = (size_t)BFS_LDS_BYTES * wg_threads / 1024;
     if (n <= BFS_LDS_MAX_N && (K & 3) == 0 && bm + 64 * 2 * sizeof(int2) <= budget) {
         // rows must be distance-sorted and padded with (inf,-1) (gf_knn_radius / faiss order): the
