@@ -36,7 +36,9 @@ def _declare(lib):
         "gf_conv_packed_floats": (c_size_t, [I, I, I]),
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P]),
-        "gf_conv_fwd_timed": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_dev_conv_fwd_timed": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_dev_conv_knobs": (I, [I, I, I, I, I]),
+        "gf_dev_conv_occupancy": (I, [I]),
         "gf_resblock_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),

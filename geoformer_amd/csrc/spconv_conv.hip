@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "geoformer_hip_dev.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CONV_MAX_CIN 512
@@ -581,9 +582,22 @@ struct ConvKnobs {
         if (const char* e = getenv("GF_CONV_PAIR")) pair = atoi(e) != 0;
     }
 };
-static const ConvKnobs& conv_knobs() {
-    static const ConvKnobs k;
+static ConvKnobs& conv_knobs_mut() {
+    static ConvKnobs k;
     return k;
+}
+static const ConvKnobs& conv_knobs() { return conv_knobs_mut(); }
+
+// Dev hook (include/geoformer_hip_dev.h): force a launch shape regardless of the level's size; -1 = size-based.
+extern "C" int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int block) {
+    ConvKnobs& k = conv_knobs_mut();
+    k.split = split < 0 ? -1 : (split != 0);
+    k.wide = wide < 0 ? -1 : (wide != 0);
+    k.pair = pair < 0 ? -1 : (pair != 0);
+    k.ldsw = ldsw > 0;
+    k.block = block <= 0 ? 0 : (block > 256 ? 256 : block);
+    g_conv_block = k.block > 0 ? k.block : 256;
+    return GF_OK;
 }
 
 extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
@@ -679,7 +693,7 @@ extern "C" int gf_resblock_fwd(const float* x, const float* Wp0, const float* Wp
 
 // Same launch bracketed by two caller-owned hipEvent_t recorded back to back with the kernel on the
 // same stream (bench.py's roofline probe: the kernel's own duration, not the host's launch gaps).
-extern "C" int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
+extern "C" int gf_dev_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
                                  int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
                                  const float* in_shift, const float* residual, float* out, void* ev_start,
                                  void* ev_stop, void* stream) {
@@ -759,7 +773,7 @@ extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* 
     return GF_OK;
 }
 
-extern "C" int gf_debug_conv_occupancy(int block) {
+extern "C" int gf_dev_conv_occupancy(int block) {
     int n = -1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_conv_os<1, false, true, true>, block,
                                                      27 * 1024) != hipSuccess)

@@ -88,7 +88,13 @@ def voxelize_host(locs: np.ndarray, mode: int = 4):
     voxelize.cpp:58-152) in vectorised numpy.  Product code for the synthetic-data
     harness (DataLoader side of the boundary); checked against the oracle in tests."""
     N = locs.shape[0]
-    key = np.ascontiguousarray(locs).view([("", locs.dtype)] * locs.shape[1]).reshape(N)
+    ext = locs.max(0).astype(np.int64) + 1 if N else np.ones(locs.shape[1], np.int64)
+    if N and locs.min() >= 0 and float(np.prod(ext.astype(np.float64))) < 2.0 ** 62:
+        key = np.zeros(N, np.int64)  # one packed integer per row: np.unique on it is ~50x faster than on records
+        for c in range(locs.shape[1]):
+            key = key * ext[c] + locs[:, c]
+    else:
+        key = np.ascontiguousarray(locs).view([("", locs.dtype)] * locs.shape[1]).reshape(N)
     _, first, inv, counts = np.unique(key, return_index=True, return_inverse=True, return_counts=True)
     order = np.argsort(first, kind="stable")  # voxel ids in order of first occurrence
     rank = np.empty_like(order)

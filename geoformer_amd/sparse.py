@@ -188,10 +188,10 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
             if not e.cuda_event:
                 e.record()  # materialise the hipEvent_t handle
         check(
-            lib.gf_conv_fwd_timed(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
+            lib.gf_dev_conv_fwd_timed(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
                                   ptr(in_shift), ptr(residual), ptr(out), events[0].cuda_event, events[1].cuda_event,
                                   stream_ptr()),
-            "gf_conv_fwd_timed",
+            "gf_dev_conv_fwd_timed",
         )
         return out
     check(
@@ -200,6 +200,11 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
         "gf_conv_fwd",
     )
     return out
+
+
+def dev_conv_knobs(split=-1, wide=-1, pair=-1, ldsw=0, block=0):
+    """Dev hook (include/geoformer_hip_dev.h): force gf_conv_fwd's launch shape; no arguments = size-based choice."""
+    check(_lib.load().gf_dev_conv_knobs(split, wide, pair, ldsw, block), "gf_dev_conv_knobs")
 
 
 def resblock_fwd(x: torch.Tensor, wp0, wp1, wpi, nbr, gmask, K: int, M: int, ld: int, Cin: int, Cout: int, s0, t0, s1,
@@ -221,12 +226,12 @@ def resblock_fwd(x: torch.Tensor, wp0, wp1, wpi, nbr, gmask, K: int, M: int, ld:
             check(lib.gf_conv_fwd(x.data_ptr(), wpi.data_ptr(), None, None, 1, M, M, 0, Cin, Cout, None, None, None,
                                   buf[2].data_ptr(), st), "gf_conv_fwd")
             idn = buf[2]
-        check(lib.gf_conv_fwd_timed(x.data_ptr(), wp0.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), K, M, M, ld, Cin,
+        check(lib.gf_dev_conv_fwd_timed(x.data_ptr(), wp0.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), K, M, M, ld, Cin,
                                     Cout, s0.data_ptr(), t0.data_ptr(), None, buf[1].data_ptr(),
-                                    events[0][0].cuda_event, events[0][1].cuda_event, st), "gf_conv_fwd_timed")
-        check(lib.gf_conv_fwd_timed(buf[1].data_ptr(), wp1.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), K, M, M, ld,
+                                    events[0][0].cuda_event, events[0][1].cuda_event, st), "gf_dev_conv_fwd_timed")
+        check(lib.gf_dev_conv_fwd_timed(buf[1].data_ptr(), wp1.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), K, M, M, ld,
                                     Cout, Cout, s1.data_ptr(), t1.data_ptr(), idn.data_ptr(), buf[0].data_ptr(),
-                                    events[1][0].cuda_event, events[1][1].cuda_event, st), "gf_conv_fwd_timed")
+                                    events[1][0].cuda_event, events[1][1].cuda_event, st), "gf_dev_conv_fwd_timed")
         return buf[0]
     check(lib.gf_resblock_fwd(x.data_ptr(), wp0.data_ptr(), wp1.data_ptr(), None if wpi is None else wpi.data_ptr(),
                               nbr.data_ptr(), gmask.data_ptr(), K, M, ld, Cin, Cout, s0.data_ptr(), t0.data_ptr(),

@@ -135,12 +135,6 @@ int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint
                 int ld, int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual,
                 float* out, void* stream);
 
-/* gf_conv_fwd with two caller-owned hipEvent_t recorded immediately before/after the launch on `stream`
- * (profiling aid used by bench.py's roofline probe). */
-int gf_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in,
-                      int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
-                      const float* residual, float* out, void* ev_start, void* ev_stop, void* stream);
-
 /* Pre-activation residual block (ResidualBlock, model/geoformer/geoformer_modules.py:10-35) in eval mode, one
  * call:  out = conv1(relu(bn1(conv0(relu(bn0(x)))))) + (Wpi ? x . Wi : x).
  *   x fp32 [M,Cin]; Wp0 (K,Cin,Cout), Wp1 (K,Cout,Cout), Wpi (1,Cin,Cout) or NULL: gf_conv_pack_weights output;

@@ -1,0 +1,36 @@
+/*
+ * geoformer_hip_dev.h -- development / measurement hooks of libgeoformer_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/geoformer_hip.h): nothing on the product path calls these.
+ * They exist for bench.py's roofline probe, for the parity tests that force every launch shape on a small
+ * input, and for the dev tools under tools/.  Same conventions as the product header (device pointers,
+ * hipStream_t as void*, 0 = ok).
+ */
+#ifndef GEOFORMER_HIP_DEV_H
+#define GEOFORMER_HIP_DEV_H
+
+#include "geoformer_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gf_conv_fwd with two caller-owned hipEvent_t recorded immediately before/after the launch on `stream`
+ * (the kernel's own duration on the stream it runs on; bench.py's roofline probe). */
+int gf_dev_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in,
+                          int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
+                          const float* residual, float* out, void* ev_start, void* ev_stop, void* stream);
+
+/* Force gf_conv_fwd's launch shape (it normally follows the level's size): split / wide / pair: 0, 1 or -1 (size
+ * based); ldsw: 1 = weights staged in LDS where supported; block: threads per workgroup of the one-wave-per-group
+ * shape (0 = default).  Process-wide; tests reset with (-1,-1,-1,0,0).  The same knobs can be set once from the
+ * environment (GF_CONV_SPLIT / _WIDE / _PAIR / _LDSW / _BLOCK). */
+int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int block);
+
+/* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
+int gf_dev_conv_occupancy(int block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,7 +30,24 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define ORC_API __attribute__((visibility("default")))
+
+/* Host threads for the embarrassingly parallel outer loops (output rows of a convolution, kNN queries, BFS
+ * sources, ball-query centres).  Every output element is still produced by ONE thread in the documented
+ * order, so results do not depend on the thread count.  Used by bench.py's cpu_baseline ("cores"). */
+ORC_API int orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------
  * small open-addressing hash (uint64 key -> int32 value), used where the reference uses
@@ -249,6 +266,7 @@ ORC_API int32_t orc_rules_down2(const int32_t *coords, int32_t M, int32_t X, int
  *   (nbr[k][i] = parent[i] iff k == koff[i]) indice_inverse_conv. */
 ORC_API void orc_conv_fwd(const float *in, const float *W, const int32_t *nbr, int32_t K, int32_t M_out, int32_t ld,
                           int32_t Cin, int32_t Cout, float *out) {
+#pragma omp parallel for schedule(static, 256)
     for (int32_t o = 0; o < M_out; o++) {
         float *dst = out + (size_t)o * Cout;
         for (int32_t c = 0; c < Cout; c++) dst[c] = 0.0f;
@@ -383,6 +401,7 @@ ORC_API void orc_ball_query(const float *new_xyz /*[b,m,3]*/, const float *xyz /
         const float *P = xyz + (size_t)bi * n * 3;
         const float *Q = new_xyz + (size_t)bi * m * 3;
         int32_t *I = idx + (size_t)bi * m * nsample;
+#pragma omp parallel for schedule(dynamic, 16)
         for (int32_t j = 0; j < m; j++) {
             float nx = Q[j * 3 + 0], ny = Q[j * 3 + 1], nz = Q[j * 3 + 2];
             int32_t cnt = 0;
@@ -463,26 +482,30 @@ ORC_API void orc_three_interpolate_grad(const float *grad_out /*[b,c,n]*/, const
  * ---------------------------------------------------------------------------------- */
 ORC_API void orc_knn(const float *base /*[n,3]*/, int32_t n, const float *query /*[nq,3]*/, int32_t nq, int32_t k,
                      float *D /*[nq,k]*/, int64_t *I /*[nq,k]*/) {
-    float *bd = (float *)malloc(sizeof(float) * (size_t)k);
-    int64_t *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
-    for (int32_t q = 0; q < nq; q++) {
-        int32_t cnt = 0;
-        float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
-        for (int32_t p = 0; p < n; p++) {
-            float dx = qx - base[p * 3 + 0], dy = qy - base[p * 3 + 1], dz = qz - base[p * 3 + 2];
-            float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            if (cnt == k && !(d < bd[k - 1])) continue; /* ascending p: ties keep the earlier index */
-            int32_t pos = cnt < k ? cnt : k - 1;
-            while (pos > 0 && d < bd[pos - 1]) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; pos--; }
-            bd[pos] = d; bi[pos] = p;
-            if (cnt < k) cnt++;
+#pragma omp parallel
+    {
+        float *bd = (float *)malloc(sizeof(float) * (size_t)k);
+        int64_t *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
+#pragma omp for schedule(dynamic, 64)
+        for (int32_t q = 0; q < nq; q++) {
+            int32_t cnt = 0;
+            float qx = query[q * 3 + 0], qy = query[q * 3 + 1], qz = query[q * 3 + 2];
+            for (int32_t p = 0; p < n; p++) {
+                float dx = qx - base[p * 3 + 0], dy = qy - base[p * 3 + 1], dz = qz - base[p * 3 + 2];
+                float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                if (cnt == k && !(d < bd[k - 1])) continue; /* ascending p: ties keep the earlier index */
+                int32_t pos = cnt < k ? cnt : k - 1;
+                while (pos > 0 && d < bd[pos - 1]) { bd[pos] = bd[pos - 1]; bi[pos] = bi[pos - 1]; pos--; }
+                bd[pos] = d; bi[pos] = p;
+                if (cnt < k) cnt++;
+            }
+            for (int32_t j = 0; j < k; j++) {
+                D[(size_t)q * k + j] = j < cnt ? bd[j] : INFINITY;
+                I[(size_t)q * k + j] = j < cnt ? bi[j] : -1;
+            }
         }
-        for (int32_t j = 0; j < k; j++) {
-            D[(size_t)q * k + j] = j < cnt ? bd[j] : INFINITY;
-            I[(size_t)q * k + j] = j < cnt ? bi[j] : -1;
-        }
+        free(bd); free(bi);
     }
-    free(bd); free(bi);
 }
 
 /* ------------------------------------------------------------------------------------
@@ -503,11 +526,14 @@ ORC_API void orc_knn(const float *base /*[n,3]*/, int32_t n, const float *query 
 ORC_API void orc_geodesic(const float *dist_arr /*[n,kk]*/, const int64_t *idx_arr /*[n,kk]*/, int32_t n, int32_t kk,
                           const int64_t *query_inds /*[nq]*/, int32_t nq, float radius, int32_t max_step,
                           float *geo /*[nq,n]*/) {
+#pragma omp parallel
+    {
     uint8_t *visited = (uint8_t *)malloc((size_t)n);
     int32_t *first = (int32_t *)malloc(sizeof(int32_t) * (size_t)n); /* stamp of the hop that listed the point */
     float *cand = (float *)malloc(sizeof(float) * (size_t)n);
     int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
     int32_t *nxt = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+#pragma omp for schedule(dynamic, 1)
     for (int32_t q = 0; q < nq; q++) {
         float *g = geo + (size_t)q * n;
         for (int32_t p = 0; p < n; p++) { g[p] = -1.0f; first[p] = -1; }
@@ -538,6 +564,7 @@ ORC_API void orc_geodesic(const float *dist_arr /*[n,kk]*/, const int64_t *idx_a
         }
     }
     free(visited); free(first); free(cand); free(cur); free(nxt);
+    }
 }
 
 /* ------------------------------------------------------------------------------------

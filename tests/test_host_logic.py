@@ -20,9 +20,14 @@ def lib():
 
 
 def _declared():
-    text = open(os.path.join(ROOT, "include", "geoformer_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gf_[a-z0-9_]+)\s*\(", text)))
+    """Every entry point declared in include/*.h (the product ABI and the dev-hook header)."""
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for f in sorted(os.listdir(inc)):
+        if f.endswith(".h"):
+            text = re.sub(r"/\*.*?\*/", "", open(os.path.join(inc, f)).read(), flags=re.S)
+            names |= set(re.findall(r"\b(gf_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -32,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(names) > 60
     raw = ctypes.CDLL(_lib.LIB_PATH)
     missing = [n for n in names if not hasattr(raw, n)]
-    assert not missing, f"declared in include/geoformer_hip.h but not exported: {missing}"
+    assert not missing, f"declared in include/*.h but not exported: {missing}"
     # every declared entry point has argument/return types bound on the handle the package uses
     unbound = [n for n in names if getattr(lib, n).argtypes is None]
     assert not unbound, f"no ctypes signature in geoformer_amd/_lib.py: {unbound}"

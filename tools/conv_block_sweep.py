@@ -3,8 +3,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from geoformer_amd import sparse, scene, _lib
 lib = _lib.load()
-lib.gf_debug_conv_occupancy.restype = ctypes.c_int
-for b in (64, 128, 256, 512): print("occupancy API blocks/CU at block", b, lib.gf_debug_conv_occupancy(b))
+lib.gf_dev_conv_occupancy.restype = ctypes.c_int
+for b in (64, 128, 256, 512): print("occupancy API blocks/CU at block", b, lib.gf_dev_conv_occupancy(b))
 sc = scene.make_scene(150_000, 1234)
 batch = scene.make_batch([sc])
 coords = batch["voxel_locs"].int().cuda().contiguous()
