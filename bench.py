@@ -96,7 +96,8 @@ class ConvProbe:
 
         def probe(x, wp0, wp1, wpi, nbr, gmask, K, M_, ld, Cin, Cout, s0, t0, s1, t1, **kw):
             # level-1 16->16 blocks: events recorded in native code right around the two 3x3x3 launches, on the
-            # kernel's stream (first conv: BN+ReLU prologue; second: prologue + residual epilogue)
+            # kernel's stream (first conv: BN+ReLU prologue and the second BN+ReLU as epilogue; second conv: residual
+            # epilogue)
             if self.on and K == 27 and M_ in self.Ms and Cin == 16 and Cout == 16:
                 self.tbl[M_] = nbr
                 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
@@ -122,7 +123,8 @@ class ConvProbe:
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC["bytes"],
                 "traffic_source": PMC_TRAFFIC["source"],
-                "kernel": "level-1 subm 3x3x3 16->16 launches (BN+ReLU prologue; residual epilogue on half of them)",
+                "kernel": "level-1 subm 3x3x3 16->16 launches of the residual blocks (first conv: BN+ReLU prologue and "
+                          "BN+ReLU epilogue; second conv: residual epilogue)",
                 "launches": len(us), "us_per_launch": round(float(np.mean(us)), 2),
                 "algorithmic_bytes": int(np.mean(byt)), "rules": R, "voxels": sorted(R),
                 "sampling": f"every level-1 launch of every {PROBE_EVERY}th timed step"}
@@ -160,7 +162,7 @@ def all_convs_roofline(model, batches, reps=2):
     def block(x, wp0, wp1, wpi, nbr, gmask, K, M, ld, Cin, Cout, s0, t0, s1, t1, **kw):
         R = rules_of(nbr, M)
         a = ev()
-        out = orig_block(x, wp0, wp1, wpi, nbr, gmask, K, M, ld, Cin, Cout, s0, t0, s1, t1)
+        out = orig_block(x, wp0, wp1, wpi, nbr, gmask, K, M, ld, Cin, Cout, s0, t0, s1, t1, **kw)
         items = [(R, M, K, Cin, Cout, False), (R, M, K, Cout, Cout, True)]
         if wpi is not None:
             items.append((torch.tensor(M, device=x.device), M, 1, Cin, Cout, False))

@@ -29,17 +29,20 @@ def _declare(lib):
         "gf_index_words": (c_size_t, [I, I, I, I]),
         "gf_index_scratch_bytes": (c_size_t, [c_size_t]),
         "gf_index_build": (I, [P, I, P, I, I, I, I, P, P, P, P, P]),
-        "gf_rules_subm3": (I, [P, I, P, I, I, I, P, P, P, P, I, P, P]),
+        "gf_rules_subm3": (I, [P, I, P, I, I, I, P, P, P, P, I, P, P, P]),
+        "gf_rules_steps_words": (c_size_t, [I]),
         "gf_rules_down2": (I, [P, I, P, I, I, I, I, P, P, P, P, P, P, I, P, P, P, I, P, P, P]),
         "gf_rules_down2_chain_plan": (I, [I, I, I, I, I, I, P, P, P, P, P]),
         "gf_rules_down2_chain": (I, [P, I, I, I, I, I, I, P, P, P]),
         "gf_conv_packed_floats": (c_size_t, [I, I, I]),
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
-        "gf_conv_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P]),
-        "gf_dev_conv_fwd_timed": (I, [P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_conv_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_dev_conv_fwd_timed": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
+        "gf_dev_conv_knobs_g16": (I, [I, I, I, I]),
+        "gf_dev_conv_chunks": (I, [I]),
         "gf_dev_conv_knobs": (I, [I, I, I, I, I]),
         "gf_dev_conv_occupancy": (I, [I]),
-        "gf_resblock_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
+        "gf_resblock_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
         "gf_voxelize_bp": (I, [P, P, I, I, I, I, P, P]),
@@ -122,7 +125,7 @@ def load():
 
     lib = ctypes.CDLL(LIB_PATH)
     EXPORTS = _declare(lib)
-    if lib.gf_abi_version() != 1:
+    if lib.gf_abi_version() != 2:
         raise GeoFormerHipError("libgeoformer_hip.so ABI version mismatch")
     _lib = lib
     return lib

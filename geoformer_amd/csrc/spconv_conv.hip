@@ -162,7 +162,8 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
                                                  int K, int M_out, int ld, int Cin, int Cout, int NCH, int NCB,
                                                  int nsplit, unsigned in_bytes, const float* __restrict__ in_scale,
                                                  const float* __restrict__ in_shift,
-                                                 const float* __restrict__ residual, float* __restrict__ out) {
+                                                 const float* __restrict__ residual, const float* __restrict__ out_scale,
+                                                 const float* __restrict__ out_shift, float* __restrict__ out) {
     constexpr int PF = ConvPF<NCBW>::value;
     constexpr bool SPLIT = SW > 0;  // SW waves of the workgroup share one item
     constexpr int NSW = SW > 0 ? SW : 1;
@@ -369,12 +370,16 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
                 v[3] = sum.w;
             }
             const int col = (cb0 + cb) * 16 + r;
+            // epilogue activation (the consumer's eval-mode BatchNorm + ReLU applied once per output element)
+            const float osc = (out_scale && col < Cout) ? out_scale[col] : 1.f;
+            const float osh = (out_scale && col < Cout) ? out_shift[col] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = g * 16 + q * 4 + j;
                 if (row < M_out && col < Cout) {
                     float x = v[j];
                     if (residual) x += (NCBW <= 2) ? res[NCBW <= 2 ? cb : 0][j] : residual[(size_t)row * Cout + col];
+                    if (out_scale) x = fmaxf(fmaf(x, osc, osh), 0.f);
                     out[(size_t)row * Cout + col] = x;
                 }
             }
@@ -400,7 +405,9 @@ __global__ __launch_bounds__(256, 5) void k_conv_pair(const float* __restrict__ 
                                                       int Cin, int Cout, int NCH, unsigned in_bytes,
                                                       const float* __restrict__ in_scale,
                                                       const float* __restrict__ in_shift,
-                                                      const float* __restrict__ residual, float* __restrict__ out) {
+                                                      const float* __restrict__ residual,
+                                                      const float* __restrict__ out_scale,
+                                                      const float* __restrict__ out_shift, float* __restrict__ out) {
     constexpr int PF = CONV_PAIR_PF;
     __shared__ unsigned s_off[4][32 * 32];
     __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];
@@ -511,15 +518,560 @@ __global__ __launch_bounds__(256, 5) void k_conv_pair(const float* __restrict__ 
         }
         // C/D layout: col = lane&15, row = (lane>>4)*4 + j
         if (r < Cout) {
+            const float osc = out_scale ? out_scale[r] : 1.f, osh = out_scale ? out_shift[r] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row0 = g0 * 16 + q * 4 + j, row1 = g1 * 16 + q * 4 + j;
-                if (row0 < M_out) out[(size_t)row0 * Cout + r] = acc0[j] + res0[j];
-                if (row1 < M_out) out[(size_t)row1 * Cout + r] = acc1[j] + res1[j];
+                float y0 = acc0[j] + res0[j], y1 = acc1[j] + res1[j];
+                if (out_scale) {
+                    y0 = fmaxf(fmaf(y0, osc, osh), 0.f);
+                    y1 = fmaxf(fmaf(y1, osc, osh), 0.f);
+                }
+                if (row0 < M_out) out[(size_t)row0 * Cout + r] = y0;
+                if (row1 < M_out) out[(size_t)row1 * Cout + r] = y1;
             }
         }
         __builtin_amdgcn_wave_barrier();  // off_l is rewritten by the next pair
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Counted-loop kernel for the 16-output-channel levels (level 1 of the U-Net: ~9000 groups, 9 launches per scene).
+//
+// What bound k_conv_pair (profiles/r1_e_pmc_conv_l1.md): ~700 scalar/vector instructions per wave around ~100 MFMAs
+// (bit-scanning step iterator, index staging through LDS, four dword stores per row block) and a chain of dependent
+// memory round trips per wave (mask -> indices -> gathers -> store).  Here
+//   * the rulebook hands over a STEP TABLE (spconv_rules.hip k_subm3): per 16-row group only the present offsets, four
+//     steps per 16-byte entry, so lane (row, *) holds the indices of up to 12 steps after three loads that do not
+//     depend on the group's mask -- no LDS staging, no iterator; missing neighbours are index -1, which the
+//     shift-and-add address turns into an out-of-range buffer offset (reads as zeros, no memory traffic);
+//   * all gathers of the first GF_STEP_PHA blocks are issued back to back (one round trip), then the MFMAs run in a
+//     fully unrolled, per-step guarded sequence;
+//   * the product is computed TRANSPOSED (A = packed weights, B = gathered rows: out^T = W^T in^T), so a lane ends
+//     up with four consecutive output channels of ONE row: one 16-byte store (and one 16-byte residual load) per
+//     lane instead of four strided dwords;
+//   * LDSW: the packed weights (27 KiB at 16->16) are staged once per workgroup and read with conflict-free
+//     ds_read_b128; a workgroup then walks `gpw` groups per wave so the staging is amortised.
+// Same arithmetic as k_conv_os / k_conv_pair: fp32 MFMA, per-offset ascending order, channel order inside an offset
+// given by the packed layout.
+// ------------------------------------------------------------------------------------
+#ifndef CONV_G16_PHA2
+#define CONV_G16_PHA2 2  // blocks of four steps gathered up front when Cin = 32 (two 16-channel chunks per step)
+#endif
+template <int NCH, bool AFF, bool RES, bool LDSW>
+__global__ __launch_bounds__(256) void k_conv_g16(const float* __restrict__ in, const float4* __restrict__ Wp,
+                                                  const int4* __restrict__ steps, const uint32_t* __restrict__ gmask,
+                                                  int K, int M_out, unsigned in_bytes, int gpw,
+                                                  const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                  const float* __restrict__ residual, const float* __restrict__ out_scale,
+                                                  const float* __restrict__ out_shift, float* __restrict__ out) {
+    constexpr int PHA = NCH == 1 ? GF_STEP_PHA : CONV_G16_PHA2;
+    constexpr unsigned ROWB = NCH * 64u;  // bytes per input row
+    constexpr int SHIFT = NCH == 1 ? 6 : 7;
+    extern __shared__ __attribute__((aligned(16))) float4 s_w[];
+    __shared__ __attribute__((aligned(16))) float s_aff[2][NCH * 16];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int ngroups = (M_out + 15) >> 4;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, K * NCH * 1024, 0x00020000);
+    if (LDSW) {
+        const int total = K * NCH * 64;
+        for (int t = threadIdx.x; t < total; t += 256) s_w[t] = Wp[t];
+    }
+    if (AFF) {
+        if (threadIdx.x < NCH * 16) {
+            s_aff[0][threadIdx.x] = in_scale[threadIdx.x];
+            s_aff[1][threadIdx.x] = in_shift[threadIdx.x];
+        }
+    }
+    if (LDSW || AFF) __syncthreads();
+    const unsigned lane_ch = 16u * (unsigned)q;  // byte offset of this lane's 4 channels inside a 16-channel chunk
+    float4 sc[NCH], sh[NCH];
+    if (AFF) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            sc[c] = *reinterpret_cast<const float4*>(&s_aff[0][c * 16 + 4 * q]);
+            sh[c] = *reinterpret_cast<const float4*>(&s_aff[1][c * 16 + 4 * q]);
+        }
+    }
+
+#ifdef CONV_G16_STRIP
+#if CONV_G16_STRIP == 0
+    return;
+#endif
+#endif
+    for (int i = 0; i < gpw; i++) {
+        const int g = (blockIdx.x * gpw + i) * 4 + w;
+        if (g >= ngroups) break;
+        const int row = g * 16 + r;
+#ifdef CONV_G16_STRIP
+#if CONV_G16_STRIP == 1  // stores only
+        if (row < M_out) *reinterpret_cast<float4*>(out + (size_t)row * 16 + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+#endif
+#endif
+        const int4* rec = steps + (size_t)g * (GF_STEP_BLKS * 16) + r;
+        int4 ib[PHA];
+#pragma unroll
+        for (int b = 0; b < PHA; b++) ib[b] = rec[b * 16];
+        uint32_t m = __builtin_amdgcn_readfirstlane(gmask[g]);
+        const int n = __popc(m);
+        float4 resv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (RES && row < M_out) resv = *reinterpret_cast<const float4*>(residual + (size_t)row * 16 + 4 * q);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#ifdef CONV_G16_STRIP
+#if CONV_G16_STRIP == 2  // index loads + mask + store
+        if (row < M_out) {
+            float4 v = make_float4((float)(ib[0].x + ib[1].y + ib[PHA - 1].z), (float)n, resv.x, 0.f);
+            *reinterpret_cast<float4*>(out + (size_t)row * 16 + 4 * q) = v;
+        }
+        continue;
+#endif
+#endif
+
+        // ---- phase A: the first PHA blocks, every gather in flight at once ----
+        u32x4 a[PHA * 4][NCH];
+#pragma unroll
+        for (int s = 0; s < PHA * 4; s++) {
+            const int idx = reinterpret_cast<const int*>(&ib[s >> 2])[s & 3];
+            const unsigned voff = ((unsigned)idx << SHIFT) + lane_ch;  // idx == -1: beyond the descriptor, reads zeros
+#if defined(CONV_G16_STRIP) && CONV_G16_STRIP == 4  // no gathers: MFMA + weights on index-derived values
+#pragma unroll
+            for (int c = 0; c < NCH; c++) a[s][c] = (u32x4){voff, voff + 1u, voff + 2u, voff + 3u};
+#else
+#pragma unroll
+            for (int c = 0; c < NCH; c++) a[s][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, c * 64, 0);
+#endif
+        }
+#ifdef CONV_G16_STRIP
+#if CONV_G16_STRIP == 3  // + gathers, summed on the VALU, no MFMA / weights
+        {
+            float4 v = resv;
+#pragma unroll
+            for (int s = 0; s < PHA * 4; s++)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    v.x += __uint_as_float(a[s][c][0]); v.y += __uint_as_float(a[s][c][1]);
+                    v.z += __uint_as_float(a[s][c][2]); v.w += __uint_as_float(a[s][c][3]);
+                }
+            if (row < M_out) *reinterpret_cast<float4*>(out + (size_t)row * 16 + 4 * q) = v;
+            continue;
+        }
+#endif
+#endif
+#pragma unroll
+        for (int s = 0; s < PHA * 4; s++) {
+            if (s < n) {
+                const int k = __builtin_ctz(m);
+                m &= m - 1;
+                const bool present = reinterpret_cast<const int*>(&ib[s >> 2])[s & 3] >= 0;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    float4 wv;
+                    if (LDSW) {
+                        wv = s_w[(k * NCH + c) * 64 + lane];
+                    } else {
+                        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)lane * 16u,
+                                                                              (unsigned)(k * NCH + c) * 1024u, 0);
+                        wv = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
+                                         __uint_as_float(t[3]));
+                    }
+                    float4 x = make_float4(__uint_as_float(a[s][c][0]), __uint_as_float(a[s][c][1]),
+                                           __uint_as_float(a[s][c][2]), __uint_as_float(a[s][c][3]));
+                    if (AFF) {
+                        x.x = present ? fmaxf(fmaf(x.x, sc[c].x, sh[c].x), 0.f) : 0.f;
+                        x.y = present ? fmaxf(fmaf(x.y, sc[c].y, sh[c].y), 0.f) : 0.f;
+                        x.z = present ? fmaxf(fmaf(x.z, sc[c].z, sh[c].z), 0.f) : 0.f;
+                        x.w = present ? fmaxf(fmaf(x.w, sc[c].w, sh[c].w), 0.f) : 0.f;
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, x.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, x.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, x.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, x.w, acc1, 0, 0, 0);
+                }
+            }
+        }
+        // ---- phase B: groups with more than 4*PHA present offsets, one block at a time ----
+        for (int b = PHA; b * 4 < n; b++) {
+            const int4 jb = rec[b * 16];
+            u32x4 e[4][NCH];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned voff = ((unsigned)reinterpret_cast<const int*>(&jb)[j] << SHIFT) + lane_ch;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) e[j][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, c * 64, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (b * 4 + j < n) {
+                    const int k = __builtin_ctz(m);
+                    m &= m - 1;
+                    const bool present = reinterpret_cast<const int*>(&jb)[j] >= 0;
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        float4 wv;
+                        if (LDSW) {
+                            wv = s_w[(k * NCH + c) * 64 + lane];
+                        } else {
+                            const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)lane * 16u,
+                                                                                  (unsigned)(k * NCH + c) * 1024u, 0);
+                            wv = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
+                                             __uint_as_float(t[3]));
+                        }
+                        float4 x = make_float4(__uint_as_float(e[j][c][0]), __uint_as_float(e[j][c][1]),
+                                               __uint_as_float(e[j][c][2]), __uint_as_float(e[j][c][3]));
+                        if (AFF) {
+                            x.x = present ? fmaxf(fmaf(x.x, sc[c].x, sh[c].x), 0.f) : 0.f;
+                            x.y = present ? fmaxf(fmaf(x.y, sc[c].y, sh[c].y), 0.f) : 0.f;
+                            x.z = present ? fmaxf(fmaf(x.z, sc[c].z, sh[c].z), 0.f) : 0.f;
+                            x.w = present ? fmaxf(fmaf(x.w, sc[c].w, sh[c].w), 0.f) : 0.f;
+                        }
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, x.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, x.y, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, x.z, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, x.w, acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // transposed C/D layout: lane (r, q) holds channels 4q..4q+3 of row g*16 + r
+        if (row < M_out) {
+            float4 v = make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+            if (RES) {
+                v.x += resv.x; v.y += resv.y; v.z += resv.z; v.w += resv.w;
+            }
+            if (out_scale) {  // epilogue activation: the consumer's BatchNorm + ReLU, once per output element
+                const float4 os = *reinterpret_cast<const float4*>(out_scale + 4 * q);
+                const float4 ot = *reinterpret_cast<const float4*>(out_shift + 4 * q);
+                v.x = fmaxf(fmaf(v.x, os.x, ot.x), 0.f); v.y = fmaxf(fmaf(v.y, os.y, ot.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, os.z, ot.z), 0.f); v.w = fmaxf(fmaf(v.w, os.w, ot.w), 0.f);
+            }
+            *reinterpret_cast<float4*>(out + (size_t)row * 16 + 4 * q) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Pipelined form of the kernel above (what bench.py's roofline line is quoted on).
+//
+// Measured on the S150k level-1 launch with parts of k_conv_g16 compiled out (rocprofv3 kernel trace, 2221
+// workgroups): empty kernel 2.5 us, + the output stores 4.4, + index loads 5.8, + gathers 10.0, and the MFMA section
+// alone adds 8.4 us (365 MFMAs per SIMD at the ~1.9 GHz the chip holds under load = 6.1 us at a fully paced matrix
+// pipe) -- and the full kernel takes the SUM, 20-21 us: every resident wave of a SIMD starts together, so they all
+// wait for memory together and then queue for the matrix pipe together; nothing overlaps.
+// Here a wave owns a CHUNK of consecutive groups of equal total cost (k_group_chunks: 2048 chunks = 8 waves per
+// compute unit, all resident at once, no tail) and software-pipelines over them: while the MFMAs of group i run,
+// the gathers of group i+1 are in flight and the indices of group i+2 are being fetched.  Every load of the
+// pipeline is issued unconditionally (a missing group or neighbour is index -1 = out of the descriptor's range, no
+// memory traffic), so the waits are exact counted vmcnt's instead of vmcnt(0).
+// ------------------------------------------------------------------------------------
+#ifdef CONV_TRACE
+// dev build: per-wave cycle stamps (s_memtime) of the pipelined kernel, written to a caller-set buffer
+__device__ unsigned long long* g_conv_trace = nullptr;
+extern "C" int gf_dev_conv_trace(void* p) {
+    GF_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_trace), &p, sizeof(p)));
+    return GF_OK;
+}
+#define TR_NOW() __builtin_amdgcn_s_memtime()
+#endif
+#ifndef CONV_G16P_WAVES
+#define CONV_G16P_WAVES 2  // resident waves per SIMD the register budget is set for
+#endif
+template <int NCH, bool AFF, bool RES, bool LDSW>
+__global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float* __restrict__ in, const float4* __restrict__ Wp,
+                                                      const int32_t* __restrict__ steps_raw,
+                                                      const uint32_t* __restrict__ gmask,
+                                                      const int32_t* __restrict__ chunks, int K, int M_out,
+                                                      unsigned in_bytes, unsigned steps_bytes,
+                                                      const float* __restrict__ in_scale,
+                                                      const float* __restrict__ in_shift,
+                                                      const float* __restrict__ residual,
+                                                      const float* __restrict__ out_scale,
+                                                      const float* __restrict__ out_shift, float* __restrict__ out) {
+    constexpr int PHA = NCH == 1 ? GF_STEP_PHA : CONV_G16_PHA2;
+    constexpr int NS = PHA * 4;  // steps of the pipelined part
+    constexpr int SHIFT = NCH == 1 ? 6 : 7;
+    extern __shared__ __attribute__((aligned(16))) float4 s_w[];
+    __shared__ __attribute__((aligned(16))) float s_aff[2][NCH * 16];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, K * NCH * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_st =
+        __builtin_amdgcn_make_buffer_rsrc((void*)steps_raw, 0, (int)steps_bytes, 0x00020000);
+    const int cw = blockIdx.x * 4 + w;
+#ifdef CONV_TRACE
+    unsigned long long tr[8] = {TR_NOW(), 0, 0, 0, 0, 0, 0, 0};  // start, after barrier, first data, [wait a0, mfma, tail] sums, end, groups
+#endif
+    const int nchunks = chunks[-1];
+    if (blockIdx.x * 4 >= nchunks) return;  // whole workgroup past the table (uniform: no barrier is skipped by part of it)
+    int g = __builtin_amdgcn_readfirstlane(chunks[min(cw, nchunks)]);
+    const int gend = __builtin_amdgcn_readfirstlane(chunks[min(cw + 1, nchunks)]);
+    const unsigned lane_ch = 16u * (unsigned)q;
+    const unsigned rec_lane = (unsigned)r * 16u;  // this lane's 16-byte entry inside a 256-byte step block
+    constexpr unsigned GROUP_BYTES = GF_STEP_BLKS * 256u;
+
+    // index blocks of one group: a group past the chunk's end reads beyond the descriptor (zeros) and is turned into
+    // "all missing" (-1) afterwards, so that every stage issues the same number of loads
+    auto load_idx = [&](u32x4 (&ib)[PHA], int gg) {
+        const unsigned base = gg < gend ? (unsigned)gg * GROUP_BYTES : 0xfffff000u;
+#pragma unroll
+        for (int b = 0; b < PHA; b++) ib[b] = __builtin_amdgcn_raw_buffer_load_b128(rs_st, rec_lane, base + b * 256u, 0);
+    };
+    auto gather = [&](u32x4 (&a)[NS][NCH], const u32x4 (&ib)[PHA], bool live, unsigned& pres) {
+        pres = 0;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int idx = live ? (int)ib[s >> 2][s & 3] : -1;
+            if (AFF) pres |= (idx >= 0 ? 1u : 0u) << s;
+            const unsigned voff = ((unsigned)idx << SHIFT) + lane_ch;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) a[s][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, c * 64, 0);
+        }
+    };
+
+    u32x4 ibX[PHA], ibY[PHA];
+    u32x4 aX[NS][NCH], aY[NS][NCH];
+    unsigned presX = 0, presY = 0;
+    // prologue part 1 (before the weights are staged: these loads overlap the staging)
+    // prologue: index blocks of the first two groups, the weights (all staging loads in flight together: a
+    // load / wait / write loop costs one memory round trip per 4 KiB, 2.6 us measured), then the first group's
+    // gathers -- all of it before the barrier the LDS weights need
+    load_idx(ibX, g);
+    load_idx(ibY, g + 1);
+    if (LDSW) {
+        const int total = K * NCH * 64;
+        constexpr int WST = 8;  // 27 x 64 x NCH float4 over 256 threads: at most 7 (NCH 1) / 14 (NCH 2) per thread
+        for (int base = 0; base < total; base += 256 * WST) {
+            u32x4 tmp[WST];
+#pragma unroll
+            for (int j = 0; j < WST; j++)
+                tmp[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(base + j * 256 + (int)threadIdx.x) * 16u, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WST; j++) {
+                const int t = base + j * 256 + (int)threadIdx.x;
+                if (t < total)
+                    s_w[t] = make_float4(__uint_as_float(tmp[j][0]), __uint_as_float(tmp[j][1]), __uint_as_float(tmp[j][2]),
+                                         __uint_as_float(tmp[j][3]));
+            }
+        }
+    }
+    float4 sc[NCH], sh[NCH];
+    if (AFF) {  // every lane reads its own channels' scale / shift directly (L2-resident, 16 bytes)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            sc[c] = *reinterpret_cast<const float4*>(in_scale + c * 16 + 4 * q);
+            sh[c] = *reinterpret_cast<const float4*>(in_shift + c * 16 + 4 * q);
+        }
+    }
+    if (g < gend) gather(aX, ibX, true, presX);
+    if (LDSW) __syncthreads();
+#ifdef CONV_TRACE
+    tr[1] = TR_NOW();
+#endif
+    if (g >= gend) return;
+
+    // one group's MFMAs + store; `a` holds its gathered rows (in flight), `pres` its presence bits
+    auto compute = [&](u32x4 (&a)[NS][NCH], unsigned pres, int gg) {
+        uint32_t m = __builtin_amdgcn_readfirstlane(gmask[gg]);
+        const int n = __popc(m);
+        const int row = gg * 16 + r;
+        float4 resv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (RES && row < M_out) resv = *reinterpret_cast<const float4*>(residual + (size_t)row * 16 + 4 * q);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // offsets of the pipelined steps up front (scalar), weights of step s+1 requested before the MFMAs of step s;
+        // steps past the group's count multiply all-missing rows (zeros) by the weights of offset 0: skipped from
+        // step 8 on (a group of a scanned room has at least 9 present offsets in 99.9 % of the cases)
+        int ks[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            ks[s] = m ? __builtin_ctz(m) : 0;
+            m &= m - 1;
+        }
+        float4 wq[NCH], wn[NCH];
+        auto fetch_w = [&](float4 (&dst)[NCH], int k) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (LDSW) {
+                    dst[c] = s_w[(k * NCH + c) * 64 + lane];
+                } else {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)lane * 16u,
+                                                                          (unsigned)(k * NCH + c) * 1024u, 0);
+                    dst[c] = make_float4(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]),
+                                         __uint_as_float(t[3]));
+                }
+            }
+        };
+        auto mfma_step = [&](const u32x4 (&av)[NCH], const float4 (&wv)[NCH], bool present) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                float4 x = make_float4(__uint_as_float(av[c][0]), __uint_as_float(av[c][1]), __uint_as_float(av[c][2]),
+                                       __uint_as_float(av[c][3]));
+                if (AFF) {
+                    x.x = present ? fmaxf(fmaf(x.x, sc[c].x, sh[c].x), 0.f) : 0.f;
+                    x.y = present ? fmaxf(fmaf(x.y, sc[c].y, sh[c].y), 0.f) : 0.f;
+                    x.z = present ? fmaxf(fmaf(x.z, sc[c].z, sh[c].z), 0.f) : 0.f;
+                    x.w = present ? fmaxf(fmaf(x.w, sc[c].w, sh[c].w), 0.f) : 0.f;
+                }
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].x, x.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].y, x.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].z, x.z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c].w, x.w, acc1, 0, 0, 0);
+            }
+        };
+        fetch_w(wq, ks[0]);
+#ifdef CONV_TRACE
+        const unsigned long long tc0 = TR_NOW();
+        {
+            // wait for the first gathered row of this group (and only for it)
+            float probe = __uint_as_float(a[0][0][0]);
+            asm volatile("v_mov_b32 %0, %0" : "+v"(probe));
+            a[0][0][0] = __float_as_uint(probe);
+        }
+        const unsigned long long tc1 = TR_NOW();
+        tr[3] += tc1 - tc0;
+        if (tr[2] == 0) tr[2] = tc1;
+#endif
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (s + 1 < NS) fetch_w(wn, ks[s + 1]);
+            if (s < 8 || s < n) mfma_step(a[s], wq, AFF ? ((pres >> s) & 1u) != 0 : true);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) wq[c] = wn[c];
+        }
+        // groups with more than NS present offsets (16 % of the level-1 groups of a scanned room): the remaining index
+        // blocks in one round trip, their gathers in another (not pipelined, but two exposed latencies per group
+        // instead of two per block)
+        if (n > NS) {
+            constexpr int RB = GF_STEP_BLKS - PHA;  // remaining blocks
+            u32x4 jb[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++)
+                jb[b] = __builtin_amdgcn_raw_buffer_load_b128(rs_st, rec_lane, (unsigned)gg * GROUP_BYTES + (PHA + b) * 256u, 0);
+            for (int h = 0; h < RB; h += 2) {  // two blocks (8 steps) of gathers in flight
+                if ((PHA + h) * 4 >= n) break;
+                u32x4 e[8][NCH];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int st = (PHA + h) * 4 + j;
+                    const int bi = h + (j >> 2);
+                    // blocks past the group's count were never written: treat as missing
+                    const int idx = (bi < RB && st < n) ? (int)jb[bi < RB ? bi : 0][j & 3] : -1;
+                    const unsigned voff = ((unsigned)idx << SHIFT) + lane_ch;
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) e[j][c] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, c * 64, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int st = (PHA + h) * 4 + j;
+                    const int bi = h + (j >> 2);
+                    if (st < n) {
+                        const int k = __builtin_ctz(m);
+                        m &= m - 1;
+                        float4 wv[NCH];
+                        fetch_w(wv, k);
+                        mfma_step(e[j], wv, bi < RB ? (int)jb[bi < RB ? bi : 0][j & 3] >= 0 : false);
+                    }
+                }
+            }
+        }
+#ifdef CONV_TRACE
+        const unsigned long long tc2 = TR_NOW();
+        tr[4] += tc2 - tc1;
+        tr[7] += 1;
+#endif
+        if (row < M_out) {
+            float4 v = make_float4(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]);
+            if (RES) {
+                v.x += resv.x; v.y += resv.y; v.z += resv.z; v.w += resv.w;
+            }
+            if (out_scale) {  // epilogue activation: the consumer's BatchNorm + ReLU, once per output element
+                const float4 os = *reinterpret_cast<const float4*>(out_scale + 4 * q);
+                const float4 ot = *reinterpret_cast<const float4*>(out_shift + 4 * q);
+                v.x = fmaxf(fmaf(v.x, os.x, ot.x), 0.f); v.y = fmaxf(fmaf(v.y, os.y, ot.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, os.z, ot.z), 0.f); v.w = fmaxf(fmaf(v.w, os.w, ot.w), 0.f);
+            }
+            *reinterpret_cast<float4*>(out + (size_t)row * 16 + 4 * q) = v;
+        }
+#ifdef CONV_TRACE
+        tr[5] += TR_NOW() - tc2;
+#endif
+    };
+
+    // steady state, unrolled by two so that the buffers keep static names:
+    //   X.a = rows of group g (in flight), Y.ib = indices of group g+1 (in flight)
+    while (true) {
+        gather(aY, ibY, g + 1 < gend, presY);  // group g+1 (all -1 past the end)
+        load_idx(ibX, g + 2);
+        compute(aX, presX, g);
+        if (++g >= gend) break;
+        gather(aX, ibX, g + 1 < gend, presX);
+        load_idx(ibY, g + 2);
+        compute(aY, presY, g);
+        if (++g >= gend) break;
+    }
+#ifdef CONV_TRACE
+    tr[6] = TR_NOW();
+    if (g_conv_trace && lane == 0)
+        for (int i = 0; i < 8; i++) g_conv_trace[(size_t)cw * 8 + i] = tr[i];
+#endif
+}
+
+template <int NCH, bool LDSW>
+static void launch_g16(dim3 grid, size_t lds, hipStream_t st, const float* in, const float4* Wp, const int4* steps,
+                       const uint32_t* gmask, int K, int M_out, unsigned in_bytes, int gpw, const float* sc,
+                       const float* sh, const float* res, const float* osc, const float* osh, float* out) {
+    if (LDSW) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k_conv_g16<NCH, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16<NCH, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16<NCH, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16<NCH, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            attr = true;
+        }
+    }
+#define G16_LAUNCH(AFF_, RES_)                                                                                        \
+    hipLaunchKernelGGL((k_conv_g16<NCH, AFF_, RES_, LDSW>), grid, dim3(256), lds, st, in, Wp, steps, gmask, K, M_out, \
+                       in_bytes, gpw, sc, sh, res, osc, osh, out)
+    if (sc && res) G16_LAUNCH(true, true);
+    else if (sc) G16_LAUNCH(true, false);
+    else if (res) G16_LAUNCH(false, true);
+    else G16_LAUNCH(false, false);
+#undef G16_LAUNCH
+}
+
+template <int NCH, bool LDSW>
+static void launch_g16p(size_t lds, hipStream_t st, const float* in, const float4* Wp, const int32_t* steps,
+                        const uint32_t* gmask, int K, int M_out, int ld, unsigned in_bytes, const float* sc,
+                        const float* sh, const float* res, const float* osc, const float* osh, float* out) {
+    if (LDSW) {
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            attr = true;
+        }
+    }
+    const size_t step_words = (size_t)(ld / 16) * GF_STEP_BLKS * 64;
+    const int32_t* chunks = steps + step_words + 1;  // [-1] = number of chunks the table was built with
+    const unsigned steps_bytes = (unsigned)(step_words * 4);
+    dim3 grid(GF_CONV_CHUNKS_MAX / 4);  // waves of chunks past the table's count leave at once
+#define G16P_LAUNCH(AFF_, RES_)                                                                                       \
+    hipLaunchKernelGGL((k_conv_g16p<NCH, AFF_, RES_, LDSW>), grid, dim3(256), lds, st, in, Wp, steps, gmask, chunks,  \
+                       K, M_out, in_bytes, steps_bytes, sc, sh, res, osc, osh, out)
+    if (sc && res) G16P_LAUNCH(true, true);
+    else if (sc) G16P_LAUNCH(true, false);
+    else if (res) G16P_LAUNCH(false, true);
+    else G16P_LAUNCH(false, false);
+#undef G16P_LAUNCH
 }
 
 struct ConvArgs {
@@ -529,11 +1081,19 @@ struct ConvArgs {
     const uint32_t* gmask;
     int K, M_out, ld, Cin, Cout, NCH, NCB, nsplit;
     unsigned in_bytes;
-    const float *sc, *sh, *res;
+    const float *sc, *sh, *res, *osc, *osh;
     float* out;
 };
 
 static int g_conv_block = 256;
+static int g_conv_chunks = GF_CONV_CHUNKS;
+int gf_conv_chunks() { return g_conv_chunks; }
+extern "C" int gf_dev_conv_chunks(int n) {
+    if (n <= 0) n = GF_CONV_CHUNKS;
+    GF_CHECK_ARG(n % 4 == 0 && n <= GF_CONV_CHUNKS_MAX, "gf_dev_conv_chunks: %d (multiple of 4, at most %d)", n, GF_CONV_CHUNKS_MAX);
+    g_conv_chunks = n;
+    return GF_OK;
+}
 template <int NCBW>
 static void launch_conv_ldsw(dim3 grid, int bs, size_t lds, hipStream_t st, const ConvArgs& a) {
     static bool attr = false;
@@ -543,17 +1103,17 @@ static void launch_conv_ldsw(dim3 grid, int bs, size_t lds, hipStream_t st, cons
         attr = true;
     }
     hipLaunchKernelGGL((k_conv_os<NCBW, 0, true, true>), grid, dim3(bs), lds, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                       a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
+                       a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
 }
 template <int NCBW, int SW>
 static void launch_conv(bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
     const int bs = SW ? SW * 64 : g_conv_block;
     if (vec)
         hipLaunchKernelGGL((k_conv_os<NCBW, SW, true, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
+                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
     else
         hipLaunchKernelGGL((k_conv_os<NCBW, SW, false, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.out);
+                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
 }
 
 template <int SW>
@@ -574,12 +1134,18 @@ static void dispatch_conv(int ncbw, bool vec, dim3 grid, hipStream_t st, const C
 // launch cost the host ~10 us -- more than a small conv kernel runs -- in the launch-bound U-Net (71 convs per scene).
 struct ConvKnobs {
     int split = -1, wide = -1, block = 0, ldsw = 0, pair = -1;  // -1 / 0: not set
+    int g16 = -1, g16_ldsw = -1, g16_gpw = 0;                   // counted-loop kernel: use / weights in LDS / groups per wave
+    int g16_pipe = -1;                                          // its pipelined form (one chunk of groups per wave)
     ConvKnobs() {
         if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
         if (const char* e = getenv("GF_CONV_WIDE")) wide = atoi(e) != 0;
         if (const char* e = getenv("GF_CONV_BLOCK")) block = atoi(e) > 256 ? 256 : atoi(e);
         if (const char* e = getenv("GF_CONV_LDSW")) ldsw = atoi(e) != 0;
         if (const char* e = getenv("GF_CONV_PAIR")) pair = atoi(e) != 0;
+        if (const char* e = getenv("GF_CONV_G16")) g16 = atoi(e) != 0;
+        if (const char* e = getenv("GF_CONV_G16_LDSW")) g16_ldsw = atoi(e) != 0;
+        if (const char* e = getenv("GF_CONV_G16_GPW")) g16_gpw = atoi(e);
+        if (const char* e = getenv("GF_CONV_G16_PIPE")) g16_pipe = atoi(e) != 0;
     }
 };
 static ConvKnobs& conv_knobs_mut() {
@@ -589,6 +1155,14 @@ static ConvKnobs& conv_knobs_mut() {
 static const ConvKnobs& conv_knobs() { return conv_knobs_mut(); }
 
 // Dev hook (include/geoformer_hip_dev.h): force a launch shape regardless of the level's size; -1 = size-based.
+extern "C" int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe) {
+    ConvKnobs& k = conv_knobs_mut();
+    k.g16_pipe = pipe < 0 ? -1 : (pipe != 0);
+    k.g16 = use < 0 ? -1 : (use != 0);
+    k.g16_ldsw = ldsw < 0 ? -1 : (ldsw != 0);
+    k.g16_gpw = gpw > 0 ? gpw : 0;
+    return GF_OK;
+}
 extern "C" int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int block) {
     ConvKnobs& k = conv_knobs_mut();
     k.split = split < 0 ? -1 : (split != 0);
@@ -600,15 +1174,19 @@ extern "C" int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int bl
     return GF_OK;
 }
 
-extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
-                           int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
-                           const float* in_shift, const float* residual, float* out, void* stream) {
+extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
+                           const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
+                           const float* in_scale, const float* in_shift, const float* residual,
+                           const float* out_scale, const float* out_shift, float* out, void* stream) {
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_fwd: K=%d out of range [1,32]", K);
     GF_CHECK_ARG(Cin >= 1 && Cout >= 1, "gf_conv_fwd: Cin=%d Cout=%d", Cin, Cout);
     GF_CHECK_ARG(in_scale == nullptr || Cin <= CONV_MAX_CIN - 16, "gf_conv_fwd: fused prologue supports Cin <= %d",
                  CONV_MAX_CIN - 16);
-    GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_fwd: nbr==NULL requires K==1");
+    GF_CHECK_ARG(nbr != nullptr || steps != nullptr || K == 1, "gf_conv_fwd: no table requires K==1");
     GF_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "gf_conv_fwd: in_scale/in_shift must come together");
+    GF_CHECK_ARG((out_scale == nullptr) == (out_shift == nullptr), "gf_conv_fwd: out_scale/out_shift must come together");
+    GF_CHECK_ARG(out_scale == nullptr || ((((uintptr_t)out_scale) | ((uintptr_t)out_shift)) % 16) == 0,
+                 "gf_conv_fwd: out_scale/out_shift must be 16-byte aligned");
     if (M_out <= 0) return GF_OK;
     const int ngroups = (M_out + 15) / 16;
     const int ncb = (Cout + 15) / 16, nch = (Cin + 15) / 16;
@@ -634,7 +1212,7 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     long long blocks = split ? nitems : (nitems + wpb - 1) / wpb;
     if (blocks > 256 * 64) blocks = 256 * 64;
     ConvArgs a{in, reinterpret_cast<const float4*>(Wp), nbr, gmask, K, M_out, ld, Cin, Cout, nch, ncb, nsplit,
-               (unsigned)(in_bytes64 < 0xfffffff0ull ? in_bytes64 : 0), in_scale, in_shift, residual, out};
+               (unsigned)(in_bytes64 < 0xfffffff0ull ? in_bytes64 : 0), in_scale, in_shift, residual, out_scale, out_shift, out};
     dim3 grid((unsigned)blocks);
     hipStream_t st = (hipStream_t)stream;
     const size_t wbytes = (size_t)K * nch * ncb * 1024;
@@ -642,6 +1220,43 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
     // S150k level 1), so it is opt-in (GF_CONV_LDSW=1) until the staging cost is amortised differently
     bool ldsw = false;
     if (knobs.ldsw) ldsw = !split && vec && ncb <= 2 && wbytes <= 64 * 1024;
+    // counted-loop kernel over the step table: 16 output channels, one or two input chunks
+    bool g16 = steps != nullptr && gmask != nullptr && vec && Cout == 16 && nch <= 2 && (((uintptr_t)out) % 16) == 0 &&
+               (residual == nullptr || (((uintptr_t)residual) % 16) == 0) && in_bytes64 <= 0xffffff00ull;
+    if (knobs.g16 >= 0) g16 = g16 && knobs.g16 != 0;
+    else g16 = g16 && !split;
+    if (g16) {
+        bool gl = wbytes <= 64 * 1024;
+        if (knobs.g16_ldsw >= 0) gl = gl && knobs.g16_ldsw != 0;
+        const size_t step_bytes64 = (size_t)(ld / 16) * GF_STEP_BLKS * 256;
+        bool pipe = step_bytes64 < 0xfffff000ull && M_out > 0 && ld >= M_out;
+        if (knobs.g16_pipe >= 0) pipe = pipe && knobs.g16_pipe != 0;
+        if (pipe) {
+            if (nch == 1) {
+                if (gl) launch_g16p<1, true>(wbytes, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
+                else launch_g16p<1, false>(0, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
+            } else {
+                if (gl) launch_g16p<2, true>(wbytes, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
+                else launch_g16p<2, false>(0, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
+            }
+            GF_CHECK_LAUNCH("gf_conv_fwd");
+            return GF_OK;
+        }
+        int gpw = knobs.g16_gpw > 0 ? knobs.g16_gpw : (gl ? 2 : 1);
+        const long long wgs = ((long long)ngroups + 4 * gpw - 1) / (4 * gpw);
+        dim3 gg((unsigned)wgs);
+        const int4* st4 = reinterpret_cast<const int4*>(steps);
+        if (nch == 1) {
+            if (gl) launch_g16<1, true>(gg, wbytes, st, a.in, a.Wp, st4, gmask, K, M_out, a.in_bytes, gpw, a.sc, a.sh, a.res, a.osc, a.osh, out);
+            else launch_g16<1, false>(gg, 0, st, a.in, a.Wp, st4, gmask, K, M_out, a.in_bytes, gpw, a.sc, a.sh, a.res, a.osc, a.osh, out);
+        } else {
+            if (gl) launch_g16<2, true>(gg, wbytes, st, a.in, a.Wp, st4, gmask, K, M_out, a.in_bytes, gpw, a.sc, a.sh, a.res, a.osc, a.osh, out);
+            else launch_g16<2, false>(gg, 0, st, a.in, a.Wp, st4, gmask, K, M_out, a.in_bytes, gpw, a.sc, a.sh, a.res, a.osc, a.osh, out);
+        }
+        GF_CHECK_LAUNCH("gf_conv_fwd");
+        return GF_OK;
+    }
+    GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_fwd: this launch shape needs the [K,ld] neighbour table");
     bool pair = !split && vec && ncb == 1 && nbr != nullptr && K <= 32 && nch <= 8 && in_bytes64 <= 0xfffff000ull - 4096ull;
     if (knobs.pair >= 0) pair = pair && knobs.pair != 0;
     if (pair && !ldsw) {
@@ -650,10 +1265,10 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
         if (pb > 256 * 64) pb = 256 * 64;
         if (a.sc)
             hipLaunchKernelGGL(k_conv_pair<true>, dim3((unsigned)pb), dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                               a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.out);
+                               a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
         else
             hipLaunchKernelGGL(k_conv_pair<false>, dim3((unsigned)pb), dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                               a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.out);
+                               a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
     } else if (ldsw) {
         // 256-thread workgroups share one weight image: 4 waves per 27-54 KiB
         const int bs = 256;
@@ -675,7 +1290,8 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
 // Three (two) launches of the kernels above; exists because the host side of a 17-26 us launch matters: one
 // boundary crossing per block instead of three.
 extern "C" int gf_resblock_fwd(const float* x, const float* Wp0, const float* Wp1, const float* Wpi,
-                               const int32_t* nbr, const uint32_t* gmask, int K, int M, int ld, int Cin, int Cout,
+                               const int32_t* nbr, const uint32_t* gmask, const int32_t* steps, int K, int M, int ld,
+                               int Cin, int Cout,
                                const float* s0, const float* t0, const float* s1, const float* t1, float* tmp,
                                float* idn, float* out, void* stream) {
     GF_CHECK_ARG(x && Wp0 && Wp1 && tmp && out, "gf_resblock_fwd: null argument");
@@ -683,23 +1299,28 @@ extern "C" int gf_resblock_fwd(const float* x, const float* Wp0, const float* Wp
     GF_CHECK_ARG((Wpi == nullptr) == (idn == nullptr), "gf_resblock_fwd: Wpi and idn come together");
     int rc;
     if (Wpi) {
-        rc = gf_conv_fwd(x, Wpi, nullptr, nullptr, 1, M, M, 0, Cin, Cout, nullptr, nullptr, nullptr, idn, stream);
+        rc = gf_conv_fwd(x, Wpi, nullptr, nullptr, nullptr, 1, M, M, 0, Cin, Cout, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, idn, stream);
         if (rc != GF_OK) return rc;
     }
-    rc = gf_conv_fwd(x, Wp0, nbr, gmask, K, M, M, ld, Cin, Cout, s0, t0, nullptr, tmp, stream);
+    // bn1 + ReLU ride in the first conv's EPILOGUE (once per element of tmp) instead of the second conv's prologue
+    // (once per gathered element: 6-10 x more often); tmp has no other reader
+    rc = gf_conv_fwd(x, Wp0, nbr, gmask, steps, K, M, M, ld, Cin, Cout, s0, t0, nullptr, s1, t1, tmp, stream);
     if (rc != GF_OK) return rc;
-    return gf_conv_fwd(tmp, Wp1, nbr, gmask, K, M, M, ld, Cout, Cout, s1, t1, Wpi ? idn : x, out, stream);
+    return gf_conv_fwd(tmp, Wp1, nbr, gmask, steps, K, M, M, ld, Cout, Cout, nullptr, nullptr, Wpi ? idn : x, nullptr,
+                       nullptr, out, stream);
 }
 
 // Same launch bracketed by two caller-owned hipEvent_t recorded back to back with the kernel on the
 // same stream (bench.py's roofline probe: the kernel's own duration, not the host's launch gaps).
-extern "C" int gf_dev_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K,
-                                 int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
-                                 const float* in_shift, const float* residual, float* out, void* ev_start,
-                                 void* ev_stop, void* stream) {
+extern "C" int gf_dev_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
+                                 const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
+                                 const float* in_shift, const float* residual, const float* out_scale,
+                                 const float* out_shift, float* out, void* ev_start, void* ev_stop, void* stream) {
     GF_TRY(hipEventRecord((hipEvent_t)ev_start, (hipStream_t)stream));
     const int rc =
-        gf_conv_fwd(in, Wp, nbr, gmask, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out, stream);
+        gf_conv_fwd(in, Wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
+                    out_shift, out, stream);
     GF_TRY(hipEventRecord((hipEvent_t)ev_stop, (hipStream_t)stream));
     return rc;
 }

@@ -175,21 +175,31 @@ extern "C" int gf_index_build(const int32_t* coords, int M, const int32_t* d_M, 
 // ------------------------------------------------------------------------------------
 // submanifold 3x3x3: one thread per output row, 27 index lookups, coalesced column writes
 // ------------------------------------------------------------------------------------
+// `steps` (optional) is the same relation laid out for the counted-loop conv kernel (spconv_conv.hip, k_conv_g16):
+// per 16-row group the PRESENT offsets only, in ascending offset order, as blocks of four steps
+//     steps[((g * GF_STEP_BLKS + s / 4) * 16 + row) * 4 + s % 4] = input row of (row, s-th present offset) or -1
+// so that lane (row, *) fetches four steps with one 16-byte load and the 16 rows of a block are one contiguous
+// 256-byte segment.  The first GF_STEP_PHA blocks of a group are always written (padded with -1): the kernel loads
+// them before it knows the group's mask.
 __global__ void k_subm3(const int32_t* __restrict__ coords, int Mcap, const int32_t* __restrict__ d_M, GfIndex ix,
-                        int32_t* __restrict__ nbr, int ld, uint32_t* __restrict__ gmask) {
+                        int32_t* __restrict__ nbr, int ld, uint32_t* __restrict__ gmask, int32_t* __restrict__ steps) {
     const int M = d_M ? *d_M : Mcap;
     int o = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t mask = 0;
+    int rk[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) rk[k] = -1;
     if (o < M) {
         int4 c = reinterpret_cast<const int4*>(coords)[o];
 #pragma unroll
         for (int k = 0; k < 27; k++) {
             const int dx = k / 9 - 1, dy = (k / 3) % 3 - 1, dz = k % 3 - 1;
             int r = (k == 13) ? o : gf_index_lookup(ix, c.x, c.y + dx, c.z + dy, c.w + dz);
-            nbr[(size_t)k * ld + o] = r;
+            rk[k] = r;
+            if (nbr) nbr[(size_t)k * ld + o] = r;
             if (r >= 0) mask |= 1u << k;
         }
-    } else if (o < ld) {
+    } else if (o < ld && nbr) {
 #pragma unroll
         for (int k = 0; k < 27; k++) nbr[(size_t)k * ld + o] = -1;
     }
@@ -197,16 +207,97 @@ __global__ void k_subm3(const int32_t* __restrict__ coords, int Mcap, const int3
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) mask |= __shfl_xor(mask, d, 64);
     if ((threadIdx.x & 15) == 0 && o < ld) gmask[o >> 4] = mask;
+    if (steps && o < ld) {
+        int32_t* rec = steps + ((size_t)(o >> 4) * GF_STEP_BLKS * 16 + (o & 15)) * 4;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            if ((mask >> k) & 1u) {
+                rec[(s >> 2) * 64 + (s & 3)] = rk[k];
+                s++;
+            }
+        }
+        const int n = __popc(mask);
+        int end = (n + 3) & ~3;
+        if (end < 4 * GF_STEP_PHA) end = 4 * GF_STEP_PHA;
+        for (s = n; s < end; s++) rec[(s >> 2) * 64 + (s & 3)] = -1;
+    }
 }
+
+// Equal-cost chunks of consecutive 16-row groups for the pipelined conv kernel (k_conv_g16p): chunk c covers groups
+// [chunks[c], chunks[c + 1]) and every chunk carries about the same number of steps (+ a fixed cost per group), so
+// one wave per chunk keeps all SIMDs busy for the same time without any dynamic scheduling; consecutive groups
+// stay together (they share neighbour rows in L1/L2).  One workgroup of 1024 threads: block scan of the costs,
+// then every group writes the chunk boundaries that fall into its cost interval.
+#define CHUNK_GROUP_COST 3
+// cost of a group in steps: its present offsets + a fixed part + the two exposed round trips of a group whose offsets
+// do not fit the pipelined part of the kernel
+__device__ __forceinline__ int chunk_cost(uint32_t mask) {
+    const int n = __popc(mask);
+    return n + CHUNK_GROUP_COST + (n > 4 * GF_STEP_PHA ? 8 : 0);
+}
+__global__ __launch_bounds__(1024) void k_group_chunks(const uint32_t* __restrict__ gmask, int ngroups, int nchunks,
+                                                       int32_t* __restrict__ chunks) {
+    __shared__ long long s_wave[16];
+    __shared__ long long s_total;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (ngroups + 1023) / 1024;
+    const int lo = min(ngroups, t * per), hi = min(ngroups, lo + per);
+    long long sum = 0;
+    for (int g = lo; g < hi; g++) sum += chunk_cost(gmask[g]);
+    long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    if (t == 0) {
+        long long acc = 0;
+        for (int i = 0; i < 16; i++) {
+            const long long v = s_wave[i];
+            s_wave[i] = acc;
+            acc += v;
+        }
+        s_total = acc;
+    }
+    __syncthreads();
+    const long long C = s_total > 0 ? s_total : 1;
+    long long before = s_wave[wv] + inc - sum;  // cost of all groups in front of this thread's first one
+    for (int g = lo; g < hi; g++) {
+        // chunk c starts at the first group whose preceding cost reaches c * C / nchunks
+        const long long c_hi = before * nchunks / C;
+        long long c_lo = 0;
+        if (g > 0) {
+            const long long prev = before - chunk_cost(gmask[g - 1]);
+            c_lo = prev * nchunks / C + 1;
+        }
+        for (long long c = c_lo; c <= c_hi && c < nchunks; c++) chunks[c] = g;
+        before += chunk_cost(gmask[g]);
+    }
+    if (t == 0) {
+        // boundaries behind the last group's start (and everything when there are no groups) end the table
+        const long long last = ngroups > 0 ? (C - chunk_cost(gmask[ngroups - 1])) * nchunks / C + 1 : 0;
+        for (long long c = last; c <= nchunks; c++) chunks[c] = ngroups;
+        chunks[-1] = nchunks;  // the count sits in front of the boundaries
+    }
+}
+
+extern "C" size_t gf_rules_steps_words(int ld) { return (size_t)(ld / 16) * GF_STEP_BLKS * 64 + GF_CONV_CHUNKS_MAX + 16; }
 
 extern "C" int gf_rules_subm3(const int32_t* coords, int M, const int32_t* d_M, int X, int Y, int Z,
                               const uint32_t* bitmap, const int32_t* prefix, const int32_t* perm, int32_t* nbr, int ld,
-                              uint32_t* gmask, void* stream) {
+                              uint32_t* gmask, int32_t* steps, void* stream) {
     GF_CHECK_ARG(ld >= M && (ld % 16) == 0, "gf_rules_subm3: ld=%d must be a multiple of 16 and >= M=%d", ld, M);
+    GF_CHECK_ARG(nbr != nullptr || steps != nullptr, "gf_rules_subm3: neither table requested");
     if (ld == 0) return GF_OK;
     GfIndex ix{bitmap, prefix, perm, X, Y, Z};
     hipLaunchKernelGGL(k_subm3, dim3(gf_div_up(ld, 256)), dim3(256), 0, (hipStream_t)stream, coords, M, d_M, ix, nbr,
-                       ld, gmask);
+                       ld, gmask, steps);
+    if (steps)  // chunk boundaries live behind the step blocks (M known on the host here; groups = ceil(M / 16))
+        hipLaunchKernelGGL(k_group_chunks, dim3(1), dim3(1024), 0, (hipStream_t)stream, gmask, (M + 15) / 16,
+                           gf_conv_chunks(), steps + (size_t)(ld / 16) * GF_STEP_BLKS * 64 + 1);
     GF_CHECK_LAUNCH("gf_rules_subm3");
     return GF_OK;
 }

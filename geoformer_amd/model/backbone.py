@@ -86,7 +86,8 @@ class ResidualBlock(SparseModule):
         out = conv1._new_like(input)
         out._index = input._index
         out.features = sparse.resblock_fwd(input.features.contiguous(), wp0, wp1, wpi, rules.nbr, rules.gmask, 27, M,
-                                           rules.ld, conv0.in_channels, conv0.out_channels, s0, t0, s1, t1)
+                                           rules.ld, conv0.in_channels, conv0.out_channels, s0, t0, s1, t1,
+                                           steps=rules.steps)
         return out
 
     def forward(self, input):

@@ -20,6 +20,9 @@ def _round16(n: int) -> int:
     return (int(n) + 15) // 16 * 16
 
 
+STEPS_MIN_ROWS = 6000 * 16  # gf_conv_fwd takes the counted-loop kernel from 6000 groups up (csrc/spconv_conv.hip)
+
+
 @dataclass
 class LevelIndex:
     """Occupancy-bitmap rank index of one voxel set (see csrc/spconv_rules.hip)."""
@@ -38,6 +41,7 @@ class SubmRules:
     ld: int
     M: int
     K: int = 27
+    steps: Optional[torch.Tensor] = None  # int32: step table [ld/16, 7, 16, 4] + chunk boundaries (gf_rules_subm3)
 
     def pairs(self):
         """Canonical spconv pair lists: for each offset k the (in,out) pairs in ascending out."""
@@ -99,13 +103,15 @@ def subm_rules(coords: torch.Tensor, index: LevelIndex) -> SubmRules:
     dev = coords.device
     nbr = torch.empty((27, ld), dtype=torch.int32, device=dev)
     gmask = torch.empty(ld // 16, dtype=torch.int32, device=dev)
+    # the step table only pays where the counted-loop kernel runs (level-1 sized voxel sets)
+    steps = torch.empty(lib.gf_rules_steps_words(ld), dtype=torch.int32, device=dev) if ld >= STEPS_MIN_ROWS else None
     X, Y, Z = index.shape
     check(
         lib.gf_rules_subm3(ptr(coords), M, None, X, Y, Z, ptr(index.bitmap), ptr(index.prefix), ptr(index.perm),
-                           ptr(nbr), ld, ptr(gmask), stream_ptr()),
+                           ptr(nbr), ld, ptr(gmask), ptr(steps), stream_ptr()),
         "gf_rules_subm3",
     )
-    return SubmRules(nbr, gmask, ld, M)
+    return SubmRules(nbr, gmask, ld, M, 27, steps)
 
 
 def down_rules(coords: torch.Tensor, batch: int, shape) -> DownRules:
@@ -169,8 +175,9 @@ def pack_weights(weight: torch.Tensor) -> torch.Tensor:
 
 def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], gmask: Optional[torch.Tensor],
              K: int, M_out: int, ld: int, in_scale=None, in_shift=None, residual=None, out=None,
-             events=None) -> torch.Tensor:
-    """out[o] = sum_k act(feats[nbr[k,o]]) @ weight[k] (+ residual).  weight is [K,Cin,Cout] fp32."""
+             events=None, steps=None, out_scale=None, out_shift=None) -> torch.Tensor:
+    """out[o] = sum_k act(feats[nbr[k,o]]) @ weight[k] (+ residual), optionally followed by the epilogue activation
+    max(out*out_scale + out_shift, 0).  weight is [K,Cin,Cout] fp32."""
     lib = _lib.load()
     assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
     assert weight.dtype == torch.float32 and weight.is_contiguous()
@@ -188,27 +195,33 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
             if not e.cuda_event:
                 e.record()  # materialise the hipEvent_t handle
         check(
-            lib.gf_dev_conv_fwd_timed(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
-                                  ptr(in_shift), ptr(residual), ptr(out), events[0].cuda_event, events[1].cuda_event,
-                                  stream_ptr()),
+            lib.gf_dev_conv_fwd_timed(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), ptr(steps), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
+                                  ptr(in_shift), ptr(residual), ptr(out_scale), ptr(out_shift), ptr(out), events[0].cuda_event,
+                                  events[1].cuda_event, stream_ptr()),
             "gf_dev_conv_fwd_timed",
         )
         return out
     check(
-        lib.gf_conv_fwd(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
-                        ptr(in_shift), ptr(residual), ptr(out), stream_ptr()),
+        lib.gf_conv_fwd(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), ptr(steps), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
+                        ptr(in_shift), ptr(residual), ptr(out_scale), ptr(out_shift), ptr(out), stream_ptr()),
         "gf_conv_fwd",
     )
     return out
 
 
-def dev_conv_knobs(split=-1, wide=-1, pair=-1, ldsw=0, block=0):
+def dev_conv_knobs(split=-1, wide=-1, pair=-1, ldsw=0, block=0, g16=-1, g16_ldsw=-1, g16_gpw=0, g16_pipe=-1):
     """Dev hook (include/geoformer_hip_dev.h): force gf_conv_fwd's launch shape; no arguments = size-based choice."""
     check(_lib.load().gf_dev_conv_knobs(split, wide, pair, ldsw, block), "gf_dev_conv_knobs")
+    check(_lib.load().gf_dev_conv_knobs_g16(g16, g16_ldsw, g16_gpw, g16_pipe), "gf_dev_conv_knobs_g16")
+
+
+def dev_conv_chunks(n=0):
+    """Dev hook: number of equal-cost chunks the next submanifold rulebooks are built with (0 = default)."""
+    check(_lib.load().gf_dev_conv_chunks(n), "gf_dev_conv_chunks")
 
 
 def resblock_fwd(x: torch.Tensor, wp0, wp1, wpi, nbr, gmask, K: int, M: int, ld: int, Cin: int, Cout: int, s0, t0, s1,
-                 t1, events=None) -> torch.Tensor:
+                 t1, events=None, steps=None) -> torch.Tensor:
     """Eval-mode pre-activation residual block in one native call (include/geoformer_hip.h: gf_resblock_fwd).
     wp0/wp1/wpi are packed weights (pack_weights), s*/t* folded BatchNorm vectors.  events: optional two
     (start, stop) torch.cuda.Event pairs recorded natively around the two 3x3x3 launches (bench.py's probe);
@@ -223,18 +236,19 @@ def resblock_fwd(x: torch.Tensor, wp0, wp1, wpi, nbr, gmask, K: int, M: int, ld:
                     e.record()  # materialise the hipEvent_t handle
         idn = x
         if wpi is not None:
-            check(lib.gf_conv_fwd(x.data_ptr(), wpi.data_ptr(), None, None, 1, M, M, 0, Cin, Cout, None, None, None,
-                                  buf[2].data_ptr(), st), "gf_conv_fwd")
+            check(lib.gf_conv_fwd(x.data_ptr(), wpi.data_ptr(), None, None, None, 1, M, M, 0, Cin, Cout, None, None, None,
+                                  None, None, buf[2].data_ptr(), st), "gf_conv_fwd")
             idn = buf[2]
-        check(lib.gf_dev_conv_fwd_timed(x.data_ptr(), wp0.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), K, M, M, ld, Cin,
-                                    Cout, s0.data_ptr(), t0.data_ptr(), None, buf[1].data_ptr(),
+        sp = ptr(steps)
+        check(lib.gf_dev_conv_fwd_timed(x.data_ptr(), wp0.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), sp, K, M, M, ld, Cin,
+                                    Cout, s0.data_ptr(), t0.data_ptr(), None, s1.data_ptr(), t1.data_ptr(), buf[1].data_ptr(),
                                     events[0][0].cuda_event, events[0][1].cuda_event, st), "gf_dev_conv_fwd_timed")
-        check(lib.gf_dev_conv_fwd_timed(buf[1].data_ptr(), wp1.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), K, M, M, ld,
-                                    Cout, Cout, s1.data_ptr(), t1.data_ptr(), idn.data_ptr(), buf[0].data_ptr(),
+        check(lib.gf_dev_conv_fwd_timed(buf[1].data_ptr(), wp1.data_ptr(), nbr.data_ptr(), gmask.data_ptr(), sp, K, M, M, ld,
+                                    Cout, Cout, None, None, idn.data_ptr(), None, None, buf[0].data_ptr(),
                                     events[1][0].cuda_event, events[1][1].cuda_event, st), "gf_dev_conv_fwd_timed")
         return buf[0]
     check(lib.gf_resblock_fwd(x.data_ptr(), wp0.data_ptr(), wp1.data_ptr(), None if wpi is None else wpi.data_ptr(),
-                              nbr.data_ptr(), gmask.data_ptr(), K, M, ld, Cin, Cout, s0.data_ptr(), t0.data_ptr(),
+                              nbr.data_ptr(), gmask.data_ptr(), ptr(steps), K, M, ld, Cin, Cout, s0.data_ptr(), t0.data_ptr(),
                               s1.data_ptr(), t1.data_ptr(), buf[1].data_ptr(),
                               None if wpi is None else buf[2].data_ptr(), buf[0].data_ptr(), st), "gf_resblock_fwd")
     return buf[0]
@@ -245,13 +259,15 @@ def conv_dgrad(grad_out: torch.Tensor, weight: torch.Tensor, bwd, M_in: int) -> 
     bwd = ("subm", (nbr, gmask, 27, M, ld)): same table, weights W[26-k]^T (the submanifold
     relation is symmetric: nbr[k][o] = i  <=>  nbr[26-k][i] = o);
     bwd = ("table", (tbl, gmask, K, M_in, ld)): explicit transposed table, weights W[k]^T."""
-    kind, (tbl, gmask, K, M, ld) = bwd
+    kind, spec = bwd
+    tbl, gmask, K, M, ld = spec[:5]
+    steps = spec[5] if len(spec) > 5 else None
     Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
     w = weight.detach().reshape(K, Cin, Cout)
     if kind == "subm":
         w = w.flip(0)
     wt = w.transpose(1, 2).contiguous()
-    return conv_fwd(grad_out, wt, tbl, gmask, K, M, ld)
+    return conv_fwd(grad_out, wt, tbl, gmask, K, M, ld, steps=steps)
 
 
 def conv_wgrad(feats: torch.Tensor, grad_out: torch.Tensor, nbr, K: int, M_out: int, ld: int) -> torch.Tensor:

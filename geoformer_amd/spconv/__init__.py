@@ -113,8 +113,9 @@ class _GatherConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feats, weight, fwd, bwd):
-        tbl, gmask, K, M_out, ld = fwd
-        out = sparse.conv_fwd(feats.contiguous(), weight, tbl, gmask, K, M_out, ld)
+        tbl, gmask, K, M_out, ld = fwd[:5]
+        out = sparse.conv_fwd(feats.contiguous(), weight, tbl, gmask, K, M_out, ld,
+                              **({"steps": fwd[5]} if len(fwd) > 5 and fwd[5] is not None else {}))
         ctx.save_for_backward(feats, weight)
         ctx.fwd, ctx.bwd = fwd, bwd
         return out
@@ -122,7 +123,7 @@ class _GatherConv(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         feats, weight = ctx.saved_tensors
-        tbl, gmask, K, M_out, ld = ctx.fwd
+        tbl, gmask, K, M_out, ld = ctx.fwd[:5]
         g = grad_out.contiguous()
         d_feats = d_weight = None
         if ctx.needs_input_grad[0]:
@@ -203,7 +204,7 @@ class SubMConv3d(_SparseConvBase):
             return self._finish(out, input.features.new_zeros((0, self.out_channels)))
         rules = self.get_rules(input)
         out._index = input._index
-        spec = (rules.nbr, rules.gmask, 27, M, rules.ld)
+        spec = (rules.nbr, rules.gmask, 27, M, rules.ld, rules.steps)
         return self._finish(out, _GatherConv.apply(input.features, self.weight, spec, ("subm", spec)))
 
 

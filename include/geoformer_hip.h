@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 1
+#define GF_ABI_VERSION 2
 
 typedef enum {
     GF_OK = 0,
@@ -85,10 +85,17 @@ int gf_index_build(const int32_t* coords, int M, const int32_t* d_M, int B, int 
 
 /* Submanifold 3x3x3 (padding 1) neighbour table from an index.
  *   perm may be NULL when rows are already in ascending linear order (levels >= 2).
- *   nbr    int32 [27*ld] out, ld >= M rounded up to 16
- *   gmask  uint32[ceil(M/16)] out: OR of the offsets present in each 16-row group */
+ *   nbr    int32 [27*ld] out, ld >= M rounded up to 16 (may be NULL when only `steps` is wanted)
+ *   gmask  uint32[ceil(M/16)] out: OR of the offsets present in each 16-row group
+ *   steps  optional int32 [gf_rules_steps_words(ld)] out: the same relation as a STEP TABLE -- per 16-row group g only
+ *          the present offsets, ascending, four steps per 16-byte entry:
+ *              steps[((g*7 + s/4)*16 + row)*4 + s%4] = input row of (row, s-th present offset of g) or -1;
+ *          the first three blocks of every group are always written (-1 padded).  gf_conv_fwd's counted-loop
+ *          kernel reads this instead of nbr. */
+size_t gf_rules_steps_words(int ld);
 int gf_rules_subm3(const int32_t* coords, int M, const int32_t* d_M, int X, int Y, int Z, const uint32_t* bitmap,
-                   const int32_t* prefix, const int32_t* perm, int32_t* nbr, int ld, uint32_t* gmask, void* stream);
+                   const int32_t* prefix, const int32_t* perm, int32_t* nbr, int ld, uint32_t* gmask, int32_t* steps,
+                   void* stream);
 
 /* Strided 2x2x2 / stride 2 rulebook: builds the OUTPUT level's index and tables.
  *   in shape (X,Y,Z) -> out shape (X/2,Y/2,Z/2) (floor; inputs mapping outside are dropped)
@@ -130,10 +137,14 @@ int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, vo
  *   in_scale/in_shift  optional fp32 [Cin]: act(x) = max(x*scale + shift, 0) fused on the
  *                      gathered rows (eval-mode BatchNorm1d + ReLU, geoformer_modules.py:19-26)
  *   residual           optional fp32 [M_out,Cout] added in the epilogue (geoformer_modules.py:33)
+ *   out_scale/out_shift optional fp32 [Cout], 16-byte aligned: out = max(out*scale + shift, 0) in the epilogue (the
+ *                      CONSUMER's BatchNorm + ReLU applied once per output element; gf_resblock_fwd uses it for bn1)
+ *   steps              optional step table of the same relation (gf_rules_subm3); nbr may then be NULL for the
+ *                      launch shapes that read it (16 output channels, Cin 16 or 32, level-1 sized inputs)
  */
-int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in, int M_out,
-                int ld, int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual,
-                float* out, void* stream);
+int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, const int32_t* steps, int K,
+                int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
+                const float* residual, const float* out_scale, const float* out_shift, float* out, void* stream);
 
 /* Pre-activation residual block (ResidualBlock, model/geoformer/geoformer_modules.py:10-35) in eval mode, one
  * call:  out = conv1(relu(bn1(conv0(relu(bn0(x)))))) + (Wpi ? x . Wi : x).
@@ -141,7 +152,7 @@ int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint
  *   nbr/gmask/K/ld: the level's submanifold table; s0,t0 [Cin], s1,t1 [Cout]: folded BatchNorm (scale, shift);
  *   tmp, idn (NULL iff Wpi NULL), out fp32 [M,Cout]. */
 int gf_resblock_fwd(const float* x, const float* Wp0, const float* Wp1, const float* Wpi, const int32_t* nbr,
-                    const uint32_t* gmask, int K, int M, int ld, int Cin, int Cout, const float* s0, const float* t0,
+                    const uint32_t* gmask, const int32_t* steps, int K, int M, int ld, int Cin, int Cout, const float* s0, const float* t0,
                     const float* s1, const float* t1, float* tmp, float* idn, float* out, void* stream);
 
 /* Weight gradient of the same operator: dW[k] = sum_o in[nbr[k][o],:]^T dOut[o,:]  (dW fp32

@@ -17,15 +17,25 @@ extern "C" {
 
 /* gf_conv_fwd with two caller-owned hipEvent_t recorded immediately before/after the launch on `stream`
  * (the kernel's own duration on the stream it runs on; bench.py's roofline probe). */
-int gf_dev_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in,
-                          int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
-                          const float* residual, float* out, void* ev_start, void* ev_stop, void* stream);
+int gf_dev_conv_fwd_timed(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
+                          const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
+                          const float* residual, const float* out_scale, const float* out_shift, float* out, void* ev_start,
+                          void* ev_stop, void* stream);
 
 /* Force gf_conv_fwd's launch shape (it normally follows the level's size): split / wide / pair: 0, 1 or -1 (size
  * based); ldsw: 1 = weights staged in LDS where supported; block: threads per workgroup of the one-wave-per-group
  * shape (0 = default).  Process-wide; tests reset with (-1,-1,-1,0,0).  The same knobs can be set once from the
  * environment (GF_CONV_SPLIT / _WIDE / _PAIR / _LDSW / _BLOCK). */
 int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int block);
+
+/* The counted-loop kernel over the step table: use (0 / 1 / -1 = size based), weights staged in LDS (0 / 1 / -1 =
+ * when they fit), groups walked per wave of the non-pipelined form (0 = default), pipelined form (0 / 1 / -1 =
+ * default on).  Environment: GF_CONV_G16 / _G16_LDSW / _G16_GPW / _G16_PIPE. */
+int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe);
+
+/* Number of equal-cost chunks (= waves of the pipelined kernel) the NEXT rulebooks are built with: a multiple of 4,
+ * at most 4096; 0 = default (2048 = 8 waves per compute unit). */
+int gf_dev_conv_chunks(int n);
 
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);

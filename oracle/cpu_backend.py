@@ -64,7 +64,8 @@ def install():
         return sparse.DownRules(_t(oc), M, oc.shape[0], _t(child), ld, _t(_gmask(child)), _t(parent), _t(koff), _t(up),
                                 ld, _t(_gmask(up)), sparse.LevelIndex(None, None, None, batch, oshape), oshape)
 
-    def conv_fwd(feats, weight, nbr, gmask, K, M_out, ld, in_scale=None, in_shift=None, residual=None, out=None):
+    def conv_fwd(feats, weight, nbr, gmask, K, M_out, ld, in_scale=None, in_shift=None, residual=None, out=None,
+                 steps=None, out_scale=None, out_shift=None):
         Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
         W = _np(weight).reshape(K, Cin, Cout)
         x = _np(feats)
@@ -78,10 +79,13 @@ def install():
         y = orc.conv_fwd(x, W, tbl, M_out)
         if residual is not None:
             y = y + _np(residual)
+        if out_scale is not None:
+            y = np.maximum(y * _np(out_scale) + _np(out_shift), 0).astype(np.float32)
         return _t(y)
 
     def conv_dgrad(grad_out, weight, bwd, M_in):
-        kind, (tbl, gmask, K, M, ld) = bwd
+        kind, spec = bwd
+        tbl, gmask, K, M, ld = spec[:5]
         Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
         w = weight.detach().reshape(K, Cin, Cout)
         if kind == "subm":

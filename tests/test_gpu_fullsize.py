@@ -81,6 +81,23 @@ def test_conv_fwd_full_size(oracle, level1, Cin, Cout):
     assert np.abs(got - (ref_plain + res)).max() < 1e-4
     got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, residual=_dev(res), **kw).cpu().numpy()
     assert np.abs(got - (ref_act + res)).max() < 1e-4
+    # the same four through the step table (the counted-loop kernels where the shape allows them), plus the
+    # epilogue activation max(out * s + t, 0)
+    osc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    osh = (0.3 * rng.standard_normal(Cout)).astype(np.float32)
+    st = dict(steps=rules.steps)
+    got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, **st).cpu().numpy()
+    assert np.abs(got - ref_plain).max() < 1e-4
+    got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, **kw, **st).cpu().numpy()
+    assert np.abs(got - ref_act).max() < 1e-4
+    got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, residual=_dev(res), **st).cpu().numpy()
+    assert np.abs(got - (ref_plain + res)).max() < 1e-4
+    got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, residual=_dev(res), **kw, **st).cpu().numpy()
+    assert np.abs(got - (ref_act + res)).max() < 1e-4
+    for use_steps in (st, {}):
+        got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, out_scale=_dev(osc), out_shift=_dev(osh),
+                              **kw, **use_steps).cpu().numpy()
+        assert np.abs(got - np.maximum(ref_act * osc + osh, 0)).max() < 1e-4
     # the 1x1x1 identity-branch conv (K == 1, no table) at the same size
     W1 = (rng.standard_normal((1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
     got = sparse.conv_fwd(x, _dev(W1), None, None, 1, M, 0).cpu().numpy()
@@ -157,11 +174,16 @@ def test_down_up_full_size(oracle, s150k, hip):
     assert np.abs(got - oracle.conv_fwd(f2, W2, nbr2, oc.shape[0])).max() < 1e-4
 
 
-KNOBS = [dict(split=0, pair=1), dict(split=0, pair=0), dict(split=0, pair=0, ldsw=1), dict(split=1, wide=0),
-         dict(split=1, wide=1), dict(split=0, pair=0, block=64), dict(split=0, pair=0, block=128)]
+KNOBS = [dict(split=0, pair=1, g16=0), dict(split=0, pair=0, g16=0), dict(split=0, pair=0, ldsw=1, g16=0),
+         dict(split=1, wide=0, g16=0), dict(split=1, wide=1, g16=0), dict(split=0, pair=0, block=64, g16=0),
+         dict(split=0, pair=0, block=128, g16=0),
+         # the counted-loop kernels over the step table (16 output channels, Cin 16 / 32 only; other widths fall
+         # through to the size-based choice): plain, LDS weights, several groups per wave, pipelined over chunks
+         dict(g16=1, g16_ldsw=0, g16_pipe=0), dict(g16=1, g16_ldsw=1, g16_pipe=0, g16_gpw=3),
+         dict(g16=1, g16_ldsw=0, g16_pipe=1), dict(g16=1, g16_ldsw=1, g16_pipe=1)]
 
 
-@pytest.mark.parametrize("Cin,Cout", [(16, 16), (6, 16), (32, 32), (48, 64), (19, 21)])
+@pytest.mark.parametrize("Cin,Cout", [(16, 16), (32, 16), (6, 16), (32, 32), (48, 64), (19, 21)])
 def test_every_launch_shape_forced(hip, oracle, Cin, Cout):
     """gf_conv_fwd chooses a launch shape from the level's size; each shape is forced here on one small input
     (dev knobs, include/geoformer_hip_dev.h) with prologue and residual, and must give the oracle's result."""
@@ -180,14 +202,34 @@ def test_every_launch_shape_forced(hip, oracle, Cin, Cout):
     ref = oracle.conv_fwd(np.maximum(feats * scale + shift, 0).astype(np.float32), W, nbr, M) + res
     ref_plain = oracle.conv_fwd(feats, W, nbr, M)
     c = _dev(coords)
-    rules = sparse.subm_rules(c, sparse.build_index(c, 1, shape))
+    old_min = sparse.STEPS_MIN_ROWS
+    sparse.STEPS_MIN_ROWS = 0  # build the step table for this small voxel set too
+    try:
+        rules = sparse.subm_rules(c, sparse.build_index(c, 1, shape))
+    finally:
+        sparse.STEPS_MIN_ROWS = old_min
+    # the step table against the neighbour table it restates: present offsets in ascending order, four per entry
+    st = rules.steps.cpu().numpy()
+    ng = rules.ld // 16
+    blocks = st[: ng * 7 * 64].reshape(ng, 7, 16, 4)
+    for g in rng.integers(0, ng, 40):
+        ks = [k for k in range(27) if (nbr[k, g * 16:(g + 1) * 16] >= 0).any()]
+        for s_, k in enumerate(ks):
+            assert (blocks[g, s_ // 4, :, s_ % 4] == nbr[k, g * 16:(g + 1) * 16]).all()
+        for s_ in range(len(ks), max(12, (len(ks) + 3) // 4 * 4)):
+            assert (blocks[g, s_ // 4, :, s_ % 4] == -1).all()
+    tail = st[ng * 7 * 64:]
+    nchunks = int(tail[0])
+    bounds = tail[1: nchunks + 2]
+    assert bounds[0] == 0 and bounds[-1] == (M + 15) // 16 and (np.diff(bounds) >= 0).all()
     x, w, s, t, r = _dev(feats), _dev(W), _dev(scale), _dev(shift), _dev(res)
     try:
         for knobs in KNOBS:
             sparse.dev_conv_knobs(**knobs)
-            got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, in_scale=s, in_shift=t, residual=r)
+            got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, in_scale=s, in_shift=t, residual=r,
+                                  steps=rules.steps)
             assert np.abs(got.cpu().numpy() - ref).max() < 1e-4, knobs
-            got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld)
+            got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, steps=rules.steps)
             assert np.abs(got.cpu().numpy() - ref_plain).max() < 1e-4, knobs
     finally:
         sparse.dev_conv_knobs()  # back to the size-based choice
