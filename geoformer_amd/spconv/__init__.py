@@ -204,6 +204,19 @@ class SubMConv3d(_SparseConvBase):
             return self._finish(out, input.features.new_zeros((0, self.out_channels)))
         rules = self.get_rules(input)
         out._index = input._index
+        if (rules.steps is not None and self.in_channels < 16 and self.out_channels == 16 and self.bias is None
+                and not torch.is_grad_enabled() and input.features.is_cuda):
+            # inference, narrow input (the 6 -> 16 input conv of the U-Net): rows and weights zero-padded to one
+            # 16-channel chunk so that the launch takes the counted-loop kernel (36 -> ~19 us at S150k)
+            key = (self.weight.data_ptr(), self.weight._version)
+            hit = self.__dict__.get("_gf_w16")
+            if hit is None or hit[0] != key:
+                w16 = torch.nn.functional.pad(self.weight.detach().reshape(27, self.in_channels, 16),
+                                              (0, 0, 0, 16 - self.in_channels)).contiguous()
+                hit = self.__dict__["_gf_w16"] = (key, w16)
+            x16 = torch.nn.functional.pad(input.features, (0, 16 - self.in_channels))
+            return self._finish(out, sparse.conv_fwd(x16, hit[1], rules.nbr, rules.gmask, 27, M, rules.ld,
+                                                     steps=rules.steps))
         spec = (rules.nbr, rules.gmask, 27, M, rules.ld, rules.steps)
         return self._finish(out, _GatherConv.apply(input.features, self.weight, spec, ("subm", spec)))
 

@@ -63,3 +63,41 @@ def test_bfs_matches_oracle(hip, oracle, n, nq, max_step):
     for wg in (256, 512):
         geo3 = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), radius, max_step, wg_threads=wg)
         assert (geo3.cpu().numpy() == ref).all()
+
+
+def test_bfs_duplicates_short_walks_and_dense_ball(hip, oracle):
+    """Corner cases of the frontier BFS against the oracle: 100 copies of one point (rows of 63 duplicates at distance 0,
+    a frontier that jumps by 100 vertices at once), hop limits of 1 / 2 / 7, and a 0.06 m ball of 3000 points whose
+    frontier reaches ~1900 vertices in the second hop (table from the oracle's brute force, laid out like
+    gf_knn_radius does: that kernel caps its candidate list at 1024 in-radius points)."""
+    from geoformer_amd import pointops
+
+    n, k, radius = 20000, 64, 0.05
+    for dup in (False, True):
+        xyz = _pts(n, 77)
+        if dup:
+            xyz[1000:1100] = xyz[5]
+        D, I = _ref_graph(oracle, xyz, k, radius)
+        src = np.random.default_rng(2).integers(0, n, 24)
+        if dup:
+            src[:3] = [5, 1003, 1099]
+        ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 256)
+        gd, gi, deg = pointops.knn_radius(_dev(xyz), k, radius)
+        for wg in (256, 1024):
+            geo = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), radius, 256, wg_threads=wg)
+            assert (geo.cpu().numpy() == ref).all(), (dup, wg)
+    for max_step in (1, 2, 7):
+        ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, max_step)
+        geo = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), radius, max_step, wg_threads=256)
+        assert (geo.cpu().numpy() == ref).all(), max_step
+    rng = np.random.default_rng(9)
+    xyz = (rng.random((3000, 3)) * 0.06).astype(np.float32)
+    D, I = _ref_graph(oracle, xyz, k, radius)
+    inr = D <= np.float32(radius)
+    Dm = np.where(inr, D, np.inf).astype(np.float32)
+    Im = np.where(inr, I, -1).astype(np.int32)
+    src = np.array([0, 17, 2999])
+    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 64)
+    deg = (inr.sum(1) - 1).astype(np.int32)
+    geo = pointops.geodesic_bfs(_dev(Dm), _dev(Im), _dev(deg), _dev(src.astype(np.int32)), radius, 64, wg_threads=256)
+    assert (geo.cpu().numpy() == ref).all()
