@@ -1,0 +1,130 @@
+"""Few-shot set criterion (criterion_fs.py:93-280): dice + focal losses on the Hungarian-matched mask logits of
+every decoder layer (matching by the dice cost alone, matcher.py:114-115), plus the hard-negative-mined BCE loss of
+the similarity head (``outputs["simnet"]``, geoformer_fs.py:572).
+
+Stock PyTorch + scipy, on the framework side of the boundary like criterion.py.  Behaviour is
+pinned by tests/golden/criterion_fs.npz, produced by the reference's own FSInstSetCriterion; that includes one
+quirk kept on purpose: ``loss_neg[train_label.long()] = 0`` (criterion_fs.py:176) indexes the BATCH dimension with
+the 0/1 label tensor, i.e. it zeroes the whole rows 0 and 1 of the negative-loss matrix (and needs batch_size >= 2
+as soon as any query is positive) instead of masking the positive entries.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import config as _config
+from .criterion import HungarianMatcher, compute_dice_loss, compute_sigmoid_focal_loss
+
+
+class FSInstSetCriterion(nn.Module):
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg if cfg is not None else _config.cfg
+        self.cfg = cfg
+        self.similarity_criterion = nn.BCEWithLogitsLoss(reduction="none")
+        self.batch_size, self.n_queries = cfg.batch_size, cfg.n_query_points
+        self.matcher = HungarianMatcher(self.batch_size, self.n_queries)
+        self.loss_weight = {"dice_loss": 1, "focal_loss": 1}
+        self.cal_simloss = "similarity_net" not in cfg.fix_module
+        self.cached = []
+
+    def sim_loss(self, similarity_score, instance_masked, mask_logits, batch_ids):
+        """Queries whose thresholded mask overlaps its dominant instance with IoU >= 0.5 are positives, IoU <= 0.3 (or
+        no instance) negatives; all positives + the `negative_ratio` x hardest negatives (criterion_fs.py:117-190)."""
+        cfg, dev = self.cfg, similarity_score.device
+        B, nq = self.batch_size, self.n_queries
+        train_label = torch.zeros((B, nq), device=dev)
+        n_hard = torch.zeros(B, device=dev)
+        for b in range(B):
+            inst_b = instance_masked[batch_ids == b]
+            pred = (mask_logits[b].detach().sigmoid() > 0.5)
+            npos = nneg = 0
+            pos = []
+            # per-query dominant label (torch.mode: the smallest of the most frequent values), IoU with that instance
+            sizes = pred.sum(1).tolist()
+            for q in range(nq):
+                if sizes[q] == 0:
+                    nneg += 1
+                    continue
+                lab = int(torch.mode(inst_b[pred[q]])[0])
+                if lab == -100:
+                    nneg += 1
+                    continue
+                gt = inst_b == lab
+                inter = int((pred[q] & gt).sum())
+                union = int((pred[q] | gt).sum())
+                iou = inter / union
+                if iou >= 0.5:
+                    npos += 1
+                    pos.append(q)
+                elif iou <= 0.3:
+                    nneg += 1
+            n_hard[b] = min(nneg, cfg.negative_ratio * npos)
+            train_label[b, pos] = 1
+        if train_label.sum() == 0:
+            return torch.zeros((), device=dev, requires_grad=True)
+        loss_all = self.similarity_criterion(similarity_score, train_label)
+        loss_pos = loss_all * train_label
+        loss_neg = loss_all.clone()
+        loss_neg[train_label.long()] = 0  # the reference's indexing (see module docstring)
+        loss_neg, _ = loss_neg.sort(dim=1, descending=True)
+        ranks = torch.arange(nq, device=dev).unsqueeze(0).expand_as(loss_neg)
+        hard = ranks < n_hard.unsqueeze(1)
+        return (loss_neg[hard].sum() + loss_pos.sum()) / train_label.sum().float()
+
+    def single_layer_loss(self, mask_prediction, similarity_score, instance_masked, semantic_masked, batch_ids,
+                          cal_match=False):
+        dev = instance_masked.device
+        mask_logits_list = mask_prediction["mask_logits"]
+        loss_dict = {k: torch.zeros((), device=dev) for k in self.loss_weight}
+        num_gt = 0
+        for b in range(self.batch_size):
+            mask_logit_b = mask_logits_list[b]
+            if mask_logit_b is None:
+                continue
+            sel = batch_ids == b
+            if cal_match:
+                self.cached.append(self.matcher.forward_seg_single(mask_logit_b.detach(), similarity_score[b],
+                                                                    instance_masked[sel], semantic_masked[sel],
+                                                                    fewshot=True))
+            pred_inds, inst_mask_gt, _ = self.cached[b]
+            if pred_inds is None:
+                continue
+            n = len(pred_inds)
+            num_gt += n
+            if n == 0:
+                continue
+            pred = mask_logit_b[pred_inds]
+            loss_dict["dice_loss"] = loss_dict["dice_loss"] + compute_dice_loss(pred, inst_mask_gt, n)
+            loss_dict["focal_loss"] = loss_dict["focal_loss"] + compute_sigmoid_focal_loss(pred, inst_mask_gt, n)
+        loss = torch.zeros((), device=dev)
+        for k, w in self.loss_weight.items():
+            loss_dict[k] = loss_dict[k] * w / self.batch_size
+            loss = loss + loss_dict[k]
+        return loss, loss_dict, num_gt
+
+    def forward(self, model_outputs, batch_inputs, epoch):
+        cfg = self.cfg
+        preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
+        instance_labels, semantic_labels = batch_inputs["instance_labels"], batch_inputs["labels"]
+        instance_masked, semantic_masked = instance_labels[fg_idxs], semantic_labels[fg_idxs]
+        batch_ids = model_outputs["batch_idxs"]
+        similarity_score = model_outputs["simnet"]
+        out = {}
+        loss = torch.zeros((), device=similarity_score.device)
+        if epoch > cfg.prepare_epochs and self.cal_simloss:
+            sim = self.sim_loss(similarity_score, instance_masked, preds[-1]["mask_logits"], batch_ids)
+            loss = loss + sim
+            out["sim_loss"] = (sim.item(), self.n_queries)
+        self.cached = []
+        main, ld, num_gt = self.single_layer_loss(preds[-1], similarity_score, instance_masked, semantic_masked,
+                                                  batch_ids, cal_match=True)
+        loss = loss + main
+        for l in range(cfg.dec_nlayers - 1):
+            loss = loss + self.single_layer_loss(preds[l], similarity_score, instance_masked, semantic_masked,
+                                                 batch_ids)[0]
+        out["focal_loss"] = (ld["focal_loss"].item(), num_gt)
+        out["dice_loss"] = (ld["dice_loss"].item(), num_gt)
+        out["loss"] = (loss.item(), semantic_labels.shape[0])
+        return loss, out

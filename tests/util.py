@@ -120,3 +120,43 @@ def check_fs_episode(z, m, emb, out, out2, cap):
         if len(scores):
             assert np.abs(c(scores) - z[ks]).max() < 1e-4
             assert np.abs(c(props.sum(1)) - z[kn]).max() <= 3
+
+
+def criterion_case(seed, fs, B=3, NQ=32, NL=4, NCLS=13):
+    """Seeded inputs of the training criteria (shared by tests/golden/make_golden_criterion.py, which feeds them to
+    the REFERENCE's criterion, and by the tests, which feed them to the build's): per scene ~500 foreground points of ~1500, 3-6 labelled instances, mask logits that
+    follow a ground-truth instance for some queries and are noise for the others."""
+    rng = np.random.default_rng(seed)
+    labels, inst, fg, bidx, offs = [], [], [], [], 0
+    masks = [[] for _ in range(NL)]
+    inst_base = 0
+    for b in range(B):
+        n = int(rng.integers(1200, 1800))
+        lab = rng.choice([0, 1, -100], n, p=[0.5, 0.4, 0.1]).astype(np.int64)
+        ins = np.full(n, -100, np.int64)
+        k = int(rng.integers(3, 7))
+        cuts = np.sort(rng.choice(np.arange(50, n - 50), 2 * k, replace=False)).reshape(k, 2)
+        for j, (a, e) in enumerate(cuts):
+            lab[a:e] = 4 + (j + b) % 9
+            ins[a:e] = inst_base + j
+        inst_base += k
+        f = np.nonzero(lab >= 4)[0]
+        f = np.sort(np.concatenate([f, rng.choice(np.nonzero(lab < 4)[0], 60, replace=False)]))  # some false foreground
+        labels.append(lab); inst.append(ins); fg.append(f + offs); bidx.append(np.full(f.size, b, np.int32))
+        gt = [(ins[f] == i).astype(np.float32) for i in np.unique(ins[f]) if i != -100]
+        for l in range(NL):
+            m = rng.standard_normal((NQ, f.size)).astype(np.float32)
+            for qi in rng.choice(NQ, min(NQ, 2 * len(gt)), replace=False):
+                m[qi] += 4.0 * gt[rng.integers(0, len(gt))] - 1.5
+            masks[l].append(m)
+        offs += n
+    case = {"labels": np.concatenate(labels), "instance_labels": np.concatenate(inst), "fg_idxs": np.concatenate(fg),
+            "batch_idxs": np.concatenate(bidx),
+            "semantic_scores": rng.standard_normal((offs, NCLS)).astype(np.float32),
+            "cls_logits": rng.standard_normal((NL, B, NQ, NCLS)).astype(np.float32)}
+    for l in range(NL):
+        for b in range(B):
+            case[f"mask_logits_{l}_{b}"] = masks[l][b]
+    if fs:
+        case["simnet"] = rng.standard_normal((B, NQ)).astype(np.float32)
+    return case
