@@ -96,7 +96,11 @@ def install():
         return _t(orc.conv_wgrad(_np(feats), _np(grad_out), _np(nbr), K))
 
     def voxelize_fp(feats, rules, mode=4, out=None):
-        return _t(orc.voxelize_fp(_np(feats), _np(rules), mode == 4))
+        r = _t(orc.voxelize_fp(_np(feats), _np(rules), mode == 4))
+        if out is not None:  # the drop-in PG_OP.voxelize_fp writes into the caller's tensor
+            out.copy_(r)
+            return out
+        return r
 
     def voxelize_bp(d_out, rules, mode, d_feats):
         d_feats += _t(orc.voxelize_bp(_np(d_out), _np(rules), d_feats.shape[0], mode == 4))
