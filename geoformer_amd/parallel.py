@@ -2,12 +2,23 @@
 
 Scenes are independent units: the forward needs no exchange and inference runs plain replicas
 (SURVEY.md 8e).  The training step has exactly one real exchange: the sum of the gradients.  The
-reference intended DDP(find_unused_parameters=True) but never wired it (train.py:156-185); here the
-gradients of ALL parameters live in one flat fp32 buffer (8 120 459 floats = 32.5 MB) that is
-all-reduced in a few large buckets -- parameters that received no gradient (decoder/head before
-``prepare_epochs``) contribute zeros, so every rank issues the identical collectives.
-xGMI is point-to-point (7 links x ~153 GB/s): 32.5 MB is ~0.4 ms as a ring, so buckets are kept large
-(default 8 MB) and the first ones start while the backbone's backward is still running.
+reference intended SyncBatchNorm + DDP(find_unused_parameters=True) but never wired them (train.py:156-185).
+
+``BucketedGradReducer``: the gradients of all trainable parameters live in ONE flat fp32 buffer (8 120 459 floats
+= 32.5 MB for GeoFormer) laid out in reverse registration order -- roughly the order the backward produces
+them -- and cut into buckets (default 8 MB: xGMI is point-to-point, 7 links x ~153 GB/s, so a ring moves 32.5 MB in
+~0.4 ms and small buckets would only add latency).  ``p.grad`` of every parameter IS a view of that buffer, so the
+backward accumulates straight into it; a post-accumulate hook counts a bucket's parameters and starts the bucket's
+asynchronous all-reduce the moment the last one is in, while the rest of the backward is still running.  Buckets
+always go out in index order and ``finish()`` sends the ones the backward never completed (parameters without a
+gradient, e.g. decoder and heads before ``prepare_epochs``, contribute zeros), so every rank issues the identical
+sequence of collectives even when the ranks' graphs differ (an empty-foreground batch on one rank).  Parameters
+that received a gradient on NO rank get ``grad = None`` back, so the optimizer skips them exactly like the
+single-GPU step does (no weight decay / moment updates on modules that are not trained yet).
+
+``SyncBatchNorm1d``: batch statistics over all ranks with one packed all-reduce per layer and direction
+(sum, sum of squares, count | sum(dy), sum(dy * xhat)); ``convert_sync_batchnorm`` swaps it in for the
+BatchNorm1d layers that see [M, C] voxel / point rows.
 """
 from __future__ import annotations
 
@@ -15,6 +26,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.nn as nn
 
 
 def init_distributed(backend=None):
@@ -28,42 +40,175 @@ def init_distributed(backend=None):
     return world
 
 
-class FlatGradAllReduce:
-    """Gradient averaging over one flat buffer, bucketed."""
+class BucketedGradReducer:
+    """Gradient averaging over one flat buffer; buckets start from gradient hooks while the backward runs."""
 
     def __init__(self, module, bucket_bytes=8 << 20, only_trainable=True):
-        self.params = [p for p in module.parameters() if (p.requires_grad or not only_trainable)]
+        params = [p for p in module.parameters() if (p.requires_grad or not only_trainable)]
+        self.params = params[::-1]  # backward order: the last layers' gradients arrive first
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
+        self.used = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        per_bucket = max(int(bucket_bytes) // 4, 1)
+        self.views, self.bucket_of, self.ranges = [], [], []
+        off = start = 0
+        count = []
         for p in self.params:
+            if off - start >= per_bucket:  # close the bucket before this parameter
+                self.ranges.append((start, off))
+                start = off
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            self.bucket_of.append(len(self.ranges))
             off += p.numel()
-        self.bucket = max(int(bucket_bytes) // 4, 1)
+        self.ranges.append((start, off))
+        self.nparams_in = [0] * len(self.ranges)
+        for b in self.bucket_of:
+            self.nparams_in[b] += 1
+        self._hooks = []
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.launched_in_backward = 0  # buckets whose all-reduce started before finish() (for tests / logs)
+        self.prepare()
 
     def numel(self):
         return self.flat.numel()
 
+    def world(self):
+        return dist.get_world_size() if dist.is_initialized() else 1
+
     @torch.no_grad()
-    def reduce(self):
-        """Average .grad across ranks (missing grads count as zero) and write the result back."""
-        world = dist.get_world_size() if dist.is_initialized() else 1
+    def prepare(self):
+        """Call before every backward: zero the buffer and point every p.grad at its view of it."""
         self.flat.zero_()
+        self.used.zero_()
         for p, v in zip(self.params, self.views):
-            if p.grad is not None:
-                v.copy_(p.grad)
+            p.grad = v
+        self._ready = [0] * len(self.ranges)
+        self._next = 0
+        self._works = []
+        self._fired = [False] * len(self.params)
+        self.launched_in_backward = 0
+
+    def _launch(self, b):
+        s, e = self.ranges[b]
+        if self.world() > 1:
+            self._works.append(dist.all_reduce(self.flat[s:e], async_op=True))
+
+    def _on_grad(self, p):
+        i = self._index[id(p)]
+        if self._fired[i]:
+            return
+        self._fired[i] = True
+        if p.grad is not self.views[i]:  # autograd replaced the tensor (first accumulation into a fresh grad)
+            self.views[i].copy_(p.grad)
+            p.grad = self.views[i]
+        self.used[i] = 1.0
+        b = self.bucket_of[i]
+        self._ready[b] += 1
+        # buckets leave in index order only: identical collective sequence on every rank
+        while self._next < len(self.ranges) and self._ready[self._next] == self.nparams_in[self._next]:
+            self._launch(self._next)
+            self._next += 1
+            self.launched_in_backward += 1
+
+    @torch.no_grad()
+    def finish(self):
+        """After backward: send the buckets the hooks did not complete, wait, average, and give parameters that no
+        rank produced a gradient for ``grad = None`` back."""
+        world = self.world()
+        while self._next < len(self.ranges):
+            self._launch(self._next)
+            self._next += 1
         if world > 1:
-            works = [dist.all_reduce(self.flat[s:s + self.bucket], async_op=True)
-                     for s in range(0, self.flat.numel(), self.bucket)]
-            for w in works:
+            self._works.append(dist.all_reduce(self.used, op=dist.ReduceOp.MAX, async_op=True))
+            for w in self._works:
                 w.wait()
             self.flat.div_(world)
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+        used = self.used.tolist()
+        for p, v, u in zip(self.params, self.views, used):
+            p.grad = v if u > 0 else None
+
+    # the round-1 name / call
+    reduce = finish
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+FlatGradAllReduce = BucketedGradReducer  # former name
+
+
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        C = x.shape[1]
+        red = [d for d in range(x.dim()) if d != 1]
+        n_local = x.numel() // C
+        stats = torch.cat([x.sum(red), (x * x).sum(red), x.new_full((1,), float(n_local))])
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(stats)
+        n = stats[-1]
+        mean = stats[:C] / n
+        var = (stats[C:2 * C] / n - mean * mean).clamp_min(0.0)
+        invstd = torch.rsqrt(var + eps)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = (x - mean.view(shape)) * invstd.view(shape)
+        ctx.save_for_backward(xhat, weight, invstd, n)
+        ctx.red, ctx.shape = red, shape
+        return xhat * weight.view(shape) + bias.view(shape), mean, var, n
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv, _gn):
+        xhat, weight, invstd, n = ctx.saved_tensors
+        red, shape = ctx.red, ctx.shape
+        C = xhat.shape[1]
+        gw_local = (gy * xhat).sum(red)
+        gb_local = gy.sum(red)
+        packed = torch.cat([gb_local, gw_local])
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(packed)  # statistics of the GLOBAL batch; weight/bias grads stay local (the reducer sums them)
+        sum_dy, sum_dy_xhat = packed[:C], packed[C:]
+        gx = (gy - sum_dy.view(shape) / n - xhat * (sum_dy_xhat.view(shape) / n)) * (weight * invstd).view(shape)
+        return gx, gw_local, gb_local, None
+
+
+class SyncBatchNorm1d(nn.BatchNorm1d):
+    """BatchNorm1d whose training statistics span all ranks (one packed all-reduce per direction); eval mode and the
+    state dict are those of nn.BatchNorm1d."""
+
+    def forward(self, x):
+        if not self.training or x.numel() == 0:
+            return super().forward(x)
+        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps)
+        with torch.no_grad():
+            if self.track_running_stats:
+                m = self.momentum if self.momentum is not None else 0.1
+                unbiased = var * (n / (n - 1).clamp_min(1.0))
+                self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                self.running_var.mul_(1 - m).add_(unbiased, alpha=m)
+                self.num_batches_tracked += 1
+        return y
+
+
+def convert_sync_batchnorm(module):
+    """Replace every nn.BatchNorm1d (incl. the build's lean subclass) by SyncBatchNorm1d, sharing parameters and
+    buffers (what the reference's ``nn.SyncBatchNorm.convert_sync_batchnorm`` call, train.py:182, intended)."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, nn.BatchNorm1d) and not isinstance(child, SyncBatchNorm1d):
+            sb = SyncBatchNorm1d(child.num_features, eps=child.eps, momentum=child.momentum, affine=child.affine,
+                                 track_running_stats=child.track_running_stats)
+            sb.weight, sb.bias = child.weight, child.bias
+            sb.running_mean, sb.running_var = child.running_mean, child.running_var
+            sb.num_batches_tracked = child.num_batches_tracked
+            sb.train(child.training)
+            setattr(module, name, sb)
+        else:
+            convert_sync_batchnorm(child)
+    return module
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

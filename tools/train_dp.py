@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Data-parallel training step of GeoFormer (BASELINE config 5: N ranks x `batch_size` scenes, RCCL gradient
+all-reduce over xGMI for the training step only; the reference's intended launch is train.py:156-185).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        tools/train_dp.py --steps 10 --warmup 2 --batch-size 4 --points 150000 [--sync-bn] [--epoch 200]
+
+One process per GPU (LOCAL_RANK selects the device; the reference's hard-coded device 0 wants
+HIP_VISIBLE_DEVICES=<rank> instead when its own train.py is used).  Every rank builds its own synthetic scenes
+(seed + rank) and rulebooks; the only exchange is BucketedGradReducer's bucketed all-reduce, started from gradient
+hooks while the backward is still running (geoformer_amd/parallel.py), plus one packed all-reduce per BatchNorm layer
+and direction with --sync-bn.  Timing: barrier + synchronize on both sides, max over ranks; rank 0 prints one JSON
+line.  --cpu runs the same loop on the host through the oracle's operators over gloo (tests / smoke only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build(args, device):
+    from geoformer_amd import parallel
+    from geoformer_amd.model import GeoFormer, InstSetCriterion, load_config
+    from tests.util import synthetic_state_dict
+
+    over = dict(batch_size=args.batch_size, dec_dropout=0.0)
+    if args.small:
+        over.update(n_decode_point=128, n_query_points=16)
+    if args.prepare_epochs is not None:
+        over["prepare_epochs"] = args.prepare_epochs
+    cfg = load_config("geoformer_scannet.yaml", **over)
+    torch.manual_seed(0)  # identical initial weights on every rank
+    m = GeoFormer(cfg)
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 1))
+    if args.sync_bn:
+        parallel.convert_sync_batchnorm(m)
+    m.to(device)
+    m.train()
+    if args.bn_eval:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return cfg, m, InstSetCriterion(cfg)
+
+
+def make_batches(args, rank, device, n):
+    from geoformer_amd import scene
+
+    out = []
+    for i in range(n):
+        scenes = []
+        for b in range(args.batch_size):
+            seed = args.seed + (rank * n + i) * args.batch_size + b
+            scenes.append(scene.make_small_scene(args.points, seed) if args.small else scene.make_scene(args.points, seed))
+        batch = scene.make_batch(scenes)
+        out.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()})
+    return out
+
+
+def step(m, crit, red, opt, batch, epoch, np_seed):
+    np.random.seed(np_seed)
+    red.prepare()  # zeroes the flat gradient buffer and points every p.grad into it (instead of zero_grad)
+    out = m(batch, epoch)
+    loss, info = crit(out, batch, epoch)
+    loss.backward()  # buckets leave from the gradient hooks while this runs
+    red.finish()
+    if opt is not None:
+        opt.step()
+    return float(loss.detach()), info
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-size", type=int, default=4)
+    ap.add_argument("--points", type=int, default=150_000)
+    ap.add_argument("--epoch", type=int, default=200)
+    ap.add_argument("--prepare-epochs", type=int, default=None)
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--bucket-mb", type=float, default=8.0)
+    ap.add_argument("--sync-bn", action="store_true")
+    ap.add_argument("--bn-eval", action="store_true")
+    ap.add_argument("--small", action="store_true", help="small scenes / heads (CPU smoke runs)")
+    ap.add_argument("--cpu", action="store_true", help="host run through the oracle operators over gloo")
+    args = ap.parse_args(argv)
+
+    import torch.distributed as dist
+
+    from geoformer_amd import parallel
+
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if args.cpu:
+        device = torch.device("cpu")
+        world = parallel.init_distributed("gloo")
+        from oracle import cpu_backend
+
+        restore = cpu_backend.install()
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("tools/train_dp.py needs a GPU (or --cpu for the oracle-backed smoke run)")
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+        world = parallel.init_distributed("nccl")
+        restore = lambda: None  # noqa: E731
+    try:
+        cfg, m, crit = build(args, device)
+        red = parallel.BucketedGradReducer(m, bucket_bytes=int(args.bucket_mb * (1 << 20)))
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        nb = 2
+        batches = make_batches(args, rank, device, nb)
+        sync = (lambda: torch.cuda.synchronize()) if device.type == "cuda" else (lambda: None)
+        for i in range(args.warmup):
+            step(m, crit, red, opt, batches[i % nb], args.epoch, 100 * rank + i)
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        early = 0
+        for i in range(args.steps):
+            loss, _ = step(m, crit, red, opt, batches[i % nb], args.epoch, 100 * rank + args.warmup + i)
+            early += red.launched_in_backward
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+        dt = parallel.max_over_ranks(time.perf_counter() - t0, device if device.type == "cuda" else None)
+        if rank == 0:
+            scenes = world * args.batch_size * args.steps
+            print(json.dumps({
+                "metric": "training scenes/sec (fwd + criterion + bwd + all-reduce + Adam)", "value": round(scenes / dt, 3),
+                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(dt / args.steps * 1e3, 2), "global_batch": world * args.batch_size,
+                "points_per_scene": args.points, "epoch": args.epoch, "sync_bn": bool(args.sync_bn),
+                "grad_floats": red.numel(), "buckets": len(red.ranges),
+                "buckets_started_inside_backward_per_step": round(early / max(args.steps, 1), 2),
+                "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        restore()
+
+
+if __name__ == "__main__":
+    main()
