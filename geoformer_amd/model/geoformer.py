@@ -86,7 +86,8 @@ def knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05
     geodesic_utils.py:11-24,110-125).  Depends on the points only, so the forward issues it before the
     host-side RNG draw and FPS."""
     offs = _offsets_list(batch_offsets_)
-    return [pointops.knn_radius(locs_float_[offs[b]:offs[b + 1]].contiguous(), neighbor, radius, sqrt_out=True)
+    return [pointops.knn_radius(locs_float_[offs[b]:offs[b + 1]].contiguous(), neighbor, radius, sqrt_out=True,
+                                return_flag=True)
             for b in range(batch_size)]
 
 
@@ -100,10 +101,17 @@ def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighb
         graphs = knn_graphs(locs_float_, batch_offsets_, pre_enc_inds.shape[0], neighbor, radius)
     out = []
     for b in range(pre_enc_inds.shape[0]):
-        D, I, deg = graphs[b]
+        D, I, deg = graphs[b][:3]
         src = pre_enc_inds[b][:n_queries].int().contiguous()
         out.append(pointops.geodesic_bfs(D, I, deg, src, radius, max_step))
     return out
+
+
+def _stream_key(device=None):
+    """(device, stream) the caller is running on: the forward's in-flight side-stream state is kept per caller
+    stream, so scenes queued from different host threads / streams on ONE model never pick up each other's events."""
+    st = torch.cuda.current_stream(device)
+    return (st.device, st.cuda_stream)
 
 
 class PendingProposals:
@@ -112,13 +120,22 @@ class PendingProposals:
     host word.  ``get()`` waits for it and queues the membership scatter on the stream the forward ran on."""
 
     _pinned = []
+    _lock = threading.Lock()
 
-    def __init__(self, final, cls_pred, scores, logits, fg_idxs, logit_thresh, num_points):
+    def __init__(self, final, cls_pred, scores, logits, fg_idxs, logit_thresh, num_points, knn_flags=()):
         self.stream = torch.cuda.current_stream(logits.device)
         sel, cls, sc, cnt = pointops.proposal_select(final.contiguous(), cls_pred.contiguous(), scores.contiguous())
         self.args = (sel, cls, sc, logits, fg_idxs, logit_thresh, num_points)
-        buf = PendingProposals._pinned.pop() if PendingProposals._pinned else torch.empty(1, dtype=torch.int32).pin_memory()
-        buf.copy_(cnt, non_blocking=True)
+        with PendingProposals._lock:
+            buf = PendingProposals._pinned.pop() if PendingProposals._pinned else None
+        if buf is None:
+            buf = torch.zeros(2, dtype=torch.int32).pin_memory()
+        buf[1] = 0
+        buf[0:1].copy_(cnt, non_blocking=True)
+        # the kNN graph's truncation flag (more in-radius candidates than the kernel's list holds: rows would no
+        # longer be the nearest neighbours) rides in the same read-back instead of costing one of its own
+        for f in knn_flags:
+            buf[1:2].copy_(f, non_blocking=True)
         self.host = buf
         self.done = torch.cuda.Event()
         self.done.record(self.stream)
@@ -128,9 +145,16 @@ class PendingProposals:
         if self.value is None:
             sel, cls, sc, logits, fg_idxs, logit_thresh, num_points = self.args
             self.done.synchronize()
-            n = int(self.host[0])
-            PendingProposals._pinned.append(self.host)
+            n, overflow = int(self.host[0]), int(self.host[1])
+            with PendingProposals._lock:
+                PendingProposals._pinned.append(self.host)
             self.host = None
+            if overflow:
+                from .._lib import GeoFormerHipError
+
+                raise GeoFormerHipError("kNN graph: a point has more in-radius neighbours than the kernel's candidate list "
+                                        "holds (1024); its row is not the 64 nearest and the geodesic distances "
+                                        "would be wrong -- deduplicate the scene's points")
             if n == 0:
                 self.value = ([], [], [])
             else:
@@ -408,6 +432,7 @@ class GeoFormer(nn.Module):
                 # (issued after their launch -- nothing may delay that one)
                 aux.wait_event(xyz_ready)
                 with torch.cuda.stream(aux):
+                    xyz_b.record_stream(aux)
                     grid = pointops.point_grid_build(xyz_b, self.set_aggregator.radius)
                     grid.record_stream(main)
                     grid_done = torch.cuda.Event()
@@ -415,7 +440,7 @@ class GeoFormer(nn.Module):
                 grid = (grid, grid_done)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                D, I, deg = graphs[b]
+                D, I, deg = graphs[b][:3]
                 g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=256 if split else 1024)
                 g.record_stream(main)
                 src.record_stream(side)
@@ -439,7 +464,7 @@ class GeoFormer(nn.Module):
             # small launches that only need the distances / the query picks ride beside the sampling instead of
             # sitting between the decoder and the mask head on the main stream
             self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready)
-        self.__dict__["_gf_pending_side"] = geo_ready
+        self.__dict__.setdefault("_gf_pending_side", {})[_stream_key(locs_float_.device)] = geo_ready
         cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
         with grad_ctx():
             fused = []
@@ -462,7 +487,7 @@ class GeoFormer(nn.Module):
         return res + (early_out,) if early is not None else res
 
     def _side_epilogue(self, b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready):
-        early = self.__dict__.setdefault("_gf_early", {})
+        early = self._early()
         if b == 0:
             early.clear()
         with torch.cuda.stream(side):
@@ -479,6 +504,7 @@ class GeoFormer(nn.Module):
                 # (the folded copy of the projection's parameters is derived on the stream that reads it)
                 qpr = self._pointwise_chain("qproj", [self.query_projection], xyz_b)
                 if qpr is not None:
+                    xyz_b.record_stream(aux)
                     q_locs = xyz_b[:, src.long()]  # the first picks = the query points (same gather as group_points)
                     qpe = self.pos_embedding(q_locs, input_range=pc_dims).float()
                     qpos = pointops.pointwise_mlp(qpe[0].t().contiguous(), qpr)
@@ -488,10 +514,18 @@ class GeoFormer(nn.Module):
                     ev.record(aux)
                     early["qpos"] = (q_locs, qpos, ev)
 
+    def _early(self):
+        """Results computed beside the BFS for the forward running on the CALLER's stream (per-stream dict)."""
+        if not torch.cuda.is_available():
+            return {}
+        return self.__dict__.setdefault("_gf_early", {}).setdefault(_stream_key(), {})
+
     def _join_side_stream(self):
         """The calling stream waits for the geodesic distances (not for the small launches queued behind them)."""
-        for ev in self.__dict__.pop("_gf_pending_side", None) or ():
-            torch.cuda.current_stream().wait_event(ev)
+        pend = self.__dict__.get("_gf_pending_side")
+        if pend and torch.cuda.is_available():
+            for ev in pend.pop(_stream_key(), None) or ():
+                torch.cuda.current_stream().wait_event(ev)
 
     # -- decoder ------------------------------------------------------------------------------
     def relative_position_embedding(self, context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds):
@@ -532,7 +566,7 @@ class GeoFormer(nn.Module):
             if e2d is not None and qpr is not None:
                 ctx = pointops.pointwise_mlp(context_feats[0].contiguous(), e2d)  # [nc, dec_dim]
                 rel = self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds)
-                hit = self.__dict__.get("_gf_early", {}).pop("qpos", None)  # computed beside the BFS (joined above)
+                hit = self._early().pop("qpos", None)  # computed beside the BFS (joined above)
                 if hit is not None and hit[0].shape == query_locs.shape:
                     torch.cuda.current_stream().wait_event(hit[2])
                     qpos = hit[1]
@@ -568,7 +602,7 @@ class GeoFormer(nn.Module):
             # inference: one fused HIP kernel (no nq x 19 x N intermediate)
             mx = None
             if use_geo:
-                early = self.__dict__.get("_gf_early", {})
+                early = self._early()
                 hit = next((early.pop(k) for k in list(early) if k[0] == "mx" and early[k][0] is geo_dist), None)
                 if hit is not None:
                     torch.cuda.current_stream().wait_event(hit[2])
@@ -599,7 +633,7 @@ class GeoFormer(nn.Module):
     def _mask_head_packed(self, geo_dist, mask_features, params, num_insts, coords_, fps_sampling_coords):
         """mask_heads_forward (geoformer.py:286-324) with the generated parameters read from `params` in place."""
         n_mask = mask_features.size(0)
-        early = self.__dict__.get("_gf_early", {})
+        early = self._early()
         hit = next((early.pop(k) for k in list(early) if k[0] == "mx" and early[k][0] is geo_dist), None)
         if hit is not None:
             torch.cuda.current_stream().wait_event(hit[2])
@@ -656,7 +690,7 @@ class GeoFormer(nn.Module):
 
     def generate_proposal(self, mask_logits, cls_logits, fg_idxs, batch_offsets, batch_offsets_,
                           semantic_scores_=None, logit_thresh=0.5, score_thresh=0.5, npoint_thresh=100, sem_prob=None,
-                          defer=False):
+                          defer=False, knn_flags=()):
         """Batch-1 proposal extraction (geoformer.py:193-262): score = mean mask prob * sqrt(cls prob) *
         mean semantic prob of the predicted class over the mask.  defer: return a PendingProposals instead of
         waiting for the device (GPU inference only)."""
@@ -676,7 +710,8 @@ class GeoFormer(nn.Module):
             cls_pred, _, scores, final = pointops.proposal_stats(
                 logits, cls_logits[b].contiguous(), sem_t.contiguous(), logit_thresh, score_thresh, npoint_thresh,
                 min_class=4, class_major=True)
-            pending = PendingProposals(final, cls_pred, scores, logits, fg_idxs.contiguous(), logit_thresh, num_points)
+            pending = PendingProposals(final, cls_pred, scores, logits, fg_idxs.contiguous(), logit_thresh, num_points,
+                                       knn_flags=knn_flags)
             return pending if defer else pending.get()
         sem = sem_prob if sem_prob is not None and not isinstance(sem_prob, tuple) else F.softmax(semantic_scores_, dim=1)
         num_points = int(batch_offsets[b + 1] - batch_offsets[b])
@@ -704,7 +739,10 @@ class GeoFormer(nn.Module):
     def forward(self, batch_input, epoch, training=True, defer_proposals=False):
         """defer_proposals (GPU inference): everything is queued on the current stream and
         ``outputs["proposal_scores"]`` is a PendingProposals whose ``get()`` makes the forward's last read-back -- a
-        serving loop can queue the next scene on another stream before it collects this one (bench.py does)."""
+        serving loop can queue the next scene on another stream before it collects this one (measured: no gain on one
+        GPU; bench.py runs one scene at a time).  The in-flight side-stream state is kept per
+        caller stream, so forwards issued from different host threads on their own streams do not interfere;
+        ``last_sampling_indices`` (a test hook) is the one attribute that is per model."""
         cfg = self.cfg
         outputs = {}
         batch_idxs = batch_input["locs"][:, 0].int()
@@ -817,6 +855,8 @@ class GeoFormer(nn.Module):
             outputs["proposal_scores"] = self.generate_proposal(
                 preds[-1]["mask_logits"], preds[-1]["cls_logits"], fg_idxs, batch_offsets, batch_offsets_,
                 semantic_scores_=semantic_scores_, logit_thresh=0.5, score_thresh=cfg.TEST_SCORE_THRESH,
-                npoint_thresh=cfg.TEST_NPOINT_THRESH, sem_prob=sem_prob, defer=defer_proposals)
-        self.__dict__.get("_gf_early", {}).clear()
+                npoint_thresh=cfg.TEST_NPOINT_THRESH, sem_prob=sem_prob, defer=defer_proposals,
+                knn_flags=[g[3] for g in (graphs or ()) if len(g) > 3])
+        if locs_float.is_cuda:
+            self._early().clear()
         return outputs

@@ -191,8 +191,10 @@ def legacy_choice(n, k):
 
 
 # ---- geodesic stage --------------------------------------------------------------------
-def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False):
-    """Radius-limited kNN graph of one scene.  Returns D [n,k] fp32, I [n,k] int32, deg [n] int32."""
+def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False, return_flag=False):
+    """Radius-limited kNN graph of one scene.  Returns D [n,k] fp32, I [n,k] int32, deg [n] int32
+    (+ with return_flag the kernel's device-side truncation flag, int32 [1], for a caller that folds it into a
+    read-back it makes anyway; check_overflow reads it here and raises)."""
     _f32c(xyz, "xyz")
     n = xyz.shape[0]
     lib = _lib.load()
@@ -208,6 +210,9 @@ def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False):
         if int(scratch[off].item()) != 0:
             raise _lib.GeoFormerHipError("gf_knn_radius: a point has more in-radius neighbours than the kernel's "
                                          "candidate list holds (rows truncated)")
+    if return_flag:
+        off = (lib.gf_knn_error_flag(ptr(scratch), n) - scratch.data_ptr()) // 4
+        return D, I, deg, scratch[off:off + 1]
     return D, I, deg
 
 

@@ -106,13 +106,14 @@ def install():
         d_feats += _t(orc.voxelize_bp(_np(d_out), _np(rules), d_feats.shape[0], mode == 4))
         return d_feats
 
-    def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False):
+    def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False, return_flag=False):
         p = _np(xyz)
         D2, I = orc.knn(p, p, k)
         D = np.sqrt(D2)
         inr = D <= np.float32(radius)
         Dm = np.where(inr, D if sqrt_out else D2, np.inf).astype(np.float32)
-        return _t(Dm), _t(np.where(inr, I, -1).astype(np.int32)), _t((inr.sum(1) - 1).astype(np.int32))
+        res = (_t(Dm), _t(np.where(inr, I, -1).astype(np.int32)), _t((inr.sum(1) - 1).astype(np.int32)))
+        return res + (torch.zeros(1, dtype=torch.int32),) if return_flag else res
 
     def geodesic_bfs(D, I, deg, src, radius, max_step):
         return _t(orc.geodesic(_np(D)[:, 1:], _np(I)[:, 1:].astype(np.int64), _np(src).astype(np.int64), radius,

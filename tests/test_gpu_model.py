@@ -187,3 +187,84 @@ def test_fused_caches_follow_parameter_updates(hip):
         m.invalidate_fused_caches()
         s3 = m(batch, 0, training=False)["semantic_scores"]
         assert torch.allclose(s3[:, 2] - s2[:, 2], torch.full_like(s0[:, 2], -3.0), atol=1e-4)
+
+
+def test_two_host_threads_on_their_own_streams_share_one_model(hip):
+    """The forward parks events and side results of its BFS / aux streams on the model between its stages; that state
+    is keyed by the caller's stream, so two host threads running different scenes through ONE model on their own
+    streams must each get exactly what a serial run gives."""
+    import threading
+
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    m = GeoFormer(load_config("test_geoformer_scannet.yaml"))
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 0))
+    m.cuda().eval()
+    batches = [_to_dev(scene.make_batch([scene.make_small_scene(n, s)])) for n, s in ((9000, 5), (7000, 6))]
+
+    def run(b, seed):
+        np.random.seed(seed)  # (the host draw is numpy's global generator: the threads below draw under a lock)
+        with torch.no_grad():
+            o = m(b, 300, training=False)
+        mp = o["mask_predictions"][-1]
+        return [o["fg_idxs"].clone(), mp["cls_logits"].clone(), mp["mask_logits"][0].clone()]
+
+    serial = [run(b, 1) for b in batches]
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+    draw_lock = threading.Lock()
+    orig_choice = __import__("geoformer_amd").pointops.legacy_choice
+
+    def locked_choice(n, k):  # same generator state for every draw: reseed under the lock
+        with draw_lock:
+            np.random.seed(1)
+            return orig_choice(n, k)
+
+    import geoformer_amd.pointops as po
+
+    po.legacy_choice = locked_choice
+    try:
+        def worker(i):
+            try:
+                st = torch.cuda.Stream()
+                for _ in range(4):
+                    with torch.cuda.stream(st), torch.no_grad():
+                        o = m(batches[i], 300, training=False)
+                        mp = o["mask_predictions"][-1]
+                        results[i] = [o["fg_idxs"].clone(), mp["cls_logits"].clone(), mp["mask_logits"][0].clone()]
+                    st.synchronize()
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        po.legacy_choice = orig_choice
+    assert not errors, errors
+    for i in range(2):
+        for a, b in zip(serial[i], results[i]):
+            assert a.shape == b.shape and torch.equal(a, b), i
+
+
+def test_knn_truncation_is_reported_with_the_last_read_back(hip):
+    """More than 1024 in-radius neighbours (1300 copies of one point): gf_knn_radius sets its device flag, the forward
+    carries it to the proposals' read-back and raises there instead of returning distances over truncated rows."""
+    from geoformer_amd import _lib, scene
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    m = GeoFormer(load_config("test_geoformer_scannet.yaml"))
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 0))
+    with torch.no_grad():
+        m.semantic_linear.bias[:4] -= 1e4  # every point is foreground
+    m.cuda().eval()
+    batch = _to_dev(scene.make_batch([scene.make_small_scene(8192, 7)]))
+    batch["locs_float"][100:1400] = batch["locs_float"][50]
+    np.random.seed(0)
+    with torch.no_grad(), pytest.raises(_lib.GeoFormerHipError, match="in-radius"):
+        m(batch, 300, training=False)
