@@ -140,6 +140,60 @@ class GeoFormerFS(GeoFormer):
         proposals[inst, fg_idxs[pts]] = 1
         return scores[final], proposals
 
+    # -- batched re-query of a cached scene ---------------------------------
+    @torch.no_grad()
+    def requery_many(self, scene_dict, support_embeddings):
+        """The few-shot test loop re-queries ONE scene with many support embeddings (every label of the scene x
+        ``run_num`` support draws, test_fs.py:157-174): ``forward(..., remember=True, support_embeddings=e)`` once per
+        embedding, each ending in the host read-backs of generate_proposal (count_nonzero, boolean indexing).
+        Here all E re-queries are queued back to back -- fusion, decoder, mask head, similarity and the proposal
+        statistics stay on the device -- and the host synchronises ONCE at the end to cut the accepted proposals.
+        ``support_embeddings``: [E, C] (or a list of [1, C]); the scene must have gone through
+        ``forward(..., remember=False)`` before (``cache_data``).  Returns a list of E ``(scores, proposals)`` pairs
+        identical to what the sequential calls return (``([], [])`` where nothing is accepted)."""
+        cfg = self.cfg
+        assert self.cache_data is not None, "requery_many: run forward(..., remember=False) on the scene first"
+        (context_locs, context_feats, pre_enc_inds, fg_idxs, batch_offsets, output_feats_, batch_idxs_, locs_float_,
+         batch_offsets_, semantic_preds_, semantic_scores, query_locs, mask_features_, geo_dists) = self.cache_data
+        if torch.is_tensor(support_embeddings):
+            embs = [support_embeddings[i:i + 1] for i in range(support_embeddings.shape[0])]
+        else:
+            embs = list(support_embeddings)
+        if len(fg_idxs) == 0:
+            return [None] * len(embs)
+        pc_dims = [scene_dict["pc_mins"], scene_dict["pc_maxs"]]
+        num_points = int(batch_offsets[1] - batch_offsets[0])
+        pending = []
+        for e in embs:
+            s = e.unsqueeze(1).repeat(1, cfg.n_decode_point, 1)
+            aggregation = torch.cat([context_feats * s, context_feats - s, context_feats], dim=2)
+            dec_outputs = self.forward_decoder(context_locs, aggregation, query_locs, pc_dims, geo_dists, pre_enc_inds)[-1:]
+            ml = self.get_mask_prediction(geo_dists, dec_outputs, mask_features_, locs_float_, query_locs,
+                                          batch_offsets_)[-1]["mask_logits"][0]
+            sim = self.similarity_net(aggregation[:, :cfg.n_query_points, :].flatten(0, 1)).squeeze(-1)
+            sim = sim.reshape(1, cfg.n_query_points)[0].sigmoid()
+            # generate_proposal (geoformer_fs.py:191-239) up to the point where it needs the host
+            prob = ml.sigmoid()
+            mask_bool = prob >= 0.2
+            npts = torch.sum(mask_bool, dim=1)
+            mask_scores = torch.sum(prob * mask_bool.int(), dim=1) / (npts + 1e-6)
+            scores = mask_scores * torch.pow(sim, 0.5)
+            final = (sim >= cfg.similarity_thresh) & (npts >= cfg.TEST_NPOINT_THRESH) & \
+                (mask_scores >= cfg.TEST_SCORE_THRESH)
+            pending.append((scores, final, mask_bool))
+        finals = torch.stack([p[1] for p in pending]).cpu()  # the one synchronisation
+        out = []
+        for (scores, final, mask_bool), f in zip(pending, finals):
+            if not bool(f.any()):
+                out.append(([], []))
+                continue
+            masks_final = mask_bool[final]
+            proposals = torch.zeros((masks_final.shape[0], num_points), dtype=torch.int, device=scores.device)
+            inst, pts = torch.nonzero(masks_final, as_tuple=True)
+            proposals[inst, fg_idxs[pts]] = 1
+            out.append((scores[final], proposals))
+        return out
+
     def forward(self, support_dict, scene_dict, training=True, remember=False, support_embeddings=None):
         cfg = self.cfg
         outputs = {}

@@ -268,3 +268,27 @@ def test_knn_truncation_is_reported_with_the_last_read_back(hip):
     np.random.seed(0)
     with torch.no_grad(), pytest.raises(_lib.GeoFormerHipError, match="in-radius"):
         m(batch, 300, training=False)
+
+
+def test_fs_requery_many_equals_sequential_requeries(hip):
+    """GeoFormerFS.requery_many (one host synchronisation for E re-queries of a cached scene) returns what E sequential
+    forward(..., remember=True) calls return."""
+    from tests.util import run_fs_episode
+
+    z, m, emb, out, out2, cap = run_fs_episode("cuda")
+    from tests.util import fs_dicts
+
+    sup, q = fs_dicts()
+    q = _to_dev(q)
+    embs = torch.cat([emb, emb * 0.5, emb * 0.0 + 0.3, -emb])
+    with torch.no_grad():
+        seq = [m(None, q, training=False, remember=True, support_embeddings=embs[i:i + 1])["proposal_scores"]
+               for i in range(embs.shape[0])]
+        many = m.requery_many(q, embs)
+    torch.cuda.synchronize()
+    assert len(many) == len(seq)
+    for a, b in zip(seq, many):
+        assert len(a[0]) == len(b[0])
+        if len(a[0]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert any(len(a[0]) for a in seq)  # at least one embedding yields proposals
