@@ -61,6 +61,8 @@ def _declare(lib):
         "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, I, P]),
         "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
         "gf_mask_head_packed": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+        "gf_mask_head_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P]),
+        "gf_mask_head_bwd_scratch_floats": (c_size_t, [I, I]),
         "gf_softmax_dim1_fwd": (I, [P, I, I, I, F, P, P]),
         "gf_softmax_dim1_bwd": (I, [P, P, I, I, I, F, P, P]),
         "gf_pointwise_mlp": (I, [P, I, I, P, P, P, P, P, P, P]),

@@ -185,3 +185,288 @@ extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const
     GF_CHECK_LAUNCH("gf_mask_head");
     return GF_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// Backward of the fused mask head (training: geoformer.py:286-324 under autograd).
+//
+//   given gout[q,p] = dL/dlogit:   dh[q,c,p] = gout * W2_q[c] * (h_pre > 0)
+//       dFeat[p,k]  = sum_q sum_c W1f_q[c,k] dh[q,c,p]           dW2_q[c] = sum_p gout * relu(h_pre)
+//       dW1_q[c,:]  = sum_p dh[q,c,p] * [rel(q,p) ; f_p]          db1_q[c] = sum_p dh[q,c,p]      db2_q = sum_p gout
+//   (no gradient flows into the coordinates or the geodesic distances).
+//
+// Nothing of the forward is stored: h_pre is recomputed with the forward's own MFMAs, once per orientation,
+// because the two reductions want the hidden activations on different operand sides:
+//   k_mask_head_bwd_feat   (forward's orientation: channels on the accumulator rows, point on the column)
+//       dFeat^T[k,p] += W1f^T . dh     A operand = weights, B operand = dh straight from the accumulator registers;
+//       a wave owns 64 points, sums over (a slice of) the queries in registers, stores once
+//   k_mask_head_bwd_param  (operands swapped: points on the rows, channel on the column)
+//       dW1^T[k,c]   += X . dh^T       A operand = features / relative coordinates, B operand = dh^T from the registers;
+//       a wave owns MHB_Q queries and one CHUNK of the points, sums over the chunk in registers and writes its
+//       337 partial sums per query to a [chunks, nq, 337] buffer that a last small kernel adds up.
+// The MFMA k index is only a summation index, so "register r of lane group g" stands for row 4g + r on either side
+// and no value ever changes lanes.  (A first version did both in one point-stationary kernel and added the parameter
+// gradients with fp32 atomics, 7 wave-wide atomics per (wave, query): every wave walks the queries in the same
+// order, so ~500 waves hit the same 337 addresses together -- 1.1 ms per call against 45 us for the forward.)
+// 9 + 13 MFMAs per (query, 16-point tile) against the forward's 5; deterministic (no atomics) when the feature
+// kernel does not have to split the queries.
+// ------------------------------------------------------------------------------------
+#define MHB_Q 4  // queries per wave of the parameter kernel (tile data loaded once for all of them)
+
+template <bool USE_GEO>
+__global__ __launch_bounds__(256, 2) void k_mask_head_bwd_feat(const float* __restrict__ feat, const float* __restrict__ coords,
+                                                               const float* __restrict__ geo, const float* __restrict__ qxyz,
+                                                               const float* __restrict__ mx, const float* __restrict__ w1,
+                                                               const float* __restrict__ b1, const float* __restrict__ w2,
+                                                               const float* __restrict__ gout, int ldp, int N, int nq,
+                                                               int qsplit, float* __restrict__ dfeat) {
+    const int ld_w1 = ldp ? ldp : 16 * 19, ld_v = ldp ? ldp : 16;
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nblocks = (N + 63) >> 6;
+    const int blk = wave / qsplit, part = wave - blk * qsplit;
+    if (blk >= nblocks) return;
+    const int p0 = blk * 64;
+    const int qper = (nq + qsplit - 1) / qsplit;
+    const int q0 = part * qper, q1 = min(nq, q0 + qper);
+    float4 fA[4];  // feat[p0+16t+j][4g..4g+3]
+    float pcA[4];  // coords[p0+16t+j][g]
+    f32x4 accF[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int pa = min(p0 + 16 * t + j, N - 1);
+        fA[t] = *reinterpret_cast<const float4*>(feat + (size_t)pa * 16 + 4 * g);
+        pcA[t] = coords[(size_t)pa * 3 + min(g, 2)];
+        accF[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int q = q0; q < q1; q++) {
+        const float* W = w1 + (size_t)q * ld_w1;
+        float wf[4], wT[4], ww[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            wf[s] = W[j * 19 + 3 + 4 * g + s];    // W1[c=j][3+4g+s]
+            wT[s] = W[(4 * g + s) * 19 + 3 + j];  // W1[c=4g+s][3+k=j]
+            ww[s] = w2[(size_t)q * ld_v + 4 * g + s];
+        }
+        const float w5 = g < 3 ? W[j * 19 + g] : b1[(size_t)q * ld_v + j];
+        const float qcA = g < 3 ? qxyz[q * 3 + g] : 0.f;
+        const float mq = USE_GEO ? mx[q] : 0.f;
+        float goA[4], gdA[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int pa = p0 + 16 * t + j;
+            goA[t] = pa < N ? gout[(size_t)q * N + pa] : 0.f;
+            gdA[t] = USE_GEO ? geo[(size_t)q * N + min(pa, N - 1)] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float rel = qcA - pcA[t];
+            if (USE_GEO) rel = rel + (gdA[t] < 0.f ? mq : 0.f) * (rel > 0.f ? 1.f : (rel < 0.f ? -1.f : 0.f));
+            if (g == 3) rel = 1.0f;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};  // h_pre[c = 4g+r][p = j]
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w5, rel, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], fA[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], fA[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], fA[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], fA[t].w, acc, 0, 0, 0);
+            // dFeat^T[k][p] += sum_c W1f[c][k] dh[c][p]: step s covers c = 4*kq + s (kq = lane group of the operand lane)
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float dh = acc[s] > 0.f ? goA[t] * ww[s] : 0.f;
+                accF[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wT[s], dh, accF[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {  // rows k = 4g+r, column p = j
+        const int p = p0 + 16 * t + j;
+        if (p < N) {
+            float* dst = dfeat + (size_t)p * 16 + 4 * g;
+            if (qsplit == 1) {
+                *reinterpret_cast<float4*>(dst) = make_float4(accF[t][0], accF[t][1], accF[t][2], accF[t][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) atomicAdd(&dst[r], accF[t][r]);
+            }
+        }
+    }
+}
+
+// partial[(chunk * nq + q) * 337 + ...] in the packed column order w1 (16x19) | w2 (16) | b1 (16) | b2
+template <bool USE_GEO>
+__global__ __launch_bounds__(256, 2) void k_mask_head_bwd_param(const float* __restrict__ feat, const float* __restrict__ coords,
+                                                                const float* __restrict__ geo, const float* __restrict__ qxyz,
+                                                                const float* __restrict__ mx, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                const float* __restrict__ gout, int ldp, int N, int nq,
+                                                                int chunks, float* __restrict__ partial) {
+    const int ld_w1 = ldp ? ldp : 16 * 19, ld_v = ldp ? ldp : 16;
+    const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int qgroups = (nq + MHB_Q - 1) / MHB_Q;
+    const int qg = wave % qgroups, chunk = wave / qgroups;
+    if (chunk >= chunks) return;
+    const int ntiles = (N + 15) >> 4;
+    const int per = (ntiles + chunks - 1) / chunks;
+    const int t0 = chunk * per, t1 = min(ntiles, t0 + per);
+    float wf[MHB_Q][4], w5[MHB_Q], w2j[MHB_Q], qcA[MHB_Q], qcB[MHB_Q], mq[MHB_Q];
+    f32x4 accW[MHB_Q], accWc[MHB_Q];
+    float pw2[MHB_Q], pb2[MHB_Q];
+#pragma unroll
+    for (int u = 0; u < MHB_Q; u++) {
+        const int q = min(qg * MHB_Q + u, nq - 1);
+        const float* W = w1 + (size_t)q * ld_w1;
+#pragma unroll
+        for (int s = 0; s < 4; s++) wf[u][s] = W[j * 19 + 3 + 4 * g + s];
+        w5[u] = g < 3 ? W[j * 19 + g] : b1[(size_t)q * ld_v + j];
+        w2j[u] = w2[(size_t)q * ld_v + j];
+        qcA[u] = g < 3 ? qxyz[q * 3 + g] : 0.f;
+        qcB[u] = j < 3 ? qxyz[q * 3 + j] : 0.f;
+        mq[u] = USE_GEO ? mx[q] : 0.f;
+        accW[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accWc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pw2[u] = 0.f;
+        pb2[u] = 0.f;
+    }
+    for (int tile = t0; tile < t1; tile++) {
+        const int pt = tile * 16;
+        const int pa = min(pt + j, N - 1);
+        const float4 fA = *reinterpret_cast<const float4*>(feat + (size_t)pa * 16 + 4 * g);  // point j, features 4g..
+        const float pcA = coords[(size_t)pa * 3 + min(g, 2)];
+        float xT[4], pcB[4];  // feature j / coordinate j of point 4g+s
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int pb = min(pt + 4 * g + s, N - 1);
+            xT[s] = feat[(size_t)pb * 16 + j];
+            pcB[s] = coords[(size_t)pb * 3 + min(j, 2)];
+        }
+#pragma unroll
+        for (int u = 0; u < MHB_Q; u++) {
+            const int q = min(qg * MHB_Q + u, nq - 1);
+            const float gdA = USE_GEO ? geo[(size_t)q * N + pa] : 0.f;
+            float goB[4], gdB[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const int pb = pt + 4 * g + s;
+                goB[s] = pb < N ? gout[(size_t)q * N + pb] : 0.f;
+                gdB[s] = USE_GEO ? geo[(size_t)q * N + min(pb, N - 1)] : 0.f;
+            }
+            float rel = qcA[u] - pcA;
+            if (USE_GEO) rel = rel + (gdA < 0.f ? mq[u] : 0.f) * (rel > 0.f ? 1.f : (rel < 0.f ? -1.f : 0.f));
+            if (g == 3) rel = 1.0f;
+            f32x4 accT = {0.f, 0.f, 0.f, 0.f};  // h_pre^T[p = 4g+r][c = j]
+            accT = __builtin_amdgcn_mfma_f32_16x16x4f32(rel, w5[u], accT, 0, 0, 0);
+            accT = __builtin_amdgcn_mfma_f32_16x16x4f32(fA.x, wf[u][0], accT, 0, 0, 0);
+            accT = __builtin_amdgcn_mfma_f32_16x16x4f32(fA.y, wf[u][1], accT, 0, 0, 0);
+            accT = __builtin_amdgcn_mfma_f32_16x16x4f32(fA.z, wf[u][2], accT, 0, 0, 0);
+            accT = __builtin_amdgcn_mfma_f32_16x16x4f32(fA.w, wf[u][3], accT, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float hT = fmaxf(accT[s], 0.f);
+                pw2[u] = fmaf(goB[s], hT, pw2[u]);
+                pb2[u] += goB[s];
+                const float dhT = accT[s] > 0.f ? goB[s] * w2j[u] : 0.f;
+                // feature block: dW1f^T[k][c] += X[k][p = 4kq+s] dh^T[p][c]
+                accW[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xT[s], dhT, accW[u], 0, 0, 0);
+                // coordinate / bias block: rows m = 0..2 relative coordinate, 3 the bias, rest zero
+                float relB = 0.f;
+                if (j < 3) {
+                    relB = qcB[u] - pcB[s];
+                    if (USE_GEO) relB = relB + (gdB[s] < 0.f ? mq[u] : 0.f) * (relB > 0.f ? 1.f : (relB < 0.f ? -1.f : 0.f));
+                } else if (j == 3) {
+                    relB = 1.0f;
+                }
+                accWc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(relB, dhT, accWc[u], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < MHB_Q; u++) {
+        const int q = qg * MHB_Q + u;
+        if (q >= nq) continue;
+        float* P = partial + ((size_t)chunk * nq + q) * 337;
+        // rows 4g+r of the accumulators, column c = j
+#pragma unroll
+        for (int r = 0; r < 4; r++) P[j * 19 + 3 + 4 * g + r] = accW[u][r];
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) P[j * 19 + r] = accWc[u][r];
+            P[320 + j] = accWc[u][3];
+        }
+        float t2 = pw2[u] + mh_xor32(pw2[u], lane);
+        t2 = t2 + mh_xor16(t2, lane);
+        if (g == 0) P[304 + j] = t2;
+        float t3 = pb2[u] + mh_xor32(pb2[u], lane);
+        t3 = t3 + mh_xor16(t3, lane);
+        if (lane == 0) P[336] = t3;
+    }
+}
+
+// dparams[q, col] (packed layout, row stride ldp >= 337) = sum over chunks of partial[chunk, q, col]
+__global__ void k_mask_head_bwd_reduce(const float* __restrict__ partial, int chunks, int nq, int ldp,
+                                       float* __restrict__ dparams) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq * 337) return;
+    const int q = t / 337, c = t - q * 337;
+    float s = 0.f;
+    for (int k = 0; k < chunks; k++) s += partial[((size_t)k * nq + q) * 337 + c];
+    dparams[(size_t)q * ldp + c] = s;
+}
+
+extern "C" size_t gf_mask_head_bwd_scratch_floats(int N, int nq) {
+    int chunks = 0;
+    (void)N;
+    chunks = 64;
+    return (size_t)chunks * (size_t)(nq > 0 ? nq : 0) * 337;
+}
+
+// dparams fp32 [nq, ldp] in the packed column order (w1 | w2 | b1 | b2, ldp >= 337) is OVERWRITTEN; dfeat fp32 [N,16]
+// must be zero on entry when the queries are split (always pass it zeroed); scratch: gf_mask_head_bwd_scratch_floats.
+extern "C" int gf_mask_head_bwd(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                                const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                                const float* gout, int ldp, int N, int nq, int C, float* dparams, float* dfeat,
+                                float* scratch, void* stream) {
+    GF_CHECK_ARG(ldp >= 337, "gf_mask_head_bwd: packed parameters expected (row stride >= 337), got %d", ldp);
+    GF_CHECK_ARG(C == 16, "gf_mask_head_bwd: only the 16-channel mask head (m=16) is implemented, got C=%d", C);
+    GF_CHECK_ARG(N >= 0 && nq >= 0, "gf_mask_head_bwd: bad sizes");
+    GF_CHECK_ARG((geo == nullptr) == (sqrt_max_geo == nullptr), "gf_mask_head_bwd: geo and sqrt_max_geo come together");
+    GF_CHECK_ARG(dparams && dfeat && scratch, "gf_mask_head_bwd: null output");
+    if (N == 0 || nq == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblocks = (N + 63) / 64;
+    // feature gradient: ~2 waves per SIMD; split the queries only when the points alone do not give them
+    int qsplit = (2 * 256 * 4 + nblocks - 1) / nblocks;
+    if (qsplit > nq) qsplit = nq;
+    if (qsplit > 16) qsplit = 16;
+    if (qsplit < 1) qsplit = 1;
+    {
+        const long long waves = (long long)nblocks * qsplit;
+        dim3 grid((unsigned)((waves + 3) / 4));
+        if (geo)
+            hipLaunchKernelGGL((k_mask_head_bwd_feat<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo,
+                               w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
+        else
+            hipLaunchKernelGGL((k_mask_head_bwd_feat<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo,
+                               w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
+    }
+    // parameter gradients: (query group, point chunk) per wave
+    const int qgroups = (nq + MHB_Q - 1) / MHB_Q;
+    const int ntiles = (N + 15) / 16;
+    int chunks = (2 * 256 * 4 + qgroups - 1) / qgroups;
+    if (chunks > 64) chunks = 64;
+    if (chunks > ntiles) chunks = ntiles;
+    if (chunks < 1) chunks = 1;
+    {
+        const long long waves = (long long)qgroups * chunks;
+        dim3 grid((unsigned)((waves + 3) / 4));
+        if (geo)
+            hipLaunchKernelGGL((k_mask_head_bwd_param<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo,
+                               w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
+        else
+            hipLaunchKernelGGL((k_mask_head_bwd_param<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz,
+                               sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
+    }
+    hipLaunchKernelGGL(k_mask_head_bwd_reduce, dim3(gf_div_up((long long)nq * 337, 256)), dim3(256), 0, st, scratch, chunks,
+                       nq, ldp, dparams);
+    GF_CHECK_LAUNCH("gf_mask_head_bwd");
+    return GF_OK;
+}

@@ -680,6 +680,18 @@ class GeoFormer(nn.Module):
                     # the controller's output read in place by the kernel (no split / reshape / contiguous copies)
                     ml = self._mask_head_packed(geo_dists[b], mask_features[s:e], controllers[b], n_queries,
                                                 locs_float_[s:e], fps_sampling_locs[b])
+                elif (mask_features.is_cuda and torch.is_grad_enabled() and self.output_dim == 16 and self.use_coords
+                      and os.environ.get("GF_FUSED_BWD", "1") != "0"):
+                    # training: the same fused kernel forward, and a fused recompute-based backward for the mask
+                    # features and the generated parameters (csrc/mask_head.hip k_mask_head_bwd) instead of PyTorch
+                    # autograd over [nq, N, 16] intermediates
+                    g = geo_dists[b].contiguous()
+                    mx = torch.max(g, dim=1)[0]
+                    mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+                    ml = pointops.mask_head_train(mask_features[s:e].reshape(e - s, self.output_dim).contiguous(),
+                                                  controllers[b].contiguous(), locs_float_[s:e].contiguous(), g,
+                                                  fps_sampling_locs[b].reshape(-1, 3).contiguous(), mx)
+                    ml = ml.reshape(1, n_queries, e - s)
                 else:
                     weights, biases = self.parse_dynamic_params(controllers[b], self.output_dim)
                     ml = self.mask_heads_forward(geo_dists[b], mask_features[s:e], weights, biases, n_queries,

@@ -264,6 +264,39 @@ def mask_head_packed(feat, coords, geo, qxyz, sqrt_max_geo, params):
     return out
 
 
+class _MaskHeadFn(torch.autograd.Function):
+    """Fused mask head with a fused, recompute-based backward (csrc/mask_head.hip): gradients for the mask features
+    and the generated per-query parameters; coordinates and geodesic distances are data."""
+
+    @staticmethod
+    def forward(ctx, feat, params, coords, geo, qxyz, sqrt_max_geo):
+        ctx.save_for_backward(feat, params, coords, geo, qxyz, sqrt_max_geo)
+        return mask_head_packed(feat, coords, geo, qxyz, sqrt_max_geo, params)
+
+    @staticmethod
+    def backward(ctx, gout):
+        feat, params, coords, geo, qxyz, mx = ctx.saved_tensors
+        N, C = feat.shape
+        nq, ld = params.shape
+        lib = _lib.load()
+        dparams = torch.empty_like(params)
+        dfeat = torch.zeros_like(feat)
+        scratch = torch.empty(lib.gf_mask_head_bwd_scratch_floats(N, nq), dtype=torch.float32, device=feat.device)
+        base = params.data_ptr()
+        o_w2, o_b1 = C * (C + 3), C * (C + 3) + C
+        check(lib.gf_mask_head_bwd(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(mx), base, base + 4 * o_b1,
+                                   base + 4 * o_w2, ptr(gout.contiguous()), ld, N, nq, C, ptr(dparams), ptr(dfeat),
+                                   ptr(scratch), stream_ptr()), "gf_mask_head_bwd")
+        return dfeat, dparams, None, None, None, None
+
+
+def mask_head_train(feat, params, coords, geo, qxyz, sqrt_max_geo):
+    """logits [nq,N] with autograd through feat [N,16] and params [nq,337] (fused forward AND backward)."""
+    for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (params, "params")):
+        _f32c(t, name)
+    return _MaskHeadFn.apply(feat, params, coords, geo, qxyz, sqrt_max_geo)
+
+
 class PointwiseChain:
     """Folded parameters of a Conv1d(k=1)/Linear + eval BatchNorm1d + ReLU stack for gf_pointwise_mlp."""
 

@@ -268,6 +268,16 @@ int gf_mask_head_packed(const float* feat, const float* coords, const float* geo
                         const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2,
                         int ldp, int N, int nq, int C, float* out, void* stream);
 
+/* Backward of the fused mask head (training): given gout = dL/dlogits fp32 [nq,N], writes the gradient of the packed
+ * per-query parameters (w1 | w2 | b1 | b2 columns, row stride ldp >= 337; the w1/b1/w2 pointers point into the packed
+ * parameter matrix like for gf_mask_head_packed) into dparams fp32 [nq,ldp] and of the mask features into dfeat fp32
+ * [N,16] (zero on entry).  The hidden activations are recomputed, nothing of the forward is kept; no gradient flows
+ * into coords / geo / qxyz (geoformer.py:296-310 treats them as data).  scratch: gf_mask_head_bwd_scratch_floats. */
+size_t gf_mask_head_bwd_scratch_floats(int N, int nq);
+int gf_mask_head_bwd(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                     const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* gout,
+                     int ldp, int N, int nq, int C, float* dparams, float* dfeat, float* scratch, void* stream);
+
 /* ===================================================================================
  * Per-point MLP chains of the eval forward, fused: mask_tower (geoformer.py:64-71), semantic head
  * (geoformer.py:54-62): Conv1d(k=1)/Linear + eval BatchNorm1d + ReLU stacks over the rows of x

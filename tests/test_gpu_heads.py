@@ -395,3 +395,46 @@ def test_softmax_dim1_forward_backward(hip, shape):
     ref.backward(g.double())
     assert (y.double() - ref).abs().max().item() < 1e-6
     assert (gx.double() - x.grad.double()).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("N,nq,use_geo", [(5037, 24, True), (700, 5, True), (3000, 16, False), (140_000, 3, True)])
+def test_mask_head_fused_backward(hip, N, nq, use_geo):
+    """gf_mask_head_bwd (recompute-based, MFMA) against float64 autograd of the reference formulation
+    (geoformer.py:286-324): gradients of the mask features and of the generated per-query parameters.
+    N = 140 000 takes the one-wave-per-block path without query splitting (plain stores of the feature gradient)."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(N * 7 + nq)
+    feat = rng.standard_normal((N, 16)).astype(np.float32)
+    coords = rng.uniform(-3, 3, (N, 3)).astype(np.float32)
+    qxyz = coords[rng.integers(0, N, nq)].copy()
+    geo = rng.uniform(0, 5, (nq, N)).astype(np.float32)
+    geo[rng.uniform(size=geo.shape) < 0.3] = -1.0
+    params = (rng.standard_normal((nq, 337)) * 0.3).astype(np.float32)
+    gout = (rng.standard_normal((nq, N)) * (rng.uniform(size=(nq, N)) < 0.5)).astype(np.float32)
+    mxv = None
+    if use_geo:
+        m = geo.max(1)
+        mxv = np.sqrt(np.where(m < 0, m.max(), m)).astype(np.float32)
+    # float64 reference with autograd
+    t64 = lambda a, g=False: torch.from_numpy(a.astype(np.float64)).requires_grad_(g)  # noqa: E731
+    F, P = t64(feat, True), t64(params, True)
+    w1 = P[:, :304].reshape(nq, 16, 19)
+    w2, b1, b2 = P[:, 304:320], P[:, 320:336], P[:, 336]
+    rel = t64(qxyz)[:, None, :] - t64(coords)[None]
+    if use_geo:
+        rel = torch.where(t64(geo)[..., None] < 0, rel + t64(mxv)[:, None, None] * torch.sign(rel), rel)
+    x = torch.cat([rel, F[None].expand(nq, N, 16)], 2)
+    h = torch.relu(torch.einsum("qck,qnk->qnc", w1, x) + b1[:, None, :])
+    ref = torch.einsum("qc,qnc->qn", w2, h) + b2[:, None]
+    (ref * t64(gout)).sum().backward()
+    d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    f, p = d(feat).requires_grad_(), d(params).requires_grad_()
+    out = pointops.mask_head_train(f, p, d(coords), d(geo) if use_geo else None, d(qxyz), d(mxv))
+    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 1e-4
+    (out * d(gout)).sum().backward()
+    gf, gp = f.grad.cpu().numpy(), p.grad.cpu().numpy()
+    rf, rp = F.grad.numpy(), P.grad.numpy()
+    assert np.abs(gf - rf).max() < 1e-4 * max(1.0, np.abs(rf).max())
+    # parameter gradients are sums over N points: relative to their magnitude
+    assert np.abs(gp - rp).max() < 2e-5 * max(1.0, np.abs(rp).max()), (np.abs(gp - rp).max(), np.abs(rp).max())
