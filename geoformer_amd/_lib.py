@@ -91,7 +91,9 @@ def _declare(lib):
         "gf_backbone_transformer": (I, [P, P, P, I, I, I, I, P, P, P, P]),
         "gf_decoder_wpack_floats": (c_size_t, []),
         "gf_decoder_pack_weights": (I, [P, P, P, P, P]),
-        "gf_decoder_cross_attn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+        "gf_decoder_cross_attn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P]),
+        "gf_decoder_cross_attn_bwd_scratch_floats": (c_size_t, [I, I, I]),
+        "gf_decoder_cross_attn_bwd": (I, [P] * 16 + [I, I, I, I] + [P] * 6),
         "gf_sec_op": (I, [I, P, P, I, I, P, P]),
         "gf_roipool_fp": (I, [P, P, I, I, P, P, P]),
         "gf_roipool_bp": (I, [P, P, I, I, P, P]),

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
     const float* __restrict__ geo_ctx, const float* __restrict__ max_geo, const float* __restrict__ qloc,
     const float* __restrict__ cloc, const float* __restrict__ lo, const float* __restrict__ hi,
     const float* __restrict__ gaussB, const float* __restrict__ Q1, const float* __restrict__ K1,
-    const float* __restrict__ Kv, const float4* __restrict__ Wpack, int nq, int nc, float* __restrict__ out) {
+    const float* __restrict__ Kv, const float4* __restrict__ Wpack, int nq, int nc, float* __restrict__ out,
+    float* __restrict__ stat_m, float* __restrict__ stat_l) {
     __shared__ float4 sW[3 * 16 * 64];       // [3][4 rb][4 kb][64 lanes]
     __shared__ float4 sQ1[16];               // Q1 row of this query: channel rb*16 + 4g + r at [rb*4 + g]
     __shared__ float4 sB[3][2][4];           // sB[axis][half][g] = gaussB[axis][half*16 + 4g .. +3]
@@ -210,6 +211,10 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
             A += sRed[2][u][tid];
         }
         out[((size_t)b * nq + qi) * DA_D + tid] = A / L;
+        if (stat_m) {  // soft-max statistics of the scaled logits per channel: the backward recomputes the rest
+            stat_m[((size_t)b * nq + qi) * DA_D + tid] = sRed[0][0][tid];
+            stat_l[((size_t)b * nq + qi) * DA_D + tid] = L;
+        }
     }
 }
 
@@ -234,13 +239,360 @@ extern "C" int gf_decoder_pack_weights(const float* W1, const float* W2, const f
 extern "C" int gf_decoder_cross_attn(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
                                      const float* lo, const float* hi, const float* gaussB, const float* Q1,
                                      const float* K1, const float* Kv, const float* Wpack, const float* b2, int B,
-                                     int nq, int nc, int d, float* out, void* stream) {
+                                     int nq, int nc, int d, float* out, float* stat_m, float* stat_l, void* stream) {
     GF_CHECK_ARG(d == DA_D, "gf_decoder_cross_attn: implemented for dec_dim = 64 (got %d)", d);
     GF_CHECK_ARG(B >= 0 && nq >= 0 && nc >= 1, "gf_decoder_cross_attn: bad sizes");
+    GF_CHECK_ARG((stat_m == nullptr) == (stat_l == nullptr), "gf_decoder_cross_attn: stat_m and stat_l come together");
     if (B == 0 || nq == 0) return GF_OK;
     (void)b2;  // a per-channel constant cancels in the per-channel soft-max over the contexts
     hipLaunchKernelGGL(k_decoder_cross_attn, dim3(nq, B), dim3(DA_WAVES * 64), 0, (hipStream_t)stream, geo_ctx, max_geo,
-                       qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out);
+                       qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out, stat_m,
+                       stat_l);
     GF_CHECK_LAUNCH("gf_decoder_cross_attn");
+    return GF_OK;
+}
+
+
+// ------------------------------------------------------------------------------------
+// Backward of the fused cross-attention (training).
+//
+//   with a = softmax_j(sim / 8) per channel and out_i = sum_j a_ij * v_ij:
+//       dv_ij   = a_ij * gout_i                      dsim_ij = a_ij * gout_i * (v_ij - out_i) / 8
+//       dH_ij   = (W2^T dsim_ij) * (H_ij > 0)        dQ1_i = sum_j dH_ij      dK1_j = -sum_i dH_ij      dKv_j = sum_i dv_ij
+//       dW1 += dH_ij r_ij^T      dW2 += dsim_ij H_ij^T      dWv += dv_ij r_ij^T      (pair parts; the hoisted parts
+//       W1 q, W1 k, Wv k are plain GEMMs whose gradients autograd adds)
+//   r_ij carries no gradient (geodesic distances are data, gauss_B is frozen), and b2 cancels in the soft-max.
+//
+// Nothing of size nq*nc*64 is stored by the forward (only the soft-max maximum and sum per (query, channel)): a
+// tile's embedding, H, sim and v are recomputed with the forward's MFMAs (orientation A: channels on the accumulator
+// rows, the 16 contexts of the tile on the columns).  The products that follow need two facts about
+// v_mfma_f32_16x16x4_f32 operands (the k index is only a summation label):
+//   * an orientation-A accumulator IS a valid A operand of a product whose output has the contexts on the ROWS
+//     (orientation B): dH_B = dsim_A . W2T   -- no data movement;
+//   * an orientation-B register block (context 4g+r on the rows, channel on lane&15) is a valid A AND B operand of
+//     the weight-gradient products, whose k index runs over the contexts: dW[co][ci] += X_B[co]^T . Y_B[ci].
+// R, H, dsim and dv change orientation through a 16 x 64 tile in LDS (four 16-byte writes, sixteen 4-byte reads per
+// lane and quantity).  A wave owns ONE context tile of one scene and walks a slice of the queries: the three 64 x 64
+// weight gradients (192 registers) and the tile's dK1 / dKv rows stay in registers for the whole walk; per query it
+// emits the column sums of dH (dQ1) into a [tiles, B*nq, 64] buffer.  One wave per SIMD (about 330 registers).
+// 448 MFMAs per (query, tile) against the forward's 192.
+// ------------------------------------------------------------------------------------
+#define DAB_TS 68  // row stride (floats) of the transposition tile: 16 contexts x 64 channels
+
+// W2T[cb][kb][lane][s] = W2[kb*16 + 4*(lane>>4) + s][cb*16 + (lane&15)]   (B operand of dH_B = dsim_A . W2)
+__global__ void k_decoder_pack_w2t(const float* __restrict__ W2, float* __restrict__ Wp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 16 * 64 * 4) return;
+    const int s = t & 3, lane = (t >> 2) & 63, kb = (t >> 8) & 3, cb = (t >> 10) & 3;
+    Wp[t] = W2[(kb * 16 + 4 * (lane >> 4) + s) * DA_D + cb * 16 + (lane & 15)];
+}
+
+__global__ __launch_bounds__(256, 1) void k_decoder_cross_attn_bwd(
+    const float* __restrict__ geo_ctx, const float* __restrict__ max_geo, const float* __restrict__ qloc,
+    const float* __restrict__ cloc, const float* __restrict__ lo, const float* __restrict__ hi,
+    const float* __restrict__ gaussB, const float* __restrict__ Q1, const float* __restrict__ K1,
+    const float* __restrict__ Kv, const float4* __restrict__ Wpack, const float4* __restrict__ W2Tpack,
+    const float* __restrict__ outv, const float* __restrict__ stat_m, const float* __restrict__ stat_l,
+    const float* __restrict__ gout, int B, int nq, int nc, int qsplit, float* __restrict__ dQ1p,
+    float* __restrict__ dK1, float* __restrict__ dKv, float* __restrict__ dWp) {
+    __shared__ float4 sW[3 * 16 * 64];
+    __shared__ float4 sW2T[16 * 64];
+    __shared__ float4 sB[3][2][4];
+    __shared__ __attribute__((aligned(16))) float sT[4][16 * DAB_TS];  // per wave: transposition tile
+    __shared__ __attribute__((aligned(16))) float sV[4][4][DA_D];      // per wave: Q1_i, m_i, gout_i / L_i, out_i
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    for (int t = tid; t < 3 * 16 * 64; t += 256) sW[t] = Wpack[t];
+    for (int t = tid; t < 16 * 64; t += 256) sW2T[t] = W2Tpack[t];
+    if (tid < 24) {
+        const int axis = tid >> 3, half = (tid >> 2) & 1, gg = tid & 3;
+        sB[axis][half][gg] = *reinterpret_cast<const float4*>(gaussB + axis * 32 + half * 16 + 4 * gg);
+    }
+    __syncthreads();
+    const int ntiles = (nc + 15) >> 4;
+    const int wave = blockIdx.x * 4 + w;
+    const int items = B * ntiles * qsplit;
+    if (wave >= items) return;  // (no barrier below this point)
+    const int part = wave % qsplit, bt = wave / qsplit;
+    const int tile = bt % ntiles, b = bt / ntiles;
+    const int qper = (nq + qsplit - 1) / qsplit;
+    const int q0 = part * qper, q1 = min(nq, q0 + qper);
+    float* T = sT[w];
+    float* V = &sV[w][0][0];
+
+    // ---- context side of the tile (constant over the queries) ----
+    const int ctx = tile * 16 + j;
+    const bool valid = ctx < nc;
+    const int cc = valid ? ctx : nc - 1;
+    const float* K1b = K1 + ((size_t)b * nc + cc) * DA_D;
+    const float* Kvb = Kv + ((size_t)b * nc + cc) * DA_D;
+    float4 k1[4], kv[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+        k1[rb] = *reinterpret_cast<const float4*>(K1b + rb * 16 + 4 * g);
+        kv[rb] = *reinterpret_cast<const float4*>(Kvb + rb * 16 + 4 * g);
+    }
+    const float cx = cloc[((size_t)b * nc + cc) * 3 + 0], cy = cloc[((size_t)b * nc + cc) * 3 + 1],
+                cz = cloc[((size_t)b * nc + cc) * 3 + 2];
+    const float lx = lo[b * 3 + 0], ly = lo[b * 3 + 1], lz = lo[b * 3 + 2];
+    const float sx = hi[b * 3 + 0] - lx, sy = hi[b * 3 + 1] - ly, sz = hi[b * 3 + 2] - lz;
+
+    f32x4 aW1[4][4], aW2[4][4], aWv[4][4];  // [out block][in block]: rows co = ob*16+4g+r, col ci = ib*16+j
+    f32x4 aK1[4], aKv[4];                   // orientation B: rows = contexts 4g+r, col = channel cb*16+j
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        aK1[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        aKv[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            aW1[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            aW2[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            aWv[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // orientation A -> B through the wave's LDS tile: X_A[rb] (rows ch = rb*16+4g+r, col context j) is written as
+    // T[context j][ch], read back as X_B[cb][r] = T[context 4g+r][ch = cb*16+j]
+    auto transpose = [&](const f32x4 (&XA)[4], f32x4 (&XB)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // earlier reads of T are done
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+            *reinterpret_cast<float4*>(&T[j * DAB_TS + rb * 16 + 4 * g]) = make_float4(XA[rb][0], XA[rb][1], XA[rb][2], XA[rb][3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) XB[cb][r] = T[(4 * g + r) * DAB_TS + cb * 16 + j];
+    };
+
+    for (int qi = q0; qi < q1; qi++) {
+        const size_t qrow = (size_t)b * nq + qi;
+        // per-query vectors -> LDS (lanes 0..15 each move a float4 of each of the four vectors)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 16) {
+            const float4 q1v = *reinterpret_cast<const float4*>(Q1 + qrow * DA_D + lane * 4);
+            const float4 mv = *reinterpret_cast<const float4*>(stat_m + qrow * DA_D + lane * 4);
+            const float4 lv = *reinterpret_cast<const float4*>(stat_l + qrow * DA_D + lane * 4);
+            const float4 gv = *reinterpret_cast<const float4*>(gout + qrow * DA_D + lane * 4);
+            const float4 ov = *reinterpret_cast<const float4*>(outv + qrow * DA_D + lane * 4);
+            *reinterpret_cast<float4*>(V + 0 * DA_D + lane * 4) = q1v;
+            *reinterpret_cast<float4*>(V + 1 * DA_D + lane * 4) = mv;
+            *reinterpret_cast<float4*>(V + 2 * DA_D + lane * 4) = make_float4(gv.x / lv.x, gv.y / lv.y, gv.z / lv.z, gv.w / lv.w);
+            *reinterpret_cast<float4*>(V + 3 * DA_D + lane * 4) = ov;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ---- relative embedding of the pair (query qi, context j): the forward's expressions ----
+        const float mg = max_geo[qrow];
+        const float gd = geo_ctx[qrow * nc + cc];
+        float g0 = gd, g1 = gd, g2 = gd;
+        if (gd < 0.f) {
+            g0 = mg + fabsf(qloc[qrow * 3 + 0] - cx);
+            g1 = mg + fabsf(qloc[qrow * 3 + 1] - cy);
+            g2 = mg + fabsf(qloc[qrow * 3 + 2] - cz);
+        }
+        const float t0 = ((g0 - lx) / sx) * 6.2831855f, t1 = ((g1 - ly) / sy) * 6.2831855f,
+                    t2 = ((g2 - lz) / sz) * 6.2831855f;
+        f32x4 RA[4];  // RA[kb][s]: channel kb*16 + 4g + s of context j
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const float4 b0 = sB[0][half][g], b1 = sB[1][half][g], b2v = sB[2][half][g];
+            const float p[4] = {fmaf(t2, b2v.x, fmaf(t1, b1.x, t0 * b0.x)), fmaf(t2, b2v.y, fmaf(t1, b1.y, t0 * b0.y)),
+                                fmaf(t2, b2v.z, fmaf(t1, b1.z, t0 * b0.z)), fmaf(t2, b2v.w, fmaf(t1, b1.w, t0 * b0.w))};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float sn, cs;
+                __sincosf(p[e], &sn, &cs);
+                RA[half][e] = sn;
+                RA[2 + half][e] = cs;
+            }
+        }
+        // ---- H_A = relu(W1 R + Q1_i - K1_j) ----
+        f32x4 HA[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                const float4 a = sW[((0 * 4 + rb) * 4 + kb) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, RA[kb][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, RA[kb][1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, RA[kb][2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, RA[kb][3], acc, 0, 0, 0);
+            }
+            const float4 q1v = *reinterpret_cast<const float4*>(V + 0 * DA_D + rb * 16 + 4 * g);
+            acc[0] = fmaxf(acc[0] + q1v.x - k1[rb].x, 0.f);
+            acc[1] = fmaxf(acc[1] + q1v.y - k1[rb].y, 0.f);
+            acc[2] = fmaxf(acc[2] + q1v.z - k1[rb].z, 0.f);
+            acc[3] = fmaxf(acc[3] + q1v.w - k1[rb].w, 0.f);
+            HA[rb] = acc;
+        }
+        // ---- sim_A, v_A -> dsim_A, dv_A ----
+        f32x4 dsA[4], dvA[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                const float4 a2 = sW[((1 * 4 + rb) * 4 + kb) * 64 + lane];
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, HA[kb][0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, HA[kb][1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, HA[kb][2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, HA[kb][3], s, 0, 0, 0);
+                const float4 av = sW[((2 * 4 + rb) * 4 + kb) * 64 + lane];
+                v = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, RA[kb][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, RA[kb][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, RA[kb][2], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, RA[kb][3], v, 0, 0, 0);
+            }
+            const float4 mv = *reinterpret_cast<const float4*>(V + 1 * DA_D + rb * 16 + 4 * g);
+            const float4 gl = *reinterpret_cast<const float4*>(V + 2 * DA_D + rb * 16 + 4 * g);
+            const float4 ov = *reinterpret_cast<const float4*>(V + 3 * DA_D + rb * 16 + 4 * g);
+            const float mm[4] = {mv.x, mv.y, mv.z, mv.w}, gg[4] = {gl.x, gl.y, gl.z, gl.w}, oo[4] = {ov.x, ov.y, ov.z, ov.w};
+            const float kk[4] = {kv[rb].x, kv[rb].y, kv[rb].z, kv[rb].w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float P = valid ? __expf(s[r] * 0.125f - mm[r]) * gg[r] : 0.f;  // a_ij * gout_i
+                dvA[rb][r] = P;
+                dsA[rb][r] = P * (v[r] + kk[r] - oo[r]) * 0.125f;
+            }
+        }
+        // ---- dH_B = (dsim_A . W2) masked by H > 0 : rows contexts 4g+r, col ci = cb*16+j ----
+        f32x4 HB[4], dHB[4];
+        transpose(HA, HB);
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; kb++) {
+                const float4 bw = sW2T[(cb * 4 + kb) * 64 + lane];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dsA[kb][0], bw.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dsA[kb][1], bw.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dsA[kb][2], bw.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dsA[kb][3], bw.w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = HB[cb][r] > 0.f ? acc[r] : 0.f;
+            dHB[cb] = acc;
+            aK1[cb][0] -= acc[0]; aK1[cb][1] -= acc[1]; aK1[cb][2] -= acc[2]; aK1[cb][3] -= acc[3];
+            // dQ1_i[ci] partial: sum over the tile's contexts (rows): registers, then the four lane groups
+            float cs = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            cs += __shfl_xor(cs, 16, 64);
+            cs += __shfl_xor(cs, 32, 64);
+            if (g == 0) dQ1p[((size_t)tile * B * nq + qrow) * DA_D + cb * 16 + j] = cs;
+        }
+        // ---- weight gradients: k index = context (lane group kq, step s <-> context 4kq+s) ----
+        f32x4 XB[4], RB[4];
+        transpose(RA, RB);
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+            for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    aW1[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(dHB[ob][s], RB[ib][s], aW1[ob][ib], 0, 0, 0);
+        transpose(dvA, XB);
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            aKv[cb][0] += XB[cb][0]; aKv[cb][1] += XB[cb][1]; aKv[cb][2] += XB[cb][2]; aKv[cb][3] += XB[cb][3];
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+            for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    aWv[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(XB[ob][s], RB[ib][s], aWv[ob][ib], 0, 0, 0);
+        transpose(dsA, XB);
+#pragma unroll
+        for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+            for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    aW2[ob][ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(XB[ob][s], HB[ib][s], aW2[ob][ib], 0, 0, 0);
+    }
+    // ---- the tile's dK1 / dKv rows (contexts 4g+r, channel cb*16+j) ----
+#pragma unroll
+    for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c2 = tile * 16 + 4 * g + r;
+            if (c2 < nc) {
+                float* d1 = dK1 + ((size_t)b * nc + c2) * DA_D + cb * 16 + j;
+                float* d2 = dKv + ((size_t)b * nc + c2) * DA_D + cb * 16 + j;
+                if (qsplit == 1) {
+                    *d1 = aK1[cb][r];
+                    *d2 = aKv[cb][r];
+                } else {
+                    atomicAdd(d1, aK1[cb][r]);
+                    atomicAdd(d2, aKv[cb][r]);
+                }
+            }
+        }
+    // ---- this wave's weight-gradient partials: dWp[wave][m][co][ci] ----
+    float* P = dWp + (size_t)wave * 3 * DA_D * DA_D;
+#pragma unroll
+    for (int ob = 0; ob < 4; ob++)
+#pragma unroll
+        for (int ib = 0; ib < 4; ib++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int co = ob * 16 + 4 * g + r, ci = ib * 16 + j;
+                P[0 * DA_D * DA_D + co * DA_D + ci] = aW1[ob][ib][r];
+                P[1 * DA_D * DA_D + co * DA_D + ci] = aW2[ob][ib][r];
+                P[2 * DA_D * DA_D + co * DA_D + ci] = aWv[ob][ib][r];
+            }
+}
+
+// out[i] = sum over `parts` of in[part * n + i]
+__global__ void k_sum_parts(const float* __restrict__ in, int parts, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; p++) s += in[(size_t)p * n + i];
+    out[i] = s;
+}
+
+static void dab_plan(int B, int nq, int nc, int* qsplit, int* waves) {
+    const int ntiles = (nc + 15) / 16;
+    int qs = (256 * 4 + B * ntiles - 1) / (B * ntiles);  // one wave per SIMD
+    if (qs > nq) qs = nq;
+    if (qs > 8) qs = 8;
+    if (qs < 1) qs = 1;
+    *qsplit = qs;
+    *waves = B * ntiles * qs;
+}
+
+extern "C" size_t gf_decoder_cross_attn_bwd_scratch_floats(int B, int nq, int nc) {
+    int qs, waves;
+    dab_plan(B, nq, nc, &qs, &waves);
+    const size_t ntiles = (size_t)(nc + 15) / 16;
+    return (size_t)waves * 3 * DA_D * DA_D + ntiles * (size_t)B * nq * DA_D + (size_t)16 * 64 * 4;
+}
+
+// dQ1 [B,nq,64], dK1 / dKv [B,nc,64] (zero on entry), dW [3,64,64] = pair parts of dW1, dW2, dWv (overwritten)
+extern "C" int gf_decoder_cross_attn_bwd(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
+                                         const float* lo, const float* hi, const float* gaussB, const float* Q1,
+                                         const float* K1, const float* Kv, const float* Wpack, const float* W2,
+                                         const float* out, const float* stat_m, const float* stat_l, const float* gout,
+                                         int B, int nq, int nc, int d, float* dQ1, float* dK1, float* dKv, float* dW,
+                                         float* scratch, void* stream) {
+    GF_CHECK_ARG(d == DA_D, "gf_decoder_cross_attn_bwd: implemented for dec_dim = 64 (got %d)", d);
+    GF_CHECK_ARG(B >= 0 && nq >= 0 && nc >= 1, "gf_decoder_cross_attn_bwd: bad sizes");
+    if (B == 0 || nq == 0) return GF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int qs, waves;
+    dab_plan(B, nq, nc, &qs, &waves);
+    const int ntiles = (nc + 15) / 16;
+    float* dWp = scratch;
+    float* dQ1p = dWp + (size_t)waves * 3 * DA_D * DA_D;
+    float* w2t = dQ1p + (size_t)ntiles * B * nq * DA_D;
+    hipLaunchKernelGGL(k_decoder_pack_w2t, dim3(16), dim3(256), 0, st, W2, w2t);
+    hipLaunchKernelGGL(k_decoder_cross_attn_bwd, dim3((waves + 3) / 4), dim3(256), 0, st, geo_ctx, max_geo, qloc, cloc, lo,
+                       hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack),
+                       reinterpret_cast<const float4*>(w2t), out, stat_m, stat_l, gout, B, nq, nc, qs, dQ1p, dK1, dKv,
+                       dWp);
+    const size_t nW = (size_t)3 * DA_D * DA_D, nQ = (size_t)B * nq * DA_D;
+    hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nW, 256)), dim3(256), 0, st, dWp, waves, nW, dW);
+    hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nQ, 256)), dim3(256), 0, st, dQ1p, ntiles, nQ, dQ1);
+    GF_CHECK_LAUNCH("gf_decoder_cross_attn_bwd");
     return GF_OK;
 }

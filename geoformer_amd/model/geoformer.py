@@ -533,8 +533,10 @@ class GeoFormer(nn.Module):
         pairs get max_geo(query) + |dxyz| per axis (geoformer.py:619-651)."""
         B = context_locs.shape[0]
         self._join_side_stream()  # the geodesic distances may still be in flight on the second stream
-        if context_locs.is_cuda and self.cfg.dec_dim == 64 and not torch.is_grad_enabled():
-            # inference: hand the fused cross-attention kernel the ingredients instead of the 134 MB tensor
+        if context_locs.is_cuda and self.cfg.dec_dim == 64 and (not torch.is_grad_enabled()
+                                                                 or os.environ.get("GF_FUSED_BWD", "1") != "0"):
+            # hand the fused cross-attention kernel the ingredients instead of the 134 MB tensor (training too: its
+            # backward recomputes the embedding, csrc/decoder_attn.hip)
             if B == 1 and pre_enc_inds.dtype == torch.int32:
                 g1, m1 = pointops.relpos_prepare(geo_dists[0].contiguous(), pre_enc_inds[0].contiguous())
                 geo, max_geo = g1.unsqueeze(0), m1.unsqueeze(0)

@@ -392,6 +392,15 @@ class TransformerDecoderLayer(nn.Module):
             self._wpack = pointops.decoder_pack_weights(w1.weight.detach().contiguous(), w2.weight.detach().contiguous(),
                                                         wv.weight.detach().contiguous())
             self._wpack_key = key
+        if torch.is_grad_enabled():
+            # training: the same kernel forward (keeping only the soft-max statistics) and a fused recompute-based
+            # backward for the hoisted projections and the pair weights (csrc/decoder_attn.hip)
+            Q1 = w1(tgt2.clone()).permute(1, 0, 2)  # (a copy: the layer's in-place dropout2 overwrites tgt2 later)
+            K1 = F.linear(memory, w1.weight).permute(1, 0, 2)
+            Kv = wv(memory).permute(1, 0, 2)
+            out = pointops.decoder_cross_attn_train(rp.geo_ctx, rp.max_geo, rp.query_locs, rp.context_locs, rp.lo, rp.hi,
+                                                    rp.gauss_B, Q1, K1, Kv, w1.weight, w2.weight, wv.weight)
+            return out.permute(1, 0, 2)
         Q1 = w1(tgt2).permute(1, 0, 2).contiguous()  # B x nq x d
         K1 = F.linear(memory, w1.weight).permute(1, 0, 2).contiguous()  # B x nc x d
         Kv = wv(memory).permute(1, 0, 2).contiguous()
@@ -486,7 +495,8 @@ class TransformerDecoder(nn.Module):
         if (isinstance(relative_pos, RelPosSpec) and tgt_mask is None and tgt_key_padding_mask is None
                 and query_pos is not None and self.norm is not None and self.return_intermediate
                 and tgt.shape[-1] == 64 and self.layers[0].nhead == 4 and self.layers[0].linear1.out_features % 16 == 0
-                and self.layers[0].linear1.out_features <= 256 and not self.layers[0].self_attn.training):
+                and self.layers[0].linear1.out_features <= 256 and not self.layers[0].self_attn.training
+                and not torch.is_grad_enabled()):
             return self._forward_fused(tgt, memory, query_pos, relative_pos)
         output, inter = tgt, []
         for layer in self.layers:

@@ -558,8 +558,56 @@ def decoder_cross_attn(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
     out = torch.empty((B, nq, d), dtype=torch.float32, device=Q1.device)
     check(_lib.load().gf_decoder_cross_attn(ptr(geo_ctx), ptr(max_geo), ptr(qloc), ptr(cloc), ptr(lo), ptr(hi),
                                             ptr(gaussB), ptr(Q1), ptr(K1), ptr(Kv), ptr(wpack), ptr(b2), B, nq, nc, d,
-                                            ptr(out), stream_ptr()), "gf_decoder_cross_attn")
+                                            ptr(out), None, None, stream_ptr()), "gf_decoder_cross_attn")
     return out
+
+
+class _CrossAttnFn(torch.autograd.Function):
+    """Fused vector cross-attention with a fused, recompute-based backward (csrc/decoder_attn.hip).  Differentiable
+    inputs: Q1 [B,nq,64], K1, Kv [B,nc,64] (the hoisted projections) and the pair weights W1, W2, Wv [64,64]; the
+    geodesic embedding inputs are data."""
+
+    @staticmethod
+    def forward(ctx, geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, W1, W2, Wv):
+        lib = _lib.load()
+        B, nq, nc = geo_ctx.shape
+        d = Q1.shape[-1]
+        wpack = decoder_pack_weights(W1.detach().contiguous(), W2.detach().contiguous(), Wv.detach().contiguous())
+        out = torch.empty((B, nq, d), dtype=torch.float32, device=Q1.device)
+        sm, sl = torch.empty_like(out), torch.empty_like(out)
+        Q1, K1, Kv = Q1.contiguous(), K1.contiguous(), Kv.contiguous()
+        check(lib.gf_decoder_cross_attn(ptr(geo_ctx), ptr(max_geo), ptr(qloc), ptr(cloc), ptr(lo), ptr(hi), ptr(gaussB),
+                                        ptr(Q1), ptr(K1), ptr(Kv), ptr(wpack), None, B, nq, nc, d, ptr(out), ptr(sm),
+                                        ptr(sl), stream_ptr()), "gf_decoder_cross_attn")
+        ctx.save_for_backward(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, wpack, W2.detach().contiguous(),
+                              out, sm, sl)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, wpack, W2, out, sm, sl = ctx.saved_tensors
+        B, nq, nc = geo_ctx.shape
+        d = Q1.shape[-1]
+        dQ1 = torch.empty_like(Q1)
+        dK1, dKv = torch.zeros_like(K1), torch.zeros_like(Kv)
+        dW = torch.empty((3, d, d), dtype=torch.float32, device=Q1.device)
+        scratch = torch.empty(lib.gf_decoder_cross_attn_bwd_scratch_floats(B, nq, nc), dtype=torch.float32,
+                              device=Q1.device)
+        check(lib.gf_decoder_cross_attn_bwd(ptr(geo_ctx), ptr(max_geo), ptr(qloc), ptr(cloc), ptr(lo), ptr(hi),
+                                            ptr(gaussB), ptr(Q1), ptr(K1), ptr(Kv), ptr(wpack), ptr(W2), ptr(out),
+                                            ptr(sm), ptr(sl), ptr(gout.contiguous()), B, nq, nc, d, ptr(dQ1), ptr(dK1),
+                                            ptr(dKv), ptr(dW), ptr(scratch), stream_ptr()),
+              "gf_decoder_cross_attn_bwd")
+        return None, None, None, None, None, None, None, dQ1, dK1, dKv, dW[0], dW[1], dW[2]
+
+
+def decoder_cross_attn_train(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, W1, W2, Wv):
+    """[B,nq,64] with autograd through Q1, K1, Kv, W1, W2, Wv (fused forward AND backward)."""
+    for t, name in ((geo_ctx, "geo_ctx"), (max_geo, "max_geo"), (qloc, "qloc"), (cloc, "cloc"), (lo, "lo"), (hi, "hi"),
+                    (gaussB, "gaussB")):
+        _f32c(t, name)
+    return _CrossAttnFn.apply(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, W1, W2, Wv)
 
 
 class _SoftmaxDim1(torch.autograd.Function):

@@ -440,7 +440,20 @@ int gf_decoder_pack_weights(const float* W1, const float* W2, const float* Wv, f
 int gf_decoder_cross_attn(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
                           const float* lo, const float* hi, const float* gaussB, const float* Q1, const float* K1,
                           const float* Kv, const float* Wpack, const float* b2, int B, int nq, int nc, int d, float* out,
-                          void* stream);
+                          float* stat_m, float* stat_l, void* stream);
+
+/* Backward of gf_decoder_cross_attn (training).  stat_m / stat_l fp32 [B,nq,64]: per (query, channel) maximum and
+ * sum of the scaled soft-max logits, written by the forward when the two pointers are given (NULL otherwise); out =
+ * the forward's output, gout = dL/dout fp32 [B,nq,64]; W2 fp32 [64,64] the second pair-MLP weight (unpacked).
+ * Outputs: dQ1 fp32 [B,nq,64] (overwritten), dK1 / dKv fp32 [B,nc,64] (zero on entry), dW fp32 [3,64,64] = the PAIR
+ * parts of dW1, dW2, dWv (overwritten; the hoisted parts W1 q, W1 k, Wv k are the caller's GEMMs).  Everything of size
+ * nq*nc*64 is recomputed.  scratch: gf_decoder_cross_attn_bwd_scratch_floats(B,nq,nc) floats. */
+size_t gf_decoder_cross_attn_bwd_scratch_floats(int B, int nq, int nc);
+int gf_decoder_cross_attn_bwd(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
+                              const float* lo, const float* hi, const float* gaussB, const float* Q1, const float* K1,
+                              const float* Kv, const float* Wpack, const float* W2, const float* out, const float* stat_m,
+                              const float* stat_l, const float* gout, int B, int nq, int nc, int d, float* dQ1, float* dK1,
+                              float* dKv, float* dW, float* scratch, void* stream);
 
 /* ===================================================================================
  * Natives GeoFormer inherits but never executes -- binding completeness

@@ -438,3 +438,50 @@ def test_mask_head_fused_backward(hip, N, nq, use_geo):
     assert np.abs(gf - rf).max() < 1e-4 * max(1.0, np.abs(rf).max())
     # parameter gradients are sums over N points: relative to their magnitude
     assert np.abs(gp - rp).max() < 2e-5 * max(1.0, np.abs(rp).max()), (np.abs(gp - rp).max(), np.abs(rp).max())
+
+
+@pytest.mark.parametrize("B,nq,nc", [(2, 24, 100), (1, 7, 16), (3, 40, 333)])
+def test_decoder_cross_attention_fused_backward(hip, B, nq, nc):
+    """gf_decoder_cross_attn_bwd (recompute-based, MFMA) against float64 autograd of the formulation of
+    transformer_detr.py:443-454 over the hoisted projections: gradients of Q1, K1, Kv and of the pair parts of W1, W2,
+    Wv.  Unreachable pairs (geo < 0) and a context count that is not a multiple of the 16-wide tile are included."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(B * 100 + nq + nc)
+    d = 64
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    geo = f32(rng.uniform(0, 6, (B, nq, nc)))
+    geo[rng.uniform(size=geo.shape) < 0.25] = -1.0
+    max_geo = f32(np.where(geo.max(2) < 0, geo.max(), geo.max(2)))
+    qloc, cloc = f32(rng.uniform(-3, 3, (B, nq, 3))), f32(rng.uniform(-3, 3, (B, nc, 3)))
+    lo, hi = f32(rng.uniform(-3.5, -3, (B, 3))), f32(rng.uniform(6, 7, (B, 3)))
+    gaussB = f32(rng.standard_normal((3, 32)))
+    Q1, K1, Kv = (f32(rng.standard_normal(s) * 0.7) for s in ((B, nq, d), (B, nc, d), (B, nc, d)))
+    W1, W2, Wv = (f32(rng.standard_normal((d, d)) / 8) for _ in range(3))
+    gout = f32(rng.standard_normal((B, nq, d)))
+    # ---- float64 reference ----
+    t = lambda a, g=False: torch.from_numpy(a.astype(np.float64)).requires_grad_(g)  # noqa: E731
+    tQ1, tK1, tKv, tW1, tW2, tWv = (t(a, True) for a in (Q1, K1, Kv, W1, W2, Wv))
+    g3 = t(geo)[..., None].repeat(1, 1, 1, 3)
+    rel = (t(qloc)[:, :, None, :] - t(cloc)[:, None, :, :]).abs()
+    g3 = torch.where(g3 < 0, t(max_geo)[:, :, None, None] + rel, g3)
+    nrm = (g3 - t(lo)[:, None, None, :]) / (t(hi) - t(lo))[:, None, None, :]
+    proj = (nrm * 6.2831855) @ t(gaussB)  # B nq nc 32
+    R = torch.cat([proj.sin(), proj.cos()], -1)  # B nq nc 64
+    H = torch.relu(R @ tW1.t() + tQ1[:, :, None, :] - tK1[:, None, :, :])
+    sim = H @ tW2.t()
+    a = torch.softmax(sim / 8.0, dim=2)
+    v = R @ tWv.t() + tKv[:, None, :, :]
+    ref = (a * v).sum(2)
+    (ref * t(gout)).sum().backward()
+    # ---- fused ----
+    dv = lambda x, g=False: torch.from_numpy(x).cuda().requires_grad_(g)  # noqa: E731
+    gQ1, gK1, gKv, gW1, gW2, gWv = (dv(x, True) for x in (Q1, K1, Kv, W1, W2, Wv))
+    out = pointops.decoder_cross_attn_train(dv(geo), dv(max_geo), dv(qloc), dv(cloc), dv(lo), dv(hi), dv(gaussB), gQ1, gK1,
+                                            gKv, gW1, gW2, gWv)
+    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() < 1e-4
+    (out * dv(gout)).sum().backward()
+    for name, got, want in (("dQ1", gQ1, tQ1), ("dK1", gK1, tK1), ("dKv", gKv, tKv), ("dW1", gW1, tW1), ("dW2", gW2, tW2),
+                            ("dWv", gWv, tWv)):
+        g_, w_ = got.grad.cpu().numpy(), want.grad.numpy()
+        assert np.abs(g_ - w_).max() < 1e-4 * max(1.0, np.abs(w_).max()), (name, np.abs(g_ - w_).max(), np.abs(w_).max())
