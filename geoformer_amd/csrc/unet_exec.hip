@@ -1,0 +1,350 @@
+// The sparse-voxel U-Net of the eval forward as ONE native call (include/geoformer_hip.h: gf_unet_fwd).
+//
+// Reference structure: GeoFormer.input_conv -> UBlock x7 -> output_layer (model/geoformer/geoformer.py:42-53,398-401;
+// UBlock / ResidualBlock: model/geoformer/geoformer_modules.py:10-35,52-129), all BatchNorm in eval mode.
+//
+// Why it exists: the 13 rulebooks and 71 convolutions are ~150 launches of 5-25 us; issued from Python (one ctypes
+// crossing + a torch allocation per block) the host needs 1.7 ms for them while the device needs ~1.3 ms -- the
+// stretch was bound by the host's launch rate.  Here the same entry points (gf_index_build, gf_rules_subm3,
+// gf_rules_down2_chain, gf_conv_fwd, gf_resblock_fwd, gf_backbone_transformer -- so results are identical to the
+// per-module path) are issued from C++ out of one caller-owned workspace, with
+//   * the down-sampling rulebook chain and the submanifold tables of levels >= 2 on a SIDE stream beside the
+//     level-1 convolutions (small latency-bound kernels next to the only HBM-heavy ones),
+//   * one host wait for the chain's voxel counts (an event behind an async copy into pinned memory), taken after
+//     the level-1 work has been queued,
+//   * the output BatchNorm + ReLU in the epilogue of the last convolution.
+#include <mutex>
+
+#include "common.h"
+
+namespace {
+
+__global__ void k_pad_channels(const float* __restrict__ in, int M, int cin, int cout, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * cout) return;
+    const int r = i / cout, c = i - r * cout;
+    out[i] = c < cin ? in[(size_t)r * cin + c] : 0.f;
+}
+
+// out[r] = (a[r], b[r]): the skip concatenation of UBlock.forward (geoformer_modules.py:116), 16-byte pieces
+__global__ void k_concat2(const float4* __restrict__ a, const float4* __restrict__ b, int M, int c4, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * 2 * c4) return;
+    const int r = i / (2 * c4), c = i - r * 2 * c4;
+    out[i] = c < c4 ? a[(size_t)r * c4 + c] : b[(size_t)r * c4 + (c - c4)];
+}
+
+// scene_offsets[b] = first row of batch b (rows in batch-major order: every level below the first)
+__global__ void k_scene_offsets(const int32_t* __restrict__ coords, int M, int B, int32_t* __restrict__ offs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    const int prev = i > 0 ? coords[(size_t)(i - 1) * 4] : -1;
+    const int cur = i < M ? coords[(size_t)i * 4] : B;
+    for (int b = prev + 1; b <= cur && b <= B; b++) offs[b] = i;
+}
+
+struct Bump {
+    unsigned char* base;
+    size_t off = 0, cap;
+    Bump(void* p, size_t c) : base((unsigned char*)p), cap(c) {}
+    template <class T>
+    T* take(size_t n) {
+        const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+inline int r16(long long n) { return (int)((n < 16 ? 16 : n + 15) / 16 * 16); }
+
+struct LevelTables {  // submanifold table of one level
+    int32_t* nbr = nullptr;
+    uint32_t* gmask = nullptr;
+    int32_t* steps = nullptr;
+    int ld = 0;
+};
+
+// events of the side-stream fork/join: two per host thread, created once
+struct EvPair {
+    hipEvent_t fork = nullptr, chain = nullptr, rules = nullptr;
+};
+thread_local EvPair t_ev;
+
+constexpr int kStepsMinRows = 6000 * 16;  // gf_conv_fwd takes the counted-loop kernel from 6000 groups up
+
+struct LevelBufs {  // feature buffers of one level, [rows, C] each (cat: [rows, 2C])
+    float *x, *tmp, *idn, *o0, *o1, *o2, *up, *tr, *cat;
+    void* tr_scratch;
+    int32_t* tr_offs;
+};
+void carve_level(Bump& a, LevelBufs& b, size_t rows, size_t C, bool transformer, int B) {
+    b.x = a.take<float>(rows * C);
+    b.tmp = a.take<float>(rows * C);
+    b.idn = a.take<float>(rows * C);
+    b.o0 = a.take<float>(rows * C);
+    b.o1 = a.take<float>(rows * C);
+    b.o2 = a.take<float>(rows * C);
+    b.up = a.take<float>(rows * C);
+    b.tr = a.take<float>(rows * C);
+    b.cat = a.take<float>(rows * 2 * C);
+    b.tr_scratch = nullptr;
+    b.tr_offs = nullptr;
+    if (transformer) {
+        b.tr_scratch = a.take<unsigned char>(gf_backbone_transformer_scratch_bytes((int)rows));
+        b.tr_offs = a.take<int32_t>(B + 1);
+    }
+}
+
+}  // namespace
+
+// int32/byte size of everything gf_unet_fwd carves out of its workspace (capacity bounds, no device access)
+static size_t unet_layout(const GfUnetParams* P, int M0, int B, int X, int Y, int Z, long long* offs, int* caps,
+                          int* shapes, int* nl_out, long long* chain_elems) {
+    int nl = 0;
+    long long total = 0;
+    gf_rules_down2_chain_plan(M0, B, X, Y, Z, P->nlevels - 1, offs, caps, shapes, &total, &nl);
+    *nl_out = nl;
+    *chain_elems = total;
+    Bump a(nullptr, 0);
+    const size_t words0 = gf_index_words(B, X, Y, Z);
+    a.take<uint32_t>(words0);
+    a.take<int32_t>(words0);
+    a.take<int32_t>(M0 > 0 ? M0 : 1);
+    a.take<unsigned char>(gf_index_scratch_bytes(words0));
+    const int ld0 = r16(M0);
+    a.take<int32_t>((size_t)27 * ld0);
+    a.take<uint32_t>(ld0 / 16);
+    a.take<int32_t>(gf_rules_steps_words(ld0));
+    a.take<int32_t>((size_t)total);
+    a.take<int32_t>(GF_UNET_MAX_LEVELS + 1);
+    for (int l = 1; l <= nl; l++) {
+        a.take<int32_t>((size_t)27 * caps[l]);
+        a.take<uint32_t>(caps[l] / 16);
+    }
+    // features: per level at its capacity (the call itself carves them at the real row counts, which are smaller)
+    for (int l = 0; l <= nl; l++) {
+        LevelBufs b;
+        carve_level(a, b, l ? (size_t)caps[l] : (size_t)ld0, (size_t)P->level[l].C, P->level[l].tr_layers > 0, B);
+    }
+    a.take<float>((size_t)ld0 * 16);  // zero-padded input rows
+    return a.off;
+}
+
+extern "C" size_t gf_unet_ws_bytes(const GfUnetParams* P, int M0, int B, int X, int Y, int Z) {
+    if (!P || P->nlevels < 1 || P->nlevels > GF_UNET_MAX_LEVELS || M0 < 0 || B < 1) return 0;
+    long long offs[GF_UNET_MAX_LEVELS * 10];
+    int caps[GF_UNET_MAX_LEVELS + 1], shapes[3 * (GF_UNET_MAX_LEVELS + 1)], nl = 0;
+    long long chain = 0;
+    return unet_layout(P, M0, B, X, Y, Z, offs, caps, shapes, &nl, &chain);
+}
+
+extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y,
+                           int Z, void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream,
+                           void* side_stream) {
+    GF_CHECK_ARG(P && feats && coords && ws && host_counts && out, "gf_unet_fwd: null argument");
+    GF_CHECK_ARG(P->nlevels >= 1 && P->nlevels <= GF_UNET_MAX_LEVELS, "gf_unet_fwd: %d levels (1..%d)", P->nlevels,
+                 GF_UNET_MAX_LEVELS);
+    GF_CHECK_ARG(P->cin >= 1 && P->cin <= 16 && P->level[0].C == 16,
+                 "gf_unet_fwd: input conv implemented for <= 16 input channels and 16 output channels (got %d -> %d)",
+                 P->cin, P->level[0].C);
+    GF_CHECK_ARG(M0 >= 0 && B >= 1, "gf_unet_fwd: bad sizes");
+    if (M0 == 0) return GF_OK;
+    for (int l = 0; l < P->nlevels; l++)
+        GF_CHECK_ARG(P->level[l].C > 0 && P->level[l].C % 16 == 0, "gf_unet_fwd: level %d width %d (multiples of 16)", l,
+                     P->level[l].C);
+    long long offs[GF_UNET_MAX_LEVELS * 10];
+    int caps[GF_UNET_MAX_LEVELS + 1], shapes[3 * (GF_UNET_MAX_LEVELS + 1)], nl = 0;
+    long long chain_elems = 0;
+    const size_t need = unet_layout(P, M0, B, X, Y, Z, offs, caps, shapes, &nl, &chain_elems);
+    GF_CHECK_ARG(nl == P->nlevels - 1, "gf_unet_fwd: the %dx%dx%d grid supports %d of the %d down-samplings", X, Y, Z, nl,
+                 P->nlevels - 1);
+    GF_CHECK_ARG(ws_bytes >= need, "gf_unet_fwd: workspace of %zu bytes, need %zu (gf_unet_ws_bytes)", ws_bytes, need);
+    GF_CHECK_ARG(((uintptr_t)ws % 256) == 0, "gf_unet_fwd: workspace must be 256-byte aligned");
+
+    hipStream_t st = (hipStream_t)stream;
+    hipStream_t ss = side_stream ? (hipStream_t)side_stream : st;
+    const bool forked = ss != st;
+    if (forked && !t_ev.fork) {
+        GF_TRY(hipEventCreateWithFlags(&t_ev.fork, hipEventDisableTiming));
+        GF_TRY(hipEventCreateWithFlags(&t_ev.rules, hipEventDisableTiming));
+    }
+    if (!t_ev.chain) GF_TRY(hipEventCreateWithFlags(&t_ev.chain, hipEventDisableTiming));
+
+    Bump a(ws, ws_bytes);
+    const size_t words0 = gf_index_words(B, X, Y, Z);
+    uint32_t* bitmap0 = a.take<uint32_t>(words0);
+    int32_t* prefix0 = a.take<int32_t>(words0);
+    int32_t* perm0 = a.take<int32_t>(M0);
+    void* iscratch = a.take<unsigned char>(gf_index_scratch_bytes(words0));
+    LevelTables T[GF_UNET_MAX_LEVELS];
+    const int ld0 = r16(M0);
+    T[0].ld = ld0;
+    T[0].nbr = a.take<int32_t>((size_t)27 * ld0);
+    T[0].gmask = a.take<uint32_t>(ld0 / 16);
+    {
+        int32_t* s = a.take<int32_t>(gf_rules_steps_words(ld0));
+        T[0].steps = ld0 >= kStepsMinRows ? s : nullptr;
+    }
+    int32_t* cws = a.take<int32_t>((size_t)chain_elems);
+    int32_t* d_counts = a.take<int32_t>(GF_UNET_MAX_LEVELS + 1);
+    for (int l = 1; l <= nl; l++) {
+        T[l].ld = caps[l];
+        T[l].nbr = a.take<int32_t>((size_t)27 * caps[l]);
+        T[l].gmask = a.take<uint32_t>(caps[l] / 16);
+    }
+
+    int rc;
+#define UN_TRY(call)                  \
+    do {                              \
+        rc = (call);                  \
+        if (rc != GF_OK) return rc;   \
+    } while (0)
+
+    // ---- side stream: the chain of down-sampling rulebooks, its counts on their way to the host ----
+    if (forked) {
+        GF_TRY(hipEventRecord(t_ev.fork, st));
+        GF_TRY(hipStreamWaitEvent(ss, t_ev.fork, 0));
+    }
+    if (nl > 0) {
+        UN_TRY(gf_rules_down2_chain(coords, M0, B, X, Y, Z, nl, cws, d_counts, ss));
+        GF_TRY(hipMemcpyAsync(host_counts + 1, d_counts + 1, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ss));
+        GF_TRY(hipEventRecord(t_ev.chain, ss));
+    }
+    // ---- main stream: level-1 index and table, input conv, first two blocks ----
+    UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, st));
+    UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, st));
+
+    // feature buffers are carved after the counts are known for the levels below the first; level 1 now
+    int M[GF_UNET_MAX_LEVELS];
+    M[0] = M0;
+    LevelBufs Bf[GF_UNET_MAX_LEVELS];
+    auto carve = [&](int l) {
+        carve_level(a, Bf[l], (size_t)r16(M[l]), (size_t)P->level[l].C, P->level[l].tr_layers > 0, B);
+    };
+    carve(0);
+    float* x16 = a.take<float>((size_t)ld0 * 16);
+
+    auto resblock = [&](const GfResBlockParams& rb, int l, int cin, const float* x, float* outp, const float* osc,
+                        const float* osh) -> int {
+        const int C = P->level[l].C;
+        const LevelTables& t = T[l];
+        GF_CHECK_ARG(rb.wp0 && rb.wp1 && rb.s0 && rb.t0 && rb.s1 && rb.t1, "gf_unet_fwd: level %d: block parameters missing", l);
+        GF_CHECK_ARG((rb.wpi != nullptr) == (cin != C), "gf_unet_fwd: level %d: identity-branch weights must exist iff the widths differ", l);
+        if (!osc) return gf_resblock_fwd(x, rb.wp0, rb.wp1, rb.wpi, t.nbr, t.gmask, t.steps, 27, M[l], t.ld, cin, C, rb.s0,
+                                         rb.t0, rb.s1, rb.t1, Bf[l].tmp, rb.wpi ? Bf[l].idn : nullptr, outp, st);
+        // the block whose output feeds the output layer: same three launches, BatchNorm + ReLU in the last epilogue
+        int r;
+        if (rb.wpi) {
+            r = gf_conv_fwd(x, rb.wpi, nullptr, nullptr, nullptr, 1, M[l], M[l], 0, cin, C, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, Bf[l].idn, st);
+            if (r != GF_OK) return r;
+        }
+        r = gf_conv_fwd(x, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, rb.s0, rb.t0, nullptr, rb.s1,
+                        rb.t1, Bf[l].tmp, st);
+        if (r != GF_OK) return r;
+        return gf_conv_fwd(Bf[l].tmp, rb.wp1, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, C, C, nullptr, nullptr,
+                           rb.wpi ? Bf[l].idn : x, osc, osh, outp, st);
+    };
+
+    {
+        const int n = M0 * 16;
+        hipLaunchKernelGGL(k_pad_channels, dim3(gf_div_up(n, 256)), dim3(256), 0, st, feats, M0, P->cin, 16, x16);
+        UN_TRY(gf_conv_fwd(x16, P->input_wp, T[0].nbr, T[0].gmask, T[0].steps, 27, M0, M0, ld0, 16, 16, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, Bf[0].x, st));
+    }
+    const bool single = P->nlevels == 1;
+    UN_TRY(resblock(P->level[0].blocks[0], 0, 16, Bf[0].x, Bf[0].o0, nullptr, nullptr));
+    UN_TRY(resblock(P->level[0].blocks[1], 0, 16, Bf[0].o0, single && P->level[0].tr_layers == 0 ? out : Bf[0].o1,
+                    single && P->level[0].tr_layers == 0 ? P->out_s : nullptr,
+                    single && P->level[0].tr_layers == 0 ? P->out_t : nullptr));
+
+    // ---- the one host wait: voxel counts of the levels below ----
+    const int32_t* lcoords[GF_UNET_MAX_LEVELS];
+    lcoords[0] = coords;
+    if (nl > 0) {
+        GF_TRY(hipEventSynchronize(t_ev.chain));
+        for (int l = 1; l <= nl; l++) {
+            M[l] = host_counts[l];
+            GF_CHECK_ARG(M[l] >= 0 && M[l] <= caps[l], "gf_unet_fwd: level %d reports %d voxels (capacity %d)", l + 1, M[l],
+                         caps[l]);
+            lcoords[l] = cws + offs[(l - 1) * 10 + 3];
+        }
+        // submanifold tables of the levels below, behind the chain on the side stream
+        for (int l = 1; l <= nl; l++) {
+            if (M[l] == 0) continue;
+            const long long* o = offs + (l - 1) * 10;
+            UN_TRY(gf_rules_subm3(lcoords[l], M[l], nullptr, shapes[3 * l], shapes[3 * l + 1], shapes[3 * l + 2],
+                                  (const uint32_t*)(cws + o[0]), cws + o[1], nullptr, T[l].nbr, T[l].ld, T[l].gmask,
+                                  nullptr, ss));
+        }
+        if (forked) {
+            GF_TRY(hipEventRecord(t_ev.rules, ss));
+            GF_TRY(hipStreamWaitEvent(st, t_ev.rules, 0));
+        }
+        for (int l = 1; l <= nl; l++) carve(l);
+    }
+    host_counts[0] = M0;
+
+    // ---- down pass ----
+    for (int l = 0; l < nl; l++) {
+        const GfUnetLevelParams& L = P->level[l];
+        const long long* o = offs + l * 10;
+        if (l > 0) {
+            UN_TRY(resblock(L.blocks[0], l, L.C, Bf[l].x, Bf[l].o0, nullptr, nullptr));
+            UN_TRY(resblock(L.blocks[1], l, L.C, Bf[l].o0, Bf[l].o1, nullptr, nullptr));
+        }
+        GF_CHECK_ARG(L.down_wp && L.down_s && L.down_t && L.up_wp && L.up_s && L.up_t,
+                     "gf_unet_fwd: level %d: strided / inverse conv parameters missing", l);
+        // BN + ReLU + SparseConv3d(k=2, s=2): child table of the chain
+        UN_TRY(gf_conv_fwd(Bf[l].o1, L.down_wp, cws + o[4], (const uint32_t*)(cws + o[8]), nullptr, 8, M[l], M[l + 1],
+                           caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x, st));
+    }
+    // ---- deepest level, then the up pass ----
+    for (int l = nl; l >= 0; l--) {
+        const GfUnetLevelParams& L = P->level[l];
+        const float* cur;
+        const bool last_tail_is_output = l == 0 && L.tr_layers == 0;
+        if (l == nl) {
+            if (l > 0) {
+                UN_TRY(resblock(L.blocks[0], l, L.C, Bf[l].x, Bf[l].o0, nullptr, nullptr));
+                UN_TRY(resblock(L.blocks[1], l, L.C, Bf[l].o0, Bf[l].o1, nullptr, nullptr));
+            }
+            cur = Bf[l].o1;
+            if (l == 0 && L.tr_layers == 0) cur = out;  // single-level net: already written with the output activation
+        } else {
+            const long long* o = offs + l * 10;
+            // BN + ReLU + SparseInverseConv3d: the one-hot `up` table of the chain; rows without a coarse cell stay zero
+            UN_TRY(gf_conv_fwd(Bf[l + 1].o2, L.up_wp, cws + o[7], (const uint32_t*)(cws + o[9]), nullptr, 8, M[l + 1], M[l],
+                               caps[l], P->level[l + 1].C, L.C, L.up_s, L.up_t, nullptr, nullptr, nullptr, Bf[l].up, st));
+            if (M[l] > 0) {
+                const int c4 = L.C / 4, n = M[l] * 2 * c4;
+                hipLaunchKernelGGL(k_concat2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)Bf[l].o1,
+                                   (const float4*)Bf[l].up, M[l], c4, (float4*)Bf[l].cat);
+            }
+            UN_TRY(resblock(L.tail[0], l, 2 * L.C, Bf[l].cat, Bf[l].o0, nullptr, nullptr));
+            float* dst = last_tail_is_output ? out : Bf[l].o2;
+            UN_TRY(resblock(L.tail[1], l, L.C, Bf[l].o0, dst, last_tail_is_output ? P->out_s : nullptr,
+                            last_tail_is_output ? P->out_t : nullptr));
+            cur = dst;
+        }
+        if (L.tr_layers > 0) {
+            GF_CHECK_ARG(l > 0, "gf_unet_fwd: the voxel transformer needs batch-major rows (levels below the first)");
+            GF_CHECK_ARG(L.tr_params != nullptr, "gf_unet_fwd: level %d: transformer parameters missing", l);
+            if (M[l] > 0) {
+                hipLaunchKernelGGL(k_scene_offsets, dim3(gf_div_up(M[l] + 1, 256)), dim3(256), 0, st, lcoords[l], M[l], B,
+                                   Bf[l].tr_offs);
+                UN_TRY(gf_backbone_transformer(cur, lcoords[l], Bf[l].tr_offs, B, M[l], L.C, L.tr_layers, L.tr_params,
+                                               Bf[l].tr_scratch, Bf[l].tr, st));
+            }
+            cur = Bf[l].tr;
+        }
+        if (l > 0 && cur != Bf[l].o2) {
+            // hand the level's result to the inverse conv above under one name
+            Bf[l].o2 = const_cast<float*>(cur);
+        }
+    }
+#undef UN_TRY
+    GF_CHECK_LAUNCH("gf_unet_fwd");
+    return GF_OK;
+}

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 from torch.nn import functional as F
 
-from .. import pointops, spconv
+from .. import pointops, spconv, unet_exec
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
 from .layers import (BatchNorm1d, GenericMLP, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
@@ -300,27 +300,38 @@ class GeoFormer(nn.Module):
         ctx = self._grad_ctx("unet")
         with ctx():
             x = self.preprocess_input(batch_input, batch_size)
+            if os.environ.get("GF_UNET_EXEC", "1") != "0" and unet_exec.supported(self, x.features, x.spatial_shape):
+                # inference on the GPU: rulebooks, the 71 convolutions and the two voxel transformers issued by one
+                # native call (csrc/unet_exec.hip) -- the same launches as the module tree below, without the host
+                # side of ~150 of them
+                x.features = unet_exec.unet_forward(self, x.features.contiguous(), x._coords(), batch_size,
+                                                    x.spatial_shape)
+                return self._semantic_head(x, batch_input, want_preds)
             # built lazily by the first strided convolution (spconv.SparseConv3d.get_rules): the host then issues
             # the chain's ~50 small launches while the GPU is busy with the level-1 blocks, and the one read-back
             # of the voxel counts waits behind real work instead of an empty queue
             x.indice_dict["_prebuild"] = self.prebuild_rulebooks
             x = self.output_layer(self.unet(self.input_conv(x)))
-            p2v = batch_input["p2v_map"]
-            if not want_preds and p2v.dtype == torch.int32 and p2v.is_contiguous():
-                # fused inference: nobody needs feats[p2v_map] as a tensor -- the semantic head and the foreground
-                # compaction read the voxel rows through the map (returned as (voxel features, map))
-                vox = x.features.contiguous()
-                chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], vox)
-                if chain is not None:
-                    return (vox, p2v), pointops.pointwise_mlp(vox, chain, rows=p2v), None
-            output_feats = x.features[p2v.long()].contiguous()
-            chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)
+            return self._semantic_head(x, batch_input, want_preds)
+
+    def _semantic_head(self, x, batch_input, want_preds):
+        """Voxel -> point gather and the semantic head (geoformer.py:541-547) behind either backbone route."""
+        p2v = batch_input["p2v_map"]
+        if not want_preds and p2v.dtype == torch.int32 and p2v.is_contiguous():
+            # fused inference: nobody needs feats[p2v_map] as a tensor -- the semantic head and the foreground
+            # compaction read the voxel rows through the map (returned as (voxel features, map))
+            vox = x.features.contiguous()
+            chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], vox)
             if chain is not None:
-                semantic_scores = pointops.pointwise_mlp(output_feats, chain)
-            else:
-                semantic_scores = self.semantic_linear(self.semantic(output_feats))
-            semantic_preds = semantic_scores.max(1)[1] if want_preds else None
-            return output_feats, semantic_scores, semantic_preds
+                return (vox, p2v), pointops.pointwise_mlp(vox, chain, rows=p2v), None
+        output_feats = x.features[p2v.long()].contiguous()
+        chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)
+        if chain is not None:
+            semantic_scores = pointops.pointwise_mlp(output_feats, chain)
+        else:
+            semantic_scores = self.semantic_linear(self.semantic(output_feats))
+        semantic_preds = semantic_scores.max(1)[1] if want_preds else None
+        return output_feats, semantic_scores, semantic_preds
 
     @staticmethod
     def prebuild_rulebooks(x, nlevels=6):

@@ -162,6 +162,46 @@ int gf_resblock_fwd(const float* x, const float* Wp0, const float* Wp1, const fl
 int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K, int M_out, int ld, int Cin, int Cout,
                   float* dW, void* stream);
 
+/* The whole sparse U-Net of the eval forward in one call: input conv -> UBlock x nlevels -> output BatchNorm + ReLU
+ * (GeoFormer.input_conv / unet / output_layer, model/geoformer/geoformer.py:42-53,398-401; UBlock and ResidualBlock,
+ * model/geoformer/geoformer_modules.py:10-35,52-129; two blocks per level before and after the inner level, all
+ * BatchNorm in eval mode).  Issues exactly the launches the per-module route makes through gf_index_build,
+ * gf_rules_subm3, gf_rules_down2_chain, gf_conv_fwd, gf_resblock_fwd and gf_backbone_transformer, from native code
+ * and out of one workspace; the rulebook chain runs on `side_stream` beside the level-1 convolutions and the call
+ * waits once on the host for the chain's voxel counts.
+ *   All pointers inside the parameter structs are DEVICE pointers except tr_params (host array of device pointers,
+ *   the table gf_backbone_transformer takes); packed weights come from gf_conv_pack_weights; (s, t) pairs are
+ *   eval-mode BatchNorm folded to y = max(x*s + t, 0) and must be 16-byte aligned. */
+#define GF_UNET_MAX_LEVELS 8
+typedef struct GfResBlockParams {
+    const float *wp0, *wp1, *wpi;   /* conv_branch.2 / conv_branch.5 / i_branch.0 weights; wpi NULL iff Cin == Cout */
+    const float *s0, *t0, *s1, *t1; /* conv_branch.0 [Cin] and conv_branch.3 [Cout] */
+} GfResBlockParams;
+typedef struct GfUnetLevelParams {
+    int C;                          /* channel width of the level (multiple of 16) */
+    int tr_layers;                  /* > 0: the level ends with the voxel transformer of that many layers */
+    GfResBlockParams blocks[2];     /* UBlock.blocks: C -> C */
+    GfResBlockParams tail[2];       /* UBlock.blocks_tail: 2C -> C, C -> C (unused on the deepest level) */
+    const float *down_wp, *down_s, *down_t; /* UBlock.conv: BN(C) + ReLU + SparseConv3d(C, C_next, k=2, s=2) */
+    const float *up_wp, *up_s, *up_t;       /* UBlock.deconv: BN(C_next) + ReLU + SparseInverseConv3d(C_next, C, k=2) */
+    const float* const* tr_params;  /* see gf_backbone_transformer */
+} GfUnetLevelParams;
+typedef struct GfUnetParams {
+    int nlevels;                    /* 7 in GeoFormer */
+    int cin;                        /* channels of the voxel features handed in (<= 16) */
+    const float* input_wp;          /* packed [27,16,16] input-conv weights, input channels zero-padded to 16 */
+    const float *out_s, *out_t;     /* output_layer BatchNorm folded, [16] */
+    GfUnetLevelParams level[GF_UNET_MAX_LEVELS];
+} GfUnetParams;
+/* bytes of workspace gf_unet_fwd needs for a scene of M0 voxels on a [B,X,Y,Z] grid (capacity bound, host only) */
+size_t gf_unet_ws_bytes(const GfUnetParams* P, int M0, int B, int X, int Y, int Z);
+/*   feats fp32 [M0,cin] voxel features, coords int32 [M0,4] (b,x,y,z) unique rows, ws 256-byte aligned device
+ *   workspace, host_counts PINNED host int32 [nlevels]: receives the voxel count of every level,
+ *   out fp32 [M0,16]; side_stream may be NULL (everything on `stream`).  Everything queued on side_stream is
+ *   joined into `stream` before the call returns control of the tables to later launches. */
+int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
+                void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream);
+
 /* ===================================================================================
  * PG_OP (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-23)
  * =================================================================================== */
