@@ -48,6 +48,10 @@ void gf_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// levels [l_begin, l_end) of gf_rules_down2_chain (spconv_rules.hip; used by unet_exec.hip)
+int gf_rules_down2_chain_range(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels, int l_begin,
+                               int l_end, int32_t* ws, int32_t* counts, hipStream_t st);
+
 static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- occupancy-bitmap rank index (see spconv_rules.hip) ----

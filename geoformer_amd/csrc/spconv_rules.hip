@@ -470,36 +470,43 @@ extern "C" int gf_rules_down2_chain_plan(int M0, int B, int X, int Y, int Z, int
     return GF_OK;
 }
 
-extern "C" int gf_rules_down2_chain(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels,
-                                    int32_t* ws, int32_t* counts, void* stream) {
+// levels [l_begin, l_end) of the chain (internal: gf_unet_fwd issues the first level, whose tables and count the
+// convolutions need first, ahead of the rest); the memsets that clear every level's bitmaps and child tables go
+// with level 0
+int gf_rules_down2_chain_range(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels, int l_begin,
+                               int l_end, int32_t* ws, int32_t* counts, hipStream_t st) {
     GF_CHECK_ARG(coords && ws && counts, "gf_rules_down2_chain: null argument");
     GF_CHECK_ARG(M0 >= 0 && B > 0 && nlevels >= 0 && nlevels <= DOWN_MAX_LEVELS, "gf_rules_down2_chain: bad sizes");
     DownPlan P;
     GF_CHECK_ARG(plan_down_chain(M0, B, X, Y, Z, nlevels, P) == 0, "gf_rules_down2_chain: grid too large");
     if (P.nl == 0 || M0 == 0) return GF_OK;
-    hipStream_t st = (hipStream_t)stream;
-    GF_TRY(hipMemsetAsync(ws + P.bitmaps_begin, 0, (size_t)(P.bitmaps_end - P.bitmaps_begin) * 4, st));
-    GF_TRY(hipMemsetAsync(ws + P.child_begin, 0xff, (size_t)(P.child_end - P.child_begin) * 4, st));
-    const int32_t* cur = coords;
-    for (int l = 0; l < P.nl; l++) {
+    if (l_end > P.nl) l_end = P.nl;
+    if (l_begin == 0) {
+        GF_TRY(hipMemsetAsync(ws + P.bitmaps_begin, 0, (size_t)(P.bitmaps_end - P.bitmaps_begin) * 4, st));
+        GF_TRY(hipMemsetAsync(ws + P.child_begin, 0xff, (size_t)(P.child_end - P.child_begin) * 4, st));
+    }
+    for (int l = l_begin; l < l_end; l++) {
+        const int32_t* cur = l ? ws + P.off[l - 1][3] : coords;
         int32_t* F[DOWN_FIELDS];
         for (int f = 0; f < DOWN_FIELDS; f++) F[f] = ws + P.off[l][f];
         const int Mcap = l ? P.cap[l] : M0;
         const int32_t* d_M = l ? counts + l : nullptr;
         const int OX = P.shape[l + 1][0], OY = P.shape[l + 1][1], OZ = P.shape[l + 1][2];
         const int ld = P.cap[l + 1], ld_up = P.cap[l];
-        {
-            if (Mcap > 0)
-                hipLaunchKernelGGL(k_down_bits, dim3(gf_div_up(Mcap, 256)), dim3(256), 0, st, cur, Mcap, d_M, OX, OY, OZ,
-                                   (uint32_t*)F[0]);
-            run_scan((uint32_t*)F[0], P.words[l], F[1], F[2], counts + l + 1, st);
-            GfIndex oix{(uint32_t*)F[0], F[1], nullptr, OX, OY, OZ};
-            hipLaunchKernelGGL(k_down_fill, dim3(gf_div_up(ld_up, 256)), dim3(256), 0, st, cur, Mcap, d_M, oix, F[3], F[4],
-                               ld, F[5], F[6], F[7], ld_up, (uint32_t*)F[9]);
-            hipLaunchKernelGGL(k_table_gmask, dim3(gf_div_up(ld, 256)), dim3(256), 0, st, F[4], 8, ld, (uint32_t*)F[8]);
-        }
-        cur = F[3];
+        if (Mcap > 0)
+            hipLaunchKernelGGL(k_down_bits, dim3(gf_div_up(Mcap, 256)), dim3(256), 0, st, cur, Mcap, d_M, OX, OY, OZ,
+                               (uint32_t*)F[0]);
+        run_scan((uint32_t*)F[0], P.words[l], F[1], F[2], counts + l + 1, st);
+        GfIndex oix{(uint32_t*)F[0], F[1], nullptr, OX, OY, OZ};
+        hipLaunchKernelGGL(k_down_fill, dim3(gf_div_up(ld_up, 256)), dim3(256), 0, st, cur, Mcap, d_M, oix, F[3], F[4],
+                           ld, F[5], F[6], F[7], ld_up, (uint32_t*)F[9]);
+        hipLaunchKernelGGL(k_table_gmask, dim3(gf_div_up(ld, 256)), dim3(256), 0, st, F[4], 8, ld, (uint32_t*)F[8]);
     }
     GF_CHECK_LAUNCH("gf_rules_down2_chain");
     return GF_OK;
+}
+
+extern "C" int gf_rules_down2_chain(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels,
+                                    int32_t* ws, int32_t* counts, void* stream) {
+    return gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nlevels, 0, nlevels, ws, counts, (hipStream_t)stream);
 }

@@ -65,9 +65,9 @@ struct LevelTables {  // submanifold table of one level
     int ld = 0;
 };
 
-// events of the side-stream fork/join: two per host thread, created once
+// events of the side-stream fork/join and the two host waits: per host thread, created once
 struct EvPair {
-    hipEvent_t fork = nullptr, chain = nullptr, rules = nullptr;
+    hipEvent_t fork = nullptr, chain = nullptr, chain2 = nullptr, rules = nullptr;
 };
 thread_local EvPair t_ev;
 
@@ -169,7 +169,10 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
         GF_TRY(hipEventCreateWithFlags(&t_ev.fork, hipEventDisableTiming));
         GF_TRY(hipEventCreateWithFlags(&t_ev.rules, hipEventDisableTiming));
     }
-    if (!t_ev.chain) GF_TRY(hipEventCreateWithFlags(&t_ev.chain, hipEventDisableTiming));
+    if (!t_ev.chain) {
+        GF_TRY(hipEventCreateWithFlags(&t_ev.chain, hipEventDisableTiming));
+        GF_TRY(hipEventCreateWithFlags(&t_ev.chain2, hipEventDisableTiming));
+    }
 
     Bump a(ws, ws_bytes);
     const size_t words0 = gf_index_words(B, X, Y, Z);
@@ -201,17 +204,8 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
         if (rc != GF_OK) return rc;   \
     } while (0)
 
-    // ---- side stream: the chain of down-sampling rulebooks, its counts on their way to the host ----
-    if (forked) {
-        GF_TRY(hipEventRecord(t_ev.fork, st));
-        GF_TRY(hipStreamWaitEvent(ss, t_ev.fork, 0));
-    }
-    if (nl > 0) {
-        UN_TRY(gf_rules_down2_chain(coords, M0, B, X, Y, Z, nl, cws, d_counts, ss));
-        GF_TRY(hipMemcpyAsync(host_counts + 1, d_counts + 1, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ss));
-        GF_TRY(hipEventRecord(t_ev.chain, ss));
-    }
     // ---- main stream: level-1 index and table, input conv, first two blocks ----
+    if (forked) GF_TRY(hipEventRecord(t_ev.fork, st));
     UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, st));
     UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, st));
 
@@ -259,46 +253,82 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
                     single && P->level[0].tr_layers == 0 ? P->out_s : nullptr,
                     single && P->level[0].tr_layers == 0 ? P->out_t : nullptr));
 
-    // ---- the one host wait: voxel counts of the levels below ----
+    // ---- side stream: the chain of down-sampling rulebooks, queued AFTER the level-1 work (its ~35 launches are
+    // 5 us of dispatch each and little else: the device runs them beside the level-1 convolutions; queued first they
+    // would hold everything back for 0.2 ms on an idle device).  First its level 0 alone: the second level's voxel
+    // count and tables are what the main stream needs next ----
     const int32_t* lcoords[GF_UNET_MAX_LEVELS];
     lcoords[0] = coords;
-    if (nl > 0) {
-        GF_TRY(hipEventSynchronize(t_ev.chain));
-        for (int l = 1; l <= nl; l++) {
+    host_counts[0] = M0;
+    auto subm_tables = [&](int l, hipStream_t s_) -> int {
+        if (M[l] == 0) return GF_OK;
+        const long long* o = offs + (l - 1) * 10;
+        return gf_rules_subm3(lcoords[l], M[l], nullptr, shapes[3 * l], shapes[3 * l + 1], shapes[3 * l + 2],
+                              (const uint32_t*)(cws + o[0]), cws + o[1], nullptr, T[l].nbr, T[l].ld, T[l].gmask, nullptr, s_);
+    };
+    auto take_counts = [&](int l0, int l1) -> int {
+        for (int l = l0; l <= l1; l++) {
             M[l] = host_counts[l];
             GF_CHECK_ARG(M[l] >= 0 && M[l] <= caps[l], "gf_unet_fwd: level %d reports %d voxels (capacity %d)", l + 1, M[l],
                          caps[l]);
             lcoords[l] = cws + offs[(l - 1) * 10 + 3];
         }
-        // submanifold tables of the levels below, behind the chain on the side stream
-        for (int l = 1; l <= nl; l++) {
-            if (M[l] == 0) continue;
-            const long long* o = offs + (l - 1) * 10;
-            UN_TRY(gf_rules_subm3(lcoords[l], M[l], nullptr, shapes[3 * l], shapes[3 * l + 1], shapes[3 * l + 2],
-                                  (const uint32_t*)(cws + o[0]), cws + o[1], nullptr, T[l].nbr, T[l].ld, T[l].gmask,
-                                  nullptr, ss));
+        return GF_OK;
+    };
+    bool blocks_done[GF_UNET_MAX_LEVELS] = {true};
+    auto down_conv = [&](int l) -> int {
+        const GfUnetLevelParams& L = P->level[l];
+        const long long* o = offs + l * 10;
+        GF_CHECK_ARG(L.down_wp && L.down_s && L.down_t && L.up_wp && L.up_s && L.up_t,
+                     "gf_unet_fwd: level %d: strided / inverse conv parameters missing", l);
+        // BN + ReLU + SparseConv3d(k=2, s=2): child table of the chain
+        return gf_conv_fwd(Bf[l].o1, L.down_wp, cws + o[4], (const uint32_t*)(cws + o[8]), nullptr, 8, M[l], M[l + 1],
+                           caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x, st);
+    };
+    auto two_blocks = [&](int l) -> int {
+        const GfUnetLevelParams& L = P->level[l];
+        int r = resblock(L.blocks[0], l, L.C, Bf[l].x, Bf[l].o0, nullptr, nullptr);
+        if (r != GF_OK) return r;
+        blocks_done[l] = true;
+        return resblock(L.blocks[1], l, L.C, Bf[l].o0, Bf[l].o1, nullptr, nullptr);
+    };
+    if (nl > 0) {
+        // the whole chain is queued at once (it carries its counts on the device); two events mark the points the
+        // host waits for
+        if (forked) GF_TRY(hipStreamWaitEvent(ss, t_ev.fork, 0));
+        UN_TRY(gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nl, 0, 1, cws, d_counts, ss));
+        GF_TRY(hipMemcpyAsync(host_counts + 1, d_counts + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ss));
+        GF_TRY(hipEventRecord(t_ev.chain, ss));
+        if (nl > 1) {
+            UN_TRY(gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nl, 1, nl, cws, d_counts, ss));
+            GF_TRY(hipMemcpyAsync(host_counts + 2, d_counts + 2, sizeof(int32_t) * (nl - 1), hipMemcpyDeviceToHost, ss));
+            GF_TRY(hipEventRecord(t_ev.chain2, ss));
         }
+        GF_TRY(hipEventSynchronize(t_ev.chain));  // host wait 1: voxel count of the second level
+        UN_TRY(take_counts(1, 1));
+        // main stream: second level's table, the first strided conv and that level's two blocks -- ~0.18 ms of device
+        // work that needs nothing from the rest of the chain
+        if (forked) GF_TRY(hipStreamWaitEvent(st, t_ev.chain, 0));
+        UN_TRY(subm_tables(1, st));
+        carve(1);
+        UN_TRY(down_conv(0));
+        UN_TRY(two_blocks(1));
+    }
+    if (nl > 1) {
+        GF_TRY(hipEventSynchronize(t_ev.chain2));  // host wait 2: the levels below (the device is busy with level 2)
+        UN_TRY(take_counts(2, nl));
+        for (int l = 2; l <= nl; l++) UN_TRY(subm_tables(l, ss));
         if (forked) {
             GF_TRY(hipEventRecord(t_ev.rules, ss));
             GF_TRY(hipStreamWaitEvent(st, t_ev.rules, 0));
         }
-        for (int l = 1; l <= nl; l++) carve(l);
+        for (int l = 2; l <= nl; l++) carve(l);
     }
-    host_counts[0] = M0;
 
     // ---- down pass ----
-    for (int l = 0; l < nl; l++) {
-        const GfUnetLevelParams& L = P->level[l];
-        const long long* o = offs + l * 10;
-        if (l > 0) {
-            UN_TRY(resblock(L.blocks[0], l, L.C, Bf[l].x, Bf[l].o0, nullptr, nullptr));
-            UN_TRY(resblock(L.blocks[1], l, L.C, Bf[l].o0, Bf[l].o1, nullptr, nullptr));
-        }
-        GF_CHECK_ARG(L.down_wp && L.down_s && L.down_t && L.up_wp && L.up_s && L.up_t,
-                     "gf_unet_fwd: level %d: strided / inverse conv parameters missing", l);
-        // BN + ReLU + SparseConv3d(k=2, s=2): child table of the chain
-        UN_TRY(gf_conv_fwd(Bf[l].o1, L.down_wp, cws + o[4], (const uint32_t*)(cws + o[8]), nullptr, 8, M[l], M[l + 1],
-                           caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x, st));
+    for (int l = 1; l < nl; l++) {
+        if (!blocks_done[l]) UN_TRY(two_blocks(l));
+        UN_TRY(down_conv(l));
     }
     // ---- deepest level, then the up pass ----
     for (int l = nl; l >= 0; l--) {
@@ -306,10 +336,7 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
         const float* cur;
         const bool last_tail_is_output = l == 0 && L.tr_layers == 0;
         if (l == nl) {
-            if (l > 0) {
-                UN_TRY(resblock(L.blocks[0], l, L.C, Bf[l].x, Bf[l].o0, nullptr, nullptr));
-                UN_TRY(resblock(L.blocks[1], l, L.C, Bf[l].o0, Bf[l].o1, nullptr, nullptr));
-            }
+            if (!blocks_done[l]) UN_TRY(two_blocks(l));
             cur = Bf[l].o1;
             if (l == 0 && L.tr_layers == 0) cur = out;  // single-level net: already written with the output activation
         } else {
