@@ -85,112 +85,97 @@ def _conv_bytes(R, M, K, Cin, Cout, residual=False):
     return 4 * (R * Cin + M * Cout + K * Cin * Cout) + 8 * R + (4 * M * Cout if residual else 0)
 
 
+def _read_probe(max_records=8192):
+    """Records of the native conv probe (include/geoformer_hip_dev.h: gf_dev_unet_probe_read): list of
+    (level, kind, K, Cin, Cout, M_in, M_out, residual, rules, microseconds)."""
+    import ctypes
+
+    from geoformer_amd import _lib
+
+    meta = (ctypes.c_int * (9 * max_records))()
+    us = (ctypes.c_float * max_records)()
+    n = _lib.load().gf_dev_unet_probe_read(max_records, ctypes.cast(meta, ctypes.c_void_p), ctypes.cast(us, ctypes.c_void_p))
+    if n < 0:
+        raise RuntimeError("gf_dev_unet_probe_read failed")
+    return [tuple(meta[9 * i:9 * i + 9]) + (float(us[i]),) for i in range(n)]
+
+
 class ConvProbe:
-    """HIP events around the level-1 16->16 submanifold conv launches (same stream as the kernel)."""
+    """HIP events around the level-1 16->16 submanifold conv launches of the residual blocks, recorded by the native
+    U-Net executor on the stream the kernels run on, inside the timed region (every PROBE_EVERY-th step)."""
 
-    def __init__(self, Ms):
-        from geoformer_amd import sparse
+    def __init__(self, batches):
+        from geoformer_amd import _lib, sparse
 
-        self.sparse, self.orig, self.Ms, self.events, self.on = sparse, sparse.resblock_fwd, set(Ms), [], False
-        self.tbl = {}
+        self.lib = _lib.load()
+        self.R = {}
+        for b in batches:  # level-1 rule counts of the benchmark scenes (setup, untimed)
+            coords = b["voxel_locs"].int().contiguous()
+            shape = tuple(int(x) for x in b["spatial_shape"])
+            M = coords.shape[0]
+            rules = sparse.subm_rules(coords, sparse.build_index(coords, 1, shape))
+            self.R[M] = int((rules.nbr[:, :M] >= 0).sum().item())
+        self.recs = []
 
-        def probe(x, wp0, wp1, wpi, nbr, gmask, K, M_, ld, Cin, Cout, s0, t0, s1, t1, **kw):
-            # level-1 16->16 blocks: events recorded in native code right around the two 3x3x3 launches, on the
-            # kernel's stream (first conv: BN+ReLU prologue and the second BN+ReLU as epilogue; second conv: residual
-            # epilogue)
-            if self.on and K == 27 and M_ in self.Ms and Cin == 16 and Cout == 16:
-                self.tbl[M_] = nbr
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
-                out = self.orig(x, wp0, wp1, wpi, nbr, gmask, K, M_, ld, Cin, Cout, s0, t0, s1, t1, events=ev)
-                self.events.append((ev[0][0], ev[0][1], False, M_))
-                self.events.append((ev[1][0], ev[1][1], True, M_))
-                return out
-            return self.orig(x, wp0, wp1, wpi, nbr, gmask, K, M_, ld, Cin, Cout, s0, t0, s1, t1, **kw)
-
-        sparse.resblock_fwd = probe
+    def arm(self, on):
+        self.lib.gf_dev_unet_probe(1 if on else 0)
 
     def close(self):
-        self.sparse.resblock_fwd = self.orig
+        self.lib.gf_dev_unet_probe(0)
+        self.recs += _read_probe()
 
     def result(self):
-        if not self.events:
+        if not self.recs:
             return None
-        R = {M: int((t[:, :M] >= 0).sum().item()) for M, t in self.tbl.items()}
-        us = [s.elapsed_time(e) * 1e3 for s, e, _, _ in self.events]
-        byt = [_conv_bytes(R[M], M, 27, 16, 16, r) for _, _, r, M in self.events]
+        us = [r[9] for r in self.recs]
+        byt = [_conv_bytes(self.R[r[6]], r[6], 27, 16, 16, bool(r[7])) for r in self.recs]
         # mean of the per-launch rates weighted by time = total bytes / total time
         ach = sum(byt) / (sum(us) * 1e-6) / 1e9
+        Ms = sorted({r[6] for r in self.recs})
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC["bytes"],
                 "traffic_source": PMC_TRAFFIC["source"],
                 "kernel": "level-1 subm 3x3x3 16->16 launches of the residual blocks (first conv: BN+ReLU prologue and "
-                          "BN+ReLU epilogue; second conv: residual epilogue)",
+                          "BN+ReLU epilogue; second conv: residual epilogue), k_conv_g16p",
                 "launches": len(us), "us_per_launch": round(float(np.mean(us)), 2),
-                "algorithmic_bytes": int(np.mean(byt)), "rules": R, "voxels": sorted(R),
-                "sampling": f"every level-1 launch of every {PROBE_EVERY}th timed step"}
+                "algorithmic_bytes": int(np.mean(byt)), "rules": {M: self.R[M] for M in Ms}, "voxels": Ms,
+                "sampling": f"every such launch of every {PROBE_EVERY}th timed step, events recorded natively around "
+                            "the launch on its stream"}
 
 
 def all_convs_roofline(model, batches, reps=2):
-    """Every sparse-conv call of a forward between two events (untimed extra pass): sum of algorithmic bytes and
-    flops over the 71 convolutions / sum of their spans.  A residual block is one native call (2-3 launches)."""
-    from geoformer_amd import sparse
+    """Every sparse-conv launch of a forward between two events (untimed extra passes through the native executor's
+    probe): sum of algorithmic bytes and flops over the 71 convolutions / sum of their launch durations."""
+    from geoformer_amd import _lib
 
-    orig_conv, orig_block = sparse.conv_fwd, sparse.resblock_fwd
-    rec = []
-    Rc = {}
-
-    def rules_of(tbl, M):
-        key = (tbl.data_ptr(), M)
-        if key not in Rc:
-            Rc[key] = (tbl[:, :M] >= 0).sum()
-        return Rc[key]
-
-    def ev():
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        return e
-
-    def conv(feats, weight, nbr, gmask, K, M_out, ld, in_scale=None, in_shift=None, residual=None, **kw):
-        Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
-        R = torch.tensor(M_out, device=feats.device) if nbr is None else rules_of(nbr, M_out)
-        a = ev()
-        out = orig_conv(feats, weight, nbr, gmask, K, M_out, ld, in_scale=in_scale, in_shift=in_shift,
-                        residual=residual, **kw)
-        rec.append((a, ev(), [(R, M_out, K, Cin, Cout, residual is not None)]))
-        return out
-
-    def block(x, wp0, wp1, wpi, nbr, gmask, K, M, ld, Cin, Cout, s0, t0, s1, t1, **kw):
-        R = rules_of(nbr, M)
-        a = ev()
-        out = orig_block(x, wp0, wp1, wpi, nbr, gmask, K, M, ld, Cin, Cout, s0, t0, s1, t1, **kw)
-        items = [(R, M, K, Cin, Cout, False), (R, M, K, Cout, Cout, True)]
-        if wpi is not None:
-            items.append((torch.tensor(M, device=x.device), M, 1, Cin, Cout, False))
-        rec.append((a, ev(), items))
-        return out
-
-    sparse.conv_fwd, sparse.resblock_fwd = conv, block
+    lib = _lib.load()
+    lib.gf_dev_unet_probe(2)
     try:
         for b in batches[:reps]:
             with torch.no_grad():
                 model(b, 0, training=False)  # backbone + semantic head only (epoch <= prepare_epochs)
         torch.cuda.synchronize()
     finally:
-        sparse.conv_fwd, sparse.resblock_fwd = orig_conv, orig_block
-    us = sum(a.elapsed_time(b) for a, b, _ in rec) * 1e3
-    byt = fl = n = 0
-    for _, _, items in rec:
-        for R, M, K, Cin, Cout, res in items:
-            R = int(R.item())
-            byt += _conv_bytes(R, M, K, Cin, Cout, res)
-            fl += 2 * R * Cin * Cout
-            n += 1
+        lib.gf_dev_unet_probe(0)
+    recs = _read_probe()
+    us = sum(r[9] for r in recs)
+    byt = fl = 0
+    per_level = {}
+    for level, kind, K, Cin, Cout, M_in, M_out, res, R, t in recs:
+        R = M_out if R < 0 else R  # 1x1x1 convs: one rule per row
+        bb = _conv_bytes(R, M_out, K, Cin, Cout, bool(res))
+        byt += bb
+        fl += 2 * R * Cin * Cout
+        pl = per_level.setdefault(level + 1, [0, 0.0, 0])
+        pl[0] += bb; pl[1] += t; pl[2] += 1
     nf = len(batches[:reps])
     return {"bound": "hbm", "achieved": round(byt / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "convs_per_forward": n // nf,
+            "frac": round(byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "convs_per_forward": len(recs) // nf,
             "us_per_forward": round(us / nf, 1), "algorithmic_bytes_per_forward": byt // nf,
             "gflop_per_forward": round(fl / nf / 1e9, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 2),
-            "note": "spans around every conv call incl. the gaps between the 2-3 launches of a residual block"}
+            "by_level": {str(l): {"convs": v[2] // nf, "us": round(v[1] / nf, 1), "GB/s": round(v[0] / (v[1] * 1e-6) / 1e9, 1)}
+                         for l, v in sorted(per_level.items())},
+            "note": "events around every conv launch of the native U-Net executor (separate untimed passes)"}
 
 
 class StageTimer:
@@ -327,7 +312,7 @@ def main():
                for i in range(ns)]
     model = build_model(dev, probe_batch=batches[0])
     Ms = [int(b["voxel_locs"].shape[0]) for b in batches]
-    probe = ConvProbe(Ms)
+    probe = ConvProbe(batches)
 
     def step(i, m=model):
         np.random.seed(1000 + i)
@@ -340,19 +325,17 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    # the probe's event pairs go around the level-1 conv launches of every PROBE_EVERY-th timed step: recording
-    # them takes the block out of its single-call path, which costs the launch-bound start of the U-Net ~0.15 ms
-    # per probed step
+    # the probe's event pairs go around the level-1 conv launches of every PROBE_EVERY-th timed step (two event
+    # records per launch, issued by the native executor itself)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        probe.on = i % PROBE_EVERY == 0
+        probe.arm(i % PROBE_EVERY == 0)
         out = step(args.warmup + i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    probe.on = False
     probe.close()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -45,6 +45,8 @@ def _declare(lib):
         "gf_resblock_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),
         "gf_unet_ws_bytes": (c_size_t, [P, I, I, I, I, I]),
+        "gf_dev_unet_probe": (I, [I]),
+        "gf_dev_unet_probe_read": (I, [I, P, P]),
         "gf_unet_fwd": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
         "gf_voxelize_bp": (I, [P, P, I, I, I, I, P, P]),

@@ -521,6 +521,13 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
 // orders by (parent, rank) first, so the distance that rides in the low word is the winner's.
 #define BFS_LDS_MAX_N (1 << 19)
 #define BFS_LDS_BYTES (150 * 1024)
+// workgroup barrier that orders LDS traffic only: global stores (the distances, never read back by this kernel) and
+// loads requested ahead of their use stay in flight across it -- __syncthreads() waits for every one (vmcnt(0))
+__device__ __forceinline__ void bfs_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __restrict__ D,
                                                                   const int32_t* __restrict__ I, int n, int K,
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                                                                   unsigned long long* __restrict__ keys,
                                                                   int2* __restrict__ queues, int qcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_cnt;
+    __shared__ int s_cnt[2];  // next-frontier counters of even / odd hops (reset a hop ahead: one barrier less)
     const int nw = (n + 31) >> 5;
     unsigned* visited = reinterpret_cast<unsigned*>(smem);
     unsigned* touched = visited + nw;
@@ -556,12 +563,21 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
         visited[s >> 5] = 1u << (s & 31);
         touched[s >> 5] = 1u << (s & 31);
         q0[0] = make_int2(s, __float_as_int(0.0f));
-        s_cnt = 0;
+        s_cnt[0] = 0;
+        s_cnt[1] = 0;
     }
     __syncthreads();
     int ncur = 1;
     int2 *cl = q0, *cg = gq0, *nl = q1, *ng = gq1;
+    // The thread that commits entry t of the next frontier is the thread that expands entry t a hop later, so it
+    // requests the first 16 entries of that vertex's row right there: the fetch (the longest wait of the expansion)
+    // then runs under the commit's own round trip and the barrier instead of after them.
+    const bool can_pf = K >= 16;
+    bool have_pf = false;
+    int4 pv[4];
+    float4 pd[4];
     for (int step = 0; step < max_step && ncur > 0; step++) {
+        int* cnt = &s_cnt[step & 1];
         for (int f = tid; f < ncur; f += THREADS) {
             const int2 e = f < qcap ? cl[f] : cg[f - qcap];
             const int u = e.x;
@@ -572,19 +588,27 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
             for (int r0 = 0; r0 < K && more; r0 += 16) {
                 int v[16];
                 float d[16];
+                if (r0 == 0 && f == tid && have_pf) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int rb = r0 + 4 * c;
-                    if (rb + 3 < K) {
-                        const int4 vi = *reinterpret_cast<const int4*>(Iu + rb);
-                        const float4 di = *reinterpret_cast<const float4*>(Du + rb);
-                        v[4 * c + 0] = vi.x; v[4 * c + 1] = vi.y; v[4 * c + 2] = vi.z; v[4 * c + 3] = vi.w;
-                        d[4 * c + 0] = di.x; d[4 * c + 1] = di.y; d[4 * c + 2] = di.z; d[4 * c + 3] = di.w;
-                    } else {
+                    for (int c = 0; c < 4; c++) {
+                        v[4 * c + 0] = pv[c].x; v[4 * c + 1] = pv[c].y; v[4 * c + 2] = pv[c].z; v[4 * c + 3] = pv[c].w;
+                        d[4 * c + 0] = pd[c].x; d[4 * c + 1] = pd[c].y; d[4 * c + 2] = pd[c].z; d[4 * c + 3] = pd[c].w;
+                    }
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            v[4 * c + j] = (rb + j < K) ? Iu[rb + j] : -1;
-                            d[4 * c + j] = (rb + j < K) ? Du[rb + j] : 0.f;
+                    for (int c = 0; c < 4; c++) {
+                        const int rb = r0 + 4 * c;
+                        if (rb + 3 < K) {
+                            const int4 vi = *reinterpret_cast<const int4*>(Iu + rb);
+                            const float4 di = *reinterpret_cast<const float4*>(Du + rb);
+                            v[4 * c + 0] = vi.x; v[4 * c + 1] = vi.y; v[4 * c + 2] = vi.z; v[4 * c + 3] = vi.w;
+                            d[4 * c + 0] = di.x; d[4 * c + 1] = di.y; d[4 * c + 2] = di.z; d[4 * c + 3] = di.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                v[4 * c + j] = (rb + j < K) ? Iu[rb + j] : -1;
+                                d[4 * c + j] = (rb + j < K) ? Du[rb + j] : 0.f;
+                            }
                         }
                     }
                 }
@@ -606,7 +630,7 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                         atomicMin(&key[v[j]], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(d[j] + gu));
                         const unsigned old = atomicOr(&touched[v[j] >> 5], bit);
                         if (!(old & bit)) {
-                            const int pos = atomicAdd(&s_cnt, 1);
+                            const int pos = atomicAdd(cnt, 1);
                             if (pos < qcap) nl[pos].x = v[j];
                             else ng[pos - qcap].x = v[j];
                         }
@@ -616,19 +640,32 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every atomicMin of this wave has been performed at L2
         __syncthreads();
-        const int nn = s_cnt;
-        __syncthreads();
-        if (tid == 0) s_cnt = 0;
+        const int nn = *cnt;
+        if (tid == 0) s_cnt[(step + 1) & 1] = 0;  // read last a hop ago, two barriers back
+        have_pf = false;
         for (int t = tid; t < nn; t += THREADS) {
             int2* slot = t < qcap ? &nl[t] : &ng[t - qcap];
             const int v = slot->x;
+            if (t == tid && can_pf && step + 1 < max_step) {
+                const int32_t* Iv = I + (size_t)v * K;
+                const float* Dv = D + (size_t)v * K;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    pv[c] = *reinterpret_cast<const int4*>(Iv + 4 * c);
+                    pd[c] = *reinterpret_cast<const float4*>(Dv + 4 * c);
+                }
+                have_pf = true;
+            }
             const unsigned long long kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int di = (int)(unsigned)(kk & 0xffffffffull);
             g[v] = __int_as_float(di);
             slot->y = di;
             atomicOr(&visited[v >> 5], 1u << (v & 31));
         }
-        __syncthreads();
+        // the next hop reads the queue and the bitmaps (LDS); only a frontier that spilled into global memory needs
+        // the stores themselves to have landed
+        if (nn > qcap) __syncthreads();
+        else bfs_lds_barrier();
         int2* t1 = cl; cl = nl; nl = t1;
         int2* t2 = cg; cg = ng; ng = t2;
         ncur = nn;

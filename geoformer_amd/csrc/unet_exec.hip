@@ -13,9 +13,10 @@
 //   * one host wait for the chain's voxel counts (an event behind an async copy into pinned memory), taken after
 //     the level-1 work has been queued,
 //   * the output BatchNorm + ReLU in the epilogue of the last convolution.
-#include <mutex>
+#include <vector>
 
 #include "common.h"
+#include "geoformer_hip_dev.h"
 
 namespace {
 
@@ -96,7 +97,74 @@ void carve_level(Bump& a, LevelBufs& b, size_t rows, size_t C, bool transformer,
     }
 }
 
+// ---- measurement hook (include/geoformer_hip_dev.h): events around the convolution launches ----
+__global__ void k_count_rules(const int32_t* __restrict__ tbl, int K, int ld, int M, int* __restrict__ out) {
+    int c = 0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (long long)K * M; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / M), o = (int)(i - (long long)k * M);
+        c += tbl[(size_t)k * ld + o] >= 0;
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+struct ProbeRec {
+    int level, kind, K, Cin, Cout, M_in, M_out, res, slot;
+    hipEvent_t a, b;
+};
+struct Probe {
+    int mode = 0;
+    std::vector<ProbeRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    int* d_counts = nullptr;  // rule counts of the tables seen in "every conv" mode
+    int nslots = 0;
+    hipEvent_t ev() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+};
+thread_local Probe t_probe;
+constexpr int kProbeSlots = 4096;
+
 }  // namespace
+
+extern "C" int gf_dev_unet_probe(int mode) {
+    GF_CHECK_ARG(mode >= 0 && mode <= 2, "gf_dev_unet_probe: mode %d (0 off, 1 level-1 block convs, 2 every conv)", mode);
+    t_probe.mode = mode;
+    if (mode == 2 && !t_probe.d_counts) GF_TRY(hipMalloc(&t_probe.d_counts, kProbeSlots * sizeof(int)));
+    return GF_OK;
+}
+
+// meta: max_records x 9 ints (level, kind, K, Cin, Cout, M_in, M_out, residual, rules or -1); us: max_records floats.
+// Waits for the recorded events; returns the number of records (clears them), or a negative status.
+extern "C" int gf_dev_unet_probe_read(int max_records, int* meta, float* us) {
+    Probe& pb = t_probe;
+    std::vector<int> counts;
+    if (pb.nslots > 0) {
+        counts.resize(pb.nslots);
+        GF_TRY(hipDeviceSynchronize());
+        GF_TRY(hipMemcpy(counts.data(), pb.d_counts, sizeof(int) * pb.nslots, hipMemcpyDeviceToHost));
+    }
+    int n = 0;
+    for (const ProbeRec& r : pb.recs) {
+        if (n >= max_records) break;
+        GF_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        GF_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        int* m = meta + (size_t)n * 9;
+        m[0] = r.level; m[1] = r.kind; m[2] = r.K; m[3] = r.Cin; m[4] = r.Cout; m[5] = r.M_in; m[6] = r.M_out; m[7] = r.res;
+        m[8] = r.slot >= 0 ? counts[r.slot] : -1;
+        us[n++] = ms * 1e3f;
+    }
+    pb.recs.clear();
+    pb.used = 0;
+    pb.nslots = 0;
+    return n;
+}
 
 // int32/byte size of everything gf_unet_fwd carves out of its workspace (capacity bounds, no device access)
 static size_t unet_layout(const GfUnetParams* P, int M0, int B, int X, int Y, int Z, long long* offs, int* caps,
@@ -219,33 +287,54 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
     carve(0);
     float* x16 = a.take<float>((size_t)ld0 * 16);
 
+    // every convolution of the call goes through here (kind: 0 input, 1 / 2 first / second conv of a block, 3 its
+    // 1x1x1 identity branch, 4 strided, 5 inverse); the dev probe, when armed, brackets the launch with two events
+    auto conv = [&](int l, int kind, const float* in, const float* wp, const int32_t* nbr, const uint32_t* gmask,
+                    const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* sc,
+                    const float* sh, const float* res, const float* osc, const float* osh, float* outp) -> int {
+        Probe& pb = t_probe;
+        const bool rec = pb.mode == 2 || (pb.mode == 1 && l == 0 && (kind == 1 || kind == 2) && Cin == 16 && Cout == 16);
+        if (!rec) return gf_conv_fwd(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp, st);
+        ProbeRec r{l, kind, K, Cin, Cout, M_in, M_out, res != nullptr, -1, pb.ev(), pb.ev()};
+        GF_CHECK_ARG(r.a && r.b, "gf_unet_fwd: probe events");
+        if (pb.mode == 2 && nbr && pb.nslots < kProbeSlots && M_out > 0) {
+            r.slot = pb.nslots++;
+            GF_TRY(hipMemsetAsync(pb.d_counts + r.slot, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_count_rules, dim3(256), dim3(256), 0, st, nbr, K, ld, M_out, pb.d_counts + r.slot);
+        }
+        GF_TRY(hipEventRecord(r.a, st));
+        const int rc_ = gf_conv_fwd(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp, st);
+        GF_TRY(hipEventRecord(r.b, st));
+        pb.recs.push_back(r);
+        return rc_;
+    };
+    // pre-activation residual block = the launches of gf_resblock_fwd (spconv_conv.hip): 1x1x1 identity branch when the
+    // widths differ, first conv with bn0+ReLU on its input and bn1+ReLU on its output, second conv + residual; the
+    // block whose output feeds the output layer carries that BatchNorm + ReLU in its last epilogue (osc, osh)
     auto resblock = [&](const GfResBlockParams& rb, int l, int cin, const float* x, float* outp, const float* osc,
                         const float* osh) -> int {
         const int C = P->level[l].C;
         const LevelTables& t = T[l];
         GF_CHECK_ARG(rb.wp0 && rb.wp1 && rb.s0 && rb.t0 && rb.s1 && rb.t1, "gf_unet_fwd: level %d: block parameters missing", l);
         GF_CHECK_ARG((rb.wpi != nullptr) == (cin != C), "gf_unet_fwd: level %d: identity-branch weights must exist iff the widths differ", l);
-        if (!osc) return gf_resblock_fwd(x, rb.wp0, rb.wp1, rb.wpi, t.nbr, t.gmask, t.steps, 27, M[l], t.ld, cin, C, rb.s0,
-                                         rb.t0, rb.s1, rb.t1, Bf[l].tmp, rb.wpi ? Bf[l].idn : nullptr, outp, st);
-        // the block whose output feeds the output layer: same three launches, BatchNorm + ReLU in the last epilogue
         int r;
         if (rb.wpi) {
-            r = gf_conv_fwd(x, rb.wpi, nullptr, nullptr, nullptr, 1, M[l], M[l], 0, cin, C, nullptr, nullptr, nullptr,
-                            nullptr, nullptr, Bf[l].idn, st);
+            r = conv(l, 3, x, rb.wpi, nullptr, nullptr, nullptr, 1, M[l], M[l], 0, cin, C, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, Bf[l].idn);
             if (r != GF_OK) return r;
         }
-        r = gf_conv_fwd(x, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, rb.s0, rb.t0, nullptr, rb.s1,
-                        rb.t1, Bf[l].tmp, st);
+        r = conv(l, 1, x, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, rb.s0, rb.t0, nullptr, rb.s1, rb.t1,
+                 Bf[l].tmp);
         if (r != GF_OK) return r;
-        return gf_conv_fwd(Bf[l].tmp, rb.wp1, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, C, C, nullptr, nullptr,
-                           rb.wpi ? Bf[l].idn : x, osc, osh, outp, st);
+        return conv(l, 2, Bf[l].tmp, rb.wp1, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, C, C, nullptr, nullptr,
+                    rb.wpi ? Bf[l].idn : x, osc, osh, outp);
     };
 
     {
         const int n = M0 * 16;
         hipLaunchKernelGGL(k_pad_channels, dim3(gf_div_up(n, 256)), dim3(256), 0, st, feats, M0, P->cin, 16, x16);
-        UN_TRY(gf_conv_fwd(x16, P->input_wp, T[0].nbr, T[0].gmask, T[0].steps, 27, M0, M0, ld0, 16, 16, nullptr, nullptr,
-                           nullptr, nullptr, nullptr, Bf[0].x, st));
+        UN_TRY(conv(0, 0, x16, P->input_wp, T[0].nbr, T[0].gmask, T[0].steps, 27, M0, M0, ld0, 16, 16, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, Bf[0].x));
     }
     const bool single = P->nlevels == 1;
     UN_TRY(resblock(P->level[0].blocks[0], 0, 16, Bf[0].x, Bf[0].o0, nullptr, nullptr));
@@ -282,8 +371,8 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
         GF_CHECK_ARG(L.down_wp && L.down_s && L.down_t && L.up_wp && L.up_s && L.up_t,
                      "gf_unet_fwd: level %d: strided / inverse conv parameters missing", l);
         // BN + ReLU + SparseConv3d(k=2, s=2): child table of the chain
-        return gf_conv_fwd(Bf[l].o1, L.down_wp, cws + o[4], (const uint32_t*)(cws + o[8]), nullptr, 8, M[l], M[l + 1],
-                           caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x, st);
+        return conv(l, 4, Bf[l].o1, L.down_wp, cws + o[4], (const uint32_t*)(cws + o[8]), nullptr, 8, M[l], M[l + 1],
+                    caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x);
     };
     auto two_blocks = [&](int l) -> int {
         const GfUnetLevelParams& L = P->level[l];
@@ -342,8 +431,8 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
         } else {
             const long long* o = offs + l * 10;
             // BN + ReLU + SparseInverseConv3d: the one-hot `up` table of the chain; rows without a coarse cell stay zero
-            UN_TRY(gf_conv_fwd(Bf[l + 1].o2, L.up_wp, cws + o[7], (const uint32_t*)(cws + o[9]), nullptr, 8, M[l + 1], M[l],
-                               caps[l], P->level[l + 1].C, L.C, L.up_s, L.up_t, nullptr, nullptr, nullptr, Bf[l].up, st));
+            UN_TRY(conv(l, 5, Bf[l + 1].o2, L.up_wp, cws + o[7], (const uint32_t*)(cws + o[9]), nullptr, 8, M[l + 1], M[l],
+                        caps[l], P->level[l + 1].C, L.C, L.up_s, L.up_t, nullptr, nullptr, nullptr, Bf[l].up));
             if (M[l] > 0) {
                 const int c4 = L.C / 4, n = M[l] * 2 * c4;
                 hipLaunchKernelGGL(k_concat2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)Bf[l].o1,

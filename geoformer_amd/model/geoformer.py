@@ -46,6 +46,7 @@ voxelization = _Voxelization.apply
 
 import threading
 
+_BFS_WG = int(os.environ.get("GF_BFS_WG", "256"))  # threads per query of the BFS launched beside the sampling
 _OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
 
 
@@ -452,7 +453,7 @@ class GeoFormer(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 D, I, deg = graphs[b][:3]
-                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=256 if split else 1024)
+                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_BFS_WG if split else 1024)
                 g.record_stream(main)
                 src.record_stream(side)
                 geo.append(g)

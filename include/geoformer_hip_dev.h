@@ -37,6 +37,16 @@ int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe);
  * at most 4096; 0 = default (2048 = 8 waves per compute unit). */
 int gf_dev_conv_chunks(int n);
 
+/* Events around the convolution launches of gf_unet_fwd, recorded on the stream the kernels run on (bench.py's
+ * roofline probes).  mode 0 = off, 1 = the level-1 3x3x3 16->16 convolutions of the residual blocks, 2 = every
+ * convolution (+ a counting kernel per table for the number of rules).  State is per host thread.
+ * gf_dev_unet_probe_read waits for the events and returns the number of records (at most max_records) and clears
+ * them: meta[9*i..] = level (0-based), kind (0 input conv, 1 / 2 first / second conv of a block, 3 identity 1x1x1,
+ * 4 strided, 5 inverse), K, Cin, Cout, M_in, M_out, residual epilogue (0/1), rules (-1 when not counted);
+ * us[i] = microseconds between the two events. */
+int gf_dev_unet_probe(int mode);
+int gf_dev_unet_probe_read(int max_records, int* meta, float* us);
+
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);
 
