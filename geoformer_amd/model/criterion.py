@@ -1,9 +1,17 @@
-"""Set criterion of the training step (criterion.py:116-245, model/matcher.py:79-126), stock PyTorch + scipy.
+"""Set criterion of the training step (criterion.py:116-245, model/matcher.py:79-126).
 
-Stays on the framework side of the boundary: semantic cross-entropy, Hungarian
-matching on the host over a (class + dice) cost, then dice + focal + classification losses per decoder
-layer.  Same loss definitions and weights as the reference; the matching cost is computed with one
-matmul instead of the reference's [nq * n_inst, N] repeat (matcher.py:102-105), which is the same number.
+Semantic cross-entropy, Hungarian matching over a (class + dice) cost, then dice + focal + classification
+losses per decoder layer.  Same loss definitions and weights as the reference; the matching cost is computed
+with one matmul instead of the reference's [nq * n_inst, N] repeat (matcher.py:102-105), which is the same number.
+
+Two routes to the same numbers (tests/test_criterion_golden.py pins both to the reference's own criterion):
+  * host route (CPU tensors, or GF_DEVICE_CRITERION=0): per scene the ground-truth instances are listed with
+    torch.unique / nonzero and the cost matrix goes to scipy.optimize.linear_sum_assignment like the reference does
+    -- about ten device synchronisations per scene and step;
+  * device route (CUDA tensors): instances are addressed by their id inside the scene's id
+    range (one read-back per STEP gives the ranges), the assignment is solved by gf_lsap (csrc/lsap.hip: scipy's
+    algorithm, float64, same tie-breaking), losses run over the fixed-size instance axis with the unmatched rows
+    masked out, and every reported number leaves the device in ONE copy at the end.
 """
 from __future__ import annotations
 
@@ -13,6 +21,98 @@ import torch.nn.functional as F
 from scipy.optimize import linear_sum_assignment
 
 from . import config as _config
+
+
+def _device_route(t):
+    import os
+
+    return t.is_cuda and os.environ.get("GF_DEVICE_CRITERION", "1") != "0"
+
+
+class DeviceMatch:
+    """Ground truth and assignment of one scene, all on the device.  The instance axis has K entries = the scene's id
+    range [lo, lo + K); `present` marks the ids that occur among the scene's (sub-sampled) foreground points."""
+
+    __slots__ = ("inst_masks", "sem_labels", "present", "match_q", "match_of_q", "n_match", "status", "lo")
+
+    def to_reference(self):
+        """(rows, inst_masks[cols], sem_labels[cols]) as HungarianMatcher.forward_seg_single returns them
+        (model/matcher.py:124-126): rows ascending, on the host.  Synchronises; for tests and debugging."""
+        if int(self.status) != 0:
+            raise RuntimeError(f"gf_lsap status {int(self.status)}")
+        mq = self.match_of_q.cpu().numpy()
+        rows = (mq >= 0).nonzero()[0]
+        cols = torch.from_numpy(mq[rows]).long().to(self.inst_masks.device)
+        return rows, self.inst_masks[cols], self.sem_labels[cols]
+
+
+@torch.no_grad()
+def device_match(mask_logit, sem_logit, inst, sem, lo, K, n_queries, fewshot=False):
+    """Matching of one scene without leaving the device.  inst / sem: instance ids (-100 = none) and semantic labels of
+    the scene's points; [lo, lo + K) the scene's id range (host integers)."""
+    from .. import _lib
+    from .._lib import check, ptr, stream_ptr
+
+    dev = mask_logit.device
+    m = DeviceMatch()
+    m.lo = lo
+    n_mask = inst.shape[0]
+    local = inst - lo
+    ids = torch.arange(K, device=dev)
+    m.inst_masks = (local[None, :] == ids[:, None]).float()  # [K, n_mask]; ids outside the range (-100) match nothing
+    counts = m.inst_masks.sum(-1)
+    m.present = (counts > 0).int()
+    # semantic label of the instance's first point (matcher.py:96)
+    first = torch.where(m.inst_masks > 0, torch.arange(n_mask, device=dev)[None, :], n_mask).amin(1).clamp(max=n_mask - 1)
+    m.sem_labels = sem[first].float()
+    prob = mask_logit.sigmoid()
+    numerator = 2 * prob @ m.inst_masks.t()
+    denominator = prob.sum(-1)[:, None] + counts[None, :]
+    cost = 1 - (numerator + 1) / (denominator + 1)
+    if not fewshot:
+        cls = torch.softmax(sem_logit, dim=-1)
+        cost = cost - torch.gather(cls, 1, m.sem_labels[None].expand(n_queries, K).long().clamp(min=0))
+    cost = cost.contiguous()
+    m.match_q = torch.empty(K, dtype=torch.int32, device=dev)
+    m.match_of_q = torch.empty(n_queries, dtype=torch.int32, device=dev)
+    m.n_match = torch.empty(1, dtype=torch.int32, device=dev)
+    m.status = torch.empty(1, dtype=torch.int32, device=dev)
+    check(_lib.load().gf_lsap(ptr(cost), n_queries, K, ptr(m.present), ptr(m.match_q), ptr(m.match_of_q), ptr(m.n_match),
+                              ptr(m.status), stream_ptr()), "gf_lsap")
+    return m
+
+
+def scene_id_ranges(instance_masked, counts):
+    """Per scene (lo, K) of the instance ids among its points -- the one read-back of the device route.  counts: points
+    per scene (host integers, scenes contiguous)."""
+    big = torch.iinfo(instance_masked.dtype).max
+    stats, s = [], 0
+    for n in counts:
+        seg = instance_masked[s:s + n]
+        s += n
+        if n == 0:
+            stats.append(instance_masked.new_tensor([0, -1]))
+            continue
+        valid = seg >= 0
+        stats.append(torch.stack([torch.where(valid, seg, big).amin(), torch.where(valid, seg, -1).amax()]))
+    out = []
+    for lo, hi in torch.stack(stats).tolist():
+        out.append((int(lo), int(hi - lo + 1)) if hi >= 0 else (0, 1))  # no instance at all: one absent slot
+    return out
+
+
+def masked_pair_losses(mask_logit_b, m, n):
+    """dice and focal loss sums over the matched (query, instance) pairs of one scene, unmatched instance rows masked
+    out; n = number of pairs as a device scalar (compute_dice_loss / compute_sigmoid_focal_loss on the matched rows)."""
+    valid = (m.match_q >= 0).float()
+    pred = mask_logit_b[m.match_q.clamp(min=0).long()]  # [K, n_mask]
+    tgt = m.inst_masks
+    p = pred.sigmoid()
+    dice = 1 - (2 * (p * tgt).sum(1) + 1) / (p.sum(-1) + tgt.sum(-1) + 1)
+    ce = F.binary_cross_entropy_with_logits(pred, tgt, reduction="none")
+    p_t = p * tgt + (1 - p) * (1 - tgt)
+    focal = ((0.25 * tgt + 0.75 * (1 - tgt)) * ce * ((1 - p_t) ** 2)).mean(1)
+    return (dice * valid).sum() / (n + 1e-6), (focal * valid).sum() / (n + 1e-6)
 
 
 def compute_dice_loss(inputs, targets, num_boxes):
@@ -103,6 +203,72 @@ class InstSetCriterion(nn.Module):
             loss = loss + loss_dict[k]
         return loss, loss_dict, num_gt
 
+    def _layer_loss_device(self, mask_prediction, matches):
+        """single_layer_loss over the device matches (None entries: scenes the reference skips)."""
+        dev = mask_prediction["cls_logits"].device
+        mask_logits_list, cls_logits = mask_prediction["mask_logits"], mask_prediction["cls_logits"]
+        loss_dict = {k: torch.zeros((), device=dev) for k in self.loss_weight}
+        for b in range(self.batch_size):
+            m = matches[b]
+            if m is None:
+                continue
+            n = m.n_match[0].float()
+            dice, focal = masked_pair_losses(mask_logits_list[b], m, n)
+            loss_dict["dice_loss"] = loss_dict["dice_loss"] + dice
+            loss_dict["focal_loss"] = loss_dict["focal_loss"] + focal
+            # class targets: 0 for unmatched queries, the instance's class for matched ones (criterion.py:170-173)
+            valid = m.match_q >= 0
+            cls_label = torch.zeros(self.n_queries + 1, device=dev)
+            cls_label.scatter_(0, torch.where(valid, m.match_q, self.n_queries).long(), m.sem_labels)
+            loss_dict["cls_loss"] = loss_dict["cls_loss"] + F.cross_entropy(cls_logits[b], cls_label[:-1].long())
+        loss = torch.zeros((), device=dev)
+        for k, w in self.loss_weight.items():
+            loss_dict[k] = loss_dict[k] * w / self.batch_size
+            loss = loss + loss_dict[k]
+        return loss, loss_dict
+
+    def _forward_device(self, model_outputs, semantic_loss, semantic_labels, instance_labels):
+        cfg = self.cfg
+        preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
+        instance_masked, semantic_masked = instance_labels[fg_idxs], semantic_labels[fg_idxs]
+        last = preds[-1]["mask_logits"]
+        counts = [0 if last[b] is None else int(last[b].shape[1]) for b in range(self.batch_size)]
+        assert sum(counts) == instance_masked.shape[0], "scenes must be contiguous in fg_idxs / batch_idxs"
+        ranges = scene_id_ranges(instance_masked, counts)  # read-back 1 of 2
+        matches, s = [], 0
+        for b in range(self.batch_size):
+            n_b = counts[b]
+            if last[b] is None or n_b == 0:
+                matches.append(None)
+            else:
+                lo, K = ranges[b]
+                matches.append(device_match(last[b].detach(), preds[-1]["cls_logits"][b].detach(),
+                                            instance_masked[s:s + n_b], semantic_masked[s:s + n_b], lo, K, self.n_queries))
+            s += n_b
+        self.device_matches = matches
+        main, ld = self._layer_loss_device(preds[-1], matches)
+        loss = semantic_loss + main
+        for l in range(cfg.dec_nlayers - 1):  # auxiliary losses reuse the matching of the last layer
+            loss = loss + self._layer_loss_device(preds[l], matches)[0]
+        live = [m for m in matches if m is not None]
+        zero = torch.zeros(1, dtype=torch.int32, device=loss.device)
+        num_gt = torch.cat([m.n_match for m in live]).sum() if live else zero.sum()
+        status = torch.cat([m.status for m in live]).amax() if live else zero.sum()
+        vals = torch.stack([ld["focal_loss"].detach(), ld["dice_loss"].detach(), ld["cls_loss"].detach(),
+                            semantic_loss.detach(), loss.detach(), num_gt.float(), status.float()]).tolist()  # 2 of 2
+        if vals[6] != 0:
+            raise RuntimeError(f"gf_lsap status {int(vals[6])} (1: more than 512 x 1024 queries x instances, "
+                               "2: non-finite costs)")
+        n, num_gt = semantic_labels.shape[0], int(vals[5])
+        out = {"focal_loss": (vals[0], num_gt), "dice_loss": (vals[1], num_gt), "cls_loss": (vals[2], self.n_queries),
+               "sem_loss": (vals[3], n), "loss": (vals[4], n)}
+        return loss, out
+
+    @property
+    def matches_reference_format(self):
+        """The last device matching in the host route's `cached` format (synchronises)."""
+        return [(None, None, None) if m is None else m.to_reference() for m in self.device_matches]
+
     def forward(self, model_outputs, batch_inputs, epoch):
         cfg = self.cfg
         semantic_scores = model_outputs["semantic_scores"]
@@ -118,6 +284,8 @@ class InstSetCriterion(nn.Module):
             out["sem_loss"] = (semantic_loss.item(), n)
             out["loss"] = (loss.item(), n)
             return loss, out
+        if _device_route(semantic_scores):
+            return self._forward_device(model_outputs, semantic_loss, semantic_labels, instance_labels)
         preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
         instance_masked, semantic_masked = instance_labels[fg_idxs], semantic_labels[fg_idxs]
         batch_ids = model_outputs["batch_idxs"]

@@ -203,6 +203,21 @@ int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int32_t* coords
                 void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream);
 
 /* ===================================================================================
+ * Training criterion: Hungarian matching on the device (model/matcher.py:79-126 moves the cost matrix to the host
+ * and calls scipy.optimize.linear_sum_assignment per scene)
+ * =================================================================================== */
+
+/* Linear sum assignment of queries to ground-truth instances, minimising the total cost.
+ *   cost fp32 [nq, K] row-major (device); present int32 [K]: instances that take part (ascending order = the column
+ *   order scipy sees); out: match_q int32 [K] = query assigned to instance k (-1: absent or left over),
+ *   match_of_q int32 [nq] = instance of query q (-1: none), n_match int32 [1] = min(nq, number present),
+ *   status int32 [1]: 0 ok, 1 problem larger than the kernel's tables (512 x 1024), 2 infeasible (non-finite costs).
+ * Same solver as scipy (shortest augmenting paths in float64, same scan order and tie-breaking, transposed when there
+ * are fewer instances than queries), so the assignment equals scipy's on the same fp32 matrix. */
+int gf_lsap(const float* cost, int nq, int K, const int32_t* present, int32_t* match_q, int32_t* match_of_q,
+            int32_t* n_match, int32_t* status, void* stream);
+
+/* ===================================================================================
  * PG_OP (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-23)
  * =================================================================================== */
 

@@ -43,7 +43,8 @@ def _check(z, name, loss, ld, crit, case, sem, cls, ml, sim, B, NL, fs):
     for b in range(B):
         if pre + f"match_rows_{b}" not in z.files:
             continue
-        rows, gm, sc = crit.cached[b]
+        cached = crit.matches_reference_format if getattr(crit, "device_matches", None) else crit.cached
+        rows, gm, sc = cached[b]
         assert (np.asarray(rows) == z[pre + f"match_rows_{b}"]).all()  # same assignment
         assert (gm.sum(1).cpu().numpy() == z[pre + f"match_gt_npoints_{b}"]).all()
         first = np.array([int(torch.nonzero(r)[0]) for r in gm])
@@ -107,8 +108,56 @@ def test_fs_inst_set_criterion_matches_reference():
 
 
 @pytest.mark.gpu
-def test_criteria_match_reference_on_gpu():
+@pytest.mark.parametrize("route", ["device", "host"])
+def test_criteria_match_reference_on_gpu(route, monkeypatch):
+    """device: matching by gf_lsap and masked losses without per-scene read-backs (csrc/lsap.hip, criterion.py);
+    host: the scipy route on CUDA tensors.  Both against the reference's fixtures."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    monkeypatch.setenv("GF_DEVICE_CRITERION", "1" if route == "device" else "0")
     _std("cuda")
     _fs("cuda")
+
+
+@pytest.mark.gpu
+def test_lsap_equals_scipy():
+    """gf_lsap against scipy.optimize.linear_sum_assignment on the same fp32 matrices: more queries than instances
+    (the training shape, transposed inside), more instances than queries, square, absent instances, and integer-valued
+    costs full of ties (where the scan order and the tie-breaking rule decide the assignment)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from scipy.optimize import linear_sum_assignment
+
+    from geoformer_amd import _lib
+    from geoformer_amd._lib import check, ptr, stream_ptr
+
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    cases = [(128, 7, 0), (128, 40, 5), (32, 32, 0), (16, 50, 3), (256, 1, 0), (128, 64, 64), (8, 300, 17), (300, 9, 2)]
+    for nq, K, absent in cases:
+        for ties in (False, True):
+            cost = rng.integers(0, 4, (nq, K)).astype(np.float32) if ties else rng.standard_normal((nq, K)).astype(np.float32)
+            present = np.ones(K, np.int32)
+            if absent:
+                present[rng.choice(K, min(absent, K), replace=False)] = 0
+            c = torch.from_numpy(cost).cuda()
+            pr = torch.from_numpy(present).cuda()
+            mq = torch.empty(K, dtype=torch.int32, device="cuda")
+            moq = torch.empty(nq, dtype=torch.int32, device="cuda")
+            nm = torch.empty(1, dtype=torch.int32, device="cuda")
+            st = torch.empty(1, dtype=torch.int32, device="cuda")
+            check(lib.gf_lsap(ptr(c), nq, K, ptr(pr), ptr(mq), ptr(moq), ptr(nm), ptr(st), stream_ptr()), "gf_lsap")
+            assert int(st) == 0
+            cols_present = np.nonzero(present)[0]
+            if cols_present.size == 0:
+                assert int(nm) == 0 and (mq.cpu().numpy() == -1).all()
+                continue
+            rows, cols = linear_sum_assignment(cost[:, cols_present])
+            ref = np.full(nq, -1, np.int64)
+            ref[rows] = cols_present[cols]
+            got = moq.cpu().numpy()
+            assert (got == ref).all(), (nq, K, absent, ties)
+            assert int(nm) == rows.size
+            inv = np.full(K, -1, np.int64)
+            inv[cols_present[cols]] = rows
+            assert (mq.cpu().numpy() == inv).all()

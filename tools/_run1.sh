@@ -1,4 +1,2 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/x5
-for wg in 256 512 256 512; do
-GF_BFS_WG=$wg timeout 600 python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-secondary > gpurun_out/x5/b_$wg.log 2>&1; echo "wg $wg rc $?: $(grep '^{' gpurun_out/x5/b_$wg.log | cut -c1-120)"; tail -2 gpurun_out/x5/b_$wg.log | cut -c1-300 | grep -v '^{'
-done
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/x6
+timeout 900 python -m pytest tests/test_criterion_golden.py tests/test_training_step.py -x -q -m gpu > gpurun_out/x6/test.log 2>&1; echo "pytest rc $?"; tail -25 gpurun_out/x6/test.log
