@@ -121,9 +121,10 @@ def voxelize_host(locs: np.ndarray, mode: int = 4):
     return voxel_locs, p2v, v2p
 
 
-def make_batch(scenes, scale: int = 50, full_scale_min: int = 128, mode: int = 4):
-    """Batch dict as built by ``datasets/scannetv2_inst.py:testMerge/trainMerge`` (CPU numpy
-    arrays / torch tensors are produced by the caller).  ``scenes`` is a list of make_scene()."""
+def collate_raw(scenes, scale: int = 50, full_scale_min: int = 128):
+    """The collate step of ``datasets/scannetv2_inst.py:testMerge/trainMerge`` without the voxelisation: per-point
+    tensors, offsets, spatial shape.  ``scenes`` is a list of make_scene().  ``geoformer_amd.feeder.DeviceFeeder``
+    uploads such a dict and voxelises it on the GPU; ``make_batch`` voxelises on the host."""
     import torch
 
     locs, locs_float, feats, labels, insts, offsets, mins, maxs = [], [], [], [], [], [0], [], []
@@ -147,12 +148,8 @@ def make_batch(scenes, scale: int = 50, full_scale_min: int = 128, mode: int = 4
         maxs.append(xyz_middle.max(0).astype(np.float32))
     locs = np.concatenate(locs)
     spatial_shape = np.clip(locs.max(0)[1:] + 1, full_scale_min, None)
-    voxel_locs, p2v, v2p = voxelize_host(locs, mode)
     return {
         "locs": torch.from_numpy(locs),
-        "voxel_locs": torch.from_numpy(voxel_locs),
-        "p2v_map": torch.from_numpy(p2v),
-        "v2p_map": torch.from_numpy(v2p),
         "locs_float": torch.from_numpy(np.concatenate(locs_float)),
         "feats": torch.from_numpy(np.concatenate(feats)),
         "labels": torch.from_numpy(np.concatenate(labels)),
@@ -162,3 +159,16 @@ def make_batch(scenes, scale: int = 50, full_scale_min: int = 128, mode: int = 4
         "pc_mins": torch.from_numpy(np.stack(mins)),
         "pc_maxs": torch.from_numpy(np.stack(maxs)),
     }
+
+
+def make_batch(scenes, scale: int = 50, full_scale_min: int = 128, mode: int = 4):
+    """Batch dict as built by ``datasets/scannetv2_inst.py:testMerge/trainMerge`` (CPU numpy
+    arrays / torch tensors are produced by the caller).  ``scenes`` is a list of make_scene()."""
+    import torch
+
+    batch = collate_raw(scenes, scale, full_scale_min)
+    voxel_locs, p2v, v2p = voxelize_host(batch["locs"].numpy(), mode)
+    batch["voxel_locs"] = torch.from_numpy(voxel_locs)
+    batch["p2v_map"] = torch.from_numpy(p2v)
+    batch["v2p_map"] = torch.from_numpy(v2p)
+    return batch
