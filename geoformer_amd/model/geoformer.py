@@ -45,6 +45,7 @@ voxelization = _Voxelization.apply
 
 
 import threading
+import weakref
 
 _BFS_WG = int(os.environ.get("GF_BFS_WG", "256"))  # threads per query of the BFS launched beside the sampling
 _OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
@@ -66,10 +67,22 @@ def get_batch_offsets(batch_idxs, bs, host_only=False):
 
 
 def _offsets_list(t):
-    """Host copy of a small offsets tensor, fetched once per tensor object (each fetch is a device sync)."""
-    if getattr(_OFFS_CACHE, "key", None) is not t:
-        _OFFS_CACHE.key, _OFFS_CACHE.val = t, t.tolist()
-    return _OFFS_CACHE.val
+    """Host copy of a small offsets tensor, fetched once per tensor object (each fetch from the device is a
+    synchronisation: a serving loop that re-uses its batch dicts must not pay it per forward, and one forward reads two
+    different offsets tensors -- the batch's and the foreground's -- alternately)."""
+    if getattr(_OFFS_CACHE, "key", None) is t:
+        return _OFFS_CACHE.val
+    lru = getattr(_OFFS_CACHE, "lru", None)
+    if lru is None:
+        lru = _OFFS_CACHE.lru = {}
+    hit = lru.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    val = t.tolist()
+    if len(lru) > 64:
+        lru.clear()
+    lru[id(t)] = (weakref.ref(t), t._version, val)
+    return val
 
 
 def _tensors_of(obj):
@@ -413,7 +426,14 @@ class GeoFormer(nn.Module):
             if sample:
                 npoint = min(n_b, self.cfg.n_downsampling)
                 # the reference's host draw (same values, same generator state), restated natively: the device idles on it
-                sampling_indices = torch.from_numpy(pointops.legacy_choice(n_b, npoint)).to(locs_float_.device)
+                # (drawn into a pinned buffer of this host thread: the upload is an asynchronous copy on the stream)
+                pin = getattr(_OFFS_CACHE, "draw_pin", None)
+                if pin is None or pin.numel() < npoint:
+                    pin = _OFFS_CACHE.draw_pin = torch.empty(max(npoint, 65536), dtype=torch.int64).pin_memory()
+                drawn = pointops.legacy_choice(n_b, npoint, out=pin.numpy())
+                if drawn.ctypes.data != pin.data_ptr():  # numpy's own route (exotic generator state): stage it
+                    pin.numpy()[:npoint] = drawn
+                sampling_indices = pin[:npoint].to(locs_float_.device, non_blocking=True)
                 self.last_sampling_indices = sampling_indices
                 xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
             else:

@@ -170,9 +170,11 @@ def select_foreground(scores, cls, equal, locs, batch_idxs, feats, feat_rows=Non
     return fg[:n], locs_o[:n], bidx_o[:n], feats_o[:n], scores_o[:n]
 
 
-def legacy_choice(n, k):
+def legacy_choice(n, k, out=None):
     """``np.random.choice(n, k, replace=False)`` on numpy's global legacy generator -- same values, same generator
-    state afterwards -- through the native restatement (csrc/host_draw.hip; about half the host time)."""
+    state afterwards -- through the native restatement (csrc/host_draw.hip; about half the host time).
+    out: optional int64 numpy array of at least k entries to draw into (e.g. the view of a pinned tensor, so that the
+    upload that follows is an asynchronous copy); the first k entries are returned."""
     import ctypes
 
     import numpy as np
@@ -183,11 +185,12 @@ def legacy_choice(n, k):
         return np.random.choice(n, k, replace=False)  # numpy's own argument errors / exotic sizes
     key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
     pos = ctypes.c_int32(int(st[2]))
-    out = np.empty(k, dtype=np.int64)
+    if out is None or out.dtype != np.int64 or out.size < k or not out.flags.c_contiguous:
+        out = np.empty(k, dtype=np.int64)
     check(_lib.load().gf_host_legacy_choice(key.ctypes.data, ctypes.addressof(pos), n, k, out.ctypes.data),
           "gf_host_legacy_choice")
     np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
-    return out
+    return out[:k]
 
 
 # ---- geodesic stage --------------------------------------------------------------------

@@ -217,10 +217,10 @@ def test_two_host_threads_on_their_own_streams_share_one_model(hip):
     draw_lock = threading.Lock()
     orig_choice = __import__("geoformer_amd").pointops.legacy_choice
 
-    def locked_choice(n, k):  # same generator state for every draw: reseed under the lock
+    def locked_choice(n, k, out=None):  # same generator state for every draw: reseed under the lock
         with draw_lock:
             np.random.seed(1)
-            return orig_choice(n, k)
+            return orig_choice(n, k, out=out)
 
     import geoformer_amd.pointops as po
 

@@ -1,3 +1,4 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/x7
-timeout 900 python -m pytest tests/test_gpu_feeder.py -x -q > gpurun_out/x7/test.log 2>&1; echo "pytest rc $?"; tail -5 gpurun_out/x7/test.log
-timeout 600 python tools/feeder_bench.py > gpurun_out/x7/feeder.log 2>&1; tail -5 gpurun_out/x7/feeder.log
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/x8
+for r in 1 2 3; do
+timeout 600 python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-secondary > gpurun_out/x8/b_$r.log 2>&1; echo "rc $?: $(grep '^{' gpurun_out/x8/b_$r.log | cut -c1-120)"
+done
