@@ -427,9 +427,12 @@ class GeoFormer(nn.Module):
                 npoint = min(n_b, self.cfg.n_downsampling)
                 # the reference's host draw (same values, same generator state), restated natively: the device idles on it
                 # (drawn into a pinned buffer of this host thread: the upload is an asynchronous copy on the stream)
-                pin = getattr(_OFFS_CACHE, "draw_pin", None)
+                pins = getattr(_OFFS_CACHE, "draw_pins", None)
+                if pins is None:
+                    pins = _OFFS_CACHE.draw_pins = {}
+                pin = pins.get((main.cuda_stream, b))  # per caller stream: scenes in flight on two streams
                 if pin is None or pin.numel() < npoint:
-                    pin = _OFFS_CACHE.draw_pin = torch.empty(max(npoint, 65536), dtype=torch.int64).pin_memory()
+                    pin = pins[(main.cuda_stream, b)] = torch.empty(max(npoint, 65536), dtype=torch.int64).pin_memory()
                 drawn = pointops.legacy_choice(n_b, npoint, out=pin.numpy())
                 if drawn.ctypes.data != pin.data_ptr():  # numpy's own route (exotic generator state): stage it
                     pin.numpy()[:npoint] = drawn
