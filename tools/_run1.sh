@@ -1,6 +1,2 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/x8
-timeout 600 python bench.py --steps 32 --warmup 8 --no-cpu-baseline > gpurun_out/x8/b.log 2>&1; python3 - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/x8/b.log') if l.startswith('{')][-1])
-print(d['value'], d['secondary'])
-PY
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/x10
+S=$(date +%s); timeout 1200 python -m pytest tests/test_training_step.py -x -q -m gpu -k full_size > gpurun_out/x10/test.log 2>&1; echo "rc $? in $(( $(date +%s) - S )) s"; tail -30 gpurun_out/x10/test.log | grep -v "^\s" | cut -c1-220 | tail -14
