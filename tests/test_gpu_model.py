@@ -162,6 +162,64 @@ def test_geoformer_fs_episode_gpu(hip):
     check_fs_episode(*run_fs_episode("cuda"))
 
 
+def test_geoformer_fs_5shot_episode_gpu_matches_oracle_backend(hip, oracle):
+    """BASELINE config 4 as named: 1-way 5-shot = process_support on five full support scenes, the mean embedding,
+    one GeoFormerFS.forward(..., training=False, support_embeddings=mean) on the query scene (yaml copy with
+    k_shot: 5; test_fs.py:157-174, geoformer_fs.py:424-455).  The GPU episode against the same episode through the
+    oracle's operators on the host: support embeddings, mask / class logits, similarity scores."""
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormerFS, load_config
+    from oracle import cpu_backend
+    from tests.util import synthetic_state_dict
+
+    def dicts():
+        q = scene.make_batch([scene.make_small_scene(8192, 7)])
+        sups = [scene.make_batch([scene.make_small_scene(5000 + 400 * i, 20 + i)]) for i in range(5)]
+        for d in [q] + sups:
+            d["batch_offsets"] = d["offsets"]
+        for d in sups:
+            d["support_masks"] = (d["instance_labels"] >= 0).long()
+        return q, sups
+
+    def episode(device):
+        m = GeoFormerFS(load_config("test_geoformer_fs_scannet.yaml", k_shot=5))
+        m.load_state_dict(synthetic_state_dict(m.state_dict(), 2))
+        m.semantic_linear.bias.data[3] += 1.0
+        m.to(device)
+        m.eval()
+        q, sups = dicts()
+        mv = lambda d: {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}  # noqa: E731
+        cap = []
+        orig = m.get_mask_prediction
+
+        def gmp(*a, **k):
+            r = orig(*a, **k)
+            cap.append(r[-1]["mask_logits"][0].detach().cpu())
+            return r
+
+        m.get_mask_prediction = gmp
+        np.random.seed(11)
+        with torch.no_grad():
+            embs = [m.process_support(mv(d), training=False) for d in sups]
+            emb = torch.stack(embs).mean(0)
+            out = m(None, mv(q), training=False, remember=False, support_embeddings=emb)
+        scores, props = out["proposal_scores"]
+        return (torch.stack(embs).cpu(), out["semantic_scores"].cpu(), m.cache_data[3].cpu(), cap[0],
+                scores.cpu() if len(scores) else torch.zeros(0), props.sum(1).cpu() if len(scores) else torch.zeros(0))
+
+    with cpu_backend.installed():
+        ref = episode("cpu")
+    got = episode("cuda")
+    assert (got[0] - ref[0]).abs().max() < 1e-4  # the five support embeddings
+    assert (got[1] - ref[1]).abs().max() < 1e-4
+    assert torch.equal(got[2], ref[2])  # foreground set
+    assert (got[3] - ref[3]).abs().max() < 2e-4 * max(1.0, float(ref[3].abs().max()))  # mask logits
+    assert got[4].shape == ref[4].shape
+    if len(ref[4]):
+        assert (got[4] - ref[4]).abs().max() < 1e-4
+        assert (got[5] - ref[5]).abs().max() <= 3
+
+
 def test_fused_caches_follow_parameter_updates(hip):
     """The fused inference paths keep derived copies of parameters (folded BatchNorm, packed weights, MLP chains):
     an in-place update (version bump) must be picked up by the next forward, a `.data` edit after
