@@ -155,6 +155,30 @@ def test_output_schema(run):
     assert out["num_insts"] == 256
 
 
+def test_early_exit_branches_gpu(hip):
+    """forward()'s early exits through the fused GPU paths (geoformer.py:423-439,451-452): backbone-only epochs, an
+    EMPTY predicted-foreground set (the fused selection's count read-back is 0; eval, deferred and training mode)."""
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    m = GeoFormer(load_config("test_geoformer_scannet.yaml"))
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 0))
+    m.cuda().eval()
+    batch = _to_dev(scene.make_batch([scene.make_small_scene(6000, 5)]))
+    with torch.no_grad():
+        early = m(batch, m.prepare_epochs, training=False)
+        assert set(early) == {"semantic_scores"}
+        m.semantic_linear.bias[:4] += 1e4  # nothing is predicted as an object class
+        empty = m(batch, 300, training=False)
+        assert empty["mask_predictions"] is None and "proposal_scores" not in empty
+        empty_d = m(batch, 300, training=False, defer_proposals=True)
+        assert empty_d["mask_predictions"] is None
+    m.train()
+    out = m(batch, 300, training=True)
+    assert out["mask_predictions"] is None
+
+
 def test_geoformer_fs_episode_gpu(hip):
     """Few-shot episode (BASELINE config 4 shape, 1-shot) through the HIP operators vs the reference golden."""
     from tests.util import check_fs_episode, run_fs_episode

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_gpu_model.py -x -q -k "early_exit" 2>&1 | tail -25 | cut -c1-200
