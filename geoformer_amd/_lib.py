@@ -37,6 +37,8 @@ def _declare(lib):
         "gf_conv_packed_floats": (c_size_t, [I, I, I]),
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_conv_dual_supported": (I, [I, I, I, I, I]),
+        "gf_conv_fwd_dual": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_dev_conv_fwd_timed": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
         "gf_dev_conv_knobs_g16": (I, [I, I, I, I]),
         "gf_dev_conv_chunks": (I, [I]),

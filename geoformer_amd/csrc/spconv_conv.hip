@@ -790,7 +790,8 @@ __global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float*
                                                       const float* __restrict__ in_shift,
                                                       const float* __restrict__ residual,
                                                       const float* __restrict__ out_scale,
-                                                      const float* __restrict__ out_shift, float* __restrict__ out) {
+                                                      const float* __restrict__ out_shift, float* __restrict__ out,
+                                                      float* __restrict__ out2) {
     constexpr int PHA = NCH == 1 ? GF_STEP_PHA : CONV_G16_PHA2;
     constexpr int NS = PHA * 4;  // steps of the pipelined part
     constexpr int SHIFT = NCH == 1 ? 6 : 7;
@@ -993,10 +994,16 @@ __global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float*
             if (out_scale) {  // epilogue activation: the consumer's BatchNorm + ReLU, once per output element
                 const float4 os = *reinterpret_cast<const float4*>(out_scale + 4 * q);
                 const float4 ot = *reinterpret_cast<const float4*>(out_shift + 4 * q);
+                if (out2) {
+                    // both forms leave the kernel: the raw sum (residual operand of the next block) and the
+                    // activated copy its first convolution gathers from -- one BatchNorm + ReLU per ELEMENT here
+                    // instead of one per GATHERED element (6-10 x more) in that convolution's prologue
+                    *reinterpret_cast<float4*>(out + (size_t)row * 16 + 4 * q) = v;
+                }
                 v.x = fmaxf(fmaf(v.x, os.x, ot.x), 0.f); v.y = fmaxf(fmaf(v.y, os.y, ot.y), 0.f);
                 v.z = fmaxf(fmaf(v.z, os.z, ot.z), 0.f); v.w = fmaxf(fmaf(v.w, os.w, ot.w), 0.f);
             }
-            *reinterpret_cast<float4*>(out + (size_t)row * 16 + 4 * q) = v;
+            *reinterpret_cast<float4*>((out2 ? out2 : out) + (size_t)row * 16 + 4 * q) = v;
         }
 #ifdef CONV_TRACE
         tr[5] += TR_NOW() - tc2;
@@ -1049,7 +1056,8 @@ static void launch_g16(dim3 grid, size_t lds, hipStream_t st, const float* in, c
 template <int NCH, bool LDSW>
 static void launch_g16p(size_t lds, hipStream_t st, const float* in, const float4* Wp, const int32_t* steps,
                         const uint32_t* gmask, int K, int M_out, int ld, unsigned in_bytes, const float* sc,
-                        const float* sh, const float* res, const float* osc, const float* osh, float* out) {
+                        const float* sh, const float* res, const float* osc, const float* osh, float* out,
+                        float* out2) {
     if (LDSW) {
         static bool attr = false;
         if (!attr) {
@@ -1066,7 +1074,7 @@ static void launch_g16p(size_t lds, hipStream_t st, const float* in, const float
     dim3 grid(GF_CONV_CHUNKS_MAX / 4);  // waves of chunks past the table's count leave at once
 #define G16P_LAUNCH(AFF_, RES_)                                                                                       \
     hipLaunchKernelGGL((k_conv_g16p<NCH, AFF_, RES_, LDSW>), grid, dim3(256), lds, st, in, Wp, steps, gmask, chunks,  \
-                       K, M_out, in_bytes, steps_bytes, sc, sh, res, osc, osh, out)
+                       K, M_out, in_bytes, steps_bytes, sc, sh, res, osc, osh, out, out2)
     if (sc && res) G16P_LAUNCH(true, true);
     else if (sc) G16P_LAUNCH(true, false);
     else if (res) G16P_LAUNCH(false, true);
@@ -1174,10 +1182,10 @@ extern "C" int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int bl
     return GF_OK;
 }
 
-extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
-                           const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
-                           const float* in_scale, const float* in_shift, const float* residual,
-                           const float* out_scale, const float* out_shift, float* out, void* stream) {
+static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
+                         const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
+                         const float* in_scale, const float* in_shift, const float* residual,
+                         const float* out_scale, const float* out_shift, float* out, float* out2, void* stream) {
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_fwd: K=%d out of range [1,32]", K);
     GF_CHECK_ARG(Cin >= 1 && Cout >= 1, "gf_conv_fwd: Cin=%d Cout=%d", Cin, Cout);
     GF_CHECK_ARG(in_scale == nullptr || Cin <= CONV_MAX_CIN - 16, "gf_conv_fwd: fused prologue supports Cin <= %d",
@@ -1233,15 +1241,16 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
         if (knobs.g16_pipe >= 0) pipe = pipe && knobs.g16_pipe != 0;
         if (pipe) {
             if (nch == 1) {
-                if (gl) launch_g16p<1, true>(wbytes, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
-                else launch_g16p<1, false>(0, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
+                if (gl) launch_g16p<1, true>(wbytes, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out, out2);
+                else launch_g16p<1, false>(0, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out, out2);
             } else {
-                if (gl) launch_g16p<2, true>(wbytes, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
-                else launch_g16p<2, false>(0, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out);
+                if (gl) launch_g16p<2, true>(wbytes, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out, out2);
+                else launch_g16p<2, false>(0, st, a.in, a.Wp, steps, gmask, K, M_out, ld, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, out, out2);
             }
             GF_CHECK_LAUNCH("gf_conv_fwd");
             return GF_OK;
         }
+        GF_CHECK_ARG(out2 == nullptr, "gf_conv_fwd_dual: this launch shape has no second output");
         int gpw = knobs.g16_gpw > 0 ? knobs.g16_gpw : (gl ? 2 : 1);
         const long long wgs = ((long long)ngroups + 4 * gpw - 1) / (4 * gpw);
         dim3 gg((unsigned)wgs);
@@ -1256,6 +1265,7 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
         GF_CHECK_LAUNCH("gf_conv_fwd");
         return GF_OK;
     }
+    GF_CHECK_ARG(out2 == nullptr, "gf_conv_fwd_dual: this launch shape has no second output");
     GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_fwd: this launch shape needs the [K,ld] neighbour table");
     bool pair = !split && vec && ncb == 1 && nbr != nullptr && K <= 32 && nch <= 8 && in_bytes64 <= 0xfffff000ull - 4096ull;
     if (knobs.pair >= 0) pair = pair && knobs.pair != 0;
@@ -1283,6 +1293,38 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
         dispatch_conv<0>(ncbw, vec, grid, st, a);
     GF_CHECK_LAUNCH("gf_conv_fwd");
     return GF_OK;
+}
+
+extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
+                           const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
+                           const float* in_scale, const float* in_shift, const float* residual,
+                           const float* out_scale, const float* out_shift, float* out, void* stream) {
+    return conv_fwd_impl(in, Wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
+                         out_shift, out, nullptr, stream);
+}
+
+// gf_conv_fwd with TWO outputs: out = the raw sums (+ residual), out_act = max(out*out_scale + out_shift, 0).  The next
+// residual block reads `out` as its residual operand and gathers from `out_act`, which takes the BatchNorm + ReLU out
+// of its first convolution's prologue.  Level-1 shape only (the pipelined counted-loop kernel); gf_conv_dual_supported
+// tells beforehand.
+extern "C" int gf_conv_dual_supported(int M_out, int ld, int Cin, int Cout, int has_steps) {
+    const ConvKnobs& knobs = conv_knobs();
+    const int ngroups = (M_out + 15) / 16;
+    bool split = ngroups < 6000;
+    if (knobs.split >= 0) split = knobs.split != 0;
+    bool g16 = has_steps && Cout == 16 && (Cin == 16 || Cin == 32) && (knobs.g16 >= 0 ? knobs.g16 != 0 : !split);
+    bool pipe = M_out > 0 && ld >= M_out && (knobs.g16_pipe < 0 || knobs.g16_pipe != 0);
+    return g16 && pipe ? 1 : 0;
+}
+extern "C" int gf_conv_fwd_dual(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
+                                const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
+                                const float* in_scale, const float* in_shift, const float* residual,
+                                const float* out_scale, const float* out_shift, float* out, float* out_act, void* stream) {
+    GF_CHECK_ARG(out_act != nullptr && out_scale != nullptr && out_shift != nullptr,
+                 "gf_conv_fwd_dual: the second output needs its scale / shift");
+    GF_CHECK_ARG(((uintptr_t)out_act % 16) == 0, "gf_conv_fwd_dual: out_act must be 16-byte aligned");
+    return conv_fwd_impl(in, Wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
+                         out_shift, out, out_act, stream);
 }
 
 // Pre-activation residual block of the U-Net in one call (ResidualBlock, geoformer_modules.py:10-35, eval):

@@ -75,7 +75,7 @@ thread_local EvPair t_ev;
 constexpr int kStepsMinRows = 6000 * 16;  // gf_conv_fwd takes the counted-loop kernel from 6000 groups up
 
 struct LevelBufs {  // feature buffers of one level, [rows, C] each (cat: [rows, 2C])
-    float *x, *tmp, *idn, *o0, *o1, *o2, *up, *tr, *cat;
+    float *x, *tmp, *idn, *o0, *o1, *o2, *up, *tr, *cat, *a0, *a1;
     void* tr_scratch;
     int32_t* tr_offs;
 };
@@ -89,6 +89,8 @@ void carve_level(Bump& a, LevelBufs& b, size_t rows, size_t C, bool transformer,
     b.up = a.take<float>(rows * C);
     b.tr = a.take<float>(rows * C);
     b.cat = a.take<float>(rows * 2 * C);
+    b.a0 = a.take<float>(rows * C);  // activated copies (dual-output convolutions of the first level)
+    b.a1 = a.take<float>(rows * C);
     b.tr_scratch = nullptr;
     b.tr_offs = nullptr;
     if (transformer) {
@@ -291,10 +293,17 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
     // 1x1x1 identity branch, 4 strided, 5 inverse); the dev probe, when armed, brackets the launch with two events
     auto conv = [&](int l, int kind, const float* in, const float* wp, const int32_t* nbr, const uint32_t* gmask,
                     const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* sc,
-                    const float* sh, const float* res, const float* osc, const float* osh, float* outp) -> int {
+                    const float* sh, const float* res, const float* osc, const float* osh, float* outp,
+                    float* out_act = nullptr) -> int {
         Probe& pb = t_probe;
         const bool rec = pb.mode == 2 || (pb.mode == 1 && l == 0 && (kind == 1 || kind == 2) && Cin == 16 && Cout == 16);
-        if (!rec) return gf_conv_fwd(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp, st);
+        auto launch = [&]() -> int {
+            if (out_act)
+                return gf_conv_fwd_dual(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp,
+                                        out_act, st);
+            return gf_conv_fwd(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp, st);
+        };
+        if (!rec) return launch();
         ProbeRec r{l, kind, K, Cin, Cout, M_in, M_out, res != nullptr, -1, pb.ev(), pb.ev()};
         GF_CHECK_ARG(r.a && r.b, "gf_unet_fwd: probe events");
         if (pb.mode == 2 && nbr && pb.nslots < kProbeSlots && M_out > 0) {
@@ -303,7 +312,7 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
             hipLaunchKernelGGL(k_count_rules, dim3(256), dim3(256), 0, st, nbr, K, ld, M_out, pb.d_counts + r.slot);
         }
         GF_TRY(hipEventRecord(r.a, st));
-        const int rc_ = gf_conv_fwd(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp, st);
+        const int rc_ = launch();
         GF_TRY(hipEventRecord(r.b, st));
         pb.recs.push_back(r);
         return rc_;
@@ -311,36 +320,63 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
     // pre-activation residual block = the launches of gf_resblock_fwd (spconv_conv.hip): 1x1x1 identity branch when the
     // widths differ, first conv with bn0+ReLU on its input and bn1+ReLU on its output, second conv + residual; the
     // block whose output feeds the output layer carries that BatchNorm + ReLU in its last epilogue (osc, osh)
+    // x_act: the block's input already through its bn0 + ReLU (written by the producer's second output): the first
+    // convolution then gathers activated rows and has no prologue.  next: the block after this one wants the same --
+    // (scale, shift) of ITS bn0 and the buffer for the activated copy of this block's output
+    struct NextAct {
+        const float *s, *t;
+        float* buf;
+    };
     auto resblock = [&](const GfResBlockParams& rb, int l, int cin, const float* x, float* outp, const float* osc,
-                        const float* osh) -> int {
+                        const float* osh, const float* x_act = nullptr, const NextAct* next = nullptr) -> int {
         const int C = P->level[l].C;
         const LevelTables& t = T[l];
         GF_CHECK_ARG(rb.wp0 && rb.wp1 && rb.s0 && rb.t0 && rb.s1 && rb.t1, "gf_unet_fwd: level %d: block parameters missing", l);
         GF_CHECK_ARG((rb.wpi != nullptr) == (cin != C), "gf_unet_fwd: level %d: identity-branch weights must exist iff the widths differ", l);
+        GF_CHECK_ARG(!(next && osc), "gf_unet_fwd: a block has one epilogue activation");
         int r;
         if (rb.wpi) {
             r = conv(l, 3, x, rb.wpi, nullptr, nullptr, nullptr, 1, M[l], M[l], 0, cin, C, nullptr, nullptr, nullptr, nullptr,
                      nullptr, Bf[l].idn);
             if (r != GF_OK) return r;
         }
-        r = conv(l, 1, x, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, rb.s0, rb.t0, nullptr, rb.s1, rb.t1,
-                 Bf[l].tmp);
+        if (x_act)
+            r = conv(l, 1, x_act, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, nullptr, nullptr, nullptr, rb.s1,
+                     rb.t1, Bf[l].tmp);
+        else
+            r = conv(l, 1, x, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, rb.s0, rb.t0, nullptr, rb.s1, rb.t1,
+                     Bf[l].tmp);
         if (r != GF_OK) return r;
+        if (next)
+            return conv(l, 2, Bf[l].tmp, rb.wp1, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, C, C, nullptr, nullptr,
+                        rb.wpi ? Bf[l].idn : x, next->s, next->t, outp, next->buf);
         return conv(l, 2, Bf[l].tmp, rb.wp1, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, C, C, nullptr, nullptr,
                     rb.wpi ? Bf[l].idn : x, osc, osh, outp);
     };
+    // the first level's 16 -> 16 convolutions run the pipelined counted-loop kernel, which can write both forms
+    const bool dual0 = gf_conv_dual_supported(M0, ld0, 16, 16, T[0].steps != nullptr) != 0;
 
     {
         const int n = M0 * 16;
         hipLaunchKernelGGL(k_pad_channels, dim3(gf_div_up(n, 256)), dim3(256), 0, st, feats, M0, P->cin, 16, x16);
-        UN_TRY(conv(0, 0, x16, P->input_wp, T[0].nbr, T[0].gmask, T[0].steps, 27, M0, M0, ld0, 16, 16, nullptr, nullptr, nullptr,
-                    nullptr, nullptr, Bf[0].x));
+        const GfResBlockParams& b0 = P->level[0].blocks[0];
+        if (dual0)
+            UN_TRY(conv(0, 0, x16, P->input_wp, T[0].nbr, T[0].gmask, T[0].steps, 27, M0, M0, ld0, 16, 16, nullptr, nullptr, nullptr,
+                        b0.s0, b0.t0, Bf[0].x, Bf[0].a0));
+        else
+            UN_TRY(conv(0, 0, x16, P->input_wp, T[0].nbr, T[0].gmask, T[0].steps, 27, M0, M0, ld0, 16, 16, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, Bf[0].x));
     }
     const bool single = P->nlevels == 1;
-    UN_TRY(resblock(P->level[0].blocks[0], 0, 16, Bf[0].x, Bf[0].o0, nullptr, nullptr));
-    UN_TRY(resblock(P->level[0].blocks[1], 0, 16, Bf[0].o0, single && P->level[0].tr_layers == 0 ? out : Bf[0].o1,
-                    single && P->level[0].tr_layers == 0 ? P->out_s : nullptr,
-                    single && P->level[0].tr_layers == 0 ? P->out_t : nullptr));
+    {
+        const GfResBlockParams& b1 = P->level[0].blocks[1];
+        const NextAct n1{b1.s0, b1.t0, Bf[0].a1};
+        UN_TRY(resblock(P->level[0].blocks[0], 0, 16, Bf[0].x, Bf[0].o0, nullptr, nullptr, dual0 ? Bf[0].a0 : nullptr,
+                        dual0 ? &n1 : nullptr));
+        const bool last = single && P->level[0].tr_layers == 0;
+        UN_TRY(resblock(b1, 0, 16, Bf[0].o0, last ? out : Bf[0].o1, last ? P->out_s : nullptr, last ? P->out_t : nullptr,
+                        dual0 ? Bf[0].a1 : nullptr, nullptr));
+    }
 
     // ---- side stream: the chain of down-sampling rulebooks, queued AFTER the level-1 work (its ~35 launches are
     // 5 us of dispatch each and little else: the device runs them beside the level-1 convolutions; queued first they
@@ -438,10 +474,12 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
                 hipLaunchKernelGGL(k_concat2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)Bf[l].o1,
                                    (const float4*)Bf[l].up, M[l], c4, (float4*)Bf[l].cat);
             }
-            UN_TRY(resblock(L.tail[0], l, 2 * L.C, Bf[l].cat, Bf[l].o0, nullptr, nullptr));
+            const bool dual = l == 0 && dual0;  // tail[0]'s second conv writes tail[1]'s activated input as well
+            const NextAct nt{L.tail[1].s0, L.tail[1].t0, Bf[l].a1};
+            UN_TRY(resblock(L.tail[0], l, 2 * L.C, Bf[l].cat, Bf[l].o0, nullptr, nullptr, nullptr, dual ? &nt : nullptr));
             float* dst = last_tail_is_output ? out : Bf[l].o2;
             UN_TRY(resblock(L.tail[1], l, L.C, Bf[l].o0, dst, last_tail_is_output ? P->out_s : nullptr,
-                            last_tail_is_output ? P->out_t : nullptr));
+                            last_tail_is_output ? P->out_t : nullptr, dual ? Bf[l].a1 : nullptr, nullptr));
             cur = dst;
         }
         if (L.tr_layers > 0) {

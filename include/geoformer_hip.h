@@ -146,6 +146,17 @@ int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr, const uint
                 int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
                 const float* residual, const float* out_scale, const float* out_shift, float* out, void* stream);
 
+/* gf_conv_fwd with two outputs: out = the raw sums (+ residual), out_act = max(out*out_scale + out_shift, 0).  A
+ * pre-activation residual block (geoformer_modules.py:10-35) reads its input twice -- raw as the residual operand,
+ * through BatchNorm + ReLU as the first convolution's input -- so the producer writes both and the consumer's
+ * convolution gathers activated rows (one activation per element instead of one per gathered element).  Implemented for
+ * the level-1 launch shape (16 output channels over a step table); gf_conv_dual_supported() tells beforehand. */
+int gf_conv_dual_supported(int M_out, int ld, int Cin, int Cout, int has_steps);
+int gf_conv_fwd_dual(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, const int32_t* steps,
+                     int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
+                     const float* residual, const float* out_scale, const float* out_shift, float* out, float* out_act,
+                     void* stream);
+
 /* Pre-activation residual block (ResidualBlock, model/geoformer/geoformer_modules.py:10-35) in eval mode, one
  * call:  out = conv1(relu(bn1(conv0(relu(bn0(x)))))) + (Wpi ? x . Wi : x).
  *   x fp32 [M,Cin]; Wp0 (K,Cin,Cout), Wp1 (K,Cout,Cout), Wpi (1,Cin,Cout) or NULL: gf_conv_pack_weights output;
