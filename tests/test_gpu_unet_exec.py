@@ -32,8 +32,9 @@ def _backbone(m, batch, native):
         os.environ.pop("GF_UNET_EXEC", None)
 
 
-@pytest.mark.parametrize("scenes", [[("small", 8192, 5)], [("small", 6000, 7), ("small", 9000, 8)], [("room", 40000, 21)]],
-                         ids=["s8k", "batch2", "room40k"])
+@pytest.mark.parametrize("scenes", [[("small", 8192, 5)], [("small", 6000, 7), ("small", 9000, 8)], [("room", 40000, 21)],
+                                    [("room", 62000, 31), ("room", 58000, 32)]],
+                         ids=["s8k", "batch2", "room40k", "batch2-level1-kernels"])
 def test_unet_exec_matches_module_route(hip, scenes):
     from geoformer_amd import scene, unet_exec
 
