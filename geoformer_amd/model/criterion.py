@@ -235,6 +235,8 @@ class InstSetCriterion(nn.Module):
         counts = [0 if last[b] is None else int(last[b].shape[1]) for b in range(self.batch_size)]
         assert sum(counts) == instance_masked.shape[0], "scenes must be contiguous in fg_idxs / batch_idxs"
         ranges = scene_id_ranges(instance_masked, counts)  # read-back 1 of 2
+        if max(K for _, K in ranges) > 1024:
+            return None  # instance ids spread over a wide range (not the collate's consecutive ids): host route
         matches, s = [], 0
         for b in range(self.batch_size):
             n_b = counts[b]
@@ -285,7 +287,10 @@ class InstSetCriterion(nn.Module):
             out["loss"] = (loss.item(), n)
             return loss, out
         if _device_route(semantic_scores):
-            return self._forward_device(model_outputs, semantic_loss, semantic_labels, instance_labels)
+            res = self._forward_device(model_outputs, semantic_loss, semantic_labels, instance_labels)
+            if res is not None:
+                return res
+            self.device_matches = None
         preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
         instance_masked, semantic_masked = instance_labels[fg_idxs], semantic_labels[fg_idxs]
         batch_ids = model_outputs["batch_idxs"]
