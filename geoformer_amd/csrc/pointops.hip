@@ -386,6 +386,20 @@ __device__ __forceinline__ int fps_code_index(unsigned long long c) {
     return c ? (int)((FPS_KEY_NONE - (unsigned)((c >> 1) & 0x7fffffffull)) & 0x3fffffu) : 0;
 }
 
+#ifdef FPS_TRACE
+// dev build: cycle stamps (s_memtime) of wave 0 of workgroup 0, summed per phase over the exchanges
+__device__ unsigned long long* g_fps_trace = nullptr;
+extern "C" int gf_dev_fps_trace(void* p) {
+    GF_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_fps_trace), &p, sizeof(p)));
+    return GF_OK;
+}
+#define FT() __builtin_amdgcn_s_memtime()
+#define FTA(i, a, b) do { ftr[i] += (b) - (a); } while (0)
+#else
+#define FT() 0ull
+#define FTA(i, a, b) do { } while (0)
+#endif
+
 // Several picks per exchange.  After the distances have absorbed the picks of the previous exchange,
 // the best candidate c1 is the next pick by definition; the runner-up c2 is the pick after that iff
 // c1 does not lower its distance (d(c2,c1) >= tmp[c2]): nobody else can then overtake it, ties
@@ -475,8 +489,12 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
         nz[0] = xyz[(size_t)pl * 3 + 2];
         done = m0;
     }
+#ifdef FPS_TRACE
+    unsigned long long ftr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int round = 1; done < m; round++) {
         const int par = round & 1;
+        const unsigned long long ft0 = FT();
         // 1) absorb the new picks, track this lane's best
         unsigned bd = 0u, bk = FPS_KEY_NONE;
 #pragma unroll
@@ -498,6 +516,8 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                 }
             }
         }
+        const unsigned long long ft1 = FT();
+        FTA(0, ft0, ft1);
         // 2) wave top-2: best, then the owner of the best exposes its runner-up
         unsigned d1 = bd, k1 = bk;
         wave_best(d1, k1);
@@ -525,7 +545,11 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             s_part[par][wid * 2 + 0] = c1;
             s_part[par][wid * 2 + 1] = c2;
         }
+        const unsigned long long ft2 = FT();
+        FTA(1, ft1, ft2);
         __syncthreads();
+        const unsigned long long ft3 = FT();
+        FTA(2, ft2, ft3);
         if (wid == 0) {
             // 3) merge the wave candidates into the workgroup's sorted prefix (<= FPS_KPUB entries)
             unsigned long long mine = lane < FPS_WAVES * 2 ? s_part[par][lane] : 0ull;
@@ -547,6 +571,8 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
 #pragma unroll
             for (int t = 0; t < FPS_KPUB; t++)
                 if (t == cnt - 1) wgc[t] |= 1ull;  // ... and the last one this workgroup forwards
+            const unsigned long long ft4 = FT();
+            FTA(3, ft3, ft4);
             // 4) grid level: publish FPS_KPUB granules, gather everybody's (FPS_NG per lane)
             unsigned long long v[FPS_NG];
             v[0] = wgc[0];
@@ -588,6 +614,8 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < FPS_NG; j++) v[j] = (lane + 64 * j < G * FPS_KPUB) ? (v[j] & ~FPS_TAG) : 0ull;
             }
+            const unsigned long long ft5 = FT();
+            FTA(4, ft4, ft5);
             // coordinates of every gathered candidate, in flight while the merge runs
             float vx[FPS_NG], vy[FPS_NG], vz[FPS_NG];
 #pragma unroll
@@ -605,6 +633,15 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             //    is simply re-ranked, so the exchange keeps going where the prefix rule had to stop (simulated on
             //    the S150k foreground: 174 exchanges for 2048 picks instead of 370).
             static_assert(FPS_NG == 1, "one gathered candidate per lane");
+#ifdef FPS_TRACE
+            {
+                float probe = vx[0];
+                asm volatile("v_mov_b32 %0, %0" : "+v"(probe));
+                vx[0] = probe;
+            }
+#endif
+            const unsigned long long ft6 = FT();
+            FTA(5, ft5, ft6);
             const unsigned long long mine0 = v[0];
             const unsigned long long Bcode = wave_max_u64((mine0 & 1ull) ? (mine0 & ~1ull) : 0ull);
             unsigned ckey = (unsigned)((mine0 >> 1) & 0x7fffffffull);  // KEY_NONE - key
@@ -649,8 +686,13 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                 nacc = t + 1;
             }
             if (lane == 0) s_pick[par][0] = nacc;
+            const unsigned long long ft7 = FT();
+            FTA(6, ft6, ft7);
         }
+        const unsigned long long ft8 = FT();
         __syncthreads();
+        const unsigned long long ft9 = FT();
+        FTA(7, ft8, ft9);
         nnew = s_pick[par][0];
 #pragma unroll
         for (int a = 0; a < FPS_K; a++) {
@@ -659,7 +701,15 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             nz[a] = s_xyz[par][a * 3 + 2];
         }
         done += nnew;
+#ifdef FPS_TRACE
+        ftr[8] += 1;
+        ftr[9] += nnew;
+#endif
     }
+#ifdef FPS_TRACE
+    if (g_fps_trace && wg == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 10; i++) g_fps_trace[i] = ftr[i];
+#endif
 }
 
 template <int P>

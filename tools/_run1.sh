@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_unet_exec.py -x -q 2>&1 | tail -12 | cut -c1-200
+GF_LIB_PATH=geoformer_amd/lib/variants/fpstrace.so timeout 300 python tools/trace_fps.py 2>&1 | tail -34
