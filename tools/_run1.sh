@@ -1,2 +1,4 @@
-cd $GRAFT_REPO_ROOT
-GF_LIB_PATH=geoformer_amd/lib/variants/fpstrace.so timeout 300 python tools/trace_fps.py 2>&1 | tail -34
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/x14
+timeout 900 python -m pytest tests/test_gpu_geodesic.py tests/test_gpu_fullsize.py -x -q -k "bfs or geodesic" 2>&1 | tail -2
+timeout 300 python tools/bench_bfs.py 2>&1 | tail -7
+for r in 1 2; do timeout 300 python bench.py --steps 32 --warmup 8 --no-cpu-baseline --no-secondary > gpurun_out/x14/b.log 2>&1; echo "rc $?: $(grep '^{' gpurun_out/x14/b.log | cut -c1-100)"; done
