@@ -309,6 +309,10 @@ def main():
 
     from geoformer_amd import scene
 
+    if os.environ.get("GF_CONV_CHUNKS"):  # dev knob: waves of the level-1 conv kernel (include/geoformer_hip_dev.h)
+        from geoformer_amd import sparse
+
+        sparse.dev_conv_chunks(int(os.environ["GF_CONV_CHUNKS"]))
     # every rank gets its own scenes: replicas of the same workload
     ns = max(1, args.scenes)
     batches = [to_device(scene.make_batch([scene.make_scene(args.points, 1234 + rank * ns + i)]), dev)

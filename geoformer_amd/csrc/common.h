@@ -12,9 +12,10 @@
 // blocks of four steps per 16-row group; GF_STEP_BLKS * 4 >= 27 offsets; the first GF_STEP_PHA blocks always exist
 #define GF_STEP_BLKS 7
 #define GF_STEP_PHA 3
-// equal-cost chunks of consecutive groups (one per wave of the pipelined level-1 conv kernel: 8 waves on each of
-// the 256 compute units); k_group_chunks writes GF_CONV_CHUNKS + 1 boundaries behind the step table
-#define GF_CONV_CHUNKS 2048      // default number of chunks
+// equal-cost chunks of consecutive groups (one per wave of the pipelined level-1 conv kernel: 12 waves on each of
+// the 256 compute units = 3 per SIMD, what its 131-158 registers allow; 2048 measured 3 % slower per launch in the
+// forward, 3584 15 % slower); k_group_chunks writes GF_CONV_CHUNKS + 1 boundaries behind the step table
+#define GF_CONV_CHUNKS 3072      // default number of chunks
 #define GF_CONV_CHUNKS_MAX 4096  // capacity of the table tail: [count, boundary 0 .. boundary count]
 int gf_conv_chunks();            // current setting (dev knob gf_dev_conv_chunks, spconv_conv.hip)
 

@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_conv_g16(const float* __restrict__ in, 
 // alone adds 8.4 us (365 MFMAs per SIMD at the ~1.9 GHz the chip holds under load = 6.1 us at a fully paced matrix
 // pipe) -- and the full kernel takes the SUM, 20-21 us: every resident wave of a SIMD starts together, so they all
 // wait for memory together and then queue for the matrix pipe together; nothing overlaps.
-// Here a wave owns a CHUNK of consecutive groups of equal total cost (k_group_chunks: 2048 chunks = 8 waves per
+// Here a wave owns a CHUNK of consecutive groups of equal total cost (k_group_chunks: 3072 chunks = 12 waves per
 // compute unit, all resident at once, no tail) and software-pipelines over them: while the MFMAs of group i run,
 // the gathers of group i+1 are in flight and the indices of group i+2 are being fetched.  Every load of the
 // pipeline is issued unconditionally (a missing group or neighbour is index -1 = out of the descriptor's range, no

@@ -34,7 +34,7 @@ int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int block);
 int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe);
 
 /* Number of equal-cost chunks (= waves of the pipelined kernel) the NEXT rulebooks are built with: a multiple of 4,
- * at most 4096; 0 = default (2048 = 8 waves per compute unit). */
+ * at most 4096; 0 = default (3072 = 12 waves per compute unit). */
 int gf_dev_conv_chunks(int n);
 
 /* Events around the convolution launches of gf_unet_fwd, recorded on the stream the kernels run on (bench.py's
