@@ -256,11 +256,17 @@ class InstSetCriterion(nn.Module):
         zero = torch.zeros(1, dtype=torch.int32, device=loss.device)
         num_gt = torch.cat([m.n_match for m in live]).sum() if live else zero.sum()
         status = torch.cat([m.status for m in live]).amax() if live else zero.sum()
+        # the per-scene slices above rely on the model's layout: points of a scene contiguous, scenes in order
+        bids = model_outputs["batch_idxs"]
+        unsorted = (bids[1:] < bids[:-1]).any().float() if bids.numel() > 1 else zero.sum().float()
         vals = torch.stack([ld["focal_loss"].detach(), ld["dice_loss"].detach(), ld["cls_loss"].detach(),
-                            semantic_loss.detach(), loss.detach(), num_gt.float(), status.float()]).tolist()  # 2 of 2
+                            semantic_loss.detach(), loss.detach(), num_gt.float(), status.float(), unsorted]).tolist()  # 2 of 2
         if vals[6] != 0:
             raise RuntimeError(f"gf_lsap status {int(vals[6])} (1: more than 512 x 1024 queries x instances, "
                                "2: non-finite costs)")
+        if vals[7] != 0:
+            raise RuntimeError("device criterion: batch_idxs is not sorted by scene (set GF_DEVICE_CRITERION=0 for "
+                               "the host route, which selects every scene's points with a mask)")
         n, num_gt = semantic_labels.shape[0], int(vals[5])
         out = {"focal_loss": (vals[0], num_gt), "dice_loss": (vals[1], num_gt), "cls_loss": (vals[2], self.n_queries),
                "sem_loss": (vals[3], n), "loss": (vals[4], n)}
