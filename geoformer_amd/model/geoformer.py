@@ -310,22 +310,24 @@ class GeoFormer(nn.Module):
         return spconv.SparseConvTensor(voxel_feats, batch_input["voxel_locs"].int(), batch_input["spatial_shape"],
                                        batch_size)
 
+    def unet_features(self, x, batch_size):
+        """input_conv -> unet -> output_layer on a SparseConvTensor (geoformer.py:398-401); returns it with the output
+        features.  Inference on the GPU: rulebooks, the 71 convolutions and the two voxel transformers issued by one
+        native call (csrc/unet_exec.hip) -- the same launches as the module tree, without the host side of ~150 of
+        them; otherwise the module tree."""
+        if os.environ.get("GF_UNET_EXEC", "1") != "0" and unet_exec.supported(self, x.features, x.spatial_shape):
+            x.features = unet_exec.unet_forward(self, x.features.contiguous(), x._coords(), batch_size, x.spatial_shape)
+            return x
+        # built lazily by the first strided convolution (spconv.SparseConv3d.get_rules): the host then issues
+        # the chain's ~50 small launches while the GPU is busy with the level-1 blocks, and the one read-back
+        # of the voxel counts waits behind real work instead of an empty queue
+        x.indice_dict["_prebuild"] = self.prebuild_rulebooks
+        return self.output_layer(self.unet(self.input_conv(x)))
+
     def forward_backbone(self, batch_input, batch_size, want_preds=True):
         ctx = self._grad_ctx("unet")
         with ctx():
-            x = self.preprocess_input(batch_input, batch_size)
-            if os.environ.get("GF_UNET_EXEC", "1") != "0" and unet_exec.supported(self, x.features, x.spatial_shape):
-                # inference on the GPU: rulebooks, the 71 convolutions and the two voxel transformers issued by one
-                # native call (csrc/unet_exec.hip) -- the same launches as the module tree below, without the host
-                # side of ~150 of them
-                x.features = unet_exec.unet_forward(self, x.features.contiguous(), x._coords(), batch_size,
-                                                    x.spatial_shape)
-                return self._semantic_head(x, batch_input, want_preds)
-            # built lazily by the first strided convolution (spconv.SparseConv3d.get_rules): the host then issues
-            # the chain's ~50 small launches while the GPU is busy with the level-1 blocks, and the one read-back
-            # of the voxel counts waits behind real work instead of an empty queue
-            x.indice_dict["_prebuild"] = self.prebuild_rulebooks
-            x = self.output_layer(self.unet(self.input_conv(x)))
+            x = self.unet_features(self.preprocess_input(batch_input, batch_size), batch_size)
             return self._semantic_head(x, batch_input, want_preds)
 
     def _semantic_head(self, x, batch_input, want_preds):

@@ -53,8 +53,7 @@ class GeoFormerFS(GeoFormer):
         batch_size = len(batch_input["batch_offsets"]) - 1
         assert batch_size > 0
         with torch.no_grad():
-            x = self.preprocess_input(batch_input, batch_size)
-            x = self.output_layer(self.unet(self.input_conv(x)))
+            x = self.unet_features(self.preprocess_input(batch_input, batch_size), batch_size)
             output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
             mask_indices = torch.nonzero(batch_input["support_masks"] == 1).view(-1)
             feats_, locs_ = output_feats[mask_indices], locs_float[mask_indices]
@@ -73,9 +72,7 @@ class GeoFormerFS(GeoFormer):
     def forward_backbone(self, batch_input, batch_size):
         ctx = torch.enable_grad if self.training and "unet" not in self.fix_module else torch.no_grad
         with ctx():
-            x = self.preprocess_input(batch_input, batch_size)
-            x.indice_dict["_prebuild"] = self.prebuild_rulebooks  # whole down-sampling chain, one host sync
-            x = self.output_layer(self.unet(self.input_conv(x)))
+            x = self.unet_features(self.preprocess_input(batch_input, batch_size), batch_size)
             output_feats = x.features[batch_input["p2v_map"].long()].contiguous()
             chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)
             if chain is not None:
