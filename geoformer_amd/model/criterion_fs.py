@@ -115,8 +115,9 @@ class FSInstSetCriterion(nn.Module):
         ranks = torch.arange(nq, device=dev).unsqueeze(0).expand_as(loss_neg)
         hard_mask = (ranks < n_hard.unsqueeze(1)).float()
         tot = train_label.sum()
-        # no positive query anywhere: the reference returns 0 (both sums are 0 then: n_hard = min(., ratio * 0))
-        return ((loss_neg * hard_mask).sum() + loss_pos.sum()) / tot.clamp(min=1)
+        # no positive query anywhere: both sums are 0 (n_hard = min(., ratio * 0)); the reference then returns a constant
+        # 0 without a graph -- the caller drops this term after its read-back in that case (second return value)
+        return ((loss_neg * hard_mask).sum() + loss_pos.sum()) / tot.clamp(min=1), tot
 
     def _layer_loss_device(self, mask_prediction, matches):
         dev = matches[0].match_q.device if any(m is not None for m in matches) else None
@@ -155,10 +156,9 @@ class FSInstSetCriterion(nn.Module):
             return None
         dev = similarity_score.device
         loss = torch.zeros((), device=dev)
-        sim = None
+        sim, sim_tot = None, None
         if epoch > cfg.prepare_epochs and self.cal_simloss:
-            sim = self._sim_loss_device(similarity_score, instance_masked, last, counts, ranges)
-            loss = loss + sim
+            sim, sim_tot = self._sim_loss_device(similarity_score, instance_masked, last, counts, ranges)
         matches, s = [], 0
         for b in range(self.batch_size):
             n_b = counts[b]
@@ -177,10 +177,15 @@ class FSInstSetCriterion(nn.Module):
         status = torch.cat([m.status for m in live]).amax().float()
         bids = model_outputs["batch_idxs"]
         unsorted = (bids[1:] < bids[:-1]).any().float()
+        zero = torch.zeros((), device=dev)
         vals = torch.stack([ld["focal_loss"].detach(), ld["dice_loss"].detach(), loss.detach(), num_gt, status, unsorted,
-                            (sim.detach() if sim is not None else torch.zeros((), device=dev))]).tolist()  # 2 of 2
+                            (sim.detach() if sim is not None else zero),
+                            (sim_tot.detach() if sim is not None else zero)]).tolist()  # 2 of 2
         if vals[4] != 0 or vals[5] != 0:
             raise RuntimeError(f"device criterion: gf_lsap status {int(vals[4])}, batch_idxs unsorted {int(vals[5])}")
+        if sim is not None and vals[7] > 0:
+            loss = loss + sim  # (with no positive query the term is a constant 0: no gradient into the similarity net)
+            vals[2] += vals[6]
         out = {}
         if sim is not None:
             out["sim_loss"] = (vals[6], self.n_queries)

@@ -109,3 +109,69 @@ def test_training_step_full_size_gpu_matches_oracle_backend(hip, oracle):
     gc, gg = _summ(n_c), _summ(n_g)
     for k in gc:
         assert abs(gg[k] - gc[k]) <= 2e-3 * max(gc[k], 1e-3), (k, gc[k], gg[k])
+
+
+def _fs_setup(device):
+    """Few-shot training-mode episode (BASELINE config 4, training variant): geoformer_fs_scannet.yaml with a batch of
+    two query scenes, one full-scene support per query (its labelled cuboids as support mask), frozen backbone."""
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormerFS, load_config
+    from geoformer_amd.model.criterion_fs import FSInstSetCriterion
+    from tests.util import synthetic_state_dict
+
+    cfg = load_config("geoformer_fs_scannet.yaml", batch_size=2, dec_dropout=0.0, n_decode_point=128, n_query_points=16)
+    torch.manual_seed(0)
+    m = GeoFormerFS(cfg)
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 4))
+    m.semantic_linear.bias.data[4:] += 1.0  # train fold == cv fold: foreground = classes >= 4
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.to(device)
+    m.train()
+    q = scene.make_batch([scene.make_small_scene(3000, 41), scene.make_small_scene(2600, 42)])
+    sup = scene.make_batch([scene.make_small_scene(2400, 43), scene.make_small_scene(2800, 44)])
+    for d in (q, sup):
+        d["batch_offsets"] = d["offsets"]
+    sup["support_masks"] = (sup["instance_labels"] >= 0).long()
+    mv = lambda d: {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}  # noqa: E731
+    return cfg, m, FSInstSetCriterion(cfg), mv(sup), mv(q)
+
+
+def _fs_step(m, crit, sup, q):
+    np.random.seed(5)
+    out = m(sup, q, training=True)
+    loss, info = crit(out, q, 5)
+    m.zero_grad()
+    loss.backward()
+    norms = {n: float(p.grad.norm()) for n, p in m.named_parameters() if p.grad is not None}
+    return float(loss), info, norms
+
+
+def test_fs_training_episode_cpu_oracle_backend(oracle):
+    from oracle import cpu_backend
+
+    with cpu_backend.installed():
+        cfg, m, crit, sup, q = _fs_setup("cpu")
+        loss, info, norms = _fs_step(m, crit, sup, q)
+    assert np.isfinite(loss) and {"focal_loss", "dice_loss", "loss"} <= set(info)
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    assert set(norms) <= trainable and sum(p.numel() for n, p in m.named_parameters() if p.requires_grad) == 42706
+    assert any(n.startswith("similarity_net") or n.startswith("encoder_to_decoder") for n in norms)
+
+
+@pytest.mark.gpu
+def test_fs_training_episode_gpu_matches_oracle_backend(hip, oracle):
+    """The few-shot training step through the HIP operators, the fused cross-attention / mask-head backward and the
+    device criterion against the same step through the oracle's operators and the host criterion."""
+    from oracle import cpu_backend
+
+    with cpu_backend.installed():
+        cfg, m, crit, sup, q = _fs_setup("cpu")
+        loss_c, _, n_c = _fs_step(m, crit, sup, q)
+    cfg, mg, critg, supg, qg = _fs_setup("cuda")
+    loss_g, _, n_g = _fs_step(mg, critg, supg, qg)
+    assert abs(loss_g - loss_c) < 1e-3 * max(1.0, abs(loss_c)), (loss_g, loss_c)
+    assert set(n_g) == set(n_c)
+    for k in n_c:
+        assert abs(n_g[k] - n_c[k]) <= 3e-3 * max(n_c[k], 1e-3), (k, n_c[k], n_g[k])
