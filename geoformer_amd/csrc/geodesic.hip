@@ -576,7 +576,18 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
     bool have_pf = false;
     int4 pv[4];
     float4 pd[4];
+#ifdef BFS_TRACE
+    // dev build (tools/trace_bfs.py): cycle stamps of the first thread of every query, summed over the hops --
+    // 0 expand, 1 atomics done, 2 barrier A, 3 commit, 4 barrier B, 5 hops, 6 sum of ring sizes, 7 largest ring,
+    // first vertex of a hop: 8 entry + row in registers, 9 probes answered, 10 bids issued, 11 number of its bids
+    unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define BT() __builtin_amdgcn_s_memtime()
+#endif
     for (int step = 0; step < max_step && ncur > 0; step++) {
+#ifdef BFS_TRACE
+        const unsigned long long t0_ = BT();
+        tr[5]++; tr[6] += ncur; tr[7] = tr[7] > (unsigned long long)ncur ? tr[7] : (unsigned long long)ncur;
+#endif
         int* cnt = &s_cnt[step & 1];
         for (int f = tid; f < ncur; f += THREADS) {
             const int2 e = f < qcap ? cl[f] : cg[f - qcap];
@@ -612,6 +623,11 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                         }
                     }
                 }
+#ifdef BFS_TRACE
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long ta_ = BT();
+                if (f == tid && r0 == 0) tr[8] += ta_ - t0_;
+#endif
                 // rows are sorted by distance and padded with (inf,-1): stop after the first pad / out-of-radius
                 more = v[15] >= 0 && d[15] <= radius;
                 // all 16 probes of the visited bitmap first (branch-free, one LDS round trip), then the bids
@@ -622,9 +638,18 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                     open_[j] = (r0 + j) >= 1 && v[j] >= 0 && d[j] <= radius;
                     wv[j] = visited[open_[j] ? (v[j] >> 5) : 0];
                 }
+#ifdef BFS_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const unsigned long long tb_ = BT();
+                if (f == tid && r0 == 0) tr[9] += tb_ - ta_;
+                int nb_ = 0;
+#endif
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
                     const unsigned bit = 1u << (v[j] & 31);
+#ifdef BFS_TRACE
+                    nb_ += (open_[j] && !(wv[j] & bit)) ? 1 : 0;
+#endif
                     if (open_[j] && !(wv[j] & bit)) {
                         const unsigned cand = (((unsigned)u << 6) | (unsigned)(r0 + j)) + 1u;
                         atomicMin(&key[v[j]], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(d[j] + gu));
@@ -636,10 +661,22 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                         }
                     }
                 }
+#ifdef BFS_TRACE
+                if (f == tid && r0 == 0) { tr[10] += BT() - tb_; tr[11] += nb_; }
+#endif
             }
         }
+#ifdef BFS_TRACE
+        const unsigned long long t1_ = BT();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every atomicMin of this wave has been performed at L2
+#ifdef BFS_TRACE
+        const unsigned long long t2_ = BT();
+#endif
         __syncthreads();
+#ifdef BFS_TRACE
+        const unsigned long long t3_ = BT();
+#endif
         const int nn = *cnt;
         if (tid == 0) s_cnt[(step + 1) & 1] = 0;  // read last a hop ago, two barriers back
         have_pf = false;
@@ -664,12 +701,23 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
         }
         // the next hop reads the queue and the bitmaps (LDS); only a frontier that spilled into global memory needs
         // the stores themselves to have landed
+#ifdef BFS_TRACE
+        const unsigned long long t4_ = BT();
+#endif
         if (nn > qcap) __syncthreads();
         else bfs_lds_barrier();
+#ifdef BFS_TRACE
+        const unsigned long long t5_ = BT();
+        tr[0] += t1_ - t0_; tr[1] += t2_ - t1_; tr[2] += t3_ - t2_; tr[3] += t4_ - t3_; tr[4] += t5_ - t4_;
+#endif
         int2* t1 = cl; cl = nl; nl = t1;
         int2* t2 = cg; cg = ng; ng = t2;
         ncur = nn;
     }
+#ifdef BFS_TRACE
+    if (tid == 0 && n >= 12)  // parked in the query's queue overflow space (unused by then)
+        for (int i = 0; i < 12; i++) reinterpret_cast<unsigned long long*>(gq0)[i] = tr[i];
+#endif
 }
 
 template <int THREADS>
