@@ -19,6 +19,7 @@
 // are fp32 sums along that parent chain, so results are bit-identical to the reference's.
 #include <cstdlib>
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------
 // spatial hash grid
@@ -569,17 +570,24 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
     __syncthreads();
     int ncur = 1;
     int2 *cl = q0, *cg = gq0, *nl = q1, *ng = gq1;
-    // The thread that commits entry t of the next frontier is the thread that expands entry t a hop later, so it
-    // requests the first 16 entries of that vertex's row right there: the fetch (the longest wait of the expansion)
-    // then runs under the commit's own round trip and the barrier instead of after them.
-    const bool can_pf = K >= 16;
+    // One LANE per row entry: 16 lanes share a frontier vertex and read 16 consecutive entries of its row (one 64-byte
+    // segment of I and of D per group), probe the visited bitmap, bid.  A thread per vertex walking 16 entries in
+    // registers was bound by instruction issue (9500 of a hop's 14 000 cycles in ~1000 instructions on the one wave
+    // its SIMD had; 7-11 of a row's 64 entries are inside the radius); a ring of 220 vertices is 3500 items over all
+    // the workgroup's lanes.  What bounds a hop then is the row fetch (~2000 cycles, the graph is larger than L2), so
+    // BFS_B items per lane go together (one round trip for a ring of up to BFS_B * THREADS / 16 vertices) and the
+    // lanes that expand entry f of the next frontier are the lanes that commit it: they request their row entry right
+    // there, and the fetch runs under the commit's own round trip and the barrier instead of after them.
+    constexpr int BFS_B = 4;
+    const int l16 = tid & 15;
+    const int gsh = (tid & 48) | 15;  // the wave's lane that holds this group's last entry
+    int pv[BFS_B];
+    float pd[BFS_B];
     bool have_pf = false;
-    int4 pv[4];
-    float4 pd[4];
 #ifdef BFS_TRACE
     // dev build (tools/trace_bfs.py): cycle stamps of the first thread of every query, summed over the hops --
     // 0 expand, 1 atomics done, 2 barrier A, 3 commit, 4 barrier B, 5 hops, 6 sum of ring sizes, 7 largest ring,
-    // first vertex of a hop: 8 entry + row in registers, 9 probes answered, 10 bids issued, 11 number of its bids
+    // 8 batches of thread 0, 9 bids of its group, first batch of a hop: 10 entries in registers, 11 bids placed
     unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BT() __builtin_amdgcn_s_memtime()
 #endif
@@ -589,83 +597,155 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
         tr[5]++; tr[6] += ncur; tr[7] = tr[7] > (unsigned long long)ncur ? tr[7] : (unsigned long long)ncur;
 #endif
         int* cnt = &s_cnt[step & 1];
-        for (int f = tid; f < ncur; f += THREADS) {
-            const int2 e = f < qcap ? cl[f] : cg[f - qcap];
-            const int u = e.x;
-            const float gu = __int_as_float(e.y);
-            const int32_t* Iu = I + (size_t)u * K;
-            const float* Du = D + (size_t)u * K;
-            bool more = true;
-            for (int r0 = 0; r0 < K && more; r0 += 16) {
-                int v[16];
-                float d[16];
-                if (r0 == 0 && f == tid && have_pf) {
+        auto bid = [&](int u, float gu, int r, int v, float d) {
+            const unsigned bit = 1u << (v & 31);
+            if (!(visited[v >> 5] & bit)) {
+#ifdef BFS_TRACE
+                if ((tid >> 4) == 0) tr[9]++;
+#endif
+                const unsigned cand = (((unsigned)u << 6) | (unsigned)r) + 1u;
+                atomicMin(&key[v], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(d + gu));
+                const unsigned old = atomicOr(&touched[v >> 5], bit);
+                if (!(old & bit)) {
+                    const int pos = atomicAdd(cnt, 1);
+                    if (pos < qcap) nl[pos].x = v;
+                    else ng[pos - qcap].x = v;
+                }
+            }
+        };
+        const int kc = l16 < K ? l16 : K - 1;
+        // (the frontier spills out of LDS into global memory only on graphs far larger than a scene's: own instance of the loop)
+        auto batch = [&](int base, auto spill, auto pf) {
+            unsigned cand[BFS_B];  // (parent << 6 | rank) + 1 of this lane's entry
+            int v[BFS_B];
+            float d[BFS_B];
+            // branch-free (clamped indices, results masked afterwards) so that the loads of the whole batch are
+            // requested back to back; the queue is read as LDS or as global memory explicitly -- a pointer that may be
+            // either makes every access a flat one, which waits for all outstanding memory traffic
+            {
+                float gu[BFS_B];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        v[4 * c + 0] = pv[c].x; v[4 * c + 1] = pv[c].y; v[4 * c + 2] = pv[c].z; v[4 * c + 3] = pv[c].w;
-                        d[4 * c + 0] = pd[c].x; d[4 * c + 1] = pd[c].y; d[4 * c + 2] = pd[c].z; d[4 * c + 3] = pd[c].w;
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const int rb = r0 + 4 * c;
-                        if (rb + 3 < K) {
-                            const int4 vi = *reinterpret_cast<const int4*>(Iu + rb);
-                            const float4 di = *reinterpret_cast<const float4*>(Du + rb);
-                            v[4 * c + 0] = vi.x; v[4 * c + 1] = vi.y; v[4 * c + 2] = vi.z; v[4 * c + 3] = vi.w;
-                            d[4 * c + 0] = di.x; d[4 * c + 1] = di.y; d[4 * c + 2] = di.z; d[4 * c + 3] = di.w;
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                v[4 * c + j] = (rb + j < K) ? Iu[rb + j] : -1;
-                                d[4 * c + j] = (rb + j < K) ? Du[rb + j] : 0.f;
-                            }
-                        }
+                for (int k = 0; k < BFS_B; k++) {
+                    const int f = (base + k * THREADS + tid) >> 4;
+                    const int fc = f < ncur ? f : ncur - 1;
+                    int2 e = cl[fc < qcap ? fc : 0];
+                    if constexpr (decltype(spill)::value)
+                        if (fc >= qcap) e = cg[fc - qcap];
+                    cand[k] = (((unsigned)e.x << 6) | (unsigned)l16) + 1u;
+                    gu[k] = __int_as_float(e.y);
+                    if constexpr (decltype(pf)::value) {  // requested by the commit of the hop before
+                        v[k] = pv[k];
+                        d[k] = pd[k];
+                    } else {
+                        v[k] = I[(size_t)e.x * K + kc];
+                        d[k] = D[(size_t)e.x * K + kc];
                     }
                 }
+#ifdef BFS_TRACE
+                if (tid == 0) tr[8]++;
+#endif
+                // every entry of the batch in its register before the first bid: one round trip for the batch
+                // (otherwise the compiler sinks each load to its use, behind the previous item's atomics)
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) asm volatile("" : "+v"(v[k]), "+v"(d[k]));
 #ifdef BFS_TRACE
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                const unsigned long long ta_ = BT();
-                if (f == tid && r0 == 0) tr[8] += ta_ - t0_;
+                if (base == 0) tr[10] += BT() - t0_;
 #endif
-                // rows are sorted by distance and padded with (inf,-1): stop after the first pad / out-of-radius
-                more = v[15] >= 0 && d[15] <= radius;
-                // all 16 probes of the visited bitmap first (branch-free, one LDS round trip), then the bids
-                unsigned wv[16];
-                bool open_[16];
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    open_[j] = (r0 + j) >= 1 && v[j] >= 0 && d[j] <= radius;
-                    wv[j] = visited[open_[j] ? (v[j] >> 5) : 0];
+                for (int k = 0; k < BFS_B; k++) {  // v = -1: not an entry inside the radius; d: the distance it bids
+                    const int f = (base + k * THREADS + tid) >> 4;
+                    if (!(f < ncur && l16 < K && d[k] <= radius)) v[k] = -1;
+                    d[k] += gu[k];
                 }
+            }
 #ifdef BFS_TRACE
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                const unsigned long long tb_ = BT();
-                if (f == tid && r0 == 0) tr[9] += tb_ - ta_;
-                int nb_ = 0;
+            const unsigned long long tb0_ = BT();
 #endif
+            // the batch's LDS traffic in three rounds instead of three per item: the probes of the visited bitmap, the
+            // marks in the touched bitmap (returning: the first to mark a vertex queues it), one add to the queue's
+            // counter per wave for all the first marks of the batch
+            unsigned long long mm = 0ull;  // bit k: this group's entry 15 of item k is inside the radius
+            unsigned w[BFS_B];
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const unsigned bit = 1u << (v[j] & 31);
+            for (int k = 0; k < BFS_B; k++) {
+                mm |= ((__ballot(v[k] >= 0) >> gsh) & 1ull) << k;
+                w[k] = visited[v[k] >= 0 ? (v[k] >> 5) : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < BFS_B; k++) {  // w becomes: nonzero = not the first to mark (or no bid at all)
+                const unsigned bit = 1u << (v[k] & 31);
+                const bool bids = v[k] >= 0 && l16 >= 1 && !(w[k] & bit);
 #ifdef BFS_TRACE
-                    nb_ += (open_[j] && !(wv[j] & bit)) ? 1 : 0;
+                if ((tid >> 4) == 0) tr[9] += bids ? 1 : 0;
 #endif
-                    if (open_[j] && !(wv[j] & bit)) {
-                        const unsigned cand = (((unsigned)u << 6) | (unsigned)(r0 + j)) + 1u;
-                        atomicMin(&key[v[j]], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(d[j] + gu));
-                        const unsigned old = atomicOr(&touched[v[j] >> 5], bit);
-                        if (!(old & bit)) {
-                            const int pos = atomicAdd(cnt, 1);
-                            if (pos < qcap) nl[pos].x = v[j];
-                            else ng[pos - qcap].x = v[j];
+                w[k] = 1u;
+                if (bids) {
+                    atomicMin(&key[v[k]], ((unsigned long long)cand[k] << 32) | (unsigned)__float_as_int(d[k]));
+                    w[k] = atomicOr(&touched[v[k] >> 5], bit) & bit;
+                }
+            }
+            unsigned long long fm[BFS_B];
+            int nfirst = 0;
+#pragma unroll
+            for (int k = 0; k < BFS_B; k++) {
+                fm[k] = __ballot(w[k] == 0u);
+                nfirst += __popcll(fm[k]);
+            }
+            if (nfirst) {  // (uniform over the wave: every lane is here, those past the ring's end with v = -1)
+                int pos = 0;
+                if ((tid & 63) == 0) pos = atomicAdd(cnt, nfirst);
+                pos = __builtin_amdgcn_readfirstlane(pos);
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    if (w[k] == 0u) {
+                        const int p = pos + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm[k] >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned)fm[k], 0u));
+                        if (p < qcap) nl[p].x = v[k];
+                        else ng[p - qcap].x = v[k];
+                    }
+                    pos += __popcll(fm[k]);
+                }
+            }
+#ifdef BFS_TRACE
+            if (base == 0) tr[11] += BT() - tb0_;
+#endif
+            // rows are sorted by distance and padded with (inf,-1): a group goes on to the next 16 entries only while
+            // its last one is still inside the radius (1-8 % of the rows)
+            if (mm) {
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    if ((mm >> k) & 1ull) {
+                        const int f = (base + k * THREADS + tid) >> 4;  // (< ncur: the entry was a real one)
+                        int2 e = cl[f < qcap ? f : 0];
+                        if constexpr (decltype(spill)::value)
+                            if (f >= qcap) e = cg[f - qcap];
+                        for (int r0 = 16; r0 < K; r0 += 16) {
+                            const int r = r0 + l16;
+                            int vv = -1;
+                            float dd = 0.f;
+                            if (r < K) {
+                                vv = I[(size_t)e.x * K + r];
+                                dd = D[(size_t)e.x * K + r];
+                            }
+                            const bool in2 = vv >= 0 && dd <= radius;
+                            if (in2) bid(e.x, __int_as_float(e.y), r, vv, dd);
+                            if (!((__ballot(in2) >> gsh) & 1ull)) break;
                         }
                     }
                 }
-#ifdef BFS_TRACE
-                if (f == tid && r0 == 0) { tr[10] += BT() - tb_; tr[11] += nb_; }
-#endif
             }
-        }
+        };
+        auto expand = [&](auto spill) {
+            int base = 0;
+            if (have_pf) {
+                batch(0, spill, std::true_type{});
+                base = BFS_B * THREADS;
+            }
+            for (; (base >> 4) < ncur; base += BFS_B * THREADS) batch(base, spill, std::false_type{});
+        };
+        if (ncur > qcap) expand(std::true_type{});
+        else expand(std::false_type{});
 #ifdef BFS_TRACE
         const unsigned long long t1_ = BT();
 #endif
@@ -679,26 +759,50 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
 #endif
         const int nn = *cnt;
         if (tid == 0) s_cnt[(step + 1) & 1] = 0;  // read last a hop ago, two barriers back
-        have_pf = false;
-        for (int t = tid; t < nn; t += THREADS) {
-            int2* slot = t < qcap ? &nl[t] : &ng[t - qcap];
-            const int v = slot->x;
-            if (t == tid && can_pf && step + 1 < max_step) {
-                const int32_t* Iv = I + (size_t)v * K;
-                const float* Dv = D + (size_t)v * K;
+        const bool pf_now = step + 1 < max_step;
+        auto commit_batch = [&](int base, auto spill, auto pf) {
+            int v[BFS_B];
+            unsigned kk[BFS_B];  // the distance half of the key (the low word)
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    pv[c] = *reinterpret_cast<const int4*>(Iv + 4 * c);
-                    pd[c] = *reinterpret_cast<const float4*>(Dv + 4 * c);
-                }
-                have_pf = true;
+            for (int k = 0; k < BFS_B; k++) {  // the keys first: loads return in order, and the rows are not waited for
+                const int t = (base + k * THREADS + tid) >> 4;
+                const int tc = t < nn ? t : nn - 1;
+                v[k] = nl[tc < qcap ? tc : 0].x;
+                if constexpr (decltype(spill)::value)
+                    if (tc >= qcap) v[k] = ng[tc - qcap].x;
+                kk[k] = __hip_atomic_load(reinterpret_cast<const unsigned*>(&key[v[k]]), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
             }
-            const unsigned long long kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int di = (int)(unsigned)(kk & 0xffffffffull);
-            g[v] = __int_as_float(di);
-            slot->y = di;
-            atomicOr(&visited[v >> 5], 1u << (v & 31));
-        }
+            if constexpr (decltype(pf)::value) {
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    pv[k] = I[(size_t)v[k] * K + kc];
+                    pd[k] = D[(size_t)v[k] * K + kc];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < BFS_B; k++) {
+                const int t = (base + k * THREADS + tid) >> 4;
+                if (t < nn && l16 == 0) {
+                    const int di = (int)kk[k];
+                    g[v[k]] = __int_as_float(di);
+                    if (!decltype(spill)::value || t < qcap) nl[t].y = di;
+                    else ng[t - qcap].y = di;
+                    atomicOr(&visited[v[k] >> 5], 1u << (v[k] & 31));
+                }
+            }
+        };
+        auto commit = [&](auto spill) {
+            int base = 0;
+            if (pf_now && nn > 0) {  // (a join of a path with and one without the row requests would wait for them)
+                commit_batch(0, spill, std::true_type{});
+                base = BFS_B * THREADS;
+            }
+            for (; (base >> 4) < nn; base += BFS_B * THREADS) commit_batch(base, spill, std::false_type{});
+        };
+        if (nn > qcap) commit(std::true_type{});
+        else commit(std::false_type{});
+        have_pf = pf_now;
         // the next hop reads the queue and the bitmaps (LDS); only a frontier that spilled into global memory needs
         // the stores themselves to have landed
 #ifdef BFS_TRACE
@@ -734,11 +838,10 @@ static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, c
                        geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
 }
 
-// wg_threads: threads (and, in proportion, LDS) per query.  1024 = one query per compute unit, the fastest when the
-// launch has the chip to itself; 256 lets four queries share a compute unit, which is what makes the launch overlap
-// with furthest point sampling (16 compute units busy for 1.3 ms): with one query per CU the 256 queries of the eval
-// forward need a second round on the remaining 240 CUs and the launch takes 2.2 ms instead of 1.3 ms; at 256 threads
-// it takes 1.45 ms alone and 1.65 ms beside the sampling kernel (S150k, tools/fps_bfs_overlap_exp.py).
+// wg_threads: threads (and, in proportion, LDS) per query.  The kernel spreads a ring's row entries over the lanes, so
+// more threads per query is faster when the launch has the chip to itself (S150k eval graphs, 256 queries: 1.06 ms at
+// 1024, 1.25 ms at 512, 2.0 ms at 256).  Beside furthest point sampling (13 compute units busy) the 256 queries at
+// 1024 threads -- one per compute unit -- need a second round, and 512 is the fastest (two queries can share a unit).
 extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K,
                                    const int32_t* src, int nq, float radius, int max_step, float* geo, void* keys_ws,
                                    void* queue_ws, int wg_threads, void* stream) {

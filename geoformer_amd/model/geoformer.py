@@ -47,7 +47,7 @@ voxelization = _Voxelization.apply
 import threading
 import weakref
 
-_BFS_WG = int(os.environ.get("GF_BFS_WG", "256"))  # threads per query of the BFS launched beside the sampling
+_BFS_WG = int(os.environ.get("GF_BFS_WG", "512"))  # threads per query of the BFS launched beside the sampling
 _OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
 
 

@@ -101,3 +101,28 @@ def test_bfs_duplicates_short_walks_and_dense_ball(hip, oracle):
     deg = (inr.sum(1) - 1).astype(np.int32)
     geo = pointops.geodesic_bfs(_dev(Dm), _dev(Im), _dev(deg), _dev(src.astype(np.int32)), radius, 64, wg_threads=256)
     assert (geo.cpu().numpy() == ref).all()
+    # 9000 points in a 0.09 m cube: every row has all 64 entries inside the radius (the lanes go through all four
+    # 16-entry rounds of a row), rings of up to 1800 vertices
+    xyz = (rng.random((9000, 3)) * 0.09).astype(np.float32)
+    D, I = _ref_graph(oracle, xyz, k, radius)
+    inr = D <= np.float32(radius)
+    Dm = np.where(inr, D, np.inf).astype(np.float32)
+    Im = np.where(inr, I, -1).astype(np.int32)
+    src = np.array([3, 4500, 8999, 77])
+    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 64)
+    deg = (inr.sum(1) - 1).astype(np.int32)
+    for wg in (256, 512, 1024):
+        geo = pointops.geodesic_bfs(_dev(Dm), _dev(Im), _dev(deg), _dev(src.astype(np.int32)), radius, 64, wg_threads=wg)
+        assert (geo.cpu().numpy() == ref).all(), wg
+    # the same cube as vertices 250000.. of a graph of 2^19 vertices (the others isolated): the two bitmaps take 128 KB
+    # of the workgroup's LDS, 1408 queue entries remain, and the rings above that spill into the queue's
+    # global-memory overflow
+    n_big, off = 1 << 19, 250000
+    Db = np.full((n_big, k), np.inf, np.float32)
+    Ib = np.full((n_big, k), -1, np.int32)
+    Db[off:off + 9000] = Dm
+    Ib[off:off + 9000] = np.where(Im >= 0, Im + off, -1)
+    geo = pointops.geodesic_bfs(_dev(Db), _dev(Ib), None, _dev((src + off).astype(np.int32)), radius, 64, wg_threads=256)
+    geo = geo.cpu().numpy()
+    assert (geo[:, off:off + 9000] == ref).all()
+    assert (geo[:, :off] == -1).all() and (geo[:, off + 9000:] == -1).all()

@@ -24,7 +24,7 @@ pointops.geodesic_bfs = orig
 names = ["expand (to bids issued)", "wait for the atomics", "barrier A", "commit", "barrier B"]
 for i, (D, I, deg, src, radius, max_step) in enumerate(cap):
     n, K = D.shape; nq = src.shape[0]
-    for wg in (256, 1024):
+    for wg in (256, 512, 1024):
         geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
         keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
         queues = torch.zeros((nq, 4, n), dtype=torch.int32, device=dev)
@@ -39,5 +39,8 @@ for i, (D, I, deg, src, radius, max_step) in enumerate(cap):
         print(f"scene {i} n {n} wg {wg}: {s.elapsed_time(e) * 1e3:.0f} us; hops {hops.mean():.0f} (max {hops.max():.0f}), ring mean {(t[:, 6] / hops).mean():.0f} max {t[:, 7].max():.0f}; slowest query {tot.max() / tot.mean():.2f} x the mean")
         for j, nme in enumerate(names):
             print(f"     {nme:26s} {(t[:, j] / hops).mean():8.0f} ticks per hop  {100 * (t[:, j] / tot).mean():5.1f} %")
-        print(f"     thread 0's first vertex per hop: entry + row {(t[:, 8] / hops).mean():.0f}, probes {(t[:, 9] / hops).mean():.0f}, "
-              f"bids {(t[:, 10] / hops).mean():.0f} ticks for {(t[:, 11] / hops).mean():.1f} bids")
+        print(f"     thread 0 per hop: {(t[:, 8] / hops).mean():.2f} batches, {(t[:, 9] / hops).mean():.2f} bids of its group; first batch: "
+              f"row entries in registers after {(t[:, 10] / hops).mean():.0f} ticks, bids placed in {(t[:, 11] / hops).mean():.0f}")
+    val = ((D <= radius) & (I >= 0)).sum(1).float()
+    print(f"     graph: K {K}, entries inside the radius per row: mean {val.mean().item():.1f}, "
+          f"rows with more than 16 / 32 / 48: {(val > 16).float().mean().item():.2f} / {(val > 32).float().mean().item():.2f} / {(val > 48).float().mean().item():.2f}")
