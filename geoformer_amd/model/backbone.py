@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import spconv
 from ..spconv.modules import SparseModule
-from .layers import BackboneTransformer, BatchNorm1d, PointwiseConv1d
+from .layers import BackboneTransformer, BatchNorm1d, PointwiseConv1d, scene_counts
 
 
 def bn_affine(bn):
@@ -152,7 +152,7 @@ class UBlock(nn.Module):
                 self._gf_offs1 = offs
             offs = offs[1]
         else:
-            counts = torch.bincount(coords[:, 0].long(), minlength=t.batch_size)[:t.batch_size]
+            counts = scene_counts(coords[:, 0], t.batch_size)
             offs = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
         return pointops.backbone_transformer(t.features.contiguous(), coords, offs, t.batch_size, hit[1], hit[2])
 
@@ -196,18 +196,29 @@ def conv1d_bn_relu(in_channels, out_channels):
     return nn.Sequential(conv, BatchNorm1d(out_channels), nn.ReLU(inplace=True))
 
 
-def random_downsample(batch_offsets, batch_size, n_subsample=30000):
+def random_downsample(batch_offsets, batch_size, n_subsample=30000, host_offsets=None):
     """Host-RNG subsampling of the mask-head points (geoformer_modules.py:165-186); consumes
-    np.random exactly like the reference (one np.random.choice per over-full scene)."""
+    np.random exactly like the reference (one np.random.choice per over-full scene).
+    host_offsets: the offsets as a host list when the caller has them (the forward read the foreground counts for its
+    sampling draw already): without it every scene's size is a read-back that blocks the host until the device has
+    caught up -- 8 ms of the batch-4 training step, whose host side is what bounds it.  On the GPU the draw goes
+    through the native restatement of numpy's legacy generator into pinned memory (a third of numpy's time, and the
+    upload is an asynchronous copy)."""
+    from .. import pointops
+
+    dev = batch_offsets.device
+    offs = host_offsets if host_offsets is not None else batch_offsets.tolist()
     idxs, raw = [], []
     for b in range(batch_size):
-        start, end = batch_offsets[b], batch_offsets[b + 1]
-        n_b = int(end - start)
+        start, n_b = int(offs[b]), int(offs[b + 1]) - int(offs[b])
         if n_subsample == -1 or n_subsample >= n_b:
-            new = torch.arange(n_b, dtype=torch.long, device=batch_offsets.device)
+            new = torch.arange(n_b, dtype=torch.long, device=dev)
+        elif dev.type == "cuda":
+            pin = torch.empty(n_subsample, dtype=torch.long, pin_memory=True)
+            pointops.legacy_choice(n_b, n_subsample, out=pin.numpy())
+            new = pin.to(dev, non_blocking=True)
         else:
-            new = torch.tensor(np.random.choice(n_b, n_subsample, replace=False), dtype=torch.long,
-                               device=batch_offsets.device)
+            new = torch.tensor(np.random.choice(n_b, n_subsample, replace=False), dtype=torch.long, device=dev)
         raw.append(new)
         idxs.append(new + start)
     return torch.cat(idxs), raw

@@ -22,7 +22,7 @@ from .. import pointops, spconv, unet_exec
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
 from .layers import (BatchNorm1d, GenericMLP, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
-                     TransformerDecoderLayer)
+                     TransformerDecoderLayer, scene_counts)
 from .set_abstraction import PointnetSAModuleVotesSeparate
 
 
@@ -61,7 +61,7 @@ def get_batch_offsets(batch_idxs, bs, host_only=False):
         t = torch.tensor([0, n], dtype=torch.int32, device="cpu" if host_only else batch_idxs.device)
         _OFFS_CACHE.key, _OFFS_CACHE.val = t, [0, n]
         return t
-    counts = torch.bincount(batch_idxs.long(), minlength=bs)[:bs]
+    counts = scene_counts(batch_idxs, bs)
     return torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
 
 
@@ -883,7 +883,8 @@ class GeoFormer(nn.Module):
         self._join_side_stream()  # no-op unless a subclass' decoder skipped relative_position_embedding
 
         if training:
-            idxs_sub, idxs_sub_raw = random_downsample(batch_offsets_, batch_size, n_subsample=30000)
+            idxs_sub, idxs_sub_raw = random_downsample(batch_offsets_, batch_size, n_subsample=30000,
+                                                         host_offsets=_offsets_list(batch_offsets_))
             geo_sub = [geo_dists[b][:, idxs_sub_raw[b]] for b in range(batch_size)]
             del geo_dists
             batch_idxs_sub = batch_idxs_[idxs_sub]

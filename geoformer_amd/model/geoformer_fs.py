@@ -254,7 +254,8 @@ class GeoFormerFS(GeoFormer):
         if not training:
             dec_outputs = dec_outputs[-1:, ...]
         else:
-            idxs_sub, idxs_sub_raw = random_downsample(batch_offsets_, batch_size, n_subsample=30000)
+            idxs_sub, idxs_sub_raw = random_downsample(batch_offsets_, batch_size, n_subsample=30000,
+                                                         host_offsets=_offsets_list(batch_offsets_))
             geo_dists = [geo_dists[b][:, idxs_sub_raw[b]] for b in range(batch_size)]
             fg_idxs = fg_idxs[idxs_sub]
             mask_features_, locs_float_, batch_idxs_ = mask_features_[idxs_sub], locs_float_[idxs_sub], batch_idxs_[idxs_sub]

@@ -1,0 +1,103 @@
+"""Dev tool: the config-3 training step (batch 4, full epoch) a few times, for rocprofv3 --kernel-trace --stats."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from geoformer_amd import scene
+from geoformer_amd.model import GeoFormer, InstSetCriterion, load_config
+from tests.util import synthetic_state_dict
+
+dev = torch.device("cuda", 0)
+mv = lambda d: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items()}
+cfg = load_config("geoformer_scannet.yaml", batch_size=4, prepare_epochs=120)
+m = GeoFormer(cfg); m.load_state_dict(synthetic_state_dict(m.state_dict(), 0)); m.to(dev); m.train()
+crit = InstSetCriterion(cfg)
+opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=1e-3)
+batch = mv(scene.make_batch([scene.make_scene(int(n), 50 + i) for i, n in enumerate((150_000, 120_000, 180_000, 100_000))]))
+def step():
+    np.random.seed(0)
+    out = m(batch, 200)
+    loss, _ = crit(out, batch, 200)
+    opt.zero_grad(); loss.backward(); opt.step()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+for _ in range(2): step()
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(n): step()
+torch.cuda.synchronize(); print(f"step {(time.perf_counter() - t) / n * 1e3:.1f} ms")
+if os.environ.get("PHASES"):
+    import collections
+    acc = collections.defaultdict(float)
+    def tick(name, t0):
+        torch.cuda.synchronize(); t1 = time.perf_counter(); acc[name] += t1 - t0; return t1
+    orig_bb = m.forward_backbone
+    def timed_bb(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = orig_bb(*a, **k)
+        tick("fwd backbone", t0)
+        return r
+    m.forward_backbone = timed_bb
+    for _ in range(n):
+        np.random.seed(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = m(batch, 200); t1 = tick("fwd total", t0)
+        loss, _ = crit(out, batch, 200); t2 = tick("criterion", t1)
+        opt.zero_grad(); loss.backward(); t3 = tick("backward", t2)
+        opt.step(); tick("optimizer", t3)
+    for k, v in acc.items(): print(f"{k:14s} {v / n * 1e3:7.1f} ms")
+if os.environ.get("HOSTBOUND"):
+    th = tt = 0.0
+    for _ in range(n):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        step(); t1 = time.perf_counter()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        th += t1 - t0; tt += t2 - t0
+    print(f"host returns after {th / n * 1e3:.1f} ms, device done after {tt / n * 1e3:.1f} ms")
+if os.environ.get("CPROFILE"):
+    import cProfile, pstats, io
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    pr.disable()
+    for key in ("tottime", "cumulative"):
+        sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats(key).print_stats(45)
+        print(sio.getvalue()[:9000])
+if os.environ.get("SYNCS"):
+    import traceback, collections
+    log = []
+    def wrap(owner, name):
+        orig = getattr(owner, name)
+        def f(*a, **k):
+            t0 = time.perf_counter(); r = orig(*a, **k); dt = time.perf_counter() - t0
+            if dt > 50e-6:
+                fr = [x for x in traceback.extract_stack()[:-1] if "geoformer_amd" in x.filename or "tools/" in x.filename][-1]
+                log.append((t0, dt, name, f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"))
+            return r
+        setattr(owner, name, f)
+    for nm in ("tolist", "item", "cpu", "numpy", "__int__", "__bool__", "__float__", "__index__"): wrap(torch.Tensor, nm)
+    wrap(torch, "nonzero"); wrap(torch.Tensor, "nonzero"); wrap(torch, "where")
+    from geoformer_amd import pointops as _po
+    wrap(_po, "legacy_choice"); wrap(np.random, "choice")
+    step(); torch.cuda.synchronize(); log.clear()
+    T0 = time.perf_counter(); step(); T1 = time.perf_counter(); torch.cuda.synchronize(); T2 = time.perf_counter()
+    print(f"host {1e3 * (T1 - T0):.1f} ms, device done {1e3 * (T2 - T0):.1f} ms; blocking / slow host calls:")
+    tot = 0
+    for t0, dt, nm, where in log:
+        print(f"  at {1e3 * (t0 - T0):7.2f} ms  {1e3 * dt:6.2f} ms  {nm:14s} {where}"); tot += dt
+    print(f"  total {1e3 * tot:.1f} ms")
+if os.environ.get("TPROF"):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        for _ in range(2): step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=50, max_name_column_width=60))
+if os.environ.get("TPROF_STACK"):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+        step()
+        torch.cuda.synchronize()
+    want = os.environ["TPROF_STACK"].split(",")
+    rows = [e for e in prof.key_averages(group_by_stack_n=6) if e.key in want]
+    rows.sort(key=lambda e: -e.self_cpu_time_total)
+    for e in rows[:40]:
+        st = [x for x in e.stack if "geoformer_amd" in x or "tools/" in x][:3]
+        print(f"{e.key:14s} n {e.count:4d} self {e.self_cpu_time_total / 1e3:7.2f} ms  avg {e.self_cpu_time_total / e.count:6.1f} us  " + " <- ".join(s.split('/')[-1][:60] for s in st))
