@@ -1420,6 +1420,142 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ in
     }
 }
 
+// The same with the table's group masks (gmask[g] bit k: some row of the 16-row group g has a neighbour at offset k)
+// and 16-byte loads.  Two things bound the kernel above (523k voxels, 16 -> 16: 226 us = 2.6x the forward):
+//   * 61 % of the (group, offset) pairs of a scanned room's level 1 are empty (6.3 of 27 offsets per voxel, 10.5 per
+//     group), and it walks them all: here a wave first lists the groups of its slice that have offset k at all;
+//   * the MFMA wants lane (r, q) to supply channel r of row 4u + q, so every operand was a 4-byte load per lane --
+//     12 vector-memory instructions of 64 addresses each per (group, offset), and the compute unit's ONE address
+//     pipeline is the limit (time scaled with the instruction count, not with rows in flight or atomics).  Here lane
+//     (row = lane >> 2, quad = lane & 3) loads 16 bytes of its row -- one instruction per operand tile -- and the tile
+//     changes orientation through a per-wave LDS buffer (two 16-byte writes, eight 4-byte reads per pair).
+// Channel counts are multiples of 16 on this route (the 6-channel input convolution takes the kernel above).
+// 523k voxels: 16 -> 16 91 us (was 226), 32 -> 16 177 (417), 32 -> 32 494 (700), 64 -> 32 964 (1380).  What bounds it
+// now is L2 bandwidth: a wave per (offset, 16 x 16 tile pair, slice) reads 2 KB per (group, offset) pair -- 700 MB per
+// tile pair, 7.7 TB/s at 91 us -- because the gradient rows are read again for every offset and both operands again
+// for every tile pair; one wave per slice for all tile pairs (and several offsets, one accumulator each) would read
+// 1.8x (16 -> 16) to 3.6x (32 -> 32) less.  Not built yet.
+#ifndef WGT_ROWS
+#define WGT_ROWS 1024  // rows per slice: more, shorter waves beat fewer, longer ones (2048: +80 %, 4096: +180 %)
+#endif
+#ifndef WGT_NB
+#define WGT_NB 2  // (group, offset) pairs per trip (three trips in flight per wave)
+#endif
+__global__ __launch_bounds__(256) void k_conv_wgrad_t(const float* __restrict__ in, const float* __restrict__ dout,
+                                                      const int32_t* __restrict__ nbr,
+                                                      const uint32_t* __restrict__ gmask, int K, int M_out, int ld,
+                                                      int Cin, int Cout, int NCI, int NCO, int nslices,
+                                                      float* __restrict__ dW) {
+    __shared__ __attribute__((aligned(16))) float sA[4][WGT_NB][256], sB[4][WGT_NB][256];
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
+    const int rho = lane >> 2, gam = lane & 3;  // loading role: row of the group, channel quad
+    long long item = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nitems = (long long)K * NCI * NCO * nslices;
+    if (item >= nitems) return;
+    const int sl = (int)(item % nslices);
+    item /= nslices;
+    const int cob = (int)(item % NCO);
+    item /= NCO;
+    const int cib = (int)(item % NCI);
+    const int k = (int)(item / NCI);
+    constexpr int GPS = WGT_ROWS / 16;  // groups per slice
+    constexpr int NPW = (GPS + 63) / 64;
+    const int g0 = sl * GPS, ngroups = (M_out + 15) >> 4;
+    unsigned long long present[NPW];
+#pragma unroll
+    for (int w = 0; w < NPW; w++) {
+        const int g = g0 + w * 64 + lane;
+        present[w] = __ballot(w * 64 + lane < GPS && g < ngroups && ((gmask[g] >> k) & 1u));
+    }
+    auto next_group = [&]() -> int {  // wave-uniform: the next listed group of the slice, -1 when the lists are empty
+#pragma unroll
+        for (int w = 0; w < NPW; w++) {
+            if (present[w]) {
+                const int b = __builtin_ctzll(present[w]);
+                present[w] &= present[w] - 1;
+                return g0 + w * 64 + b;
+            }
+        }
+        return -1;
+    };
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* inc = in + cib * 16 + 4 * gam;
+    const float* doc = dout + cob * 16 + 4 * gam;
+    const int32_t* nk = nbr + (size_t)k * ld;
+    float* la = &sA[wv][0][0];
+    float* lb = &sB[wv][0][0];
+    // Three trips in flight per wave (the loop is a chain of two dependent memory round trips per trip otherwise):
+    // while trip i goes through LDS and the MFMAs, the gathers of trip i+1 and the neighbour indices + gradient rows
+    // of trip i+2 are on their way.  Every load is issued unconditionally (clamped address, result masked), so the
+    // waits are exact counted ones.
+    struct Trip {
+        int idx[WGT_NB];   // neighbour row (or -1) of this lane's row in each of the trip's groups
+        float4 bv[WGT_NB];
+    };
+    auto request = [&](Trip& tr) -> bool {  // lists the trip's groups, requests indices and gradient rows
+        bool any = false;
+#pragma unroll
+        for (int t = 0; t < WGT_NB; t++) {
+            const int g = next_group();
+            any = any || g >= 0;
+            const int row = g * 16 + rho;
+            const bool ok = g >= 0 && row < M_out;
+            const int rc = ok ? row : 0;
+            const int i = nk[rc];
+            const float4 v = *reinterpret_cast<const float4*>(doc + (size_t)rc * Cout);
+            tr.idx[t] = ok ? i : -1;
+            tr.bv[t] = v;
+        }
+        return any;
+    };
+    auto gather = [&](float4 (&av)[WGT_NB], const Trip& tr) {
+#pragma unroll
+        for (int t = 0; t < WGT_NB; t++) {
+            const int i = tr.idx[t];
+            const float4 v = *reinterpret_cast<const float4*>(inc + (size_t)(i >= 0 ? i : 0) * Cin);
+            av[t] = i >= 0 ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    Trip t0, t1, t2;
+    float4 a0[WGT_NB], a1[WGT_NB];
+    bool live0 = request(t0);
+    bool live1 = request(t1);
+    gather(a0, t0);
+    while (live0) {
+        const bool live2 = request(t2);
+        gather(a1, t1);
+#pragma unroll
+        for (int t = 0; t < WGT_NB; t++) {
+            *reinterpret_cast<float4*>(la + t * 256 + rho * 16 + 4 * gam) = a0[t];
+            *reinterpret_cast<float4*>(lb + t * 256 + rho * 16 + 4 * gam) = t0.bv[t];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < WGT_NB; t++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float a = la[t * 256 + (4 * u + q) * 16 + r];
+                const float b = lb[t * 256 + (4 * u + q) * 16 + r];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        t0 = t1;
+        t1 = t2;
+#pragma unroll
+        for (int t = 0; t < WGT_NB; t++) a0[t] = a1[t];
+        live0 = live1;
+        live1 = live2;
+    }
+    // D layout: col (output channel) = lane&15, row (input channel) = 4*(lane>>4) + j
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int cii = cib * 16 + q * 4 + j, co = cob * 16 + r;
+        if (acc[j] != 0.f) atomicAdd(&dW[((size_t)k * Cin + cii) * Cout + co], acc[j]);
+    }
+}
+
 extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K, int M_out, int ld, int Cin,
                              int Cout, float* dW, void* stream) {
     GF_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1, "gf_conv_wgrad: bad sizes");
@@ -1433,6 +1569,23 @@ extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* 
     hipLaunchKernelGGL(k_conv_wgrad, dim3(gf_div_up(nitems, 4)), dim3(256), 0, st, in, dout, nbr, K, M_out, ld, Cin,
                        Cout, nci, nco, nslices, dW);
     GF_CHECK_LAUNCH("gf_conv_wgrad");
+    return GF_OK;
+}
+
+extern "C" int gf_conv_wgrad_masked(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K,
+                                    int M_out, int ld, int Cin, int Cout, float* dW, void* stream) {
+    if (gmask == nullptr || nbr == nullptr || (Cin & 15) || (Cout & 15))
+        return gf_conv_wgrad(in, dout, nbr, K, M_out, ld, Cin, Cout, dW, stream);
+    GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_wgrad_masked: K=%d (at most 32 offsets)", K);
+    hipStream_t st = (hipStream_t)stream;
+    GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
+    if (M_out <= 0) return GF_OK;
+    const int nci = Cin / 16, nco = Cout / 16;
+    const int nslices = (M_out + WGT_ROWS - 1) / WGT_ROWS;
+    const long long nitems = (long long)K * nci * nco * nslices;
+    hipLaunchKernelGGL(k_conv_wgrad_t, dim3(gf_div_up(nitems, 4)), dim3(256), 0, st, in, dout, nbr, gmask, K, M_out, ld,
+                       Cin, Cout, nci, nco, nslices, dW);
+    GF_CHECK_LAUNCH("gf_conv_wgrad_masked");
     return GF_OK;
 }
 

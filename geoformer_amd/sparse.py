@@ -270,12 +270,18 @@ def conv_dgrad(grad_out: torch.Tensor, weight: torch.Tensor, bwd, M_in: int) -> 
     return conv_fwd(grad_out, wt, tbl, gmask, K, M, ld, steps=steps)
 
 
-def conv_wgrad(feats: torch.Tensor, grad_out: torch.Tensor, nbr, K: int, M_out: int, ld: int) -> torch.Tensor:
+def conv_wgrad(feats: torch.Tensor, grad_out: torch.Tensor, nbr, K: int, M_out: int, ld: int, gmask=None) -> torch.Tensor:
+    """dW[k] = sum_o feats[nbr[k][o]]^T grad_out[o]; with the table's group masks the (group, offset) pairs that have
+    no neighbour at all are skipped."""
     lib = _lib.load()
     Cin, Cout = feats.shape[1], grad_out.shape[1]
     dW = torch.empty((K, Cin, Cout), dtype=torch.float32, device=feats.device)
-    check(lib.gf_conv_wgrad(ptr(feats), ptr(grad_out), ptr(nbr), K, M_out, ld, Cin, Cout, ptr(dW), stream_ptr()),
-          "gf_conv_wgrad")
+    if gmask is not None and nbr is not None and K <= 32:
+        check(lib.gf_conv_wgrad_masked(ptr(feats), ptr(grad_out), ptr(nbr), ptr(gmask), K, M_out, ld, Cin, Cout, ptr(dW),
+                                       stream_ptr()), "gf_conv_wgrad_masked")
+    else:
+        check(lib.gf_conv_wgrad(ptr(feats), ptr(grad_out), ptr(nbr), K, M_out, ld, Cin, Cout, ptr(dW), stream_ptr()),
+              "gf_conv_wgrad")
     return dW
 
 

@@ -129,7 +129,7 @@ class _GatherConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             d_feats = sparse.conv_dgrad(g, weight, ctx.bwd, feats.shape[0])
         if ctx.needs_input_grad[1]:
-            d_weight = sparse.conv_wgrad(feats.contiguous(), g, tbl, K, M_out, ld).view_as(weight)
+            d_weight = sparse.conv_wgrad(feats.contiguous(), g, tbl, K, M_out, ld, gmask=gmask).view_as(weight)
         return d_feats, d_weight, None, None
 
 

@@ -92,7 +92,7 @@ def install():
             w = w.flip(0)
         return conv_fwd(grad_out, w.transpose(1, 2).contiguous(), tbl, gmask, K, M, ld)
 
-    def conv_wgrad(feats, grad_out, nbr, K, M_out, ld):
+    def conv_wgrad(feats, grad_out, nbr, K, M_out, ld, gmask=None):  # (the group masks only let the GPU kernel skip work)
         return _t(orc.conv_wgrad(_np(feats), _np(grad_out), _np(nbr), K))
 
     def voxelize_fp(feats, rules, mode=4, out=None):

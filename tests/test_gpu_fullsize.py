@@ -142,6 +142,9 @@ def test_conv_dgrad_wgrad_full_size(oracle, level1, Cin, Cout):
     got_w = sparse.conv_wgrad(_dev(feats), _dev(gout), rules.nbr, 27, M, rules.ld).cpu().numpy()
     # sums of ~35 000 products of unit-variance terms (|dW| ~ 200): relative to the magnitude
     assert np.abs(got_w - ref_w).max() < 2e-4 * max(1.0, float(np.abs(ref_w).max()))
+    # the route the training step takes: (group, offset) pairs without a neighbour skipped by the table's group masks
+    got_m = sparse.conv_wgrad(_dev(feats), _dev(gout), rules.nbr, 27, M, rules.ld, gmask=rules.gmask).cpu().numpy()
+    assert np.abs(got_m - ref_w).max() < 2e-4 * max(1.0, float(np.abs(ref_w).max()))
 
 
 def test_down_up_full_size(oracle, s150k, hip):
