@@ -51,6 +51,9 @@ def _declare(lib):
         "gf_unet_ws_bytes": (c_size_t, [P, I, I, I, I, I]),
         "gf_dev_unet_probe": (I, [I]),
         "gf_dev_unet_probe_read": (I, [I, P, P]),
+        "gf_dev_unet_probe_read2": (I, [I, P, P, P]),
+        "gf_dev_conv_kernel_events": (I, [P, P]),
+        "gf_dev_conv_kernel_events_taken": (I, []),
         "gf_unet_fwd": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
         "gf_voxelize_bp": (I, [P, P, I, I, I, I, P, P]),

@@ -111,7 +111,8 @@ __global__ void k_count_rules(const int32_t* __restrict__ tbl, int K, int ld, in
 }
 struct ProbeRec {
     int level, kind, K, Cin, Cout, M_in, M_out, res, slot;
-    hipEvent_t a, b;
+    hipEvent_t a, b;    // recorded on the stream before / after the launch
+    hipEvent_t ka, kb;  // bound to the kernel itself (null: the launch took another kernel than the pipelined one)
 };
 struct Probe {
     int mode = 0;
@@ -135,7 +136,7 @@ constexpr int kProbeSlots = 4096;
 }  // namespace
 
 extern "C" int gf_dev_unet_probe(int mode) {
-    GF_CHECK_ARG(mode >= 0 && mode <= 2, "gf_dev_unet_probe: mode %d (0 off, 1 level-1 block convs, 2 every conv)", mode);
+    GF_CHECK_ARG(mode >= 0 && mode <= 3, "gf_dev_unet_probe: mode %d (0 off, 1 / 3 level-1 block convs, 2 every conv)", mode);
     t_probe.mode = mode;
     if (mode == 2 && !t_probe.d_counts) GF_TRY(hipMalloc(&t_probe.d_counts, kProbeSlots * sizeof(int)));
     return GF_OK;
@@ -143,7 +144,12 @@ extern "C" int gf_dev_unet_probe(int mode) {
 
 // meta: max_records x 9 ints (level, kind, K, Cin, Cout, M_in, M_out, residual, rules or -1); us: max_records floats.
 // Waits for the recorded events; returns the number of records (clears them), or a negative status.
+extern "C" int gf_dev_unet_probe_read2(int max_records, int* meta, float* us, float* us_kernel);
 extern "C" int gf_dev_unet_probe_read(int max_records, int* meta, float* us) {
+    return gf_dev_unet_probe_read2(max_records, meta, us, nullptr);
+}
+// us_kernel (optional): the launch's duration by the events bound to the kernel itself, -1 where there are none
+extern "C" int gf_dev_unet_probe_read2(int max_records, int* meta, float* us, float* us_kernel) {
     Probe& pb = t_probe;
     std::vector<int> counts;
     if (pb.nslots > 0) {
@@ -160,6 +166,15 @@ extern "C" int gf_dev_unet_probe_read(int max_records, int* meta, float* us) {
         int* m = meta + (size_t)n * 9;
         m[0] = r.level; m[1] = r.kind; m[2] = r.K; m[3] = r.Cin; m[4] = r.Cout; m[5] = r.M_in; m[6] = r.M_out; m[7] = r.res;
         m[8] = r.slot >= 0 ? counts[r.slot] : -1;
+        if (us_kernel) {
+            us_kernel[n] = -1.f;
+            if (r.ka) {
+                float km = 0.f;
+                GF_TRY(hipEventSynchronize(r.kb));
+                GF_TRY(hipEventElapsedTime(&km, r.ka, r.kb));
+                us_kernel[n] = km * 1e3f;
+            }
+        }
         us[n++] = ms * 1e3f;
     }
     pb.recs.clear();
@@ -296,7 +311,7 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
                     const float* sh, const float* res, const float* osc, const float* osh, float* outp,
                     float* out_act = nullptr) -> int {
         Probe& pb = t_probe;
-        const bool rec = pb.mode == 2 || (pb.mode == 1 && l == 0 && (kind == 1 || kind == 2) && Cin == 16 && Cout == 16);
+        const bool rec = pb.mode == 2 || ((pb.mode == 1 || pb.mode == 3) && l == 0 && (kind == 1 || kind == 2) && Cin == 16 && Cout == 16);
         auto launch = [&]() -> int {
             if (out_act)
                 return gf_conv_fwd_dual(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp,
@@ -304,8 +319,14 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
             return gf_conv_fwd(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp, st);
         };
         if (!rec) return launch();
-        ProbeRec r{l, kind, K, Cin, Cout, M_in, M_out, res != nullptr, -1, pb.ev(), pb.ev()};
+        ProbeRec r{l, kind, K, Cin, Cout, M_in, M_out, res != nullptr, -1, pb.ev(), pb.ev(), nullptr, nullptr};
         GF_CHECK_ARG(r.a && r.b, "gf_unet_fwd: probe events");
+        if (pb.mode == 3) {
+            r.ka = pb.ev();
+            r.kb = pb.ev();
+            GF_CHECK_ARG(r.ka && r.kb, "gf_unet_fwd: probe events");
+            gf_dev_conv_kernel_events(r.ka, r.kb);
+        }
         if (pb.mode == 2 && nbr && pb.nslots < kProbeSlots && M_out > 0) {
             r.slot = pb.nslots++;
             GF_TRY(hipMemsetAsync(pb.d_counts + r.slot, 0, sizeof(int), st));
@@ -314,6 +335,10 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
         GF_TRY(hipEventRecord(r.a, st));
         const int rc_ = launch();
         GF_TRY(hipEventRecord(r.b, st));
+        if (r.ka && !gf_dev_conv_kernel_events_taken()) {
+            gf_dev_conv_kernel_events(nullptr, nullptr);
+            r.ka = r.kb = nullptr;
+        }
         pb.recs.push_back(r);
         return rc_;
     };

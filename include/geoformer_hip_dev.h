@@ -38,7 +38,8 @@ int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe);
 int gf_dev_conv_chunks(int n);
 
 /* Events around the convolution launches of gf_unet_fwd, recorded on the stream the kernels run on (bench.py's
- * roofline probes).  mode 0 = off, 1 = the level-1 3x3x3 16->16 convolutions of the residual blocks, 2 = every
+ * roofline probes).  mode 0 = off, 1 = the level-1 3x3x3 16->16 convolutions of the residual blocks, 3 = the same
+ * with two more events bound to the kernel launch itself (gf_dev_unet_probe_read2), 2 = every
  * convolution (+ a counting kernel per table for the number of rules).  State is per host thread.
  * gf_dev_unet_probe_read waits for the events and returns the number of records (at most max_records) and clears
  * them: meta[9*i..] = level (0-based), kind (0 input conv, 1 / 2 first / second conv of a block, 3 identity 1x1x1,
@@ -46,6 +47,15 @@ int gf_dev_conv_chunks(int n);
  * us[i] = microseconds between the two events. */
 int gf_dev_unet_probe(int mode);
 int gf_dev_unet_probe_read(int max_records, int* meta, float* us);
+/* The same plus, in mode 1, the launch's duration by two events BOUND TO THE KERNEL (hipExtLaunchKernelGGL: the
+ * dispatch's own begin / end timestamps -- what a profiler's kernel trace reports), -1 where the launch did not take
+ * the pipelined level-1 kernel.  Events recorded before / after a launch on its stream (us[]) add the command
+ * processor's handling of the two event packets, ~1.3 us on a 20 us kernel. */
+int gf_dev_unet_probe_read2(int max_records, int* meta, float* us, float* us_kernel);
+/* Two caller-owned hipEvent_t that the next launch of the pipelined level-1 kernel on this host thread binds to itself
+ * (NULL, NULL: none); ..._taken: 1 if the last launch consumed them. */
+int gf_dev_conv_kernel_events(void* start, void* stop);
+int gf_dev_conv_kernel_events_taken(void);
 
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);

@@ -388,3 +388,37 @@ def test_forward_s150k_matches_oracle_backed_forward(hip, oracle, s150k):
         assert np.abs(pg[1].cpu().numpy() - pc[1].numpy()).max() < 1e-4
         d = np.abs(pg[2].sum(1).cpu().numpy() - pc[2].sum(1).numpy())
         assert d.max() <= 3
+
+
+def test_conv_probe_events_s150k(hip, s150k):
+    """bench.py's roofline probe on the benchmark scene: the seven level-1 16->16 launches of a forward are recorded in
+    both modes, the events bound to the kernel launch give a duration inside the one of the events recorded around it,
+    and binding them does not change what the forward computes."""
+    import bench
+    from geoformer_amd import _lib
+
+    _, batch, _, _ = s150k
+    dev_batch = bench.to_device(batch, "cuda")
+    m = bench.build_model("cuda", probe_batch=dev_batch)
+    lib = _lib.load()
+    outs = {}
+    for mode in (0, 1, 3):
+        lib.gf_dev_unet_probe(mode)
+        try:
+            np.random.seed(5)
+            with torch.no_grad():
+                outs[mode] = m(dev_batch, 0, training=False)["semantic_scores"].clone()
+            torch.cuda.synchronize()
+        finally:
+            lib.gf_dev_unet_probe(0)
+        recs = bench._read_probe()
+        if mode == 0:
+            assert recs == []
+            continue
+        assert len(recs) == 7 and all(r[3] == 16 and r[4] == 16 and r[2] == 27 for r in recs)
+        assert all(5.0 < r[9] < 200.0 for r in recs)
+        if mode == 1:
+            assert all(r[10] == -1.0 for r in recs)
+        else:
+            assert all(5.0 < r[10] <= r[9] for r in recs), recs
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3])
