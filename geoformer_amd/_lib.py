@@ -36,6 +36,7 @@ def _declare(lib):
         "gf_rules_down2_chain": (I, [P, I, I, I, I, I, I, P, P, P]),
         "gf_conv_packed_floats": (c_size_t, [I, I, I]),
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
+        "gf_conv_pack_weights_t": (I, [P, I, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
         "gf_conv_dual_supported": (I, [I, I, I, I, I]),
         "gf_conv_fwd_dual": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P]),

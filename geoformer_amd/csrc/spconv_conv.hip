@@ -66,6 +66,44 @@ extern "C" int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, fl
     return GF_OK;
 }
 
+// The input gradient's weights in one launch: Wp = pack(W'), W'[k] = W[flip ? K-1-k : k]^T  ([K,Cin,Cout] -> the packed
+// stream of a [K,Cout,Cin] operand).  (A flip copy + a transpose copy + the pack: three launches per convolution and
+// backward, 128 launches per training step.)
+__global__ void k_pack_weights_t(const float* __restrict__ W, int K, int Cin, int Cout, int NCH, int NCB, int flip,
+                                 float* __restrict__ Wp) {
+    // the packed operand has Cout rows (input channels of the gradient convolution) and Cin columns
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)K * NCH * NCB * 64;
+    if (t >= total) return;
+    const int lane = (int)(t & 63);
+    size_t u = t >> 6;
+    const int cb = (int)(u % NCB);
+    u /= NCB;
+    const int ch = (int)(u % NCH);
+    const int k = (int)(u / NCH);
+    const int ks = flip ? K - 1 - k : k;
+    const int r = lane & 15, q = lane >> 4;
+    const int col = cb * 16 + r;  // column of W' = input channel of W
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* pv = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+        const int row = ch * 16 + 4 * q + kk;  // row of W' = output channel of W
+        if (row < Cout && col < Cin) pv[kk] = W[((size_t)ks * Cin + col) * Cout + row];
+    }
+    reinterpret_cast<float4*>(Wp)[t] = v;
+}
+
+extern "C" int gf_conv_pack_weights_t(const float* W, int K, int Cin, int Cout, int flip, float* Wp, void* stream) {
+    GF_CHECK_ARG(W && Wp && K >= 1 && Cin >= 1 && Cout >= 1, "gf_conv_pack_weights_t: bad arguments");
+    const int nch = (Cout + 15) / 16, ncb = (Cin + 15) / 16;
+    size_t total = (size_t)K * nch * ncb * 64;
+    hipLaunchKernelGGL(k_pack_weights_t, dim3(gf_div_up((long long)total, 256)), dim3(256), 0, (hipStream_t)stream, W, K,
+                       Cin, Cout, nch, ncb, flip, Wp);
+    GF_CHECK_LAUNCH("gf_conv_pack_weights_t");
+    return GF_OK;
+}
+
 // Raw gather of this lane's 4 channels of row idx (zeros for a missing neighbour).  The fused
 // BatchNorm+ReLU is applied later (activate_a), next to the MFMAs, so that the gathers of a batch
 // are issued back to back instead of each waiting for its own data.

@@ -175,19 +175,23 @@ def pack_weights(weight: torch.Tensor) -> torch.Tensor:
 
 def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], gmask: Optional[torch.Tensor],
              K: int, M_out: int, ld: int, in_scale=None, in_shift=None, residual=None, out=None,
-             events=None, steps=None, out_scale=None, out_shift=None) -> torch.Tensor:
+             events=None, steps=None, out_scale=None, out_shift=None, packed=None) -> torch.Tensor:
     """out[o] = sum_k act(feats[nbr[k,o]]) @ weight[k] (+ residual), optionally followed by the epilogue activation
-    max(out*out_scale + out_shift, 0).  weight is [K,Cin,Cout] fp32."""
+    max(out*out_scale + out_shift, 0).  weight is [K,Cin,Cout] fp32; packed = (wp, Cin, Cout): weights that are
+    packed already (weight is ignored)."""
     lib = _lib.load()
     assert feats.is_cuda and feats.dtype == torch.float32 and feats.is_contiguous()
-    assert weight.dtype == torch.float32 and weight.is_contiguous()
-    Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
+    if packed is not None:
+        Cin, Cout = int(packed[1]), int(packed[2])
+    else:
+        assert weight.dtype == torch.float32 and weight.is_contiguous()
+        Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
     assert feats.shape[1] == Cin, (feats.shape, weight.shape)
     if out is None:
         out = torch.empty((M_out, Cout), dtype=torch.float32, device=feats.device)
     if residual is not None:
         assert residual.is_contiguous() and residual.shape == (M_out, Cout)
-    wp = pack_weights(weight)
+    wp = packed[0] if packed is not None else pack_weights(weight)
     if events is not None:  # (start, stop) torch.cuda.Event pair recorded around the launch in native code
         from ctypes import c_void_p
 
@@ -263,11 +267,13 @@ def conv_dgrad(grad_out: torch.Tensor, weight: torch.Tensor, bwd, M_in: int) -> 
     tbl, gmask, K, M, ld = spec[:5]
     steps = spec[5] if len(spec) > 5 else None
     Cin, Cout = int(weight.shape[-2]), int(weight.shape[-1])
-    w = weight.detach().reshape(K, Cin, Cout)
-    if kind == "subm":
-        w = w.flip(0)
-    wt = w.transpose(1, 2).contiguous()
-    return conv_fwd(grad_out, wt, tbl, gmask, K, M, ld, steps=steps)
+    w = weight.detach()
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+    lib = _lib.load()
+    wp = torch.empty(lib.gf_conv_packed_floats(K, Cout, Cin), dtype=torch.float32, device=w.device)
+    check(lib.gf_conv_pack_weights_t(ptr(w), K, Cin, Cout, 1 if kind == "subm" else 0, ptr(wp), stream_ptr()),
+          "gf_conv_pack_weights_t")
+    return conv_fwd(grad_out, None, tbl, gmask, K, M, ld, steps=steps, packed=(wp, Cout, Cin))
 
 
 def conv_wgrad(feats: torch.Tensor, grad_out: torch.Tensor, nbr, K: int, M_out: int, ld: int, gmask=None) -> torch.Tensor:

@@ -129,6 +129,10 @@ int gf_rules_down2_chain(const int32_t* coords, int M0, int B, int X, int Y, int
  * (channels zero-padded to multiples of 16). */
 size_t gf_conv_packed_floats(int K, int Cin, int Cout);
 int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream);
+/* Packed weights of the INPUT GRADIENT's convolution in one launch: the pack of W'[k] = W[flip ? K-1-k : k]^T, a
+ * [K,Cout,Cin] operand (gf_conv_packed_floats(K, Cout, Cin) floats); flip = 1 for submanifold tables (gf_conv_wgrad's
+ * comment: weights W[K-1-k]^T over the same table), 0 for the child <-> up tables. */
+int gf_conv_pack_weights_t(const float* W, int K, int Cin, int Cout, int flip, float* Wp, void* stream);
 
 /* Forward gather-GEMM (output-stationary): out[o,:] = sum_k act(in[nbr[k][o],:]) @ W[k] (+ residual[o,:])
  *   in fp32 [M_in,Cin]   Wp = packed W (gf_conv_pack_weights)   out fp32 [M_out,Cout]

@@ -11,7 +11,7 @@ mv = lambda d: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d.items(
 cfg = load_config("geoformer_scannet.yaml", batch_size=4, prepare_epochs=120)
 m = GeoFormer(cfg); m.load_state_dict(synthetic_state_dict(m.state_dict(), 0)); m.to(dev); m.train()
 crit = InstSetCriterion(cfg)
-opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=1e-3)
+opt = torch.optim.Adam(filter(lambda p: p.requires_grad, m.parameters()), lr=1e-3, fused=os.environ.get("ADAM_FUSED", "1") == "1")
 batch = mv(scene.make_batch([scene.make_scene(int(n), 50 + i) for i, n in enumerate((150_000, 120_000, 180_000, 100_000))]))
 def step():
     np.random.seed(0)
@@ -101,3 +101,28 @@ if os.environ.get("TPROF_STACK"):
     for e in rows[:40]:
         st = [x for x in e.stack if "geoformer_amd" in x or "tools/" in x][:3]
         print(f"{e.key:14s} n {e.count:4d} self {e.self_cpu_time_total / 1e3:7.2f} ms  avg {e.self_cpu_time_total / e.count:6.1f} us  " + " <- ".join(s.split('/')[-1][:60] for s in st))
+if os.environ.get("COPIES"):
+    import traceback, collections
+    cnt = collections.Counter(); byt = collections.Counter()
+    def site():
+        fr = [x for x in traceback.extract_stack()[:-2] if "geoformer_amd" in x.filename]
+        return f"{os.path.basename(fr[-1].filename)}:{fr[-1].lineno} {fr[-1].name}" if fr else "?"
+    oc = torch.Tensor.contiguous
+    def contiguous(self, *a, **k):
+        if not self.is_contiguous():
+            s = site(); cnt["contiguous " + s] += 1; byt["contiguous " + s] += self.numel() * self.element_size()
+        return oc(self, *a, **k)
+    torch.Tensor.contiguous = contiguous
+    for nm in ("float", "long", "int", "clone", "to", "half", "double", "bool"):
+        def mk(nm, orig):
+            def f(self, *a, **k):
+                r = orig(self, *a, **k)
+                if r.data_ptr() != self.data_ptr() and self.is_cuda:
+                    s = site(); cnt[nm + " " + s] += 1; byt[nm + " " + s] += r.numel() * r.element_size()
+                return r
+            return f
+        setattr(torch.Tensor, nm, mk(nm, getattr(torch.Tensor, nm)))
+    step(); torch.cuda.synchronize(); cnt.clear(); byt.clear()
+    step(); torch.cuda.synchronize()
+    print("copies per step by call site (python-visible ones):", sum(cnt.values()))
+    for k, v in cnt.most_common(40): print(f"  {v:4d}  {byt[k] / 1e6:9.2f} MB  {k}")

@@ -116,7 +116,8 @@ def main(argv=None):
     try:
         cfg, m, crit = build(args, device)
         red = parallel.BucketedGradReducer(m, bucket_bytes=int(args.bucket_mb * (1 << 20)))
-        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3,
+                               fused=device.type == "cuda")  # one launch per step on the GPU (the foreach form: ~5 ms of host time)
         nb = 2
         batches = make_batches(args, rank, device, nb)
         sync = (lambda: torch.cuda.synchronize()) if device.type == "cuda" else (lambda: None)
