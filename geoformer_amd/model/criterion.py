@@ -101,9 +101,48 @@ def scene_id_ranges(instance_masked, counts):
     return out
 
 
+class _PairLossFn(torch.autograd.Function):
+    """(dice, focal) of one scene's matched pairs through gf_pair_losses_fwd / _bwd (csrc/pair_losses.hip): three
+    launches instead of the ~75 of the operator-by-operator formulation below."""
+
+    @staticmethod
+    def forward(ctx, mask_logit_b, m):
+        from .. import _lib
+        from .._lib import check, ptr, stream_ptr
+
+        x = mask_logit_b.contiguous()
+        nq, n = x.shape
+        K = m.inst_masks.shape[0]
+        sums = torch.empty((max(K, 1), 4), dtype=torch.float32, device=x.device)
+        out = torch.empty(2, dtype=torch.float32, device=x.device)
+        check(_lib.load().gf_pair_losses_fwd(ptr(x), ptr(m.inst_masks), ptr(m.match_q), nq, K, n, ptr(m.n_match), ptr(sums),
+                                             ptr(out), stream_ptr()), "gf_pair_losses_fwd")
+        ctx.save_for_backward(x, sums)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from .. import _lib
+        from .._lib import check, ptr, stream_ptr
+
+        x, sums = ctx.saved_tensors
+        m = ctx.m
+        nq, n = x.shape
+        g = grad_out.contiguous().float()
+        dx = torch.empty_like(x)
+        check(_lib.load().gf_pair_losses_bwd(ptr(x), ptr(m.inst_masks), ptr(m.match_of_q), ptr(sums), nq,
+                                             m.inst_masks.shape[0], n, ptr(m.n_match), ptr(g), ptr(dx), stream_ptr()),
+              "gf_pair_losses_bwd")
+        return dx, None
+
+
 def masked_pair_losses(mask_logit_b, m, n):
     """dice and focal loss sums over the matched (query, instance) pairs of one scene, unmatched instance rows masked
     out; n = number of pairs as a device scalar (compute_dice_loss / compute_sigmoid_focal_loss on the matched rows)."""
+    if mask_logit_b.is_cuda and mask_logit_b.dtype == torch.float32 and m.inst_masks.is_contiguous():
+        out = _PairLossFn.apply(mask_logit_b, m)
+        return out[0], out[1]
     valid = (m.match_q >= 0).float()
     pred = mask_logit_b[m.match_q.clamp(min=0).long()]  # [K, n_mask]
     tgt = m.inst_masks

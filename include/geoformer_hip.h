@@ -236,6 +236,17 @@ int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int32_t* coords
 int gf_lsap(const float* cost, int nq, int K, const int32_t* present, int32_t* match_q, int32_t* match_of_q,
             int32_t* n_match, int32_t* status, void* stream);
 
+/* Dice and focal loss of one scene's matched (query, instance) pairs for one decoder layer
+ * (compute_dice_loss / compute_sigmoid_focal_loss on the matched rows, /root/reference/criterion.py:26-58,137-190), and
+ * their gradient.  mask_logits fp32 [nq,n]; inst_masks fp32 0/1 [K,n]; match_q [K] / match_of_q [nq] / n_match [1] as
+ * gf_lsap wrote them.  fwd: sums fp32 [K,4] (row sums: p t, p, t, focal term; kept for the backward),
+ * out[0] = sum_k dice_k / (n_match + 1e-6), out[1] = sum_k mean_j focal_kj / (n_match + 1e-6).
+ * bwd: grad_out fp32 [2] (d loss / d out), d_logits fp32 [nq,n] written in full (zero rows for unmatched queries). */
+int gf_pair_losses_fwd(const float* mask_logits, const float* inst_masks, const int32_t* match_q, int nq, int K, int n,
+                       const int32_t* n_match, float* sums, float* out, void* stream);
+int gf_pair_losses_bwd(const float* mask_logits, const float* inst_masks, const int32_t* match_of_q, const float* sums,
+                       int nq, int K, int n, const int32_t* n_match, const float* grad_out, float* d_logits, void* stream);
+
 /* ===================================================================================
  * PG_OP (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-23)
  * =================================================================================== */

@@ -161,3 +161,52 @@ def test_lsap_equals_scipy():
             inv = np.full(K, -1, np.int64)
             inv[cols_present[cols]] = rows
             assert (mq.cpu().numpy() == inv).all()
+
+
+@pytest.mark.gpu
+def test_pair_losses_kernel_equals_operator_formulation():
+    """gf_pair_losses_fwd / _bwd (the fused dice + focal loss of a scene's matched pairs) against the operator-by-operator
+    PyTorch formulation of criterion.masked_pair_losses on the same device match: values and the gradient with respect
+    to the mask logits, with absent instances, unmatched queries, more instances than queries, and large logits."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from geoformer_amd.model import criterion as C
+
+    g = torch.Generator().manual_seed(3)
+    for nq, K, n, absent, scale in ((128, 9, 30000, 2, 3.0), (16, 40, 5001, 0, 1.0), (64, 1, 777, 0, 20.0), (8, 5, 64, 5, 1.0)):
+        x = (torch.randn(nq, n, generator=g) * scale).cuda().requires_grad_(True)
+        ids = torch.randint(0, K, (n,), generator=g)
+        present = torch.ones(K, dtype=torch.bool)
+        present[torch.randperm(K, generator=g)[:absent]] = False
+        ids[~present[ids]] = -100 + 0 * ids[~present[ids]]
+        m = C.DeviceMatch()
+        m.lo = 0
+        m.inst_masks = (ids[None, :] == torch.arange(K)[:, None]).float().cuda().contiguous()
+        pres = (m.inst_masks.sum(1) > 0).cpu()
+        cols = torch.nonzero(pres).flatten()
+        nm = min(nq, cols.numel())
+        qs = torch.randperm(nq, generator=g)[:nm]
+        ks = cols[torch.randperm(cols.numel(), generator=g)[:nm]]
+        mq = torch.full((K,), -1, dtype=torch.int32)
+        moq = torch.full((nq,), -1, dtype=torch.int32)
+        mq[ks] = qs.int()
+        moq[qs] = ks.int()
+        m.match_q, m.match_of_q = mq.cuda(), moq.cuda()
+        m.n_match = torch.tensor([nm], dtype=torch.int32).cuda()
+        w = torch.tensor([0.7, 1.3]).cuda()
+        n_f = m.n_match[0].float()
+        # reference: the operator formulation (the same function, taken on a float64 copy it does not fuse)
+        xr = x.detach().double().requires_grad_(True)
+        m64 = C.DeviceMatch()
+        m64.inst_masks, m64.match_q, m64.match_of_q, m64.n_match = m.inst_masks.double(), m.match_q, m.match_of_q, m.n_match
+        dr, fr = C.masked_pair_losses(xr, m64, n_f.double())
+        (dr * w[0] + fr * w[1]).backward()
+        dg, fg = C.masked_pair_losses(x, m, n_f)
+        (dg * w[0] + fg * w[1]).backward()
+        assert abs(dg.item() - dr.item()) <= 1e-5 * max(1.0, abs(dr.item())), (nq, K, n)
+        assert abs(fg.item() - fr.item()) <= 1e-5 * max(1.0, abs(fr.item())), (nq, K, n)
+        gr = xr.grad.float()
+        assert (x.grad - gr).abs().max().item() <= 1e-5 * max(gr.abs().max().item(), 1e-12), (nq, K, n)
+        if nm:
+            unmatched = (m.match_of_q < 0)
+            assert (x.grad[unmatched] == 0).all()

@@ -126,3 +126,19 @@ if os.environ.get("COPIES"):
     step(); torch.cuda.synchronize()
     print("copies per step by call site (python-visible ones):", sum(cnt.values()))
     for k, v in cnt.most_common(40): print(f"  {v:4d}  {byt[k] / 1e6:9.2f} MB  {k}")
+if os.environ.get("OPCOUNT"):
+    from torch.profiler import profile, ProfilerActivity
+    import collections
+    def prof_phase(fn):
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as p:
+            r = fn(); torch.cuda.synchronize()
+        ev = [e for e in p.events() if e.device_type.name != "CPU"]
+        return r, len(ev), sum(e.device_time for e in ev) / 1e3 if ev else 0.0
+    np.random.seed(0)
+    orig_bb = m.forward_backbone; bbk = [0, 0.0]
+    out, nf, tf = prof_phase(lambda: m(batch, 200))
+    (loss, _), nc, tc = prof_phase(lambda: crit(out, batch, 200))
+    opt.zero_grad()
+    _, nb, tb = prof_phase(lambda: loss.backward())
+    _, no, to = prof_phase(lambda: opt.step())
+    print(f"device activities (kernels + copies): forward {nf} ({tf:.1f} ms), criterion {nc} ({tc:.1f} ms), backward {nb} ({tb:.1f} ms), optimizer {no} ({to:.1f} ms)")
