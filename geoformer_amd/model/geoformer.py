@@ -421,35 +421,53 @@ class GeoFormer(nn.Module):
             aux = sides[(locs_float_.device, main.cuda_stream, "aux")] = torch.cuda.Stream(device=locs_float_.device)
         geo_ready = []
         staged, geo = [], []
+        # Several scenes with gradients (the training step): every scene's sampling goes to a stream of its own and its
+        # BFS to another, so the scenes' two latency-bound launches run beside each other instead of one scene after
+        # the other (4 x (0.4 + 3.3) ms of a batch-4 step in which the device finishes last); the main stream joins
+        # them before the grouping.  One scene / inference: the streams of the docstring.
+        multi = batch_size > 1 and early is None and not epilogue
+        scene_streams = []
         for b in range(batch_size):
             n_b = offs[b + 1] - offs[b]
             if n_b == 0:
                 return None, None
-            if sample:
-                npoint = min(n_b, self.cfg.n_downsampling)
-                # the reference's host draw (same values, same generator state), restated natively: the device idles on it
-                # (drawn into a pinned buffer of this host thread: the upload is an asynchronous copy on the stream)
-                pins = getattr(_OFFS_CACHE, "draw_pins", None)
-                if pins is None:
-                    pins = _OFFS_CACHE.draw_pins = {}
-                pin = pins.get((main.cuda_stream, b))  # per caller stream: scenes in flight on two streams
-                if pin is None or pin.numel() < npoint:
-                    pin = pins[(main.cuda_stream, b)] = torch.empty(max(npoint, 65536), dtype=torch.int64).pin_memory()
-                drawn = pointops.legacy_choice(n_b, npoint, out=pin.numpy())
-                if drawn.ctypes.data != pin.data_ptr():  # numpy's own route (exotic generator state): stage it
-                    pin.numpy()[:npoint] = drawn
-                sampling_indices = pin[:npoint].to(locs_float_.device, non_blocking=True)
-                self.last_sampling_indices = sampling_indices
-                xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
+            if multi:
+                sb = sides.get((locs_float_.device, main.cuda_stream, "scene", b))
+                if sb is None:
+                    sb = sides[(locs_float_.device, main.cuda_stream, "scene", b)] = torch.cuda.Stream(device=locs_float_.device)
+                side_b = sides.get((locs_float_.device, main.cuda_stream, "bfs", b))
+                if side_b is None:
+                    side_b = sides[(locs_float_.device, main.cuda_stream, "bfs", b)] = torch.cuda.Stream(device=locs_float_.device)
+                sb.wait_stream(main)
+                scene_streams.append(sb)
             else:
-                sampling_indices = None
-                xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
-            xyz_ready = torch.cuda.Event()
-            xyz_ready.record(main)
-            first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
-            src = first[0, :nq].contiguous()
-            first_ready = torch.cuda.Event()
-            first_ready.record(main)
+                sb, side_b = main, side
+            with torch.cuda.stream(sb):
+                if sample:
+                    npoint = min(n_b, self.cfg.n_downsampling)
+                    # the reference's host draw (same values, same generator state), restated natively: the device idles on it
+                    # (drawn into a pinned buffer of this host thread: the upload is an asynchronous copy on the stream)
+                    pins = getattr(_OFFS_CACHE, "draw_pins", None)
+                    if pins is None:
+                        pins = _OFFS_CACHE.draw_pins = {}
+                    pin = pins.get((main.cuda_stream, b))  # per caller stream: scenes in flight on two streams
+                    if pin is None or pin.numel() < npoint:
+                        pin = pins[(main.cuda_stream, b)] = torch.empty(max(npoint, 65536), dtype=torch.int64).pin_memory()
+                    drawn = pointops.legacy_choice(n_b, npoint, out=pin.numpy())
+                    if drawn.ctypes.data != pin.data_ptr():  # numpy's own route (exotic generator state): stage it
+                        pin.numpy()[:npoint] = drawn
+                    sampling_indices = pin[:npoint].to(locs_float_.device, non_blocking=True)
+                    self.last_sampling_indices = sampling_indices
+                    xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
+                else:
+                    sampling_indices = None
+                    xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
+                xyz_ready = torch.cuda.Event()
+                xyz_ready.record(sb)
+                first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
+                src = first[0, :nq].contiguous()
+                first_ready = torch.cuda.Event()
+                first_ready.record(sb)
             if early is not None and b == 0:
                 # work of the caller that does not depend on the sampling (early() -> (.., .., kNN graphs)): queued on
                 # the third stream now that the first sampling launch is out
@@ -475,32 +493,44 @@ class GeoFormer(nn.Module):
                     grid_done = torch.cuda.Event()
                     grid_done.record(aux)
                 grid = (grid, grid_done)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+            if multi:
+                side_b.wait_event(first_ready)
+            else:
+                side.wait_stream(main)
+            with torch.cuda.stream(side_b):
                 D, I, deg = graphs[b][:3]
                 g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_BFS_WG if split else 1024)
                 g.record_stream(main)
-                src.record_stream(side)
+                src.record_stream(side_b)
                 geo.append(g)
                 ev = torch.cuda.Event()
-                ev.record(side)
+                ev.record(side_b)
                 geo_ready.append(ev)
             # the rest of the sampling is on the critical path: issue it before anything else
-            idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+            with torch.cuda.stream(sb):
+                idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+            if multi:
+                for t in (xyz_b, idx, first, sampling_indices):
+                    if t is not None:
+                        t.record_stream(main)
             if early is not None and b == 0:
                 main.wait_event(early_done)
-            # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
-            with grad_ctx():
-                feat_b = output_feats_[offs[b]:offs[b + 1]]
-                if sampling_indices is not None:
-                    feat_b = feat_b[sampling_indices]
-                feat_b = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
-            staged.append((xyz_b, feat_b, idx, grid))
+            staged.append([xyz_b, None, idx, grid, sampling_indices])
             if not epilogue:
                 continue
             # small launches that only need the distances / the query picks ride beside the sampling instead of
             # sitting between the decoder and the mask head on the main stream
             self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready)
+        for sb in scene_streams:
+            main.wait_stream(sb)
+        # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
+        with grad_ctx():
+            for b, st in enumerate(staged):
+                feat_b = output_feats_[offs[b]:offs[b + 1]]
+                if st[4] is not None:
+                    feat_b = feat_b[st[4]]
+                st[1] = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
+        staged = [tuple(st[:4]) for st in staged]
         self.__dict__.setdefault("_gf_pending_side", {})[_stream_key(locs_float_.device)] = geo_ready
         cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
         with grad_ctx():

@@ -142,3 +142,21 @@ if os.environ.get("OPCOUNT"):
     _, nb, tb = prof_phase(lambda: loss.backward())
     _, no, to = prof_phase(lambda: opt.step())
     print(f"device activities (kernels + copies): forward {nf} ({tf:.1f} ms), criterion {nc} ({tc:.1f} ms), backward {nb} ({tb:.1f} ms), optimizer {no} ({to:.1f} ms)")
+if os.environ.get("BWDNAMES"):
+    from torch.profiler import profile, ProfilerActivity
+    import collections
+    np.random.seed(0)
+    which = os.environ["BWDNAMES"]
+    if which == "fwd":
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as p:
+            out = m(batch, 200); torch.cuda.synchronize()
+    else:
+        out = m(batch, 200); loss, _ = crit(out, batch, 200); opt.zero_grad()
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as p:
+            loss.backward(); torch.cuda.synchronize()
+    cnt = collections.Counter(); tim = collections.Counter()
+    for e in p.events():
+        if e.device_type.name != "CPU":
+            k = e.name.split("(")[0][:70]; cnt[k] += 1; tim[k] += e.device_time
+    print(which, "launches", sum(cnt.values()))
+    for k, v in cnt.most_common(28): print(f"  {v:5d}  {tim[k] / 1e3:7.2f} ms  {k}")
