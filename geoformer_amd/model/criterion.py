@@ -29,6 +29,12 @@ def _device_route(t):
     return t.is_cuda and os.environ.get("GF_DEVICE_CRITERION", "1") != "0"
 
 
+def _fused_pair_loss():
+    import os
+
+    return os.environ.get("GF_FUSED_PAIR_LOSS", "1") != "0"  # dev knob: 0 = the operator-by-operator formulation
+
+
 class DeviceMatch:
     """Ground truth and assignment of one scene, all on the device.  The instance axis has K entries = the scene's id
     range [lo, lo + K); `present` marks the ids that occur among the scene's (sub-sampled) foreground points."""
@@ -140,7 +146,8 @@ class _PairLossFn(torch.autograd.Function):
 def masked_pair_losses(mask_logit_b, m, n):
     """dice and focal loss sums over the matched (query, instance) pairs of one scene, unmatched instance rows masked
     out; n = number of pairs as a device scalar (compute_dice_loss / compute_sigmoid_focal_loss on the matched rows)."""
-    if mask_logit_b.is_cuda and mask_logit_b.dtype == torch.float32 and m.inst_masks.is_contiguous():
+    if (mask_logit_b.is_cuda and mask_logit_b.dtype == torch.float32 and m.inst_masks.is_contiguous()
+            and _fused_pair_loss()):
         out = _PairLossFn.apply(mask_logit_b, m)
         return out[0], out[1]
     valid = (m.match_q >= 0).float()

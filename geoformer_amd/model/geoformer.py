@@ -425,7 +425,7 @@ class GeoFormer(nn.Module):
         # BFS to another, so the scenes' two latency-bound launches run beside each other instead of one scene after
         # the other (4 x (0.4 + 3.3) ms of a batch-4 step in which the device finishes last); the main stream joins
         # them before the grouping.  One scene / inference: the streams of the docstring.
-        multi = batch_size > 1 and early is None and not epilogue
+        multi = batch_size > 1 and early is None and not epilogue and os.environ.get("GF_SCENE_STREAMS", "1") != "0"
         scene_streams = []
         for b in range(batch_size):
             n_b = offs[b + 1] - offs[b]
