@@ -323,8 +323,13 @@ class BackboneTransformer(nn.Module):
             # rows of a scene are contiguous: ONE read-back gives every scene's range (a nonzero + min + max per scene
             # blocked the host thirteen times per call)
             nb = batch_size if batch_size is not None else int(batch_ids.max().item()) + 1
-            bounds = [0] + torch.cumsum(scene_counts(batch_ids, nb), 0).tolist()
-        for b in range(len(bounds) - 1):
+            counts = scene_counts(batch_ids, nb)
+            ends = torch.cumsum(counts, 0)
+            bounds = [0] + ends.tolist()
+            if nb > 1 and features.is_cuda and features.shape[0] > 0:
+                return self._forward_padded(xyz, features, batch_ids, bounds, ends - counts)
+        nb = len(bounds) - 1
+        for b in range(nb):
             s, e = bounds[b], bounds[b + 1]
             if e == s:
                 continue
@@ -336,6 +341,29 @@ class BackboneTransformer(nn.Module):
                 x = layer(x, mask=None)
             out[rows] = self.norm(x).squeeze(0)
         return out
+
+    def _forward_padded(self, xyz, features, batch_ids, bounds, starts):
+        """Several scenes in ONE pass: rows padded to the longest scene, padded keys masked out (the reference
+        layers' own `mask` argument: scores of masked keys are filled with -1e9, their soft-max weight is exactly 0).
+        The per-scene loop above issues the ~45 small launches of a layer once per scene -- and as many again in the
+        backward; on a few hundred voxels per scene the host's launch rate is all that takes time."""
+        nb, d = len(bounds) - 1, self.d_model
+        M = features.shape[0]
+        lens = [bounds[b + 1] - bounds[b] for b in range(nb)]
+        L = max(lens)
+        rels = []
+        for b in range(nb):  # the position term with the reference's own expression (same rounding), per scene
+            pts = xyz[bounds[b]:bounds[b + 1]].view(-1, 3)
+            if pts.shape[0]:
+                rels.append((pts.unsqueeze(1) - pts.unsqueeze(0)).float().mean(dim=1))
+        x_all = features.view(-1, d) + self.position_linear(torch.cat(rels))
+        bid = batch_ids.long()
+        slot = torch.arange(M, device=features.device) - starts[bid] + bid * L  # row -> padded position
+        x = x_all.new_zeros(nb * L, d).index_copy(0, slot, x_all).view(nb, L, d)
+        mask = torch.zeros(nb * L, device=features.device, dtype=torch.long).index_fill_(0, slot, 1).view(nb, 1, L)
+        for layer in self.layers:
+            x = layer(x, mask=mask)
+        return self.norm(x).view(nb * L, d)[slot]
 
 
 # ------------------------------------------------------------------------------------------

@@ -160,3 +160,16 @@ if os.environ.get("BWDNAMES"):
             k = e.name.split("(")[0][:70]; cnt[k] += 1; tim[k] += e.device_time
     print(which, "launches", sum(cnt.values()))
     for k, v in cnt.most_common(28): print(f"  {v:5d}  {tim[k] / 1e3:7.2f} ms  {k}")
+if os.environ.get("NODES"):
+    from torch.profiler import profile, ProfilerActivity
+    import collections
+    np.random.seed(0)
+    out = m(batch, 200); loss, _ = crit(out, batch, 200); opt.zero_grad()
+    with profile(activities=[ProfilerActivity.CPU]) as p:
+        loss.backward(); torch.cuda.synchronize()
+    cnt = collections.Counter(); tim = collections.Counter()
+    for e in p.key_averages():
+        if e.key.startswith("autograd::engine::evaluate_function: "):
+            k = e.key.split(": ", 1)[1]; cnt[k] = e.count; tim[k] = e.cpu_time_total
+    print("autograd nodes", sum(cnt.values()), "host ms", sum(tim.values()) / 1e3)
+    for k, v in sorted(cnt.items(), key=lambda kv: -tim[kv[0]])[:32]: print(f"  {v:5d}  {tim[k] / 1e3:7.2f} ms  {k}")
