@@ -21,7 +21,7 @@ from torch.nn import functional as F
 from .. import pointops, spconv, unet_exec
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
-from .layers import (BatchNorm1d, GenericMLP, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
+from .layers import (BatchNorm1d, BigLinear, GenericMLP, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
                      TransformerDecoderLayer, scene_counts)
 from .set_abstraction import PointnetSAModuleVotesSeparate
 
@@ -198,9 +198,10 @@ class GeoFormer(nn.Module):
         self.output_layer = spconv.SparseSequential(norm_fn(m), nn.ReLU())
 
         # semantic head
-        self.semantic = nn.Sequential(nn.Linear(m, m, bias=True), norm_fn(m), nn.ReLU(),
-                                      nn.Linear(m, m, bias=True), norm_fn(m), nn.ReLU())
-        self.semantic_linear = nn.Linear(m, classes, bias=True)
+        # (BigLinear = nn.Linear with a split-K weight gradient: these run over every point of the batch)
+        self.semantic = nn.Sequential(BigLinear(m, m, bias=True), norm_fn(m), nn.ReLU(),
+                                      BigLinear(m, m, bias=True), norm_fn(m), nn.ReLU())
+        self.semantic_linear = BigLinear(m, classes, bias=True)
 
         # mask features, controller of the dynamic convolution
         self.output_dim = m

@@ -72,11 +72,12 @@ class _SplitKLinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.shape[-1])
             rows = x2.shape[0]
-            chunks = 256
-            while chunks > 1 and rows % chunks:
-                chunks //= 2
-            gw = torch.bmm(g2.view(chunks, rows // chunks, -1).transpose(1, 2),
-                           x2.view(chunks, rows // chunks, -1)).sum(0)
+            chunks = 256 if rows >= 256 else 1
+            per = rows // chunks
+            main = chunks * per  # (a row count that is not a multiple of the chunk count: the rest as one small product)
+            gw = torch.bmm(g2[:main].view(chunks, per, -1).transpose(1, 2), x2[:main].view(chunks, per, -1)).sum(0)
+            if main < rows:
+                gw = gw + g2[main:].t() @ x2[main:]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb
@@ -144,7 +145,12 @@ class PointwiseConv2d(nn.Conv2d):
         if self.kernel_size != (1, 1) or self.stride != (1, 1) or self.padding != (0, 0) or self.groups != 1:
             return super().forward(x)
         b, c, h, w = x.shape
-        y = torch.matmul(self.weight[:, :, 0, 0], x.reshape(b, c, h * w)).reshape(b, -1, h, w)
+        if x.is_cuda and torch.is_grad_enabled() and h * w >= (1 << 15):
+            # (the set abstraction's shared MLP over [B, C, 1024, 128] groups: the library runs the weight gradient's
+            # 524 288-long reduction on a handful of workgroups, 1.1 ms per layer; chunked it is bandwidth-bound)
+            y = _PointwiseSplitKFn.apply(x.reshape(b, c, h * w), self.weight[:, :, 0, 0]).reshape(b, -1, h, w)
+        else:
+            y = torch.matmul(self.weight[:, :, 0, 0], x.reshape(b, c, h * w)).reshape(b, -1, h, w)
         return y if self.bias is None else y + self.bias[None, :, None, None]
 
 

@@ -199,7 +199,15 @@ class SubMConv3d(_SparseConvBase):
         out._index = input._index
         M = input.indices.shape[0]
         if self.kernel_size[0] == 1:
-            return self._finish(out, torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels)))
+            w2 = self.weight.view(self.in_channels, self.out_channels)
+            f = input.features
+            if f.is_cuda and torch.is_grad_enabled() and f.shape[0] >= (1 << 14):
+                # 1x1x1 convolution = a GEMM whose weight gradient reduces over every voxel: split over row chunks
+                # (the library runs the 523 008-long reduction on a handful of workgroups, 0.9 ms per layer)
+                from ..model.layers import _SplitKLinearFn
+
+                return self._finish(out, _SplitKLinearFn.apply(f, w2.t(), None))
+            return self._finish(out, torch.mm(f, w2))
         if M == 0:
             return self._finish(out, input.features.new_zeros((0, self.out_channels)))
         rules = self.get_rules(input)

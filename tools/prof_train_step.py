@@ -173,3 +173,11 @@ if os.environ.get("NODES"):
             k = e.key.split(": ", 1)[1]; cnt[k] = e.count; tim[k] = e.cpu_time_total
     print("autograd nodes", sum(cnt.values()), "host ms", sum(tim.values()) / 1e3)
     for k, v in sorted(cnt.items(), key=lambda kv: -tim[kv[0]])[:32]: print(f"  {v:5d}  {tim[k] / 1e3:7.2f} ms  {k}")
+if os.environ.get("GEMMS"):
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], record_shapes=True) as p:
+        step(); torch.cuda.synchronize()
+    rows = [e for e in p.key_averages(group_by_input_shape=True) if e.key in ("aten::mm", "aten::addmm", "aten::bmm", "aten::matmul", "aten::linear")]
+    rows.sort(key=lambda e: -e.device_time_total)
+    for e in rows[:14]:
+        print(f"{e.key:12s} n {e.count:3d} device {e.device_time_total / 1e3:7.2f} ms  avg {e.device_time_total / e.count:8.1f} us  {e.input_shapes}")
