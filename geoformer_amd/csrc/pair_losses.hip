@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int PL_THREADS = 256;
+constexpr int PL_SPLIT = 8;  // workgroups per row (a row is ~30 000 points, a scene has ~20 matched rows)
 
 __device__ __forceinline__ float pl_block_sum(float v, float* red) {
 #pragma unroll
@@ -30,22 +31,24 @@ __device__ __forceinline__ float pl_block_sum(float v, float* red) {
     return s;
 }
 
-// sums[k] = (sum p t, sum p, sum t, sum f) of instance row k (zeros for an unmatched row)
+// part[k][s] = (sum p t, sum p, sum t, sum f) over the s-th segment of instance row k (zeros for an unmatched row)
 __global__ __launch_bounds__(PL_THREADS) void k_pair_loss_sums(const float* __restrict__ logits,
                                                                 const float* __restrict__ inst,
                                                                 const int32_t* __restrict__ match_q, int n,
-                                                                float4* __restrict__ sums) {
+                                                                float4* __restrict__ part) {
     __shared__ float red[PL_THREADS / 64];
-    const int k = blockIdx.x;
+    const int k = blockIdx.x, sp = blockIdx.y;
     const int q = match_q[k];
     if (q < 0) {
-        if (threadIdx.x == 0) sums[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (threadIdx.x == 0) part[k * PL_SPLIT + sp] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
+    const int seg = (n + PL_SPLIT - 1) / PL_SPLIT;
+    const int j0 = sp * seg, j1 = min(n, j0 + seg);
     const float* x = logits + (size_t)q * n;
     const float* t = inst + (size_t)k * n;
     float a = 0.f, b = 0.f, c = 0.f, f = 0.f;
-    for (int j = threadIdx.x; j < n; j += PL_THREADS) {
+    for (int j = j0 + threadIdx.x; j < j1; j += PL_THREADS) {
         const float xv = x[j], tv = t[j];
         const float p = 1.f / (1.f + expf(-xv));
         const float ce = fmaxf(xv, 0.f) - xv * tv + log1pf(expf(-fabsf(xv)));
@@ -60,19 +63,25 @@ __global__ __launch_bounds__(PL_THREADS) void k_pair_loss_sums(const float* __re
     b = pl_block_sum(b, red);
     c = pl_block_sum(c, red);
     f = pl_block_sum(f, red);
-    if (threadIdx.x == 0) sums[k] = make_float4(a, b, c, f);
+    if (threadIdx.x == 0) part[k * PL_SPLIT + sp] = make_float4(a, b, c, f);
 }
 
-// out[0] = dice, out[1] = focal
-__global__ __launch_bounds__(PL_THREADS) void k_pair_loss_final(const float4* __restrict__ sums,
+// sums[k] = the row sums (segments added in a fixed order), out[0] = dice, out[1] = focal
+__global__ __launch_bounds__(PL_THREADS) void k_pair_loss_final(const float4* __restrict__ part,
                                                                  const int32_t* __restrict__ match_q, int K, int n,
                                                                  const int32_t* __restrict__ n_match,
-                                                                 float* __restrict__ out) {
+                                                                 float4* __restrict__ sums, float* __restrict__ out) {
     __shared__ float red[PL_THREADS / 64];
     float dice = 0.f, focal = 0.f;
     for (int k = threadIdx.x; k < K; k += PL_THREADS) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < PL_SPLIT; i++) {
+            const float4 v = part[k * PL_SPLIT + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        sums[k] = s;
         if (match_q[k] < 0) continue;
-        const float4 s = sums[k];
         dice += 1.f - (2.f * s.x + 1.f) / (s.y + s.z + 1.f);
         focal += s.w / (float)n;
     }
@@ -96,8 +105,10 @@ __global__ __launch_bounds__(PL_THREADS) void k_pair_loss_bwd(const float* __res
     const int q = blockIdx.x;
     const int k = match_of_q[q];
     float* dx = d_logits + (size_t)q * n;
+    const int seg = (n + PL_SPLIT - 1) / PL_SPLIT;
+    const int j0 = blockIdx.y * seg, j1 = min(n, j0 + seg);
     if (k < 0) {
-        for (int j = threadIdx.x; j < n; j += PL_THREADS) dx[j] = 0.f;
+        for (int j = j0 + threadIdx.x; j < j1; j += PL_THREADS) dx[j] = 0.f;
         return;
     }
     const float nm = (float)n_match[0] + 1e-6f;
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_pair_loss_bwd(const float* __res
     const float inv2 = 1.f / (S1 * S1);
     const float* x = logits + (size_t)q * n;
     const float* t = inst + (size_t)k * n;
-    for (int j = threadIdx.x; j < n; j += PL_THREADS) {
+    for (int j = j0 + threadIdx.x; j < j1; j += PL_THREADS) {
         const float xv = x[j], tv = t[j];
         const float p = 1.f / (1.f + expf(-xv));
         const float dp = p * (1.f - p);
@@ -125,16 +136,20 @@ __global__ __launch_bounds__(PL_THREADS) void k_pair_loss_bwd(const float* __res
 
 }  // namespace
 
+extern "C" size_t gf_pair_losses_sums_floats(int K) { return (size_t)K * 4 * (1 + PL_SPLIT); }
+
 extern "C" int gf_pair_losses_fwd(const float* mask_logits, const float* inst_masks, const int32_t* match_q, int nq, int K,
                                   int n, const int32_t* n_match, float* sums, float* out, void* stream) {
     GF_CHECK_ARG(mask_logits && inst_masks && match_q && n_match && sums && out, "gf_pair_losses_fwd: null argument");
     GF_CHECK_ARG(nq >= 1 && K >= 0 && n >= 1, "gf_pair_losses_fwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
+    // sums: [K, 4] row sums followed by the [K, PL_SPLIT, 4] partial sums of the segments (gf_pair_losses_sums_floats)
+    float4* rows = reinterpret_cast<float4*>(sums);
+    float4* part = rows + K;
     if (K > 0)
-        hipLaunchKernelGGL(k_pair_loss_sums, dim3(K), dim3(PL_THREADS), 0, st, mask_logits, inst_masks, match_q, n,
-                           reinterpret_cast<float4*>(sums));
-    hipLaunchKernelGGL(k_pair_loss_final, dim3(1), dim3(PL_THREADS), 0, st, reinterpret_cast<const float4*>(sums), match_q,
-                       K, n, n_match, out);
+        hipLaunchKernelGGL(k_pair_loss_sums, dim3(K, PL_SPLIT), dim3(PL_THREADS), 0, st, mask_logits, inst_masks, match_q,
+                           n, part);
+    hipLaunchKernelGGL(k_pair_loss_final, dim3(1), dim3(PL_THREADS), 0, st, part, match_q, K, n, n_match, rows, out);
     GF_CHECK_LAUNCH("gf_pair_losses_fwd");
     return GF_OK;
 }
@@ -145,7 +160,7 @@ extern "C" int gf_pair_losses_bwd(const float* mask_logits, const float* inst_ma
     GF_CHECK_ARG(mask_logits && inst_masks && match_of_q && n_match && sums && grad_out && d_logits,
                  "gf_pair_losses_bwd: null argument");
     GF_CHECK_ARG(nq >= 1 && K >= 0 && n >= 1, "gf_pair_losses_bwd: bad sizes");
-    hipLaunchKernelGGL(k_pair_loss_bwd, dim3(nq), dim3(PL_THREADS), 0, (hipStream_t)stream, mask_logits, inst_masks,
+    hipLaunchKernelGGL(k_pair_loss_bwd, dim3(nq, PL_SPLIT), dim3(PL_THREADS), 0, (hipStream_t)stream, mask_logits, inst_masks,
                        match_of_q, reinterpret_cast<const float4*>(sums), n, n_match, grad_out, d_logits);
     GF_CHECK_LAUNCH("gf_pair_losses_bwd");
     return GF_OK;

@@ -119,7 +119,8 @@ class _PairLossFn(torch.autograd.Function):
         x = mask_logit_b.contiguous()
         nq, n = x.shape
         K = m.inst_masks.shape[0]
-        sums = torch.empty((max(K, 1), 4), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        sums = torch.empty(max(int(lib.gf_pair_losses_sums_floats(K)), 4), dtype=torch.float32, device=x.device)
         out = torch.empty(2, dtype=torch.float32, device=x.device)
         check(_lib.load().gf_pair_losses_fwd(ptr(x), ptr(m.inst_masks), ptr(m.match_q), nq, K, n, ptr(m.n_match), ptr(sums),
                                              ptr(out), stream_ptr()), "gf_pair_losses_fwd")

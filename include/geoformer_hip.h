@@ -239,9 +239,11 @@ int gf_lsap(const float* cost, int nq, int K, const int32_t* present, int32_t* m
 /* Dice and focal loss of one scene's matched (query, instance) pairs for one decoder layer
  * (compute_dice_loss / compute_sigmoid_focal_loss on the matched rows, /root/reference/criterion.py:26-58,137-190), and
  * their gradient.  mask_logits fp32 [nq,n]; inst_masks fp32 0/1 [K,n]; match_q [K] / match_of_q [nq] / n_match [1] as
- * gf_lsap wrote them.  fwd: sums fp32 [K,4] (row sums: p t, p, t, focal term; kept for the backward),
+ * gf_lsap wrote them.  fwd: sums fp32, gf_pair_losses_sums_floats(K) floats (first [K,4] row sums: p t, p, t, focal
+ * term -- kept for the backward --, then the partial sums of the row segments),
  * out[0] = sum_k dice_k / (n_match + 1e-6), out[1] = sum_k mean_j focal_kj / (n_match + 1e-6).
  * bwd: grad_out fp32 [2] (d loss / d out), d_logits fp32 [nq,n] written in full (zero rows for unmatched queries). */
+size_t gf_pair_losses_sums_floats(int K);
 int gf_pair_losses_fwd(const float* mask_logits, const float* inst_masks, const int32_t* match_q, int nq, int K, int n,
                        const int32_t* n_match, float* sums, float* out, void* stream);
 int gf_pair_losses_bwd(const float* mask_logits, const float* inst_masks, const int32_t* match_of_q, const float* sums,
