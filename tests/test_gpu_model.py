@@ -374,3 +374,34 @@ def test_fs_requery_many_equals_sequential_requeries(hip):
         if len(a[0]):
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert any(len(a[0]) for a in seq)  # at least one embedding yields proposals
+
+
+@pytest.mark.gpu
+def test_backbone_transformer_padded_pass_equals_per_scene_loop():
+    """layers.BackboneTransformer with several scenes on the GPU (one padded pass with the layers' key mask) against the
+    per-scene loop (the route CPU tensors take): outputs and gradients, scenes of different sizes and an empty one."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from geoformer_amd.model.layers import BackboneTransformer
+
+    torch.manual_seed(0)
+    d = 32
+    tr = BackboneTransformer(d, 2, 4, 64).eval()  # eval: dropout off (its draws differ between the two layouts)
+    sizes = [37, 0, 120, 5]
+    bid = torch.cat([torch.full((n,), b, dtype=torch.int32) for b, n in enumerate(sizes)])
+    xyz = torch.randint(0, 40, (bid.numel(), 3)).float()
+    feats = torch.randn(bid.numel(), d, requires_grad=True)
+    gout = torch.randn(bid.numel(), d)
+    ref = tr(xyz, feats, bid, batch_size=len(sizes))
+    ref.backward(gout)
+    g_ref = [feats.grad.clone()] + [p.grad.clone() for p in tr.parameters()]
+    trg = BackboneTransformer(d, 2, 4, 64).eval()
+    trg.load_state_dict(tr.state_dict())
+    trg.cuda()
+    fg = feats.detach().cuda().requires_grad_(True)
+    out = trg(xyz.cuda(), fg, bid.cuda(), batch_size=len(sizes))
+    out.backward(gout.cuda())
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    g_got = [fg.grad.cpu()] + [p.grad.cpu() for p in trg.parameters()]
+    for a, b in zip(g_got, g_ref):
+        assert (a - b).abs().max().item() < 2e-4 * max(1.0, b.abs().max().item())
