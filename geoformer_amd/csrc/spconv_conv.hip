@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ in
 //     (row = lane >> 2, quad = lane & 3) loads 16 bytes of its row -- one instruction per operand tile -- and the tile
 //     changes orientation through a per-wave LDS buffer (two 16-byte writes, eight 4-byte reads per pair).
 // Channel counts are multiples of 16 on this route (the 6-channel input convolution takes the kernel above).
-// 523k voxels: 16 -> 16 91 us (was 226), 32 -> 16 177 (417), 32 -> 32 494 (700), 64 -> 32 964 (1380).  What bounds it
+// 523k voxels: 16 -> 16 91 us (was 226), 32 -> 16 140 (417), 32 -> 32 239 (700), 64 -> 32 465 (1380).  What bounds it
 // now is L2 bandwidth: a wave per (offset, 16 x 16 tile pair, slice) reads 2 KB per (group, offset) pair -- 700 MB per
 // tile pair, 7.7 TB/s at 91 us -- because the gradient rows are read again for every offset and both operands again
 // for every tile pair; one wave per slice for all tile pairs (and several offsets, one accumulator each) would read
@@ -1515,12 +1515,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_t(const float* __restrict__ 
     long long item = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nitems = (long long)K * NCI * NCO * nslices;
     if (item >= nitems) return;
-    const int sl = (int)(item % nslices);
-    item /= nslices;
+    // neighbouring waves = the tile pairs of one (offset, slice): they read the same rows at the same time, and the
+    // compute unit's L1 serves the repeats (slices innermost instead: 32 -> 32 490 us against 239, 64 -> 32 957 / 465)
     const int cob = (int)(item % NCO);
     item /= NCO;
     const int cib = (int)(item % NCI);
-    const int k = (int)(item / NCI);
+    item /= NCI;
+    const int sl = (int)(item % nslices);
+    const int k = (int)(item / nslices);
     constexpr int GPS = WGT_ROWS / 16;  // groups per slice
     constexpr int NPW = (GPS + 63) / 64;
     const int g0 = sl * GPS, ngroups = (M_out + 15) >> 4;
