@@ -181,3 +181,28 @@ if os.environ.get("GEMMS"):
     rows.sort(key=lambda e: -e.device_time_total)
     for e in rows[:14]:
         print(f"{e.key:12s} n {e.count:3d} device {e.device_time_total / 1e3:7.2f} ms  avg {e.device_time_total / e.count:8.1f} us  {e.input_shapes}")
+if os.environ.get("BFSCAP"):
+    # the BFS inputs of the training forward through the -DBFS_TRACE build (GF_LIB_PATH): hops, ring sizes, phases
+    from geoformer_amd import pointops, _lib
+    from geoformer_amd._lib import ptr, check, stream_ptr
+    cap = []
+    orig = pointops.geodesic_bfs
+    def spy(D, I, deg, src, radius, max_step, wg_threads=1024):
+        cap.append((D, I, deg, src.clone(), radius, max_step)); return orig(D, I, deg, src, radius, max_step, wg_threads=wg_threads)
+    pointops.geodesic_bfs = spy
+    np.random.seed(0); out = m(batch, 200); torch.cuda.synchronize(); pointops.geodesic_bfs = orig
+    lib = _lib.load()
+    for i, (D, I, deg, src, radius, max_step) in enumerate(cap):
+        n, K = D.shape; nq = src.shape[0]
+        val = ((D <= radius) & (I >= 0)).sum(1).float()
+        for wg in (512, 1024):
+            geo = torch.empty((nq, n), dtype=torch.float32, device=dev); keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
+            queues = torch.zeros((nq, 4, n), dtype=torch.int32, device=dev)
+            for _ in range(2):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); s.record()
+                check(lib.gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), ptr(keys), ptr(queues), wg, stream_ptr()), "bfs")
+                e.record(); torch.cuda.synchronize()
+            t = queues.view(nq, -1)[:, :24].contiguous().view(torch.int64).cpu().numpy().astype(np.float64)
+            hops = np.maximum(t[:, 5], 1)
+            print(f"scene {i} n {n} nq {nq} max_step {max_step} wg {wg}: {s.elapsed_time(e) * 1e3:.0f} us; hops {hops.mean():.0f}, ring mean {(t[:, 6] / hops).mean():.0f} max {t[:, 7].max():.0f}; "
+                  f"batches/hop {(t[:, 8] / hops).mean():.1f}; in-radius entries per row {val.mean().item():.1f}, rows >16: {(val > 16).float().mean().item():.2f}")
