@@ -40,7 +40,29 @@ class BatchNorm1d(nn.BatchNorm1d):
         # 59.6 vs 73.5 ms for the backbone-only training step); the [B,C,L] ones go the lean way
         if self.training and x.dim() == 3 and x.numel() > 0:
             return _bn_train(self, x, [0, 2])
+        if (self.training and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and self.track_running_stats
+                and self.momentum is not None):
+            # the same library kernels without nn.BatchNorm1d's `num_batches_tracked += 1` on the device (a launch
+            # per layer and step for a counter that only a momentum of None reads): counted on the host, written
+            # back when the state is saved
+            self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True, self.momentum,
+                                self.eps)
         return super().forward(x)
+
+    def _flush_counter(self):
+        n = getattr(self, "_nbt_pending", 0)
+        if n and self.num_batches_tracked is not None:
+            self.num_batches_tracked += n
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
 
 class BatchNorm2d(nn.BatchNorm2d):
