@@ -429,15 +429,42 @@ class GeoFormer(nn.Module):
         aux = sides.get((locs_float_.device, main.cuda_stream, "aux"))
         if aux is None:
             aux = sides[(locs_float_.device, main.cuda_stream, "aux")] = torch.cuda.Stream(device=locs_float_.device)
-        geo_ready = []
-        staged, geo = [], []
+        geo_ready = [None] * batch_size
+        staged, geo = [None] * batch_size, [None] * batch_size
         # Several scenes with gradients (the training step): every scene's sampling goes to a stream of its own and its
         # BFS to another, so the scenes' two latency-bound launches run beside each other instead of one scene after
         # the other (4 x (0.4 + 3.3) ms of a batch-4 step in which the device finishes last); the main stream joins
         # them before the grouping.  One scene / inference: the streams of the docstring.
         multi = batch_size > 1 and early is None and not epilogue and os.environ.get("GF_SCENE_STREAMS", "1") != "0"
         scene_streams = []
-        for b in range(batch_size):
+
+        def host_draw(b, n_b):
+            """The reference's host draw of scene b (same values, same generator state), restated natively, into a pinned
+            buffer of this host thread (the upload that follows is an asynchronous copy)."""
+            npoint = min(n_b, self.cfg.n_downsampling)
+            pins = getattr(_OFFS_CACHE, "draw_pins", None)
+            if pins is None:
+                pins = _OFFS_CACHE.draw_pins = {}
+            pin = pins.get((main.cuda_stream, b))  # per caller stream: scenes in flight on two streams
+            if pin is None or pin.numel() < npoint:
+                pin = pins[(main.cuda_stream, b)] = torch.empty(max(npoint, 65536), dtype=torch.int64).pin_memory()
+            drawn = pointops.legacy_choice(n_b, npoint, out=pin.numpy())
+            if drawn.ctypes.data != pin.data_ptr():  # numpy's own route (exotic generator state): stage it
+                pin.numpy()[:npoint] = drawn
+            return pin, npoint
+
+        order = list(range(batch_size))
+        draws = {}
+        if multi:
+            # the draws consume the generator in scene order; the device work goes out largest scene first -- its BFS
+            # is the stretch's long pole (5.8 of ~10 ms when it was issued third)
+            for b in order:
+                if offs[b + 1] - offs[b] == 0:
+                    return None, None  # (after the draws of the scenes before it, like the scene-by-scene order)
+                if sample:
+                    draws[b] = host_draw(b, offs[b + 1] - offs[b])
+            order.sort(key=lambda b: -(offs[b + 1] - offs[b]))
+        for b in order:
             n_b = offs[b + 1] - offs[b]
             if n_b == 0:
                 return None, None
@@ -454,18 +481,8 @@ class GeoFormer(nn.Module):
                 sb, side_b = main, side
             with torch.cuda.stream(sb):
                 if sample:
-                    npoint = min(n_b, self.cfg.n_downsampling)
-                    # the reference's host draw (same values, same generator state), restated natively: the device idles on it
-                    # (drawn into a pinned buffer of this host thread: the upload is an asynchronous copy on the stream)
-                    pins = getattr(_OFFS_CACHE, "draw_pins", None)
-                    if pins is None:
-                        pins = _OFFS_CACHE.draw_pins = {}
-                    pin = pins.get((main.cuda_stream, b))  # per caller stream: scenes in flight on two streams
-                    if pin is None or pin.numel() < npoint:
-                        pin = pins[(main.cuda_stream, b)] = torch.empty(max(npoint, 65536), dtype=torch.int64).pin_memory()
-                    drawn = pointops.legacy_choice(n_b, npoint, out=pin.numpy())
-                    if drawn.ctypes.data != pin.data_ptr():  # numpy's own route (exotic generator state): stage it
-                        pin.numpy()[:npoint] = drawn
+                    # (one scene: the device idles on this draw)
+                    pin, npoint = draws[b] if b in draws else host_draw(b, n_b)
                     sampling_indices = pin[:npoint].to(locs_float_.device, non_blocking=True)
                     self.last_sampling_indices = sampling_indices
                     xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
@@ -512,10 +529,10 @@ class GeoFormer(nn.Module):
                 g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0])) if split else 1024)
                 g.record_stream(main)
                 src.record_stream(side_b)
-                geo.append(g)
+                geo[b] = g
                 ev = torch.cuda.Event()
                 ev.record(side_b)
-                geo_ready.append(ev)
+                geo_ready[b] = ev
             # the rest of the sampling is on the critical path: issue it before anything else
             with torch.cuda.stream(sb):
                 idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
@@ -525,7 +542,7 @@ class GeoFormer(nn.Module):
                         t.record_stream(main)
             if early is not None and b == 0:
                 main.wait_event(early_done)
-            staged.append([xyz_b, None, idx, grid, sampling_indices])
+            staged[b] = [xyz_b, None, idx, grid, sampling_indices]
             if not epilogue:
                 continue
             # small launches that only need the distances / the query picks ride beside the sampling instead of
