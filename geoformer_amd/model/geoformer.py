@@ -747,8 +747,23 @@ class GeoFormer(nn.Module):
         num_layers, n_queries, batch = param_kernels.shape[:3]
         offs = _offsets_list(batch_offsets_)
         outputs = []
-        for l in range(num_layers):
-            pk = param_kernels[l]  # nq x B x C
+        # what the fused training route reads of a scene does not depend on the decoder layer: sliced / reduced once per
+        # scene instead of once per (layer, scene) -- 80 small launches and 12 slice-gradient passes over the batch's
+        # mask features less per batch-4 step
+        fused_train = (mask_features.is_cuda and torch.is_grad_enabled() and self.output_dim == 16 and self.use_coords
+                       and os.environ.get("GF_FUSED_BWD", "1") != "0")
+        per_scene = {}
+        if fused_train:
+            for b in range(batch):
+                s, e = offs[b], offs[b + 1]
+                if e - s == 0:
+                    continue
+                g = geo_dists[b].contiguous()
+                mx = torch.max(g, dim=1)[0]
+                mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+                per_scene[b] = (mask_features[s:e].reshape(e - s, self.output_dim).contiguous(),
+                                locs_float_[s:e].contiguous(), g, fps_sampling_locs[b].reshape(-1, 3).contiguous(), mx)
+        for l, pk in enumerate(param_kernels.unbind(0) if fused_train else param_kernels):  # pk: nq x B x C
             pk2 = pk.transpose(0, 1).flatten(0, 1)  # [B*nq, C] token rows
             sem_chain = self._pointwise_chain("detr_sem_head", [self.detr_sem_head], pk2)
             tow_chain = self._pointwise_chain("before_embedding_tower", [self.before_embedding_tower], pk2)
@@ -766,6 +781,7 @@ class GeoFormer(nn.Module):
                 cls_logits = self.detr_sem_head(pk.permute(1, 2, 0)).transpose(1, 2)  # B x nq x classes
                 controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
             controllers = controllers.reshape(batch, n_queries, -1)
+            ctrl = controllers.unbind(0) if fused_train else controllers
             mask_logits_list = []
             for b in range(batch):
                 s, e = offs[b], offs[b + 1]
@@ -776,17 +792,12 @@ class GeoFormer(nn.Module):
                     # the controller's output read in place by the kernel (no split / reshape / contiguous copies)
                     ml = self._mask_head_packed(geo_dists[b], mask_features[s:e], controllers[b], n_queries,
                                                 locs_float_[s:e], fps_sampling_locs[b])
-                elif (mask_features.is_cuda and torch.is_grad_enabled() and self.output_dim == 16 and self.use_coords
-                      and os.environ.get("GF_FUSED_BWD", "1") != "0"):
+                elif fused_train:
                     # training: the same fused kernel forward, and a fused recompute-based backward for the mask
                     # features and the generated parameters (csrc/mask_head.hip k_mask_head_bwd) instead of PyTorch
                     # autograd over [nq, N, 16] intermediates
-                    g = geo_dists[b].contiguous()
-                    mx = torch.max(g, dim=1)[0]
-                    mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
-                    ml = pointops.mask_head_train(mask_features[s:e].reshape(e - s, self.output_dim).contiguous(),
-                                                  controllers[b].contiguous(), locs_float_[s:e].contiguous(), g,
-                                                  fps_sampling_locs[b].reshape(-1, 3).contiguous(), mx)
+                    mf_b, locs_b, g, fps_b, mx = per_scene[b]
+                    ml = pointops.mask_head_train(mf_b, ctrl[b].contiguous(), locs_b, g, fps_b, mx)
                     ml = ml.reshape(1, n_queries, e - s)
                 else:
                     weights, biases = self.parse_dynamic_params(controllers[b], self.output_dim)
