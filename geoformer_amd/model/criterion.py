@@ -39,7 +39,7 @@ class DeviceMatch:
     """Ground truth and assignment of one scene, all on the device.  The instance axis has K entries = the scene's id
     range [lo, lo + K); `present` marks the ids that occur among the scene's (sub-sampled) foreground points."""
 
-    __slots__ = ("inst_masks", "sem_labels", "present", "match_q", "match_of_q", "n_match", "status", "lo")
+    __slots__ = ("inst_masks", "sem_labels", "present", "match_q", "match_of_q", "n_match", "status", "lo", "cls_target")
 
     def to_reference(self):
         """(rows, inst_masks[cols], sem_labels[cols]) as HungarianMatcher.forward_seg_single returns them
@@ -263,11 +263,15 @@ class InstSetCriterion(nn.Module):
             dice, focal = masked_pair_losses(mask_logits_list[b], m, n)
             loss_dict["dice_loss"] = loss_dict["dice_loss"] + dice
             loss_dict["focal_loss"] = loss_dict["focal_loss"] + focal
-            # class targets: 0 for unmatched queries, the instance's class for matched ones (criterion.py:170-173)
-            valid = m.match_q >= 0
-            cls_label = torch.zeros(self.n_queries + 1, device=dev)
-            cls_label.scatter_(0, torch.where(valid, m.match_q, self.n_queries).long(), m.sem_labels)
-            loss_dict["cls_loss"] = loss_dict["cls_loss"] + F.cross_entropy(cls_logits[b], cls_label[:-1].long())
+            # class targets: 0 for unmatched queries, the instance's class for matched ones (criterion.py:170-173);
+            # the matching is the last layer's for every layer, so they are built once per scene
+            tgt = getattr(m, "cls_target", None)
+            if tgt is None:
+                valid = m.match_q >= 0
+                cls_label = torch.zeros(self.n_queries + 1, device=dev)
+                cls_label.scatter_(0, torch.where(valid, m.match_q, self.n_queries).long(), m.sem_labels)
+                tgt = m.cls_target = cls_label[:-1].long()
+            loss_dict["cls_loss"] = loss_dict["cls_loss"] + F.cross_entropy(cls_logits[b], tgt)
         loss = torch.zeros((), device=dev)
         for k, w in self.loss_weight.items():
             loss_dict[k] = loss_dict[k] * w / self.batch_size
