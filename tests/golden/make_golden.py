@@ -6,6 +6,12 @@ The reference model code is imported, never copied; its native dependencies are 
 CPU oracle through tests/golden/ref_shims.py.  Outputs (committed, small):
     geoformer_state_dict_keys.json   parameter/buffer names and shapes of GeoFormer
     geoformer_s8k_eval.npz           S8k scene, test yaml (nq=256, nc=2048), eval forward: stage outputs
+    geoformer_train_small.npz        (`train`) the TRAINING branch (geoformer.py:468-493) + InstSetCriterion + backward on a
+                                     2-scene small batch, train yaml with batch_size 2 / dec_dropout 0 / nq 32 / nc 512 and
+                                     the mask-head subsample cut to 2000 points so the host RNG draw is exercised:
+                                     subsample indices, per-layer logits, loss dict, per-parameter gradient norms + samples
+    geoformer_train_mid.npz          (`train_mid`) the same on two room-sized scenes (90k + 70k points) with the yaml's own
+                                     nq=128 / nc=2048 and the reference's own 30 000-point subsample (GPU test only)
     geodesic_vectorize.npz           cal_geodesic_vectorize on a 3k-point cloud (pins the BFS oracle)
     decoder_layer.npz                one TransformerDecoderLayer + fourier embedding on random inputs
     matrix_nms.npz                   util.utils_3d.matrix_non_max_suppression on overlapping random proposals (`nms`)
@@ -19,8 +25,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
-_WHICH = [a for a in sys.argv[1:] if a in ("geodesic", "decoder", "model", "fs", "nms")]
-_YAML = "config/test_geoformer_fs_scannet.yaml" if _WHICH == ["fs"] else "config/test_geoformer_scannet.yaml"
+_WHICH = [a for a in sys.argv[1:] if a in ("geodesic", "decoder", "model", "fs", "nms", "train", "train_mid")]
+_TRAIN = _WHICH in (["train"], ["train_mid"])
+_YAML = ("config/test_geoformer_fs_scannet.yaml" if _WHICH == ["fs"] else
+         "config/geoformer_scannet.yaml" if _TRAIN else "config/test_geoformer_scannet.yaml")
 sys.argv = ["make_golden", "--config", os.path.join(REF, _YAML)]  # util/config.py parses argv at import: one yaml per process
 
 import numpy as np  # noqa: E402
@@ -220,7 +228,109 @@ def golden_fs():
     print("fs golden: N_fg", ctx[3].shape[0], "proposals", len(scores), len(scores2), "emb", emb.shape)
 
 
+def train_case(mid):
+    """Inputs of the training golden, shared with tests/test_training_golden.py through tests.util.train_golden_case."""
+    from tests.util import train_golden_case
+
+    return train_golden_case(mid)
+
+
+def golden_train(mid):
+    """The reference's GeoFormer.forward(batch, epoch > prepare_epochs, training=True) (geoformer.py:402-493) + its
+    InstSetCriterion (criterion.py:137-245) + backward(), as train.py:63-75 runs them.  `self.get_batch_offsets` is
+    undefined in the shipped class (geoformer.py:482); the instance gets util.utils.get_batch_offsets
+    as the attribute, which is the intended function.  Dropout off everywhere."""
+    import criterion as ref_crit  # reference module
+    import model.geoformer.geoformer as ref_gf
+    from util import utils as ref_utils
+    from util.config import cfg
+
+    case = train_case(mid)
+    for k, v in case["cfg"].items():
+        setattr(cfg, k, v)
+    # the CPU `.to(device)` of a requires-grad leaf returns the leaf itself; on a GPU it is a copy the criterion then
+    # updates in place (criterion.py:139,203) -- same patch as make_golden_criterion.py
+    _to = torch.Tensor.to
+
+    def _to_like_gpu(self, *a, **k):
+        r = _to(self, *a, **k)
+        return r.clone() if (r is self and self.requires_grad and self.is_leaf) else r
+
+    torch.Tensor.to = _to_like_gpu
+    torch.Tensor.cuda = lambda self, *a, **k: (self.clone() if (self.requires_grad and self.is_leaf) else self)
+    if case["n_subsample"] != 30000:  # small case: cut the hard-coded 30 000 so np.random.choice is actually drawn
+        orig_rd = ref_gf.random_downsample
+        ref_gf.random_downsample = lambda bo, bs, n_subsample=30000: orig_rd(bo, bs, n_subsample=case["n_subsample"])
+    torch.manual_seed(0)
+    m = GeoFormer()
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), case["weight_seed"]))
+    with torch.no_grad():
+        m.semantic_linear.bias[4:] += case["fg_bias"]
+    m.get_batch_offsets = ref_utils.get_batch_offsets
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.train()
+    batch = case["batch"]()
+    cap = {}
+    orig_agg, orig_gmp = m.forward_aggregator, m.get_mask_prediction
+
+    def agg(*a, **k):
+        r = orig_agg(*a, **k)
+        cap["pre_enc_inds"] = r[2].detach().numpy().copy()
+        return r
+
+    def gmp(geo, dec_outputs, *a, **k):
+        cap["dec_outputs"] = dec_outputs.detach().numpy().copy()
+        cap["geo_reached"] = np.stack([(g >= 0).sum(1).numpy() for g in geo])
+        return orig_gmp(geo, dec_outputs, *a, **k)
+
+    m.forward_aggregator, m.get_mask_prediction = agg, gmp
+    np.random.seed(case["numpy_seed"])
+    epoch = cfg.prepare_epochs + 1
+    out = m(batch, epoch)
+    crit = ref_crit.InstSetCriterion()
+    loss, ld = crit(out, batch, epoch)
+    m.zero_grad()
+    loss.backward()
+    res = {"loss": float(loss), "epoch": epoch, "n_layers": len(out["mask_predictions"])}
+    for k, v in ld.items():
+        res["ld_" + k] = np.array(v, np.float64)
+    res["fg_idxs"] = out["fg_idxs"].numpy()  # = fg_idxs[idxs_subsample]: pins the subsample draw
+    res["batch_idxs"] = out["batch_idxs"].numpy()
+    res["semantic_scores_sub"] = np.ascontiguousarray(out["semantic_scores"].detach().numpy()[::16])
+    res["pre_enc_inds"] = cap["pre_enc_inds"]
+    res["dec_outputs"] = cap["dec_outputs"]
+    res["geo_reached"] = cap["geo_reached"]
+    for l, mp in enumerate(out["mask_predictions"]):
+        res[f"cls_logits_{l}"] = mp["cls_logits"].detach().numpy()
+        for b, ml in enumerate(mp["mask_logits"]):
+            ml = ml.detach().numpy()
+            res[f"mask_logits_sub_{l}_{b}"] = sub(ml, 4, 16 if mid else 4)
+            res[f"mask_logits_rowsum_{l}_{b}"] = ml.astype(np.float64).sum(1)
+    names, gnorm, gsum, gsamp, goff = [], [], [], [], [0]
+    for n, p in m.named_parameters():
+        g = np.zeros(p.shape, np.float32) if p.grad is None else p.grad.numpy()
+        g64 = g.astype(np.float64).ravel()
+        names.append(n + ("" if p.grad is not None else "|none"))
+        gnorm.append(np.sqrt((g64 ** 2).sum()))
+        gsum.append(g64.sum())
+        stride = max(1, g64.size // 256)
+        gsamp.append(g.ravel()[::stride].copy())
+        goff.append(goff[-1] + gsamp[-1].size)
+    res["grad_names"] = np.array(names)
+    res["grad_norm"], res["grad_sum"] = np.array(gnorm), np.array(gsum)
+    res["grad_samples"], res["grad_sample_offsets"] = np.concatenate(gsamp), np.array(goff)
+    f = os.path.join(HERE, "geoformer_train_mid.npz" if mid else "geoformer_train_small.npz")
+    np.savez_compressed(f, **res)
+    print("train golden", "mid" if mid else "small", "loss", res["loss"], {k: np.asarray(v).ravel()[:2].tolist() for k, v in res.items() if k.startswith("ld_")},
+          "N_sub", res["fg_idxs"].shape, "size", os.path.getsize(f))
+
+
 if __name__ == "__main__":
+    if _TRAIN:
+        golden_train(_WHICH == ["train_mid"])
+        sys.exit(0)
     which = _WHICH or ["geodesic", "decoder", "model"]
     if "fs" in which:
         golden_fs()

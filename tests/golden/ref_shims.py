@@ -68,6 +68,25 @@ class SparseSequential(SparseModule):
         return input
 
 
+class _ConvFn(torch.autograd.Function):
+    """out[o] = sum_k in[nbr[k][o]] @ W[k] over an output-stationary table, with the backward the
+    training golden needs: dIn[i] += dOut[o] @ W[k]^T, dW[k] = sum in[i]^T dOut[o] (oracle operators)."""
+
+    @staticmethod
+    def forward(ctx, feats, W, nbr, M_out):
+        ctx.save_for_backward(feats, W)
+        ctx.nbr = nbr
+        return torch.from_numpy(orc.conv_fwd(feats.detach().numpy(), W.detach().numpy(), nbr, M_out))
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, W = ctx.saved_tensors
+        g = np.ascontiguousarray(g.detach().numpy())
+        d_in = torch.from_numpy(orc.conv_dgrad(g, W.detach().numpy(), ctx.nbr, feats.shape[0]))
+        d_w = torch.from_numpy(orc.conv_wgrad(feats.detach().numpy(), g, ctx.nbr, W.shape[0]))
+        return d_in, d_w, None, None
+
+
 class _Conv(SparseModule):
     def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=0, bias=False, indice_key=None,
                  kind="subm"):
@@ -79,31 +98,31 @@ class _Conv(SparseModule):
         assert not bias
 
     def forward(self, input):
-        feats = input.features.detach().numpy()
-        W = self.weight.detach().numpy().reshape(-1, self.in_channels, self.out_channels)
+        feats = input.features
+        W = self.weight.reshape(-1, self.in_channels, self.out_channels)
         coords = input.indices.numpy().astype(np.int32)
         shape = input.spatial_shape
         out = SparseConvTensor(None, input.indices, shape, input.batch_size)
         out.indice_dict = input.indice_dict
         if self.ks == 1:
-            out.features = torch.from_numpy(feats @ W[0])
+            out.features = feats @ W[0]
             return out
         if self.kind == "subm":
             nbr = input.indice_dict.get(self.indice_key)
             if nbr is None:
                 nbr = orc.rules_subm3(coords, shape)
                 input.indice_dict[self.indice_key] = nbr
-            out.features = torch.from_numpy(orc.conv_fwd(feats, W, nbr, coords.shape[0]))
+            out.features = _ConvFn.apply(feats, W, nbr, coords.shape[0])
         elif self.kind == "down":
             oc, child, parent, koff = orc.rules_down2(coords, shape)
             input.indice_dict[self.indice_key] = (coords, shape, parent, koff, input.indices)
-            out.features = torch.from_numpy(orc.conv_fwd(feats, W, child, oc.shape[0]))
+            out.features = _ConvFn.apply(feats, W, child, oc.shape[0])
             out.indices = torch.from_numpy(oc)
             out.spatial_shape = [(s - 2) // 2 + 1 for s in shape]
         else:  # inverse
             coords_f, shape_f, parent, koff, ind_f = input.indice_dict[self.indice_key]
             up = orc.up_table(parent, koff)
-            out.features = torch.from_numpy(orc.conv_fwd(feats, W, up, coords_f.shape[0]))
+            out.features = _ConvFn.apply(feats, W, up, coords_f.shape[0])
             out.indices = ind_f
             out.spatial_shape = list(shape_f)
         return out
@@ -138,6 +157,18 @@ def _pg_voxelize_idx(coords, output_coords, input_map, output_map, batch_size, m
 
 def _pg_voxelize_fp(feats, out, rules, mode, M, maxActive, C):
     out.copy_(torch.from_numpy(orc.voxelize_fp(feats.detach().numpy(), rules.numpy(), mode == 4)))
+
+
+def _pg_voxelize_bp(d_out, d_feats, rules, mode, M, maxActive, C):
+    d_feats.copy_(torch.from_numpy(orc.voxelize_bp(d_out.detach().numpy(), rules.numpy(), d_feats.shape[0], mode == 4)))
+
+
+def _ext_gather_grad(grad_out, idx, n):
+    return torch.from_numpy(orc.gather_points_grad(grad_out.detach().numpy(), idx.numpy(), n))
+
+
+def _ext_group_grad(grad_out, idx, n):
+    return torch.from_numpy(orc.group_points_grad(np.ascontiguousarray(grad_out.detach().numpy()), idx.numpy(), n))
 
 
 def _ext_fps(xyz, m):
@@ -185,13 +216,14 @@ def install(reference_root="/root/reference"):
     sys.modules["spconv"], sys.modules["spconv.modules"] = sp, spm
 
     pg = types.ModuleType("PG_OP")
-    pg.voxelize_idx, pg.voxelize_fp = _pg_voxelize_idx, _pg_voxelize_fp
+    pg.voxelize_idx, pg.voxelize_fp, pg.voxelize_bp = _pg_voxelize_idx, _pg_voxelize_fp, _pg_voxelize_bp
     sys.modules["PG_OP"] = pg
 
     p2 = types.ModuleType("pointnet2")
     ext = types.ModuleType("pointnet2._ext")
     ext.furthest_point_sampling, ext.gather_points = _ext_fps, _ext_gather
     ext.ball_query, ext.group_points = _ext_ball_query, _ext_group
+    ext.gather_points_grad, ext.group_points_grad = _ext_gather_grad, _ext_group_grad
     p2._ext = ext
     sys.modules["pointnet2"], sys.modules["pointnet2._ext"] = p2, ext
 

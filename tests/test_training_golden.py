@@ -1,0 +1,141 @@
+"""The TRAINING branch against fixtures produced by the reference's own code (tests/golden/make_golden.py train /
+train_mid): `GeoFormer.forward(batch, epoch > prepare_epochs, training=True)` (geoformer.py:402-493: host-RNG
+`random_downsample`, the sub-sampled mask head over all four decoder layers) + the reference's `InstSetCriterion` +
+`backward()` as train.py:63-75 runs them.  Compared: the subsample draw (through `fg_idxs`), FPS picks, reach sets, the
+decoder output, every layer's class / mask logits, the loss dict, and the gradient of EVERY parameter (l2 norm, sum and
+a strided element sample, so a sign flip or a permutation inside a module cannot hide behind a norm).
+
+CPU: the build's model over the oracle's operators (host logic of the branch).  GPU: the HIP forward / backward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(device, mid):
+    import geoformer_amd.model.geoformer as G
+    from geoformer_amd.model import GeoFormer, InstSetCriterion, load_config
+    from tests.util import synthetic_state_dict, train_golden_case
+
+    case = train_golden_case(mid)
+    cfg = load_config("geoformer_scannet.yaml", **case["cfg"])
+    torch.manual_seed(0)
+    m = GeoFormer(cfg)
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), case["weight_seed"]))
+    with torch.no_grad():
+        m.semantic_linear.bias[4:] += case["fg_bias"]
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m.to(device)
+    m.train()
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in case["batch"]().items()}
+    cap = {}
+    orig_agg, orig_gmp, orig_rd = m.forward_aggregator, m.get_mask_prediction, G.random_downsample
+
+    def agg(*a, **k):
+        r = orig_agg(*a, **k)
+        cap["pre_enc_inds"] = r[2].detach().cpu().numpy().copy()
+        return r
+
+    def gmp(geo, dec_outputs, *a, **k):
+        cap["dec_outputs"] = dec_outputs.detach().cpu().numpy().copy()
+        cap["geo_reached"] = np.stack([(g >= 0).sum(1).cpu().numpy() for g in geo])
+        return orig_gmp(geo, dec_outputs, *a, **k)
+
+    m.forward_aggregator, m.get_mask_prediction = agg, gmp
+    if case["n_subsample"] != 30000:  # the generator cuts the reference's hard-coded 30 000 the same way
+        G.random_downsample = lambda bo, bs, n_subsample=30000, **k: orig_rd(bo, bs, n_subsample=case["n_subsample"], **k)
+    try:
+        np.random.seed(case["numpy_seed"])
+        epoch = cfg.prepare_epochs + 1
+        out = m(batch, epoch)
+        loss, ld = InstSetCriterion(cfg)(out, batch, epoch)
+        m.zero_grad()
+        loss.backward()
+    finally:
+        G.random_downsample = orig_rd
+    return m, out, float(loss.detach()), ld, cap
+
+
+def _check(z, m, out, loss, ld, cap, tol, gtol, cstride=4):
+    c = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    assert (c(out["fg_idxs"]) == z["fg_idxs"]).all(), "subsample draw / foreground set"
+    assert (c(out["batch_idxs"]) == z["batch_idxs"]).all()
+    assert np.abs(c(out["semantic_scores"])[::16] - z["semantic_scores_sub"]).max() < tol
+    assert (cap["pre_enc_inds"] == z["pre_enc_inds"]).all(), "FPS picks"
+    assert (cap["geo_reached"] == z["geo_reached"]).all(), "BFS reach sets"
+    assert np.abs(cap["dec_outputs"] - z["dec_outputs"]).max() < tol
+    assert len(out["mask_predictions"]) == int(z["n_layers"]) == 4
+    for l, mp in enumerate(out["mask_predictions"]):
+        assert np.abs(c(mp["cls_logits"]) - z[f"cls_logits_{l}"]).max() < tol, l
+        for b, ml in enumerate(mp["mask_logits"]):
+            ml = c(ml)
+            ref = z[f"mask_logits_sub_{l}_{b}"]
+            got = ml[::4, ::cstride]
+            assert got.shape == ref.shape, (got.shape, ref.shape)
+            assert np.abs(got - ref).max() < tol * max(1.0, np.abs(ref).max()), (l, b)
+            rs = z[f"mask_logits_rowsum_{l}_{b}"]
+            assert np.abs(ml.astype(np.float64).sum(1) - rs).max() < 1e-3 * max(1.0, np.abs(rs).max())
+    assert abs(loss - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"]))), (loss, float(z["loss"]))
+    for k, v in ld.items():
+        ref = np.asarray(z["ld_" + k], np.float64).ravel()
+        assert abs(float(v[0]) - ref[0]) < 1e-4 * max(1.0, abs(ref[0])), (k, v, ref)
+        assert int(v[1]) == int(ref[1]), (k, v, ref)
+    # every parameter's gradient: presence, l2 norm, sum, and a strided sample compared element-wise
+    names = [str(n) for n in z["grad_names"]]
+    params = dict(m.named_parameters())
+    assert [n.split("|")[0] for n in names] == list(params), "parameter order / names"
+    offs = z["grad_sample_offsets"]
+    # gradients that are zero by construction (a key bias under a soft-max) come out as rounding noise on both sides:
+    # everything is measured against a floor of 1e-5 of the largest parameter gradient
+    floor = 1e-5 * float(z["grad_norm"].max())
+    bad = []
+    for i, n in enumerate(names):
+        n, none = (n.split("|") + [""])[:2]
+        g = params[n].grad
+        if none:
+            assert g is None or float(g.abs().max()) == 0.0, n
+            continue
+        assert g is not None, n
+        g = c(g).astype(np.float64).ravel()
+        ref_n, ref_s = float(z["grad_norm"][i]), float(z["grad_sum"][i])
+        samp = z["grad_samples"][offs[i]:offs[i + 1]].astype(np.float64)
+        got = g[::max(1, g.size // 256)]
+        scale = max(np.abs(samp).max(), ref_n / np.sqrt(g.size), floor)
+        err = np.abs(got - samp).max() / scale
+        cos = float(got @ samp) / max(np.linalg.norm(got) * np.linalg.norm(samp), 1e-30)
+        nerr = abs(np.linalg.norm(g) - ref_n) / max(ref_n, floor)
+        serr = abs(g.sum() - ref_s) / (max(ref_n, floor) * np.sqrt(g.size))
+        if err > gtol or nerr > gtol or serr > gtol or (np.linalg.norm(samp) > 100 * floor and cos < 1 - gtol):
+            bad.append((n, err, nerr, serr, cos))
+    assert not bad, bad[:8]
+
+
+def test_training_branch_cpu_matches_reference_golden(oracle):
+    from oracle import cpu_backend
+
+    z = np.load(os.path.join(HERE, "golden", "geoformer_train_small.npz"))
+    with cpu_backend.installed():
+        m, out, loss, ld, cap = _run("cpu", False)
+    _check(z, m, out, loss, ld, cap, 1e-4, 2e-3)
+
+
+@pytest.mark.gpu
+def test_training_branch_gpu_matches_reference_golden(hip):
+    z = np.load(os.path.join(HERE, "golden", "geoformer_train_small.npz"))
+    m, out, loss, ld, cap = _run("cuda", False)
+    _check(z, m, out, loss, ld, cap, 1e-4, 2e-3)
+
+
+@pytest.mark.gpu
+def test_training_branch_mid_size_gpu_matches_reference_golden(hip):
+    """Two room-sized scenes (90k + 70k points), the train yaml's own nq=128 / nc=2048 and the reference's own 30 000-point
+    subsample."""
+    f = os.path.join(HERE, "golden", "geoformer_train_mid.npz")
+    z = np.load(f)
+    m, out, loss, ld, cap = _run("cuda", True)
+    _check(z, m, out, loss, ld, cap, 1e-4, 3e-3, cstride=16)

@@ -160,3 +160,18 @@ def criterion_case(seed, fs, B=3, NQ=32, NL=4, NCLS=13):
     if fs:
         case["simnet"] = rng.standard_normal((B, NQ)).astype(np.float32)
     return case
+
+
+def train_golden_case(mid):
+    """Inputs of the training-branch goldens (tests/golden/make_golden.py train / train_mid): config overrides on the
+    train yaml, weight / numpy seeds, the foreground bias and the batch builder.  Shared so that the reference (generator)
+    and the build (tests) see the same thing; nothing here is stored in the fixture."""
+    from geoformer_amd import scene
+
+    if mid:
+        return {"cfg": dict(batch_size=2, dec_dropout=0.0), "n_subsample": 30000, "weight_seed": 1, "numpy_seed": 9,
+                "fg_bias": 1.0,
+                "batch": lambda: scene.make_batch([scene.make_scene(90_000, 61), scene.make_scene(70_000, 62)])}
+    return {"cfg": dict(batch_size=2, dec_dropout=0.0, n_decode_point=512, n_query_points=32), "n_subsample": 2000,
+            "weight_seed": 1, "numpy_seed": 9, "fg_bias": 0.5,
+            "batch": lambda: scene.make_batch([scene.make_small_scene(8192, 7), scene.make_small_scene(6000, 8)])}
