@@ -515,8 +515,8 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
                                    Bf[l].tr_offs);
                 UN_TRY(gf_backbone_transformer(cur, lcoords[l], Bf[l].tr_offs, B, M[l], L.C, L.tr_layers, L.tr_params,
                                                Bf[l].tr_scratch, Bf[l].tr, st));
+                cur = Bf[l].tr;  // (a level without voxels has no rows to hand on: `tr` would be unwritten)
             }
-            cur = Bf[l].tr;
         }
         if (l > 0 && cur != Bf[l].o2) {
             // hand the level's result to the inverse conv above under one name

@@ -23,6 +23,15 @@ from scipy.optimize import linear_sum_assignment
 from . import config as _config
 
 
+def raise_if_knn_truncated(value):
+    """The forward's kNN truncation flag (outputs["knn_truncated"]), read back with the step's losses."""
+    if value:
+        from .._lib import GeoFormerHipError
+
+        raise GeoFormerHipError("kNN graph: a point has more in-radius neighbours than the kernel's candidate list "
+                                "holds (rows truncated, geodesic distances would be wrong)")
+
+
 def _device_route(t):
     import os
 
@@ -310,8 +319,12 @@ class InstSetCriterion(nn.Module):
         # the per-scene slices above rely on the model's layout: points of a scene contiguous, scenes in order
         bids = model_outputs["batch_idxs"]
         unsorted = (bids[1:] < bids[:-1]).any().float() if bids.numel() > 1 else zero.sum().float()
+        trunc = model_outputs.get("knn_truncated")  # the forward's kNN truncation flag rides in this read-back
+        trunc = trunc.reshape(()).float() if trunc is not None else zero.sum().float()
         vals = torch.stack([ld["focal_loss"].detach(), ld["dice_loss"].detach(), ld["cls_loss"].detach(),
-                            semantic_loss.detach(), loss.detach(), num_gt.float(), status.float(), unsorted]).tolist()  # 2 of 2
+                            semantic_loss.detach(), loss.detach(), num_gt.float(), status.float(), unsorted,
+                            trunc]).tolist()  # 2 of 2
+        raise_if_knn_truncated(vals[8])
         if vals[6] != 0:
             raise RuntimeError(f"gf_lsap status {int(vals[6])} (1: more than 512 x 1024 queries x instances, "
                                "2: non-finite costs)")
@@ -348,6 +361,8 @@ class InstSetCriterion(nn.Module):
             if res is not None:
                 return res
             self.device_matches = None
+        if model_outputs.get("knn_truncated") is not None:  # (the host route synchronises per scene anyway)
+            raise_if_knn_truncated(int(model_outputs["knn_truncated"].item()))
         preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
         instance_masked, semantic_masked = instance_labels[fg_idxs], semantic_labels[fg_idxs]
         batch_ids = model_outputs["batch_idxs"]

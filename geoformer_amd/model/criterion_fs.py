@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import config as _config
-from .criterion import (HungarianMatcher, _device_route, compute_dice_loss, compute_sigmoid_focal_loss, device_match,
+from .criterion import (HungarianMatcher, raise_if_knn_truncated, _device_route, compute_dice_loss, compute_sigmoid_focal_loss, device_match,
                         masked_pair_losses, scene_id_ranges)
 
 
@@ -178,9 +178,12 @@ class FSInstSetCriterion(nn.Module):
         bids = model_outputs["batch_idxs"]
         unsorted = (bids[1:] < bids[:-1]).any().float()
         zero = torch.zeros((), device=dev)
+        trunc = model_outputs.get("knn_truncated")  # the forward's kNN truncation flag rides in this read-back
         vals = torch.stack([ld["focal_loss"].detach(), ld["dice_loss"].detach(), loss.detach(), num_gt, status, unsorted,
                             (sim.detach() if sim is not None else zero),
-                            (sim_tot.detach() if sim is not None else zero)]).tolist()  # 2 of 2
+                            (sim_tot.detach() if sim is not None else zero),
+                            (trunc.reshape(()).float() if trunc is not None else zero)]).tolist()  # 2 of 2
+        raise_if_knn_truncated(vals[8])
         if vals[4] != 0 or vals[5] != 0:
             raise RuntimeError(f"device criterion: gf_lsap status {int(vals[4])}, batch_idxs unsorted {int(vals[5])}")
         if sim is not None and vals[7] > 0:
@@ -238,6 +241,8 @@ class FSInstSetCriterion(nn.Module):
             if res is not None:
                 return res
             self.device_matches = None
+        if model_outputs.get("knn_truncated") is not None:  # (the host route synchronises per scene anyway)
+            raise_if_knn_truncated(int(model_outputs["knn_truncated"].item()))
         preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
         instance_labels, semantic_labels = batch_inputs["instance_labels"], batch_inputs["labels"]
         instance_masked, semantic_masked = instance_labels[fg_idxs], semantic_labels[fg_idxs]

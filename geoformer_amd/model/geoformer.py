@@ -114,6 +114,14 @@ def knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05
             for b in range(batch_size)]
 
 
+def knn_truncated(graphs):
+    """One device word (int32 [1]) that is non-zero when a scene's kNN rows were cut at the kernel's candidate list
+    (rows are then no longer the k nearest: wrong geodesic distances).  A copy: the per-scene flags are views of the
+    kNN scratch buffers, which must not be kept alive by them.  None without graphs / flags (host operators)."""
+    fl = [g[3] for g in (graphs or ()) if len(g) > 3]
+    return torch.stack([f.reshape(()) for f in fl]).amax().reshape(1) if fl else None
+
+
 @torch.no_grad()
 def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighbor=64, radius=0.05, n_queries=128,
                  graphs=None):
@@ -196,6 +204,7 @@ class GeoFormer(nn.Module):
         input_c = cfg.input_channel + (3 if cfg.use_coords else 0)
         m, classes = cfg.m, cfg.classes
         self.prepare_epochs = cfg.prepare_epochs
+        self.rank_agreement = None  # set by parallel.convert_sync_batchnorm: callable(flag, device) -> bool over all ranks
         self.fix_module = list(cfg.fix_module)
         norm_fn = functools.partial(BatchNorm1d, eps=1e-4, momentum=0.1)
 
@@ -890,7 +899,11 @@ class GeoFormer(nn.Module):
         else:
             fg = semantic_preds >= 4 if same_fold else semantic_preds == 3
             fg_idxs = torch.nonzero(fg).view(-1)
+        # data-parallel training with SyncBatchNorm layers in the heads: the ranks leave here TOGETHER (parallel.py)
+        agree = self.rank_agreement if (training and torch.is_grad_enabled()) else None
         if len(fg_idxs) == 0:
+            if agree is not None:
+                agree(False, locs_float.device)
             outputs["mask_predictions"] = None
             return outputs
         if not fused_fg:
@@ -901,6 +914,9 @@ class GeoFormer(nn.Module):
         batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size, host_only=fused_fg and not training)
         offs_ = _offsets_list(batch_offsets_)  # the only read-back of this stretch, before the heavy launches
         nonempty = min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0
+        if agree is not None and not agree(nonempty, locs_float.device):
+            outputs["mask_predictions"] = None
+            return outputs
 
         def sampling_independent():
             """Everything of this stretch that does not need the sampling: mask features, class probabilities (read
@@ -962,6 +978,9 @@ class GeoFormer(nn.Module):
             outputs["fg_idxs"] = fg_idxs[idxs_sub]
             outputs["num_insts"] = cfg.n_query_points * batch_size
             outputs["batch_idxs"] = batch_idxs_sub
+            trunc = knn_truncated(graphs)
+            if trunc is not None:  # read by the criterion together with its own end-of-step values
+                outputs["knn_truncated"] = trunc
             outputs["mask_predictions"] = self.get_mask_prediction(geo_sub, dec_outputs, mask_features_[idxs_sub],
                                                                    locs_float_[idxs_sub], query_locs, offsets_sub)
         else:
@@ -976,7 +995,7 @@ class GeoFormer(nn.Module):
                 preds[-1]["mask_logits"], preds[-1]["cls_logits"], fg_idxs, batch_offsets, batch_offsets_,
                 semantic_scores_=semantic_scores_, logit_thresh=0.5, score_thresh=cfg.TEST_SCORE_THRESH,
                 npoint_thresh=cfg.TEST_NPOINT_THRESH, sem_prob=sem_prob, defer=defer_proposals,
-                knn_flags=[g[3] for g in (graphs or ()) if len(g) > 3])
+                knn_flags=[f for f in (knn_truncated(graphs),) if f is not None])
         if locs_float.is_cuda:
             self._early().clear()
         return outputs

@@ -20,8 +20,9 @@ import torch.nn as nn
 
 from . import config as _config
 from .backbone import random_downsample
+from .criterion import raise_if_knn_truncated
 from .. import pointops
-from .geoformer import GeoFormer, _offsets_list, cal_geodesic, get_batch_offsets, knn_graphs
+from .geoformer import GeoFormer, _offsets_list, cal_geodesic, get_batch_offsets, knn_graphs, knn_truncated
 from .layers import BatchNorm1d, GenericMLP
 
 
@@ -129,7 +130,13 @@ class GeoFormerFS(GeoFormer):
         mask_scores = torch.sum(prob * mask_bool.int(), dim=1) / (npts + 1e-6)
         scores = mask_scores * torch.pow(sim, 0.5)
         final = (sim >= sim_score_thresh) & (npts >= npoint_thresh) & (mask_scores >= score_thresh)
-        if torch.count_nonzero(final) == 0:
+        flag = getattr(self, "_knn_flag", None)
+        if flag is not None:  # the scene's kNN truncation flag rides in this read-back
+            n_final, trunc = torch.stack([torch.count_nonzero(final), flag.reshape(()).long()]).tolist()
+            raise_if_knn_truncated(trunc)
+        else:
+            n_final = int(torch.count_nonzero(final))
+        if n_final == 0:
             return [], []
         masks_final = mask_bool[final]
         proposals = torch.zeros((masks_final.shape[0], num_points), dtype=torch.int, device=prob.device)
@@ -178,7 +185,13 @@ class GeoFormerFS(GeoFormer):
             final = (sim >= cfg.similarity_thresh) & (npts >= cfg.TEST_NPOINT_THRESH) & \
                 (mask_scores >= cfg.TEST_SCORE_THRESH)
             pending.append((scores, final, mask_bool))
-        finals = torch.stack([p[1] for p in pending]).cpu()  # the one synchronisation
+        flag = getattr(self, "_knn_flag", None)
+        if flag is not None:  # the scene's kNN truncation flag rides in the one synchronisation
+            both = torch.cat([torch.stack([p[1] for p in pending]).reshape(-1).int(), flag.reshape(1).int()]).cpu()
+            raise_if_knn_truncated(int(both[-1]))
+            finals = both[:-1].reshape(len(pending), -1).bool()
+        else:
+            finals = torch.stack([p[1] for p in pending]).cpu()  # the one synchronisation
         out = []
         for (scores, final, mask_bool), f in zip(pending, finals):
             if not bool(f.any()):
@@ -220,10 +233,11 @@ class GeoFormerFS(GeoFormer):
             max_step = 128 if self.training else 256
             geo_dists = None
             offs_ = _offsets_list(batch_offsets_)
-            if (locs_float_.is_cuda and not torch.is_grad_enabled() and os.environ.get("GF_OVERLAP", "1") != "0"
-                    and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0):
-                # inference on the GPU: sampling cut after the query picks, BFS beside the rest of it (GeoFormer)
+            graphs = None
+            if locs_float_.is_cuda and min(offs_[b + 1] - offs_[b] for b in range(batch_size)) > 0:
                 graphs = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
+            if graphs is not None and not torch.is_grad_enabled() and os.environ.get("GF_OVERLAP", "1") != "0":
+                # inference on the GPU: sampling cut after the query picks, BFS beside the rest of it (GeoFormer)
                 contexts, geo_dists = self._aggregate_geodesic_overlapped(
                     locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step, sample=False,
                     epilogue=False)
@@ -237,7 +251,9 @@ class GeoFormerFS(GeoFormer):
             query_locs = context_locs[:, :cfg.n_query_points, :]
             if geo_dists is None:
                 geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=max_step, neighbor=64,
-                                         radius=0.05, n_queries=cfg.n_query_points)
+                                         radius=0.05, n_queries=cfg.n_query_points, graphs=graphs)
+            # the kNN truncation flag: read with the criterion's values (training) / the proposals' count (inference)
+            self._knn_flag = knn_truncated(graphs)
             self.cache_data = (context_locs, context_feats, pre_enc_inds, fg_idxs, batch_offsets, output_feats_,
                                batch_idxs_, locs_float_, batch_offsets_, semantic_preds_, semantic_scores, query_locs,
                                mask_features_, geo_dists)
@@ -267,6 +283,8 @@ class GeoFormerFS(GeoFormer):
         if training:
             outputs.update(fg_idxs=fg_idxs, num_insts=cfg.n_query_points * batch_size, batch_idxs=batch_idxs_,
                            simnet=similarity, mask_predictions=mask_predictions)
+            if getattr(self, "_knn_flag", None) is not None:
+                outputs["knn_truncated"] = self._knn_flag
             return outputs
         outputs["proposal_scores"] = self.generate_proposal(
             mask_predictions[-1]["mask_logits"], similarity.detach().sigmoid(), fg_idxs, batch_offsets,

@@ -16,9 +16,17 @@ sequence of collectives even when the ranks' graphs differ (an empty-foreground 
 that received a gradient on NO rank get ``grad = None`` back, so the optimizer skips them exactly like the
 single-GPU step does (no weight decay / moment updates on modules that are not trained yet).
 
-``SyncBatchNorm1d``: batch statistics over all ranks with one packed all-reduce per layer and direction
-(sum, sum of squares, count | sum(dy), sum(dy * xhat)); ``convert_sync_batchnorm`` swaps it in for the
-BatchNorm1d layers that see [M, C] voxel / point rows.
+``SyncBatchNorm1d``: batch statistics over all ranks with ONE packed collective per layer and direction (forward: an
+all-gather of every rank's (count, mean, M2) merged with Chan's parallel formula, the arithmetic of
+``batch_norm_gather_stats_with_counts``; backward: an all-reduce of (sum(dy), sum(dy * xhat))).  A layer's statistics
+are needed before the next convolution can run, and the layers of a U-Net level feed each other (BN -> ReLU -> conv ->
+BN ...), so the collectives of different layers cannot be packed into one: SURVEY 8e's "one packed all-reduce per
+level" would need statistics that are one layer stale.  What is packed is everything one layer exchanges.  A rank with
+an EMPTY input still takes part (count 0), and ``convert_sync_batchnorm`` gives the model a ``rank_agreement`` hook so
+that all ranks leave the forward together when one of them has no foreground -- the ranks' collective sequences stay
+identical.  With SyncBatchNorm layers in the module the gradient buckets are NOT started from the backward hooks
+(they would interleave with the layers' backward collectives in a rank-dependent order on the same communicator) but
+all from ``finish()``.
 """
 from __future__ import annotations
 
@@ -43,13 +51,19 @@ def init_distributed(backend=None):
 class BucketedGradReducer:
     """Gradient averaging over one flat buffer; buckets start from gradient hooks while the backward runs."""
 
-    def __init__(self, module, bucket_bytes=8 << 20, only_trainable=True):
+    def __init__(self, module, bucket_bytes=8 << 20, only_trainable=True, overlap=None):
+        """overlap: start a bucket's all-reduce from the gradient hooks while the backward runs.  Default: on, unless the
+        module holds SyncBatchNorm1d layers -- their backward collectives share the communicator, and a rank whose
+        first bucket completes late would order the two kinds differently from its peers."""
+        if overlap is None:
+            overlap = not any(isinstance(m, SyncBatchNorm1d) for m in module.modules())
+        self.overlap = bool(overlap)
         params = [p for p in module.parameters() if (p.requires_grad or not only_trainable)]
         self.params = params[::-1]  # backward order: the last layers' gradients arrive first
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.used = torch.zeros(len(self.params), dtype=torch.float32, device=dev)
+        self.used = [0.0] * len(self.params)  # host side; uploaded once in finish()
         per_bucket = max(int(bucket_bytes) // 4, 1)
         self.views, self.bucket_of, self.ranges = [], [], []
         off = start = 0
@@ -82,7 +96,7 @@ class BucketedGradReducer:
     def prepare(self):
         """Call before every backward: zero the buffer and point every p.grad at its view of it."""
         self.flat.zero_()
-        self.used.zero_()
+        self.used = [0.0] * len(self.params)
         for p, v in zip(self.params, self.views):
             p.grad = v
         self._ready = [0] * len(self.ranges)
@@ -108,7 +122,7 @@ class BucketedGradReducer:
         b = self.bucket_of[i]
         self._ready[b] += 1
         # buckets leave in index order only: identical collective sequence on every rank
-        while self._next < len(self.ranges) and self._ready[self._next] == self.nparams_in[self._next]:
+        while self.overlap and self._next < len(self.ranges) and self._ready[self._next] == self.nparams_in[self._next]:
             self._launch(self._next)
             self._next += 1
             self.launched_in_backward += 1
@@ -121,17 +135,16 @@ class BucketedGradReducer:
         while self._next < len(self.ranges):
             self._launch(self._next)
             self._next += 1
+        used = self.used
         if world > 1:
-            self._works.append(dist.all_reduce(self.used, op=dist.ReduceOp.MAX, async_op=True))
+            flags = torch.tensor(used, dtype=torch.float32, device=self.flat.device)
+            self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.MAX, async_op=True))
             for w in self._works:
                 w.wait()
             self.flat.div_(world)
-        used = self.used.tolist()
+            used = flags.tolist()
         for p, v, u in zip(self.params, self.views, used):
             p.grad = v if u > 0 else None
-
-    # the round-1 name / call
-    reduce = finish
 
     def remove_hooks(self):
         for h in self._hooks:
@@ -139,7 +152,14 @@ class BucketedGradReducer:
         self._hooks = []
 
 
-FlatGradAllReduce = BucketedGradReducer  # former name
+def all_ranks_agree(flag: bool, device) -> bool:
+    """True iff `flag` holds on every rank (one MIN all-reduce of a word + its read-back)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32,
+                     device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
 
 
 class _SyncBNFn(torch.autograd.Function):
@@ -148,12 +168,23 @@ class _SyncBNFn(torch.autograd.Function):
         C = x.shape[1]
         red = [d for d in range(x.dim()) if d != 1]
         n_local = x.numel() // C
-        stats = torch.cat([x.sum(red), (x * x).sum(red), x.new_full((1,), float(n_local))])
+        if n_local > 0:
+            var_l, mean_l = torch.var_mean(x, red, unbiased=False)  # two-pass / Welford: no E[x^2] - mean^2 cancellation
+            m2_l = var_l * float(n_local)
+        else:  # an empty rank still takes part, with count 0
+            mean_l, m2_l = x.new_zeros(C), x.new_zeros(C)
+        local = torch.cat([x.new_full((1,), float(n_local)), mean_l, m2_l])
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(stats)
-        n = stats[-1]
-        mean = stats[:C] / n
-        var = (stats[C:2 * C] / n - mean * mean).clamp_min(0.0)
+            flat = x.new_empty(dist.get_world_size() * (2 * C + 1))  # (flat: gloo takes the concatenated form only)
+            dist.all_gather_into_tensor(flat, local)
+            allst = flat.view(dist.get_world_size(), 2 * C + 1)
+        else:
+            allst = local.view(1, -1)
+        # Chan et al.: n = sum n_r, mean = sum n_r mean_r / n, M2 = sum M2_r + sum n_r (mean_r - mean)^2
+        n_r, mean_r, m2_r = allst[:, :1], allst[:, 1:1 + C], allst[:, 1 + C:]
+        n = n_r.sum().clamp_min(1.0)
+        mean = (n_r * mean_r).sum(0) / n
+        var = ((m2_r + n_r * (mean_r - mean) ** 2).sum(0) / n).clamp_min(0.0)
         invstd = torch.rsqrt(var + eps)
         shape = [1, C] + [1] * (x.dim() - 2)
         xhat = (x - mean.view(shape)) * invstd.view(shape)
@@ -181,8 +212,9 @@ class SyncBatchNorm1d(nn.BatchNorm1d):
     state dict are those of nn.BatchNorm1d."""
 
     def forward(self, x):
-        if not self.training or x.numel() == 0:
+        if not self.training:
             return super().forward(x)
+        # (an empty input goes through as well: the other ranks are waiting in this layer's collective)
         y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps)
         with torch.no_grad():
             if self.track_running_stats:
@@ -196,7 +228,11 @@ class SyncBatchNorm1d(nn.BatchNorm1d):
 
 def convert_sync_batchnorm(module):
     """Replace every nn.BatchNorm1d (incl. the build's lean subclass) by SyncBatchNorm1d, sharing parameters and
-    buffers (what the reference's ``nn.SyncBatchNorm.convert_sync_batchnorm`` call, train.py:182, intended)."""
+    buffers (what the reference's ``nn.SyncBatchNorm.convert_sync_batchnorm`` call, train.py:182, intended).  A model
+    with a ``rank_agreement`` attribute (GeoFormer) gets ``all_ranks_agree``: its forward then leaves on ALL ranks when
+    one rank's batch has no foreground, instead of skipping the heads' layers on that rank alone."""
+    if hasattr(module, "rank_agreement"):
+        module.rank_agreement = all_ranks_agree
     for name, child in list(module.named_children()):
         if isinstance(child, nn.BatchNorm1d) and not isinstance(child, SyncBatchNorm1d):
             sb = SyncBatchNorm1d(child.num_features, eps=child.eps, momentum=child.momentum, affine=child.affine,

@@ -167,6 +167,11 @@ def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     side = sides.get((dev, main.cuda_stream))
     if side is None:
         side = sides[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
-    check(lib.gf_unet_fwd(plan.ref, voxel_feats.data_ptr(), coords.data_ptr(), M, batch_size, X, Y, Z, ws.data_ptr(),
-                          nbytes, pinned.data_ptr(), out.data_ptr(), stream_ptr(), side.cuda_stream), "gf_unet_fwd")
+    rc = lib.gf_unet_fwd(plan.ref, voxel_feats.data_ptr(), coords.data_ptr(), M, batch_size, X, Y, Z, ws.data_ptr(),
+                         nbytes, pinned.data_ptr(), out.data_ptr(), stream_ptr(), side.cuda_stream)
+    if rc != 0:
+        # an error return can leave the rulebook chain queued on the side stream, still writing `ws`: the caching
+        # allocator must not hand the block to the caller's stream before that work has drained
+        side.synchronize()
+    check(rc, "gf_unet_fwd")
     return out

@@ -219,3 +219,111 @@ def test_sync_batchnorm_matches_single_process():
     assert np.abs(gw0 - bn.weight.grad.numpy()).max() < 1e-4 and np.abs(gb0 - bn.bias.grad.numpy()).max() < 1e-4
     assert np.abs(rm0 - bn.running_mean.numpy()).max() < 1e-6 and np.abs(rv0 - bn.running_var.numpy()).max() < 1e-5
     assert np.array_equal(rm0, rm1) and np.array_equal(rv0, rv1)
+
+
+# ---- SyncBatchNorm + divergent ranks through the real model -----------------------------------------------------
+def _syncbn_worker(rank, world, port, ret):
+    """sync-bn on, rank 1's first batch has NO foreground: both ranks must issue the same sequence of collectives
+    (the empty rank still takes part in every BatchNorm layer's exchange up to the point where ALL ranks leave the
+    forward together), nobody hangs, and the next step -- both ranks with foreground -- trains normally."""
+    parallel = _init(rank, world, port)
+    import argparse
+    import sys
+
+    from geoformer_amd import scene
+    from oracle import cpu_backend
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_dp
+
+    torch.set_num_threads(2)
+    counts = {"n": 0}
+    for name in ("all_reduce", "all_gather_into_tensor"):
+        orig = getattr(dist, name)
+
+        def counted(*a, _orig=orig, **k):
+            counts["n"] += 1
+            return _orig(*a, **k)
+
+        setattr(dist, name, counted)
+    with cpu_backend.installed():
+        args = argparse.Namespace(batch_size=1, small=True, prepare_epochs=1, sync_bn=True, bn_eval=False)
+        cfg, m, crit = train_dp.build(args, torch.device("cpu"))
+        assert m.rank_agreement is parallel.all_ranks_agree
+        red = parallel.BucketedGradReducer(m, bucket_bytes=2 << 20)
+        assert not red.overlap  # SyncBatchNorm layers present: buckets leave from finish() only
+        batch = scene.make_batch([_scenes()[rank]])
+        orig_bb = m.forward_backbone
+        if rank == 1:  # an empty-foreground batch: every point predicted background
+            def no_fg(*a, **k):
+                feats, scores, preds = orig_bb(*a, **k)
+                return feats, scores, torch.zeros_like(preds)
+
+            m.forward_backbone = no_fg
+        loss0, _ = train_dp.step(m, crit, red, None, batch, 5, 3)
+        n0 = counts["n"]
+        m.forward_backbone = orig_bb
+        loss1, _ = train_dp.step(m, crit, red, None, batch, 5, 4)
+        g = {n: (None if p.grad is None else p.grad.detach().clone().numpy()) for n, p in m.named_parameters()}
+        ret[rank] = (loss0, n0, loss1, counts["n"] - n0, g)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_with_an_empty_foreground_rank_keeps_the_collective_sequence(oracle):
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_syncbn_worker, args=(world, port, ret), nprocs=world, join=True)
+    (l00, n00, l01, n01, g0), (l10, n10, l11, n11, g1) = ret[0], ret[1]
+    assert np.isnan(l00) and np.isnan(l10)  # BOTH ranks left the first forward (agreement), nobody computed a loss
+    assert n00 == n10 and n01 == n11 and n01 > n00  # identical numbers of collectives on both ranks, in both steps
+    assert np.isfinite(l01) and np.isfinite(l11)
+    for name in g0:
+        assert (g0[name] is None) == (g1[name] is None), name
+        if g0[name] is not None:
+            assert np.array_equal(g0[name], g1[name]), name  # the averaged gradient is the same tensor on both ranks
+
+
+def test_sync_batchnorm_empty_rank_takes_part():
+    """One rank with zero rows: it contributes count 0 and the other rank's statistics are those of its own rows."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bn_empty_worker, args=(world, port, ret), nprocs=world, join=True)
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((40, 6)).astype(np.float32) * 3 + 100.0)  # |mean| >> std: no cancellation
+    bn = torch.nn.BatchNorm1d(6, eps=1e-4, momentum=0.1)
+    y = bn(x)
+    assert np.abs(ret[0] - y.detach().numpy()).max() < 1e-4
+    assert ret[1].shape == (0, 6)
+
+
+def _bn_empty_worker(rank, world, port, ret):
+    parallel = _init(rank, world, port)
+    rng = np.random.default_rng(0)
+    x_all = torch.from_numpy(rng.standard_normal((40, 6)).astype(np.float32) * 3 + 100.0)
+    bn = parallel.SyncBatchNorm1d(6, eps=1e-4, momentum=0.1)
+    x = (x_all if rank == 0 else x_all[:0]).clone().requires_grad_()
+    y = bn(x)
+    y.sum().backward()
+    ret[rank] = y.detach().numpy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ---- bench.py --gpus N launches its own ranks -------------------------------------------------------------------
+def test_bench_self_launch_prints_one_line_with_n_gpus():
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--plumbing-test"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3

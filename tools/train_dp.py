@@ -10,7 +10,8 @@ HIP_VISIBLE_DEVICES=<rank> instead when its own train.py is used).  Every rank b
 (seed + rank) and rulebooks; the only exchange is BucketedGradReducer's bucketed all-reduce, started from gradient
 hooks while the backward is still running (geoformer_amd/parallel.py), plus one packed all-reduce per BatchNorm layer
 and direction with --sync-bn.  Timing: barrier + synchronize on both sides, max over ranks; rank 0 prints one JSON
-line.  --cpu runs the same loop on the host through the oracle's operators over gloo (tests / smoke only).
+line.  `run()` is the loop itself: bench.py calls it for its `secondary.train_step_b4` (one GPU) and
+`secondary.train_dp_step` (N ranks) lines; tests/test_parallel_gloo.py drives it over gloo on the host.
 """
 import argparse
 import json
@@ -68,9 +69,17 @@ def make_batches(args, rank, device, n):
 
 
 def step(m, crit, red, opt, batch, epoch, np_seed):
+    """One training step.  A rank whose batch has no foreground (mask_predictions None past prepare_epochs) skips its
+    backward like train.py:68-69 does, but still takes part in the gradient exchange with zeros; with SyncBatchNorm the
+    model itself makes all ranks leave the forward together (parallel.all_ranks_agree)."""
     np.random.seed(np_seed)
     red.prepare()  # zeroes the flat gradient buffer and points every p.grad into it (instead of zero_grad)
     out = m(batch, epoch)
+    if epoch > m.prepare_epochs and out.get("mask_predictions") is None:
+        red.finish()
+        if opt is not None:
+            opt.step()  # the other ranks' averaged gradients (none when every rank skipped): parameters stay in step
+        return float("nan"), {}
     loss, info = crit(out, batch, epoch)
     loss.backward()  # buckets leave from the gradient hooks while this runs
     red.finish()
@@ -79,7 +88,58 @@ def step(m, crit, red, opt, batch, epoch, np_seed):
     return float(loss.detach()), info
 
 
-def main(argv=None):
+def run(args, device, batches=None):
+    """Build model / criterion / reducer / Adam, run `warmup` + `steps` training steps over two rotating batches and
+    return the result dict (time = barrier + synchronise on both sides, max over ranks).  The process group, if any,
+    is the caller's."""
+    import torch.distributed as dist
+
+    from geoformer_amd import parallel
+
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    cfg, m, crit = build(args, device)
+    red = parallel.BucketedGradReducer(m, bucket_bytes=int(args.bucket_mb * (1 << 20)))
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3,
+                           fused=device.type == "cuda")  # one launch per step on the GPU (the foreach form: ~5 ms of host time)
+    nb = 2
+    if batches is None:
+        batches = make_batches(args, rank, device, nb)
+    sync = (lambda: torch.cuda.synchronize()) if device.type == "cuda" else (lambda: None)
+    for i in range(args.warmup):
+        step(m, crit, red, opt, batches[i % len(batches)], args.epoch, 100 * rank + i)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    early = 0
+    loss = float("nan")
+    for i in range(args.steps):
+        loss, _ = step(m, crit, red, opt, batches[i % len(batches)], args.epoch, 100 * rank + args.warmup + i)
+        early += red.launched_in_backward
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, device if device.type == "cuda" else None)
+    scenes = world * args.batch_size * args.steps
+    return {"metric": "training scenes/sec (fwd + criterion + bwd + all-reduce + Adam)", "value": round(scenes / dt, 3),
+            "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "global_batch": world * args.batch_size,
+            "points_per_scene": args.points, "points_per_batch": [int(b["locs"].shape[0]) for b in batches],
+            "epoch": args.epoch, "prepare_epochs": int(m.prepare_epochs), "sync_bn": bool(args.sync_bn),
+            "grad_floats": red.numel(), "buckets": len(red.ranges),
+            "buckets_started_inside_backward_per_step": round(early / max(args.steps, 1), 2),
+            "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}
+
+
+def default_args(**over):
+    """The argument namespace of `main` with its defaults (for callers of `run`)."""
+    return parser().parse_args([], argparse.Namespace(**over))
+
+
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -91,67 +151,28 @@ def main(argv=None):
     ap.add_argument("--bucket-mb", type=float, default=8.0)
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--bn-eval", action="store_true")
-    ap.add_argument("--small", action="store_true", help="small scenes / heads (CPU smoke runs)")
-    ap.add_argument("--cpu", action="store_true", help="host run through the oracle operators over gloo")
-    args = ap.parse_args(argv)
+    ap.add_argument("--small", action="store_true", help="small scenes / heads (host-side test runs)")
+    return ap
 
+
+def main(argv=None):
+    args = parser().parse_args(argv)
     import torch.distributed as dist
 
     from geoformer_amd import parallel
 
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if args.cpu:
-        device = torch.device("cpu")
-        world = parallel.init_distributed("gloo")
-        from oracle import cpu_backend
-
-        restore = cpu_backend.install()
-    else:
-        if not torch.cuda.is_available():
-            raise SystemExit("tools/train_dp.py needs a GPU (or --cpu for the oracle-backed smoke run)")
-        torch.cuda.set_device(local)
-        device = torch.device("cuda", local)
-        world = parallel.init_distributed("nccl")
-        restore = lambda: None  # noqa: E731
-    try:
-        cfg, m, crit = build(args, device)
-        red = parallel.BucketedGradReducer(m, bucket_bytes=int(args.bucket_mb * (1 << 20)))
-        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3,
-                               fused=device.type == "cuda")  # one launch per step on the GPU (the foreach form: ~5 ms of host time)
-        nb = 2
-        batches = make_batches(args, rank, device, nb)
-        sync = (lambda: torch.cuda.synchronize()) if device.type == "cuda" else (lambda: None)
-        for i in range(args.warmup):
-            step(m, crit, red, opt, batches[i % nb], args.epoch, 100 * rank + i)
-        sync()
-        if world > 1:
-            dist.barrier()
-        sync()
-        t0 = time.perf_counter()
-        early = 0
-        for i in range(args.steps):
-            loss, _ = step(m, crit, red, opt, batches[i % nb], args.epoch, 100 * rank + args.warmup + i)
-            early += red.launched_in_backward
-        sync()
-        if world > 1:
-            dist.barrier()
-        sync()
-        dt = parallel.max_over_ranks(time.perf_counter() - t0, device if device.type == "cuda" else None)
-        if rank == 0:
-            scenes = world * args.batch_size * args.steps
-            print(json.dumps({
-                "metric": "training scenes/sec (fwd + criterion + bwd + all-reduce + Adam)", "value": round(scenes / dt, 3),
-                "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 2), "global_batch": world * args.batch_size,
-                "points_per_scene": args.points, "epoch": args.epoch, "sync_bn": bool(args.sync_bn),
-                "grad_floats": red.numel(), "buckets": len(red.ranges),
-                "buckets_started_inside_backward_per_step": round(early / max(args.steps, 1), 2),
-                "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}), flush=True)
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-    finally:
-        restore()
+    if not torch.cuda.is_available():
+        raise SystemExit("tools/train_dp.py needs a GPU: the HIP operators have no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    world = parallel.init_distributed("nccl")
+    res = run(args, device)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
