@@ -43,6 +43,7 @@ def _declare(lib):
         "gf_dev_conv_fwd_timed": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
         "gf_dev_conv_knobs_g16": (I, [I, I, I, I]),
         "gf_dev_conv_chunks": (I, [I]),
+        "gf_dev_conv_g16p_wpb": (I, [I]),
         "gf_dev_conv_knobs": (I, [I, I, I, I, I]),
         "gf_dev_conv_occupancy": (I, [I]),
         "gf_resblock_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
@@ -109,6 +110,9 @@ def _declare(lib):
         "gf_decoder_cross_attn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P]),
         "gf_decoder_cross_attn_bwd_scratch_floats": (c_size_t, [I, I, I]),
         "gf_decoder_cross_attn_bwd": (I, [P] * 16 + [I, I, I, I] + [P] * 6),
+        "gf_bn_train_scratch_floats": (c_size_t, [I, I]),
+        "gf_bn_relu_train_fwd": (I, [P, I, I, P, P, F, F, I, P, P, P, P, P, P, P, P]),
+        "gf_bn_relu_train_bwd": (I, [P, P, P, I, I, P, P, P, I, P, P, P, P, P, P]),
         "gf_sec_op": (I, [I, P, P, I, I, P, P]),
         "gf_roipool_fp": (I, [P, P, I, I, P, P, P]),
         "gf_roipool_bp": (I, [P, P, I, I, P, P]),

@@ -819,8 +819,8 @@ extern "C" int gf_dev_conv_trace(void* p) {
 #ifndef CONV_G16P_WAVES
 #define CONV_G16P_WAVES 2  // resident waves per SIMD the register budget is set for
 #endif
-template <int NCH, bool AFF, bool RES, bool LDSW>
-__global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float* __restrict__ in, const float4* __restrict__ Wp,
+template <int NCH, bool AFF, bool RES, bool LDSW, int WPB>
+__global__ __launch_bounds__(64 * WPB, CONV_G16P_WAVES) void k_conv_g16p(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                       const int32_t* __restrict__ steps_raw,
                                                       const uint32_t* __restrict__ gmask,
                                                       const int32_t* __restrict__ chunks, int K, int M_out,
@@ -844,14 +844,24 @@ __global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float*
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, K * NCH * 1024, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_st =
         __builtin_amdgcn_make_buffer_rsrc((void*)steps_raw, 0, (int)steps_bytes, 0x00020000);
-    const int cw = blockIdx.x * 4 + w;
+    const int cw = blockIdx.x * WPB + w;
 #ifdef CONV_TRACE
     unsigned long long tr[8] = {TR_NOW(), 0, 0, 0, 0, 0, 0, 0};  // start, after barrier, first data, [wait a0, mfma, tail] sums, end, groups
 #endif
+    // the table's count and this wave's two boundaries as three INDEPENDENT loads (count -> boundaries was one more
+    // dependent round trip in front of the first index load; the table's tail is sized for GF_CONV_CHUNKS_MAX entries)
+    const int cwc = min(cw, GF_CONV_CHUNKS_MAX - 1);
     const int nchunks = chunks[-1];
-    if (blockIdx.x * 4 >= nchunks) return;  // whole workgroup past the table (uniform: no barrier is skipped by part of it)
-    int g = __builtin_amdgcn_readfirstlane(chunks[min(cw, nchunks)]);
-    const int gend = __builtin_amdgcn_readfirstlane(chunks[min(cw + 1, nchunks)]);
+    const int c0 = chunks[cwc], c1 = chunks[cwc + 1];
+    if (blockIdx.x * WPB >= nchunks) return;  // whole workgroup past the table (uniform: no barrier is skipped by part of it)
+    const bool live_chunk = cw < nchunks;     // (a wave past the count inside the last workgroup: empty range)
+    int g = __builtin_amdgcn_readfirstlane(live_chunk ? c0 : 0);
+    const int gend = __builtin_amdgcn_readfirstlane(live_chunk ? c1 : 0);
+    // the offset masks of the chunk's groups, one per lane (a chunk holds ~3 groups): one load in the prologue instead
+    // of a dependent load in front of every group's first weight fetch
+    const int g_first = g;
+    uint32_t mask_v = 0;
+    if (g_first + lane < gend) mask_v = gmask[g_first + lane];
     const unsigned lane_ch = 16u * (unsigned)q;
     const unsigned rec_lane = (unsigned)r * 16u;  // this lane's 16-byte entry inside a 256-byte step block
     constexpr unsigned GROUP_BYTES = GF_STEP_BLKS * 256u;
@@ -886,15 +896,16 @@ __global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float*
     load_idx(ibY, g + 1);
     if (LDSW) {
         const int total = K * NCH * 64;
-        constexpr int WST = 8;  // 27 x 64 x NCH float4 over 256 threads: at most 7 (NCH 1) / 14 (NCH 2) per thread
-        for (int base = 0; base < total; base += 256 * WST) {
+        constexpr int T = 64 * WPB;
+        constexpr int WST = WPB >= 8 ? 4 : 8;  // 27 x 64 x NCH float4 over T threads: 7 (NCH 1) / 14 (NCH 2) per thread at T = 256
+        for (int base = 0; base < total; base += T * WST) {
             u32x4 tmp[WST];
 #pragma unroll
             for (int j = 0; j < WST; j++)
-                tmp[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(base + j * 256 + (int)threadIdx.x) * 16u, 0, 0);
+                tmp[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)(base + j * T + (int)threadIdx.x) * 16u, 0, 0);
 #pragma unroll
             for (int j = 0; j < WST; j++) {
-                const int t = base + j * 256 + (int)threadIdx.x;
+                const int t = base + j * T + (int)threadIdx.x;
                 if (t < total)
                     s_w[t] = make_float4(__uint_as_float(tmp[j][0]), __uint_as_float(tmp[j][1]), __uint_as_float(tmp[j][2]),
                                          __uint_as_float(tmp[j][3]));
@@ -909,6 +920,12 @@ __global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float*
             sh[c] = *reinterpret_cast<const float4*>(in_shift + c * 16 + 4 * q);
         }
     }
+    // the epilogue activation's scale / shift of this lane's four channels, once per wave (not once per group)
+    float4 os = make_float4(1.f, 1.f, 1.f, 1.f), ot = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (out_scale) {
+        os = *reinterpret_cast<const float4*>(out_scale + 4 * q);
+        ot = *reinterpret_cast<const float4*>(out_shift + 4 * q);
+    }
     if (g < gend) gather(aX, ibX, true, presX);
     if (LDSW) __syncthreads();
 #ifdef CONV_TRACE
@@ -918,7 +935,8 @@ __global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float*
 
     // one group's MFMAs + store; `a` holds its gathered rows (in flight), `pres` its presence bits
     auto compute = [&](u32x4 (&a)[NS][NCH], unsigned pres, int gg) {
-        uint32_t m = __builtin_amdgcn_readfirstlane(gmask[gg]);
+        uint32_t m = (gg - g_first) < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)mask_v, gg - g_first)
+                                         : __builtin_amdgcn_readfirstlane(gmask[gg]);
         const int n = __popc(m);
         const int row = gg * 16 + r;
         float4 resv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1031,8 +1049,6 @@ __global__ __launch_bounds__(256, CONV_G16P_WAVES) void k_conv_g16p(const float*
                 v.x += resv.x; v.y += resv.y; v.z += resv.z; v.w += resv.w;
             }
             if (out_scale) {  // epilogue activation: the consumer's BatchNorm + ReLU, once per output element
-                const float4 os = *reinterpret_cast<const float4*>(out_scale + 4 * q);
-                const float4 ot = *reinterpret_cast<const float4*>(out_shift + 4 * q);
                 if (out2) {
                     // both forms leave the kernel: the raw sum (residual operand of the next block) and the
                     // activated copy its first convolution gathers from -- one BatchNorm + ReLU per ELEMENT here
@@ -1106,35 +1122,47 @@ extern "C" int gf_dev_conv_kernel_events(void* start, void* stop) {
 }
 extern "C" int gf_dev_conv_kernel_events_taken(void) { return t_kev_taken ? 1 : 0; }
 
-template <int NCH, bool LDSW>
-static void launch_g16p(size_t lds, hipStream_t st, const float* in, const float4* Wp, const int32_t* steps,
-                        const uint32_t* gmask, int K, int M_out, int ld, unsigned in_bytes, const float* sc,
-                        const float* sh, const float* res, const float* osc, const float* osh, float* out,
-                        float* out2) {
+// waves per workgroup of the pipelined kernel.  12 = ONE workgroup per compute unit with the default 3072 chunks (256
+// workgroups, the kernel's 133-148 VGPRs allow three waves per SIMD): the 27 KiB of packed weights are staged once per
+// compute unit instead of three times.  Measured on the S150k level-1 launch (tools/conv_wpb_exp.py, back-to-back
+// launches): residual epilogue 18.95 -> 17.32 us, activation epilogue 18.62 -> 18.23; 8 or 16 waves leave compute units
+// with a second round (23-25 us).  0 = 12 when the table's chunk count is a multiple of 12, else 4.
+static int g_g16p_wpb = 0;
+extern "C" int gf_dev_conv_g16p_wpb(int wpb) {
+    GF_CHECK_ARG(wpb == 0 || wpb == 4 || wpb == 8 || wpb == 12 || wpb == 16, "gf_dev_conv_g16p_wpb: %d (4, 8, 12 or 16)", wpb);
+    g_g16p_wpb = wpb;
+    return GF_OK;
+}
+
+template <int NCH, bool LDSW, int WPB>
+static void launch_g16p_w(size_t lds, hipStream_t st, const float* in, const float4* Wp, const int32_t* steps,
+                          const uint32_t* gmask, int K, int M_out, int ld, unsigned in_bytes, const float* sc,
+                          const float* sh, const float* res, const float* osc, const float* osh, float* out,
+                          float* out2) {
     if (LDSW) {
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, false, false, true, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, false, true, true, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, true, false, true, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_conv_g16p<NCH, true, true, true, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             attr = true;
         }
     }
     const size_t step_words = (size_t)(ld / 16) * GF_STEP_BLKS * 64;
     const int32_t* chunks = steps + step_words + 1;  // [-1] = number of chunks the table was built with
     const unsigned steps_bytes = (unsigned)(step_words * 4);
-    dim3 grid(GF_CONV_CHUNKS_MAX / 4);  // waves of chunks past the table's count leave at once
+    dim3 grid((GF_CONV_CHUNKS_MAX + WPB - 1) / WPB);  // waves of chunks past the table's count leave at once
 #define G16P_LAUNCH(AFF_, RES_)                                                                                       \
     do {                                                                                                              \
         if (t_kev_start) {                                                                                            \
-            hipExtLaunchKernelGGL((k_conv_g16p<NCH, AFF_, RES_, LDSW>), grid, dim3(256), (std::uint32_t)lds, st,      \
+            hipExtLaunchKernelGGL((k_conv_g16p<NCH, AFF_, RES_, LDSW, WPB>), grid, dim3(64 * WPB), (std::uint32_t)lds, st, \
                                   t_kev_start, t_kev_stop, 0u, in, Wp, steps, gmask, chunks, K, M_out, in_bytes,      \
                                   steps_bytes, sc, sh, res, osc, osh, out, out2);                                     \
             t_kev_start = t_kev_stop = nullptr;                                                                       \
             t_kev_taken = true;                                                                                       \
         } else {                                                                                                      \
-            hipLaunchKernelGGL((k_conv_g16p<NCH, AFF_, RES_, LDSW>), grid, dim3(256), lds, st, in, Wp, steps, gmask,  \
+            hipLaunchKernelGGL((k_conv_g16p<NCH, AFF_, RES_, LDSW, WPB>), grid, dim3(64 * WPB), lds, st, in, Wp, steps, gmask,  \
                                chunks, K, M_out, in_bytes, steps_bytes, sc, sh, res, osc, osh, out, out2);            \
         }                                                                                                             \
     } while (0)
@@ -1143,6 +1171,24 @@ static void launch_g16p(size_t lds, hipStream_t st, const float* in, const float
     else if (res) G16P_LAUNCH(false, true);
     else G16P_LAUNCH(false, false);
 #undef G16P_LAUNCH
+}
+
+template <int NCH, bool LDSW>
+static void launch_g16p(size_t lds, hipStream_t st, const float* in, const float4* Wp, const int32_t* steps,
+                        const uint32_t* gmask, int K, int M_out, int ld, unsigned in_bytes, const float* sc,
+                        const float* sh, const float* res, const float* osc, const float* osh, float* out,
+                        float* out2) {
+#define G16P_W(W_) launch_g16p_w<NCH, LDSW, W_>(lds, st, in, Wp, steps, gmask, K, M_out, ld, in_bytes, sc, sh, res, osc, osh, out, out2)
+    // (the launch with the residual epilogue gains 10 % from one workgroup per compute unit, 18.9 -> 17.1 us; the one with
+    // the activation epilogue is level, 17.8 / 18.0 us)
+    const int wpb = g_g16p_wpb ? g_g16p_wpb : (res != nullptr && gf_conv_chunks() % 12 == 0 ? 12 : 4);
+    switch (wpb) {
+        case 8: G16P_W(8); break;
+        case 12: G16P_W(12); break;
+        case 16: G16P_W(16); break;
+        default: G16P_W(4); break;
+    }
+#undef G16P_W
 }
 
 struct ConvArgs {

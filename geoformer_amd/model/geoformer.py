@@ -643,6 +643,12 @@ class GeoFormer(nn.Module):
             if B == 1 and pre_enc_inds.dtype == torch.int32:
                 g1, m1 = pointops.relpos_prepare(geo_dists[0].contiguous(), pre_enc_inds[0].contiguous())
                 geo, max_geo = g1.unsqueeze(0), m1.unsqueeze(0)
+            elif B > 1 and pre_enc_inds.stride(0) == 0 and all(g is geo_dists[0] for g in geo_dists):
+                # B episodes over ONE cached scene (GeoFormerFS.requery_many): gathered once, shared by all of them
+                g1 = geo_dists[0][:, pre_enc_inds[0].long()]
+                m1 = torch.max(g1, dim=1)[0]
+                m1 = torch.where(m1 < 0, torch.max(m1), m1)
+                geo, max_geo = g1.unsqueeze(0).expand(B, -1, -1).contiguous(), m1.unsqueeze(0).expand(B, -1).contiguous()
             else:
                 geo = torch.stack([geo_dists[b][:, pre_enc_inds[b].long()] for b in range(B)], dim=0).contiguous()
                 max_geo = torch.max(geo, dim=2)[0]

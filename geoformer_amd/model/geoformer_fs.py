@@ -145,46 +145,62 @@ class GeoFormerFS(GeoFormer):
         return scores[final], proposals
 
     # -- batched re-query of a cached scene ---------------------------------
+    REQUERY_CHUNK = 16  # episodes per decoder pass (the pair products of a pass are E x 2048 x 64 floats per layer)
+
     @torch.no_grad()
     def requery_many(self, scene_dict, support_embeddings):
         """The few-shot test loop re-queries ONE scene with many support embeddings (every label of the scene x
         ``run_num`` support draws, test_fs.py:157-174): ``forward(..., remember=True, support_embeddings=e)`` once per
         embedding, each ending in the host read-backs of generate_proposal (count_nonzero, boolean indexing).
-        Here all E re-queries are queued back to back -- fusion, decoder, mask head, similarity and the proposal
-        statistics stay on the device -- and the host synchronises ONCE at the end to cut the accepted proposals.
+        Here the E re-queries are ONE decoder pass with the episode as the batch index: the fused context
+        [E, nc, 3C], the projections, the token stages and the cross-attention kernels run once over E "scenes" that
+        share the geodesic distances, context / query positions and mask features of the cached scene; per episode
+        remain one mask-head launch (its own generated weights over the shared features) and the proposal statistics.
+        The host synchronises ONCE at the end to cut the accepted proposals.
         ``support_embeddings``: [E, C] (or a list of [1, C]); the scene must have gone through
         ``forward(..., remember=False)`` before (``cache_data``).  Returns a list of E ``(scores, proposals)`` pairs
-        identical to what the sequential calls return (``([], [])`` where nothing is accepted)."""
+        as the sequential calls return them (``([], [])`` where nothing is accepted)."""
         cfg = self.cfg
         assert self.cache_data is not None, "requery_many: run forward(..., remember=False) on the scene first"
         (context_locs, context_feats, pre_enc_inds, fg_idxs, batch_offsets, output_feats_, batch_idxs_, locs_float_,
          batch_offsets_, semantic_preds_, semantic_scores, query_locs, mask_features_, geo_dists) = self.cache_data
         if torch.is_tensor(support_embeddings):
-            embs = [support_embeddings[i:i + 1] for i in range(support_embeddings.shape[0])]
+            embs = support_embeddings
         else:
-            embs = list(support_embeddings)
+            embs = torch.cat(list(support_embeddings))
+        n_emb = embs.shape[0]
         if len(fg_idxs) == 0:
-            return [None] * len(embs)
-        pc_dims = [scene_dict["pc_mins"], scene_dict["pc_maxs"]]
+            return [None] * n_emb
+        assert context_locs.shape[0] == 1, "requery_many: one cached scene"
+        nq, nc = cfg.n_query_points, cfg.n_decode_point
         num_points = int(batch_offsets[1] - batch_offsets[0])
         pending = []
-        for e in embs:
-            s = e.unsqueeze(1).repeat(1, cfg.n_decode_point, 1)
-            aggregation = torch.cat([context_feats * s, context_feats - s, context_feats], dim=2)
-            dec_outputs = self.forward_decoder(context_locs, aggregation, query_locs, pc_dims, geo_dists, pre_enc_inds)[-1:]
-            ml = self.get_mask_prediction(geo_dists, dec_outputs, mask_features_, locs_float_, query_locs,
-                                          batch_offsets_)[-1]["mask_logits"][0]
-            sim = self.similarity_net(aggregation[:, :cfg.n_query_points, :].flatten(0, 1)).squeeze(-1)
-            sim = sim.reshape(1, cfg.n_query_points)[0].sigmoid()
-            # generate_proposal (geoformer_fs.py:191-239) up to the point where it needs the host
-            prob = ml.sigmoid()
-            mask_bool = prob >= 0.2
-            npts = torch.sum(mask_bool, dim=1)
-            mask_scores = torch.sum(prob * mask_bool.int(), dim=1) / (npts + 1e-6)
-            scores = mask_scores * torch.pow(sim, 0.5)
-            final = (sim >= cfg.similarity_thresh) & (npts >= cfg.TEST_NPOINT_THRESH) & \
-                (mask_scores >= cfg.TEST_SCORE_THRESH)
-            pending.append((scores, final, mask_bool))
+        for c0 in range(0, n_emb, self.REQUERY_CHUNK):
+            e = embs[c0:c0 + self.REQUERY_CHUNK]
+            E = e.shape[0]
+            s = e.unsqueeze(1)  # [E, 1, C]
+            ctx = context_feats.expand(E, -1, -1)
+            aggregation = torch.cat([ctx * s, ctx - s, ctx], dim=2)  # [E, nc, 3C]
+            pc_dims = [scene_dict["pc_mins"].expand(E, -1), scene_dict["pc_maxs"].expand(E, -1)]
+            dec_outputs = self.forward_decoder(context_locs.expand(E, -1, -1), aggregation, query_locs.expand(E, -1, -1),
+                                               pc_dims, [geo_dists[0]] * E, pre_enc_inds.expand(E, -1))[-1]  # [nq, E, d]
+            pk2 = dec_outputs.transpose(0, 1).flatten(0, 1)  # [E * nq, d] token rows
+            controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2).reshape(E, nq, -1)
+            sim_all = self.similarity_net(aggregation[:, :nq, :].flatten(0, 1)).squeeze(-1).reshape(E, nq).sigmoid()
+            for i in range(E):
+                weights, biases = self.parse_dynamic_params(controllers[i], self.output_dim)
+                ml = self.mask_heads_forward(geo_dists[0], mask_features_, weights, biases, nq, locs_float_,
+                                             query_locs[0], use_geo=True).float().squeeze(0)
+                # generate_proposal (geoformer_fs.py:191-239) up to the point where it needs the host
+                prob = ml.sigmoid()
+                mask_bool = prob >= 0.2
+                npts = torch.sum(mask_bool, dim=1)
+                mask_scores = torch.sum(prob * mask_bool.int(), dim=1) / (npts + 1e-6)
+                sim = sim_all[i]
+                scores = mask_scores * torch.pow(sim, 0.5)
+                final = (sim >= cfg.similarity_thresh) & (npts >= cfg.TEST_NPOINT_THRESH) & \
+                    (mask_scores >= cfg.TEST_SCORE_THRESH)
+                pending.append((scores, final, mask_bool))
         flag = getattr(self, "_knn_flag", None)
         if flag is not None:  # the scene's kNN truncation flag rides in the one synchronisation
             both = torch.cat([torch.stack([p[1] for p in pending]).reshape(-1).int(), flag.reshape(1).int()]).cpu()

@@ -211,6 +211,8 @@ class SyncBatchNorm1d(nn.BatchNorm1d):
     """BatchNorm1d whose training statistics span all ranks (one packed all-reduce per direction); eval mode and the
     state dict are those of nn.BatchNorm1d."""
 
+    sync_across_ranks = True  # (the single-rank fused BatchNorm + ReLU pair of spconv.SparseSequential must not take it)
+
     def forward(self, x):
         if not self.training:
             return super().forward(x)

@@ -642,3 +642,67 @@ def softmax_dim1(x, scale=1.0):
     """softmax(scale * x, dim=1) for a float32 GPU tensor with >= 2 dims, differentiable (streaming HIP kernels)."""
     _f32c(x.detach() if x.is_contiguous() else x.detach().contiguous(), "x")
     return _SoftmaxDim1.apply(x, scale)
+
+
+# ---- training-mode BatchNorm1d + ReLU over voxel rows (csrc/bn_train.hip) -----------------------------------------
+_bn_counters = {}
+
+
+def _bn_counter(dev):
+    """The reduction kernels' arrival counter: one zeroed int32 per (device, stream), zero again after every call."""
+    key = (dev.index, stream_ptr())
+    c = _bn_counters.get(key)
+    if c is None:
+        c = _bn_counters[key] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return c
+
+
+class _BNReLUTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+        lib = _lib.load()
+        M, C = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.gf_bn_train_scratch_floats(M, C), dtype=torch.float32, device=x.device)
+        check(lib.gf_bn_relu_train_fwd(ptr(x), M, C, ptr(weight), ptr(bias), float(eps), float(momentum), int(relu),
+                                       ptr(running_mean), ptr(running_var), ptr(y), stats[0].data_ptr(),
+                                       stats[1].data_ptr(), ptr(scratch), ptr(_bn_counter(x.device)), stream_ptr()),
+              "gf_bn_relu_train_fwd")
+        ctx.save_for_backward(x, y, weight, stats)
+        ctx.relu = int(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight, stats = ctx.saved_tensors
+        lib = _lib.load()
+        M, C = x.shape
+        gy = gy.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_x else None
+        dwb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.gf_bn_train_scratch_floats(M, C), dtype=torch.float32, device=x.device)
+        check(lib.gf_bn_relu_train_bwd(ptr(x), ptr(y), ptr(gy), M, C, ptr(weight), stats[0].data_ptr(),
+                                       stats[1].data_ptr(), ctx.relu, ptr(dx), dwb[0].data_ptr(), dwb[1].data_ptr(),
+                                       ptr(scratch), ptr(_bn_counter(x.device)), stream_ptr()), "gf_bn_relu_train_bwd")
+        return dx, dwb[0], dwb[1], None, None, None, None, None
+
+
+def bn_relu_train_supported(bn, x):
+    """Training-mode BatchNorm1d over fp32 voxel rows [M, C] on the GPU that the fused pair can take."""
+    return (bn.training and not getattr(bn, "sync_across_ranks", False) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 2
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 256 and bn.affine and bn.track_running_stats
+            and bn.momentum is not None)
+
+
+def bn_relu_train(bn, x, relu=True):
+    """relu(bn(x)) for a training-mode nn.BatchNorm1d `bn` over rows x [M, C]: batch statistics, running statistics
+    updated like nn.BatchNorm1d does, two launches forward and two backward (autograd through x, weight, bias)."""
+    _f32c(x, "x")
+    y = _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+    if hasattr(bn, "_flush_counter"):
+        bn._nbt_pending = getattr(bn, "_nbt_pending", 0) + 1  # the lean subclass counts on the host (model/layers.py)
+    elif bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y

@@ -219,6 +219,11 @@ def dev_conv_knobs(split=-1, wide=-1, pair=-1, ldsw=0, block=0, g16=-1, g16_ldsw
     check(_lib.load().gf_dev_conv_knobs_g16(g16, g16_ldsw, g16_gpw, g16_pipe), "gf_dev_conv_knobs_g16")
 
 
+def dev_conv_g16p_wpb(wpb=0):
+    """Dev hook: waves per workgroup of the pipelined level-1 conv kernel (4, 8, 12, 16; 0 = default)."""
+    check(_lib.load().gf_dev_conv_g16p_wpb(wpb), "gf_dev_conv_g16p_wpb")
+
+
 def dev_conv_chunks(n=0):
     """Dev hook: number of equal-cost chunks the next submanifold rulebooks are built with (0 = default)."""
     check(_lib.load().gf_dev_conv_chunks(n), "gf_dev_conv_chunks")

@@ -21,9 +21,13 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
-from .. import sparse
+import os
+
+from .. import pointops, sparse
 from . import modules
 from .modules import SparseModule
+
+_fused_bn = os.environ.get("GF_FUSED_BN", "1") != "0"  # dev knob: the framework's BatchNorm / ReLU kernels instead
 
 __all__ = ["SparseConvTensor", "SparseSequential", "SubMConv3d", "SparseConv3d", "SparseInverseConv3d", "modules"]
 
@@ -96,12 +100,23 @@ class SparseSequential(SparseModule):
         return len(self._modules)
 
     def forward(self, input):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
+            i += 1
             if isinstance(module, SparseModule):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input.features = module(input.features)
+                    # training: BatchNorm1d + ReLU (the pre-activation pair in front of every convolution,
+                    # geoformer_modules.py:15-27) as ONE fused pair of launches per direction (csrc/bn_train.hip)
+                    if (i < len(mods) and isinstance(module, nn.BatchNorm1d) and type(mods[i]) is nn.ReLU
+                            and _fused_bn and pointops.bn_relu_train_supported(module, input.features)):
+                        input.features = pointops.bn_relu_train(module, input.features.contiguous())
+                        i += 1
+                    else:
+                        input.features = module(input.features)
             else:
                 input = module(input)
         return input

@@ -36,6 +36,8 @@ int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe);
 /* Number of equal-cost chunks (= waves of the pipelined kernel) the NEXT rulebooks are built with: a multiple of 4,
  * at most 4096; 0 = default (3072 = 12 waves per compute unit). */
 int gf_dev_conv_chunks(int n);
+/* waves per workgroup of the pipelined level-1 kernel (4, 8, 12, 16; 0 = default). */
+int gf_dev_conv_g16p_wpb(int wpb);
 
 /* Events around the convolution launches of gf_unet_fwd, recorded on the stream the kernels run on (bench.py's
  * roofline probes).  mode 0 = off, 1 = the level-1 3x3x3 16->16 convolutions of the residual blocks, 3 = the same

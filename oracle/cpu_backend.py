@@ -36,9 +36,17 @@ def _gmask(tbl):
     return (present * (1 << np.arange(K, dtype=np.int64))[:, None]).sum(0).astype(np.uint32).view(np.int32)
 
 
-def install():
-    """Patch the operator functions in place; returns a callable that restores them."""
+def install(f64=False):
+    """Patch the operator functions in place; returns a callable that restores them.
+
+    f64: the ARBITER backend of the full-size float comparisons -- the model runs in double precision (`model.double()`,
+    float inputs cast to double): convolutions, voxel means and the gathers carry float64; everything that DECIDES an
+    integer (FPS, ball query, kNN, BFS) is evaluated on the float32 coordinates exactly like the fp32 run, so the two
+    runs see identical point sets and the comparison is about floating-point sums only."""
     from geoformer_amd import pointops, sparse
+
+    fdt = np.float64 if f64 else np.float32
+    f32 = lambda t: np.ascontiguousarray(_np(t), np.float32)  # noqa: E731  (exact: the coordinates started as fp32)
 
     saved = {(mod, n): getattr(mod, n) for mod, names in (
         (sparse, ["build_index", "subm_rules", "down_rules", "conv_fwd", "conv_dgrad", "conv_wgrad"]),
@@ -70,17 +78,17 @@ def install():
         W = _np(weight).reshape(K, Cin, Cout)
         x = _np(feats)
         if in_scale is not None:
-            x = np.maximum(x * _np(in_scale) + _np(in_shift), 0).astype(np.float32)
+            x = np.maximum(x * _np(in_scale) + _np(in_shift), 0).astype(fdt)
         if nbr is None:
             tbl = np.full((1, _r16(M_out)), -1, np.int32)
             tbl[0, :M_out] = np.arange(M_out)
         else:
             tbl = _np(nbr)
-        y = orc.conv_fwd(x, W, tbl, M_out)
+        y = orc.conv_fwd_f64(x, W, tbl, M_out) if f64 else orc.conv_fwd(x, W, tbl, M_out)
         if residual is not None:
             y = y + _np(residual)
         if out_scale is not None:
-            y = np.maximum(y * _np(out_scale) + _np(out_shift), 0).astype(np.float32)
+            y = np.maximum(y * _np(out_scale) + _np(out_shift), 0).astype(fdt)
         return _t(y)
 
     def conv_dgrad(grad_out, weight, bwd, M_in):
@@ -96,7 +104,16 @@ def install():
         return _t(orc.conv_wgrad(_np(feats), _np(grad_out), _np(nbr), K))
 
     def voxelize_fp(feats, rules, mode=4, out=None):
-        r = _t(orc.voxelize_fp(_np(feats), _np(rules), mode == 4))
+        if f64:  # per-voxel mean in double (voxelize.cu:9-22: sum over the voxel's points / count)
+            x, ru = np.asarray(_np(feats), np.float64), _np(rules)
+            cnt = ru[:, 0]
+            acc = np.zeros((ru.shape[0], x.shape[1]), np.float64)
+            for j in range(1, ru.shape[1]):
+                live = cnt >= j
+                acc[live] += x[ru[live, j]]
+            r = _t(acc / np.maximum(cnt, 1)[:, None] if mode == 4 else acc)
+        else:
+            r = _t(orc.voxelize_fp(_np(feats), _np(rules), mode == 4))
         if out is not None:  # the drop-in PG_OP.voxelize_fp writes into the caller's tensor
             out.copy_(r)
             return out
@@ -107,7 +124,7 @@ def install():
         return d_feats
 
     def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False, return_flag=False):
-        p = _np(xyz)
+        p = f32(xyz)
         D2, I = orc.knn(p, p, k)
         D = np.sqrt(D2)
         inr = D <= np.float32(radius)
@@ -116,34 +133,42 @@ def install():
         return res + (torch.zeros(1, dtype=torch.int32),) if return_flag else res
 
     def geodesic_bfs(D, I, deg, src, radius, max_step):
+        # (fp32 sums along the parent chain, as the reference computes them, in both modes: the distances are DATA of the
+        # decoder / mask head; the arbiter run carries the same values as doubles)
         return _t(orc.geodesic(_np(D)[:, 1:], _np(I)[:, 1:].astype(np.int64), _np(src).astype(np.int64), radius,
-                               max_step))
+                               max_step).astype(fdt))
 
     patch = {
         (sparse, "build_index"): build_index, (sparse, "subm_rules"): subm_rules, (sparse, "down_rules"): down_rules,
         (sparse, "conv_fwd"): conv_fwd, (sparse, "conv_dgrad"): conv_dgrad, (sparse, "conv_wgrad"): conv_wgrad,
         (pointops, "voxelize_fp"): voxelize_fp, (pointops, "voxelize_bp"): voxelize_bp,
-        (pointops, "gather_points"): lambda p, i: _t(orc.gather_points(_np(p), _np(i))),
+        (pointops, "gather_points"): (lambda p, i: _t(np.stack([_np(p)[b][:, _np(i)[b]] for b in range(p.shape[0])])))
+        if f64 else (lambda p, i: _t(orc.gather_points(_np(p), _np(i)))),
         (pointops, "gather_points_grad"): lambda g, i, n: _t(orc.gather_points_grad(_np(g), _np(i), n)),
-        (pointops, "group_points"): lambda p, i: _t(orc.group_points(_np(p), _np(i))),
+        (pointops, "group_points"): (lambda p, i: _t(np.stack([_np(p)[b][:, _np(i)[b]] for b in range(p.shape[0])])))
+        if f64 else (lambda p, i: _t(orc.group_points(_np(p), _np(i)))),
         (pointops, "group_points_grad"): lambda g, i, n: _t(orc.group_points_grad(_np(g), _np(i), n)),
-        (pointops, "ball_query"): lambda q, p, r, ns: _t(orc.ball_query(_np(q), _np(p), r, ns)),
-        (pointops, "furthest_point_sampling"): lambda p, m: _t(orc.fps(_np(p), m)),
+        (pointops, "ball_query"): lambda q, p, r, ns: _t(orc.ball_query(f32(q), f32(p), r, ns)),
+        (pointops, "furthest_point_sampling"): lambda p, m: _t(orc.fps(f32(p), m)),
         (pointops, "knn_radius"): knn_radius, (pointops, "geodesic_bfs"): geodesic_bfs,
     }
     for (mod, name), fn in patch.items():
         setattr(mod, name, fn)
+    orig_float = torch.Tensor.float
+    if f64:  # the model's explicit `.float()` casts (the reference has the same ones) mean "the working precision"
+        torch.Tensor.float = lambda self, *a, **k: self.double()
 
     def restore():
         for (mod, name), fn in saved.items():
             setattr(mod, name, fn)
+        torch.Tensor.float = orig_float
 
     return restore
 
 
 @contextlib.contextmanager
-def installed():
-    restore = install()
+def installed(f64=False):
+    restore = install(f64)
     try:
         yield
     finally:

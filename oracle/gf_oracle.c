@@ -283,6 +283,28 @@ ORC_API void orc_conv_fwd(const float *in, const float *W, const int32_t *nbr, i
         }
     }
 }
+/* The same sum in double precision: the ARBITER of the full-size float comparisons (tests/test_gpu_fullsize.py).  Two
+ * fp32 evaluations with different summation orders (this file's sequential fmaf chain, the HIP kernel's MFMA k-blocks)
+ * are each compared with this one instead of with each other. */
+ORC_API void orc_conv_fwd_f64(const double *in, const double *W, const int32_t *nbr, int32_t K, int32_t M_out, int32_t ld,
+                              int32_t Cin, int32_t Cout, double *out) {
+#pragma omp parallel for schedule(static, 256)
+    for (int32_t o = 0; o < M_out; o++) {
+        double *dst = out + (size_t)o * Cout;
+        for (int32_t c = 0; c < Cout; c++) dst[c] = 0.0;
+        for (int32_t k = 0; k < K; k++) {
+            int32_t i = nbr[(size_t)k * ld + o];
+            if (i < 0) continue;
+            const double *src = in + (size_t)i * Cin;
+            const double *w = W + (size_t)k * Cin * Cout;
+            for (int32_t ci = 0; ci < Cin; ci++) {
+                double a = src[ci];
+                const double *wr = w + (size_t)ci * Cout;
+                for (int32_t c = 0; c < Cout; c++) dst[c] += a * wr[c];
+            }
+        }
+    }
+}
 /* backward wrt input: dIn[i,:] += dOut[o,:] @ W[k]^T over all pairs (i = nbr[k][o]). dIn pre-zeroed. */
 ORC_API void orc_conv_dgrad(const float *dout, const float *W, const int32_t *nbr, int32_t K, int32_t M_out,
                             int32_t ld, int32_t Cin, int32_t Cout, float *din) {

@@ -124,6 +124,16 @@ def conv_fwd(feats, W, nbr, M_out):
     return out
 
 
+def conv_fwd_f64(feats, W, nbr, M_out):
+    """conv_fwd in double precision (the arbiter of the full-size float comparisons)."""
+    feats, W, nbr = np.ascontiguousarray(feats, np.float64), np.ascontiguousarray(W, np.float64), _i32(nbr)
+    K, Cin, Cout = W.shape
+    out = np.zeros((M_out, Cout), np.float64)
+    lib().orc_conv_fwd_f64(_p(feats), _p(W), _p(nbr), c_int32(K), c_int32(M_out), c_int32(nbr.shape[1]), c_int32(Cin),
+                           c_int32(Cout), _p(out))
+    return out
+
+
 def conv_dgrad(dout, W, nbr, M_in):
     dout, W, nbr = _f32(dout), _f32(W), _i32(nbr)
     K, Cin, Cout = W.shape

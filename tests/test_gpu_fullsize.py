@@ -422,3 +422,207 @@ def test_conv_probe_events_s150k(hip, s150k):
         else:
             assert all(5.0 < r[10] <= r[9] for r in recs), recs
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[3])
+
+
+# ---- float64 arbiter: GPU fp32 and host fp32 against the same forward in double precision --------------------------
+ARBITER_EPS = 32  # fp32 epsilons (2^-23) of a tensor's largest magnitude; DESIGN.md section 2 states the bound
+
+
+def _arb_close(got, ref64, what, log):
+    got, ref64 = np.asarray(got, np.float64), np.asarray(ref64, np.float64)
+    scale = float(np.abs(ref64).max())
+    err = float(np.abs(got - ref64).max())
+    tol = max(1e-4, ARBITER_EPS * 1.1920929e-07 * scale)
+    log.append((what, err, scale, err / (1.1920929e-07 * max(scale, 1e-30)), tol))
+    return err <= tol
+
+
+def test_forward_s150k_fp32_paths_against_float64_arbiter(hip, oracle, s150k):
+    """North-star parity is "<= 1e-4 abs"; 71 convolutions deep the random-init activations reach |x| ~ 60, where 1e-4
+    is 14 fp32 epsilons and two fp32 evaluations with different summation orders cannot agree to it.  Instead of
+    comparing the two fp32 paths with each other (and calling the difference rounding), BOTH are compared with an
+    arbiter: the same forward of the build's model in double precision (oracle.cpu_backend f64 mode: float64
+    convolutions / voxel means / gathers / torch modules; every integer decision -- FPS, ball query, kNN, BFS -- on the
+    fp32 coordinates as in the fp32 runs).  No backbone re-injection: each run carries its own features end to end.
+    Only the CLASS DECISION (an integer vector) of the GPU run is handed to the two host runs, after checking that
+    their own decisions differ from it on near-ties only.  Bound for every float stage, GPU and host alike:
+    max(1e-4, ARBITER_EPS * 2^-23 * max|arbiter|)."""
+    from bench import build_model, to_device
+    from oracle import cpu_backend
+    from oracle import oracle as orc
+
+    L = orc.lib()
+    L.orc_set_threads.restype = int
+    L.orc_set_threads(64)
+    _, batch, _, _ = s150k
+    dev_batch = to_device(batch, "cuda")
+    m = build_model("cuda", probe_batch=dev_batch)
+    shift = m._bench_bias_shift
+    cap = {}
+
+    def wrap(model, tag):
+        dec = model.forward_decoder
+
+        def dec_w(cl, cf, ql, pc, geo, pei):
+            r = dec(cl, cf, ql, pc, geo, pei)
+            cap[tag] = dict(context_locs=cl.detach().cpu().numpy(), context_feats=cf.detach().cpu().numpy(),
+                            pre_enc_inds=pei.detach().cpu().numpy(), geo=geo[0].detach().cpu().numpy(),
+                            dec=r.detach().cpu().numpy())
+            return r
+
+        model.forward_decoder = dec_w
+
+    wrap(m, "gpu")
+    np.random.seed(11)
+    with torch.no_grad():
+        out = m(dev_batch, 300, training=False)
+    torch.cuda.synchronize()
+    g_sem = out["semantic_scores"].cpu().numpy()
+    g_preds = torch.from_numpy(g_sem).max(1)[1]
+    g_fg = out["fg_idxs"].cpu().numpy()
+    flips = {}
+
+    def host(tag, f64):
+        with cpu_backend.installed(f64=f64), torch.no_grad():
+            mc = build_model("cpu", bias_shift=shift)
+            b = batch
+            if f64:
+                mc.double()
+                b = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+            wrap(mc, tag)
+            fb = mc.forward_backbone
+
+            def fb_w(batch_input, batch_size, want_preds=True):
+                feats, sem, preds = fb(batch_input, batch_size, want_preds=True)
+                own = sem.max(1)[1]
+                diff = torch.nonzero(own != g_preds).view(-1)
+                top2 = torch.sort(sem[diff].double(), dim=1)[0][:, -2:] if diff.numel() else torch.zeros(0, 2)
+                flips[tag] = (int(diff.numel()), float((top2[:, 1] - top2[:, 0]).max()) if diff.numel() else 0.0)
+                return feats, sem, g_preds  # the GPU's class decision (integers); features and scores stay this run's own
+
+            mc.forward_backbone = fb_w
+            np.random.seed(11)
+            o = mc(b, 300, training=False)
+        return mc, o
+
+    mc32, o32 = host("f32", False)
+    mc64, o64 = host("f64", True)
+    for tag in ("f32", "f64"):  # differing class decisions are near-ties
+        assert flips[tag][0] <= 8 and flips[tag][1] < 2e-4, flips
+    # integers: identical in all three runs
+    for o, mc, tag in ((o32, mc32, "f32"), (o64, mc64, "f64")):
+        assert (o["fg_idxs"].numpy() == g_fg).all()
+        assert (m.last_sampling_indices.cpu().numpy() == mc.last_sampling_indices.numpy()).all()
+        assert (cap["gpu"]["pre_enc_inds"] == cap[tag]["pre_enc_inds"]).all()
+        assert (cap["gpu"]["context_locs"] == cap[tag]["context_locs"]).all()
+        assert (cap["gpu"]["geo"] == cap[tag]["geo"]).all()  # reach sets and fp32 sums (carried as doubles in the arbiter)
+    log = []
+    ok = True
+    ref = {"semantic_scores": o64["semantic_scores"].numpy(), "context_feats": cap["f64"]["context_feats"],
+           "dec": cap["f64"]["dec"][-1], "cls_logits": o64["mask_predictions"][-1]["cls_logits"].numpy(),
+           "mask_logits": o64["mask_predictions"][-1]["mask_logits"][0].numpy()}
+    runs = {"gpu": {"semantic_scores": g_sem, "context_feats": cap["gpu"]["context_feats"], "dec": cap["gpu"]["dec"][-1],
+                    "cls_logits": out["mask_predictions"][-1]["cls_logits"].cpu().numpy(),
+                    "mask_logits": out["mask_predictions"][-1]["mask_logits"][0].cpu().numpy()},
+            "host_f32": {"semantic_scores": o32["semantic_scores"].numpy(), "context_feats": cap["f32"]["context_feats"],
+                         "dec": cap["f32"]["dec"][-1], "cls_logits": o32["mask_predictions"][-1]["cls_logits"].numpy(),
+                         "mask_logits": o32["mask_predictions"][-1]["mask_logits"][0].numpy()}}
+    for run, d in runs.items():
+        for k, v in d.items():
+            ok = _arb_close(v, ref[k], f"{run}.{k}", log) and ok
+    print("\narbiter (what, max-abs error vs float64, max|float64|, error in fp32 eps of that magnitude, bound):")
+    for row in log:
+        print("  %-28s %.3e %8.3f %6.1f %.3e" % row)
+    assert ok, log
+    # proposals: the same accepted set, scores to 1e-4
+    pg, p64 = out["proposal_scores"], o64["proposal_scores"]
+    assert len(pg[0]) == len(p64[0]) == len(o32["proposal_scores"][0])
+    if len(pg[0]):
+        assert (pg[0].cpu().numpy() == p64[0].numpy()).all()
+        assert np.abs(pg[1].cpu().numpy() - p64[1].numpy()).max() < 1e-4
+
+
+# ---- BASELINE config 4 at its real size -----------------------------------------------------------------------------
+def test_fs_5shot_episode_full_size_matches_oracle_backend(hip, oracle):
+    """1-way 5-shot as BASELINE.json names it, at scene size: an S150k query scene + five FULL support scenes of
+    100k-140k points (process_support x 5 -> mean embedding -> GeoFormerFS.forward(..., training=False)).  The few-shot
+    model samples ALL foreground points (no 50 000 cap) and 32 support centres: launch shapes the GeoFormer S150k test
+    does not reach.  GPU episode against the same episode through the oracle's operators on the host; the host run is
+    handed the GPU's class decision for the query scene after checking that its own differs on near-ties only."""
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormerFS, load_config
+    from oracle import cpu_backend
+    from oracle import oracle as orc
+    from tests.util import synthetic_state_dict
+
+    L = orc.lib()
+    L.orc_set_threads.restype = int
+    L.orc_set_threads(64)
+
+    def dicts():
+        q = scene.make_batch([scene.make_scene(150_000, 1234)])
+        sups = [scene.make_batch([scene.make_scene(100_000 + 10_000 * i, 70 + i)]) for i in range(5)]
+        for d in [q] + sups:
+            d["batch_offsets"] = d["offsets"]
+        for d in sups:
+            d["support_masks"] = (d["instance_labels"] >= 0).long()
+        return q, sups
+
+    q, sups = dicts()
+
+    def episode(device, preds=None):
+        m = GeoFormerFS(load_config("test_geoformer_fs_scannet.yaml", k_shot=5))
+        m.load_state_dict(synthetic_state_dict(m.state_dict(), 2))
+        with torch.no_grad():
+            m.semantic_linear.bias[3] += 1.0
+        m.to(device)
+        m.eval()
+        mv = lambda d: {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}  # noqa: E731
+        cap, flips = [], {}
+        orig = m.get_mask_prediction
+
+        def gmp(*a, **k):
+            r = orig(*a, **k)
+            cap.append(r[-1]["mask_logits"][0].detach().cpu())
+            return r
+
+        m.get_mask_prediction = gmp
+        np.random.seed(11)
+        with torch.no_grad():
+            embs = [m.process_support(mv(d), training=False) for d in sups]
+            emb = torch.stack(embs).mean(0)
+            fb = m.forward_backbone
+            own = {}
+
+            def fb_w(batch_input, batch_size):
+                feats, sem, p = fb(batch_input, batch_size)
+                own["preds"] = p.detach().cpu()
+                if preds is not None:
+                    diff = torch.nonzero(p.cpu() != preds).view(-1)
+                    top2 = torch.sort(sem[diff].double(), dim=1)[0][:, -2:]
+                    flips["n"], flips["gap"] = int(diff.numel()), float((top2[:, 1] - top2[:, 0]).max()) if diff.numel() else 0.0
+                    p = preds.to(p.device)
+                return feats, sem, p
+
+            m.forward_backbone = fb_w
+            out = m(None, mv(q), training=False, remember=False, support_embeddings=emb)
+        scores, props = out["proposal_scores"]
+        return dict(embs=torch.stack(embs).cpu(), sem=out["semantic_scores"].cpu(), fg=m.cache_data[3].cpu(),
+                    inds=m.cache_data[2].cpu(), ml=cap[0], preds=own["preds"], flips=flips,
+                    scores=scores.cpu() if len(scores) else torch.zeros(0),
+                    npts=props.sum(1).cpu() if len(scores) else torch.zeros(0))
+
+    got = episode("cuda")
+    with cpu_backend.installed():
+        ref = episode("cpu", preds=got["preds"])
+    assert ref["flips"].get("n", 0) <= 8 and ref["flips"].get("gap", 0.0) < 2e-4, ref["flips"]
+    assert (got["embs"] - ref["embs"]).abs().max() < 1e-4  # the five support embeddings
+    assert _close(got["sem"].numpy(), ref["sem"].numpy())
+    assert torch.equal(got["fg"], ref["fg"]) and got["fg"].numel() > 30_000
+    assert torch.equal(got["inds"], ref["inds"])  # FPS over ALL foreground points of the query scene
+    assert got["ml"].shape == ref["ml"].shape
+    assert _close(got["ml"].numpy(), ref["ml"].numpy())
+    assert got["scores"].shape == ref["scores"].shape
+    if len(ref["scores"]):
+        assert (got["scores"] - ref["scores"]).abs().max() < 1e-4
+        assert (got["npts"] - ref["npts"]).abs().max() <= 3

@@ -8,13 +8,13 @@ import pytest
 import torch
 
 
-def _setup(device, full=False):
+def _setup(device, full=False, batch4=False):
     from geoformer_amd import scene
     from geoformer_amd.model import GeoFormer, InstSetCriterion, load_config
     from tests.util import synthetic_state_dict
 
-    if full:  # the train yaml as shipped (nq=128, nc=2048), two room-sized scenes
-        cfg = load_config("geoformer_scannet.yaml", batch_size=2, dec_dropout=0.0, prepare_epochs=1)
+    if full:  # the train yaml as shipped (nq=128, nc=2048), two room-sized scenes (batch4: BASELINE config 3's four)
+        cfg = load_config("geoformer_scannet.yaml", batch_size=4 if batch4 else 2, dec_dropout=0.0, prepare_epochs=1)
     else:
         cfg = load_config("geoformer_scannet.yaml", batch_size=2, dec_dropout=0.0, n_decode_point=128, n_query_points=16,
                           prepare_epochs=1)
@@ -26,7 +26,10 @@ def _setup(device, full=False):
             mod.p = 0.0
     m.to(device)
     m.train()
-    if full:
+    if full and batch4:
+        batch = scene.make_batch([scene.make_scene(n, sd) for n, sd in ((150_000, 50), (120_000, 51), (180_000, 52),
+                                                                        (100_000, 53))])
+    elif full:
         batch = scene.make_batch([scene.make_scene(150_000, 41), scene.make_scene(110_000, 42)])
     else:
         batch = scene.make_batch([scene.make_small_scene(2500, 31), scene.make_small_scene(2000, 32)])
@@ -42,6 +45,34 @@ def _step(m, crit, batch, epoch):
     loss.backward()
     norms = {n: float(p.grad.norm()) for n, p in m.named_parameters() if p.grad is not None}
     return float(loss), info, norms
+
+
+def _grads(m):
+    return {n: p.grad.detach().cpu().double().numpy() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _compare_grads(g_ref, g_got, tol):
+    """Per parameter, element-wise: max-abs error relative to the parameter's own gradient scale, and the cosine between
+    the two gradients -- a sign flip or a permutation inside a module cannot hide behind a norm.  Gradients that are
+    zero by construction (biases in front of a normalisation / soft-max) are rounding noise on both sides: everything
+    is measured against a floor of 1e-5 of the largest parameter gradient."""
+    gmax = max(float(np.linalg.norm(v)) for v in g_ref.values())
+    floor = 1e-5 * gmax
+    bad = []
+    for n, r in g_ref.items():
+        g = g_got.get(n)
+        rn = float(np.linalg.norm(r))
+        if g is None:
+            if rn > floor:
+                bad.append((n, "missing", rn))
+            continue
+        scale = max(float(np.abs(r).max()), rn / np.sqrt(r.size), floor)
+        err = float(np.abs(g - r).max()) / scale
+        cos = float((g * r).sum()) / max(float(np.linalg.norm(g)) * rn, 1e-300)
+        if err > tol or (rn > 100 * floor and cos < 1 - tol):
+            bad.append((n, err, cos))
+    extra = [n for n in g_got if n not in g_ref and float(np.linalg.norm(g_got[n])) > floor]
+    assert not bad and not extra, (bad[:8], extra[:8])
 
 
 def _summ(norms):
@@ -78,12 +109,14 @@ def test_training_step_gpu_matches_oracle_backend(hip, oracle):
     with cpu_backend.installed():
         cfg, m, crit, batch = _setup("cpu")
         loss_c, _, n_c = _step(m, crit, batch, 5)
+        g_c = _grads(m)
     cfg, mg, critg, batchg = _setup("cuda")
     loss_g, _, n_g = _step(mg, critg, batchg, 5)
     assert abs(loss_g - loss_c) < 1e-3 * max(1.0, abs(loss_c))
     gc, gg = _summ(n_c), _summ(n_g)
     for k in gc:
         assert abs(gg[k] - gc[k]) <= 2e-3 * max(gc[k], 1e-3), (k, gc[k], gg[k])
+    _compare_grads(g_c, _grads(mg), 2e-3)  # every parameter, element by element
     torch.optim.Adam(mg.parameters(), lr=1e-3).step()
 
 
@@ -102,6 +135,7 @@ def test_training_step_full_size_gpu_matches_oracle_backend(hip, oracle):
     with cpu_backend.installed():
         cfg, m, crit, batch = _setup("cpu", full=True)
         loss_c, _, n_c = _step(m, crit, batch, 5)
+        g_c = _grads(m)
     del m, batch
     cfg, mg, critg, batchg = _setup("cuda", full=True)
     loss_g, _, n_g = _step(mg, critg, batchg, 5)
@@ -109,6 +143,33 @@ def test_training_step_full_size_gpu_matches_oracle_backend(hip, oracle):
     gc, gg = _summ(n_c), _summ(n_g)
     for k in gc:
         assert abs(gg[k] - gc[k]) <= 2e-3 * max(gc[k], 1e-3), (k, gc[k], gg[k])
+    _compare_grads(g_c, _grads(mg), 5e-3)  # every parameter, element by element
+
+
+@pytest.mark.gpu
+def test_training_step_batch4_550k_gpu_matches_oracle_backend(hip, oracle):
+    """BASELINE config 3 as named: batch 4 (150k + 120k + 180k + 100k = 550k points), the train yaml with
+    batch_size 4: loss, per-module gradient norms and every parameter's gradient element by element against the same
+    step through the oracle's operators on the host."""
+    from oracle import cpu_backend
+    from oracle import oracle as orc
+
+    L = orc.lib()
+    L.orc_set_threads.restype = int
+    L.orc_set_threads(64)
+    with cpu_backend.installed():
+        cfg, m, crit, batch = _setup("cpu", full=True, batch4=True)
+        loss_c, _, n_c = _step(m, crit, batch, 5)
+        g_c = _grads(m)
+    assert int(batch["locs"].shape[0]) > 540_000
+    del m, batch
+    cfg, mg, critg, batchg = _setup("cuda", full=True, batch4=True)
+    loss_g, _, n_g = _step(mg, critg, batchg, 5)
+    assert abs(loss_g - loss_c) < 1e-3 * max(1.0, abs(loss_c)), (loss_g, loss_c)
+    gc, gg = _summ(n_c), _summ(n_g)
+    for k in gc:
+        assert abs(gg[k] - gc[k]) <= 2e-3 * max(gc[k], 1e-3), (k, gc[k], gg[k])
+    _compare_grads(g_c, _grads(mg), 5e-3)
 
 
 def _fs_setup(device):

@@ -10,5 +10,16 @@ rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print('total GPU ms', round(tot/1e6,2))
 for r in rows[:int('${2:-28}')]:
+    pass
+conv=[r for r in rows if 'k_conv_g16p<1, false' in r['Name']]
+if conv:
+    import json
+    calls=sum(int(r['Calls']) for r in conv); tot=sum(float(r['TotalDurationNs']) for r in conv)
+    json.dump({"us_per_launch": round(tot/calls/1e3,3), "calls": calls,
+               "per_kernel": {r['Name'].split('(')[0].replace('void ',''): round(float(r['AverageNs'])/1e3,3) for r in conv},
+               "source": "profiles/<round>_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of bench.py (tools/bench_trace.sh), "
+                         "call-weighted mean of the level-1 16->16 launches of the residual blocks (k_conv_g16p<1, false, *>)"},
+              open('$R/gpurun_out/$tag/rocprof_conv_l1.json','w'), indent=1)
+for r in rows[:int('${2:-28}')]:
     print(f"{r['Name'][:64]:64s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} min {float(r['MinNs'])/1e3:7.2f} total {float(r['TotalDurationNs'])/1e6:7.3f} ms {float(r['Percentage']):5.1f}%")
 PY
