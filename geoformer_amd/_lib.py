@@ -111,8 +111,11 @@ def _declare(lib):
         "gf_decoder_cross_attn_bwd_scratch_floats": (c_size_t, [I, I, I]),
         "gf_decoder_cross_attn_bwd": (I, [P] * 16 + [I, I, I, I] + [P] * 6),
         "gf_bn_train_scratch_floats": (c_size_t, [I, I]),
-        "gf_bn_relu_train_fwd": (I, [P, I, I, P, P, F, F, I, P, P, P, P, P, P, P, P]),
-        "gf_bn_relu_train_bwd": (I, [P, P, P, I, I, P, P, P, I, P, P, P, P, P, P]),
+        "gf_bn_relu_train_fwd": (I, [P, I, I, P, P, F, F, I, P, P, P, P, P, P, P]),
+        "gf_bn_relu_train_bwd": (I, [P, P, P, I, I, P, P, P, I, P, P, P, P, P]),
+        "gf_bn_train_cl_scratch_floats": (c_size_t, [I, I, c_longlong]),
+        "gf_bn_relu_train_cl_fwd": (I, [P, I, I, c_longlong, P, P, F, F, I, P, P, P, P, P, P, P]),
+        "gf_bn_relu_train_cl_bwd": (I, [P, P, P, I, I, c_longlong, P, P, P, I, P, P, P, P, P]),
         "gf_sec_op": (I, [I, P, P, I, I, P, P]),
         "gf_roipool_fp": (I, [P, P, I, I, P, P, P]),
         "gf_roipool_bp": (I, [P, P, I, I, P, P]),

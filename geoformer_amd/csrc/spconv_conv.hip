@@ -1179,9 +1179,9 @@ static void launch_g16p(size_t lds, hipStream_t st, const float* in, const float
                         const float* sh, const float* res, const float* osc, const float* osh, float* out,
                         float* out2) {
 #define G16P_W(W_) launch_g16p_w<NCH, LDSW, W_>(lds, st, in, Wp, steps, gmask, K, M_out, ld, in_bytes, sc, sh, res, osc, osh, out, out2)
-    // (the launch with the residual epilogue gains 10 % from one workgroup per compute unit, 18.9 -> 17.1 us; the one with
-    // the activation epilogue is level, 17.8 / 18.0 us)
-    const int wpb = g_g16p_wpb ? g_g16p_wpb : (res != nullptr && gf_conv_chunks() % 12 == 0 ? 12 : 4);
+    // (S150k level 1, back-to-back launches: residual epilogue 18.4 -> 17.0 us, activation epilogue 17.9 -> 17.4 us)
+    // (the 32 -> 16 launch, NCH = 2, keeps four waves: 55.7 us against 59.9 us with twelve)
+    const int wpb = g_g16p_wpb ? g_g16p_wpb : (NCH == 1 && gf_conv_chunks() % 12 == 0 ? 12 : 4);
     switch (wpb) {
         case 8: G16P_W(8); break;
         case 12: G16P_W(12); break;

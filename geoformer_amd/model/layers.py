@@ -7,16 +7,27 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import pointops
+
+_FUSED_BN = os.environ.get("GF_FUSED_BN", "1") != "0"  # dev knob: the framework's kernels for training-mode BatchNorm
+
 
 def _bn_train(mod, x, dims):
     """Training-mode batch norm written with plain reductions (autograd-differentiable).  MIOpen's training
     BN costs ~1.1 ms of HOST time per call on this stack (87 calls = 97 ms of a 180 ms training forward)."""
+    if _FUSED_BN and isinstance(mod, _HostCounter) and pointops.bn_train_cl_supported(mod, x):
+        # the whole layer as three launches per direction (csrc/bn_train.hip) instead of var_mean + five element-wise
+        # passes forward and a dozen kernels backward
+        y = pointops.bn_train_cl(mod, x)
+        mod._nbt_pending = getattr(mod, "_nbt_pending", 0) + 1  # counted on the host (see BatchNorm1d below)
+        return y
     shape = [1, -1] + [1] * (x.dim() - 2)
     var, mean = torch.var_mean(x, dims, unbiased=False)  # one pass (Welford) instead of two reductions
     if mod.track_running_stats:
@@ -32,7 +43,26 @@ def _bn_train(mod, x, dims):
     return y
 
 
-class BatchNorm1d(nn.BatchNorm1d):
+class _HostCounter:
+    """`num_batches_tracked` counted on the host between state-dict saves (a device launch per layer and step for a
+    counter that only a momentum of None reads)."""
+
+    def _flush_counter(self):
+        n = getattr(self, "_nbt_pending", 0)
+        if n and self.num_batches_tracked is not None:
+            self.num_batches_tracked += n
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self._flush_counter()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
+
+class BatchNorm1d(_HostCounter, nn.BatchNorm1d):
     """nn.BatchNorm1d (same parameters, buffers and eval behaviour) with a lean training forward."""
 
     def forward(self, x):
@@ -50,22 +80,8 @@ class BatchNorm1d(nn.BatchNorm1d):
                                 self.eps)
         return super().forward(x)
 
-    def _flush_counter(self):
-        n = getattr(self, "_nbt_pending", 0)
-        if n and self.num_batches_tracked is not None:
-            self.num_batches_tracked += n
-        self._nbt_pending = 0
 
-    def _save_to_state_dict(self, destination, prefix, keep_vars):
-        self._flush_counter()
-        super()._save_to_state_dict(destination, prefix, keep_vars)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self._nbt_pending = 0
-        super()._load_from_state_dict(*args, **kwargs)
-
-
-class BatchNorm2d(nn.BatchNorm2d):
+class BatchNorm2d(_HostCounter, nn.BatchNorm2d):
     def forward(self, x):
         if self.training and x.numel() > 0:
             return _bn_train(self, x, [0, 2, 3])

@@ -645,18 +645,6 @@ def softmax_dim1(x, scale=1.0):
 
 
 # ---- training-mode BatchNorm1d + ReLU over voxel rows (csrc/bn_train.hip) -----------------------------------------
-_bn_counters = {}
-
-
-def _bn_counter(dev):
-    """The reduction kernels' arrival counter: one zeroed int32 per (device, stream), zero again after every call."""
-    key = (dev.index, stream_ptr())
-    c = _bn_counters.get(key)
-    if c is None:
-        c = _bn_counters[key] = torch.zeros(4, dtype=torch.int32, device=dev)
-    return c
-
-
 class _BNReLUTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
@@ -667,7 +655,7 @@ class _BNReLUTrainFn(torch.autograd.Function):
         scratch = torch.empty(lib.gf_bn_train_scratch_floats(M, C), dtype=torch.float32, device=x.device)
         check(lib.gf_bn_relu_train_fwd(ptr(x), M, C, ptr(weight), ptr(bias), float(eps), float(momentum), int(relu),
                                        ptr(running_mean), ptr(running_var), ptr(y), stats[0].data_ptr(),
-                                       stats[1].data_ptr(), ptr(scratch), ptr(_bn_counter(x.device)), stream_ptr()),
+                                       stats[1].data_ptr(), ptr(scratch), stream_ptr()),
               "gf_bn_relu_train_fwd")
         ctx.save_for_backward(x, y, weight, stats)
         ctx.relu = int(relu)
@@ -685,7 +673,7 @@ class _BNReLUTrainFn(torch.autograd.Function):
         scratch = torch.empty(lib.gf_bn_train_scratch_floats(M, C), dtype=torch.float32, device=x.device)
         check(lib.gf_bn_relu_train_bwd(ptr(x), ptr(y), ptr(gy), M, C, ptr(weight), stats[0].data_ptr(),
                                        stats[1].data_ptr(), ctx.relu, ptr(dx), dwb[0].data_ptr(), dwb[1].data_ptr(),
-                                       ptr(scratch), ptr(_bn_counter(x.device)), stream_ptr()), "gf_bn_relu_train_bwd")
+                                       ptr(scratch), stream_ptr()), "gf_bn_relu_train_bwd")
         return dx, dwb[0], dwb[1], None, None, None, None, None
 
 
@@ -698,7 +686,7 @@ def bn_relu_train_supported(bn, x):
 
 def bn_relu_train(bn, x, relu=True):
     """relu(bn(x)) for a training-mode nn.BatchNorm1d `bn` over rows x [M, C]: batch statistics, running statistics
-    updated like nn.BatchNorm1d does, two launches forward and two backward (autograd through x, weight, bias)."""
+    updated like nn.BatchNorm1d does, three launches forward and three backward (autograd through x, weight, bias)."""
     _f32c(x, "x")
     y = _BNReLUTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
     if hasattr(bn, "_flush_counter"):
@@ -706,3 +694,50 @@ def bn_relu_train(bn, x, relu=True):
     elif bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return y
+
+
+class _BNTrainCLFn(torch.autograd.Function):
+    """Training-mode batch norm over the channel-major layouts [B, C, L] / [B, C, H, W] (csrc/bn_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, relu):
+        lib = _lib.load()
+        B, C = x.shape[0], x.shape[1]
+        L = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.gf_bn_train_cl_scratch_floats(B, C, L), dtype=torch.float32, device=x.device)
+        check(lib.gf_bn_relu_train_cl_fwd(ptr(x), B, C, L, ptr(weight), ptr(bias), float(eps), float(momentum), int(relu),
+                                          ptr(running_mean), ptr(running_var), ptr(y), stats[0].data_ptr(),
+                                          stats[1].data_ptr(), ptr(scratch), stream_ptr()),
+              "gf_bn_relu_train_cl_fwd")
+        ctx.save_for_backward(x, y if relu else None, weight, stats)
+        ctx.relu, ctx.dims = int(relu), (B, C, L)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, weight, stats = ctx.saved_tensors
+        lib = _lib.load()
+        B, C, L = ctx.dims
+        gy = gy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dwb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        scratch = torch.empty(lib.gf_bn_train_cl_scratch_floats(B, C, L), dtype=torch.float32, device=x.device)
+        check(lib.gf_bn_relu_train_cl_bwd(ptr(x), ptr(y), ptr(gy), B, C, L, ptr(weight), stats[0].data_ptr(),
+                                          stats[1].data_ptr(), ctx.relu, ptr(dx), dwb[0].data_ptr(), dwb[1].data_ptr(),
+                                          ptr(scratch), stream_ptr()),
+              "gf_bn_relu_train_cl_bwd")
+        return dx, dwb[0], dwb[1], None, None, None, None, None
+
+
+def bn_train_cl_supported(bn, x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() >= 3 and x.is_contiguous() and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and x.shape[1] <= 256
+            and x.shape[0] * x.shape[1] < 65536 and x.numel() // x.shape[1] >= 2)
+
+
+def bn_train_cl(bn, x, relu=False):
+    """bn(x) (optionally followed by ReLU) for a training-mode BatchNorm over x [B, C, L...]: batch statistics, running
+    statistics updated; three launches forward, three backward."""
+    return _BNTrainCLFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)

@@ -110,7 +110,7 @@ class SparseSequential(SparseModule):
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     # training: BatchNorm1d + ReLU (the pre-activation pair in front of every convolution,
-                    # geoformer_modules.py:15-27) as ONE fused pair of launches per direction (csrc/bn_train.hip)
+                    # geoformer_modules.py:15-27) as three launches per direction (csrc/bn_train.hip)
                     if (i < len(mods) and isinstance(module, nn.BatchNorm1d) and type(mods[i]) is nn.ReLU
                             and _fused_bn and pointops.bn_relu_train_supported(module, input.features)):
                         input.features = pointops.bn_relu_train(module, input.features.contiguous())

@@ -251,20 +251,30 @@ int gf_pair_losses_bwd(const float* mask_logits, const float* inst_masks, const 
 
 /* Training-mode BatchNorm1d (+ ReLU) over voxel rows x[M,C], forward and backward: the pre-activation pair in front of
  * every sparse convolution of the U-Net (geoformer_modules.py:10-35,52-129; BatchNorm1d(eps 1e-4, momentum 0.1),
- * geoformer.py:39), two launches per direction (csrc/bn_train.hip).  C a multiple of 4, M >= 2, pointers 16-byte aligned.
+ * geoformer.py:39), three launches per direction (csrc/bn_train.hip).  C a multiple of 4, M >= 2, pointers 16-byte aligned.
  *   fwd: y = relu((x - mean) * invstd * gamma + beta) with the batch's biased variance; running_mean / running_var
  *        (optional, both or none) updated in place with `momentum` (unbiased variance), save_mean / save_invstd [C]
  *        written for the backward.
  *   bwd: dx (optional) [M,C], dgamma / dbeta (optional) [C] from x, y (the forward's output: ReLU mask), dy.
- * scratch: gf_bn_train_scratch_floats(M, C) floats; counter: ONE int32 that is zero on entry (it is zero again when the
- * call's kernels have run: an arrival counter of the reduction's last workgroup), private to the stream. */
+ * scratch: gf_bn_train_scratch_floats(M, C) floats. */
 size_t gf_bn_train_scratch_floats(int M, int C);
 int gf_bn_relu_train_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
                          int relu, float* running_mean, float* running_var, float* y, float* save_mean,
-                         float* save_invstd, float* scratch, int32_t* counter, void* stream);
+                         float* save_invstd, float* scratch, void* stream);
 int gf_bn_relu_train_bwd(const float* x, const float* y, const float* dy, int M, int C, const float* gamma,
                          const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
-                         float* dbeta, float* scratch, int32_t* counter, void* stream);
+                         float* dbeta, float* scratch, void* stream);
+
+/* The same pair for the channel-major layouts x[B,C,L]: nn.BatchNorm1d over [B,C,L] (semantic head, mask tower:
+ * geoformer.py:55-70, B = 1, L = number of points) and nn.BatchNorm2d over [B,C,H,W] with L = H*W (the set-abstraction
+ * MLP, lib/pointnet2/pytorch_utils.py:9-32).  No alignment requirement on L.  scratch: gf_bn_train_cl_scratch_floats. */
+size_t gf_bn_train_cl_scratch_floats(int B, int C, long long L);
+int gf_bn_relu_train_cl_fwd(const float* x, int B, int C, long long L, const float* gamma, const float* beta, float eps,
+                            float momentum, int relu, float* running_mean, float* running_var, float* y,
+                            float* save_mean, float* save_invstd, float* scratch, void* stream);
+int gf_bn_relu_train_cl_bwd(const float* x, const float* y, const float* dy, int B, int C, long long L,
+                            const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                            float* dgamma, float* dbeta, float* scratch, void* stream);
 
 /* ===================================================================================
  * PG_OP (lib/pointgroup_ops/src/pointgroup_ops_api.cpp:6-23)

