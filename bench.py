@@ -178,13 +178,18 @@ class ConvProbe:
         prof = None
         if os.path.exists(ROCPROF_FILE):
             prof = json.load(open(ROCPROF_FILE))
-            ach_prof = float(np.mean(byt)) / (prof["us_per_launch"] * 1e-6) / 1e9
+            # the trace's average covers every such launch of every scene of the rotation: bytes averaged the same way
+            # (a forward issues seven of these launches, four of them with the residual epilogue)
+            byt_all = float(np.mean([(3 * _conv_bytes(R, M, 27, 16, 16, False) + 4 * _conv_bytes(R, M, 27, 16, 16, True)) / 7.0
+                                     for M, R in self.R.items()]))
+            ach_prof = byt_all / (prof["us_per_launch"] * 1e-6) / 1e9
             ach = min(ach, ach_prof)
         return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4),
                 "frac_by_launch_events": round(ach_events / HBM_PEAK_GBS, 4),
                 "frac_by_rocprof_trace": round(ach_prof / HBM_PEAK_GBS, 4) if prof else None,
                 "rocprof_us_per_launch": prof["us_per_launch"] if prof else None,
+                "rocprof_algorithmic_bytes": int(byt_all) if prof else None,
                 "rocprof_source": prof["source"] if prof else None,
                 "traffic": PMC_TRAFFIC["bytes"],
                 "traffic_source": PMC_TRAFFIC["source"],

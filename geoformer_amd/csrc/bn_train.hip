@@ -25,7 +25,7 @@ namespace {
 
 constexpr int BN_THREADS = 256;
 constexpr int BN_MAX_C = 256;
-constexpr int BN_MAX_WG = 1024;
+constexpr int BN_MAX_WG = 512;
 
 struct BnGeom {
     int c4;    // float4 columns per row
@@ -78,8 +78,19 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ partia
         const int nrg = BN_THREADS / tile;
         const int j = t % tile, rg = t / tile;
         double acc = 0.0;
-        if (rg < nrg)
-            for (int w = rg; w < nwg; w += nrg) acc += (double)partials[(size_t)w * ncol + col0 + j];
+        if (rg < nrg) {
+            // eight partials in flight per trip (one at a time this kernel took 22 us for 1024 partials, longer than the
+            // statistics pass it follows); the order of the additions stays fixed
+            int w = rg;
+            for (; w + 7 * nrg < nwg; w += 8 * nrg) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = partials[(size_t)(w + u * nrg) * ncol + col0 + j];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += (double)v[u];
+            }
+            for (; w < nwg; w += nrg) acc += (double)partials[(size_t)w * ncol + col0 + j];
+        }
         s_tmp[t] = acc;
         __syncthreads();
         if (t < tile) {
@@ -282,7 +293,7 @@ struct BnClGeom {
 };
 inline BnClGeom bncl_geom(int R, long long L) {
     BnClGeom g;
-    long long nchunk = 2048 / (R > 0 ? R : 1);
+    long long nchunk = 1024 / (R > 0 ? R : 1);
     const long long max_by_len = (L + 2047) / 2048;  // at least ~2048 elements per workgroup
     if (nchunk > max_by_len) nchunk = max_by_len;
     if (nchunk > 256) nchunk = 256;
