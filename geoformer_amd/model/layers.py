@@ -116,7 +116,17 @@ class _SplitKLinearFn(torch.autograd.Function):
             if main < rows:
                 gw = gw + g2[main:].t() @ x2[main:]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
+            rows = g2.shape[0]
+            if rows >= (1 << 14) and g2.is_contiguous():
+                # a column sum over ~10^5 rows of a 13-wide matrix is ONE slow reduction launch (0.69 ms for the
+                # semantic head's [550k, 13]): per-chunk sums first (parallel over chunks x columns), then the chunks
+                chunks = 256
+                per = rows // chunks
+                gb = g2[:chunks * per].view(chunks, per, -1).sum(1).sum(0)
+                if chunks * per < rows:
+                    gb = gb + g2[chunks * per:].sum(0)
+            else:
+                gb = g2.sum(0)
         return gx, gw, gb
 
 
@@ -124,7 +134,7 @@ class BigLinear(nn.Linear):
     """nn.Linear (same parameters / state-dict entries) for inputs with ~10^6 rows: split-K weight gradient."""
 
     def forward(self, x):
-        if x.is_cuda and torch.is_grad_enabled() and x.numel() // max(x.shape[-1], 1) >= (1 << 16):
+        if x.is_cuda and torch.is_grad_enabled() and x.numel() // max(x.shape[-1], 1) >= (1 << 12):  # (8192 context tokens: 70 -> ~15 us)
             return _SplitKLinearFn.apply(x, self.weight, self.bias)
         return super().forward(x)
 
@@ -474,7 +484,9 @@ class TransformerDecoderLayer(nn.Module):
             # training: the same kernel forward (keeping only the soft-max statistics) and a fused recompute-based
             # backward for the hoisted projections and the pair weights (csrc/decoder_attn.hip)
             Q1 = w1(tgt2.clone()).permute(1, 0, 2)  # (a copy: the layer's in-place dropout2 overwrites tgt2 later)
-            K1 = F.linear(memory, w1.weight).permute(1, 0, 2)
+            # (split-K weight gradient: the library runs dW = gy^T memory, a [64, nc*B] x [nc*B, 64] product, on a
+            # handful of workgroups -- 70 us per layer for 67 MFLOP)
+            K1 = _SplitKLinearFn.apply(memory, w1.weight, None).permute(1, 0, 2)
             Kv = wv(memory).permute(1, 0, 2)
             out = pointops.decoder_cross_attn_train(rp.geo_ctx, rp.max_geo, rp.query_locs, rp.context_locs, rp.lo, rp.hi,
                                                     rp.gauss_B, Q1, K1, Kv, w1.weight, w2.weight, wv.weight)
