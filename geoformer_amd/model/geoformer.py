@@ -384,6 +384,32 @@ class GeoFormer(nn.Module):
             x.indice_dict[f"spconv{l + 1}"] = r
             cur = r.out_coords
 
+    def _mask_tower_rows(self, feats):
+        """Training on the GPU: the mask tower (Conv1d(k=1) + BatchNorm1d + ReLU three times + Conv1d, geoformer.py:64-70)
+        evaluated on the point ROWS [N_fg, 16] -- the k=1 convolutions are row GEMMs with the same weights, the
+        BatchNorm + ReLU pairs the row-major training kernels (csrc/bn_train.hip) -- instead of on the [1, 16, N_fg]
+        layout of the module tree, which costs two transposes of the whole tensor per direction and the channel-major
+        BatchNorm form.  Same parameters, same running statistics, autograd through every op.  None: not applicable."""
+        if not (feats.is_cuda and torch.is_grad_enabled() and feats.dim() == 2 and feats.dtype == torch.float32
+                and os.environ.get("GF_FUSED_BN", "1") != "0"):
+            return None
+        mods = list(self.mask_tower)
+        x = feats.contiguous()
+        for mod in mods[:-1]:
+            conv, bn, act = mod[0], mod[1], mod[2]
+            if not (isinstance(conv, nn.Conv1d) and conv.kernel_size == (1,) and conv.bias is None
+                    and isinstance(act, nn.ReLU) and pointops.bn_relu_train_supported(bn, x)):
+                return None
+            from .layers import _SplitKLinearFn
+
+            x = pointops.bn_relu_train(bn, _SplitKLinearFn.apply(x, conv.weight[:, :, 0], None))
+        last = mods[-1]
+        if not (isinstance(last, nn.Conv1d) and last.kernel_size == (1,)):
+            return None
+        from .layers import _SplitKLinearFn
+
+        return _SplitKLinearFn.apply(x, last.weight[:, :, 0], last.bias).unsqueeze(2)  # [N_fg, output_dim, 1]
+
     # -- set aggregation ------------------------------------------------------------------------
     def forward_aggregator(self, locs_float_, output_feats_, batch_offsets_, batch_size):
         ctx = self._grad_ctx("set_aggregator")
@@ -504,6 +530,9 @@ class GeoFormer(nn.Module):
                 src = first[0, :nq].contiguous()
                 first_ready = torch.cuda.Event()
                 first_ready.record(sb)
+                # the rest of the sampling is the stretch's long pole: queued right behind the first picks, before the
+                # host spends ~60 us on everything below (the stream idled that long between the two launches)
+                idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
             if early is not None and b == 0:
                 # work of the caller that does not depend on the sampling (early() -> (.., .., kNN graphs)): queued on
                 # the third stream now that the first sampling launch is out
@@ -529,10 +558,8 @@ class GeoFormer(nn.Module):
                     grid_done = torch.cuda.Event()
                     grid_done.record(aux)
                 grid = (grid, grid_done)
-            if multi:
-                side_b.wait_event(first_ready)
-            else:
-                side.wait_stream(main)
+            # (the BFS waits for the query picks only -- not for the rest of the sampling queued behind them)
+            side_b.wait_event(first_ready)
             with torch.cuda.stream(side_b):
                 D, I, deg = graphs[b][:3]
                 g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0])) if split else 1024)
@@ -542,9 +569,6 @@ class GeoFormer(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record(side_b)
                 geo_ready[b] = ev
-            # the rest of the sampling is on the critical path: issue it before anything else
-            with torch.cuda.stream(sb):
-                idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
             if multi:
                 for t in (xyz_b, idx, first, sampling_indices):
                     if t is not None:
@@ -931,7 +955,9 @@ class GeoFormer(nn.Module):
             if chain is not None:
                 mf = pointops.pointwise_mlp(output_feats_.contiguous(), chain).unsqueeze(2)
             else:
-                mf = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
+                mf = self._mask_tower_rows(output_feats_)
+                if mf is None:
+                    mf = self.mask_tower(output_feats_.unsqueeze(2).permute(2, 1, 0)).permute(2, 1, 0)
             sp = None
             if not training:
                 sp = F.softmax(semantic_scores_, dim=1)

@@ -70,6 +70,10 @@ class BatchNorm1d(_HostCounter, nn.BatchNorm1d):
         # 59.6 vs 73.5 ms for the backbone-only training step); the [B,C,L] ones go the lean way
         if self.training and x.dim() == 3 and x.numel() > 0:
             return _bn_train(self, x, [0, 2])
+        if self.training and x.dim() == 2 and _FUSED_BN and pointops.bn_relu_train_supported(self, x):
+            # rows [N, C] outside the sparse backbone (the semantic head over all points): the same kernels without the
+            # ReLU (the next module applies it)
+            return pointops.bn_relu_train(self, x.contiguous(), relu=False)
         if (self.training and x.is_cuda and x.dim() == 2 and x.shape[0] > 1 and self.track_running_stats
                 and self.momentum is not None):
             # the same library kernels without nn.BatchNorm1d's `num_batches_tracked += 1` on the device (a launch
