@@ -376,13 +376,16 @@ def secondary_train_step_b4(dev, steps=5):
                mk(((140_000, 54), (160_000, 55), (110_000, 56), (130_000, 57)))]
     out = {}
     for tag, epoch in (("full_step", 200), ("prepare_epochs_step", 1)):
-        args = train_dp.default_args(steps=steps, warmup=2, batch_size=4, epoch=epoch, prepare_epochs=120)
+        args = train_dp.default_args(steps=steps, warmup=2, batch_size=4, epoch=epoch, prepare_epochs=120, fg_frac=0.4)
         r = train_dp.run(args, dev, batches=batches)
         out[tag] = {"ms_per_step": r["ms_per_step"], "scenes_per_s": r["value"], "steps": steps, "epoch": epoch,
-                    "prepare_epochs": 120, "points_per_batch": r["points_per_batch"], "last_loss": r["last_loss"]}
+                    "prepare_epochs": 120, "points_per_batch": r["points_per_batch"], "last_loss": r["last_loss"],
+                    "n_fg_per_step": r["n_fg_per_step"], "fg_frac_target": 0.4}
         torch.cuda.empty_cache()
     out["config"] = ("config/geoformer_scannet.yaml with batch_size 4, dec_dropout 0; forward + InstSetCriterion + backward + "
-                     "fused Adam; full_step = epoch > prepare_epochs (all heads), prepare_epochs_step = backbone + semantic")
+                     "fused Adam; full_step = epoch > prepare_epochs (all heads), prepare_epochs_step = backbone + semantic; "
+                     "random-init weights with the background logits shifted so that ~40 % of the points are predicted "
+                     "foreground like a real scene (as the eval model; n_fg_per_step is what the steps actually saw)")
     return out
 
 
@@ -699,7 +702,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import train_dp
 
-        dp = train_dp.run(train_dp.default_args(steps=5, warmup=2, batch_size=4, epoch=200, prepare_epochs=120), dev)
+        dp = train_dp.run(train_dp.default_args(steps=5, warmup=2, batch_size=4, epoch=200, prepare_epochs=120, fg_frac=0.4), dev)
         torch.cuda.empty_cache()
     if rank == 0:
         n_fg = int(out["fg_idxs"].shape[0])

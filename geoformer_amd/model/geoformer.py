@@ -1010,6 +1010,7 @@ class GeoFormer(nn.Module):
             outputs["fg_idxs"] = fg_idxs[idxs_sub]
             outputs["num_insts"] = cfg.n_query_points * batch_size
             outputs["batch_idxs"] = batch_idxs_sub
+            outputs["n_fg_total"] = int(offs_[-1])  # (host integer: the forward read the scenes' offsets back already)
             trunc = knn_truncated(graphs)
             if trunc is not None:  # read by the criterion together with its own end-of-step values
                 outputs["knn_truncated"] = trunc

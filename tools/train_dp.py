@@ -54,6 +54,21 @@ def build(args, device):
     return cfg, m, InstSetCriterion(cfg)
 
 
+def calibrate_foreground(m, batch, frac):
+    """Random-init weights make the predicted-foreground share of a synthetic scene arbitrary (80-90 % with this seed);
+    real ScanNet scenes have ~40 %.  Like bench.py's eval model, the background logits are shifted so
+    that `frac` of the batch's points are predicted foreground -- from one no-grad forward of the model as it stands
+    (training-mode BatchNorm: batch statistics).  Returns the shift (identical on every rank: same weights, rank 0's
+    batch decides when the caller broadcasts it)."""
+    with torch.no_grad():
+        s = m(batch, 0)["semantic_scores"]
+        margin = s[:, 4:].max(1)[0] - s[:, :4].max(1)[0]
+        k = max(1, min(margin.numel(), int(round((1.0 - frac) * margin.numel()))))
+        shift = float(torch.kthvalue(margin.float().flatten(), k)[0])
+        m.semantic_linear.bias[:4] += shift
+    return shift
+
+
 def make_batches(args, rank, device, n):
     from geoformer_amd import scene
 
@@ -81,6 +96,8 @@ def step(m, crit, red, opt, batch, epoch, np_seed):
             opt.step()  # the other ranks' averaged gradients (none when every rank skipped): parameters stay in step
         return float("nan"), {}
     loss, info = crit(out, batch, epoch)
+    if "n_fg_total" in out:
+        info = dict(info, n_fg=out["n_fg_total"])
     loss.backward()  # buckets leave from the gradient hooks while this runs
     red.finish()
     if opt is not None:
@@ -105,6 +122,15 @@ def run(args, device, batches=None):
     nb = 2
     if batches is None:
         batches = make_batches(args, rank, device, nb)
+    fg_shift = None
+    if getattr(args, "fg_frac", None):
+        fg_shift = calibrate_foreground(m, batches[0], args.fg_frac)
+        if world > 1:  # every rank carries rank 0's value: the replicas must stay identical
+            t = torch.tensor([fg_shift], dtype=torch.float64, device=device if device.type == "cuda" else "cpu")
+            dist.broadcast(t, 0)
+            with torch.no_grad():
+                m.semantic_linear.bias[:4] += float(t.item()) - fg_shift
+            fg_shift = float(t.item())
     sync = (lambda: torch.cuda.synchronize()) if device.type == "cuda" else (lambda: None)
     for i in range(args.warmup):
         step(m, crit, red, opt, batches[i % len(batches)], args.epoch, 100 * rank + i)
@@ -115,9 +141,12 @@ def run(args, device, batches=None):
     t0 = time.perf_counter()
     early = 0
     loss = float("nan")
+    n_fg = []
     for i in range(args.steps):
-        loss, _ = step(m, crit, red, opt, batches[i % len(batches)], args.epoch, 100 * rank + args.warmup + i)
+        loss, info = step(m, crit, red, opt, batches[i % len(batches)], args.epoch, 100 * rank + args.warmup + i)
         early += red.launched_in_backward
+        if "n_fg" in info:
+            n_fg.append(info["n_fg"])
     sync()
     if world > 1:
         dist.barrier()
@@ -131,7 +160,8 @@ def run(args, device, batches=None):
             "epoch": args.epoch, "prepare_epochs": int(m.prepare_epochs), "sync_bn": bool(args.sync_bn),
             "grad_floats": red.numel(), "buckets": len(red.ranges),
             "buckets_started_inside_backward_per_step": round(early / max(args.steps, 1), 2),
-            "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}
+            "fg_frac_target": getattr(args, "fg_frac", None), "fg_bias_shift": fg_shift,
+            "n_fg_per_step": n_fg, "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}
 
 
 def default_args(**over):
@@ -151,6 +181,8 @@ def parser():
     ap.add_argument("--bucket-mb", type=float, default=8.0)
     ap.add_argument("--sync-bn", action="store_true")
     ap.add_argument("--bn-eval", action="store_true")
+    ap.add_argument("--fg-frac", type=float, default=None,
+                    help="shift the background logits so that this share of the first batch's points is predicted foreground")
     ap.add_argument("--small", action="store_true", help="small scenes / heads (host-side test runs)")
     return ap
 
