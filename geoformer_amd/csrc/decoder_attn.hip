@@ -543,12 +543,30 @@ __global__ __launch_bounds__(256, 1) void k_decoder_cross_attn_bwd(
 }
 
 // out[i] = sum over `parts` of in[part * n + i]
+// (n is a multiple of 4 for both callers: 3 * 64 * 64 weight words, B * nq * 64 query words.)  A thread owns four
+// consecutive words and keeps eight parts in flight; the additions stay in part order (deterministic).  One load per
+// trip took 134 us for the 1024 x 12288 weight partials of a training batch.
 __global__ void k_sum_parts(const float* __restrict__ in, int parts, size_t n, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < parts; p++) s += in[(size_t)p * n + i];
-    out[i] = s;
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = n >> 2;
+    if (i4 >= n4) return;
+    const float4* in4 = reinterpret_cast<const float4*>(in);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = 0;
+    for (; p + 8 <= parts; p += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = in4[(size_t)(p + u) * n4 + i4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+        }
+    }
+    for (; p < parts; p++) {
+        const float4 v = in4[(size_t)p * n4 + i4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i4] = s;
 }
 
 static void dab_plan(int B, int nq, int nc, int* qsplit, int* waves) {
@@ -591,8 +609,8 @@ extern "C" int gf_decoder_cross_attn_bwd(const float* geo_ctx, const float* max_
                        reinterpret_cast<const float4*>(w2t), out, stat_m, stat_l, gout, B, nq, nc, qs, dQ1p, dK1, dKv,
                        dWp);
     const size_t nW = (size_t)3 * DA_D * DA_D, nQ = (size_t)B * nq * DA_D;
-    hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nW, 256)), dim3(256), 0, st, dWp, waves, nW, dW);
-    hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nQ, 256)), dim3(256), 0, st, dQ1p, ntiles, nQ, dQ1);
+    hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nW / 4, 64)), dim3(64), 0, st, dWp, waves, nW, dW);
+    hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nQ / 4, 64)), dim3(64), 0, st, dQ1p, ntiles, nQ, dQ1);
     GF_CHECK_LAUNCH("gf_decoder_cross_attn_bwd");
     return GF_OK;
 }
