@@ -327,3 +327,37 @@ def test_bench_self_launch_prints_one_line_with_n_gpus():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3
+
+
+# ---- tools/train_dp.run(): the loop bench.py times as secondary.train_step_b4 / train_dp_step -------------------------
+def _run_worker(rank, world, port, ret):
+    _init(rank, world, port)
+    import sys
+
+    from oracle import cpu_backend
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_dp
+
+    torch.set_num_threads(2)
+    with cpu_backend.installed():
+        args = train_dp.default_args(steps=2, warmup=0, batch_size=1, points=2200, small=True, prepare_epochs=1, epoch=5,
+                                     fg_frac=0.4, bucket_mb=2.0)
+        res = train_dp.run(args, torch.device("cpu"))
+    ret[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_dp_run_two_ranks(oracle):
+    """The harness loop itself over gloo (the model on the host through the oracle's operators): foreground calibration
+    broadcast from rank 0, two steps with the bucketed reducer, slowest-rank timing, the result dict bench.py prints."""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run_worker, args=(world, port, ret), nprocs=world, join=True)
+    r0, r1 = ret[0], ret[1]
+    assert r0["n_gpus"] == 2 and r0["global_batch"] == 2 and r0["steps"] == 2
+    assert r0["fg_bias_shift"] == r1["fg_bias_shift"] and r0["ms_per_step"] == r1["ms_per_step"]
+    assert np.isfinite(r0["last_loss"]) and np.isfinite(r1["last_loss"]) and r0["backend"] == "gloo"
+    assert len(r0["n_fg_per_step"]) == 2 and all(0 < n < 2200 for n in r0["n_fg_per_step"])
