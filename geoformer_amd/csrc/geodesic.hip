@@ -19,6 +19,17 @@
 // are fp32 sums along that parent chain, so results are bit-identical to the reference's.
 #include <cstdlib>
 #include "common.h"
+
+// Scope of the atomics on a query's key row.  Every access to the row of query q -- the bids' atomic minima, the
+// commit's loads -- comes from the ONE workgroup that owns q, so WORKGROUP scope is what the algorithm needs (the
+// commit's loads become sc0 instead of sc1 loads; the read-modify-writes are the same instruction at either scope).
+// Measured (profiles/r3_pmc_bfs.md): no difference in time or traffic -- a 256-query launch moves 2.4 GB of fetches +
+// 1.4 GB of writes through the fabric (TCC hit rate 12 %) against ~0.24 GB of algorithmic traffic, at either scope: it is
+// the ~76 M scattered 8-byte minima themselves (~5 bids per reached vertex, each a 32-byte sector each way), which the
+// XCD's L2 does not hold on to (32 queries x 480 KB of keys per XCD against 4 MB).
+#ifndef BFS_KEY_SCOPE
+#define BFS_KEY_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 #include <type_traits>
 
 // ------------------------------------------------------------------------------------
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
                 for (int j = 0; j < 16; j++) {
                     if (gv[j] < 0.0f) {
                         const unsigned cand = (((unsigned)u << 6) | (unsigned)(r0 + j)) + 1u;
-                        const unsigned old = atomicMin(&key[v[j]], cand);
+                        const unsigned old = __hip_atomic_fetch_min(&key[v[j]], cand, __ATOMIC_RELAXED, BFS_KEY_SCOPE);
                         if (old == 0xffffffffu) {
                             const int pos = atomicAdd(&s_cnt, 1);
                             nxt[pos].x = v[j];
@@ -501,7 +512,7 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
         if (tid == 0) s_cnt = 0;
         for (int t = tid; t < nn; t += BFS_THREADS) {
             const int v = nxt[t].x;
-            const unsigned kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1u;
+            const unsigned kk = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, BFS_KEY_SCOPE) - 1u;
             const int u = (int)(kk >> 6), r = (int)(kk & 63u);
             const int dv = deg ? deg[v] : K - 1;
             g[v] = D[(size_t)u * K + r] + g[u];
@@ -604,7 +615,8 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                 if ((tid >> 4) == 0) tr[9]++;
 #endif
                 const unsigned cand = (((unsigned)u << 6) | (unsigned)r) + 1u;
-                atomicMin(&key[v], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(d + gu));
+                __hip_atomic_fetch_min(&key[v], ((unsigned long long)cand << 32) | (unsigned)__float_as_int(d + gu),
+                                       __ATOMIC_RELAXED, BFS_KEY_SCOPE);
                 const unsigned old = atomicOr(&touched[v >> 5], bit);
                 if (!(old & bit)) {
                     const int pos = atomicAdd(cnt, 1);
@@ -681,7 +693,8 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
 #endif
                 w[k] = 1u;
                 if (bids) {
-                    atomicMin(&key[v[k]], ((unsigned long long)cand[k] << 32) | (unsigned)__float_as_int(d[k]));
+                    __hip_atomic_fetch_min(&key[v[k]], ((unsigned long long)cand[k] << 32) | (unsigned)__float_as_int(d[k]),
+                                           __ATOMIC_RELAXED, BFS_KEY_SCOPE);
                     w[k] = atomicOr(&touched[v[k] >> 5], bit) & bit;
                 }
             }
@@ -770,8 +783,7 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                 v[k] = nl[tc < qcap ? tc : 0].x;
                 if constexpr (decltype(spill)::value)
                     if (tc >= qcap) v[k] = ng[tc - qcap].x;
-                kk[k] = __hip_atomic_load(reinterpret_cast<const unsigned*>(&key[v[k]]), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
+                kk[k] = __hip_atomic_load(reinterpret_cast<const unsigned*>(&key[v[k]]), __ATOMIC_RELAXED, BFS_KEY_SCOPE);
             }
             if constexpr (decltype(pf)::value) {
 #pragma unroll
