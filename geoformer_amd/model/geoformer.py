@@ -359,7 +359,7 @@ class GeoFormer(nn.Module):
             chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], vox)
             if chain is not None:
                 return (vox, p2v), pointops.pointwise_mlp(vox, chain, rows=p2v), None
-        output_feats = x.features[p2v.long()].contiguous()
+        output_feats = pointops.points_from_voxels(x.features, p2v, batch_input.get("v2p_map")).contiguous()
         chain = self._pointwise_chain("semantic", [self.semantic, self.semantic_linear], output_feats)
         if chain is not None:
             semantic_scores = pointops.pointwise_mlp(output_feats, chain)
@@ -588,7 +588,7 @@ class GeoFormer(nn.Module):
             for b, st in enumerate(staged):
                 feat_b = output_feats_[offs[b]:offs[b + 1]]
                 if st[4] is not None:
-                    feat_b = feat_b[st[4]]
+                    feat_b = pointops.take_rows_unique(feat_b, st[4])  # (a draw without replacement)
                 st[1] = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
         staged = [tuple(st[:4]) for st in staged]
         self.__dict__.setdefault("_gf_pending_side", {})[_stream_key(locs_float_.device)] = geo_ready
@@ -939,7 +939,7 @@ class GeoFormer(nn.Module):
         if not fused_fg:
             batch_idxs_ = batch_idxs[fg_idxs]
             locs_float_ = locs_float[fg_idxs]
-            output_feats_ = output_feats[fg_idxs]
+            output_feats_ = pointops.take_rows_unique(output_feats, fg_idxs)
             semantic_scores_ = semantic_scores[fg_idxs]
         batch_offsets_ = get_batch_offsets(batch_idxs_, batch_size, host_only=fused_fg and not training)
         offs_ = _offsets_list(batch_offsets_)  # the only read-back of this stretch, before the heavy launches
@@ -1014,7 +1014,8 @@ class GeoFormer(nn.Module):
             trunc = knn_truncated(graphs)
             if trunc is not None:  # read by the criterion together with its own end-of-step values
                 outputs["knn_truncated"] = trunc
-            outputs["mask_predictions"] = self.get_mask_prediction(geo_sub, dec_outputs, mask_features_[idxs_sub],
+            outputs["mask_predictions"] = self.get_mask_prediction(geo_sub, dec_outputs,
+                                                                   pointops.take_rows_unique(mask_features_, idxs_sub),
                                                                    locs_float_[idxs_sub], query_locs, offsets_sub)
         else:
             dec_outputs = dec_outputs[-1:, ...]
