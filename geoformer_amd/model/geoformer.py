@@ -393,21 +393,24 @@ class GeoFormer(nn.Module):
         if not (feats.is_cuda and torch.is_grad_enabled() and feats.dim() == 2 and feats.dtype == torch.float32
                 and os.environ.get("GF_FUSED_BN", "1") != "0"):
             return None
-        mods = list(self.mask_tower)
-        x = feats.contiguous()
-        for mod in mods[:-1]:
-            conv, bn, act = mod[0], mod[1], mod[2]
-            if not (isinstance(conv, nn.Conv1d) and conv.kernel_size == (1,) and conv.bias is None
-                    and isinstance(act, nn.ReLU) and pointops.bn_relu_train_supported(bn, x)):
-                return None
-            from .layers import _SplitKLinearFn
-
-            x = pointops.bn_relu_train(bn, _SplitKLinearFn.apply(x, conv.weight[:, :, 0], None))
-        last = mods[-1]
-        if not (isinstance(last, nn.Conv1d) and last.kernel_size == (1,)):
-            return None
         from .layers import _SplitKLinearFn
 
+        mods = list(self.mask_tower)
+        x = feats.contiguous()
+        last = mods[-1]
+        # (the whole structure is checked before anything runs: a stage must not update its running statistics and then
+        # hand the tensor back to the module route)
+        if not (isinstance(last, nn.Conv1d) and last.kernel_size == (1,)):
+            return None
+        for mod in mods[:-1]:
+            if not (isinstance(mod, nn.Sequential) and len(mod) == 3 and isinstance(mod[0], nn.Conv1d)
+                    and mod[0].kernel_size == (1,) and mod[0].bias is None and isinstance(mod[2], nn.ReLU)
+                    and isinstance(mod[1], nn.BatchNorm1d) and mod[1].num_features == mod[0].out_channels
+                    and pointops.bn_relu_train_supported(
+                        mod[1], x if mod[0].out_channels == x.shape[1] else x.new_empty((x.shape[0], mod[0].out_channels)))):
+                return None
+        for mod in mods[:-1]:
+            x = pointops.bn_relu_train(mod[1], _SplitKLinearFn.apply(x, mod[0].weight[:, :, 0], None))
         return _SplitKLinearFn.apply(x, last.weight[:, :, 0], last.bias).unsqueeze(2)  # [N_fg, output_dim, 1]
 
     # -- set aggregation ------------------------------------------------------------------------
