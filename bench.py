@@ -32,7 +32,7 @@ The JSON line also carries
                     C operators ("port"; rank 0, N=1 only), with per-stage seconds;
   secondary      -- nq128_train_yaml_eval_forward (config 2's other yaml), train_step_b4 (config 3: batch 4, ~550k
                     points, forward + criterion + backward + Adam, both epoch regimes), fs_1shot / fs_5shot (config 4:
-                    S150k query + k full support scenes) and, for N > 1, train_dp_step (config 5: every rank a batch of 4,
+                    S150k query + k full support scenes), fs_train_episode_b4 (its training-mode episode) and, for N > 1, train_dp_step (config 5: every rank a batch of 4,
                     bucketed RCCL gradient all-reduce; tools/train_dp.py's loop).
 
 `--gpus N` without a torchrun environment launches the N ranks itself (python -m torch.distributed.run ... bench.py,
@@ -423,6 +423,7 @@ def secondary_few_shot(dev, steps=5):
         out[f"fs_{k}shot"] = {"ms_per_episode": round(dt * 1e3, 2), "episodes_per_s": round(1.0 / dt, 2), "steps": steps,
                               "config": f"config/test_geoformer_fs_scannet.yaml, 1-way {k}-shot: {k} full support scenes "
                                         "(130k points) + one S150k query scene"}
+    out.update(secondary_few_shot_train(dev))
     with torch.no_grad():
         emb0 = m.process_support(sups[0], training=False)
         embs = torch.cat([emb0 * (0.5 + 0.1 * i) for i in range(10)])
@@ -431,6 +432,48 @@ def secondary_few_shot(dev, steps=5):
     out["fs_requery_x10"] = {"ms_per_requery": round(dt * 1e2, 3), "steps": steps,
                              "config": "10 cached re-queries of the query scene queued together (requery_many, row f4)"}
     return out
+
+
+def secondary_few_shot_train(dev, steps=4):
+    """The training-mode few-shot episode of config/geoformer_fs_scannet.yaml: a batch of 4 query
+    scenes, one FULL support scene per query, frozen backbone (42 706 trainable parameters), forward +
+    FSInstSetCriterion + backward + Adam."""
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormerFS, load_config
+    from geoformer_amd.model.criterion_fs import FSInstSetCriterion
+    from tests.util import synthetic_state_dict
+
+    cfg = load_config("geoformer_fs_scannet.yaml", batch_size=4, dec_dropout=0.0)
+    m = GeoFormerFS(cfg)
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 4))
+    with torch.no_grad():
+        m.semantic_linear.bias[4:] += 1.0  # train fold == cv fold: foreground = classes >= 4
+    m.to(dev)
+    m.train()
+    crit = FSInstSetCriterion(cfg)
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+    q = scene.make_batch([scene.make_scene(n, 80 + i) for i, n in enumerate((150_000, 120_000, 140_000, 110_000))])
+    sup = scene.make_batch([scene.make_scene(n, 90 + i) for i, n in enumerate((130_000, 100_000, 120_000, 110_000))])
+    for d in (q, sup):
+        d["batch_offsets"] = d["offsets"]
+    sup["support_masks"] = (sup["instance_labels"] >= 0).long()
+    q, sup = to_device(q, dev), to_device(sup, dev)
+
+    def step():
+        np.random.seed(5)
+        o = m(sup, q, training=True)
+        loss, _ = crit(o, q, 5)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    dt = _timed(step, steps)
+    return {"fs_train_episode_b4": {"ms_per_step": round(dt * 1e3, 2), "steps": steps,
+                                    "trainable_parameters": int(sum(p.numel() for p in params)),
+                                    "points": [int(q["locs"].shape[0]), int(sup["locs"].shape[0])],
+                                    "config": "config/geoformer_fs_scannet.yaml with batch_size 4: 4 query scenes + one full support "
+                                              "scene each, backbone frozen (no_grad), forward + FSInstSetCriterion + backward + Adam"}}
 
 
 def _free_port():
