@@ -389,7 +389,7 @@ def secondary_train_step_b4(dev, steps=5):
     return out
 
 
-def secondary_few_shot(dev, steps=5):
+def secondary_few_shot(dev, steps=5, train_leg=True):
     """BASELINE config 4: a 1-way k-shot episode = k full support scenes through process_support, their mean embedding,
     one GeoFormerFS.forward on the S150k query scene (test yaml); k = 1 (the shipped yaml) and 5 (BASELINE.json)."""
     from geoformer_amd import scene
@@ -423,7 +423,8 @@ def secondary_few_shot(dev, steps=5):
         out[f"fs_{k}shot"] = {"ms_per_episode": round(dt * 1e3, 2), "episodes_per_s": round(1.0 / dt, 2), "steps": steps,
                               "config": f"config/test_geoformer_fs_scannet.yaml, 1-way {k}-shot: {k} full support scenes "
                                         "(130k points) + one S150k query scene"}
-    out.update(secondary_few_shot_train(dev))
+    if train_leg:
+        out.update(secondary_few_shot_train(dev))
     with torch.no_grad():
         emb0 = m.process_support(sups[0], training=False)
         embs = torch.cat([emb0 * (0.5 + 0.1 * i) for i in range(10)])

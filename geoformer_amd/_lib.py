@@ -99,6 +99,7 @@ def _declare(lib):
         "gf_fg_scratch_bytes": (c_size_t, [I]),
         "gf_fg_select": (I, [P, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
+        "gf_proposal_stats_fs": (I, [P, P, I, I, F, F, I, F, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),
         "gf_relpos_prepare": (I, [P, P, I, I, I, P, P, P]),
         "gf_proposal_select": (I, [P, P, P, I, P, P, P, P, P]),

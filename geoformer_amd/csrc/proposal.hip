@@ -101,6 +101,60 @@ __global__ __launch_bounds__(PR_THREADS) void k_proposal_stats(const float* __re
     }
 }
 
+// Few-shot variant (GeoFormerFS.generate_proposal, model/geoformer/geoformer_fs.py:205-238): no class head -- the
+// query's cosine similarity to the support prototype takes the class score's place.
+__global__ __launch_bounds__(PR_THREADS) void k_proposal_stats_fs(const float* __restrict__ logits,
+                                                                  const float* __restrict__ sim, int N,
+                                                                  float logit_thresh, float score_thresh,
+                                                                  int npoint_thresh, float sim_thresh,
+                                                                  int* __restrict__ npoints_out,
+                                                                  float* __restrict__ scores_out,
+                                                                  int* __restrict__ final_out) {
+    __shared__ int r_cnt[PR_THREADS / 64];
+    __shared__ float r_prob[PR_THREADS / 64];
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (size_t)q * N;
+    int cnt = 0;
+    float sp = 0.f;
+    for (int p0 = tid; p0 < N; p0 += 4 * PR_THREADS) {
+        float x[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int p = p0 + e * PR_THREADS;
+            x[e] = row[p < N ? p : N - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float pr = pr_sigmoid(x[e]);
+            const bool in = (p0 + e * PR_THREADS) < N && pr >= logit_thresh;
+            cnt += in ? 1 : 0;
+            sp += in ? pr : 0.f;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_xor(cnt, d, 64);
+        sp += __shfl_xor(sp, d, 64);
+    }
+    if (lane == 0) {
+        r_cnt[wave] = cnt;
+        r_prob[wave] = sp;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        float a = 0.f;
+        for (int w = 0; w < PR_THREADS / 64; w++) {
+            n += r_cnt[w];
+            a += r_prob[w];
+        }
+        const float mask_score = a / ((float)n + 1e-6f), s = sim[q];
+        npoints_out[q] = n;
+        scores_out[q] = mask_score * sqrtf(s);  // NaN for a negative similarity, like torch.pow(sim, 0.5); never accepted
+        final_out[q] = (s >= sim_thresh) && (n >= npoint_thresh) && (mask_score >= score_thresh);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_proposal_scatter(const float* __restrict__ logits,
                                                           const int* __restrict__ sel, int N,
                                                           const long long* __restrict__ fg_idxs, float logit_thresh,
@@ -135,6 +189,17 @@ extern "C" int gf_proposal_stats(const float* mask_logits, const float* cls_logi
                        sem_prob, N, ncls, logit_thresh, score_thresh, npoint_thresh, min_class, cls_pred, npoints,
                        scores, final_mask);
     GF_CHECK_LAUNCH("gf_proposal_stats");
+    return GF_OK;
+}
+
+extern "C" int gf_proposal_stats_fs(const float* mask_logits, const float* sim, int nq, int N, float logit_thresh,
+                                    float score_thresh, int npoint_thresh, float sim_thresh, int* npoints,
+                                    float* scores, int* final_mask, void* stream) {
+    GF_CHECK_ARG(nq >= 0 && N >= 0, "gf_proposal_stats_fs: bad sizes nq=%d N=%d", nq, N);
+    if (nq == 0) return GF_OK;
+    hipLaunchKernelGGL(k_proposal_stats_fs, dim3(nq), dim3(PR_THREADS), 0, (hipStream_t)stream, mask_logits, sim, N,
+                       logit_thresh, score_thresh, npoint_thresh, sim_thresh, npoints, scores, final_mask);
+    GF_CHECK_LAUNCH("gf_proposal_stats_fs");
     return GF_OK;
 }
 

@@ -142,6 +142,17 @@ class GeoFormerFS(GeoFormer):
                           score_thresh=0.5, npoint_thresh=100, sim_score_thresh=0.5):
         b = 0
         num_points = int(batch_offsets[b + 1] - batch_offsets[b])
+        if mask_logits[b].is_cuda:
+            # one sweep over the logit rows (gf_proposal_stats_fs), ONE read-back (acceptance flags + the scene's kNN
+            # truncation flag), then the membership rows written by the native scatter straight from the logits
+            ml = mask_logits[b].float().contiguous()
+            _, scores, final = pointops.proposal_stats_fs(ml, similarity_score[b].float().contiguous(), logit_thresh,
+                                                          score_thresh, npoint_thresh, sim_score_thresh)
+            flag = getattr(self, "_knn_flag", None)
+            host = (torch.cat([final, flag.reshape(1).int()]) if flag is not None else final).cpu()
+            if flag is not None:
+                raise_if_knn_truncated(int(host[-1]))
+            return self._cut_proposals(ml, scores, host[:final.shape[0]], fg_idxs, logit_thresh, num_points)
         prob = mask_logits[b].sigmoid()
         sim = similarity_score[b]
         mask_bool = prob >= logit_thresh
@@ -162,6 +173,18 @@ class GeoFormerFS(GeoFormer):
         inst, pts = torch.nonzero(masks_final, as_tuple=True)
         proposals[inst, fg_idxs[pts]] = 1
         return scores[final], proposals
+
+    @staticmethod
+    def _cut_proposals(logits, scores, final_host, fg_idxs, logit_thresh, num_points):
+        """(scores, 0/1 membership rows) of the accepted queries: `final_host` is the acceptance vector ON THE HOST (the
+        caller's one read-back), the rows come from gf_proposal_scatter (sigmoid(logit) >= logit_thresh over the scene's
+        points, geoformer_fs.py:229-238)."""
+        idx = torch.nonzero(final_host).view(-1)
+        if idx.numel() == 0:
+            return [], []
+        sel = idx.to(dtype=torch.int32).to(logits.device, non_blocking=True)
+        proposals = pointops.proposal_scatter(logits, sel, fg_idxs.contiguous(), logit_thresh, num_points)
+        return scores[sel.long()], proposals
 
     # -- batched re-query of a cached scene (SURVEY.md 8f row f4) ---------------------------------
     REQUERY_CHUNK = 16  # episodes per decoder pass (the pair products of a pass are E x 2048 x 64 floats per layer)
@@ -211,6 +234,13 @@ class GeoFormerFS(GeoFormer):
                 ml = self.mask_heads_forward(geo_dists[0], mask_features_, weights, biases, nq, locs_float_,
                                              query_locs[0], use_geo=True).float().squeeze(0)
                 # generate_proposal (geoformer_fs.py:191-239) up to the point where it needs the host
+                if ml.is_cuda:
+                    ml = ml.contiguous()
+                    _, scores, final = pointops.proposal_stats_fs(
+                        ml, sim_all[i].float().contiguous(), 0.2, cfg.TEST_SCORE_THRESH, cfg.TEST_NPOINT_THRESH,
+                        cfg.similarity_thresh)
+                    pending.append((scores, final, ml))
+                    continue
                 prob = ml.sigmoid()
                 mask_bool = prob >= 0.2
                 npts = torch.sum(mask_bool, dim=1)
@@ -229,6 +259,9 @@ class GeoFormerFS(GeoFormer):
             finals = torch.stack([p[1] for p in pending]).cpu()  # the one synchronisation
         out = []
         for (scores, final, mask_bool), f in zip(pending, finals):
+            if scores.is_cuda:  # (mask_bool holds the logits here)
+                out.append(self._cut_proposals(mask_bool, scores, f, fg_idxs, 0.2, num_points))
+                continue
             if not bool(f.any()):
                 out.append(([], []))
                 continue

@@ -460,6 +460,21 @@ def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh
     return ints[0], ints[1], scores, ints[2]
 
 
+def proposal_stats_fs(mask_logits, sim, logit_thresh, score_thresh, npoint_thresh, sim_thresh):
+    """Few-shot proposal statistics (geoformer_fs.py:205-238): (npoints i32[nq], scores f32[nq], final i32[nq]) of
+    the queries' mask-logit rows [nq,N] and their similarities to the support prototype [nq]."""
+    _f32c(mask_logits, "mask_logits"), _f32c(sim, "sim")
+    nq, N = mask_logits.shape
+    if sim.shape != (nq,):
+        raise RuntimeError(f"sim must be [{nq}], got {tuple(sim.shape)}")
+    ints = torch.empty((2, nq), dtype=torch.int32, device=mask_logits.device)
+    scores = torch.empty(nq, dtype=torch.float32, device=mask_logits.device)
+    check(_lib.load().gf_proposal_stats_fs(ptr(mask_logits), ptr(sim), nq, N, float(logit_thresh), float(score_thresh),
+                                           int(npoint_thresh), float(sim_thresh), ptr(ints[0]), ptr(scores),
+                                           ptr(ints[1]), stream_ptr()), "gf_proposal_stats_fs")
+    return ints[0], scores, ints[1]
+
+
 def proposal_select(final, cls_pred, scores):
     """Accepted queries compacted on the device: (sel i32[nq], cls i64[nq], scores f32[nq], count i32[1]); the first
     `count` entries are valid."""

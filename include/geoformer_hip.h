@@ -491,6 +491,14 @@ int gf_proposal_stats(const float* mask_logits, const float* cls_logits, const f
                       int ncls, float logit_thresh, float score_thresh, int npoint_thresh, int min_class,
                       int* cls_pred, int* npoints, float* scores, int* final_mask, void* stream);
 
+/* Few-shot form (GeoFormerFS.generate_proposal, model/geoformer/geoformer_fs.py:205-238): members as above,
+ *   mask_score = sum prob / (npoints + 1e-6), scores[q] = mask_score * sqrt(sim[q]),
+ *   final[q] = sim[q] >= sim_thresh && npoints >= npoint_thresh && mask_score >= score_thresh.
+ *   mask_logits fp32 [nq,N], sim fp32 [nq] (cosine similarity of the query to the support prototype). */
+int gf_proposal_stats_fs(const float* mask_logits, const float* sim, int nq, int N, float logit_thresh,
+                         float score_thresh, int npoint_thresh, float sim_thresh, int* npoints, float* scores,
+                         int* final_mask, void* stream);
+
 /* proposals[i, fg_idxs[p]] = 1 for every member p of query sel[i]; proposals int32 [n_sel,num_points] must be
  * zero-filled by the caller, fg_idxs int64 [N] (row of each foreground point in the scene), sel int32 [n_sel]. */
 int gf_proposal_scatter(const float* mask_logits, const int* sel, int n_sel, int N, const long long* fg_idxs,

@@ -717,6 +717,23 @@ ORC_API void orc_proposal_stats(const float *mask_logits, const float *cls_logit
         final_mask[q] = (arg >= min_class) && (n >= npoint_thresh) && (mask_score >= score_thresh);
     }
 }
+/* few-shot form: GeoFormerFS.generate_proposal (model/geoformer/geoformer_fs.py:205-222), the query's similarity to
+ * the support prototype in the class score's place */
+ORC_API void orc_proposal_stats_fs(const float *mask_logits, const float *sim, int32_t nq, int32_t N, float logit_thresh,
+                                   float score_thresh, int32_t npoint_thresh, float sim_thresh, int32_t *npoints,
+                                   float *scores, int32_t *final_mask) {
+    for (int32_t q = 0; q < nq; q++) {
+        int32_t n = 0; float sp = 0.f;
+        for (int32_t p = 0; p < N; p++) {
+            float pr = 1.0f / (1.0f + expf(-mask_logits[(size_t)q * N + p]));
+            if (pr >= logit_thresh) { n++; sp += pr; }
+        }
+        float mask_score = sp / ((float)n + 1e-6f);
+        npoints[q] = n;
+        scores[q] = mask_score * sqrtf(sim[q]);
+        final_mask[q] = (sim[q] >= sim_thresh) && (n >= npoint_thresh) && (mask_score >= score_thresh);
+    }
+}
 ORC_API void orc_proposal_scatter(const float *mask_logits, const int32_t *sel, int32_t n_sel, int32_t N,
                                   const int64_t *fg_idxs, float logit_thresh, int32_t num_points, int32_t *proposals) {
     for (int32_t i = 0; i < n_sel; i++) for (int32_t p = 0; p < N; p++)

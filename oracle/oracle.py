@@ -325,6 +325,17 @@ def proposal_stats(mask_logits, cls_logits, sem_prob, logit_thresh, score_thresh
     return cls_pred, npts, scores, fin
 
 
+def proposal_stats_fs(mask_logits, sim, logit_thresh, score_thresh, npoint_thresh, sim_thresh):
+    mask_logits, sim = _f32(mask_logits), _f32(sim)
+    nq, N = mask_logits.shape
+    npts, fin = np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+    scores = np.zeros(nq, np.float32)
+    lib().orc_proposal_stats_fs(_p(mask_logits), _p(sim), c_int32(nq), c_int32(N), c_float(logit_thresh),
+                                c_float(score_thresh), c_int32(npoint_thresh), c_float(sim_thresh), _p(npts), _p(scores),
+                                _p(fin))
+    return npts, scores, fin
+
+
 def proposal_scatter(mask_logits, sel, fg_idxs, logit_thresh, num_points):
     mask_logits, sel, fg_idxs = _f32(mask_logits), _i32(sel), _i64(fg_idxs)
     out = np.zeros((sel.shape[0], num_points), np.int32)

@@ -146,6 +146,35 @@ def test_proposal_stats_and_scatter(hip, oracle, nq, N, ncls, npts):
         assert (want.sum(1) == ref[1][sel]).all()
 
 
+@pytest.mark.parametrize("nq,N", [(64, 5000), (256, 333), (3, 1)])
+def test_proposal_stats_few_shot(hip, oracle, nq, N):
+    """Few-shot generate_proposal statistics (geoformer_fs.py:205-222) vs the oracle and vs the reference's torch
+    expressions on the host: counts / acceptance bit-exact, scores <= 1e-4."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(nq * 7 + N)
+    logits = (rng.standard_normal((nq, N)) * 3).astype(np.float32)
+    logits[0] = -5.0  # an empty mask
+    sim = rng.uniform(0.0, 1.0, nq).astype(np.float32)
+    thr = max(1, N // 3)
+    ref = oracle.proposal_stats_fs(logits, sim, 0.2, 0.55, thr, 0.4)
+    got = pointops.proposal_stats_fs(torch.from_numpy(logits).cuda(), torch.from_numpy(sim).cuda(), 0.2, 0.55, thr, 0.4)
+    npoints, scores, final = [g.cpu().numpy() for g in got]
+    assert (npoints == ref[0]).all() and (final == ref[2]).all()
+    assert np.abs(scores - ref[1]).max() < 1e-4
+    assert npoints[0] == 0 and final[0] == 0 and scores[0] == 0
+    # the reference's own expressions
+    prob = torch.from_numpy(logits).sigmoid()
+    mb = prob >= 0.2
+    n_t = mb.sum(1)
+    ms = (prob * mb.int()).sum(1) / (n_t + 1e-6)
+    st = torch.from_numpy(sim)
+    fin_t = (st >= 0.4) & (n_t >= thr) & (ms >= 0.55)
+    assert np.abs(npoints - n_t.numpy()).max() <= 1  # (torch's vectorised sigmoid may differ by an ulp at the threshold)
+    assert np.abs(scores - (ms * st.pow(0.5)).numpy()).max() < 1e-4
+    assert (final != fin_t.numpy().astype(np.int32)).sum() <= 1
+
+
 @pytest.mark.parametrize("nq,nc,B,ff", [(256, 512, 1, 64), (100, 300, 2, 128), (16, 40, 1, 256)])
 def test_decoder_token_stages_fused(hip, nq, nc, B, ff):
     """Whole fused decoder (token stages + cross-attention launches) vs the layer-by-layer PyTorch modules
