@@ -52,6 +52,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import geoformer_amd  # noqa: E402,F401  (before the first HIP call: the package sets the runtime's hardware-queue count)
+
 PROBE_EVERY = 4  # timed steps between two probed ones
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32)

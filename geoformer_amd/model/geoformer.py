@@ -50,13 +50,15 @@ import weakref
 _BFS_WG = int(os.environ.get("GF_BFS_WG", "0"))  # threads per query of the BFS launched beside the sampling (0: by the number of queries)
 
 
-def _bfs_wg(nq):
-    """1024 threads per query (the kernel's fastest layout: 1.06 against 1.25 ms at 512) when the launch's workgroups
-    fit the compute units the sampling kernel leaves free in one round -- the train yaml's 128 queries, the few-shot
-    model's; 512 for the test yaml's 256 queries (two queries can share a unit)."""
+def _bfs_wg(nq, scenes=1):
+    """1024 threads per query (the kernel's fastest layout: 1.06 against 1.25 ms at 512) when the workgroups of the
+    scenes' launches -- they run beside each other on streams of their own -- fit the compute units the sampling
+    kernels leave free in one round: the train yaml's 128 queries on one scene, the few-shot model's; 512 (two queries
+    share a unit) for the test yaml's 256 queries and for a training batch (4 x 128 queries: 56.3 -> 52.9 ms per step;
+    256 threads: 57.1)."""
     if _BFS_WG:
         return _BFS_WG
-    return 1024 if nq <= 224 else 512
+    return 1024 if nq * scenes <= 224 else 512
 _OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
 
 
@@ -565,7 +567,7 @@ class GeoFormer(nn.Module):
             side_b.wait_event(first_ready)
             with torch.cuda.stream(side_b):
                 D, I, deg = graphs[b][:3]
-                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0])) if split else 1024)
+                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), batch_size) if split else 1024)
                 g.record_stream(main)
                 src.record_stream(side_b)
                 geo[b] = g

@@ -25,6 +25,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+import geoformer_amd  # noqa: E402,F401  (before the first HIP call: the package sets the runtime's hardware-queue count)
+
 
 def build(args, device):
     from geoformer_amd import parallel
