@@ -214,6 +214,17 @@ class HungarianMatcher(nn.Module):
         return rows, inst_masks[cols], sem_labels[cols]
 
 
+def semantic_cross_entropy(scores, labels, ignore_label, module):
+    """nn.CrossEntropyLoss(ignore_index) over all points of the batch (criterion.py:120).  On the GPU the mean is taken
+    outside the library's loss: its 'mean' reduction runs on ONE workgroup (0.57 ms forward + 0.52 ms backward over the
+    550k points of a training batch); per-point losses (an element-wise kernel, zeros at ignored points) summed by a
+    parallel reduction and divided by the number of counted points are the same number."""
+    if not scores.is_cuda:
+        return module(scores, labels)
+    per_point = F.cross_entropy(scores, labels, ignore_index=ignore_label, reduction="none")
+    return per_point.sum() / (labels != ignore_label).sum()
+
+
 class InstSetCriterion(nn.Module):
     def __init__(self, cfg=None):
         super().__init__()
@@ -347,7 +358,8 @@ class InstSetCriterion(nn.Module):
         semantic_labels, instance_labels = batch_inputs["labels"], batch_inputs["instance_labels"]
         out = {}
         if "semantic" not in cfg.fix_module:
-            semantic_loss = self.semantic_criterion(semantic_scores, semantic_labels)
+            semantic_loss = semantic_cross_entropy(semantic_scores, semantic_labels, cfg.ignore_label,
+                                                   self.semantic_criterion)
         else:
             semantic_loss = torch.zeros((), device=semantic_scores.device, requires_grad=True)
         loss = semantic_loss

@@ -143,32 +143,46 @@ class BigLinear(nn.Linear):
         return super().forward(x)
 
 
+def _pointwise(w, x):
+    """W x[b] for w [Co,Ci], x [B,Ci,L] as a batched product.  (``torch.matmul`` of a 2-D with a 3-D operand folds the
+    batch into the rows of x^T: a transposing copy of x going in and of y coming out, 80 us each over the set
+    abstraction's 16.7 M group values.)"""
+    return torch.matmul(w.unsqueeze(0), x)
+
+
 class _PointwiseSplitKFn(torch.autograd.Function):
     """y[b] = W x[b] for x [B,Cin,L] with L ~ 10^5: the weight gradient sum_b gy[b] x[b]^T reduces over L into a
     Cout x Cin tile, which the library runs on a single workgroup (0.6 ms at 16x16x240k); chunked into a batched
-    product it is bandwidth-bound."""
+    product it is bandwidth-bound.  The chunks are strided views of gy / x (row stride L, batch stride L/S): the
+    library takes them as they lie, no packed copies."""
 
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return torch.matmul(w, x)
+        return _pointwise(w, x)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.matmul(w.t(), gy)
+            gx = _pointwise(w.t(), gy)
         if ctx.needs_input_grad[1]:
             B, Co, L = gy.shape
+            Ci = x.shape[1]
             S = 128
             Lc = L // S
             main = S * Lc
             gw = torch.zeros_like(w)
             if Lc > 0:
-                a = gy[:, :, :main].reshape(B, Co, S, Lc).permute(0, 2, 1, 3).reshape(B * S, Co, Lc)
-                b = x[:, :, :main].reshape(B, x.shape[1], S, Lc).permute(0, 2, 3, 1).reshape(B * S, Lc, x.shape[1])
-                gw = torch.bmm(a, b).sum(0)
+                if not gy.is_contiguous():
+                    gy = gy.contiguous()
+                parts = gy.new_empty((B, S, Co, Ci))
+                for b in range(B):
+                    a = gy[b, :, :main].view(Co, S, Lc).permute(1, 0, 2)  # [S, Co, Lc], strides (Lc, L, 1)
+                    c = x[b, :, :main].view(Ci, S, Lc).permute(1, 2, 0)  # [S, Lc, Ci], strides (Lc, 1, L)
+                    torch.bmm(a, c, out=parts[b])
+                gw = parts.sum((0, 1))
             if main < L:
                 gw = gw + torch.einsum("bol,bil->oi", gy[:, :, main:], x[:, :, main:])
         return gx, gw
@@ -185,7 +199,7 @@ class PointwiseConv1d(nn.Conv1d):
         if x.is_cuda and torch.is_grad_enabled() and x.dim() == 3 and x.shape[-1] >= (1 << 15):
             y = _PointwiseSplitKFn.apply(x, self.weight[:, :, 0])
         else:
-            y = torch.matmul(self.weight[:, :, 0], x)
+            y = _pointwise(self.weight[:, :, 0], x) if x.dim() == 3 else torch.matmul(self.weight[:, :, 0], x)
         return y if self.bias is None else y + self.bias[:, None]
 
 
@@ -201,7 +215,7 @@ class PointwiseConv2d(nn.Conv2d):
             # 524 288-long reduction on a handful of workgroups, 1.1 ms per layer; chunked it is bandwidth-bound)
             y = _PointwiseSplitKFn.apply(x.reshape(b, c, h * w), self.weight[:, :, 0, 0]).reshape(b, -1, h, w)
         else:
-            y = torch.matmul(self.weight[:, :, 0, 0], x.reshape(b, c, h * w)).reshape(b, -1, h, w)
+            y = _pointwise(self.weight[:, :, 0, 0], x.reshape(b, c, h * w)).reshape(b, -1, h, w)
         return y if self.bias is None else y + self.bias[None, :, None, None]
 
 

@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import pointops
+from . import layers
 from .layers import BatchNorm2d, PointwiseConv2d
 
 
@@ -111,6 +112,18 @@ class _ConvBNReLU2d(nn.Sequential):
         self.add_module("conv", conv)
         self.add_module("bn", _BN2d(cout))
         self.add_module("activation", act)
+
+    def forward(self, x):
+        bn = self.bn.bn
+        if bn.training and isinstance(self.activation, nn.ReLU) and layers._FUSED_BN:
+            y = self.conv(x)
+            if pointops.bn_train_cl_supported(bn, y):
+                # BatchNorm + ReLU of the layer as one pass over the [B, C, npoint, nsample] values per direction
+                # (csrc/bn_train.hip) instead of the norm's launches plus a clamp / threshold pass each way
+                bn._nbt_pending = getattr(bn, "_nbt_pending", 0) + 1
+                return pointops.bn_train_cl(bn, y, relu=True)
+            return self.activation(self.bn(y))
+        return super().forward(x)
 
 
 class SharedMLP(nn.Sequential):

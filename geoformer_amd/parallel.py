@@ -4,17 +4,19 @@ Scenes are independent units: the forward needs no exchange and inference runs p
 (SURVEY.md 8e).  The training step has exactly one real exchange: the sum of the gradients.  The
 reference intended SyncBatchNorm + DDP(find_unused_parameters=True) but never wired them (train.py:156-185).
 
-``BucketedGradReducer``: the gradients of all trainable parameters live in ONE flat fp32 buffer (8 120 459 floats
-= 32.5 MB for GeoFormer) laid out in reverse registration order -- roughly the order the backward produces
-them -- and cut into buckets (default 8 MB: xGMI is point-to-point, 7 links x ~153 GB/s, so a ring moves 32.5 MB in
-~0.4 ms and small buckets would only add latency).  ``p.grad`` of every parameter IS a view of that buffer, so the
-backward accumulates straight into it; a post-accumulate hook counts a bucket's parameters and starts the bucket's
-asynchronous all-reduce the moment the last one is in, while the rest of the backward is still running.  Buckets
-always go out in index order and ``finish()`` sends the ones the backward never completed (parameters without a
-gradient, e.g. decoder and heads before ``prepare_epochs``, contribute zeros), so every rank issues the identical
-sequence of collectives even when the ranks' graphs differ (an empty-foreground batch on one rank).  Parameters
-that received a gradient on NO rank get ``grad = None`` back, so the optimizer skips them exactly like the
-single-GPU step does (no weight decay / moment updates on modules that are not trained yet).
+``BucketedGradReducer``: the gradients of all trainable parameters are exchanged through ONE flat fp32 buffer
+(8 120 459 floats = 32.5 MB for GeoFormer) laid out in reverse registration order -- roughly the order the backward
+produces them -- and cut into buckets (default 8 MB: xGMI is point-to-point, 7 links x ~153 GB/s, so a ring moves
+32.5 MB in ~0.4 ms and small buckets would only add latency).  Every ``p.grad`` starts a step as ``None``, so autograd
+hands a parameter's gradient over without an accumulation launch; a post-accumulate hook counts a bucket's parameters,
+and the moment the last one is in, the bucket's gradients are packed into their slice of the buffer by one
+concatenation, ``p.grad`` is re-pointed at the slice and the bucket's asynchronous all-reduce starts, while the rest of
+the backward is still running.  Buckets always go out in index order and ``finish()`` sends the ones the backward
+never completed (parameters without a gradient, e.g. decoder and heads before ``prepare_epochs``, contribute zeros),
+so every rank issues the identical sequence of collectives even when the ranks' graphs differ (an empty-foreground
+batch on one rank).  Parameters that received a gradient on NO rank get ``grad = None`` back, so the optimizer skips
+them exactly like the single-GPU step does (no weight decay / moment updates on modules that are not trained yet).
+With one process nothing is packed or exchanged: the gradients stay where autograd put them.
 
 ``SyncBatchNorm1d``: batch statistics over all ranks with ONE packed collective per layer and direction (forward: an
 all-gather of every rank's (count, mean, M2) merged with Chan's parallel formula, the arithmetic of
@@ -67,7 +69,6 @@ class BucketedGradReducer:
         per_bucket = max(int(bucket_bytes) // 4, 1)
         self.views, self.bucket_of, self.ranges = [], [], []
         off = start = 0
-        count = []
         for p in self.params:
             if off - start >= per_bucket:  # close the bucket before this parameter
                 self.ranges.append((start, off))
@@ -77,12 +78,12 @@ class BucketedGradReducer:
             off += p.numel()
         self.ranges.append((start, off))
         self.nparams_in = [0] * len(self.ranges)
-        for b in self.bucket_of:
+        self.members = [[] for _ in self.ranges]  # parameter indices of every bucket
+        for i, b in enumerate(self.bucket_of):
             self.nparams_in[b] += 1
+            self.members[b].append(i)
         self._hooks = []
         self._index = {id(p): i for i, p in enumerate(self.params)}
-        for p in self.params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self.launched_in_backward = 0  # buckets whose all-reduce started before finish() (for tests / logs)
         self.prepare()
 
@@ -94,30 +95,57 @@ class BucketedGradReducer:
 
     @torch.no_grad()
     def prepare(self):
-        """Call before every backward: zero the buffer and point every p.grad at its view of it."""
-        self.flat.zero_()
+        """Call before every backward (instead of ``zero_grad``): every ``p.grad`` is dropped, so autograd hands each
+        parameter's gradient over without an accumulation launch; a bucket's gradients are packed into the flat buffer in
+        one launch when the bucket is complete (``_pack``).  (Pointing the gradients at zeroed views of the buffer, as
+        this class first did, costs a fill of the whole buffer plus one in-place add per parameter and step: ~400 launches.)"""
         self.used = [0.0] * len(self.params)
-        for p, v in zip(self.params, self.views):
-            p.grad = v
+        for p in self.params:
+            p.grad = None
+        # the hooks exist only while there is somebody to exchange with (one process: ~400 Python calls per backward
+        # on the autograd thread for nothing)
+        if self.world() > 1 and not self._hooks:
+            self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        elif self.world() == 1 and self._hooks:
+            self.remove_hooks()
         self._ready = [0] * len(self.ranges)
         self._next = 0
         self._works = []
         self._fired = [False] * len(self.params)
         self.launched_in_backward = 0
 
+    def _pack(self, b):
+        """The gradients of bucket b into their slice of the flat buffer (one concatenation; zeros where a parameter got
+        no gradient), and the parameters' ``grad`` re-pointed at the slice so that the optimizer reads the averaged values.
+        One process: nothing to exchange -- the gradients stay where autograd put them."""
+        if self.world() == 1:
+            return
+        s, e = self.ranges[b]
+        idxs = self.members[b]
+        grads = [self.params[i].grad for i in idxs]
+        if all(g is not None for g in grads):
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat[s:e])
+        else:
+            self.flat[s:e].zero_()
+            have = [(self.views[i], g) for i, g in zip(idxs, grads) if g is not None]
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for i, g in zip(idxs, grads):
+            if g is not None:
+                self.params[i].grad = self.views[i]
+
     def _launch(self, b):
+        self._pack(b)
         s, e = self.ranges[b]
         if self.world() > 1:
             self._works.append(dist.all_reduce(self.flat[s:e], async_op=True))
 
+    @torch.no_grad()
     def _on_grad(self, p):
         i = self._index[id(p)]
         if self._fired[i]:
             return
         self._fired[i] = True
-        if p.grad is not self.views[i]:  # autograd replaced the tensor (first accumulation into a fresh grad)
-            self.views[i].copy_(p.grad)
-            p.grad = self.views[i]
         self.used[i] = 1.0
         b = self.bucket_of[i]
         self._ready[b] += 1
@@ -135,14 +163,14 @@ class BucketedGradReducer:
         while self._next < len(self.ranges):
             self._launch(self._next)
             self._next += 1
-        used = self.used
-        if world > 1:
-            flags = torch.tensor(used, dtype=torch.float32, device=self.flat.device)
-            self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.MAX, async_op=True))
-            for w in self._works:
-                w.wait()
-            self.flat.div_(world)
-            used = flags.tolist()
+        if world == 1:
+            return
+        flags = torch.tensor(self.used, dtype=torch.float32, device=self.flat.device)
+        self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.MAX, async_op=True))
+        for w in self._works:
+            w.wait()
+        self.flat.div_(world)
+        used = flags.tolist()
         for p, v, u in zip(self.params, self.views, used):
             p.grad = v if u > 0 else None
 

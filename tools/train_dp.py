@@ -154,6 +154,17 @@ def run(args, device, batches=None):
         dist.barrier()
     sync()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device if device.type == "cuda" else None)
+    host_ms = None
+    if getattr(args, "host_split", 0):
+        # untimed extra steps: when the host has queued a whole step against when the device has finished it
+        th = 0.0
+        for i in range(args.host_split):
+            sync()
+            h0 = time.perf_counter()
+            step(m, crit, red, opt, batches[i % len(batches)], args.epoch, 7000 + i)
+            th += time.perf_counter() - h0
+        sync()
+        host_ms = round(th / args.host_split * 1e3, 2)
     scenes = world * args.batch_size * args.steps
     return {"metric": "training scenes/sec (fwd + criterion + bwd + all-reduce + Adam)", "value": round(scenes / dt, 3),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -163,7 +174,7 @@ def run(args, device, batches=None):
             "grad_floats": red.numel(), "buckets": len(red.ranges),
             "buckets_started_inside_backward_per_step": round(early / max(args.steps, 1), 2),
             "fg_frac_target": getattr(args, "fg_frac", None), "fg_bias_shift": fg_shift,
-            "n_fg_per_step": n_fg, "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}
+            "host_ms_per_step": host_ms, "n_fg_per_step": n_fg, "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}
 
 
 def default_args(**over):
@@ -185,6 +196,8 @@ def parser():
     ap.add_argument("--bn-eval", action="store_true")
     ap.add_argument("--fg-frac", type=float, default=None,
                     help="shift the background logits so that this share of the first batch's points is predicted foreground")
+    ap.add_argument("--host-split", type=int, default=0,
+                    help="extra untimed steps that measure when the host has queued a step (host_ms_per_step)")
     ap.add_argument("--small", action="store_true", help="small scenes / heads (host-side test runs)")
     return ap
 
