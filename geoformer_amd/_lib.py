@@ -114,6 +114,10 @@ def _declare(lib):
         "gf_bn_train_scratch_floats": (c_size_t, [I, I]),
         "gf_bn_relu_train_fwd": (I, [P, I, I, P, P, F, F, I, P, P, P, P, P, P, P]),
         "gf_bn_relu_train_bwd": (I, [P, P, P, I, I, P, P, P, I, P, P, P, P, P]),
+        "gf_bn_relu_train_bwd_add": (I, [P, P, P, I, I, P, P, P, I, P, P, P, P, P, P]),
+        "gf_unet_train_scratch_floats": (c_size_t, [P, I, P]),
+        "gf_unet_train_fwd": (I, [P, I, I, P, P, P, P, P, P]),
+        "gf_unet_train_bwd": (I, [P, I, I, P, P, P, P, P, P, P, P]),
         "gf_bn_train_cl_scratch_floats": (c_size_t, [I, I, c_longlong]),
         "gf_bn_relu_train_cl_fwd": (I, [P, I, I, c_longlong, P, P, F, F, I, P, P, P, P, P, P, P]),
         "gf_bn_relu_train_cl_bwd": (I, [P, P, P, I, I, c_longlong, P, P, P, I, P, P, P, P, P]),

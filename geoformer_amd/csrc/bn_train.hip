@@ -250,7 +250,8 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float* __rest
                                                             const float* __restrict__ save_mean,
                                                             const float* __restrict__ save_invstd,
                                                             const float* __restrict__ means, int relu,
-                                                            float* __restrict__ dx) {
+                                                            const float* addend, float* dx) {
+    // (addend may be dx itself: the element is read and written by the same thread)
     const long long stride = (long long)gridDim.x * BN_THREADS / c4 * c4;
     long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
     if (i >= stride) return;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(BN_THREADS) void k_bn_bwd_apply(const float* __rest
         r.y = (g.y - c1.y - (v.y - m.y) * is.y * c2.y) * k.y;
         r.z = (g.z - c1.z - (v.z - m.z) * is.z * c2.z) * k.z;
         r.w = (g.w - c1.w - (v.w - m.w) * is.w * c2.w) * k.w;
+        if (addend) r = f4_add(r, reinterpret_cast<const float4*>(addend)[i]);
         o4[i] = r;
     }
 }
@@ -492,11 +494,18 @@ extern "C" int gf_bn_relu_train_fwd(const float* x, int M, int C, const float* g
 extern "C" int gf_bn_relu_train_bwd(const float* x, const float* y, const float* dy, int M, int C, const float* gamma,
                                     const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
                                     float* dbeta, float* scratch, void* stream) {
+    return gf_bn_relu_train_bwd_add(x, y, dy, M, C, gamma, save_mean, save_invstd, relu, nullptr, dx, dgamma, dbeta, scratch,
+                                    stream);
+}
+
+extern "C" int gf_bn_relu_train_bwd_add(const float* x, const float* y, const float* dy, int M, int C, const float* gamma,
+                                        const float* save_mean, const float* save_invstd, int relu, const float* addend,
+                                        float* dx, float* dgamma, float* dbeta, float* scratch, void* stream) {
     GF_CHECK_ARG(x && dy && gamma && save_mean && save_invstd && scratch && (y || !relu), "gf_bn_relu_train_bwd: null argument");
     GF_CHECK_ARG(M >= 2, "gf_bn_relu_train_bwd: M=%d", M);
     GF_CHECK_ARG(C >= 4 && C <= BN_MAX_C && (C % 4) == 0, "gf_bn_relu_train_bwd: C=%d (multiples of 4 up to %d)", C, BN_MAX_C);
     GF_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gamma) |
-                   ((uintptr_t)save_mean) | ((uintptr_t)save_invstd) | ((uintptr_t)scratch)) % 16) == 0,
+                   ((uintptr_t)save_mean) | ((uintptr_t)save_invstd) | ((uintptr_t)scratch) | ((uintptr_t)addend)) % 16) == 0,
                  "gf_bn_relu_train_bwd: 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     const BnGeom g = bn_geom(M, C);
@@ -508,7 +517,7 @@ extern "C" int gf_bn_relu_train_bwd(const float* x, const float* y, const float*
     if (dx) {
         const long long total4 = (long long)M * g.c4;
         hipLaunchKernelGGL(k_bn_bwd_apply, dim3(apply_grid(total4)), dim3(BN_THREADS), 0, st, x, y, dy, total4, C, g.c4, gamma,
-                           save_mean, save_invstd, means, relu, dx);
+                           save_mean, save_invstd, means, relu, addend, dx);
     }
     GF_CHECK_LAUNCH("gf_bn_relu_train_bwd");
     return GF_OK;

@@ -1,0 +1,227 @@
+// The sparse U-Net in training mode as a layer program (include/geoformer_hip.h: gf_unet_train_fwd / _bwd).
+//
+// Reference structure: GeoFormer.input_conv -> UBlock x7 -> output_layer (model/geoformer/geoformer.py:39-53,398-401;
+// ResidualBlock / UBlock: model/geoformer/geoformer_modules.py:10-35,52-129), BatchNorm1d in training mode, the
+// backward of train.py:63-75.
+//
+// Why it exists: per batch-4 step the module tree costs the host ~10 ms forward (71 convolutions, 70 BatchNorm + ReLU
+// pairs, residual adds, concatenations: ~600 framework / ctypes calls) and ~12 ms backward (135 Python autograd
+// functions + ~250 framework nodes on the autograd thread) for ~21 ms of device work; the step was bound by the host.
+// The same entry points issued from C++ in program order cost ~2 us per launch.  Nothing is computed differently:
+// gf_conv_fwd (+ residual epilogue), gf_conv_pack_weights(_t), gf_conv_wgrad_masked, gf_bn_relu_train_fwd / _bwd_add.
+#include "common.h"
+
+namespace {
+
+// out[r] = (a[r], b[r]) in 16-byte pieces
+__global__ void k_tr_concat2(const float4* __restrict__ a, const float4* __restrict__ b, long long M, int ca4, int cb4,
+                             float4* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = ca4 + cb4;
+    if (i >= M * c4) return;
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4);
+    out[i] = c < ca4 ? a[r * ca4 + c] : b[r * cb4 + (c - ca4)];
+}
+
+// (ga[r], gb[r]) (+)= g[r]: the concatenation's backward
+__global__ void k_tr_split2(const float4* __restrict__ g, long long M, int ca4, int cb4, float4* ga, int acc_a, float4* gb,
+                            int acc_b) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = ca4 + cb4;
+    if (i >= M * c4) return;
+    const long long r = i / c4;
+    const int c = (int)(i - r * c4);
+    const float4 v = g[i];
+    float4* dst = c < ca4 ? ga + r * ca4 + c : gb + r * cb4 + (c - ca4);
+    if (c < ca4 ? acc_a : acc_b) {
+        const float4 o = *dst;
+        *dst = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+    } else {
+        *dst = v;
+    }
+}
+
+__global__ void k_tr_add(float4* __restrict__ dst, const float4* __restrict__ src, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = dst[i], b = src[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+struct ConvGeom {  // one convolution op resolved against the step's levels
+    const int32_t *tbl, *btbl, *steps, *bsteps;
+    const uint32_t *gmask, *bgmask;
+    int K, rows_in, rows_out, ld, bld, flip;
+};
+
+inline bool conv_geom(const GfTrainOp& op, const GfTrainLevel* lv, ConvGeom& g) {
+    const GfTrainLevel& L = lv[op.level];
+    g.steps = g.bsteps = nullptr;
+    g.flip = 0;
+    switch (op.table) {
+    case 0:
+        g.tbl = g.btbl = nullptr;
+        g.gmask = g.bgmask = nullptr;
+        g.K = 1;
+        g.rows_in = g.rows_out = L.M;
+        g.ld = g.bld = 0;
+        return true;
+    case 1:  // the submanifold relation is symmetric: the same table with weights W[26-k]^T gives the input gradient
+        g.tbl = g.btbl = L.nbr;
+        g.gmask = g.bgmask = L.gmask;
+        g.steps = g.bsteps = L.steps;
+        g.K = 27;
+        g.rows_in = g.rows_out = L.M;
+        g.ld = g.bld = L.ld;
+        g.flip = 1;
+        return true;
+    case 2:
+        g.tbl = L.child; g.gmask = L.gmask_down; g.ld = L.ld_down;
+        g.btbl = L.up; g.bgmask = L.gmask_up; g.bld = L.ld_up;
+        g.K = 8;
+        g.rows_in = L.M;
+        g.rows_out = L.M_coarse;
+        return true;
+    case 3:
+        g.tbl = L.up; g.gmask = L.gmask_up; g.ld = L.ld_up;
+        g.btbl = L.child; g.bgmask = L.gmask_down; g.bld = L.ld_down;
+        g.K = 8;
+        g.rows_in = L.M_coarse;
+        g.rows_out = L.M;
+        return true;
+    default:
+        return false;
+    }
+}
+
+inline long long rows_of(const GfTrainOp& op, const GfTrainLevel* lv) { return lv[op.level].M; }
+
+}  // namespace
+
+extern "C" size_t gf_unet_train_scratch_floats(const GfTrainOp* ops, int nops, const GfTrainLevel* levels) {
+    size_t bn = 0, wt = 0;
+    for (int i = 0; i < nops; i++) {
+        const GfTrainOp& op = ops[i];
+        if (op.kind == 0) {
+            const size_t f = gf_bn_train_scratch_floats(levels[op.level].M, op.Cin);
+            if (f > bn) bn = f;
+        } else if (op.kind == 1) {
+            const int K = op.table == 0 ? 1 : (op.table == 1 ? 27 : 8);
+            const size_t f = gf_conv_packed_floats(K, op.Cout, op.Cin);
+            if (f > wt) wt = f;
+        }
+    }
+    return ((bn + 63) & ~(size_t)63) + ((wt + 63) & ~(size_t)63) + 64;
+}
+
+extern "C" int gf_unet_train_fwd(const GfTrainOp* ops, int op_begin, int op_end, const GfTrainLevel* levels,
+                                 float* const* act, float* wp, float* stats, float* scratch, void* stream) {
+    GF_CHECK_ARG(ops && levels && act && wp && stats && scratch && op_begin >= 0 && op_end >= op_begin,
+                 "gf_unet_train_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = op_begin; i < op_end; i++) {
+        const GfTrainOp& op = ops[i];
+        if (op.kind == 0) {
+            const int M = (int)rows_of(op, levels);
+            int rc = gf_bn_relu_train_fwd(act[op.src], M, op.Cin, op.gamma, op.beta, op.eps, op.momentum, 1, op.running_mean,
+                                          op.running_var, act[op.dst], stats + op.stats_off, stats + op.stats_off + op.Cin,
+                                          scratch, stream);
+            if (rc != GF_OK) return rc;
+        } else if (op.kind == 1) {
+            ConvGeom g;
+            GF_CHECK_ARG(conv_geom(op, levels, g), "gf_unet_train_fwd: op %d: table %d", i, op.table);
+            float* wpk = wp + op.wp_off;
+            int rc = gf_conv_pack_weights(op.w, g.K, op.Cin, op.Cout, wpk, stream);
+            if (rc != GF_OK) return rc;
+            rc = gf_conv_fwd(act[op.src], wpk, g.tbl, g.gmask, g.steps, g.K, g.rows_in, g.rows_out, g.ld, op.Cin, op.Cout,
+                             nullptr, nullptr, op.aux >= 0 ? act[op.aux] : nullptr, nullptr, nullptr, act[op.dst], stream);
+            if (rc != GF_OK) return rc;
+        } else if (op.kind == 2) {
+            const long long M = rows_of(op, levels);
+            GF_CHECK_ARG((op.Cin % 4) == 0 && (op.Cout % 4) == 0, "gf_unet_train_fwd: op %d: widths %d + %d", i, op.Cin, op.Cout);
+            const int ca4 = op.Cin / 4, cb4 = op.Cout / 4;  // (Cin / Cout: widths of src / aux)
+            const long long n = M * (ca4 + cb4);
+            if (n > 0)
+                hipLaunchKernelGGL(k_tr_concat2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)act[op.src],
+                                   (const float4*)act[op.aux], M, ca4, cb4, (float4*)act[op.dst]);
+        } else {
+            GF_CHECK_ARG(false, "gf_unet_train_fwd: op %d: kind %d", i, op.kind);
+        }
+    }
+    GF_CHECK_LAUNCH("gf_unet_train_fwd");
+    return GF_OK;
+}
+
+extern "C" int gf_unet_train_bwd(const GfTrainOp* ops, int op_begin, int op_end, const GfTrainLevel* levels,
+                                 float* const* act, float** grad, unsigned char* ghas, const float* stats, float* pgrad,
+                                 float* scratch, void* stream) {
+    GF_CHECK_ARG(ops && levels && act && grad && ghas && stats && pgrad && scratch && op_begin >= 0 && op_end >= op_begin,
+                 "gf_unet_train_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    // scratch: [BatchNorm partials | transposed weight pack]; the split is the one gf_unet_train_scratch_floats makes
+    size_t bn = 0;
+    for (int i = op_begin; i < op_end; i++)
+        if (ops[i].kind == 0) {
+            const size_t f = gf_bn_train_scratch_floats(levels[ops[i].level].M, ops[i].Cin);
+            if (f > bn) bn = f;
+        }
+    float* wt = scratch + ((bn + 63) & ~(size_t)63);
+    for (int i = op_end - 1; i >= op_begin; i--) {
+        const GfTrainOp& op = ops[i];
+        GF_CHECK_ARG(ghas[op.dst], "gf_unet_train_bwd: op %d: no gradient for its output (buffer %d)", i, op.dst);
+        if (op.kind == 0) {
+            const int M = (int)rows_of(op, levels);
+            float* dgb = pgrad + op.pgrad_off;
+            int rc = gf_bn_relu_train_bwd_add(act[op.src], act[op.dst], grad[op.dst], M, op.Cin, op.gamma, stats + op.stats_off,
+                                              stats + op.stats_off + op.Cin, 1, ghas[op.src] ? grad[op.src] : nullptr,
+                                              grad[op.src], dgb, dgb + op.Cin, scratch, stream);
+            if (rc != GF_OK) return rc;
+            if (!ghas[op.src]) ghas[op.src] = 1;
+        } else if (op.kind == 1) {
+            ConvGeom g;
+            GF_CHECK_ARG(conv_geom(op, levels, g), "gf_unet_train_bwd: op %d: table %d", i, op.table);
+            const float* gy = grad[op.dst];
+            if (op.aux >= 0) {  // residual operand: its gradient is gy
+                const long long n4 = (long long)g.rows_out * op.Cout / 4;
+                if (ghas[op.aux]) {
+                    if (n4 > 0)
+                        hipLaunchKernelGGL(k_tr_add, dim3(gf_div_up(n4, 256)), dim3(256), 0, st, (float4*)grad[op.aux],
+                                           (const float4*)gy, n4);
+                } else if (ghas[op.dst] == 2) {  // not ours to write into later: copy
+                    GF_TRY(hipMemcpyAsync(grad[op.aux], gy, (size_t)n4 * 16, hipMemcpyDeviceToDevice, st));
+                    ghas[op.aux] = 1;
+                } else {
+                    grad[op.aux] = grad[op.dst];  // (dead after this op: later in-place accumulation is safe)
+                    ghas[op.aux] = 1;
+                }
+            }
+            if (!op.no_dgrad) {
+                int rc = gf_conv_pack_weights_t(op.w, g.K, op.Cin, op.Cout, g.flip, wt, stream);
+                if (rc != GF_OK) return rc;
+                // (rows of the gradient = the forward's output rows; the residual epilogue adds what the source has)
+                rc = gf_conv_fwd(gy, wt, g.btbl, g.bgmask, g.bsteps, g.K, g.rows_out, g.rows_in, g.bld, op.Cout, op.Cin, nullptr,
+                                 nullptr, ghas[op.src] ? grad[op.src] : nullptr, nullptr, nullptr, grad[op.src], stream);
+                if (rc != GF_OK) return rc;
+                if (!ghas[op.src]) ghas[op.src] = 1;
+            }
+            int rc = gf_conv_wgrad_masked(act[op.src], gy, g.tbl, g.gmask, g.K, g.rows_out, g.ld, op.Cin, op.Cout,
+                                          pgrad + op.pgrad_off, stream);
+            if (rc != GF_OK) return rc;
+        } else if (op.kind == 2) {
+            const long long M = rows_of(op, levels);
+            const int ca4 = op.Cin / 4, cb4 = op.Cout / 4;
+            const long long n = M * (ca4 + cb4);
+            if (n > 0)
+                hipLaunchKernelGGL(k_tr_split2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)grad[op.dst], M, ca4,
+                                   cb4, (float4*)grad[op.src], ghas[op.src] ? 1 : 0, (float4*)grad[op.aux],
+                                   ghas[op.aux] ? 1 : 0);
+            if (!ghas[op.src]) ghas[op.src] = 1;
+            if (!ghas[op.aux]) ghas[op.aux] = 1;
+        } else {
+            GF_CHECK_ARG(false, "gf_unet_train_bwd: op %d: kind %d", i, op.kind);
+        }
+    }
+    GF_CHECK_LAUNCH("gf_unet_train_bwd");
+    return GF_OK;
+}

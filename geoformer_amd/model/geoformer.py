@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 from torch.nn import functional as F
 
-from .. import pointops, spconv, unet_exec
+from .. import pointops, spconv, unet_exec, unet_train
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
 from .layers import (BatchNorm1d, BigLinear, GenericMLP, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
@@ -339,6 +339,13 @@ class GeoFormer(nn.Module):
         if os.environ.get("GF_UNET_EXEC", "1") != "0" and unet_exec.supported(self, x.features, x.spatial_shape):
             x.features = unet_exec.unet_forward(self, x.features.contiguous(), x._coords(), batch_size, x.spatial_shape)
             return x
+        if unet_train.supported(self, x):
+            # training: the same launches as the module tree below, forward and backward, issued by native code
+            # (csrc/unet_train.hip); the two voxel transformers stay framework modules between its three ranges
+            feats = unet_train.unet_forward(self, x, batch_size)
+            if feats is not None:
+                x.features = feats
+                return x
         # built lazily by the first strided convolution (spconv.SparseConv3d.get_rules): the host then issues
         # the chain's ~50 small launches while the GPU is busy with the level-1 blocks, and the one read-back
         # of the voxel counts waits behind real work instead of an empty queue

@@ -181,6 +181,47 @@ int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K,
 int gf_conv_wgrad_masked(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K, int M_out,
                          int ld, int Cin, int Cout, float* dW, void* stream);
 
+/* The sparse U-Net in TRAINING mode (batch statistics, saved activations, backward) as a layer program run from native
+ * code: GeoFormer.input_conv -> UBlock x7 -> output_layer with requires_grad (model/geoformer/geoformer.py:39-53,
+ * 398-401; ResidualBlock / UBlock: model/geoformer/geoformer_modules.py:10-35,52-129; the training loop's backward:
+ * train.py:63-75).  The host compiles the module tree ONCE into a list of ops over numbered feature buffers; a call
+ * runs a contiguous range of ops (the two voxel transformers of the deepest levels stay framework modules, so a step
+ * is three ranges) with exactly the launches the per-module route makes through gf_conv_fwd, gf_conv_pack_weights(_t),
+ * gf_conv_wgrad_masked and gf_bn_relu_train_fwd / _bwd -- without ~1 500 framework calls and ~230 autograd nodes per
+ * step.
+ *   op kinds     0  dst = relu(batchnorm(src))      batch statistics; running statistics updated; mean / invstd saved
+ *                1  dst = conv(src) (+ aux)         table 0: 1x1x1 (plain rows), 1: submanifold 3x3x3 of `level`,
+ *                                                   2: 2x2x2 stride 2 from `level` to level+1, 3: its inverse
+ *                2  dst = [src | aux]               the skip concatenation (UBlock.forward, geoformer_modules.py:116)
+ *   buffers      act[i] / grad[i]: fp32 [rows(level of i), C of i], 16-byte aligned, caller-owned for the whole step
+ *   backward     ops in reverse; an op ACCUMULATES into a source's gradient when ghas[src] != 0 and sets ghas[src];
+ *                a residual operand's gradient is the output's gradient itself: grad[aux] is re-pointed at grad[dst]
+ *                (copied when ghas[dst] == 2: a gradient tensor the caller does not own).  Parameter gradients land
+ *                in pgrad at the op's pgrad_off: dW [K,Cin,Cout], or dgamma [C] followed by dbeta [C]. */
+typedef struct GfTrainOp {
+    int kind, level, table, src, dst, aux, Cin, Cout, no_dgrad, pad_;
+    const float* w;                                 /* convolution weights [K,Cin,Cout] */
+    const float *gamma, *beta;                      /* BatchNorm */
+    float *running_mean, *running_var;
+    float eps, momentum;
+    long long wp_off;                               /* packed forward weights: floats into `wp` */
+    long long pgrad_off;                            /* floats into `pgrad` */
+    long long stats_off;                            /* save_mean [C] then save_invstd [C]: floats into `stats` */
+} GfTrainOp;
+typedef struct GfTrainLevel {
+    int M, ld;                                      /* voxels of the level; leading dimension of its 27-offset table */
+    const int32_t* nbr; const uint32_t* gmask; const int32_t* steps;
+    int M_coarse, ld_down;                          /* the level below: rows, leading dimension of child */
+    const int32_t* child; const uint32_t* gmask_down;
+    int ld_up, pad_; const int32_t* up; const uint32_t* gmask_up;
+} GfTrainLevel;
+/* floats of `scratch` a range of ops needs (BatchNorm partials + the transposed weight pack of the widest op) */
+size_t gf_unet_train_scratch_floats(const GfTrainOp* ops, int nops, const GfTrainLevel* levels);
+int gf_unet_train_fwd(const GfTrainOp* ops, int op_begin, int op_end, const GfTrainLevel* levels, float* const* act,
+                      float* wp, float* stats, float* scratch, void* stream);
+int gf_unet_train_bwd(const GfTrainOp* ops, int op_begin, int op_end, const GfTrainLevel* levels, float* const* act,
+                      float** grad, unsigned char* ghas, const float* stats, float* pgrad, float* scratch, void* stream);
+
 /* The whole sparse U-Net of the eval forward in one call: input conv -> UBlock x nlevels -> output BatchNorm + ReLU
  * (GeoFormer.input_conv / unet / output_layer, model/geoformer/geoformer.py:42-53,398-401; UBlock and ResidualBlock,
  * model/geoformer/geoformer_modules.py:10-35,52-129; two blocks per level before and after the inner level, all
@@ -264,6 +305,11 @@ int gf_bn_relu_train_fwd(const float* x, int M, int C, const float* gamma, const
 int gf_bn_relu_train_bwd(const float* x, const float* y, const float* dy, int M, int C, const float* gamma,
                          const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
                          float* dbeta, float* scratch, void* stream);
+/* gf_bn_relu_train_bwd with dx = (the layer's input gradient) + addend[M,C] (the gradient the input already received
+ * through another consumer, e.g. a residual block's identity branch); addend may be NULL or dx itself. */
+int gf_bn_relu_train_bwd_add(const float* x, const float* y, const float* dy, int M, int C, const float* gamma,
+                             const float* save_mean, const float* save_invstd, int relu, const float* addend, float* dx,
+                             float* dgamma, float* dbeta, float* scratch, void* stream);
 
 /* The same pair for the channel-major layouts x[B,C,L]: nn.BatchNorm1d over [B,C,L] (semantic head, mask tower:
  * geoformer.py:55-70, B = 1, L = number of points) and nn.BatchNorm2d over [B,C,H,W] with L = H*W (the set-abstraction

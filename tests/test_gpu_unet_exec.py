@@ -72,3 +72,71 @@ def test_unet_exec_training_mode_bn_takes_module_route(hip):
     m.unet.blocks.block0.conv_branch[0].train()
     with torch.no_grad():
         assert not unet_exec.supported(m, x.features, x.spatial_shape)
+
+
+def _train_backbone(m, batch, native, seed):
+    """One training forward + backward of the backbone (input_conv -> unet -> output_layer -> a fixed random
+    projection as the loss) through the native training route or the module tree; returns output features, every
+    parameter's gradient and the BatchNorm running statistics afterwards."""
+    os.environ["GF_UNET_TRAIN_EXEC"] = "1" if native else "0"
+    try:
+        m.zero_grad(set_to_none=True)
+        x = m.preprocess_input(batch, len(batch["offsets"]) - 1)
+        x = m.unet_features(x, len(batch["offsets"]) - 1)
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        w = torch.randn(x.features.shape, device="cuda", generator=g)
+        (x.features * w).sum().backward()
+        torch.cuda.synchronize()
+        mods = (m.input_conv, m.unet, m.output_layer)
+        grads = {n: p.grad.clone() for mod in mods for n, p in mod.named_parameters()}
+        stats = {n: b.clone() for mod in mods for n, b in mod.named_buffers() if b.dtype == torch.float32}
+        return x.features.detach().clone(), grads, stats
+    finally:
+        os.environ.pop("GF_UNET_TRAIN_EXEC", None)
+
+
+@pytest.mark.parametrize("scenes", [[("small", 8192, 5)], [("small", 6000, 7), ("small", 9000, 8)],
+                                    [("room", 62000, 31), ("room", 58000, 32)]], ids=["s8k", "batch2", "batch2-rooms"])
+def test_unet_train_exec_matches_module_route(hip, scenes):
+    """gf_unet_train_fwd / _bwd (csrc/unet_train.hip) against the module tree in training mode: the same kernels in the
+    same order, so features and BatchNorm statistics agree to the last bits and the gradients to the summation order of
+    the weight gradient's atomics."""
+    import copy
+
+    from geoformer_amd import scene, unet_train
+
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    m = GeoFormer(load_config("geoformer_scannet.yaml", batch_size=len(scenes)))  # the training yaml: nothing frozen
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 3))
+    m.cuda()
+    m.train()
+    for mod in m.modules():  # (the voxel transformers' dropout would make two forwards differ)
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    mk = {"small": scene.make_small_scene, "room": scene.make_scene}
+    batch = scene.make_batch([mk[k](n, s) for k, n, s in scenes])
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    assert unet_train.supported(m, m.preprocess_input(batch, len(scenes)))
+    state = copy.deepcopy(m.state_dict())
+    f_ref, g_ref, s_ref = _train_backbone(m, batch, native=False, seed=1)
+    m.load_state_dict(state)  # the running statistics back to where they were
+    f_nat, g_nat, s_nat = _train_backbone(m, batch, native=True, seed=1)
+    assert f_nat.shape == f_ref.shape
+    assert float((f_nat - f_ref).abs().max()) <= 2e-6 * max(1.0, float(f_ref.abs().max()))
+    for n in s_ref:
+        assert float((s_nat[n] - s_ref[n]).abs().max()) <= 1e-6 * max(1.0, float(s_ref[n].abs().max())), n
+    assert set(g_nat) == set(g_ref)
+    top = max(float(g.norm()) for g in g_ref.values())
+    for n, gr in g_ref.items():
+        gn = g_nat[n]
+        assert gn.shape == gr.shape, n
+        ref = float(gr.norm())
+        # (the 1x1x1 identity convolutions are library GEMMs on the module route and the MFMA kernel here: rounding-level
+        # differences in the features, amplified where a 10^5-row sum cancels
+        # -- BatchNorm's gamma / beta gradients: 1.2e-3 at 120k rows; 3e-3 is the training golden's bound as well)
+        assert float((gn - gr).norm()) <= 3e-3 * max(ref, 1e-5 * top), (n, float((gn - gr).norm()), ref)
+    # eval-mode BatchNorm or a frozen parameter: not this route
+    m.unet.blocks.block0.conv_branch[0].eval()
+    assert not unet_train.supported(m, m.preprocess_input(batch, len(scenes)))
