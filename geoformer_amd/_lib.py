@@ -49,6 +49,7 @@ def _declare(lib):
         "gf_resblock_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),
         "gf_conv_wgrad_masked": (I, [P, P, P, P, I, I, I, I, I, P, P]),
+        "gf_conv_wgrad_masked_acc": (I, [P, P, P, P, I, I, I, I, I, P, P]),
         "gf_lsap": (I, [P, I, I, P, P, P, P, P, P]),
         "gf_pair_losses_sums_floats": (c_size_t, [I]),
         "gf_pair_losses_fwd": (I, [P, P, P, I, I, I, P, P, P, P]),

@@ -23,6 +23,7 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 #include "geoformer_hip_dev.h"
+#include "conv_pack.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CONV_MAX_CIN 512
@@ -33,27 +34,13 @@ extern "C" size_t gf_conv_packed_floats(int K, int Cin, int Cout) {
 }
 
 // Wp[(((k*NCH + ch)*NCB + cb)*64 + lane)*4 + kk] = W[k][ch*16 + 4*(lane>>4) + kk][cb*16 + (lane&15)]
+// (element functions in conv_pack.h: the training executor packs all of a step's weights in one launch)
 __global__ void k_pack_weights(const float* __restrict__ W, int K, int Cin, int Cout, int NCH, int NCB,
                                float* __restrict__ Wp) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)K * NCH * NCB * 64;
     if (t >= total) return;
-    const int lane = (int)(t & 63);
-    size_t u = t >> 6;
-    const int cb = (int)(u % NCB);
-    u /= NCB;
-    const int ch = (int)(u % NCH);
-    const int k = (int)(u / NCH);
-    const int r = lane & 15, q = lane >> 4;
-    const int col = cb * 16 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    float* pv = reinterpret_cast<float*>(&v);
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-        const int row = ch * 16 + 4 * q + kk;
-        if (row < Cin && col < Cout) pv[kk] = W[((size_t)k * Cin + row) * Cout + col];
-    }
-    reinterpret_cast<float4*>(Wp)[t] = v;
+    reinterpret_cast<float4*>(Wp)[t] = gf_pack_weights_elem(W, Cin, Cout, NCH, NCB, t);
 }
 
 extern "C" int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, void* stream) {
@@ -75,23 +62,7 @@ __global__ void k_pack_weights_t(const float* __restrict__ W, int K, int Cin, in
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t total = (size_t)K * NCH * NCB * 64;
     if (t >= total) return;
-    const int lane = (int)(t & 63);
-    size_t u = t >> 6;
-    const int cb = (int)(u % NCB);
-    u /= NCB;
-    const int ch = (int)(u % NCH);
-    const int k = (int)(u / NCH);
-    const int ks = flip ? K - 1 - k : k;
-    const int r = lane & 15, q = lane >> 4;
-    const int col = cb * 16 + r;  // column of W' = input channel of W
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    float* pv = reinterpret_cast<float*>(&v);
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-        const int row = ch * 16 + 4 * q + kk;  // row of W' = output channel of W
-        if (row < Cout && col < Cin) pv[kk] = W[((size_t)ks * Cin + col) * Cout + row];
-    }
-    reinterpret_cast<float4*>(Wp)[t] = v;
+    reinterpret_cast<float4*>(Wp)[t] = gf_pack_weights_t_elem(W, K, Cin, Cout, NCH, NCB, flip, t);
 }
 
 extern "C" int gf_conv_pack_weights_t(const float* W, int K, int Cin, int Cout, int flip, float* Wp, void* stream) {
@@ -1667,12 +1638,12 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_t(const float* __restrict__ 
     }
 }
 
-extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K, int M_out, int ld, int Cin,
-                             int Cout, float* dW, void* stream) {
+static int conv_wgrad_impl(const float* in, const float* dout, const int32_t* nbr, int K, int M_out, int ld, int Cin,
+                           int Cout, float* dW, bool zero, void* stream) {
     GF_CHECK_ARG(K >= 1 && Cin >= 1 && Cout >= 1, "gf_conv_wgrad: bad sizes");
     GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_wgrad: nbr==NULL requires K==1");
     hipStream_t st = (hipStream_t)stream;
-    GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
+    if (zero) GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
     if (M_out <= 0) return GF_OK;
     const int nci = (Cin + 15) / 16, nco = (Cout + 15) / 16;
     const int nslices = (M_out + WG_ROWS - 1) / WG_ROWS;
@@ -1683,13 +1654,18 @@ extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* 
     return GF_OK;
 }
 
-extern "C" int gf_conv_wgrad_masked(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K,
-                                    int M_out, int ld, int Cin, int Cout, float* dW, void* stream) {
+extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K, int M_out, int ld, int Cin,
+                             int Cout, float* dW, void* stream) {
+    return conv_wgrad_impl(in, dout, nbr, K, M_out, ld, Cin, Cout, dW, true, stream);
+}
+
+static int conv_wgrad_masked_impl(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K,
+                                  int M_out, int ld, int Cin, int Cout, float* dW, bool zero, void* stream) {
     if (gmask == nullptr || nbr == nullptr || (Cin & 15) || (Cout & 15))
-        return gf_conv_wgrad(in, dout, nbr, K, M_out, ld, Cin, Cout, dW, stream);
+        return conv_wgrad_impl(in, dout, nbr, K, M_out, ld, Cin, Cout, dW, zero, stream);
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_wgrad_masked: K=%d (at most 32 offsets)", K);
     hipStream_t st = (hipStream_t)stream;
-    GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
+    if (zero) GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
     if (M_out <= 0) return GF_OK;
     const int nci = Cin / 16, nco = Cout / 16;
     const int nslices = (M_out + WGT_ROWS - 1) / WGT_ROWS;
@@ -1698,6 +1674,16 @@ extern "C" int gf_conv_wgrad_masked(const float* in, const float* dout, const in
                        Cin, Cout, nci, nco, nslices, dW);
     GF_CHECK_LAUNCH("gf_conv_wgrad_masked");
     return GF_OK;
+}
+
+extern "C" int gf_conv_wgrad_masked(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K,
+                                    int M_out, int ld, int Cin, int Cout, float* dW, void* stream) {
+    return conv_wgrad_masked_impl(in, dout, nbr, gmask, K, M_out, ld, Cin, Cout, dW, true, stream);
+}
+
+extern "C" int gf_conv_wgrad_masked_acc(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask,
+                                        int K, int M_out, int ld, int Cin, int Cout, float* dW, void* stream) {
+    return conv_wgrad_masked_impl(in, dout, nbr, gmask, K, M_out, ld, Cin, Cout, dW, false, stream);
 }
 
 extern "C" int gf_dev_conv_occupancy(int block) {

@@ -10,6 +10,7 @@
 // The same entry points issued from C++ in program order cost ~2 us per launch.  Nothing is computed differently:
 // gf_conv_fwd (+ residual epilogue), gf_conv_pack_weights(_t), gf_conv_wgrad_masked, gf_bn_relu_train_fwd / _bwd_add.
 #include "common.h"
+#include "conv_pack.h"
 
 namespace {
 
@@ -47,6 +48,27 @@ __global__ void k_tr_add(float4* __restrict__ dst, const float4* __restrict__ sr
     if (i >= n4) return;
     const float4 a = dst[i], b = src[i];
     dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// All weight packs of a range in one launch (blockIdx.y = convolution): the per-convolution gf_conv_pack_weights(_t)
+// launches are ~4 us each, 71 forward + 64 backward per step.  The table travels as a kernel argument.
+constexpr int kPackMax = 80;
+struct PackTable {
+    const float* w[kPackMax];
+    long long dst[kPackMax];  // floats into the destination area
+    short K[kPackMax], Cin[kPackMax], Cout[kPackMax], flip[kPackMax];
+};
+template <bool T>
+__global__ void k_tr_pack_batch(PackTable tb, float* __restrict__ base) {
+    const int e = blockIdx.y;
+    const int K = tb.K[e], Cin = tb.Cin[e], Cout = tb.Cout[e];
+    // T: the packed operand is W' [K,Cout,Cin]
+    const int NCH = ((T ? Cout : Cin) + 15) / 16, NCB = ((T ? Cin : Cout) + 15) / 16;
+    const size_t total = (size_t)K * NCH * NCB * 64;
+    float4* out = reinterpret_cast<float4*>(base + tb.dst[e]);
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x)
+        out[t] = T ? gf_pack_weights_t_elem(tb.w[e], K, Cin, Cout, NCH, NCB, tb.flip[e], t)
+                   : gf_pack_weights_elem(tb.w[e], Cin, Cout, NCH, NCB, t);
 }
 
 struct ConvGeom {  // one convolution op resolved against the step's levels
@@ -106,13 +128,12 @@ extern "C" size_t gf_unet_train_scratch_floats(const GfTrainOp* ops, int nops, c
         if (op.kind == 0) {
             const size_t f = gf_bn_train_scratch_floats(levels[op.level].M, op.Cin);
             if (f > bn) bn = f;
-        } else if (op.kind == 1) {
+        } else if (op.kind == 1) {  // every convolution's transposed pack has its own slot (packed in one launch)
             const int K = op.table == 0 ? 1 : (op.table == 1 ? 27 : 8);
-            const size_t f = gf_conv_packed_floats(K, op.Cout, op.Cin);
-            if (f > wt) wt = f;
+            wt += (gf_conv_packed_floats(K, op.Cout, op.Cin) + 63) & ~(size_t)63;
         }
     }
-    return ((bn + 63) & ~(size_t)63) + ((wt + 63) & ~(size_t)63) + 64;
+    return ((bn + 63) & ~(size_t)63) + wt + 64;
 }
 
 extern "C" int gf_unet_train_fwd(const GfTrainOp* ops, int op_begin, int op_end, const GfTrainLevel* levels,
@@ -120,6 +141,28 @@ extern "C" int gf_unet_train_fwd(const GfTrainOp* ops, int op_begin, int op_end,
     GF_CHECK_ARG(ops && levels && act && wp && stats && scratch && op_begin >= 0 && op_end >= op_begin,
                  "gf_unet_train_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
+    {  // the range's weights, packed for the MFMA B operand, in one launch per kPackMax convolutions
+        PackTable tb;
+        int n = 0;
+        size_t most = 0;
+        auto flush = [&]() {
+            if (n) hipLaunchKernelGGL(k_tr_pack_batch<false>, dim3(gf_div_up((long long)most, 256 * 4), n), dim3(256), 0, st, tb, wp);
+            n = 0;
+            most = 0;
+        };
+        for (int i = op_begin; i < op_end; i++) {
+            const GfTrainOp& op = ops[i];
+            if (op.kind != 1) continue;
+            ConvGeom g;
+            GF_CHECK_ARG(conv_geom(op, levels, g), "gf_unet_train_fwd: op %d: table %d", i, op.table);
+            tb.w[n] = op.w; tb.dst[n] = op.wp_off;
+            tb.K[n] = (short)g.K; tb.Cin[n] = (short)op.Cin; tb.Cout[n] = (short)op.Cout; tb.flip[n] = 0;
+            const size_t f4 = gf_conv_packed_floats(g.K, op.Cin, op.Cout) / 4;
+            if (f4 > most) most = f4;
+            if (++n == kPackMax) flush();
+        }
+        flush();
+    }
     for (int i = op_begin; i < op_end; i++) {
         const GfTrainOp& op = ops[i];
         if (op.kind == 0) {
@@ -132,9 +175,7 @@ extern "C" int gf_unet_train_fwd(const GfTrainOp* ops, int op_begin, int op_end,
             ConvGeom g;
             GF_CHECK_ARG(conv_geom(op, levels, g), "gf_unet_train_fwd: op %d: table %d", i, op.table);
             float* wpk = wp + op.wp_off;
-            int rc = gf_conv_pack_weights(op.w, g.K, op.Cin, op.Cout, wpk, stream);
-            if (rc != GF_OK) return rc;
-            rc = gf_conv_fwd(act[op.src], wpk, g.tbl, g.gmask, g.steps, g.K, g.rows_in, g.rows_out, g.ld, op.Cin, op.Cout,
+            int rc = gf_conv_fwd(act[op.src], wpk, g.tbl, g.gmask, g.steps, g.K, g.rows_in, g.rows_out, g.ld, op.Cin, op.Cout,
                              nullptr, nullptr, op.aux >= 0 ? act[op.aux] : nullptr, nullptr, nullptr, act[op.dst], stream);
             if (rc != GF_OK) return rc;
         } else if (op.kind == 2) {
@@ -167,6 +208,42 @@ extern "C" int gf_unet_train_bwd(const GfTrainOp* ops, int op_begin, int op_end,
             if (f > bn) bn = f;
         }
     float* wt = scratch + ((bn + 63) & ~(size_t)63);
+    long long wt_off[kPackMax * 4];
+    {
+        // the transposed (input-gradient) packs of the range in one launch, and ONE zero fill for the range's weight
+        // gradients (op order = pgrad order: the range is contiguous; gf_conv_wgrad_masked clears per convolution)
+        GF_CHECK_ARG(op_end - op_begin <= kPackMax * 4, "gf_unet_train_bwd: %d ops in a range", op_end - op_begin);
+        PackTable tb;
+        int n = 0;
+        size_t most = 0, off = 0;
+        long long p_lo = -1, p_hi = -1;
+        auto flush = [&]() {
+            if (n) hipLaunchKernelGGL(k_tr_pack_batch<true>, dim3(gf_div_up((long long)most, 256 * 4), n), dim3(256), 0, st, tb, wt);
+            n = 0;
+            most = 0;
+        };
+        for (int i = op_begin; i < op_end; i++) {
+            const GfTrainOp& op = ops[i];
+            wt_off[i - op_begin] = -1;
+            if (op.kind != 1) continue;
+            ConvGeom g;
+            GF_CHECK_ARG(conv_geom(op, levels, g), "gf_unet_train_bwd: op %d: table %d", i, op.table);
+            const long long pe = op.pgrad_off + (long long)g.K * op.Cin * op.Cout;
+            if (p_lo < 0 || op.pgrad_off < p_lo) p_lo = op.pgrad_off;
+            if (pe > p_hi) p_hi = pe;
+            if (op.no_dgrad) continue;
+            const size_t f = gf_conv_packed_floats(g.K, op.Cout, op.Cin);
+            wt_off[i - op_begin] = (long long)off;
+            tb.w[n] = op.w; tb.dst[n] = (long long)off;
+            tb.K[n] = (short)g.K; tb.Cin[n] = (short)op.Cin; tb.Cout[n] = (short)op.Cout; tb.flip[n] = (short)g.flip;
+            off += (f + 63) & ~(size_t)63;
+            if (f / 4 > most) most = f / 4;
+            if (++n == kPackMax) flush();
+        }
+        flush();
+        // (BatchNorm's dgamma / dbeta inside the span are written in full by their op afterwards)
+        if (p_hi > p_lo) GF_TRY(hipMemsetAsync(pgrad + p_lo, 0, (size_t)(p_hi - p_lo) * sizeof(float), st));
+    }
     for (int i = op_end - 1; i >= op_begin; i--) {
         const GfTrainOp& op = ops[i];
         GF_CHECK_ARG(ghas[op.dst], "gf_unet_train_bwd: op %d: no gradient for its output (buffer %d)", i, op.dst);
@@ -197,15 +274,13 @@ extern "C" int gf_unet_train_bwd(const GfTrainOp* ops, int op_begin, int op_end,
                 }
             }
             if (!op.no_dgrad) {
-                int rc = gf_conv_pack_weights_t(op.w, g.K, op.Cin, op.Cout, g.flip, wt, stream);
-                if (rc != GF_OK) return rc;
                 // (rows of the gradient = the forward's output rows; the residual epilogue adds what the source has)
-                rc = gf_conv_fwd(gy, wt, g.btbl, g.bgmask, g.bsteps, g.K, g.rows_out, g.rows_in, g.bld, op.Cout, op.Cin, nullptr,
+                int rc = gf_conv_fwd(gy, wt + wt_off[i - op_begin], g.btbl, g.bgmask, g.bsteps, g.K, g.rows_out, g.rows_in, g.bld, op.Cout, op.Cin, nullptr,
                                  nullptr, ghas[op.src] ? grad[op.src] : nullptr, nullptr, nullptr, grad[op.src], stream);
                 if (rc != GF_OK) return rc;
                 if (!ghas[op.src]) ghas[op.src] = 1;
             }
-            int rc = gf_conv_wgrad_masked(act[op.src], gy, g.tbl, g.gmask, g.K, g.rows_out, g.ld, op.Cin, op.Cout,
+            int rc = gf_conv_wgrad_masked_acc(act[op.src], gy, g.tbl, g.gmask, g.K, g.rows_out, g.ld, op.Cin, op.Cout,
                                           pgrad + op.pgrad_off, stream);
             if (rc != GF_OK) return rc;
         } else if (op.kind == 2) {

@@ -264,7 +264,7 @@ class _SegFn(torch.autograd.Function):
         seg = run.prog.segments[k]
         h = h.contiguous()
         assert h.dtype == torch.float32 and h.shape == (run.rows[run.prog.bufs[seg.in_buf][0]], run.prog.bufs[seg.in_buf][1])
-        run.keep.append(h)
+        run.keep.append(h.detach())  # (detached: the tensor's history leads back to the previous range's node -> this Run)
         run.act[seg.in_buf] = h.data_ptr()
         check(run.prog.lib.gf_unet_train_fwd(run.prog.ref, seg.begin, seg.end, run.levels_ref, run.act, run.wp_ptr,
                                              run.stats_ptr, run.scratch_ptr, stream_ptr()), "gf_unet_train_fwd")
@@ -279,7 +279,7 @@ class _SegFn(torch.autograd.Function):
         seg = run.prog.segments[k]
         run.ensure_grad()
         g = g.contiguous()
-        run.keep.append(g)
+        run.keep.append(g.detach())
         run.grad[seg.out_buf] = g.data_ptr()
         run.ghas[seg.out_buf] = 2  # the caller's tensor: never written into
         check(run.prog.lib.gf_unet_train_bwd(run.prog.ref, seg.begin, seg.end, run.levels_ref, run.act, run.grad, run.ghas,

@@ -180,6 +180,9 @@ int gf_conv_wgrad(const float* in, const float* dout, const int32_t* nbr, int K,
  * single neighbour are skipped -- 61 % of them on a scanned room's level 1.  gmask or nbr NULL: gf_conv_wgrad. */
 int gf_conv_wgrad_masked(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K, int M_out,
                          int ld, int Cin, int Cout, float* dW, void* stream);
+/* dW += ... : the same without the zero fill (a caller that clears all of a step's weight gradients at once). */
+int gf_conv_wgrad_masked_acc(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K,
+                             int M_out, int ld, int Cin, int Cout, float* dW, void* stream);
 
 /* The sparse U-Net in TRAINING mode (batch statistics, saved activations, backward) as a layer program run from native
  * code: GeoFormer.input_conv -> UBlock x7 -> output_layer with requires_grad (model/geoformer/geoformer.py:39-53,
