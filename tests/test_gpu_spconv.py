@@ -217,3 +217,24 @@ def test_spconv_modules_forward_backward(hip, oracle):
     for m, dW in zip(mods, dWs):
         got = m.weight.grad.cpu().numpy().reshape(dW.shape)
         assert np.abs(got - dW).max() < 2e-4 * max(1.0, float(np.abs(dW).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Cin,Cout", [(50_000, 32, 16), (3_001, 224, 112), (17, 64, 32)])
+def test_wgrad_without_table_is_xt_g(hip, M, Cin, Cout):
+    """gf_conv_wgrad_masked(_acc) with K = 1 and no table (a 1x1x1 convolution: the training executor's identity
+    branches): dW = X^T G on the tiled kernel, against float64; the _acc form adds to what dW holds."""
+    from geoformer_amd import _lib
+    from geoformer_amd._lib import check, ptr, stream_ptr
+
+    g = torch.Generator(device="cuda").manual_seed(M)
+    x = torch.randn(M, Cin, device="cuda", generator=g)
+    gy = torch.randn(M, Cout, device="cuda", generator=g)
+    want = (x.double().t() @ gy.double())
+    lib = _lib.load()
+    dW = torch.full((1, Cin, Cout), 7.0, device="cuda")
+    check(lib.gf_conv_wgrad_masked(ptr(x), ptr(gy), None, None, 1, M, 0, Cin, Cout, ptr(dW), stream_ptr()), "wgrad")
+    tol = 1e-5 * float(want.abs().max()) + 1e-4
+    assert float((dW[0].double() - want).abs().max()) <= tol
+    check(lib.gf_conv_wgrad_masked_acc(ptr(x), ptr(gy), None, None, 1, M, 0, Cin, Cout, ptr(dW), stream_ptr()), "wgrad")
+    assert float((dW[0].double() - 2 * want).abs().max()) <= 2 * tol
