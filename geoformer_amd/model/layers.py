@@ -147,7 +147,9 @@ def _pointwise(w, x):
     """W x[b] for w [Co,Ci], x [B,Ci,L] as a batched product.  (``torch.matmul`` of a 2-D with a 3-D operand folds the
     batch into the rows of x^T: a transposing copy of x going in and of y coming out, 80 us each over the set
     abstraction's 16.7 M group values.)"""
-    return torch.matmul(w.unsqueeze(0), x)
+    # (bmm on the broadcast weight, not matmul: matmul folds whenever the small operand requires grad -- also inside an
+    # autograd function's forward, where that is only the tensor's flag)
+    return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
 
 
 class _PointwiseSplitKFn(torch.autograd.Function):
