@@ -88,7 +88,7 @@ class Program:
         self.segments.append(self.seg)
 
     def _param(self, p, off, n):
-        assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad
+        assert p.dtype == torch.float32 and p.is_contiguous() and p.requires_grad  # (on the GPU: `supported`)
         self.seg.params.append(p)
         self.seg.grads.append((off, n, tuple(p.shape)))
 

@@ -59,3 +59,41 @@ def test_geoformer_fs_state_dict_and_episode_cpu(oracle):
     assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 42706
     with cpu_backend.installed():
         check_fs_episode(*run_fs_episode("cpu"))
+
+
+def test_unet_train_program_covers_the_module_tree():
+    """The training layer program (geoformer_amd/unet_train.py) compiled from the module tree on the host: one op per
+    convolution / BatchNorm + ReLU pair / concatenation of input_conv -> UBlock x7 -> output_layer
+    (geoformer.py:39-53, geoformer_modules.py:10-35,52-129), three ranges around the two voxel transformers, every
+    U-Net parameter outside the transformers with exactly one gradient slot."""
+    from geoformer_amd import unet_train as ut
+    from geoformer_amd.model import GeoFormer, load_config
+    from geoformer_amd.spconv import SubMConv3d, SparseConv3d, SparseInverseConv3d
+
+    m = GeoFormer(load_config("geoformer_scannet.yaml"))
+    P = ut.Program(m)
+    mods = [mod for top in (m.input_conv, m.unet, m.output_layer) for mod in top.modules()]
+    convs = [mod for mod in mods if isinstance(mod, (SubMConv3d, SparseConv3d, SparseInverseConv3d))]
+    bns = [mod for mod in mods if isinstance(mod, torch.nn.BatchNorm1d)]
+    kinds = [op.kind for op in P.ops]
+    assert kinds.count(ut.CONV) == len(convs) == 71 and kinds.count(ut.BN_RELU) == len(bns) == 65
+    assert kinds.count(ut.CAT) == 6 and P.nlevels == 7
+    assert [(s.begin, s.end) for s in P.segments] == [(0, 69), (69, 81), (81, 142)]
+    assert [s.transformer is not None for s in P.segments] == [True, True, False]
+    # every op reads buffers that exist already and writes a new one; rows per buffer follow the level
+    seen = {P.segments[0].in_buf} | {s.in_buf for s in P.segments}
+    for op in P.ops:
+        assert op.src in seen and (op.aux < 0 or op.aux in seen) and op.dst not in seen
+        seen.add(op.dst)
+    # parameters: each exactly once, gradient slots disjoint and inside the buffer
+    params = [p for s in P.segments for p in s.params]
+    tr = {id(p) for u in (m.unet.u.u.u.u.u, m.unet.u.u.u.u.u.u)
+          for mod in (u.before_transformer_linear, u.transformer, u.after_transformer_linear) for p in mod.parameters()}
+    want = [p for top in (m.input_conv, m.unet, m.output_layer) for p in top.parameters() if id(p) not in tr]
+    assert len(params) == len(want) and {id(p) for p in params} == {id(p) for p in want}
+    slots = sorted((o, n) for s in P.segments for o, n, _ in s.grads)
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(slots, slots[1:])) and slots[-1][0] + slots[-1][1] <= P.pgrad_floats
+    assert sum(n for _, n in slots) == sum(p.numel() for p in want)
+    # the residual operand of a block's second convolution is the block's input or its 1x1x1 identity convolution
+    res = [op for op in P.ops if op.kind == ut.CONV and op.aux >= 0]
+    assert len(res) == 26
