@@ -1659,111 +1659,6 @@ extern "C" int gf_conv_wgrad(const float* in, const float* dout, const int32_t* 
     return conv_wgrad_impl(in, dout, nbr, K, M_out, ld, Cin, Cout, dW, true, stream);
 }
 
-// Offset-stationary form for the large levels: a workgroup owns ONE 16 x 16 tile pair and a slice of groups, its four
-// waves walk the slice's groups, and a group's gradient rows are read ONCE for all of its present offsets; the 27
-// per-offset accumulators live in LDS (ds_add_f32 of each step's 16 x 16 product) because the offset is a run-time
-// index.  Per (group, offset): four 4-byte gathers per lane (the MFMA's own operand orientation, no LDS transposition),
-// indices staged in LDS as in the forward kernel, steps issued PF at a time.  L2 traffic per tile pair: pairs x 64 B +
-// rows x 64 B instead of (pairs + padded rows) x 128 B per offset.
-#ifndef WGK_PF
-#define WGK_PF 4
-#endif
-__global__ __launch_bounds__(256) void k_conv_wgrad_ks(const float* __restrict__ in, const float* __restrict__ dout,
-                                                       const int32_t* __restrict__ nbr,
-                                                       const uint32_t* __restrict__ gmask, int K, int M_out, int ld,
-                                                       int Cin, int Cout, int NCI, int NCO, int gps,
-                                                       float* __restrict__ dW) {
-    __shared__ float s_acc[27 * 256];
-    __shared__ int s_idx[4][27 * 16];
-    __shared__ int s_kl[4][32];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
-    int item = blockIdx.x;
-    const int cob = item % NCO;
-    item /= NCO;
-    const int cib = item % NCI;
-    const int sl = item / NCI;
-    for (int t = threadIdx.x; t < K * 256; t += 256) s_acc[t] = 0.f;
-    __syncthreads();
-    const int ngroups = (M_out + 15) >> 4;
-    const int g_end = min(ngroups, (sl + 1) * gps);
-    const float* inc = in + cib * 16 + r;
-    const float* doc = dout + cob * 16 + r;
-    int* idx_l = s_idx[w];
-    for (int g = sl * gps + w; g < g_end; g += 4) {
-        uint32_t mask = gmask ? gmask[g] : ((1u << K) - 1u);
-        mask = __builtin_amdgcn_readfirstlane(mask);
-        if (!mask) continue;
-        // the group's gradient rows in the B-operand orientation: lane (r, q) holds G[row 4q + j][co = r]
-        float b[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int row = g * 16 + 4 * q + j;
-            b[j] = row < M_out ? doc[(size_t)row * Cout] : 0.f;
-        }
-        {
-            int iv[7];
-            const int o = g * 16 + r;
-#pragma unroll
-            for (int i = 0; i < 7; i++) {
-                const int k = q + 4 * i;
-                const bool want = k < K && ((mask >> k) & 1u) && o < M_out;
-                iv[i] = want ? (nbr ? nbr[(size_t)k * ld + o] : o) : -1;
-            }
-#pragma unroll
-            for (int i = 0; i < 7; i++) {
-                const int k = q + 4 * i;
-                if (k < K) idx_l[k * 16 + r] = iv[i];
-            }
-        }
-        if (lane < 32 && ((mask >> lane) & 1u)) s_kl[w][__popc(mask & ((1u << lane) - 1u))] = lane;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int ns = __popc(mask);
-        for (int s0 = 0; s0 < ns; s0 += WGK_PF) {
-            float a[WGK_PF][4];
-            int kq[WGK_PF];
-#pragma unroll
-            for (int p = 0; p < WGK_PF; p++) {
-                kq[p] = __builtin_amdgcn_readfirstlane(s_kl[w][min(s0 + p, ns - 1)]);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int i = idx_l[kq[p] * 16 + 4 * q + j];
-                    const float v = inc[(size_t)(i >= 0 ? i : 0) * Cin];
-                    a[p][j] = i >= 0 ? v : 0.f;
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < WGK_PF; p++) {
-                if (s0 + p < ns) {
-                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][j], b[j], acc, 0, 0, 0);
-                    // D layout: row (input channel) = 4q + jj, col (output channel) = r
-                    float* dst = s_acc + kq[p] * 256 + (4 * q) * 16 + r;
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) atomicAdd(dst + jj * 16, acc[jj]);
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // the next group's index writes stay behind this group's reads
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < K * 256; t += 256) {
-        const float v = s_acc[t];
-        if (v != 0.f) {
-            const int k = t >> 8, e = t & 255;
-            atomicAdd(&dW[((size_t)k * Cin + cib * 16 + (e >> 4)) * Cout + cob * 16 + (e & 15)], v);
-        }
-    }
-}
-
-static int g_wgrad_ks = -1;  // dev knob: -1 by size, 0 never, 1 whenever the shape allows
-extern "C" int gf_dev_conv_wgrad_ks(int mode) {
-    g_wgrad_ks = mode;
-    return GF_OK;
-}
-
 static int conv_wgrad_masked_impl(const float* in, const float* dout, const int32_t* nbr, const uint32_t* gmask, int K,
                                   int M_out, int ld, int Cin, int Cout, float* dW, bool zero, void* stream) {
     // (K == 1 without a table -- a 1x1x1 convolution -- takes the tiled kernel as well: every group present, rows as
@@ -1771,23 +1666,6 @@ static int conv_wgrad_masked_impl(const float* in, const float* dout, const int3
     if (((gmask == nullptr || nbr == nullptr) && !(K == 1 && nbr == nullptr)) || (Cin & 15) || (Cout & 15))
         return conv_wgrad_impl(in, dout, nbr, K, M_out, ld, Cin, Cout, dW, zero, stream);
     if (nbr == nullptr) gmask = nullptr;
-    {
-        const int ngroups = (M_out + 15) / 16;
-        const bool fits = K <= 27;
-        if (fits && (g_wgrad_ks == 1 || (g_wgrad_ks < 0 && ngroups >= 2048))) {
-            hipStream_t st = (hipStream_t)stream;
-            if (zero) GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));
-            if (M_out <= 0) return GF_OK;
-            const int pairs = (Cin / 16) * (Cout / 16);
-            int gps = 64;  // groups per workgroup: fewer where the launch would not fill the chip
-            while (gps > 8 && (long long)gf_div_up(ngroups, gps) * pairs < 1024) gps >>= 1;
-            const long long nwg = (long long)gf_div_up(ngroups, gps) * pairs;
-            hipLaunchKernelGGL(k_conv_wgrad_ks, dim3((unsigned)nwg), dim3(256), 0, st, in, dout, nbr, gmask, K, M_out, ld, Cin,
-                               Cout, Cin / 16, Cout / 16, gps, dW);
-            GF_CHECK_LAUNCH("gf_conv_wgrad_masked");
-            return GF_OK;
-        }
-    }
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_wgrad_masked: K=%d (at most 32 offsets)", K);
     hipStream_t st = (hipStream_t)stream;
     if (zero) GF_TRY(hipMemsetAsync(dW, 0, (size_t)K * Cin * Cout * sizeof(float), st));

@@ -59,10 +59,6 @@ int gf_dev_unet_probe_read2(int max_records, int* meta, float* us, float* us_ker
 int gf_dev_conv_kernel_events(void* start, void* stop);
 int gf_dev_conv_kernel_events_taken(void);
 
-/* Weight gradient: the offset-stationary kernel (k_conv_wgrad_ks) -1 by size (default), 0 never, 1 whenever the shape
- * allows (channel multiples of 16, K <= 27). */
-int gf_dev_conv_wgrad_ks(int mode);
-
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);
 
