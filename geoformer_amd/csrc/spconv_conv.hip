@@ -397,6 +397,164 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
     }
 }
 
+// Flat-chain form for the deep levels (a few hundred items at most: S150k levels 5-7 and every strided / inverse /
+// 1x1x1 launch between them).  Such a launch is ONE dependent chain per workgroup and nothing else -- the chip is
+// nearly empty -- so what it costs is the number of memory round trips in that chain, ~1 us each after the kernel
+// boundary's cache invalidation.  k_conv_os<1,16> has eight of them in a row: prologue vectors -> (barrier) -> group
+// mask -> neighbour indices -> (LDS) -> first batch of gathers and weights -> second batch -> (barrier) -> epilogue
+// vectors -> store.  Here a workgroup's sixteen waves take the item's steps (offset k, 16-channel chunk c) = s,
+// s + 16, ... over ALL K offsets -- no group mask, an absent offset is a step of zeros: 10-25 % more steps on these
+// levels, each ~0.1 us of MFMA -- which makes every address of the chain known at launch: prologue / epilogue vectors,
+// residual rows, ALL neighbour indices of the wave's steps and the weights of its first two batches are requested
+// together, the gathers follow as one dependent round trip (two batches of FLAT_PF steps in flight, the later ones
+// behind the MFMAs), then the LDS reduction over the waves and the store: three round trips.
+#define FLAT_PF 4
+#define FLAT_MAXB 4  // batches per wave: K * NCH <= 16 * FLAT_PF * FLAT_MAXB = 256 steps per item
+__global__ __launch_bounds__(1024, 1) void k_conv_flat(const float* __restrict__ in, const float4* __restrict__ Wp,
+                                                       const int32_t* __restrict__ nbr, int K, int M_out, int ld, int Cin,
+                                                       int Cout, int NCH, int NCB, unsigned in_bytes,
+                                                       const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                       const float* __restrict__ residual, const float* __restrict__ out_scale,
+                                                       const float* __restrict__ out_shift, float* __restrict__ out) {
+    constexpr int PF = FLAT_PF, MAXB = FLAT_MAXB;
+    __shared__ float4 s_red[16 * 64];
+    __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int g = blockIdx.x / NCB, cb = blockIdx.x - g * NCB;
+    const int o = g * 16 + r;
+    const bool row_ok = o < M_out;
+    const int nsteps = K * NCH;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, K * NCH * NCB * 1024, 0x00020000);
+    const unsigned rowbytes = (unsigned)Cin * 4u;
+    const unsigned inv_nch = (65536u + (unsigned)NCH - 1u) / (unsigned)NCH;  // s / NCH for s < 4096, NCH <= 16
+
+    // ---- everything whose address is known now ----
+    float av_s = 0.f, av_t = 0.f;
+    const int tch = threadIdx.x;
+    if (in_scale && tch < NCH * 16 && tch < Cin) {
+        av_s = in_scale[tch];
+        av_t = in_shift[tch];
+    }
+    float res[4] = {0.f, 0.f, 0.f, 0.f};
+    float osc = 1.f, osh = 0.f;
+    const int col = cb * 16 + r;
+    if (w == 0 && col < Cout) {
+        if (residual) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = g * 16 + q * 4 + j;
+                if (row < M_out) res[j] = residual[(size_t)row * Cout + col];
+            }
+        }
+        if (out_scale) {
+            osc = out_scale[col];
+            osh = out_shift[col];
+        }
+    }
+    int idx[MAXB * PF];
+    int kk[MAXB * PF], cc[MAXB * PF];  // uniform (scalar registers)
+#pragma unroll
+    for (int j = 0; j < MAXB * PF; j++) {
+        const int s = w + 16 * j;
+        const int sj = min(s, nsteps - 1);
+        kk[j] = (int)(((unsigned)sj * inv_nch) >> 16);
+        cc[j] = sj - kk[j] * NCH;
+        idx[j] = -1;
+        if (s < nsteps && row_ok) idx[j] = nbr ? nbr[(size_t)kk[j] * ld + o] : o;
+    }
+    float4 a[2][PF], b[2][PF];
+    auto issue_w = [&](int bt) {  // weights of batch bt (uniform block, lane's 16 bytes)
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const int e = bt * PF + j;
+            const unsigned wblk = (unsigned)((kk[e] * NCH + cc[e]) * NCB + cb);
+            // (a step past the wave's last one restates that one's block: loaded, never multiplied)
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (unsigned)lane * 16u, wblk * 1024u, 0);
+            b[bt & 1][j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    auto issue_a = [&](int bt) {  // gathers of batch bt (a missing neighbour is out of the descriptor's range: zeros)
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const int e = bt * PF + j;
+            const unsigned voff = idx[e] >= 0 ? (unsigned)idx[e] * rowbytes + (unsigned)(cc[e] * 64 + q * 16) : 0xffffffffu;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+            a[bt & 1][j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+    };
+    const int nb = w < nsteps ? ((nsteps - w + 15) / 16 + PF - 1) / PF : 0;  // batches of this wave (uniform)
+    if (nb > 0) issue_w(0);
+    if (nb > 1) issue_w(1);
+    if (nb > 0) issue_a(0);
+    if (nb > 1) issue_a(1);
+    const float* sc_l = nullptr;
+    const float* sh_l = nullptr;
+    if (in_scale) {  // workgroup-uniform
+        if (tch < NCH * 16) {
+            s_aff[0][tch] = av_s;
+            s_aff[1][tch] = av_t;
+        }
+        __syncthreads();
+        sc_l = s_aff[0];
+        sh_l = s_aff[1];
+    }
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int bt = 0; bt < MAXB; bt++) {
+        if (bt < nb) {
+#pragma unroll
+            for (int j = 0; j < PF; j++) {
+                const int e = bt * PF + j;
+                if (w + 16 * e < nsteps) {
+                    float4 av = a[bt & 1][j];
+                    if (sc_l) av = activate_a(av, idx[e] >= 0, sc_l, sh_l, cc[e] * 16 + 4 * q);
+                    const float4 bb = b[bt & 1][j];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bb.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bb.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bb.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bb.w, acc, 0, 0, 0);
+                }
+            }
+            if (bt + 2 < MAXB && bt + 2 < nb) {
+                issue_w(bt + 2);
+                issue_a(bt + 2);
+            }
+        }
+    }
+    s_red[w * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    __syncthreads();
+    if (w != 0) return;
+    // fixed-order sum over the sixteen waves; C/D layout: col = lane & 15, row = (lane >> 4) * 4 + j
+    float4 t[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float4 p0 = s_red[(4 * e + 0) * 64 + lane];
+        const float4 p1 = s_red[(4 * e + 1) * 64 + lane];
+        const float4 p2 = s_red[(4 * e + 2) * 64 + lane];
+        const float4 p3 = s_red[(4 * e + 3) * 64 + lane];
+        t[e] = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                           (p0.w + p1.w) + (p2.w + p3.w));
+    }
+    const float v[4] = {(t[0].x + t[1].x) + (t[2].x + t[3].x), (t[0].y + t[1].y) + (t[2].y + t[3].y),
+                        (t[0].z + t[1].z) + (t[2].z + t[3].z), (t[0].w + t[1].w) + (t[2].w + t[3].w)};
+    if (col < Cout) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int row = g * 16 + q * 4 + j;
+            if (row < M_out) {
+                float x = v[j];
+                if (residual) x += res[j];
+                if (out_scale) x = fmaxf(fmaf(x, osc, osh), 0.f);
+                out[(size_t)row * Cout + col] = x;
+            }
+        }
+    }
+}
+
 // Two 16-row groups per wave for the big 16-output-channel levels (level 1 of the U-Net: ~9000 groups).
 // Measured on the S150k level-1 launch (variants with parts compiled out, rocprofv3 kernel trace): index staging +
 // output 4.3 us, gathers 3.3 us, weight fetches 0.3 us, and 13.8 us for the loop WITHOUT any memory access, i.e. the
@@ -1224,6 +1382,7 @@ struct ConvKnobs {
     int split = -1, wide = -1, block = 0, ldsw = 0, pair = -1;  // -1 / 0: not set
     int g16 = -1, g16_ldsw = -1, g16_gpw = 0;                   // counted-loop kernel: use / weights in LDS / groups per wave
     int g16_pipe = -1;                                          // its pipelined form (one chunk of groups per wave)
+    int flat = -1, flat_items = 0;                              // flat-chain kernel: use / item bound of the size-based choice
     ConvKnobs() {
         if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
         if (const char* e = getenv("GF_CONV_WIDE")) wide = atoi(e) != 0;
@@ -1249,6 +1408,12 @@ extern "C" int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe) {
     k.g16 = use < 0 ? -1 : (use != 0);
     k.g16_ldsw = ldsw < 0 ? -1 : (ldsw != 0);
     k.g16_gpw = gpw > 0 ? gpw : 0;
+    return GF_OK;
+}
+extern "C" int gf_dev_conv_knob_flat(int use, int max_items) {
+    ConvKnobs& k = conv_knobs_mut();
+    k.flat = use < 0 ? -1 : (use != 0);
+    k.flat_items = max_items > 0 ? max_items : 0;
     return GF_OK;
 }
 extern "C" int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int block) {
@@ -1292,6 +1457,10 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
     // of gather batches is 4x shorter again (S150k levels 5-7: 13.5/15.8/16.0 -> 10.6/11.4/11.5 us)
     bool wide = split && (long long)ngroups * ncb <= 256;
     if (knobs.wide >= 0) wide = split && knobs.wide != 0;
+    // the flat-chain kernel wherever the wide shape would go (every address known at launch: k_conv_flat)
+    const bool flat_ok = vec && nch <= 16 && K * nch <= 16 * FLAT_PF * FLAT_MAXB && in_bytes64 < 0xfffffff0ull;
+    bool flat = flat_ok && (knobs.flat < 0 ? (split && (long long)ngroups * ncb <= (knobs.flat_items > 0 ? knobs.flat_items : 256))
+                                           : knobs.flat != 0);
     const int ncbw = split ? (!wide && ncb >= 2 && ngroups >= 2048 ? 2 : 1) : (ncb > 8 ? 8 : ncb);
     const int nsplit = (ncb + ncbw - 1) / ncbw;
     const long long nitems = (long long)ngroups * nsplit;
@@ -1313,6 +1482,12 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
                (residual == nullptr || (((uintptr_t)residual) % 16) == 0) && in_bytes64 <= 0xffffff00ull;
     if (knobs.g16 >= 0) g16 = g16 && knobs.g16 != 0;
     else g16 = g16 && !split;
+    if (flat && (nbr != nullptr || K == 1) && out2 == nullptr) {
+        hipLaunchKernelGGL(k_conv_flat, dim3((unsigned)((long long)ngroups * ncb)), dim3(1024), 0, st, a.in, a.Wp, a.nbr, a.K,
+                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
+        GF_CHECK_LAUNCH("gf_conv_fwd");
+        return GF_OK;
+    }
     if (g16) {
         bool gl = wbytes <= 64 * 1024;
         if (knobs.g16_ldsw >= 0) gl = gl && knobs.g16_ldsw != 0;

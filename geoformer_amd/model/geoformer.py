@@ -59,6 +59,10 @@ def _bfs_wg(nq, scenes=1):
     if _BFS_WG:
         return _BFS_WG
     return 1024 if nq * scenes <= 224 else 512
+# Side streams of the sampling / BFS stretch, keyed by (device, caller stream, role): a process resource, not a model's --
+# a second model instance taking fresh streams from the framework's pool measured 6.0 against 4.5 ms per scene on the
+# nq = 128 forward (bench.py's secondary leg; which hardware queue a stream lands on depends on what was created before it)
+_SIDE_STREAMS = {}
 _OFFS_CACHE = threading.local()  # per thread: concurrent scenes run on separate host threads / streams
 
 
@@ -466,7 +470,7 @@ class GeoFormer(nn.Module):
         npoint_sa = self.set_aggregator.npoint
         split = os.environ.get("GF_OVERLAP", "1") != "2" and npoint_sa > nq
         main = torch.cuda.current_stream()
-        sides = self.__dict__.setdefault("_gf_side_streams", {})  # one per caller stream: scenes in flight on
+        sides = _SIDE_STREAMS  # process-wide, one set per caller stream: scenes in flight on
         side = sides.get((locs_float_.device, main.cuda_stream))   # different streams do not queue behind each other
         if side is None:
             side = torch.cuda.Stream(device=locs_float_.device)  # (stream priorities made no difference: measured)

@@ -143,6 +143,7 @@ def supported(model, voxel_feats, spatial_shape):
 
 
 _tls = threading.local()
+_SIDE_STREAMS = {}  # (device, caller stream) -> the executor's side stream
 
 
 def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
@@ -163,7 +164,7 @@ def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     if pinned is None:
         pinned = _tls.counts = torch.zeros(MAX_LEVELS + 1, dtype=torch.int32).pin_memory()
     main = torch.cuda.current_stream(dev)
-    sides = model.__dict__.setdefault("_gf_unet_side", {})
+    sides = _SIDE_STREAMS  # process-wide (geoformer._SIDE_STREAMS: why)
     side = sides.get((dev, main.cuda_stream))
     if side is None:
         side = sides[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)

@@ -33,6 +33,11 @@ int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int block);
  * default on).  Environment: GF_CONV_G16 / _G16_LDSW / _G16_GPW / _G16_PIPE. */
 int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe);
 
+/* The flat-chain kernel of the deep levels (k_conv_flat): use 0 / 1 (whenever the shape allows: 16-channel multiples,
+ * K * Cin / 16 <= 256) / -1 = size based, i.e. launches of at most max_items (group, column block) items (0 = the
+ * default bound of 256). */
+int gf_dev_conv_knob_flat(int use, int max_items);
+
 /* Number of equal-cost chunks (= waves of the pipelined kernel) the NEXT rulebooks are built with: a multiple of 4,
  * at most 4096; 0 = default (3072 = 12 waves per compute unit). */
 int gf_dev_conv_chunks(int n);

@@ -184,6 +184,8 @@ KNOBS = [dict(split=0, pair=1, g16=0), dict(split=0, pair=0, g16=0), dict(split=
          # through to the size-based choice): plain, LDS weights, several groups per wave, pipelined over chunks
          dict(g16=1, g16_ldsw=0, g16_pipe=0), dict(g16=1, g16_ldsw=1, g16_pipe=0, g16_gpw=3),
          dict(g16=1, g16_ldsw=0, g16_pipe=1), dict(g16=1, g16_ldsw=1, g16_pipe=1)]
+# none of the above may fall into the flat-chain kernel of the deep levels (size-based for small inputs); it is a shape of its own
+KNOBS = [dict(k, flat=0) for k in KNOBS] + [dict(flat=1)]
 
 
 @pytest.mark.parametrize("Cin,Cout", [(16, 16), (32, 16), (6, 16), (32, 32), (48, 64), (19, 21)])
