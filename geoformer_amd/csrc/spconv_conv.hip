@@ -207,12 +207,28 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
     }
     const float* sc_l = nullptr;
     const float* sh_l = nullptr;
+    // SPLIT (all waves of the workgroup walk the same items): the prologue vectors are only REQUESTED here and land in
+    // LDS behind the first item's mask / index requests -- one memory round trip for the three instead of two
+    float av_s[2] = {0.f, 0.f}, av_t[2] = {0.f, 0.f};
+    bool aff_pending = false;
     if (in_scale) {  // workgroup-uniform
-        for (int c = threadIdx.x; c < NCH * 16; c += blockDim.x) {
-            s_aff[0][c] = c < Cin ? in_scale[c] : 0.f;
-            s_aff[1][c] = c < Cin ? in_shift[c] : 0.f;
+        if (SPLIT && NCH * 16 <= 2 * (int)blockDim.x) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int c = threadIdx.x + e * blockDim.x;
+                if (c < Cin) {
+                    av_s[e] = in_scale[c];
+                    av_t[e] = in_shift[c];
+                }
+            }
+            aff_pending = true;
+        } else {
+            for (int c = threadIdx.x; c < NCH * 16; c += blockDim.x) {
+                s_aff[0][c] = c < Cin ? in_scale[c] : 0.f;
+                s_aff[1][c] = c < Cin ? in_shift[c] : 0.f;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         sc_l = s_aff[0];
         sh_l = s_aff[1];
     }
@@ -240,16 +256,38 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
                 }
         }
         uint32_t mask = nbr ? (gmask ? gmask[g] : ((K >= 32) ? 0xffffffffu : ((1u << K) - 1u))) : 1u;
-        mask = __builtin_amdgcn_readfirstlane(mask);
-        // stage the neighbour indices of the present offsets (lane (r,q) fetches offsets q, q+4, ...): all loads
-        // first -- one memory round trip instead of up to eight dependent ones -- then the LDS writes
+        // epilogue vectors of this lane's columns, requested with everything else
+        float osc_r[NCBW <= 2 ? NCBW : 1], osh_r[NCBW <= 2 ? NCBW : 1];
+        if (NCBW <= 2) {
+#pragma unroll
+            for (int cb = 0; cb < (NCBW <= 2 ? NCBW : 1); cb++) {
+                const int col = (cb0 + cb) * 16 + r;
+                osc_r[cb] = (out_scale && col < Cout) ? out_scale[col] : 1.f;
+                osh_r[cb] = (out_scale && col < Cout) ? out_shift[col] : 0.f;
+            }
+        }
+        // stage the neighbour indices (lane (r,q) fetches offsets q, q+4, ...): all loads first -- one memory round trip
+        // instead of up to eight dependent ones -- then the LDS writes.  The requests do not wait for the group mask (an
+        // absent offset's entries are all -1 in the table anyway): mask and indices share a round trip
         {
             int iv[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int k = q + 4 * i;
-                const bool want = k < K && ((mask >> k) & 1u) && row_ok;
+                const bool want = k < K && row_ok;
                 iv[i] = want ? (nbr ? nbr[(size_t)k * ld + o] : o) : -1;
+            }
+            if (aff_pending) {  // workgroup-uniform, first item only
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int c = threadIdx.x + e * blockDim.x;
+                    if (c < NCH * 16) {
+                        s_aff[0][c] = av_s[e];
+                        s_aff[1][c] = av_t[e];
+                    }
+                }
+                __syncthreads();
+                aff_pending = false;
             }
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -260,6 +298,7 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
         // the steps of the item are (present offset i, chunk c), numbered s = i*NCH + c; a wave takes s = first, first +
         // stride, ...  (plain index arithmetic: the earlier bit-scanning iterator cost ~20 scalar branches per
         // step, 0.26 us per step and wave on the small levels -- more than the step's memory round trip)
+        mask = __builtin_amdgcn_readfirstlane(mask);
         if (lane < 32 && ((mask >> lane) & 1u)) s_kl[w][__popc(mask & ((1u << lane) - 1u))] = lane;
         __builtin_amdgcn_wave_barrier();
         const int nsteps = __popc(mask) * NCH;
@@ -381,8 +420,8 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
             }
             const int col = (cb0 + cb) * 16 + r;
             // epilogue activation (the consumer's eval-mode BatchNorm + ReLU applied once per output element)
-            const float osc = (out_scale && col < Cout) ? out_scale[col] : 1.f;
-            const float osh = (out_scale && col < Cout) ? out_shift[col] : 0.f;
+            const float osc = NCBW <= 2 ? osc_r[NCBW <= 2 ? cb : 0] : ((out_scale && col < Cout) ? out_scale[col] : 1.f);
+            const float osh = NCBW <= 2 ? osh_r[NCBW <= 2 ? cb : 0] : ((out_scale && col < Cout) ? out_shift[col] : 0.f);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int row = g * 16 + q * 4 + j;
