@@ -656,6 +656,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=8, help="resident scenes the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="one scene at a time on one stream instead of two staggered scenes in flight")
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -679,7 +681,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from geoformer_amd import scene
+    from geoformer_amd import scene, serving
 
     if os.environ.get("GF_CONV_CHUNKS"):  # dev knob: waves of the level-1 conv kernel (include/geoformer_hip_dev.h)
         from geoformer_amd import sparse
@@ -694,26 +696,42 @@ def main():
     probe = ConvProbe(batches)
 
     class Loop:
-        """One scene per step.  The forward queues everything up to the copy of the accepted-proposal count and
-        returns (defer_proposals); the proposals of scene i are collected -- count read, membership scatter queued --
-        right after scene i+1 has been issued, when that count has long reached the host, so the loop never sits in
-        the forward's last read-back.  Every scene's outputs, proposals included, are complete when `finish` returns."""
+        """One scene per step.  Default: two scenes in flight, staggered (geoformer_amd/serving.py: scene i's decoder +
+        mask head run under scene i+1's sampling / BFS stretch, scene i+1's backbone starts when scene i's stretch has
+        ended).  --no-pipeline: one scene at a time on the current stream, scene i's proposals collected after scene
+        i+1 is issued (the loop of rounds 1-3).  Every scene's outputs, proposals included, are complete when `finish`
+        returns."""
 
         def __init__(self):
             self.prev = None
+            self.last = None
+            self.stag = {}
 
         def step(self, i, m=model):
             np.random.seed(1000 + i)
-            with torch.no_grad():
-                out = m(batches[i % ns], 300, training=False, defer_proposals=True)
-            self.finish()
-            self.prev = out
-            return out
+            if not args.pipeline:
+                with torch.no_grad():
+                    out = m(batches[i % ns], 300, training=False, defer_proposals=True)
+                self._collect()
+                self.prev = self.last = out
+                return out
+            st = self.stag.get(id(m))
+            if st is None:
+                st = self.stag[id(m)] = serving.StaggeredForward(m, dev)
+            out = st.submit(batches[i % ns])
+            if out is not None:
+                self.last = out
 
-        def finish(self):
+        def _collect(self):
             if self.prev is not None and not isinstance(self.prev.get("proposal_scores"), (tuple, type(None))):
                 self.prev["proposal_scores"] = self.prev["proposal_scores"].get()
             self.prev = None
+
+        def finish(self):
+            self._collect()
+            for st in self.stag.values():
+                for out in st.drain():
+                    self.last = out
 
     loop = Loop()
     step = loop.step
@@ -751,7 +769,7 @@ def main():
         dp = train_dp.run(train_dp.default_args(steps=5, warmup=2, batch_size=4, epoch=200, prepare_epochs=120, fg_frac=0.4), dev)
         torch.cuda.empty_cache()
     if rank == 0:
-        n_fg = int(out["fg_idxs"].shape[0])
+        n_fg = int(loop.last["fg_idxs"].shape[0])
         res = {
             "metric": "scenes/sec forward (ScanNetV2 ~150k pts)",
             "value": round(world * args.steps / elapsed, 3),
@@ -767,7 +785,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"S150k eval forward, batch=1 per GPU, rotating over {ns} resident scenes, "
                                    "config/test_geoformer_scannet.yaml (nq=256, nc=2048, 4 decoder layers), "
-                                   "random-init weights; proposals of scene i collected after scene i+1 is issued",
+                                   "random-init weights; " +
+                                   ("two scenes in flight on two streams, staggered (geoformer_amd/serving.py): scene i's "
+                                    "decoder + mask head run under scene i+1's sampling / BFS stretch, scene i+1's backbone "
+                                    "starts when scene i's stretch has ended; all scenes complete inside the timed region"
+                                    if args.pipeline else
+                                    "one scene at a time, proposals of scene i collected after scene i+1 is issued"),
                        "points": [int(b["locs"].shape[0]) for b in batches], "voxels": Ms, "n_fg_last": n_fg,
                        "parallelism": f"replicas x{world}"},
             "roofline": probe.result(),

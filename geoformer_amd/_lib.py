@@ -111,6 +111,7 @@ def _declare(lib):
         "gf_decoder_wpack_floats": (c_size_t, []),
         "gf_decoder_pack_weights": (I, [P, P, P, P, P]),
         "gf_decoder_cross_attn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P]),
+        "gf_decoder_cross_attn_cfg": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, I, P]),
         "gf_decoder_cross_attn_bwd_scratch_floats": (c_size_t, [I, I, I]),
         "gf_decoder_cross_attn_bwd": (I, [P] * 16 + [I, I, I, I] + [P] * 6),
         "gf_bn_train_scratch_floats": (c_size_t, [I, I]),

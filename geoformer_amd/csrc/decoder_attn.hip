@@ -51,7 +51,12 @@ __device__ __forceinline__ float da_row_sum(float v) {
 // (48 values) stays in registers across tiles; the per-query constants (Q1 row, the lane's Fourier projections)
 // sit in LDS next to the weights.  b2 is not needed at all: the soft-max runs over the contexts separately for
 // every channel, and a per-channel constant cancels in it.
-__global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
+// WAVES = 8 (gf_decoder_cross_attn_cfg): half the contexts' tiles per wave more, but a 512-thread workgroup at 120
+// registers takes 240 of a SIMD's 512 -- it fits on a compute unit BESIDE a 512-thread BFS workgroup (144 registers, 75 KiB
+// of LDS), which the 16-wave shape does not: a serving loop runs the previous scene's decoder under the current
+// scene's sampling / BFS stretch that way (GeoFormer.forward_split; alone the 8-wave launch is 6 % slower).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn(
     const float* __restrict__ geo_ctx, const float* __restrict__ max_geo, const float* __restrict__ qloc,
     const float* __restrict__ cloc, const float* __restrict__ lo, const float* __restrict__ hi,
     const float* __restrict__ gaussB, const float* __restrict__ Q1, const float* __restrict__ K1,
@@ -60,10 +65,10 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
     __shared__ float4 sW[3 * 16 * 64];       // [3][4 rb][4 kb][64 lanes]
     __shared__ float4 sQ1[16];               // Q1 row of this query: channel rb*16 + 4g + r at [rb*4 + g]
     __shared__ float4 sB[3][2][4];           // sB[axis][half][g] = gaussB[axis][half*16 + 4g .. +3]
-    __shared__ float sRed[3][DA_WAVES][DA_D];
+    __shared__ float sRed[3][WAVES][DA_D];
     const int qi = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
-    for (int t = tid; t < 3 * 16 * 64; t += DA_WAVES * 64) sW[t] = Wpack[t];
+    for (int t = tid; t < 3 * 16 * 64; t += WAVES * 64) sW[t] = Wpack[t];
     if (tid < 16) sQ1[tid] = *reinterpret_cast<const float4*>(Q1 + ((size_t)b * nq + qi) * DA_D + tid * 4);
     if (tid >= 64 && tid < 64 + 24) {
         const int e = tid - 64, axis = e >> 3, half = (e >> 2) & 1, gg = e & 3;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
     __syncthreads();
 
     const int ntiles = (nc + 15) >> 4;
-    for (int t = w; t < ntiles; t += DA_WAVES) {
+    for (int t = w; t < ntiles; t += WAVES) {
         const int ctx = t * 16 + j;
         const bool valid = ctx < nc;
         const int cc = valid ? ctx : nc - 1;
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
     if (tid < DA_D) {
         float m = sRed[0][0][tid];
 #pragma unroll
-        for (int u = 1; u < DA_WAVES; u++) m = fmaxf(m, sRed[0][u][tid]);
+        for (int u = 1; u < WAVES; u++) m = fmaxf(m, sRed[0][u][tid]);
         sRed[0][0][tid] = m;
     }
     __syncthreads();
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(DA_WAVES * 64) void k_decoder_cross_attn(
     if (tid < DA_D) {
         float L = 0.f, A = 0.f;
 #pragma unroll
-        for (int u = 0; u < DA_WAVES; u++) {
+        for (int u = 0; u < WAVES; u++) {
             L += sRed[1][u][tid];
             A += sRed[2][u][tid];
         }
@@ -236,20 +241,33 @@ extern "C" int gf_decoder_pack_weights(const float* W1, const float* W2, const f
     return GF_OK;
 }
 
+extern "C" int gf_decoder_cross_attn_cfg(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
+                                         const float* lo, const float* hi, const float* gaussB, const float* Q1,
+                                         const float* K1, const float* Kv, const float* Wpack, const float* b2, int B,
+                                         int nq, int nc, int d, float* out, float* stat_m, float* stat_l, int wg_waves,
+                                         void* stream) {
+    GF_CHECK_ARG(d == DA_D, "gf_decoder_cross_attn: implemented for dec_dim = 64 (got %d)", d);
+    GF_CHECK_ARG(B >= 0 && nq >= 0 && nc >= 1, "gf_decoder_cross_attn: bad sizes");
+    GF_CHECK_ARG((stat_m == nullptr) == (stat_l == nullptr), "gf_decoder_cross_attn: stat_m and stat_l come together");
+    GF_CHECK_ARG(wg_waves == 16 || wg_waves == 8, "gf_decoder_cross_attn_cfg: %d waves per workgroup (16 or 8)", wg_waves);
+    if (B == 0 || nq == 0) return GF_OK;
+    (void)b2;  // a per-channel constant cancels in the per-channel soft-max over the contexts
+    if (wg_waves == 16)
+        hipLaunchKernelGGL(k_decoder_cross_attn<16>, dim3(nq, B), dim3(16 * 64), 0, (hipStream_t)stream, geo_ctx, max_geo, qloc,
+                           cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out, stat_m, stat_l);
+    else
+        hipLaunchKernelGGL(k_decoder_cross_attn<8>, dim3(nq, B), dim3(8 * 64), 0, (hipStream_t)stream, geo_ctx, max_geo, qloc,
+                           cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out, stat_m, stat_l);
+    GF_CHECK_LAUNCH("gf_decoder_cross_attn");
+    return GF_OK;
+}
+
 extern "C" int gf_decoder_cross_attn(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
                                      const float* lo, const float* hi, const float* gaussB, const float* Q1,
                                      const float* K1, const float* Kv, const float* Wpack, const float* b2, int B,
                                      int nq, int nc, int d, float* out, float* stat_m, float* stat_l, void* stream) {
-    GF_CHECK_ARG(d == DA_D, "gf_decoder_cross_attn: implemented for dec_dim = 64 (got %d)", d);
-    GF_CHECK_ARG(B >= 0 && nq >= 0 && nc >= 1, "gf_decoder_cross_attn: bad sizes");
-    GF_CHECK_ARG((stat_m == nullptr) == (stat_l == nullptr), "gf_decoder_cross_attn: stat_m and stat_l come together");
-    if (B == 0 || nq == 0) return GF_OK;
-    (void)b2;  // a per-channel constant cancels in the per-channel soft-max over the contexts
-    hipLaunchKernelGGL(k_decoder_cross_attn, dim3(nq, B), dim3(DA_WAVES * 64), 0, (hipStream_t)stream, geo_ctx, max_geo,
-                       qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out, stat_m,
-                       stat_l);
-    GF_CHECK_LAUNCH("gf_decoder_cross_attn");
-    return GF_OK;
+    return gf_decoder_cross_attn_cfg(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, Wpack, b2, B, nq, nc, d, out,
+                                     stat_m, stat_l, 16, stream);
 }
 
 

@@ -202,6 +202,44 @@ class PendingProposals:
         return self.value
 
 
+class SplitForward:
+    """Handle of GeoFormer.forward_split, a forward in three parts, all queued on the stream that is current when the
+    handle is created (the scene's lane):
+      1. (constructor) backbone + semantic head queued; ``backbone_done`` is the event behind them;
+      2. ``advance()``: foreground selection (the forward's host read-back), sampling / BFS stretch, set abstraction;
+         ``stretch_done`` are the events behind the stretch (end of the sampling, end of every scene's BFS);
+      3. ``finish()``: decoder, mask head, proposals -- launched in the co-resident workgroup shapes
+         (pointops.co_resident_launches), because a serving loop queues this part behind the NEXT scene's
+         ``backbone_done`` so that it runs under that scene's sampling / BFS stretch; returns the outputs.
+    A forward that ends early (no foreground, ``epoch <= prepare_epochs``) has its outputs after whichever call saw it
+    end; the later calls are no-ops."""
+
+    def __init__(self, steps):
+        self._steps, self.outputs, self.backbone_done, self.stretch_done = steps, None, None, ()
+        self.backbone_done = self._next()
+
+    def _next(self):
+        if self._steps is None:
+            return None
+        try:
+            return next(self._steps)
+        except StopIteration as done:
+            self.outputs, self._steps = done.value, None
+            return None
+
+    def advance(self):
+        self.stretch_done = self._next() or ()
+        return self
+
+    def finish(self):
+        if self._steps is not None:
+            with pointops.co_resident_launches():
+                self._next()
+            if self._steps is not None:
+                raise RuntimeError("SplitForward: the forward has more parts than this handle knows")
+        return self.outputs
+
+
 class GeoFormer(nn.Module):
     def __init__(self, cfg=None):
         super().__init__()
@@ -482,6 +520,7 @@ class GeoFormer(nn.Module):
             aux = sides[(locs_float_.device, main.cuda_stream, "aux")] = torch.cuda.Stream(device=locs_float_.device)
         geo_ready = [None] * batch_size
         staged, geo = [None] * batch_size, [None] * batch_size
+        fps_done_evs = []  # (forward_split: the end of every scene's sampling)
         # Several scenes with gradients (the training step): every scene's sampling goes to a stream of its own and its
         # BFS to another, so the scenes' two latency-bound launches run beside each other instead of one scene after
         # the other (4 x (0.4 + 3.3) ms of a batch-4 step in which the device finishes last); the main stream joins
@@ -549,6 +588,9 @@ class GeoFormer(nn.Module):
                 # the rest of the sampling is the stretch's long pole: queued right behind the first picks, before the
                 # host spends ~60 us on everything below (the stream idled that long between the two launches)
                 idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+                fps_done = torch.cuda.Event()
+                fps_done.record(sb)
+                fps_done_evs.append(fps_done)
             if early is not None and b == 0:
                 # work of the caller that does not depend on the sampling (early() -> (.., .., kNN graphs)): queued on
                 # the third stream now that the first sampling launch is out
@@ -608,6 +650,8 @@ class GeoFormer(nn.Module):
                 st[1] = feat_b.unsqueeze(0).transpose(1, 2).contiguous()
         staged = [tuple(st[:4]) for st in staged]
         self.__dict__.setdefault("_gf_pending_side", {})[_stream_key(locs_float_.device)] = geo_ready
+        self.__dict__.setdefault("_gf_stretch_events", {})[_stream_key(locs_float_.device)] = fps_done_evs + [
+            ev for ev in geo_ready if ev is not None]
         cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts)  # noqa: E731
         with grad_ctx():
             fused = []
@@ -913,10 +957,29 @@ class GeoFormer(nn.Module):
     def forward(self, batch_input, epoch, training=True, defer_proposals=False):
         """defer_proposals (GPU inference): everything is queued on the current stream and
         ``outputs["proposal_scores"]`` is a PendingProposals whose ``get()`` makes the forward's last read-back -- a
-        serving loop can queue the next scene on another stream before it collects this one (measured: no gain on one
-        GPU; bench.py runs one scene at a time).  The in-flight side-stream state is kept per
-        caller stream, so forwards issued from different host threads on their own streams do not interfere;
-        ``last_sampling_indices`` (a test hook) is the one attribute that is per model."""
+        serving loop can queue the next scene on another stream before it collects this one.  The in-flight side-stream
+        state is kept per caller stream, so forwards issued on their own streams (from one host thread or several) do
+        not interfere; ``last_sampling_indices`` (a test hook) is the one attribute that is per model."""
+        steps = self._forward_steps(batch_input, epoch, training, defer_proposals, False)
+        try:
+            while True:
+                next(steps)
+        except StopIteration as done:
+            return done.value
+
+    def forward_split(self, batch_input, epoch, training=True, defer_proposals=False):
+        """The forward in three parts for a serving loop (bench.py; class SplitForward): this scene's decoder and mask
+        head (matrix work) are queued behind the NEXT scene's backbone and run under that scene's sampling / BFS stretch
+        -- a few latency-bound workgroups that otherwise leave the chip idle for 40 % of a forward -- while the next
+        scene's backbone is held back until this scene's stretch has ended (conv kernels beside it slow every one of
+        its 2047 sampling rounds).  Every call of the handle must see the stream of the first one as the current
+        stream.  Same launches as ``forward`` except the cross-attention's workgroup shape (8 waves, so that it fits
+        beside a BFS workgroup); values agree to rounding."""
+        return SplitForward(self._forward_steps(batch_input, epoch, training, defer_proposals, True))
+
+    def _forward_steps(self, batch_input, epoch, training, defer_proposals, split):
+        """The forward as a generator: with ``split`` it yields an event behind the backbone + semantic head and the
+        events behind the sampling / BFS stretch; returns the outputs."""
         cfg = self.cfg
         outputs = {}
         batch_idxs = batch_input["locs"][:, 0].int()
@@ -935,6 +998,13 @@ class GeoFormer(nn.Module):
         outputs["semantic_scores"] = semantic_scores
         if epoch <= self.prepare_epochs:
             return outputs
+        if split:
+            # backbone and semantic head are queued (the read-back of the foreground count comes next): the loop holds
+            # the PREVIOUS scene's decoder back until here and queues it now, while the host would otherwise wait
+            backbone_done = torch.cuda.Event() if locs_float.is_cuda else None
+            if backbone_done is not None:
+                backbone_done.record()
+            yield backbone_done
 
         same_fold = cfg.train_fold == cfg.cvfold
         if fused_fg:
@@ -1011,6 +1081,19 @@ class GeoFormer(nn.Module):
         if geo_dists is None:
             geo_dists = cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=max_step, neighbor=64,
                                      radius=0.05, n_queries=cfg.n_query_points, graphs=graphs)
+        if split:
+            # everything below waits for the geodesic distances anyway; the event marks the end of this scene's
+            # sampling / BFS stretch for the loop that holds the next scene's backbone back until then
+            stretch = []
+            if locs_float.is_cuda:
+                # the end of the sampling and of every scene's BFS -- not of the set abstraction queued behind them on
+                # this stream (~0.2 ms that the next scene's backbone need not wait for)
+                stretch = list(self.__dict__.get("_gf_stretch_events", {}).pop(_stream_key(locs_float.device), ()))
+                if not stretch:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    stretch = [ev]
+            yield stretch
         dec_outputs = self.forward_decoder(context_locs, context_feats, query_locs, pc_dims, geo_dists, pre_enc_inds)
         self._join_side_stream()  # no-op unless a subclass' decoder skipped relative_position_embedding
 

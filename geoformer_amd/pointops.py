@@ -6,6 +6,9 @@ the current stream.  The module-shaped mirrors of the reference bindings live in
 """
 from __future__ import annotations
 
+import contextlib
+import threading
+
 import torch
 
 from . import _lib
@@ -566,6 +569,22 @@ def decoder_pack_weights(W1, W2, Wv):
     return wp
 
 
+_launch_cfg = threading.local()
+
+
+@contextlib.contextmanager
+def co_resident_launches():
+    """Inside this context the inference cross-attention is launched in its 8-wave workgroup shape
+    (gf_decoder_cross_attn_cfg), which fits on a compute unit beside a BFS workgroup: SplitForward.finish() queues one
+    scene's decoder under the next scene's sampling / BFS stretch.  Per host thread."""
+    old = getattr(_launch_cfg, "cross_attn_waves", 16)
+    _launch_cfg.cross_attn_waves = 8
+    try:
+        yield
+    finally:
+        _launch_cfg.cross_attn_waves = old
+
+
 def decoder_cross_attn(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, wpack, b2):
     """Fused vector cross-attention; shapes as in include/geoformer_hip.h.  Returns [B,nq,64]."""
     for t, name in ((geo_ctx, "geo_ctx"), (max_geo, "max_geo"), (qloc, "qloc"), (cloc, "cloc"), (lo, "lo"), (hi, "hi"),
@@ -574,9 +593,10 @@ def decoder_cross_attn(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
     B, nq, nc = geo_ctx.shape
     d = Q1.shape[-1]
     out = torch.empty((B, nq, d), dtype=torch.float32, device=Q1.device)
-    check(_lib.load().gf_decoder_cross_attn(ptr(geo_ctx), ptr(max_geo), ptr(qloc), ptr(cloc), ptr(lo), ptr(hi),
-                                            ptr(gaussB), ptr(Q1), ptr(K1), ptr(Kv), ptr(wpack), ptr(b2), B, nq, nc, d,
-                                            ptr(out), None, None, stream_ptr()), "gf_decoder_cross_attn")
+    check(_lib.load().gf_decoder_cross_attn_cfg(ptr(geo_ctx), ptr(max_geo), ptr(qloc), ptr(cloc), ptr(lo), ptr(hi),
+                                                ptr(gaussB), ptr(Q1), ptr(K1), ptr(Kv), ptr(wpack), ptr(b2), B, nq, nc, d,
+                                                ptr(out), None, None, getattr(_launch_cfg, "cross_attn_waves", 16),
+                                                stream_ptr()), "gf_decoder_cross_attn")
     return out
 
 

@@ -612,6 +612,14 @@ int gf_decoder_cross_attn(const float* geo_ctx, const float* max_geo, const floa
                           const float* lo, const float* hi, const float* gaussB, const float* Q1, const float* K1,
                           const float* Kv, const float* Wpack, const float* b2, int B, int nq, int nc, int d, float* out,
                           float* stat_m, float* stat_l, void* stream);
+/* The same with the workgroup shape chosen: wg_waves = 16 (gf_decoder_cross_attn) or 8 -- 512 threads at 120 registers
+ * fit on a compute unit BESIDE a 512-thread workgroup of gf_geodesic_bfs_cfg, for a serving loop that runs one scene's
+ * decoder under the next scene's sampling / BFS stretch (GeoFormer.forward_split).  Results agree to rounding (the
+ * per-wave partial soft-max states are merged over 8 instead of 16 waves). */
+int gf_decoder_cross_attn_cfg(const float* geo_ctx, const float* max_geo, const float* qloc, const float* cloc,
+                              const float* lo, const float* hi, const float* gaussB, const float* Q1, const float* K1,
+                              const float* Kv, const float* Wpack, const float* b2, int B, int nq, int nc, int d,
+                              float* out, float* stat_m, float* stat_l, int wg_waves, void* stream);
 
 /* Backward of gf_decoder_cross_attn (training).  stat_m / stat_l fp32 [B,nq,64]: per (query, channel) maximum and
  * sum of the scaled soft-max logits, written by the forward when the two pointers are given (NULL otherwise); out =

@@ -97,3 +97,46 @@ def test_unet_train_program_covers_the_module_tree():
     # the residual operand of a block's second convolution is the block's input or its 1x1x1 identity convolution
     res = [op for op in P.ops if op.kind == ut.CONV and op.aux >= 0]
     assert len(res) == 26
+
+
+def test_split_forward_handle_drives_a_three_part_generator():
+    """SplitForward (GeoFormer.forward_split's handle) over stand-in generators: parts run in order, early ends are
+    absorbed by whichever call sees them, finish() is idempotent and runs its part in the co-resident launch context."""
+    from geoformer_amd import pointops
+    from geoformer_amd.model.geoformer import SplitForward
+
+    log = []
+
+    def three():
+        log.append("backbone")
+        yield "bb"
+        log.append("stretch")
+        yield ["fps", "bfs"]
+        log.append(("tail", getattr(pointops._launch_cfg, "cross_attn_waves", 16)))
+        return {"done": True}
+
+    h = SplitForward(three())
+    assert h.backbone_done == "bb" and log == ["backbone"] and h.outputs is None
+    assert h.advance() is h and h.stretch_done == ["fps", "bfs"] and h.outputs is None
+    out = h.finish()
+    assert out == {"done": True} and h.finish() is out and log[-1] == ("tail", 8)
+    assert getattr(pointops._launch_cfg, "cross_attn_waves", 16) == 16  # restored
+
+    def early():
+        return {"semantic_scores": 1}
+        yield  # pragma: no cover
+
+    h = SplitForward(early())
+    assert h.outputs == {"semantic_scores": 1} and h.backbone_done is None
+    assert h.advance().stretch_done == () and h.finish() == {"semantic_scores": 1}
+
+    def four():
+        yield 1
+        yield 2
+        yield 3
+
+    h = SplitForward(four()).advance()
+    import pytest
+
+    with pytest.raises(RuntimeError):
+        h.finish()
