@@ -7,10 +7,14 @@
 A "step" is one full ``GeoFormer.forward(batch, epoch, training=False)`` over one ~150k-point synthetic
 scene (BASELINE.json configs[1]; test yaml: nq=256, nc=2048, batch 1) with the batch dict already
 resident in HBM: voxel mean, 13 rulebooks, 71 sparse convs, semantic head, FPS, ball query, grouping,
-kNN graph + geodesic BFS, 4 decoder layers, dynamic-conv mask head, proposals.  The loop is a serving loop: the
-forward of scene i returns once everything up to the copy of the accepted-proposal count is queued, and the proposals
-of scene i are collected right after scene i+1 has been issued (``defer_proposals``); all K scenes, proposals
-included, are complete inside the timed region.  The steps rotate over
+kNN graph + geodesic BFS, 4 decoder layers, dynamic-conv mask head, proposals.  The loop is a serving loop
+(geoformer_amd/serving.py): two scenes in flight on two streams, staggered -- scene i's decoder + mask head are queued
+behind scene i+1's sampling launches and run under that scene's sampling / BFS stretch (which leaves the chip nearly
+idle), scene i+1's backbone starts when scene i's stretch has ended, scene i's proposals are collected after scene i+2
+has been issued.  Same launches and per-scene results as ``forward`` (the cross-attention in its 8-wave workgroup shape).
+``--no-pipeline``: one scene at a time (the forward of scene i returns once everything up to the copy of the
+accepted-proposal count is queued -- ``defer_proposals`` -- and its proposals are collected after scene i+1 has been
+issued).  Either way all K scenes, proposals included, are complete inside the timed region.  The steps rotate over
 ``--scenes`` (8) different resident scenes (seeds 1234, 1235, ...), so no step finds the previous step's
 tables or features in L2/MALL.  Weights are random-init of the real architecture (no checkpoints
 offline); the semantic head's bias is shifted so ~40 % of the points are foreground like a real scene
