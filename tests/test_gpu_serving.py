@@ -128,3 +128,52 @@ def test_staggered_loop_equals_one_scene_at_a_time(hip):
         assert len(outs) == len(batches)
         for r, o in zip(refs, outs):
             _same(r, _key(o))
+
+
+def test_staggered_loop_with_scenes_that_end_early(hip):
+    """A scene without predicted foreground leaves the forward behind the backbone (mask_predictions None): the loop
+    must hand it back in order, and the scenes around it must come out as from plain forwards."""
+    from geoformer_amd import scene, serving
+
+    m = _model()
+    full = _to_dev(scene.make_batch([scene.make_small_scene(12000, 4)]))
+    other = _to_dev(scene.make_batch([scene.make_small_scene(9000, 3)]))
+    # a scene whose every point is predicted background: the backbone's class scores of a marked batch are pushed to the
+    # first (non-object) classes before the foreground selection reads them
+    empty = dict(other)
+    empty["_all_background"] = True
+    backbone = m.forward_backbone
+
+    def marked(batch_input, *a, **k):
+        res = backbone(batch_input, *a, **k)
+        if batch_input.get("_all_background"):
+            res[1][:, :4] += 1e4
+        return res
+
+    m.forward_backbone = marked
+    with torch.no_grad():
+        probe = m(empty, 300, training=False)
+    assert probe["mask_predictions"] is None
+    np.random.seed(1)
+    with torch.no_grad():
+        ref_full = _key(m(full, 300, training=False))
+    np.random.seed(2)
+    with torch.no_grad():
+        ref_other = _key(m(other, 300, training=False))
+    torch.cuda.synchronize()
+    loop = serving.StaggeredForward(m, "cuda")
+    order = [("full", full, 1), ("empty", empty, 5), ("other", other, 2), ("full", full, 1), ("empty", empty, 6)]
+    outs = []
+    for _, b, seed in order:
+        np.random.seed(seed)
+        o = loop.submit(b)
+        if o is not None:
+            outs.append(o)
+    outs += loop.drain()
+    torch.cuda.synchronize()
+    assert len(outs) == len(order)
+    for (name, _, _), o in zip(order, outs):
+        if name == "empty":
+            assert o["mask_predictions"] is None and "semantic_scores" in o
+        else:
+            _same(ref_full if name == "full" else ref_other, _key(o))
