@@ -722,8 +722,7 @@ def main():
             st = self.stag.get(id(m))
             if st is None:
                 st = self.stag[id(m)] = serving.StaggeredForward(m, dev)
-            out = st.submit(batches[i % ns])
-            if out is not None:
+            for out in st.submit(batches[i % ns], seed=1000 + i):
                 self.last = out
 
         def _collect(self):

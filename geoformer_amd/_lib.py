@@ -62,6 +62,7 @@ def _declare(lib):
         "gf_dev_conv_kernel_events": (I, [P, P]),
         "gf_dev_conv_kernel_events_taken": (I, []),
         "gf_unet_fwd": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P]),
+        "gf_unet_fwd_phased": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P, P, I, P, P]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
         "gf_voxelize_bp": (I, [P, P, I, I, I, I, P, P]),
         "gf_gather_points": (I, [P, P, I, I, I, I, P, P]),

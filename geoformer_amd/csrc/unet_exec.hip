@@ -227,14 +227,38 @@ extern "C" size_t gf_unet_ws_bytes(const GfUnetParams* P, int M0, int B, int X, 
 extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y,
                            int Z, void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream,
                            void* side_stream) {
+    return gf_unet_fwd_phased(P, feats, coords, M0, B, X, Y, Z, ws, ws_bytes, host_counts, out, stream, side_stream, nullptr,
+                              0, nullptr, nullptr);
+}
+
+extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X,
+                                  int Y, int Z, void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream,
+                                  void* side_stream, void* const* gate_events, int n_gate, GfUnetBetween between,
+                                  void* user) {
     GF_CHECK_ARG(P && feats && coords && ws && host_counts && out, "gf_unet_fwd: null argument");
+    GF_CHECK_ARG(n_gate >= 0 && (n_gate == 0 || gate_events != nullptr), "gf_unet_fwd_phased: %d gate events without a list", n_gate);
+    // the hand-over between the phases happens exactly once on every path that gets past the argument checks below
+    bool handed = false;
+    auto hand_over = [&](hipStream_t s_) -> int {
+        if (handed) return GF_OK;
+        handed = true;
+        if (!between) return GF_OK;
+        void* evs[8];
+        const int n = between(user, evs, 8);
+        if (n < 0 || n > 8) {
+            gf_set_error("gf_unet_fwd_phased: the hand-over callback failed (%d)", n);
+            return GF_ERR_CALLBACK;
+        }
+        for (int e = 0; e < n; e++) GF_TRY(hipStreamWaitEvent(s_, (hipEvent_t)evs[e], 0));
+        return GF_OK;
+    };
     GF_CHECK_ARG(P->nlevels >= 1 && P->nlevels <= GF_UNET_MAX_LEVELS, "gf_unet_fwd: %d levels (1..%d)", P->nlevels,
                  GF_UNET_MAX_LEVELS);
     GF_CHECK_ARG(P->cin >= 1 && P->cin <= 16 && P->level[0].C == 16,
                  "gf_unet_fwd: input conv implemented for <= 16 input channels and 16 output channels (got %d -> %d)",
                  P->cin, P->level[0].C);
     GF_CHECK_ARG(M0 >= 0 && B >= 1, "gf_unet_fwd: bad sizes");
-    if (M0 == 0) return GF_OK;
+    if (M0 == 0) return hand_over((hipStream_t)stream);
     for (int l = 0; l < P->nlevels; l++)
         GF_CHECK_ARG(P->level[l].C > 0 && P->level[l].C % 16 == 0, "gf_unet_fwd: level %d width %d (multiples of 16)", l,
                      P->level[l].C);
@@ -381,6 +405,9 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
     // the first level's 16 -> 16 convolutions run the pipelined counted-loop kernel, which can write both forms
     const bool dual0 = gf_conv_dual_supported(M0, ld0, 16, 16, T[0].steps != nullptr) != 0;
 
+    // phased call: every convolution sits behind the caller's events; the level-1 index / table above and the rulebook
+    // chain on the side stream (forked from a point in front of the waits) do not
+    for (int e = 0; e < n_gate; e++) GF_TRY(hipStreamWaitEvent(st, (hipEvent_t)gate_events[e], 0));
     {
         const int n = M0 * 16;
         hipLaunchKernelGGL(k_pad_channels, dim3(gf_div_up(n, 256)), dim3(256), 0, st, feats, M0, P->cin, 16, x16);
@@ -454,6 +481,10 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
             GF_TRY(hipMemcpyAsync(host_counts + 2, d_counts + 2, sizeof(int32_t) * (nl - 1), hipMemcpyDeviceToHost, ss));
             GF_TRY(hipEventRecord(t_ev.chain2, ss));
         }
+        // ---- end of phase A (level 1 and the whole rulebook chain queued): the caller's hand-over BEFORE this call's
+        // first host wait -- the hand-over serves another scene's read-back, which must not sit behind a wait for THIS
+        // scene's rulebooks (they crawl beside that scene's convolutions) -- then phase B behind the events it returns
+        UN_TRY(hand_over(st));
         GF_TRY(hipEventSynchronize(t_ev.chain));  // host wait 1: voxel count of the second level
         UN_TRY(take_counts(1, 1));
         // main stream: second level's table, the first strided conv and that level's two blocks -- ~0.18 ms of device
@@ -464,6 +495,7 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
         UN_TRY(down_conv(0));
         UN_TRY(two_blocks(1));
     }
+    UN_TRY(hand_over(st));  // (a single-level net: here)
     if (nl > 1) {
         GF_TRY(hipEventSynchronize(t_ev.chain2));  // host wait 2: the levels below (the device is busy with level 2)
         UN_TRY(take_counts(2, nl));

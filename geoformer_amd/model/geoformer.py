@@ -998,20 +998,24 @@ class GeoFormer(nn.Module):
         outputs["semantic_scores"] = semantic_scores
         if epoch <= self.prepare_epochs:
             return outputs
+        same_fold = cfg.train_fold == cfg.cvfold
+        fg_pending = None
+        if fused_fg:
+            # (the selection's launches and the copy of its count belong to the backbone's part: the device runs them
+            # without waiting for the host to come back)
+            feats_src, feat_rows = output_feats if isinstance(output_feats, tuple) else (output_feats.contiguous(), None)
+            fg_pending = pointops.select_foreground(
+                semantic_scores.contiguous(), 4 if same_fold else 3, not same_fold, locs_float.contiguous(),
+                batch_idxs.contiguous(), feats_src, feat_rows, deferred=True)
         if split:
-            # backbone and semantic head are queued (the read-back of the foreground count comes next): the loop holds
-            # the PREVIOUS scene's decoder back until here and queues it now, while the host would otherwise wait
+            # backbone, semantic head and foreground selection are queued (the read-back of the foreground count comes
+            # next): the event marks the end of this scene's throughput-bound work for the loop
             backbone_done = torch.cuda.Event() if locs_float.is_cuda else None
             if backbone_done is not None:
                 backbone_done.record()
             yield backbone_done
-
-        same_fold = cfg.train_fold == cfg.cvfold
         if fused_fg:
-            feats_src, feat_rows = output_feats if isinstance(output_feats, tuple) else (output_feats.contiguous(), None)
-            fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = pointops.select_foreground(
-                semantic_scores.contiguous(), 4 if same_fold else 3, not same_fold, locs_float.contiguous(),
-                batch_idxs.contiguous(), feats_src, feat_rows)
+            fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = fg_pending.get()
         else:
             fg = semantic_preds >= 4 if same_fold else semantic_preds == 3
             fg_idxs = torch.nonzero(fg).view(-1)

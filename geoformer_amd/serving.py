@@ -1,69 +1,102 @@
-"""Serving loop for the eval forward: two scenes in flight on one GPU, staggered.
+"""Serving loop for the eval forward: scenes staggered over two streams on one GPU.
 
-The reference's test loop (test.py:60-110) runs one scene after the other.  On MI355X a scene's forward has a stretch of
-~2 ms -- 2047 serial sampling rounds on 16 compute units beside the geodesic BFS, one latency-bound workgroup per query --
-during which the chip is nearly idle, and the decoder + mask head that follow are matrix work that needs nothing but
-free compute units.  ``StaggeredForward`` overlaps the two ACROSS scenes:
+The reference's test loop (test.py:60-110) runs one scene after the other.  On MI355X a scene's forward has two stretches
+during which the chip is nearly idle -- ~0.7 ms behind the backbone (the foreground count travels to the host, the host
+makes the reference's sampling draw, the first 256 sampling picks run on 16 compute units) and then ~2 ms of sampling
+rounds beside the geodesic BFS (one latency-bound workgroup per query) -- and two that need nothing but free compute
+units: the backbone's convolutions and the decoder + mask head.  ``StaggeredForward`` fills the former with the latter
+ACROSS scenes (device order; lanes are HIP streams, a scene runs on one of them):
 
-    lane A:  backbone(i) | sampling / BFS (i) | set abstr. |                  decoder + mask head (i) | backbone(i+2) ...
-    lane B:                                     backbone(i+1) | sampling / BFS (i+1) .................. | set abstr. | ...
-                                                ^ starts when stretch(i) has ended
+    lane A:  bb-B(i) | count, draw, first picks (i) | sampling / BFS (i) | s.a. |                        tail(i) | bb-B(i+2) ..
+    lane B:            bb-A(i+1) ..................... | tail(i-1) ......... | bb-B(i+1) | count.. (i+1) | sampling / BFS (i+1) ..
 
-* a scene's backbone waits for the END of the previous scene's sampling / BFS stretch (stream events): conv kernels
-  beside that stretch slow every one of its sampling rounds and BFS hops by more than they gain;
-* scene i's decoder / mask head / proposal statistics are queued by the host right after scene i+1's sampling and BFS
-  launches and execute under that stretch, in workgroup shapes that fit on a compute unit beside a BFS workgroup
-  (``pointops.co_resident_launches``: the 16-wave cross-attention does not, it waited for the BFS queries to retire);
-* the host collects scene i-1's proposals (one pinned word, long there) after that.
+* bb-A = the next scene's voxelisation, rulebooks and first two U-Net levels (gf_unet_fwd_phased), queued by the host
+  BEFORE it waits for scene i's foreground count and gated on scene i's backbone event: it runs under scene i's
+  read-back, draw and first picks;
+* tail = a scene's decoder layers, mask head and proposal statistics, in workgroup shapes that fit on a compute unit
+  beside a BFS workgroup (``pointops.co_resident_launches``): it runs under the NEXT scene's sampling / BFS stretch;
+* bb-B = the rest of the backbone, held behind the END of the previous scene's stretch (stream events): conv kernels
+  beside that stretch slow every one of its sampling rounds and BFS hops by more than they gain.
 
-Same operators and values as ``GeoFormer.forward`` (the cross-attention's 8-wave shape: equal to rounding); every scene
-handed to ``submit`` is complete when ``drain`` returns.  Measured and dropped: holding scene i's decoder behind scene
-i+1's BACKBONE with a device-side gate so that it could be queued earlier (a polling one-wave kernel: every launch of
-the other stream then started ~60 us after the previous one; hipStreamWaitValue32: the streams stopped for good --
-the gated lane shares a hardware queue with a stream the other lane's backbone needs).
+Host order of ``submit(scene i+1)``: queue bb-A(i+1); [hand-over, called by the native backbone between its phases:
+scene i's read-back, draw, sampling / BFS launches and set abstraction; then tail(i-1); then the proposals of scene i-2];
+queue bb-B(i+1) and scene i+1's semantic head.  Same operators and values per scene as ``GeoFormer.forward`` (the
+cross-attention's 8-wave shape: equal to rounding); every scene handed to ``submit`` is complete when ``drain`` returns.
 """
 from __future__ import annotations
 
-import collections
 
+import numpy as np
 import torch
+
+from . import unet_exec
 
 
 
 class StaggeredForward:
-    def __init__(self, model, device, epoch=300):
-        self.model, self.device, self.epoch = model, torch.device(device), epoch
+    def __init__(self, model, device, epoch=300, phased=True):
+        self.model, self.device, self.epoch, self.phased = model, torch.device(device), epoch, bool(phased)
         self.lanes = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         self.n = 0          # scenes submitted so far
-        self.stretch = ()   # events behind the newest scene's sampling / BFS stretch
-        self.head = None    # (SplitForward, lane) of the newest scene: its last part is not queued yet
+        self.head = None    # (SplitForward, lane, seed) of the newest scene: backbone queued, nothing behind it yet
+        self.tailq = None   # (SplitForward, lane) of the scene before it: stretch queued, last part not yet
         self.prev = None    # outputs whose proposals are not collected yet
+        self._done = []
 
-    def submit(self, batch):
-        """Queues one scene; returns the outputs of the scene that completed meanwhile (or None)."""
+    def submit(self, batch, seed=None):
+        """Queues one scene; returns the outputs of the scenes that completed meanwhile (oldest first, usually one).
+        seed: numpy seed set right before THIS scene's sampling draw (which the loop makes one ``submit`` later)."""
         lane = self.lanes[self.n % 2]
         self.n += 1
+        self._done = []
+        if not self.phased:
+            # the plain staggering: this scene's whole backbone behind the end of the previous scene's stretch, then its
+            # own read-back / draw / sampling launches, then the previous scene's last part (4.68 against 4.55 ms per scene)
+            with torch.cuda.stream(lane), torch.no_grad():
+                if self.tailq is not None:
+                    for ev in self.tailq[0].stretch_done:
+                        lane.wait_event(ev)
+                h = self.model.forward_split(batch, self.epoch, training=False, defer_proposals=True)
+            self.head = (h, lane, seed)
+            self._hand_over()
+            return list(self._done)
+        gate = [self.head[0].backbone_done] if self.head is not None and self.head[0].backbone_done is not None else []
         with torch.cuda.stream(lane), torch.no_grad():
-            for ev in self.stretch:
-                lane.wait_event(ev)
-            h = self.model.forward_split(batch, self.epoch, training=False, defer_proposals=True)
+            unet_exec.phase_next_forward(gate, self._hand_over)
+            try:
+                h = self.model.forward_split(batch, self.epoch, training=False, defer_proposals=True)
+            finally:
+                unused = unet_exec.take_phase()
+            if unused is not None:  # a backbone that did not go through the native executor: the hand-over comes now
+                self._hand_over()
+        self.head = (h, lane, seed)
+        return list(self._done)
+
+    def _hand_over(self):
+        """The newest scene's read-back, draw, sampling / BFS launches and set abstraction; then the last part of the
+        scene before it, under that stretch.  Returns the events behind the stretch."""
+        if self.head is None:
+            return []
+        h, lane, seed = self.head
+        self.head = None
+        if seed is not None:
+            np.random.seed(seed)
+        with torch.cuda.stream(lane), torch.no_grad():
             h.advance()
-        self.stretch = h.stretch_done
-        done = self._tail()
-        self.head = (h, lane)
-        return done
+        self._tail()
+        self.tailq = (h, lane)
+        return list(h.stretch_done)
 
     def _tail(self):
-        """The newest scene's last part (under the stretch just queued), then the proposals of the scene before it."""
-        done = None
-        if self.head is not None:
-            h, lane = self.head
-            self.head = None
+        if self.tailq is not None:
+            h, lane = self.tailq
+            self.tailq = None
             with torch.cuda.stream(lane), torch.no_grad():
                 out = h.finish()
             done = self._collect(self.prev)
+            if done is not None:
+                self._done.append(done)
             self.prev = out
-        return done
 
     @staticmethod
     def _collect(out):
@@ -74,10 +107,14 @@ class StaggeredForward:
 
     def drain(self):
         """Queues what is left, collects every pending scene and joins the lanes into the current stream."""
-        done = [o for o in (self._tail(), self._collect(self.prev)) if o is not None]
+        self._done = []
+        self._hand_over()
+        self._tail()
+        done = self._collect(self.prev)
         self.prev = None
-        self.stretch = ()
+        if done is not None:
+            self._done.append(done)
         cur = torch.cuda.current_stream(self.device)
         for lane in self.lanes:
             cur.wait_stream(lane)
-        return done
+        return list(self._done)

@@ -146,6 +146,24 @@ _tls = threading.local()
 _SIDE_STREAMS = {}  # (device, caller stream) -> the executor's side stream
 
 
+_BETWEEN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int)
+
+
+def phase_next_forward(gate_events, between):
+    """The NEXT unet_forward of this host thread runs as gf_unet_fwd_phased: its convolutions wait for the recorded
+    torch.cuda.Event objects in gate_events, and ``between()`` -- a callable that returns a list of recorded events -- is
+    called on the host once the first two levels are queued; the rest of the backbone waits for the events it returns
+    (geoformer_amd/serving.py).  ``take_phase()`` tells whether a forward consumed the request."""
+    _tls.phase = (list(gate_events or ()), between)
+
+
+def take_phase():
+    """The pending phase request (gate events, callable) that no unet_forward has consumed, or None; clears it."""
+    req = getattr(_tls, "phase", None)
+    _tls.phase = None
+    return req
+
+
 def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     """[M,16] output features of input_conv -> unet -> output_layer for voxel features [M,cin] / coords int32 [M,4]."""
     lib = _lib.load()
@@ -168,8 +186,39 @@ def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     side = sides.get((dev, main.cuda_stream))
     if side is None:
         side = sides[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
-    rc = lib.gf_unet_fwd(plan.ref, voxel_feats.data_ptr(), coords.data_ptr(), M, batch_size, X, Y, Z, ws.data_ptr(),
-                         nbytes, pinned.data_ptr(), out.data_ptr(), stream_ptr(), side.cuda_stream)
+    req = take_phase()
+    if req is None:
+        rc = lib.gf_unet_fwd(plan.ref, voxel_feats.data_ptr(), coords.data_ptr(), M, batch_size, X, Y, Z, ws.data_ptr(),
+                             nbytes, pinned.data_ptr(), out.data_ptr(), stream_ptr(), side.cuda_stream)
+    else:
+        gate, between = req
+        state = {"called": False, "error": None, "keep": None}
+
+        def _between(_user, events_out, max_events):
+            state["called"] = True
+            try:
+                evs = list(between() or ())
+                if len(evs) > max_events:
+                    raise RuntimeError(f"gf_unet_fwd_phased: {len(evs)} hand-over events (at most {max_events})")
+                state["keep"] = evs  # alive until the call has queued its waits
+                for i, e in enumerate(evs):
+                    events_out[i] = e.cuda_event
+                return len(evs)
+            except BaseException as e:  # noqa: BLE001  (re-raised by the caller below: never through the C frame)
+                state["error"] = e
+                return -1
+
+        cb = _BETWEEN(_between)
+        evs = (ctypes.c_void_p * max(len(gate), 1))(*[ctypes.c_void_p(e.cuda_event) for e in gate])
+        rc = lib.gf_unet_fwd_phased(plan.ref, voxel_feats.data_ptr(), coords.data_ptr(), M, batch_size, X, Y, Z,
+                                    ws.data_ptr(), nbytes, pinned.data_ptr(), out.data_ptr(), stream_ptr(),
+                                    side.cuda_stream, evs, len(gate), cb, None)
+        if state["error"] is not None:
+            side.synchronize()
+            raise state["error"]
+        if not state["called"]:  # an early error return: the hand-over still has to happen (the loop depends on it)
+            for e in (between() or ()):
+                main.wait_event(e)
     if rc != 0:
         # an error return can leave the rulebook chain queued on the side stream, still writing `ws`: the caching
         # allocator must not hand the block to the caller's stream before that work has drained

@@ -32,6 +32,7 @@ typedef enum {
     GF_ERR_INVALID_ARG = -1,
     GF_ERR_LAUNCH = -2,
     GF_ERR_UNSUPPORTED = -3,
+    GF_ERR_CALLBACK = -4, /* a caller-supplied callback reported a failure (gf_unet_fwd_phased) */
 } gf_status;
 
 int gf_abi_version(void);
@@ -264,6 +265,20 @@ size_t gf_unet_ws_bytes(const GfUnetParams* P, int M0, int B, int X, int Y, int 
  *   joined into `stream` before the call returns control of the tables to later launches. */
 int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
                 void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream);
+/* The same in two phases, for the staggered serving loop (geoformer_amd/serving.py):
+ *   phase A = level-1 index and table, the first level's convolutions (input conv + two residual blocks) and the
+ *             down-sampling rulebook chain, all queued without a host wait; the CONVOLUTIONS wait for the n_gate recorded
+ *             events (hipEvent_t handles), the integer work does not;
+ *   `between(user, events_out, max_events)` is then called on the host (may be NULL): it may queue any other work on
+ *             other streams and returns the number of recorded events it stored in events_out (<= max_events = 8), or a
+ *             negative number to abort the call (GF_ERR_CALLBACK);
+ *   phase B = everything below the first level and the whole up pass, behind those events.
+ * The loop uses `between` to issue the PREVIOUS scene's sampling / BFS stretch (whose events phase B then waits for):
+ * this scene's phase A runs under that scene's foreground read-back and first sampling picks, when the chip is idle. */
+typedef int (*GfUnetBetween)(void* user, void** events_out, int max_events);
+int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
+                       void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream,
+                       void* const* gate_events, int n_gate, GfUnetBetween between, void* user);
 
 /* ===================================================================================
  * Training criterion: Hungarian matching on the device (model/matcher.py:79-126 moves the cost matrix to the host

@@ -101,9 +101,11 @@ def test_forward_split_equals_forward_on_the_golden_scene(hip):
     assert h.advance().stretch_done == () and h.finish() is h.outputs
 
 
-def test_staggered_loop_equals_one_scene_at_a_time(hip):
-    """Seven scenes of different sizes through StaggeredForward (two in flight, each scene's decoder under the next
-    scene's sampling / BFS stretch) against plain forwards, in submission order, twice through the same loop object."""
+@pytest.mark.parametrize("phased", [True, False], ids=["phased-backbone", "whole-backbone"])
+def test_staggered_loop_equals_one_scene_at_a_time(hip, phased):
+    """Seven scenes of different sizes through StaggeredForward (each scene's decoder under the next scene's sampling /
+    BFS stretch; phased: the next scene's first U-Net level under this scene's read-back and first picks, the hand-over
+    called from inside gf_unet_fwd_phased) against plain forwards, in submission order, twice through one loop object."""
     from geoformer_amd import scene, serving
 
     m = _model()
@@ -115,14 +117,11 @@ def test_staggered_loop_equals_one_scene_at_a_time(hip):
         with torch.no_grad():
             refs.append(_key(m(b, 300, training=False)))
     torch.cuda.synchronize()
-    loop = serving.StaggeredForward(m, "cuda")
+    loop = serving.StaggeredForward(m, "cuda", phased=phased)
     for rep in range(2):
         outs = []
         for i, b in enumerate(batches):
-            np.random.seed(100 + i)
-            o = loop.submit(b)
-            if o is not None:
-                outs.append(o)
+            outs += loop.submit(b, seed=100 + i)
         outs += loop.drain()
         torch.cuda.synchronize()
         assert len(outs) == len(batches)
@@ -165,10 +164,7 @@ def test_staggered_loop_with_scenes_that_end_early(hip):
     order = [("full", full, 1), ("empty", empty, 5), ("other", other, 2), ("full", full, 1), ("empty", empty, 6)]
     outs = []
     for _, b, seed in order:
-        np.random.seed(seed)
-        o = loop.submit(b)
-        if o is not None:
-            outs.append(o)
+        outs += loop.submit(b, seed=seed)
     outs += loop.drain()
     torch.cuda.synchronize()
     assert len(outs) == len(order)
