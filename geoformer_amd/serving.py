@@ -33,10 +33,19 @@ from . import unet_exec
 
 
 
+_LANES = {}
+
+
 class StaggeredForward:
     def __init__(self, model, device, epoch=300, phased=True):
         self.model, self.device, self.epoch, self.phased = model, torch.device(device), epoch, bool(phased)
-        self.lanes = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        # the two lanes are a process resource (like the forward's side streams, which are keyed by them): a second loop
+        # object with fresh streams from the framework's pool has measured 5.0 against 4.2 ms per scene (bench.py's nq = 128
+        # leg) -- which hardware queue a stream lands on depends on what was created before it
+        key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
+        if key not in _LANES:
+            _LANES[key] = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        self.lanes = _LANES[key]
         self.n = 0          # scenes submitted so far
         self.head = None    # (SplitForward, lane, seed) of the newest scene: backbone queued, nothing behind it yet
         self.tailq = None   # (SplitForward, lane) of the scene before it: stretch queued, last part not yet
