@@ -173,3 +173,28 @@ def test_staggered_loop_with_scenes_that_end_early(hip):
             assert o["mask_predictions"] is None and "semantic_scores" in o
         else:
             _same(ref_full if name == "full" else ref_other, _key(o))
+
+
+def test_staggered_loop_over_the_module_route(hip, monkeypatch):
+    """GF_UNET_EXEC=0: the backbone runs as the module tree, nothing consumes the loop's phase request -- the hand-over
+    then happens right behind the scene's own backbone, and every scene still comes out as from a plain forward."""
+    from geoformer_amd import scene, serving
+
+    monkeypatch.setenv("GF_UNET_EXEC", "0")
+    m = _model()
+    batches = [_to_dev(scene.make_batch([scene.make_small_scene(n, s)])) for n, s in [(9000, 3), (12000, 4), (8192, 11)]]
+    refs = []
+    for i, b in enumerate(batches):
+        np.random.seed(50 + i)
+        with torch.no_grad():
+            refs.append(_key(m(b, 300, training=False)))
+    torch.cuda.synchronize()
+    loop = serving.StaggeredForward(m, "cuda")
+    outs = []
+    for i, b in enumerate(batches):
+        outs += loop.submit(b, seed=50 + i)
+    outs += loop.drain()
+    torch.cuda.synchronize()
+    assert len(outs) == len(batches)
+    for r, o in zip(refs, outs):
+        _same(r, _key(o))
