@@ -147,8 +147,14 @@ def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighb
 def _stream_key(device=None):
     """(device, stream) the caller is running on: the forward's in-flight side-stream state is kept per caller
     stream, so scenes queued from different host threads / streams on ONE model never pick up each other's events."""
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is not None:  # (constructing a torch.cuda.Stream object costs ~8 us, this is called ~10 times per forward)
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        return (idx, raw(idx))
     st = torch.cuda.current_stream(device)
-    return (st.device, st.cuda_stream)
+    return (st.device.index, st.cuda_stream)
 
 
 class PendingProposals:
