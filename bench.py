@@ -34,7 +34,8 @@ The JSON line also carries
                     MFMA peak, mask head against both peaks, the BFS's achieved GB/s, microseconds per sampling pick;
   cpu_baseline   -- the same forward of scene 0 through the build's model on the host cores with the oracle's
                     C operators ("port"; rank 0, N=1 only), with per-stage seconds;
-  secondary      -- nq128_train_yaml_eval_forward (config 2's other yaml), train_step_b4 (config 3: batch 4, ~550k
+  secondary      -- nq128_train_yaml_eval_forward (config 2's other yaml), one_scene_at_a_time (the headline workload
+                    without the staggered loop), train_step_b4 (config 3: batch 4, ~550k
                     points, forward + criterion + backward + Adam, both epoch regimes), fs_1shot / fs_5shot (config 4:
                     S150k query + k full support scenes), fs_train_episode_b4 (its training-mode episode) and, for N > 1, train_dp_step (config 5: every rank a batch of 4,
                     bucketed RCCL gradient all-reduce; tools/train_dp.py's loop).
@@ -706,14 +707,15 @@ def main():
         i+1 is issued (the loop of rounds 1-3).  Every scene's outputs, proposals included, are complete when `finish`
         returns."""
 
-        def __init__(self):
+        def __init__(self, pipeline=None):
             self.prev = None
             self.last = None
             self.stag = {}
+            self.pipeline = args.pipeline if pipeline is None else pipeline
 
         def step(self, i, m=model):
             np.random.seed(1000 + i)
-            if not args.pipeline:
+            if not self.pipeline:
                 with torch.no_grad():
                     out = m(batches[i % ns], 300, training=False, defer_proposals=True)
                 self._collect()
@@ -820,6 +822,22 @@ def main():
                 "config": "config/geoformer_scannet.yaml (nq=128), same scenes, one GPU"}}
             del m128
             torch.cuda.empty_cache()
+            if args.pipeline:
+                # the same model and scenes one scene at a time (the loop of rounds 1-3; `--no-pipeline` makes it the headline)
+                plain = Loop(pipeline=False)
+                for i in range(ns):
+                    plain.step(i)
+                plain.finish()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(k):
+                    plain.step(200 + i)
+                plain.finish()
+                torch.cuda.synchronize()
+                e1 = time.perf_counter() - t1
+                res["secondary"]["one_scene_at_a_time"] = {
+                    "value": round(k / e1, 3), "unit": "scenes/s", "ms_per_step": round(e1 / k * 1e3, 3), "steps": k,
+                    "config": "the headline workload without the staggered serving loop (--no-pipeline)"}
             res["secondary"]["train_step_b4"] = secondary_train_step_b4(dev)
             res["secondary"].update(secondary_few_shot(dev))
             torch.cuda.empty_cache()
