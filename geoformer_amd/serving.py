@@ -25,13 +25,10 @@ cross-attention's 8-wave shape: equal to rounding); every scene handed to ``subm
 """
 from __future__ import annotations
 
-
 import numpy as np
 import torch
 
 from . import unet_exec
-
-
 
 _LANES = {}
 
@@ -40,7 +37,7 @@ class StaggeredForward:
     def __init__(self, model, device, epoch=300, phased=True):
         self.model, self.device, self.epoch, self.phased = model, torch.device(device), epoch, bool(phased)
         # the two lanes are a process resource (like the forward's side streams, which are keyed by them): a second loop
-        # object with fresh streams from the framework's pool has measured 5.0 against 4.2 ms per scene (bench.py's nq = 128
+        # object with fresh streams from the framework's pool has measured 5.0 against 3.9 ms per scene (bench.py's nq = 128
         # leg) -- which hardware queue a stream lands on depends on what was created before it
         key = (self.device.type, self.device.index if self.device.index is not None else torch.cuda.current_device())
         if key not in _LANES:
