@@ -7,14 +7,13 @@
 A "step" is one full ``GeoFormer.forward(batch, epoch, training=False)`` over one ~150k-point synthetic
 scene (BASELINE.json configs[1]; test yaml: nq=256, nc=2048, batch 1) with the batch dict already
 resident in HBM: voxel mean, 13 rulebooks, 71 sparse convs, semantic head, FPS, ball query, grouping,
-kNN graph + geodesic BFS, 4 decoder layers, dynamic-conv mask head, proposals.  The loop is a serving loop
-(geoformer_amd/serving.py): two scenes in flight on two streams, staggered -- scene i's decoder + mask head are queued
-behind scene i+1's sampling launches and run under that scene's sampling / BFS stretch (which leaves the chip nearly
-idle), scene i+1's backbone starts when scene i's stretch has ended, scene i's proposals are collected after scene i+2
-has been issued.  Same launches and per-scene results as ``forward`` (the cross-attention in its 8-wave workgroup shape).
-``--no-pipeline``: one scene at a time (the forward of scene i returns once everything up to the copy of the
-accepted-proposal count is queued -- ``defer_proposals`` -- and its proposals are collected after scene i+1 has been
-issued).  Either way all K scenes, proposals included, are complete inside the timed region.  The steps rotate over
+kNN graph + geodesic BFS, 4 decoder layers, dynamic-conv mask head, proposals.  The loop is the reference's test loop
+(test.py:60-110): ONE scene at a time on the current stream (the forward of scene i returns once everything up to the
+copy of the accepted-proposal count is queued -- ``defer_proposals`` -- and its proposals are collected after scene i+1
+has been issued).  ``--staggered``: the serving loop of geoformer_amd/serving.py instead (two scenes in flight on two
+streams: scene i's decoder + mask head under scene i+1's sampling / BFS stretch); it is timed as
+``secondary.staggered_two_in_flight`` in the default run -- it wins on some boxes and loses on others, so it
+is not the headline.  Either way all K scenes, proposals included, are complete inside the timed region.  The steps rotate over
 ``--scenes`` (8) different resident scenes (seeds 1234, 1235, ...), so no step finds the previous step's
 tables or features in L2/MALL.  Weights are random-init of the real architecture (no checkpoints
 offline); the semantic head's bias is shifted so ~40 % of the points are foreground like a real scene
@@ -34,8 +33,9 @@ The JSON line also carries
                     MFMA peak, mask head against both peaks, the BFS's achieved GB/s, microseconds per sampling pick;
   cpu_baseline   -- the same forward of scene 0 through the build's model on the host cores with the oracle's
                     C operators ("port"; rank 0, N=1 only), with per-stage seconds;
-  secondary      -- nq128_train_yaml_eval_forward (config 2's other yaml), one_scene_at_a_time (the headline workload
-                    without the staggered loop), train_step_b4 (config 3: batch 4, ~550k
+  secondary      -- nq128_train_yaml_eval_forward (config 2's other yaml), staggered_two_in_flight (the headline workload
+                    through the serving loop), fresh_scenes (24 timed steps, every one a never-before-seen scene of a
+                    new size: nothing cached per scene size can help), train_step_b4 (config 3: batch 4, ~550k
                     points, forward + criterion + backward + Adam, both epoch regimes), fs_1shot / fs_5shot (config 4:
                     S150k query + k full support scenes), fs_train_episode_b4 (its training-mode episode) and, for N > 1, train_dp_step (config 5: every rank a batch of 4,
                     bucketed RCCL gradient all-reduce; tools/train_dp.py's loop).
@@ -57,7 +57,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import geoformer_amd  # noqa: E402,F401  (before the first HIP call: the package sets the runtime's hardware-queue count)
+import geoformer_amd  # noqa: E402
+
+geoformer_amd.configure_runtime()  # GPU_MAX_HW_QUEUES, before this process's first HIP call (a user's value wins)
 
 PROBE_EVERY = 4  # timed steps between two probed ones
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -493,12 +495,9 @@ def _free_port():
 
 
 def self_launch(args, argv):
-    """`bench.py --gpus N` outside a torchrun environment: start the N ranks as a CHILD process (this process has not
-    touched a GPU and never will), relay what rank 0 prints, exit with the child's code."""
-    if not args.plumbing_test:
-        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
-        if have < args.gpus:
-            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+    """`bench.py --gpus N` outside a torchrun environment: start the N ranks as a CHILD process, relay what rank 0
+    prints, exit with the child's code.  This process makes no HIP call at all (not even a device count, which would
+    initialise the runtime here): a rank without a device fails with its own message."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
     r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
@@ -661,8 +660,10 @@ def main():
     ap.add_argument("--scenes", type=int, default=8, help="resident scenes the steps rotate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
-                    help="one scene at a time on one stream instead of two staggered scenes in flight")
+    ap.add_argument("--staggered", dest="pipeline", action="store_true",
+                    help="two staggered scenes in flight (geoformer_amd/serving.py) instead of one scene at a time")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="(default) one scene at a time")
+    ap.set_defaults(pipeline=False)
     ap.add_argument("--plumbing-test", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -701,30 +702,30 @@ def main():
     probe = ConvProbe(batches)
 
     class Loop:
-        """One scene per step.  Default: two scenes in flight, staggered (geoformer_amd/serving.py: scene i's decoder +
-        mask head run under scene i+1's sampling / BFS stretch, scene i+1's backbone starts when scene i's stretch has
-        ended).  --no-pipeline: one scene at a time on the current stream, scene i's proposals collected after scene
-        i+1 is issued (the loop of rounds 1-3).  Every scene's outputs, proposals included, are complete when `finish`
-        returns."""
+        """One scene per step.  Default: one scene at a time on the current stream, scene i's proposals collected after
+        scene i+1 is issued (what the unchanged test.py:60-110 runs).  pipeline=True: two scenes in flight, staggered
+        (geoformer_amd/serving.py).  Every scene's outputs, proposals included, are complete when `finish` returns."""
 
-        def __init__(self, pipeline=None):
+        def __init__(self, pipeline=None, scenes=None):
             self.prev = None
             self.last = None
             self.stag = {}
             self.pipeline = args.pipeline if pipeline is None else pipeline
+            self.scenes = batches if scenes is None else scenes
 
         def step(self, i, m=model):
             np.random.seed(1000 + i)
+            b = self.scenes[i % len(self.scenes)]
             if not self.pipeline:
                 with torch.no_grad():
-                    out = m(batches[i % ns], 300, training=False, defer_proposals=True)
+                    out = m(b, 300, training=False, defer_proposals=True)
                 self._collect()
                 self.prev = self.last = out
                 return out
             st = self.stag.get(id(m))
             if st is None:
                 st = self.stag[id(m)] = serving.StaggeredForward(m, dev)
-            for out in st.submit(batches[i % ns], seed=1000 + i):
+            for out in st.submit(b, seed=1000 + i):
                 self.last = out
 
         def _collect(self):
@@ -737,6 +738,16 @@ def main():
             for st in self.stag.values():
                 for out in st.drain():
                     self.last = out
+
+        def timed(self, first, k, m=model):
+            """k steps between two device synchronisations -> seconds."""
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(k):
+                self.step(first + i, m)
+            self.finish()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
 
     loop = Loop()
     step = loop.step
@@ -795,7 +806,8 @@ def main():
                                     "decoder + mask head run under scene i+1's sampling / BFS stretch, scene i+1's backbone "
                                     "starts when scene i's stretch has ended; all scenes complete inside the timed region"
                                     if args.pipeline else
-                                    "one scene at a time, proposals of scene i collected after scene i+1 is issued"),
+                                    "one scene at a time as in the reference's test.py:60-110, proposals of scene i "
+                                    "collected after scene i+1 is issued; all scenes complete inside the timed region"),
                        "points": [int(b["locs"].shape[0]) for b in batches], "voxels": Ms, "n_fg_last": n_fg,
                        "parallelism": f"replicas x{world}"},
             "roofline": probe.result(),
@@ -810,34 +822,41 @@ def main():
             for i in range(max(min(args.warmup, 4), ns)):  # every scene once: one-time costs per (model, scene) stay out
                 step(i, m128)
             loop.finish()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(k):
-                step(100 + i, m128)
-            loop.finish()
-            torch.cuda.synchronize()
-            e1 = time.perf_counter() - t1
+            e1 = loop.timed(100, k, m128)
             res["secondary"] = {"nq128_train_yaml_eval_forward": {
                 "value": round(k / e1, 3), "unit": "scenes/s", "ms_per_step": round(e1 / k * 1e3, 3), "steps": k,
-                "config": "config/geoformer_scannet.yaml (nq=128), same scenes, one GPU"}}
+                "config": "config/geoformer_scannet.yaml (nq=128), same scenes, one GPU, same loop as the headline"}}
             del m128
             torch.cuda.empty_cache()
-            if args.pipeline:
-                # the same model and scenes one scene at a time (the loop of rounds 1-3; `--no-pipeline` makes it the headline)
-                plain = Loop(pipeline=False)
-                for i in range(ns):
-                    plain.step(i)
-                plain.finish()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(k):
-                    plain.step(200 + i)
-                plain.finish()
-                torch.cuda.synchronize()
-                e1 = time.perf_counter() - t1
-                res["secondary"]["one_scene_at_a_time"] = {
-                    "value": round(k / e1, 3), "unit": "scenes/s", "ms_per_step": round(e1 / k * 1e3, 3), "steps": k,
-                    "config": "the headline workload without the staggered serving loop (--no-pipeline)"}
+            # the headline workload through the other loop (every scene warmed once in it first)
+            other = Loop(pipeline=not args.pipeline)
+            for i in range(ns):
+                other.step(i)
+            other.finish()
+            e1 = other.timed(200, k)
+            res["secondary"]["one_scene_at_a_time" if args.pipeline else "staggered_two_in_flight"] = {
+                "value": round(k / e1, 3), "unit": "scenes/s", "ms_per_step": round(e1 / k * 1e3, 3), "steps": k,
+                "config": ("the headline workload one scene at a time" if args.pipeline else
+                           "the headline workload through geoformer_amd/serving.py: two scenes in flight on two streams, "
+                           "staggered (--staggered makes it the headline); every scene seen once before the timed steps")}
+            # a serving workload: every timed step a scene of a size the process has never seen (no per-size cache, no
+            # allocator block of the right size), through the headline's loop
+            nfresh = 24
+            rs = np.random.RandomState(99)
+            sizes = rs.permutation(np.linspace(0.72, 1.28, nfresh + 2) * args.points).astype(int)
+            fresh = [to_device(scene.make_batch([scene.make_scene(int(n), 5000 + j)]), dev) for j, n in enumerate(sizes)]
+            fl = Loop(scenes=fresh)
+            fl.step(0), fl.step(1)
+            fl.finish()
+            e1 = fl.timed(2, nfresh)
+            res["secondary"]["fresh_scenes"] = {
+                "value": round(nfresh / e1, 3), "unit": "scenes/s", "ms_per_step": round(e1 / nfresh * 1e3, 3), "steps": nfresh,
+                "points": [int(b["locs"].shape[0]) for b in fresh[2:]],
+                "config": f"{nfresh} timed steps, every one a never-before-seen scene ({int(sizes.min())}-{int(sizes.max())} "
+                          "points, all sizes different; two other fresh scenes as warm-up), resident in HBM, same model and "
+                          "loop as the headline"}
+            del fresh, fl
+            torch.cuda.empty_cache()
             res["secondary"]["train_step_b4"] = secondary_train_step_b4(dev)
             res["secondary"].update(secondary_few_shot(dev))
             torch.cuda.empty_cache()

@@ -146,6 +146,28 @@ def _declare(lib):
 EXPORTS = None
 
 
+def _check_hw_queues(torch):
+    """The forward runs its latency-bound kernels beside each other on several streams; with the HIP runtime's default
+    of 4 hardware queues streams alias and those kernels serialise (geoformer_amd/__init__.py).  The runtime reads
+    GPU_MAX_HW_QUEUES once, at its first call: nothing can be fixed from here, so say so."""
+    import warnings
+
+    from . import HW_QUEUES_MIN, HW_QUEUES_WANTED, hw_queues_setting
+
+    have = hw_queues_setting()
+    if have is not None and have >= HW_QUEUES_MIN:
+        return
+    up = torch.cuda.is_initialized()
+    warnings.warn(
+        f"geoformer_amd: GPU_MAX_HW_QUEUES is {'unset (runtime default 4)' if have is None else have}"
+        + (" and the HIP runtime is already initialised" if up else "")
+        + f": streams will share hardware queues and the sampling / BFS kernels of a forward run one after the other "
+        f"(measured: eval forward 183 -> 143 scenes/s, batch-4 training step +3.6 ms).  Export GPU_MAX_HW_QUEUES="
+        f"{HW_QUEUES_WANTED} or call geoformer_amd.configure_runtime() before the process's first HIP call"
+        + (" (e.g. before torch.cuda.set_device in train.py / test.py)." if up else "."),
+        RuntimeWarning, stacklevel=3)
+
+
 def load():
     """Load the shared library (after ``import torch`` so both share one HIP runtime)."""
     global _lib, EXPORTS
@@ -158,6 +180,7 @@ def load():
         )
     import torch  # noqa: F401  (loads libamdhip64 first; our library binds to the same SONAME)
 
+    _check_hw_queues(torch)
     lib = ctypes.CDLL(LIB_PATH)
     EXPORTS = _declare(lib)
     if lib.gf_abi_version() != 2:

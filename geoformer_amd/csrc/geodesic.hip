@@ -20,15 +20,16 @@
 #include <cstdlib>
 #include "common.h"
 
-// Scope of the atomics on a query's key row.  Every access to the row of query q -- the bids' atomic minima, the
-// commit's loads -- comes from the ONE workgroup that owns q, so WORKGROUP scope is what the algorithm needs (the
-// commit's loads become sc0 instead of sc1 loads; the read-modify-writes are the same instruction at either scope).
-// Measured (profiles/r3_pmc_bfs.md): no difference in time or traffic -- a 256-query launch moves 2.4 GB of fetches +
+// Scope of the atomics on a query's key row: AGENT.  Every access to the row of query q -- the bids' atomic minima, the
+// commit's loads -- comes from the ONE workgroup that owns q, so workgroup scope would be what the algorithm needs, but
+// it is only correct while all waves of a workgroup share one coherent L1 (not in tgsplit mode), and it buys nothing:
+// measured (profiles/r3_pmc_bfs.md), no difference in time or traffic -- a 256-query launch moves 2.4 GB of fetches +
 // 1.4 GB of writes through the fabric (TCC hit rate 12 %) against ~0.24 GB of algorithmic traffic, at either scope: it is
 // the ~76 M scattered 8-byte minima themselves (~5 bids per reached vertex, each a 32-byte sector each way), which the
 // XCD's L2 does not hold on to (32 queries x 480 KB of keys per XCD against 4 MB).
+// -DBFS_KEY_SCOPE=__HIP_MEMORY_SCOPE_WORKGROUP is a dev knob.
 #ifndef BFS_KEY_SCOPE
-#define BFS_KEY_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#define BFS_KEY_SCOPE __HIP_MEMORY_SCOPE_AGENT
 #endif
 #include <type_traits>
 

@@ -387,10 +387,11 @@ class GeoFormer(nn.Module):
         if os.environ.get("GF_UNET_EXEC", "1") != "0" and unet_exec.supported(self, x.features, x.spatial_shape):
             x.features = unet_exec.unet_forward(self, x.features.contiguous(), x._coords(), batch_size, x.spatial_shape)
             return x
-        if unet_train.supported(self, x):
+        sig = unet_train.supported(self, x)
+        if sig:
             # training: the same launches as the module tree below, forward and backward, issued by native code
             # (csrc/unet_train.hip); the two voxel transformers stay framework modules between its three ranges
-            feats = unet_train.unet_forward(self, x, batch_size)
+            feats = unet_train.unet_forward(self, x, batch_size, sig)
             if feats is not None:
                 x.features = feats
                 return x

@@ -117,6 +117,10 @@ class SparseSequential(SparseModule):
                         i += 1
                     else:
                         input.features = module(input.features)
+                elif getattr(module, "sync_across_ranks", False) and module.training:
+                    # spconv skips dense modules on an empty tensor; a layer whose statistics span ranks must still be
+                    # entered (count 0): the other ranks are waiting in its collective (parallel.SyncBatchNorm1d)
+                    input.features = module(input.features)
             else:
                 input = module(input)
         return input

@@ -54,15 +54,34 @@ class Segment:
         self.transformer = None  # (UBlock, level) applied to the range's output by the framework
 
 
-class Program:
-    """The module tree as ops (built once per model; parameters are referenced by address: in-place optimizer updates
-    keep it valid)."""
+def tree_signature(model):
+    """Identity of everything a Program bakes in: the ids of the U-Net's modules and the addresses of their parameters
+    and buffers (~900 integers, ~0.4 ms per training forward).  A module replaced (convert_sync_batchnorm, a swapped
+    block) or a tensor re-allocated (load_state_dict(assign=True), ``p.data = ...``, an EMA swap) changes it."""
+    sig = []
+    for root in (model.input_conv, model.unet, model.output_layer):
+        for mod in root.modules():
+            sig.append(id(mod))
+            for t in mod._parameters.values():
+                if t is not None:
+                    sig.append(t.data_ptr())
+            for t in mod._buffers.values():
+                if t is not None:
+                    sig.append(t.data_ptr())
+    return tuple(sig)
 
-    def __init__(self, model):
+
+class Program:
+    """The module tree as ops.  Parameters and BatchNorm buffers are referenced by ADDRESS (in-place optimizer updates
+    keep them valid); the program holds a reference to every such tensor (``keep``: the addresses stay allocated for as
+    long as the program lives) and the tree's signature, against which every forward re-validates it (``_program``)."""
+
+    def __init__(self, model, signature=None):
         lib = _lib.load()
         self.ops, self.bufs, self.segments = [], [], []
         self.wp_floats = self.pgrad_floats = self.stats_floats = 0
         self.keep = []
+        self.signature = tree_signature(model) if signature is None else signature
         ic = model.input_conv[0]
         x0 = self._buf(0, ic.in_channels)
         self.seg = Segment(0, x0)
@@ -75,7 +94,6 @@ class Program:
         self.ref = ctypes.addressof(self.array)
         self.buf_level = np.array([b[0] for b in self.bufs], dtype=np.int64)
         self.buf_C = np.array([b[1] for b in self.bufs], dtype=np.int64)
-        self.first_ptr = model.input_conv[0].weight.data_ptr()
         self.lib = lib
 
     # -- compilation --------------------------------------------------------------------------
@@ -100,6 +118,7 @@ class Program:
         op = TrainOp(kind=BN_RELU, level=level, src=src, dst=dst, aux=-1, Cin=C, Cout=C)
         op.gamma, op.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
         op.running_mean, op.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        self.keep += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
         op.eps, op.momentum = float(bn.eps), float(bn.momentum)
         op.stats_off, op.pgrad_off = self.stats_floats, self.pgrad_floats
         self.stats_floats += 2 * C
@@ -119,6 +138,7 @@ class Program:
         op = TrainOp(kind=CONV, level=level, table=table, src=src, dst=dst, aux=aux, Cin=Cin, Cout=Cout,
                      no_dgrad=int(no_dgrad))
         op.w = conv.weight.data_ptr()
+        self.keep.append(conv.weight)
         op.wp_off, op.pgrad_off = self.wp_floats, self.pgrad_floats
         self.wp_floats += _r(_lib.load().gf_conv_packed_floats(K, Cin, Cout), 64)
         self._param(conv.weight, self.pgrad_floats, K * Cin * Cout)
@@ -171,15 +191,18 @@ def _bn_list(model):
     return _bn_modules(model)
 
 
-def supported(model, x):
-    """Training on the GPU with every U-Net parameter trainable and every BatchNorm in training mode."""
+def supported(model, x, signature=None):
+    """Training on the GPU with every U-Net parameter trainable and every BatchNorm in training mode.  The structural
+    part of the answer is cached per tree signature: a tree that changed (SyncBatchNorm conversion after a first
+    training forward, re-allocated tensors) is examined again."""
     if os.environ.get("GF_UNET_TRAIN_EXEC", "1") == "0" or os.environ.get("GF_FUSED_BN", "1") == "0":
         return False
     f = x.features
     if not (torch.is_grad_enabled() and f.is_cuda and f.dtype == torch.float32 and f.shape[0] >= 2 and not f.requires_grad):
         return False
+    sig = tree_signature(model) if signature is None else signature
     hit = model.__dict__.get("_gf_unet_train_static")
-    if hit is None:
+    if hit is None or hit[0] != sig:
         try:
             from .model.backbone import ResidualBlock, UBlock
             from .unet_exec import _levels
@@ -196,17 +219,20 @@ def supported(model, x):
         except Exception:  # an unfamiliar module tree: the module route handles it
             ok, bns, lv = False, [], []
         params = [p for m in (model.input_conv, model.unet, model.output_layer) for p in m.parameters()]
-        hit = model.__dict__["_gf_unet_train_static"] = (ok, bns, params, len(lv))
-    ok, bns, params, nl = hit
+        hit = model.__dict__["_gf_unet_train_static"] = (sig, ok, bns, params, len(lv))
+    _, ok, bns, params, nl = hit
     if not ok or not all(b.training for b in bns) or not all(p.requires_grad for p in params):
         return False
-    return all((int(s) >> k) >= 2 for s in x.spatial_shape for k in range(nl - 1))
+    if not all((int(s) >> k) >= 2 for s in x.spatial_shape for k in range(nl - 1)):
+        return False
+    return sig  # (truthy; unet_forward takes it, so the tree is walked once per forward)
 
 
-def _program(model):
+def _program(model, signature=None):
+    sig = tree_signature(model) if signature is None else signature
     hit = model.__dict__.get("_gf_unet_train_prog")
-    if hit is None or hit.first_ptr != model.input_conv[0].weight.data_ptr():
-        hit = model.__dict__["_gf_unet_train_prog"] = Program(model)
+    if hit is None or hit.signature != sig:
+        hit = model.__dict__["_gf_unet_train_prog"] = Program(model, sig)
     return hit
 
 
@@ -292,10 +318,10 @@ class _SegFn(torch.autograd.Function):
         return (None, None, gin, *pg)
 
 
-def unet_forward(model, x, batch_size):
+def unet_forward(model, x, batch_size, signature=None):
     """Output features [M,16] (with autograd history) of input_conv -> unet -> output_layer for the SparseConvTensor x
     in training mode; None when a level is too small for the native route (the module route then runs)."""
-    prog = _program(model)
+    prog = _program(model, signature)
     coords = x._coords()
     nl = prog.nlevels
     chain = sparse.down_rules_chain(coords, x.batch_size, x.spatial_shape, nl - 1)

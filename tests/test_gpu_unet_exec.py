@@ -141,3 +141,57 @@ def test_unet_train_exec_matches_module_route(hip, scenes):
     # eval-mode BatchNorm or a frozen parameter: not this route
     m.unet.blocks.block0.conv_branch[0].eval()
     assert not unet_train.supported(m, m.preprocess_input(batch, len(scenes)))
+
+
+def test_unet_train_exec_sees_reallocated_tensors_and_replaced_modules(hip):
+    """The layer program bakes addresses in: after a first native training forward, (i) tensors that are
+    re-allocated -- a BatchNorm's running statistics and gamma through ``.data =``, a convolution weight through
+    load_state_dict(assign=True) -- must be the ones the next forward reads and updates, and (ii) a BatchNorm replaced by
+    a SyncBatchNorm1d must take the model off the native route."""
+    import copy
+
+    from geoformer_amd import parallel, scene, unet_train
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    m = GeoFormer(load_config("geoformer_scannet.yaml", batch_size=1))
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 3))
+    m.cuda()
+    m.train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    batch = scene.make_batch([scene.make_small_scene(8192, 5)])
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    state = copy.deepcopy(m.state_dict())
+    _train_backbone(m, batch, native=True, seed=1)  # compiles the program
+    prog0 = m.__dict__["_gf_unet_train_prog"]
+    m.load_state_dict(state)
+    # (i) new storage for some tensors, new VALUES in them: the old addresses keep the old values (the program's
+    # references keep them allocated), so a forward that still read them would reproduce the first run
+    bn = m.unet.blocks.block0.conv_branch[0]
+    with torch.no_grad():
+        bn.weight.data = bn.weight.data.clone() * 1.5
+        bn.running_mean.data = bn.running_mean.data.clone() + 0.25
+        bn.running_var.data = bn.running_var.data.clone() * 2.0
+    w = m.unet.blocks.block1.conv_branch[2].weight
+    sd = {k: v for k, v in m.state_dict().items()}
+    sd["unet.blocks.block1.conv_branch.2.weight"] = (w.detach() * 0.5).clone()
+    m.load_state_dict(sd, assign=True)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    state2 = copy.deepcopy(m.state_dict())
+    f_ref, g_ref, s_ref = _train_backbone(m, batch, native=False, seed=1)
+    m.load_state_dict(state2)
+    assert unet_train.supported(m, m.preprocess_input(batch, 1))
+    f_nat, g_nat, s_nat = _train_backbone(m, batch, native=True, seed=1)
+    assert m.__dict__["_gf_unet_train_prog"] is not prog0
+    assert float((f_nat - f_ref).abs().max()) <= 2e-6 * max(1.0, float(f_ref.abs().max()))
+    for n in s_ref:
+        assert float((s_nat[n] - s_ref[n]).abs().max()) <= 1e-6 * max(1.0, float(s_ref[n].abs().max())), n
+    for n in ("blocks.block0.conv_branch.0.weight", "blocks.block1.conv_branch.2.weight"):  # (names inside m.unet)
+        gr, gn = g_ref[n], g_nat[n]
+        assert float((gn - gr).norm()) <= 5e-3 * max(float(gr.norm()), 1e-8), n
+    # (ii) SyncBatchNorm conversion AFTER a first native forward: the structural answer is not a stale cache entry
+    parallel.convert_sync_batchnorm(m)
+    assert not unet_train.supported(m, m.preprocess_input(batch, 1))

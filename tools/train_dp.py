@@ -25,7 +25,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-import geoformer_amd  # noqa: E402,F401  (before the first HIP call: the package sets the runtime's hardware-queue count)
+import geoformer_amd  # noqa: E402
+
+geoformer_amd.configure_runtime()  # GPU_MAX_HW_QUEUES, before this process's first HIP call (a user's value wins)
 
 
 def build(args, device):
