@@ -250,17 +250,30 @@ def all_convs_roofline(model, batches, reps=2):
 
 
 class OpProbe:
-    """Event pairs around the launches of the other blocks north_star names, in untimed extra forwards: the fused
-    cross-attention (MFMA-bound), the mask head, the geodesic BFS (HBM / latency) and the sampling.  The events are
-    recorded on the stream the operator is launched on (the BFS runs on the model's side stream beside the sampling,
-    as in the timed loop)."""
+    """The other blocks north_star names, in untimed extra forwards: the fused cross-attention (MFMA-bound), the mask
+    head, the geodesic BFS (HBM / latency) and the sampling.  Durations are those of the operators' main KERNELS: two
+    events bound to the launch itself inside the native call (gf_dev_op_kernel_events -> hipExtLaunchKernelGGL: the
+    dispatch's begin / end timestamps, the quantity a rocprofv3 kernel trace reports) -- not events recorded around the
+    Python call, which would include host work between the records (12.7 ms read for a 2.06 ms BFS).  The
+    kernels run where the forward launches them (the BFS on the side stream beside the sampling)."""
 
-    NAMES = ("decoder_cross_attn", "mask_head_packed", "mask_head", "geodesic_bfs", "furthest_point_sampling")
+    NAMES = {"decoder_cross_attn": 1, "mask_head_packed": 2, "mask_head": 2, "geodesic_bfs": 0, "furthest_point_sampling": 3}
 
     def __init__(self):
-        from geoformer_amd import pointops
+        import ctypes
+
+        from geoformer_amd import _lib, pointops
 
         self.po, self.saved, self.recs = pointops, {}, []
+        self.lib, self.ct = _lib.load(), ctypes
+        self.pool = []
+
+    def _ev(self):
+        e = self.lib.gf_dev_event_create()
+        if not e:
+            raise RuntimeError("gf_dev_event_create failed")
+        self.pool.append(e)
+        return e
 
     def __enter__(self):
         for name in self.NAMES:
@@ -272,24 +285,35 @@ class OpProbe:
     def __exit__(self, *exc):
         for name, fn in self.saved.items():
             setattr(self.po, name, fn)
+        for op in set(self.NAMES.values()):
+            self.lib.gf_dev_op_kernel_events(op, None, None)
 
     def _wrap(self, name, fn):
+        op = self.NAMES[name]
+
         def w(*a, **k):
-            st = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(st)
+            e0, e1 = self._ev(), self._ev()
+            self.lib.gf_dev_op_kernel_events(op, e0, e1)
             r = fn(*a, **k)
-            e1.record(st)
-            self.recs.append((name, e0, e1, a, r, k))
+            if self.lib.gf_dev_op_kernel_events_taken(op):
+                self.recs.append((name, e0, e1, a, r, k))
+            else:  # (an early exit without a launch)
+                self.lib.gf_dev_op_kernel_events(op, None, None)
             return r
 
         return w
+
+    def _us(self, e0, e1):
+        us = self.ct.c_float()
+        if self.lib.gf_dev_event_elapsed_us(e0, e1, self.ct.byref(us)) != 0:
+            raise RuntimeError("gf_dev_event_elapsed_us failed")
+        return float(us.value)
 
     def result(self):
         torch.cuda.synchronize()
         acc = {}
         for name, e0, e1, a, r, kw in self.recs:
-            us = e0.elapsed_time(e1) * 1e3
+            us = self._us(e0, e1)
             if name == "decoder_cross_attn":
                 B, nq, nc = a[0].shape
                 d = a[7].shape[-1]
@@ -313,6 +337,11 @@ class OpProbe:
             t["n"] += 1
             for k2, v in w.items():
                 t[k2] = t.get(k2, 0) + v
+        for e in self.pool:
+            self.lib.gf_dev_event_destroy(e)
+        self.pool = []
+        clock = ("two events bound to the kernel launch inside the native call (hipExtLaunchKernelGGL: the dispatch's "
+                 "begin / end timestamps), on the stream the forward launches it on")
         out = {}
         if "decoder_cross_attn" in acc:
             t = acc["decoder_cross_attn"]
@@ -321,7 +350,8 @@ class OpProbe:
                                        "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_decoder_cross_attn",
                                        "launches": t["n"], "us_per_launch": round(t["us"] / t["n"], 2),
                                        "flop_per_launch": t["flop"] // t["n"],
-                                       "formula": "3 * 2 * nq * nc * B * d^2 (SURVEY 8d: the pair MLP's two layers + the value projection)"}
+                                       "formula": "3 * 2 * nq * nc * B * d^2 (SURVEY 8d: the pair MLP's two layers + the value projection)",
+                                       "clock": clock}
         if "mask_head" in acc:
             t = acc["mask_head"]
             tf = t["flop"] / (t["us"] * 1e-6) / 1e12
@@ -332,7 +362,7 @@ class OpProbe:
                                          "flop_per_launch": t["flop"] // t["n"], "bytes_per_launch": t["bytes"] // t["n"],
                                          "hbm_GB/s": round(gb, 1), "hbm_frac": round(gb / HBM_PEAK_GBS, 4),
                                          "formula": "flop 2 * nq * N_fg * (19 * 16 + 16), bytes 4 * (2 * nq * N_fg + 19 * N_fg): "
-                                                    "80 flop/B, above the fp32 ridge (20)"}
+                                                    "80 flop/B, above the fp32 ridge (20)", "clock": clock}
         if "geodesic_bfs" in acc:
             t = acc["geodesic_bfs"]
             gb = t["bytes"] / (t["us"] * 1e-6) / 1e9
@@ -342,12 +372,14 @@ class OpProbe:
                                    "bytes_per_launch": t["bytes"] // t["n"],
                                    "frontier_entries_per_launch": t["pairs_reached"] // t["n"],
                                    "formula": "12 * 63 * N_fg (graph) + 4 * nq * N_fg (distances) + 8 * sum of frontier sizes",
-                                   "note": "a chain of up to 256 dependent hops per query: latency-bound, runs beside the sampling"}
+                                   "note": "a chain of up to 256 dependent hops per query: latency-bound, runs beside the sampling",
+                                   "clock": clock}
         if "furthest_point_sampling" in acc:
             t = acc["furthest_point_sampling"]
             out["sampling"] = {"kernel": "k_fps", "launches": t["n"], "us_total_per_forward": None, "picks": t["picks"],
                                "us_per_pick": round(t["us"] / max(t["picks"], 1), 3),
-                               "note": "2047 dependent arg-max rounds over <= 50 000 points: serial latency, no roofline"}
+                               "note": "2047 dependent arg-max rounds over <= 50 000 points: serial latency, no roofline",
+                               "clock": clock}
         return out
 
 

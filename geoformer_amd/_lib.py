@@ -61,6 +61,11 @@ def _declare(lib):
         "gf_dev_unet_probe_read2": (I, [I, P, P, P]),
         "gf_dev_conv_kernel_events": (I, [P, P]),
         "gf_dev_conv_kernel_events_taken": (I, []),
+        "gf_dev_op_kernel_events": (I, [I, P, P]),
+        "gf_dev_op_kernel_events_taken": (I, [I]),
+        "gf_dev_event_create": (P, []),
+        "gf_dev_event_destroy": (I, [P]),
+        "gf_dev_event_elapsed_us": (I, [P, P, P]),
         "gf_unet_fwd": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P]),
         "gf_unet_fwd_phased": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P, P, I, P, P]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
@@ -80,6 +85,7 @@ def _declare(lib):
         "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, I, P]),
         "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
         "gf_mask_head_packed": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+        "gf_mask_head_episodes": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
         "gf_mask_head_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P]),
         "gf_mask_head_bwd_scratch_floats": (c_size_t, [I, I]),
         "gf_softmax_dim1_fwd": (I, [P, I, I, I, F, P, P]),

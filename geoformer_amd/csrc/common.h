@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels of libgeoformer_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -54,6 +55,29 @@ int gf_rules_down2_chain_range(const int32_t* coords, int M0, int B, int X, int 
                                int l_end, int32_t* ws, int32_t* counts, hipStream_t st);
 
 static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- dev hook: events BOUND to the next launch of an operator's main kernel (include/geoformer_hip_dev.h:
+// gf_dev_op_kernel_events).  hipExtLaunchKernelGGL's start / stop events are the dispatch's own begin / end timestamps,
+// i.e. what a profiler's kernel trace reports for that kernel -- no host time, no neighbouring launches inside.
+// Per host thread; defined in spconv_rules.hip. ----
+enum { GF_OP_BFS = 0, GF_OP_CROSS_ATTN = 1, GF_OP_MASK_HEAD = 2, GF_OP_FPS = 3, GF_OP_CROSS_ATTN_BWD = 4,
+       GF_OP_MASK_HEAD_BWD_FEAT = 5, GF_OP_MASK_HEAD_BWD_PARAM = 6, GF_OP_WGRAD = 7, GF_OP_COUNT = 8 };
+struct GfOpEvents {
+    hipEvent_t start, stop;
+    int taken;
+};
+GfOpEvents* gf_op_events(int op);
+#define GF_LAUNCH_OP(op, kernel, grid, block, lds, st, ...)                                              \
+    do {                                                                                                 \
+        GfOpEvents* oe__ = gf_op_events(op);                                                             \
+        if (oe__->start) {                                                                               \
+            hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)(lds), st, oe__->start, oe__->stop, 0u, __VA_ARGS__); \
+            oe__->start = oe__->stop = nullptr;                                                          \
+            oe__->taken = 1;                                                                             \
+        } else {                                                                                         \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                               \
+        }                                                                                                \
+    } while (0)
 
 // ---- occupancy-bitmap rank index (see spconv_rules.hip) ----
 struct GfIndex {

@@ -253,11 +253,13 @@ extern "C" int gf_decoder_cross_attn_cfg(const float* geo_ctx, const float* max_
     if (B == 0 || nq == 0) return GF_OK;
     (void)b2;  // a per-channel constant cancels in the per-channel soft-max over the contexts
     if (wg_waves == 16)
-        hipLaunchKernelGGL(k_decoder_cross_attn<16>, dim3(nq, B), dim3(16 * 64), 0, (hipStream_t)stream, geo_ctx, max_geo, qloc,
-                           cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out, stat_m, stat_l);
+        GF_LAUNCH_OP(GF_OP_CROSS_ATTN, k_decoder_cross_attn<16>, dim3(nq, B), dim3(16 * 64), 0, (hipStream_t)stream, geo_ctx,
+                     max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out,
+                     stat_m, stat_l);
     else
-        hipLaunchKernelGGL(k_decoder_cross_attn<8>, dim3(nq, B), dim3(8 * 64), 0, (hipStream_t)stream, geo_ctx, max_geo, qloc,
-                           cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out, stat_m, stat_l);
+        GF_LAUNCH_OP(GF_OP_CROSS_ATTN, k_decoder_cross_attn<8>, dim3(nq, B), dim3(8 * 64), 0, (hipStream_t)stream, geo_ctx,
+                     max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out,
+                     stat_m, stat_l);
     GF_CHECK_LAUNCH("gf_decoder_cross_attn");
     return GF_OK;
 }
@@ -622,10 +624,9 @@ extern "C" int gf_decoder_cross_attn_bwd(const float* geo_ctx, const float* max_
     float* dQ1p = dWp + (size_t)waves * 3 * DA_D * DA_D;
     float* w2t = dQ1p + (size_t)ntiles * B * nq * DA_D;
     hipLaunchKernelGGL(k_decoder_pack_w2t, dim3(16), dim3(256), 0, st, W2, w2t);
-    hipLaunchKernelGGL(k_decoder_cross_attn_bwd, dim3((waves + 3) / 4), dim3(256), 0, st, geo_ctx, max_geo, qloc, cloc, lo,
-                       hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack),
-                       reinterpret_cast<const float4*>(w2t), out, stat_m, stat_l, gout, B, nq, nc, qs, dQ1p, dK1, dKv,
-                       dWp);
+    GF_LAUNCH_OP(GF_OP_CROSS_ATTN_BWD, k_decoder_cross_attn_bwd, dim3((waves + 3) / 4), dim3(256), 0, st, geo_ctx, max_geo,
+                 qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack),
+                 reinterpret_cast<const float4*>(w2t), out, stat_m, stat_l, gout, B, nq, nc, qs, dQ1p, dK1, dKv, dWp);
     const size_t nW = (size_t)3 * DA_D * DA_D, nQ = (size_t)B * nq * DA_D;
     hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nW / 4, 64)), dim3(64), 0, st, dWp, waves, nW, dW);
     hipLaunchKernelGGL(k_sum_parts, dim3(gf_div_up((long long)nQ / 4, 64)), dim3(64), 0, st, dQ1p, ntiles, nQ, dQ1);

@@ -847,8 +847,8 @@ static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, c
                                   BFS_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_geodesic_bfs_lds<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
-                       geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
+    GF_LAUNCH_OP(GF_OP_BFS, k_geodesic_bfs_lds<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
+                 geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
 }
 
 // wg_threads: threads (and, in proportion, LDS) per query.  The kernel spreads a ring's row entries over the lanes, so

@@ -42,8 +42,11 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
                                                       const float* __restrict__ geo, const float* __restrict__ qxyz,
                                                       const float* __restrict__ mx, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
-                                                      const float* __restrict__ b2, int ldp, int N, int nq, int chunks,
-                                                      float* __restrict__ out) {
+                                                      const float* __restrict__ b2, int ldp, int N, int nq, int qmod,
+                                                      int chunks, float* __restrict__ out) {
+    // nq = E * qmod rows of generated parameters and of logits: E episodes (few-shot re-queries of one cached scene,
+    // test_fs.py:157-174) over the SAME qmod queries -- row qq reads the geodesic row, position and maximum of query
+    // qq % qmod.  qmod = nq: one episode.
     // ldp: 0 = four dense arrays (w1 [nq,16,19], b1 [nq,16], w2 [nq,16], b2 [nq]); else the row stride of ONE packed
     // parameter matrix the four pointers point into (the controller's output, geoformer.py:264-284)
     const int ld_w1 = ldp ? ldp : 16 * 19, ld_v = ldp ? ldp : 16, ld_s = ldp ? ldp : 1;
@@ -74,9 +77,13 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; r++) ww[t][r] = w2[(size_t)q * ld_v + 4 * g + r];
         b2q[t] = b2[(size_t)q * ld_s];
-        qc[t] = g < 3 ? qxyz[q * 3 + g] : 0.f;
-        mq[t] = USE_GEO ? mx[q] : 0.f;
+        const int qs = q % qmod;  // the scene-side query of this parameter row
+        qc[t] = g < 3 ? qxyz[qs * 3 + g] : 0.f;
+        mq[t] = USE_GEO ? mx[qs] : 0.f;
     }
+    int qrow[MH_Q];  // geodesic row of each of the wave's queries
+#pragma unroll
+    for (int u = 0; u < MH_Q; u++) qrow[u] = min(qg * MH_Q + u, nq - 1) % qmod;
 
     // Operands of one 64-point block: features (B operand) and this lane group's coordinate of column j for the four
     // 16-point tiles, and the block's geodesic distances for this wave's queries.  Everything a block needs is
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
             B.pc[t] = coords[(size_t)pc * 3 + min(g, 2)];
 #pragma unroll
             for (int u = 0; u < MH_Q; u++)
-                B.gd[u][t] = USE_GEO ? geo[(size_t)min(qg * MH_Q + u, nq - 1) * N + pc] : 0.f;
+                B.gd[u][t] = USE_GEO ? geo[(size_t)qrow[u] * N + pc] : 0.f;
         }
     };
     Block cur, nxt;
@@ -151,6 +158,9 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
 extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const float* geo, const float* qxyz,
                                    const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
                                    const float* b2, int ldp, int N, int nq, int C, float* out, void* stream);
+extern "C" int gf_mask_head_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                                     const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                                     const float* b2, int ldp, int N, int nq, int E, int C, float* out, void* stream);
 extern "C" int gf_mask_head(const float* feat, const float* coords, const float* geo, const float* qxyz,
                             const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
                             const float* b2, int N, int nq, int C, float* out, void* stream) {
@@ -162,11 +172,22 @@ extern "C" int gf_mask_head(const float* feat, const float* coords, const float*
 extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const float* geo, const float* qxyz,
                                    const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
                                    const float* b2, int ldp, int N, int nq, int C, float* out, void* stream) {
+    return gf_mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2, ldp, N, nq, 1, C, out, stream);
+}
+
+// E episodes over one scene in ONE launch (test_fs.py:157-174 re-queries a cached scene once per
+// (label, run)): parameters [E * nq, ...] and logits [E * nq, N], episode-major; geo [nq, N], qxyz [nq, 3],
+// sqrt_max_geo [nq], feat and coords are the scene's and shared by all episodes.
+extern "C" int gf_mask_head_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                                     const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                                     const float* b2, int ldp, int N, int nq_scene, int E, int C, float* out, void* stream) {
     GF_CHECK_ARG(ldp >= 0, "gf_mask_head: negative parameter stride");
     GF_CHECK_ARG(C == 16, "gf_mask_head: only the 16-channel mask head (m=16) is implemented, got C=%d", C);
-    GF_CHECK_ARG(N >= 0 && nq >= 0, "gf_mask_head: bad sizes");
+    GF_CHECK_ARG(N >= 0 && nq_scene >= 0 && E >= 1, "gf_mask_head: bad sizes");
+    GF_CHECK_ARG((long long)nq_scene * E < (1ll << 30), "gf_mask_head: %d episodes x %d queries", E, nq_scene);
     GF_CHECK_ARG((geo == nullptr) == (sqrt_max_geo == nullptr), "gf_mask_head: geo and sqrt_max_geo come together");
-    if (N == 0 || nq == 0) return GF_OK;
+    if (N == 0 || nq_scene == 0) return GF_OK;
+    const int qmod = nq_scene, nq = nq_scene * E;
     const int qgroups = (nq + MH_Q - 1) / MH_Q;
     const int nblocks = (N + 63) / 64;
     // enough waves for ~8 per SIMD; every wave sweeps a contiguous range of 64-point blocks
@@ -177,11 +198,11 @@ extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const
     dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
     if (geo)
-        hipLaunchKernelGGL((k_mask_head<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1, b1,
-                           w2, b2, ldp, N, nq, chunks, out);
+        GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1,
+                     b1, w2, b2, ldp, N, nq, qmod, chunks, out);
     else
-        hipLaunchKernelGGL((k_mask_head<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1, b1,
-                           w2, b2, ldp, N, nq, chunks, out);
+        GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1,
+                     b1, w2, b2, ldp, N, nq, qmod, chunks, out);
     GF_CHECK_LAUNCH("gf_mask_head");
     return GF_OK;
 }
@@ -442,11 +463,11 @@ extern "C" int gf_mask_head_bwd(const float* feat, const float* coords, const fl
         const long long waves = (long long)nblocks * qsplit;
         dim3 grid((unsigned)((waves + 3) / 4));
         if (geo)
-            hipLaunchKernelGGL((k_mask_head_bwd_feat<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo,
-                               w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
+            GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_FEAT, (k_mask_head_bwd_feat<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz,
+                         sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
         else
-            hipLaunchKernelGGL((k_mask_head_bwd_feat<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo,
-                               w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
+            GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_FEAT, (k_mask_head_bwd_feat<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz,
+                         sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
     }
     // parameter gradients: (query group, point chunk) per wave
     const int qgroups = (nq + MHB_Q - 1) / MHB_Q;
@@ -459,11 +480,11 @@ extern "C" int gf_mask_head_bwd(const float* feat, const float* coords, const fl
         const long long waves = (long long)qgroups * chunks;
         dim3 grid((unsigned)((waves + 3) / 4));
         if (geo)
-            hipLaunchKernelGGL((k_mask_head_bwd_param<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo,
-                               w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
+            GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_PARAM, (k_mask_head_bwd_param<true>), grid, dim3(256), 0, st, feat, coords, geo,
+                         qxyz, sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
         else
-            hipLaunchKernelGGL((k_mask_head_bwd_param<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz,
-                               sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
+            GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_PARAM, (k_mask_head_bwd_param<false>), grid, dim3(256), 0, st, feat, coords, geo,
+                         qxyz, sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
     }
     hipLaunchKernelGGL(k_mask_head_bwd_reduce, dim3(gf_div_up((long long)nq * 337, 256)), dim3(256), 0, st, scratch, chunks,
                        nq, ldp, dparams);

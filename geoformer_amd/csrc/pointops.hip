@@ -715,8 +715,8 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
 template <int P>
 static void launch_fps(int G, int nb, hipStream_t st, const float* xyz, int n, int m, int m0, int bs_log2, int batch0,
                        unsigned long long* slots, int32_t* idxs, int* err) {
-    hipLaunchKernelGGL((k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), 0, st, xyz, n, m, m0, G, bs_log2, batch0, slots,
-                       idxs, err);
+    GF_LAUNCH_OP(GF_OP_FPS, (k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), 0, st, xyz, n, m, m0, G, bs_log2, batch0, slots,
+                 idxs, err);
 }
 
 extern "C" size_t gf_fps_scratch_bytes(int b) {

@@ -1887,8 +1887,8 @@ static int conv_wgrad_masked_impl(const float* in, const float* dout, const int3
     const int nci = Cin / 16, nco = Cout / 16;
     const int nslices = (M_out + WGT_ROWS - 1) / WGT_ROWS;
     const long long nitems = (long long)K * nci * nco * nslices;
-    hipLaunchKernelGGL(k_conv_wgrad_t, dim3(gf_div_up(nitems, 4)), dim3(256), 0, st, in, dout, nbr, gmask, K, M_out, ld,
-                       Cin, Cout, nci, nco, nslices, dW);
+    GF_LAUNCH_OP(GF_OP_WGRAD, k_conv_wgrad_t, dim3(gf_div_up(nitems, 4)), dim3(256), 0, st, in, dout, nbr, gmask, K, M_out, ld,
+                 Cin, Cout, nci, nco, nslices, dW);
     GF_CHECK_LAUNCH("gf_conv_wgrad_masked");
     return GF_OK;
 }

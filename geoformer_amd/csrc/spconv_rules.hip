@@ -25,6 +25,43 @@ void gf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gf_last_error(void) { return g_err; }
+
+// dev hook (common.h: GF_LAUNCH_OP): events bound to the next launch of an operator's main kernel, per host thread
+static thread_local GfOpEvents t_op_events[GF_OP_COUNT] = {};
+GfOpEvents* gf_op_events(int op) { return &t_op_events[op]; }
+extern "C" int gf_dev_op_kernel_events(int op, void* start, void* stop) {
+    GF_CHECK_ARG(op >= 0 && op < GF_OP_COUNT, "gf_dev_op_kernel_events: operator %d (0..%d)", op, GF_OP_COUNT - 1);
+    GF_CHECK_ARG((start == nullptr) == (stop == nullptr), "gf_dev_op_kernel_events: start and stop come together");
+    t_op_events[op].start = (hipEvent_t)start;
+    t_op_events[op].stop = (hipEvent_t)stop;
+    t_op_events[op].taken = 0;
+    return GF_OK;
+}
+extern "C" int gf_dev_op_kernel_events_taken(int op) {
+    return op >= 0 && op < GF_OP_COUNT ? t_op_events[op].taken : 0;
+}
+// timing events for the hook above, owned by the caller (bench.py has no other way to hold a raw hipEvent_t)
+extern "C" void* gf_dev_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) {
+        gf_set_error("gf_dev_event_create: hipEventCreate failed");
+        return nullptr;
+    }
+    return e;
+}
+extern "C" int gf_dev_event_destroy(void* e) {
+    if (e) GF_TRY(hipEventDestroy((hipEvent_t)e));
+    return GF_OK;
+}
+// waits for `stop`; microseconds between the two events in *us
+extern "C" int gf_dev_event_elapsed_us(void* start, void* stop, float* us) {
+    GF_CHECK_ARG(start && stop && us, "gf_dev_event_elapsed_us: null argument");
+    GF_TRY(hipEventSynchronize((hipEvent_t)stop));
+    float ms = 0.f;
+    GF_TRY(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+    *us = ms * 1e3f;
+    return GF_OK;
+}
 extern "C" int gf_abi_version(void) { return GF_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------

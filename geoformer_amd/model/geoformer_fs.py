@@ -196,8 +196,9 @@ class GeoFormerFS(GeoFormer):
         embedding, each ending in the host read-backs of generate_proposal (count_nonzero, boolean indexing).
         Here the E re-queries are ONE decoder pass with the episode as the batch index: the fused context
         [E, nc, 3C], the projections, the token stages and the cross-attention kernels run once over E "scenes" that
-        share the geodesic distances, context / query positions and mask features of the cached scene; per episode
-        remain one mask-head launch (its own generated weights over the shared features) and the proposal statistics.
+        share the geodesic distances, context / query positions and mask features of the cached scene.  The mask head
+        has an episode dimension as well (gf_mask_head_episodes: the chunk's [E, nq, N] logits in one launch,
+        gf_proposal_stats_fs over all E * nq rows in another).
         The host synchronises ONCE at the end to cut the accepted proposals.
         ``support_embeddings``: [E, C] (or a list of [1, C]); the scene must have gone through
         ``forward(..., remember=False)`` before (``cache_data``).  Returns a list of E ``(scores, proposals)`` pairs
@@ -217,6 +218,7 @@ class GeoFormerFS(GeoFormer):
         nq, nc = cfg.n_query_points, cfg.n_decode_point
         num_points = int(batch_offsets[1] - batch_offsets[0])
         pending = []
+        mx = None  # sqrt of the queries' largest geodesic distance (mask head), once for all episodes
         for c0 in range(0, n_emb, self.REQUERY_CHUNK):
             e = embs[c0:c0 + self.REQUERY_CHUNK]
             E = e.shape[0]
@@ -229,18 +231,26 @@ class GeoFormerFS(GeoFormer):
             pk2 = dec_outputs.transpose(0, 1).flatten(0, 1)  # [E * nq, d] token rows
             controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2).reshape(E, nq, -1)
             sim_all = self.similarity_net(aggregation[:, :nq, :].flatten(0, 1)).squeeze(-1).reshape(E, nq).sigmoid()
+            if controllers.is_cuda and self.output_dim == 16:
+                # the mask head with an episode dimension: ONE launch writes the [E, nq, N] logits of the chunk (the
+                # generated parameters read in place from the controller's output), ONE launch their proposal statistics
+                if mx is None:
+                    mx = torch.max(geo_dists[0], dim=1)[0]
+                    mx = torch.sqrt(torch.where(mx < 0, torch.max(mx), mx)).contiguous()
+                ml_all = pointops.mask_head_episodes(
+                    mask_features_.reshape(-1, self.output_dim).contiguous(), locs_float_.contiguous(),
+                    geo_dists[0].contiguous(), query_locs[0].reshape(-1, 3).contiguous(), mx, controllers.float().contiguous())
+                _, scores_all, final_all = pointops.proposal_stats_fs(
+                    ml_all.view(E * nq, -1), sim_all.float().reshape(-1).contiguous(), 0.2, cfg.TEST_SCORE_THRESH,
+                    cfg.TEST_NPOINT_THRESH, cfg.similarity_thresh)
+                for i in range(E):
+                    pending.append((scores_all[i * nq:(i + 1) * nq], final_all[i * nq:(i + 1) * nq], ml_all[i]))
+                continue
             for i in range(E):
                 weights, biases = self.parse_dynamic_params(controllers[i], self.output_dim)
                 ml = self.mask_heads_forward(geo_dists[0], mask_features_, weights, biases, nq, locs_float_,
                                              query_locs[0], use_geo=True).float().squeeze(0)
                 # generate_proposal (geoformer_fs.py:191-239) up to the point where it needs the host
-                if ml.is_cuda:
-                    ml = ml.contiguous()
-                    _, scores, final = pointops.proposal_stats_fs(
-                        ml, sim_all[i].float().contiguous(), 0.2, cfg.TEST_SCORE_THRESH, cfg.TEST_NPOINT_THRESH,
-                        cfg.similarity_thresh)
-                    pending.append((scores, final, ml))
-                    continue
                 prob = ml.sigmoid()
                 mask_bool = prob >= 0.2
                 npts = torch.sum(mask_bool, dim=1)

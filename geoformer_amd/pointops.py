@@ -299,6 +299,24 @@ def mask_head_packed(feat, coords, geo, qxyz, sqrt_max_geo, params):
     return out
 
 
+def mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, params):
+    """E episodes over one scene in ONE launch (gf_mask_head_episodes): params [E, nq, 337] -> logits [E, nq, N];
+    feat / coords / geo [nq,N] / qxyz [nq,3] / sqrt_max_geo [nq] are the scene's and shared by the episodes."""
+    for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (params, "params")):
+        _f32c(t, name)
+    N, C = feat.shape
+    E, nq, ld = params.shape
+    if ld != C * (C + 3) + C + C + 1 or qxyz.shape[0] != nq:
+        raise RuntimeError(f"mask_head_episodes: params {tuple(params.shape)} for {qxyz.shape[0]} queries, C={C}")
+    base = params.data_ptr()
+    o_w2, o_b1, o_b2 = C * (C + 3), C * (C + 3) + C, C * (C + 3) + 2 * C
+    out = torch.empty((E, nq, N), dtype=torch.float32, device=feat.device)
+    check(_lib.load().gf_mask_head_episodes(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), base,
+                                            base + 4 * o_b1, base + 4 * o_w2, base + 4 * o_b2, ld, N, nq, E, C, ptr(out),
+                                            stream_ptr()), "gf_mask_head_episodes")
+    return out
+
+
 class _MaskHeadFn(torch.autograd.Function):
     """Fused mask head with a fused, recompute-based backward (csrc/mask_head.hip): gradients for the mask features
     and the generated per-query parameters; coordinates and geodesic distances are data."""

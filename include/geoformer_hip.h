@@ -445,6 +445,14 @@ int gf_mask_head(const float* feat, const float* coords, const float* geo, const
 int gf_mask_head_packed(const float* feat, const float* coords, const float* geo, const float* qxyz,
                         const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2,
                         int ldp, int N, int nq, int C, float* out, void* stream);
+/* E episodes over ONE scene in one launch: the few-shot test loop re-queries a cached scene once per (label, run)
+ * (test_fs.py:157-174; GeoFormerFS.get_mask_prediction, model/geoformer/geoformer_fs.py:326-355 once per call).
+ * Parameters [E*nq, ...] and logits out fp32 [E*nq, N] are episode-major (row e*nq + q); feat / coords are the
+ * scene's, geo [nq,N], qxyz [nq,3] and sqrt_max_geo [nq] the scene's queries', shared by every episode.  Row e*nq + q
+ * of `out` equals what gf_mask_head_packed writes to row q for episode e's parameters. */
+int gf_mask_head_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                          const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2,
+                          int ldp, int N, int nq, int E, int C, float* out, void* stream);
 
 /* Backward of the fused mask head (training): given gout = dL/dlogits fp32 [nq,N], writes the gradient of the packed
  * per-query parameters (w1 | w2 | b1 | b2 columns, row stride ldp >= 337; the w1/b1/w2 pointers point into the packed

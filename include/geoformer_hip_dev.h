@@ -64,6 +64,19 @@ int gf_dev_unet_probe_read2(int max_records, int* meta, float* us, float* us_ker
 int gf_dev_conv_kernel_events(void* start, void* stop);
 int gf_dev_conv_kernel_events_taken(void);
 
+/* Two caller-owned hipEvent_t that the NEXT launch of operator `op`'s main kernel on this host thread binds to itself
+ * (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps -- what a profiler's kernel trace reports for that
+ * kernel; no host time and no neighbouring launch between them); (NULL, NULL) disarms.  op: 0 geodesic BFS
+ * (k_geodesic_bfs_lds), 1 decoder cross-attention (k_decoder_cross_attn), 2 mask head (k_mask_head), 3 furthest point
+ * sampling (k_fps), 4 cross-attention backward, 5 / 6 mask-head backward (feature / parameter kernel), 7 the mask-driven
+ * weight gradient (k_conv_wgrad_t).  ..._taken: 1 once a launch has consumed them.  bench.py's operator rooflines. */
+int gf_dev_op_kernel_events(int op, void* start, void* stop);
+int gf_dev_op_kernel_events_taken(int op);
+/* hipEvent_t (timing enabled) for the hook above, owned by the caller; elapsed waits for `stop`. */
+void* gf_dev_event_create(void);
+int gf_dev_event_destroy(void* event);
+int gf_dev_event_elapsed_us(void* start, void* stop, float* us);
+
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);
 

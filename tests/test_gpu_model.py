@@ -389,6 +389,43 @@ def test_fs_requery_many_equals_sequential_requeries(hip):
             assert np.abs(props.sum(1).cpu().numpy() - z[kn]).max() <= 3
 
 
+def test_fs_requery_many_against_the_oracle_backed_sequential_loop(hip):
+    """Row f4 against the ORACLE, not against the HIP path itself: the same few-shot model on the host over the oracle's
+    C operators (oracle/cpu_backend.py) runs the reference's loop -- one forward(..., remember=True) per support embedding
+    (test_fs.py:157-174) -- and GeoFormerFS.requery_many on the GPU (one decoder pass, gf_mask_head_episodes,
+    gf_proposal_stats_fs over all episodes) must reproduce every episode: the same accepted queries, scores to 1e-4,
+    point memberships up to threshold ties.  Six embeddings in chunks of 6 / 4 / 1 episodes per pass."""
+    from oracle import cpu_backend
+    from tests.util import fs_dicts, run_fs_episode
+
+    with cpu_backend.installed():
+        zc, mc, emb_c, _, _, _ = run_fs_episode("cpu")
+        _, qc = fs_dicts()
+        scale = [1.0, 0.5, 0.75, -1.0, 1.5, 0.25]
+        embs_c = torch.cat([emb_c * f for f in scale])
+        with torch.no_grad():
+            ref = [mc(None, qc, training=False, remember=True, support_embeddings=embs_c[i:i + 1])["proposal_scores"]
+                   for i in range(len(scale))]
+    z, m, emb, out, out2, cap = run_fs_episode("cuda")
+    assert (emb.cpu() - emb_c).abs().max().item() < 1e-4
+    _, q = fs_dicts()
+    q = _to_dev(q)
+    embs = embs_c.cuda()  # the host run's embeddings: both sides start from identical numbers
+    assert sum(len(r[0]) > 0 for r in ref) >= 2  # (episodes with and without accepted proposals)
+    for chunk in (16, 4, 1):
+        m.REQUERY_CHUNK = chunk
+        with torch.no_grad():
+            many = m.requery_many(q, embs)
+        torch.cuda.synchronize()
+        assert len(many) == len(ref)
+        for e, (a, b) in enumerate(zip(ref, many)):
+            assert len(a[0]) == len(b[0]), (chunk, e, len(a[0]), len(b[0]))
+            if len(a[0]):
+                assert (a[0] - b[0].cpu()).abs().max().item() < 1e-4, (chunk, e)
+                assert a[1].shape == b[1].shape
+                assert int((a[1] != b[1].cpu()).sum()) <= 3, (chunk, e)
+
+
 @pytest.mark.gpu
 def test_backbone_transformer_padded_pass_equals_per_scene_loop():
     """layers.BackboneTransformer with several scenes on the GPU (one padded pass with the layers' key mask) against the
