@@ -837,6 +837,431 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
 #endif
 }
 
+// ------------------------------------------------------------------------------------
+// Round 4: the same search with the DISTANCES and the ROW FETCH taken off the hop's critical path
+// (k_geodesic_bfs_pipe).
+//
+// A hop of k_geodesic_bfs_lds is: expand the ring (bids = 64-bit minima carrying distance(parent) + edge) -> barrier ->
+// commit: read the winning key of every new vertex back from L2, store its distance, request its row -> barrier.  The
+// next hop cannot bid before the commit's read-back has returned (its bids carry the new distances) and cannot expand
+// before the rows requested at the commit have arrived: ~9700 cycles per hop at 1024 threads, 4400 of them the expansion.
+// But WHICH vertices a hop reaches, and who the winning parent of each is, does not depend on any distance: the level
+// sets need the LDS bitmaps only and the parent is decided by the key's high word (parent << 6 | rank).  Hence
+//   * the key's low word carries the parent's POSITION IN ITS LEVEL'S QUEUE instead of a distance, and the distances
+//     follow two hops behind as a software pipeline whose loads are requested a whole hop before they are used:
+//         mark(i-1)  S1(level i)   request key[v] of every vertex of the level (final: every wave has drained its bids
+//                                  before the barrier in front of this section)
+//         mark(i)    S2(level i)   key -> (parent u, rank r, parent's queue position); request the edge D[u][r]
+//         mark(i+1)  S3(level i)   distance = D[u][r] + distance(level i-1)[position]  (LDS; the oracle's d + base, the
+//                                  same two operands), kept per queue position for the level's children, stored to geo
+//   * the lane that first touches a vertex pulls the vertex's row towards the compute unit right there (a 4-byte
+//     LDS-DMA load per row array into a scratch word: no register, nothing waits for it), a good part of a hop before
+//     the row is read.
+// Levels, parents and the fp32 sums are those of k_geodesic_bfs_lds / the oracle bit for bit.  A lane holds SE entries
+// of two levels in registers (S1 -> S2 and S2 -> S3); the entries of a ring beyond SE * THREADS go through a blocking
+// slow path and a per-query scratch in global memory (rings that large: a few hops of the largest training scenes).
+// ------------------------------------------------------------------------------------
+#ifndef BFS_PIPE_WARM
+#define BFS_PIPE_WARM 0
+#endif
+#ifndef BFS_PIPE_WPS
+#define BFS_PIPE_WPS 6  // waves per SIMD the 512-thread form is compiled for (<= 80 registers: fits beside the sampler)
+#endif
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 512 ? BFS_PIPE_WPS : 4) void k_geodesic_bfs_pipe(const float* __restrict__ D, const int32_t* __restrict__ I,
+                                                               int n, int K, const int32_t* __restrict__ src, float radius,
+                                                               int max_step, float* __restrict__ geo,
+                                                               unsigned long long* __restrict__ keys,
+                                                               int32_t* __restrict__ ws, int qcap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_cnt[2];
+    __shared__ int s_sink[THREADS];               // landing zone of the row-warming loads (never read)
+    constexpr int BFS_B = 4;                      // frontier vertices per 16-lane group and expansion batch
+    #ifndef BFS_PIPE_SE
+#define BFS_PIPE_SE 2
+#endif
+    constexpr int SE = BFS_PIPE_SE;               // level entries per lane whose distance pipeline lives in registers
+#ifndef BFS_PIPE_PFB
+#define BFS_PIPE_PFB 1
+#endif
+    constexpr int PFB = BFS_PIPE_PFB;             // expansion batches whose rows are requested in the mark section before
+    const int nw = (n + 31) >> 5;
+    unsigned* visited = reinterpret_cast<unsigned*>(smem);
+    unsigned* touched = visited + nw;
+    int* qv = reinterpret_cast<int*>(touched + nw);               // [2][qcap] vertex of (level & 1, position)
+    float* qd = reinterpret_cast<float*>(qv + 2 * (size_t)qcap);  // [2][qcap] its distance (written two hops later)
+    const int q = blockIdx.x;
+    float* g = geo + (size_t)q * n;
+    unsigned long long* key = keys + (size_t)q * n;
+    // per-query global space (10 n words): queue overflow past qcap (vertex, distance) x 2 levels, slow-path scratch x 2
+    int32_t* gws = ws + (size_t)q * 10 * n;
+    int* gv = gws;                                              // [2][n]
+    float* gd = reinterpret_cast<float*>(gws + 2 * (size_t)n);  // [2][n]
+    int* xs = gws + 4 * (size_t)n;  // [2][3 n]: (vertex, parent position, edge bits) of slow-path entries
+    const int tid = threadIdx.x;
+    for (int t = tid; t < n; t += THREADS) {
+        g[t] = -1.0f;
+        key[t] = ~0ull;
+    }
+    for (int t = tid; t < nw; t += THREADS) {
+        visited[t] = 0u;
+        touched[t] = 0u;
+    }
+    for (int t = tid; t < 2 * qcap; t += THREADS) {  // (a stale queue entry read speculatively must be a valid vertex)
+        qv[t] = 0;
+        qd[t] = 0.f;
+    }
+    const int s = src[q];
+    __syncthreads();
+    if (tid == 0) {
+        g[s] = 0.0f;
+        visited[s >> 5] = 1u << (s & 31);
+        touched[s >> 5] = 1u << (s & 31);
+        qv[0] = s;
+        qd[0] = 0.0f;
+        s_cnt[0] = 0;
+        s_cnt[1] = 0;
+    }
+    __syncthreads();
+    const int l16 = tid & 15;
+    const int gsh = (tid & 48) | 15;
+    const int kc = l16 < K ? l16 : K - 1;
+    // Scattered global accesses as (uniform base, 32-bit byte offset): one address register per lane instead of a 64-bit
+    // pair built with two or three vector instructions per access (n <= 2^19, K <= 64: every offset is below 2^27)
+    auto ld_I = [&](unsigned idx) { return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(I) + idx * 4u); };
+    auto ld_D = [&](unsigned idx) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(D) + idx * 4u); };
+    auto key_at = [&](int v) { return reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(key) + (unsigned)v * 8u); };
+    auto g_at = [&](int v) { return reinterpret_cast<float*>(reinterpret_cast<char*>(g) + (unsigned)v * 4u); };
+    const unsigned uK = (unsigned)K;
+    // queue accessors: position < qcap in LDS, the rest in the query's global overflow (read past L1: sc1).  READS
+    // take a compile-time flag: a value that MAY come from global memory makes the compiler wait for every outstanding
+    // memory operation where the two paths join (first version: four serialised round trips per expansion batch), so
+    // the hop has its own instance for rings that reach into the overflow -- graphs far larger than a scene's.
+    auto qv_get = [&](auto spill, int slot, int pos) -> int {
+        if constexpr (!decltype(spill)::value) return qv[slot * qcap + pos];
+        if (pos < qcap) return qv[slot * qcap + pos];
+        return __hip_atomic_load(&gv[(size_t)slot * n + (pos - qcap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto qv_set = [&](int slot, int pos, int v) {
+        if (pos < qcap) qv[slot * qcap + pos] = v;
+        else gv[(size_t)slot * n + (pos - qcap)] = v;
+    };
+    auto qd_get = [&](auto spill, int slot, int pos) -> float {
+        if constexpr (!decltype(spill)::value) return qd[slot * qcap + pos];
+        if (pos < qcap) return qd[slot * qcap + pos];
+        return __hip_atomic_load(&gd[(size_t)slot * n + (pos - qcap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto qd_set = [&](auto spill, int slot, int pos, float d) {
+        if constexpr (!decltype(spill)::value) {
+            qd[slot * qcap + pos] = d;
+        } else {
+            if (pos < qcap) qd[slot * qcap + pos] = d;
+            else gd[(size_t)slot * n + (pos - qcap)] = d;
+        }
+    };
+    // first touch of vertex v: pull the first 16 entries of its two rows towards this compute unit
+    auto warm = [&](int v) {
+#if BFS_PIPE_WARM
+        auto* lds = (__attribute__((address_space(3))) void*)&s_sink[tid & ~63];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(I + (size_t)v * K), lds, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(D + (size_t)v * K), lds, 4, 0, 0);
+#endif
+    };
+    // distance pipeline registers: stage A = S1 -> S2 (vertex, key), stage B = S2 -> S3 (vertex, parent position, edge)
+    int av[SE], bv[SE], bpp[SE];
+    unsigned long long akey[SE];
+    float bw[SE];
+#pragma unroll
+    for (int k = 0; k < SE; k++) {
+        av[k] = -1;
+        bv[k] = -1;
+        bpp[k] = 0;
+        akey[k] = 0ull;
+        bw[k] = 0.f;
+    }
+    int pv[PFB * BFS_B];
+    float pd[PFB * BFS_B];
+    bool have_pf = false;
+    int n_m2 = 0, n_m1 = 0, n_0 = 1;  // sizes of the levels step - 2, step - 1 and step (uniform)
+    int last_level = 0;     // deepest level that holds a vertex so far
+#ifdef BFS_PIPE_TRACE
+    // dev build (tools/bench_bfs_pipe.py): cycle stamps of thread 0 summed over the hops -- 0 expansion, 1 drain of the
+    // wave's memory operations, 2 barrier A, 3 mark section, 4 barrier B, 5 hops, 6 sum of ring sizes
+    unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pm[5] = {0, 0, 0, 0, 0};
+#define PT() __builtin_amdgcn_s_memtime()
+#endif
+    for (int step = 0; step <= last_level + 1; step++) {
+#ifdef BFS_PIPE_TRACE
+        const unsigned long long pt0 = PT();
+#endif
+        const int ncur = n_0;
+        const int sc = step & 1, sn = sc ^ 1;  // queue slots of level `step` and of level step + 1
+        int* cnt = &s_cnt[step & 1];
+        const bool grow = step < max_step && ncur > 0;
+        if (grow) {
+            auto bid = [&](unsigned cand, int f, int v) {  // late entries of long rows (beyond the first 16)
+                const unsigned bit = 1u << (v & 31);
+                if (!(visited[v >> 5] & bit)) {
+                    __hip_atomic_fetch_min(key_at(v), ((unsigned long long)cand << 32) | (unsigned)f, __ATOMIC_RELAXED,
+                                           BFS_KEY_SCOPE);
+                    const unsigned old = atomicOr(&touched[v >> 5], bit);
+                    if (!(old & bit)) {
+                        qv_set(sn, atomicAdd(cnt, 1), v);
+                        warm(v);
+                    }
+                }
+            };
+            auto batch = [&](int base, auto pf, auto spill) {  // pf: integral_constant, slot of prefetched rows or -1
+                unsigned cand[BFS_B];
+                int v[BFS_B], fpos[BFS_B];
+                float d[BFS_B];
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    const int f = (base + k * THREADS + tid) >> 4;
+                    const int fc = f < ncur ? f : ncur - 1;
+                    const int u = qv_get(spill, sc, fc);
+                    fpos[k] = fc;
+                    cand[k] = (((unsigned)u << 6) | (unsigned)l16) + 1u;
+                    if constexpr (decltype(pf)::value >= 0) {
+                        v[k] = pv[decltype(pf)::value * BFS_B + k];
+                        d[k] = pd[decltype(pf)::value * BFS_B + k];
+                    } else {
+                        v[k] = ld_I((unsigned)u * uK + (unsigned)kc);
+                        d[k] = ld_D((unsigned)u * uK + (unsigned)kc);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) asm volatile("" : "+v"(v[k]), "+v"(d[k]));
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    const int f = (base + k * THREADS + tid) >> 4;
+                    if (!(f < ncur && l16 < K && d[k] <= radius)) v[k] = -1;
+                }
+                unsigned long long mm = 0ull;
+                unsigned w[BFS_B];
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    mm |= ((__ballot(v[k] >= 0) >> gsh) & 1ull) << k;
+                    w[k] = visited[v[k] >= 0 ? (v[k] >> 5) : 0];
+                }
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    const unsigned bit = 1u << (v[k] & 31);
+                    const bool bids = v[k] >= 0 && l16 >= 1 && !(w[k] & bit);
+                    w[k] = 1u;
+                    if (bids) {
+                        __hip_atomic_fetch_min(key_at(v[k]), ((unsigned long long)cand[k] << 32) | (unsigned)fpos[k],
+                                               __ATOMIC_RELAXED, BFS_KEY_SCOPE);
+                        w[k] = atomicOr(&touched[v[k] >> 5], bit) & bit;
+                    }
+                }
+                unsigned long long fm[BFS_B];
+                int nfirst = 0;
+#pragma unroll
+                for (int k = 0; k < BFS_B; k++) {
+                    fm[k] = __ballot(w[k] == 0u);
+                    nfirst += __popcll(fm[k]);
+                }
+                if (nfirst) {
+#pragma unroll
+                    for (int k = 0; k < BFS_B; k++)
+                        if (w[k] == 0u) warm(v[k]);
+                    int pos = 0;
+                    if ((tid & 63) == 0) pos = atomicAdd(cnt, nfirst);
+                    pos = __builtin_amdgcn_readfirstlane(pos);
+#pragma unroll
+                    for (int k = 0; k < BFS_B; k++) {
+                        if (w[k] == 0u) {
+                            const int p = pos + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm[k] >> 32),
+                                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)fm[k], 0u));
+                            qv_set(sn, p, v[k]);
+                        }
+                        pos += __popcll(fm[k]);
+                    }
+                }
+                if (mm) {
+#pragma unroll
+                    for (int k = 0; k < BFS_B; k++) {
+                        if ((mm >> k) & 1ull) {
+                            const int f = (base + k * THREADS + tid) >> 4;
+                            const int u = qv_get(spill, sc, f);
+                            for (int r0 = 16; r0 < K; r0 += 16) {
+                                const int r = r0 + l16;
+                                int vv = -1;
+                                float dd = 0.f;
+                                if (r < K) {
+                                    vv = ld_I((unsigned)u * uK + (unsigned)r);
+                                    dd = ld_D((unsigned)u * uK + (unsigned)r);
+                                }
+                                const bool in2 = vv >= 0 && dd <= radius;
+                                if (in2) bid((((unsigned)u << 6) | (unsigned)r) + 1u, f, vv);
+                                if (!((__ballot(in2) >> gsh) & 1ull)) break;
+                            }
+                        }
+                    }
+                }
+            };
+            auto expand = [&](auto spill) {
+                int base = 0;
+                if (have_pf) {
+                    batch(0, std::integral_constant<int, 0>{}, spill);
+                    base = BFS_B * THREADS;
+                    if constexpr (PFB > 1) {
+                        if ((base >> 4) < ncur) {
+                            batch(base, std::integral_constant<int, (PFB > 1 ? 1 : 0)>{}, spill);
+                            base += BFS_B * THREADS;
+                        }
+                    }
+                    if constexpr (PFB > 2) {
+                        if ((base >> 4) < ncur) {
+                            batch(base, std::integral_constant<int, (PFB > 2 ? 2 : 0)>{}, spill);
+                            base += BFS_B * THREADS;
+                        }
+                    }
+                }
+                for (; (base >> 4) < ncur; base += BFS_B * THREADS) batch(base, std::integral_constant<int, -1>{}, spill);
+            };
+            if (ncur > qcap) expand(std::true_type{});
+            else expand(std::false_type{});
+        }
+        // every bid of this wave has been performed at L2 (and whatever it stored to the global overflow has landed):
+        // behind the barrier the keys of the new level are final
+#ifdef BFS_PIPE_TRACE
+        const unsigned long long pt1 = PT();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef BFS_PIPE_TRACE
+        const unsigned long long pt2 = PT();
+#endif
+        bfs_lds_barrier();
+#ifdef BFS_PIPE_TRACE
+        const unsigned long long pt3 = PT();
+#endif
+        // ---- mark section: the new level's visited bits and first rows; the distance pipeline ----
+        const int nn = grow ? *cnt : 0;
+        if (tid == 0) s_cnt[(step + 1) & 1] = 0;
+        if (nn > 0) last_level = step + 1;
+        auto mark_section = [&](auto spill) {
+            // Every LDS read of the section up front, in ONE round trip (the section used to be a chain of six): this
+            // lane's SE entries of the new level, the vertices whose rows it requests for the next expansion, and the
+            // parents' distances of the level S3 finishes.  Positions are clamped, not tested: a stale entry is a
+            // valid vertex (the queues are cleared at the start), its loads are harmless and its results unused.
+            const int sl = (step - 1) & 1, sp = sl ^ 1;  // queue slots of level step - 1 and of its parents' level
+            const bool s3 = step >= 2 && n_m1 > 0;
+            int ev[SE], pfv[PFB * BFS_B];
+            float pdist[SE];
+    #pragma unroll
+            for (int k = 0; k < SE; k++) {
+                const int t = k * THREADS + tid;
+                ev[k] = qv_get(spill, sn, decltype(spill)::value ? (t < nn ? t : 0) : (t < qcap ? t : qcap - 1));
+                const int pp = decltype(spill)::value ? bpp[k] : (bpp[k] < qcap ? bpp[k] : qcap - 1);
+                pdist[k] = qd_get(spill, sp, pp);
+            }
+            have_pf = nn > 0 && step + 1 < max_step;
+    #pragma unroll
+            for (int k = 0; k < PFB * BFS_B; k++) {
+                const int f = (k * THREADS + tid) >> 4;
+                pfv[k] = qv_get(spill, sn, f < nn ? f : (nn > 0 ? nn - 1 : 0));
+            }
+    #pragma unroll
+            for (int k = 0; k < SE; k++) asm volatile("" : "+v"(ev[k]), "+v"(pdist[k]));
+    #pragma unroll
+            for (int k = 0; k < PFB * BFS_B; k++) asm volatile("" : "+v"(pfv[k]));
+#ifdef BFS_PIPE_TRACE
+            pm[0] = PT();
+#endif
+            // rows of the new level's first PFB batches, into the registers of the lanes that expand them
+            if (have_pf) {
+    #pragma unroll
+                for (int k = 0; k < PFB * BFS_B; k++) {
+                    if (((k * THREADS) >> 4) < nn || k == 0) {  // (uniform: no row of a batch the ring does not reach)
+                        pv[k] = ld_I((unsigned)pfv[k] * uK + (unsigned)kc);
+                        pd[k] = ld_D((unsigned)pfv[k] * uK + (unsigned)kc);
+                    }
+                }
+            }
+            // S1 (level step + 1): key request -- and the level's visited bits
+    #pragma unroll
+            for (int k = 0; k < SE; k++) {
+                const int t = k * THREADS + tid;
+                const int vprev = av[k];
+                const unsigned long long kprev = akey[k];
+                av[k] = -1;
+                if (k * THREADS < nn && t < nn) {
+                    av[k] = ev[k];
+                    akey[k] = __hip_atomic_load(key_at(ev[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_or(&visited[ev[k] >> 5], 1u << (ev[k] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // S3 (level step - 1): distance = edge + distance(parent), S2's registers
+                if (s3 && k * THREADS < n_m1 && bv[k] >= 0) {  // (first tests uniform)
+                    const float dist = bw[k] + pdist[k];
+                    qd_set(spill, sl, t, dist);
+                    *g_at(bv[k]) = dist;
+                }
+                // S2 (level step): key -> (parent position, edge request), S1's registers of the hop before
+                bv[k] = vprev;
+                if (step >= 1 && k * THREADS < ncur && vprev >= 0) {
+                    const unsigned kk = (unsigned)(kprev >> 32) - 1u;
+                    bpp[k] = (int)(unsigned)kprev;
+                    bw[k] = ld_D((kk >> 6) * uK + (kk & 63u));
+                }
+            }
+#ifdef BFS_PIPE_TRACE
+            pm[1] = pm[2] = pm[3] = PT();
+#endif
+            // rings beyond SE * THREADS entries: visited bits; S3 from the scratch; key and edge now (blocking), parked
+            // in the query's scratch until their S3
+            for (int t = SE * THREADS + tid; t < nn; t += THREADS) {
+                const int v = qv_get(spill, sn, t);
+                __hip_atomic_fetch_or(&visited[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (s3) {
+                for (int t = SE * THREADS + tid; t < n_m1; t += THREADS) {
+                    const int* e = xs + ((size_t)sl * n + t) * 3;
+                    const int v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int pp = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float w = __int_as_float(__hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const float dist = w + qd_get(spill, sp, pp);
+                    qd_set(spill, sl, t, dist);
+                    g[v] = dist;
+                }
+            }
+            for (int t = SE * THREADS + tid; t < nn; t += THREADS) {
+                const int v = qv_get(spill, sn, t);
+                const unsigned long long kx = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned kk = (unsigned)(kx >> 32) - 1u;
+                const float w = D[(size_t)(kk >> 6) * K + (kk & 63u)];
+                int* e = xs + ((size_t)sn * n + t) * 3;
+                e[0] = v;
+                e[1] = (int)(unsigned)kx;
+                e[2] = __float_as_int(w);
+            }
+        };
+        if (nn > qcap || ncur > qcap || n_m1 > qcap || n_m2 > qcap) mark_section(std::true_type{});
+        else mark_section(std::false_type{});
+#ifdef BFS_PIPE_TRACE
+        const unsigned long long pt4 = PT();
+#endif
+        bfs_lds_barrier();
+#ifdef BFS_PIPE_TRACE
+        const unsigned long long pt5 = PT();
+        tr[0] += pt1 - pt0; tr[1] += pt2 - pt1; tr[2] += pt3 - pt2; tr[3] += pt4 - pt3; tr[4] += pt5 - pt4;
+        tr[5]++; tr[6] += ncur;
+        tr[7] += pm[0] - pt3; tr[8] += pm[1] - pm[0]; tr[9] += pm[2] - pm[1]; tr[10] += pm[3] - pm[2]; tr[11] += pt4 - pm[3];
+#endif
+        n_m2 = n_m1;
+        n_m1 = n_0;
+        n_0 = nn;
+    }
+#ifdef BFS_PIPE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && n >= 12)
+        for (int i = 0; i < 12; i++) reinterpret_cast<unsigned long long*>(xs)[i] = tr[i];
+#endif
+}
+
 template <int THREADS>
 static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, const int32_t* I, int n, int K,
                            const int32_t* src, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
@@ -850,6 +1275,40 @@ static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, c
     GF_LAUNCH_OP(GF_OP_BFS, k_geodesic_bfs_lds<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
                  geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
 }
+template <int THREADS>
+static void launch_bfs_pipe(int nq, size_t lds, hipStream_t st, const float* D, const int32_t* I, int n, int K,
+                            const int32_t* src, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
+                            int qcap) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_geodesic_bfs_pipe<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  BFS_LDS_BYTES);
+        attr_set = true;
+    }
+    GF_LAUNCH_OP(GF_OP_BFS, k_geodesic_bfs_pipe<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
+                 geo, (unsigned long long*)keys_ws, (int32_t*)queue_ws, qcap);
+}
+// dev knob: 1 (default) = the pipelined-distance kernel, 0 = k_geodesic_bfs_lds (GF_BFS_PIPE, read once; gf_dev_bfs_pipe)
+static int g_bfs_pipe = -1;
+static bool bfs_pipe_on() {
+    if (g_bfs_pipe < 0) {
+        const char* e = getenv("GF_BFS_PIPE");
+        g_bfs_pipe = e ? (atoi(e) != 0) : 1;
+    }
+    return g_bfs_pipe != 0;
+}
+extern "C" int gf_dev_bfs_pipe(int on) {
+    g_bfs_pipe = on < 0 ? -1 : (on != 0);
+    return GF_OK;
+}
+// dev knob (tests): upper bound of the LDS queue capacity, so that small graphs exercise the global overflow
+static int g_bfs_qcap_max = 0;
+extern "C" int gf_dev_bfs_qcap_max(int qcap) {
+    g_bfs_qcap_max = qcap > 0 ? qcap : 0;
+    return GF_OK;
+}
+// int32 words of queue_ws per query
+extern "C" size_t gf_geodesic_bfs_queue_words(int n) { return (size_t)10 * (size_t)(n > 0 ? n : 0); }
 
 // wg_threads: threads (and, in proportion, LDS) per query.  The kernel spreads a ring's row entries over the lanes, so
 // more threads per query is faster when the launch has the chip to itself (S150k eval graphs, 256 queries: 1.06 ms at
@@ -874,8 +1333,17 @@ extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32
         // LDS variant relies on that to stop scanning a row early
         int qcap = (int)((budget - bm) / (2 * sizeof(int2)));
         if (qcap > n) qcap = n;
+        if (g_bfs_qcap_max > 0 && qcap > g_bfs_qcap_max) qcap = g_bfs_qcap_max < 64 ? 64 : g_bfs_qcap_max;
         const size_t lds = bm + (size_t)qcap * 2 * sizeof(int2);
         hipStream_t st = (hipStream_t)stream;
+        if (bfs_pipe_on() && wg_threads >= 512) {
+            if (wg_threads == 512)
+                launch_bfs_pipe<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
+            else
+                launch_bfs_pipe<1024>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
+            GF_CHECK_LAUNCH("gf_geodesic_bfs");
+            return GF_OK;
+        }
         if (wg_threads == 256)
             launch_bfs_lds<256>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
         else if (wg_threads == 512)

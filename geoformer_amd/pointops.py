@@ -260,8 +260,9 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     dev = D.device
     geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
     keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
-    queues = torch.empty((nq, 4, n), dtype=torch.int32, device=dev)
-    check(_lib.load().gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
+    lib = _lib.load()
+    queues = torch.empty((nq, int(lib.gf_geodesic_bfs_queue_words(n))), dtype=torch.int32, device=dev)
+    check(lib.gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
                                           ptr(geo), ptr(keys), ptr(queues), int(wg_threads), stream_ptr()),
           "gf_geodesic_bfs")
     return geo

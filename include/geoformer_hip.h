@@ -415,8 +415,9 @@ const int32_t* gf_knn_error_flag(void* scratch, int n);
 /* Hop-synchronous geodesic BFS (cal_geodesic_vectorize, geodesic_utils.py:91-164) for nq sources of
  * one scene.  D/I are kNN rows INCLUDING column 0 (which is skipped, :110-111), D already sqrt'ed.
  *   geo fp32 [nq,n] out (-1 = not reached within max_step hops)
- *   keys_ws: nq*n uint64, queue_ws: nq*4*n int32 (scratch).
+ *   keys_ws: nq*n uint64, queue_ws: nq * gf_geodesic_bfs_queue_words(n) int32 (scratch).
  *   D/I rows must be sorted by distance with (inf,-1) padding (the order gf_knn_radius and faiss emit). */
+size_t gf_geodesic_bfs_queue_words(int n);
 int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
                     float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, void* stream);
 /* Same, with the workgroup size per query chosen by the caller: wg_threads = 1024 (one query per compute unit,

@@ -275,6 +275,37 @@ def test_bfs_large_scenes(hip, oracle, n, nq, wg):
     assert (geo >= 0).sum(1).max() > n // 20  # the walk really spreads (not a trivially empty frontier)
 
 
+@pytest.mark.parametrize("pipe", [1, 0], ids=["pipelined-distances", "read-back-per-hop"])
+@pytest.mark.parametrize("wg,qcap", [(512, 0), (1024, 0), (512, 300), (1024, 64)])
+def test_bfs_kernels_queue_overflow_and_long_rings(hip, oracle, pipe, wg, qcap):
+    """Both LDS-resident kernels (k_geodesic_bfs_pipe: distances pipelined two hops behind the level search, round 4;
+    k_geodesic_bfs_lds) on a 90 000-point foreground against the oracle, bit for bit, with the LDS queue capacity as
+    the launch derives it and cut to 300 / 64 entries (gf_dev_bfs_qcap_max): rings of up to ~2 000 vertices then live
+    mostly in the global overflow, and -- at 512 threads per query -- reach past the SE * THREADS entries whose
+    distance pipeline a lane holds in registers (the blocking slow path through the query's scratch)."""
+    from geoformer_amd import _lib, pointops
+
+    lib = _lib.load()
+    n = 90_000
+    xyz = _scene_points(n, 977)[:n]
+    gd, gi, deg = _graph(xyz)
+    D, I = gd.cpu().numpy(), gi.cpu().numpy()
+    src = np.random.default_rng(3).integers(0, n, 10)
+    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, 0.05, 256)
+    lib.gf_dev_bfs_pipe(pipe)
+    lib.gf_dev_bfs_qcap_max(qcap)
+    try:
+        geo = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), 0.05, 256, wg_threads=wg).cpu().numpy()
+        short = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), 0.05, 7, wg_threads=wg).cpu().numpy()
+    finally:
+        lib.gf_dev_bfs_pipe(-1)
+        lib.gf_dev_bfs_qcap_max(0)
+    assert (geo == ref).all()
+    assert (short == oracle.geodesic(D[:, 1:], I[:, 1:], src, 0.05, 7)).all()  # the max_step cut with levels in flight
+    reached = (geo >= 0).sum(1)
+    assert reached.max() > n // 3
+
+
 @pytest.mark.parametrize("case", ["K63", "n>2^19"])
 def test_bfs_global_memory_kernel(hip, oracle, case):
     """Tables the LDS-resident kernel does not take: a column count that is not a multiple of four, and more

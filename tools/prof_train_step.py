@@ -197,7 +197,7 @@ if os.environ.get("BFSCAP"):
         val = ((D <= radius) & (I >= 0)).sum(1).float()
         for wg in (512, 1024):
             geo = torch.empty((nq, n), dtype=torch.float32, device=dev); keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
-            queues = torch.zeros((nq, 4, n), dtype=torch.int32, device=dev)
+            queues = torch.zeros((nq, 10, n), dtype=torch.int32, device=dev)
             for _ in range(2):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); s.record()
                 check(lib.gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), ptr(keys), ptr(queues), wg, stream_ptr()), "bfs")

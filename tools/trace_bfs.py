@@ -27,7 +27,7 @@ for i, (D, I, deg, src, radius, max_step) in enumerate(cap):
     for wg in (256, 512, 1024):
         geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
         keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
-        queues = torch.zeros((nq, 4, n), dtype=torch.int32, device=dev)
+        queues = torch.zeros((nq, 10, n), dtype=torch.int32, device=dev)
         for _ in range(2):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
