@@ -1288,12 +1288,17 @@ static void launch_bfs_pipe(int nq, size_t lds, hipStream_t st, const float* D, 
     GF_LAUNCH_OP(GF_OP_BFS, k_geodesic_bfs_pipe<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
                  geo, (unsigned long long*)keys_ws, (int32_t*)queue_ws, qcap);
 }
-// dev knob: 1 (default) = the pipelined-distance kernel, 0 = k_geodesic_bfs_lds (GF_BFS_PIPE, read once; gf_dev_bfs_pipe)
+// Kernel choice: 0 (default) = k_geodesic_bfs_lds, 1 = the pipelined-distance kernel (GF_BFS_PIPE, read once;
+// gf_dev_bfs_pipe).  Measured (round 4): alone on the device the pipelined kernel is 3-13 % faster at 512
+// threads per query (1.16 against 1.23 ms on the S150k graphs, 3.4 against 3.9 ms on a 150 000-point foreground), in
+// the forward its launch is 8 % shorter -- and the forward is not: paired in one process over the eight benchmark scenes
+// +0.03 ms per scene (-0.07 on the two scenes whose search outlasts the sampling, +0.03..+0.14 on the others, where the
+// sampling beside it is what ends last and the extra memory instructions of the distance pipeline slow its exchanges).
 static int g_bfs_pipe = -1;
 static bool bfs_pipe_on() {
     if (g_bfs_pipe < 0) {
         const char* e = getenv("GF_BFS_PIPE");
-        g_bfs_pipe = e ? (atoi(e) != 0) : 1;
+        g_bfs_pipe = e ? (atoi(e) != 0) : 0;
     }
     return g_bfs_pipe != 0;
 }

@@ -77,8 +77,8 @@ void* gf_dev_event_create(void);
 int gf_dev_event_destroy(void* event);
 int gf_dev_event_elapsed_us(void* start, void* stop, float* us);
 
-/* Geodesic BFS kernel choice: 1 = distances pipelined three hops behind the level search (k_geodesic_bfs_pipe, default),
- * 0 = read back and re-bid per hop (k_geodesic_bfs_lds), -1 = default / GF_BFS_PIPE.  Results are identical. */
+/* Geodesic BFS kernel choice: 1 = distances pipelined two hops behind the level search (k_geodesic_bfs_pipe),
+ * 0 = read back and re-bid per hop (k_geodesic_bfs_lds, the default), -1 = default / GF_BFS_PIPE.  Results are identical. */
 int gf_dev_bfs_pipe(int on);
 /* Upper bound of the BFS kernels' LDS queue capacity (entries per level, >= 64; 0 = what the LDS share allows): tests
  * set it so that scene-sized graphs exercise the queues' overflow into global memory. */
