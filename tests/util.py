@@ -175,3 +175,44 @@ def train_golden_case(mid):
     return {"cfg": dict(batch_size=2, dec_dropout=0.0, n_decode_point=512, n_query_points=32), "n_subsample": 2000,
             "weight_seed": 1, "numpy_seed": 9, "fg_bias": 0.5,
             "batch": lambda: scene.make_batch([scene.make_small_scene(8192, 7), scene.make_small_scene(6000, 8)])}
+
+
+def calibrated_benchmark_state(host_batch, nfg_frac=0.4, seed=77, cfg_name="test_geoformer_scannet.yaml", mask_logit_target=10.0):
+    """State dict of the benchmark architecture with TRAINED-NET-LIKE activation scales: the synthetic
+    weights of ``synthetic_state_dict`` keep random BatchNorm statistics, so 71 convolutions deep the activations reach
+    |x| ~ 60 and 1e-4 absolute is 14 fp32 epsilons there.  A trained network's BatchNorm statistics are those of its own
+    activations.  Here every BatchNorm layer takes the statistics of THIS scene's activations (one host forward with the
+    layers in batch-statistics mode and momentum 1, through the oracle's operators -- test infrastructure), and the
+    background logits are shifted so that ~nfg_frac of the points are foreground, like bench.build_model does; the
+    controller that generates the mask head's weights is scaled so that the mask logits come out at ~ +-mask_logit_target.
+    Returns (state_dict, largest |activation| seen at the mask logits of the calibration pass)."""
+    import torch
+
+    import bench
+    from oracle import cpu_backend
+
+    with cpu_backend.installed(), torch.no_grad():
+        m = bench.build_model("cpu", cfg_name=cfg_name)
+        bns = [mod for mod in m.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]
+        saved = [b.momentum for b in bns]
+        for b in bns:
+            b.train()
+            b.momentum = 1.0
+        np.random.seed(seed)
+        out = m(host_batch, 300, training=False)
+        for b, mo in zip(bns, saved):
+            b.eval()
+            b.momentum = mo
+        s = out["semantic_scores"]
+        margin = s[:, 4:].max(1)[0] - s[:, :4].max(1)[0]
+        m.semantic_linear.bias[:4] += float(torch.quantile(margin.float(), 1.0 - nfg_frac))
+        scale = 0.0
+        if out.get("mask_predictions"):
+            scale = float(out["mask_predictions"][-1]["mask_logits"][0].abs().max())
+        if scale > mask_logit_target:
+            # the dynamic-conv head is quadratic in the controller's output (W2 relu(W1 x + b1) + b2, all four generated):
+            # a random controller yields logits of several hundred where a trained one yields ~ +-10
+            a = (mask_logit_target / scale) ** 0.5
+            m.controller.weight.mul_(a)
+            m.controller.bias.mul_(a)
+        return {k: v.clone() for k, v in m.state_dict().items()}, scale
