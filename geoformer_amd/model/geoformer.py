@@ -324,6 +324,33 @@ class GeoFormer(nn.Module):
             mod.weight.data.fill_(1.0)
             mod.bias.data.fill_(0.0)
 
+    @torch.no_grad()
+    def reserve_for(self, max_points, epoch=300):
+        """Serving warm-up: one eval forward of a synthetic scene of ``max_points`` points (the yaml's ``max_npoint`` is
+        the natural bound), so that the framework's caching allocator holds device blocks large enough for every scene
+        up to that size.  Without it a scene larger than any seen before makes the allocator call hipMalloc for its
+        largest buffers in the middle of the forward -- 20-30 ms per call on a fast host, several times that on a slow
+        one (bench.py secondary.fresh_scenes: 5.5 against 9.3 ms per never-before-seen scene on such a box).  Uses the
+        process's numpy generator state and restores it."""
+        import numpy as np
+
+        from .. import scene
+
+        dev = next(self.parameters()).device
+        b = scene.make_batch([scene.make_scene(int(max_points), 987654)])
+        b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
+        state = np.random.get_state()
+        was_training = self.training
+        try:
+            torch.nn.Module.train(self, False)
+            self(b, epoch, training=False)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+        finally:
+            np.random.set_state(state)
+            if was_training:
+                self.train(True)
+
     def invalidate_fused_caches(self):
         """Drop every derived copy the fused inference paths keep (packed conv weights, folded BatchNorm, MLP chains,
         pointer tables).  They are re-derived automatically when a parameter's version counter changes

@@ -177,14 +177,18 @@ def train_golden_case(mid):
             "batch": lambda: scene.make_batch([scene.make_small_scene(8192, 7), scene.make_small_scene(6000, 8)])}
 
 
-def calibrated_benchmark_state(host_batch, nfg_frac=0.4, seed=77, cfg_name="test_geoformer_scannet.yaml", mask_logit_target=10.0):
+def calibrated_benchmark_state(host_batch, nfg_frac=0.4, seed=77, cfg_name="test_geoformer_scannet.yaml", mask_logit_target=4.0,
+                               semantic_target=8.0):
     """State dict of the benchmark architecture with TRAINED-NET-LIKE activation scales: the synthetic
     weights of ``synthetic_state_dict`` keep random BatchNorm statistics, so 71 convolutions deep the activations reach
     |x| ~ 60 and 1e-4 absolute is 14 fp32 epsilons there.  A trained network's BatchNorm statistics are those of its own
     activations.  Here every BatchNorm layer takes the statistics of THIS scene's activations (one host forward with the
     layers in batch-statistics mode and momentum 1, through the oracle's operators -- test infrastructure), and the
     background logits are shifted so that ~nfg_frac of the points are foreground, like bench.build_model does; the
-    controller that generates the mask head's weights is scaled so that the mask logits come out at ~ +-mask_logit_target.
+    controller that generates the mask head's weights is scaled so that the mask logits come out at ~ +-mask_logit_target
+    and the last semantic layer so that the class scores stay within ~ +-semantic_target.  (What the two fp32 paths agree
+    to is RELATIVE: ~1e-5 of a tensor's magnitude after 71 convolutions with BatchNorm re-centring -- 1.5e-4 on class
+    scores of magnitude 28, measured -- so 1e-4 absolute is a statement about outputs of magnitude <= ~8.)
     Returns (state_dict, largest |activation| seen at the mask logits of the calibration pass)."""
     import torch
 
@@ -204,6 +208,12 @@ def calibrated_benchmark_state(host_batch, nfg_frac=0.4, seed=77, cfg_name="test
             b.eval()
             b.momentum = mo
         s = out["semantic_scores"]
+        sem_scale = float(s.abs().max())
+        if sem_scale > semantic_target:  # class scores of ~ +-semantic_target (the last linear layer scaled)
+            a = semantic_target / sem_scale
+            m.semantic_linear.weight.mul_(a)
+            m.semantic_linear.bias.mul_(a)
+            s = s * a
         margin = s[:, 4:].max(1)[0] - s[:, :4].max(1)[0]
         m.semantic_linear.bias[:4] += float(torch.quantile(margin.float(), 1.0 - nfg_frac))
         scale = 0.0
