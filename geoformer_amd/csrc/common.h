@@ -59,7 +59,7 @@ static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1)
 // ---- dev hook: events BOUND to the next launch of an operator's main kernel (include/geoformer_hip_dev.h:
 // gf_dev_op_kernel_events).  hipExtLaunchKernelGGL's start / stop events are the dispatch's own begin / end timestamps,
 // i.e. what a profiler's kernel trace reports for that kernel -- no host time, no neighbouring launches inside.
-// Per host thread; defined in spconv_rules.hip. ----
+// Process-wide (backward kernels are launched from the autograd thread); defined in spconv_rules.hip. ----
 enum { GF_OP_BFS = 0, GF_OP_CROSS_ATTN = 1, GF_OP_MASK_HEAD = 2, GF_OP_FPS = 3, GF_OP_CROSS_ATTN_BWD = 4,
        GF_OP_MASK_HEAD_BWD_FEAT = 5, GF_OP_MASK_HEAD_BWD_PARAM = 6, GF_OP_WGRAD = 7, GF_OP_COUNT = 8 };
 struct GfOpEvents {

@@ -1313,7 +1313,10 @@ extern "C" int gf_dev_bfs_qcap_max(int qcap) {
     return GF_OK;
 }
 // int32 words of queue_ws per query
-extern "C" size_t gf_geodesic_bfs_queue_words(int n) { return (size_t)10 * (size_t)(n > 0 ? n : 0); }
+extern "C" size_t gf_geodesic_bfs_queue_words(int n) {
+    // two queues of (vertex, distance) overflow: 4 n; the pipelined kernel adds its slow-path scratch: 10 n
+    return (size_t)(bfs_pipe_on() ? 10 : 4) * (size_t)(n > 0 ? n : 0);
+}
 
 // wg_threads: threads (and, in proportion, LDS) per query.  The kernel spreads a ring's row entries over the lanes, so
 // more threads per query is faster when the launch has the chip to itself (S150k eval graphs, 256 queries: 1.06 ms at

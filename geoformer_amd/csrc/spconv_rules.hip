@@ -26,8 +26,10 @@ void gf_set_error(const char* fmt, ...) {
 }
 extern "C" const char* gf_last_error(void) { return g_err; }
 
-// dev hook (common.h: GF_LAUNCH_OP): events bound to the next launch of an operator's main kernel, per host thread
-static thread_local GfOpEvents t_op_events[GF_OP_COUNT] = {};
+// dev hook (common.h: GF_LAUNCH_OP): events bound to the next launch of an operator's main kernel.  Process-wide, not
+// per host thread: a backward kernel is launched from the framework's autograd thread, not from the thread that armed
+// the hook (measurement runs are single-stepped, nothing else launches these operators meanwhile).
+static GfOpEvents t_op_events[GF_OP_COUNT] = {};
 GfOpEvents* gf_op_events(int op) { return &t_op_events[op]; }
 extern "C" int gf_dev_op_kernel_events(int op, void* start, void* stop) {
     GF_CHECK_ARG(op >= 0 && op < GF_OP_COUNT, "gf_dev_op_kernel_events: operator %d (0..%d)", op, GF_OP_COUNT - 1);

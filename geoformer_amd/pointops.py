@@ -251,6 +251,25 @@ def knn_radius(xyz, k, radius, sqrt_out=True, check_overflow=False, return_flag=
     return D, I, deg
 
 
+_SCRATCH = {}
+
+
+def scratch(name, numel, dtype, device):
+    """Grow-only scratch tensor per (device, current stream, name): PURE scratch of one native call (workspaces the
+    kernels fill and nobody reads afterwards), reused by the next call on the same stream, which stream order places
+    behind this one.  The big per-scene workspaces (U-Net workspace, BFS keys and queues: ~0.8 GB for a 150k-point
+    scene) then never go through the framework's caching allocator, whose blocks get split by scenes of other sizes
+    until a larger scene needs a fresh hipMalloc in the middle of a forward (20-30 ms; bench.py secondary.fresh_scenes)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream,
+           name, dtype)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < numel:
+        _SCRATCH[key] = None  # (drop the old block before asking for the new one)
+        t = _SCRATCH[key] = torch.empty(int(numel * 1.25) + 64, dtype=dtype, device=dev)
+    return t[:numel]
+
+
 def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     """geo [nq,n] fp32 for the sources `src` (int32 [nq]) over the kNN rows D/I (column 0 skipped).
     wg_threads: 1024 = one query per compute unit; 256 / 512 = several per unit (to run beside another kernel)."""
@@ -259,9 +278,9 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     nq = src.shape[0]
     dev = D.device
     geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
-    keys = torch.empty((nq, n), dtype=torch.int64, device=dev)
     lib = _lib.load()
-    queues = torch.empty((nq, int(lib.gf_geodesic_bfs_queue_words(n))), dtype=torch.int32, device=dev)
+    keys = scratch("bfs_keys", nq * n, torch.int64, dev)
+    queues = scratch("bfs_queues", nq * int(lib.gf_geodesic_bfs_queue_words(n)), torch.int32, dev)
     check(lib.gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
                                           ptr(geo), ptr(keys), ptr(queues), int(wg_threads), stream_ptr()),
           "gf_geodesic_bfs")

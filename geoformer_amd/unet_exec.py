@@ -176,7 +176,10 @@ def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     X, Y, Z = (int(s) for s in spatial_shape)
     dev = voxel_feats.device
     nbytes = lib.gf_unet_ws_bytes(plan.ref, M, batch_size, X, Y, Z)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    from .pointops import scratch
+
+    ws = scratch("unet_ws", nbytes + 256, torch.uint8, dev)  # (grow-only per stream: pointops.scratch)
+    ws = ws[(-ws.data_ptr()) % 256:][:nbytes]  # the executor wants 256-byte alignment
     out = torch.empty((M, 16), dtype=torch.float32, device=dev)
     pinned = getattr(_tls, "counts", None)
     if pinned is None:

@@ -64,7 +64,8 @@ int gf_dev_unet_probe_read2(int max_records, int* meta, float* us, float* us_ker
 int gf_dev_conv_kernel_events(void* start, void* stop);
 int gf_dev_conv_kernel_events_taken(void);
 
-/* Two caller-owned hipEvent_t that the NEXT launch of operator `op`'s main kernel on this host thread binds to itself
+/* Two caller-owned hipEvent_t that the NEXT launch of operator `op`'s main kernel (from any host thread: backward
+ * kernels are launched by the framework's autograd thread) binds to itself
  * (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps -- what a profiler's kernel trace reports for that
  * kernel; no host time and no neighbouring launch between them); (NULL, NULL) disarms.  op: 0 geodesic BFS
  * (k_geodesic_bfs_lds), 1 decoder cross-attention (k_decoder_cross_attn), 2 mask head (k_mask_head), 3 furthest point
