@@ -57,6 +57,7 @@ def _declare(lib):
         "gf_pair_losses_bwd": (I, [P, P, P, P, I, I, I, P, P, P, P]),
         "gf_unet_ws_bytes": (c_size_t, [P, I, I, I, I, I]),
         "gf_dev_unet_probe": (I, [I]),
+        "gf_dev_unet_chain": (I, [I]),
         "gf_dev_unet_probe_read": (I, [I, P, P]),
         "gf_dev_unet_probe_read2": (I, [I, P, P, P]),
         "gf_dev_conv_kernel_events": (I, [P, P]),

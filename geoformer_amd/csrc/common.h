@@ -56,6 +56,22 @@ int gf_rules_down2_chain_range(const int32_t* coords, int M0, int B, int X, int 
 
 static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- a chain of small sparse convolutions in one persistent launch (spconv_conv.hip: k_conv_chain; used by
+// unet_exec.hip for the deep U-Net levels).  Same operands as gf_conv_fwd, plus `in2`: the input rows are the
+// concatenation (in[:, :Cin1], in2[:, :Cin - Cin1]). ----
+struct GfChainOp {
+    const float *in, *in2, *Wp;
+    const int32_t* nbr;
+    const float *in_scale, *in_shift, *residual, *out_scale, *out_shift;
+    float* out;
+    int K, M_in, M_out, ld, Cin, Cin1, Cout;
+};
+#define GF_CHAIN_MAX_OPS 16
+// 1 if gf_conv_chain takes this layer (the flat form's shape limits, at most 256 items)
+int gf_conv_chain_supported(const GfChainOp& op);
+// counter: one zeroed device word per call.  Every op must pass gf_conv_chain_supported; nops <= GF_CHAIN_MAX_OPS.
+int gf_conv_chain(const GfChainOp* ops, int nops, unsigned* counter, hipStream_t st);
+
 // ---- dev hook: events BOUND to the next launch of an operator's main kernel (include/geoformer_hip_dev.h:
 // gf_dev_op_kernel_events).  hipExtLaunchKernelGGL's start / stop events are the dispatch's own begin / end timestamps,
 // i.e. what a profiler's kernel trace reports for that kernel -- no host time, no neighbouring launches inside.

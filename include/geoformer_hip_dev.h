@@ -53,6 +53,10 @@ int gf_dev_conv_g16p_wpb(int wpb);
  * 4 strided, 5 inverse), K, Cin, Cout, M_in, M_out, residual epilogue (0/1), rules (-1 when not counted);
  * us[i] = microseconds between the two events. */
 int gf_dev_unet_probe(int mode);
+/* The deep U-Net levels of gf_unet_fwd as persistent chain launches (k_conv_chain: a grid barrier between layers instead of a
+ * launch) or one launch per convolution (default: the chains measured 0.08 ms slower per forward): 1 / 0, -1 = default /
+ * GF_UNET_CHAIN.  Identical sums either way. */
+int gf_dev_unet_chain(int on);
 int gf_dev_unet_probe_read(int max_records, int* meta, float* us);
 /* The same plus, in mode 1, the launch's duration by two events BOUND TO THE KERNEL (hipExtLaunchKernelGGL: the
  * dispatch's own begin / end timestamps -- what a profiler's kernel trace reports), -1 where the launch did not take
