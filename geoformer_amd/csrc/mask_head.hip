@@ -37,13 +37,62 @@ __device__ __forceinline__ float mh_xor16(float v, int lane) {
     return __uint_as_float((lane & 16) ? r[0] : r[1]);
 }
 
-template <bool USE_GEO>
+// max(x, 0) as exactly one instruction.  fmaxf(x, 0.f) compiles to v_max(x, x) + v_max(0, .): IEEE maxnum must quiet a
+// signalling NaN and the compiler cannot see that an MFMA result never is one (fmed3 is folded back to that pair; inline
+// assembly would read the MFMA's result without the wait states the compiler inserts for instructions it knows).  The
+// INTEGER maximum of the bit pattern with 0 is the same function for every non-NaN float: negative floats (and -0) are
+// negative integers, positive floats keep their order.
+__device__ __forceinline__ float mh_relu(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
+
+// ---- fp32 products on the bf16 matrix pipe (round 4) ----
+// The fp32 MFMA (v_mfma_f32_16x16x4_f32: 32 cycles for K = 4) is the slowest matrix instruction of the chip and, measured
+// on this kernel, does not overlap with the vector instructions around it: the loop without its MFMAs takes 64 us, with
+// them 135 (62 us of MFMA time at the peak rate).  An fp32 number is EXACTLY the sum of three bf16 numbers (8 + 8 + 8
+// significant bits, by truncation: x = hi + mid + lo), so a product of two fp32 numbers is the sum of nine bf16 products,
+// of which the six largest carry everything above 2^-24 of the result (dropped: mid*lo, lo*mid, lo*lo <= 3 * 2^-24
+// relative -- the size of ONE fp32 rounding); bf16 products are exact in the MFMA's fp32 accumulator.  One
+// v_mfma_f32_16x16x16_bf16 (16 cycles, K = 16) does the whole 16-channel feature product of a tile per piece pair:
+// 6 x 16 cycles instead of 4 x 32.  The features' three pieces are written once per scene by k_mh_split (every query
+// shares them), the generated weights are split once per wave.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mh_split3(float x, unsigned& h, unsigned& m, unsigned& l) {  // the pieces as bf16 bit patterns
+    const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hb);  // exact
+    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);  // exact, at most 8 significant bits left
+    h = hb >> 16;
+    m = mb >> 16;
+    l = __float_as_uint(r2) >> 16;
+}
+__device__ __forceinline__ void mh_split3x4(const float (&x)[4], bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        unsigned a, b, c;
+        mh_split3(x[s], a, b, c);
+        h[s] = (short)a;
+        m[s] = (short)b;
+        l[s] = (short)c;
+    }
+}
+// feat fp32 [N,16] -> fs ushort [3][N][16] (hi, mid, lo)
+__global__ void k_mh_split(const float* __restrict__ feat, int n16, unsigned short* __restrict__ fs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n16) return;
+    unsigned h, m, l;
+    mh_split3(feat[i], h, m, l);
+    fs[i] = (unsigned short)h;
+    fs[(size_t)n16 + i] = (unsigned short)m;
+    fs[2 * (size_t)n16 + i] = (unsigned short)l;
+}
+
+template <bool USE_GEO, bool SPLIT>
 __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restrict__ feat, const float* __restrict__ coords,
                                                       const float* __restrict__ geo, const float* __restrict__ qxyz,
                                                       const float* __restrict__ mx, const float* __restrict__ w1,
                                                       const float* __restrict__ b1, const float* __restrict__ w2,
                                                       const float* __restrict__ b2, int ldp, int N, int nq, int qmod,
-                                                      int chunks, float* __restrict__ out) {
+                                                      int chunks, const unsigned short* __restrict__ fs,
+                                                      float* __restrict__ out) {
     // nq = E * qmod rows of generated parameters and of logits: E episodes (few-shot re-queries of one cached scene,
     // test_fs.py:157-174) over the SAME qmod queries -- row qq reads the geodesic row, position and maximum of query
     // qq % qmod.  qmod = nq: one episode.
@@ -78,8 +127,15 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
         for (int r = 0; r < 4; r++) ww[t][r] = w2[(size_t)q * ld_v + 4 * g + r];
         b2q[t] = b2[(size_t)q * ld_s];
         const int qs = q % qmod;  // the scene-side query of this parameter row
-        qc[t] = g < 3 ? qxyz[qs * 3 + g] : 0.f;
-        mq[t] = USE_GEO ? mx[qs] : 0.f;
+        // lane group 3 feeds the bias row of the fifth MFMA: its "relative coordinate" is the constant 1 = 1 - 0 (its
+        // point coordinate is loaded as 0 and its fix-up magnitude is 0), no select per (query, tile)
+        qc[t] = g < 3 ? qxyz[qs * 3 + g] : 1.f;
+        mq[t] = (USE_GEO && g < 3) ? mx[qs] : 0.f;
+    }
+    bf16x4 wh[MH_Q], wm[MH_Q], wl[MH_Q];  // (SPLIT) the feature weights' three bf16 pieces
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int t = 0; t < MH_Q; t++) mh_split3x4(wf[t], wh[t], wm[t], wl[t]);
     }
     int qrow[MH_Q];  // geodesic row of each of the wave's queries
 #pragma unroll
@@ -90,17 +146,26 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
     // requested in one go, one block ahead of the arithmetic (a load inside the per-tile code would expose one HBM
     // round trip per tile and query: an earlier version of this loop spent most of its time there).
     struct Block {
-        float4 f[4];
+        float4 f[4];          // (!SPLIT) fp32 features of the lane's four channels
+        bf16x4 fh[4], fm[4], fl[4];  // (SPLIT) their three bf16 pieces
         float pc[4];
         float gd[MH_Q][4];
     };
+    const size_t n16 = (size_t)N * 16;
     auto fetch = [&](int blk, Block& B) {
         const int p0 = blk * 64;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int pc = min(p0 + 16 * t + j, N - 1);
-            B.f[t] = *reinterpret_cast<const float4*>(feat + (size_t)pc * 16 + 4 * g);
-            B.pc[t] = coords[(size_t)pc * 3 + min(g, 2)];
+            if constexpr (SPLIT) {
+                const size_t e = (size_t)pc * 16 + 4 * g;
+                B.fh[t] = *reinterpret_cast<const bf16x4*>(fs + e);
+                B.fm[t] = *reinterpret_cast<const bf16x4*>(fs + n16 + e);
+                B.fl[t] = *reinterpret_cast<const bf16x4*>(fs + 2 * n16 + e);
+            } else {
+                B.f[t] = *reinterpret_cast<const float4*>(feat + (size_t)pc * 16 + 4 * g);
+            }
+            B.pc[t] = g < 3 ? coords[(size_t)pc * 3 + g] : 0.f;
 #pragma unroll
             for (int u = 0; u < MH_Q; u++)
                 B.gd[u][t] = USE_GEO ? geo[(size_t)qrow[u] * N + pc] : 0.f;
@@ -119,20 +184,39 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
             for (int tl = 0; tl < 4; tl++) {
                 float rel = qc[t] - cur.pc[tl];
                 if (USE_GEO) {
-                    // unreachable point: rel += sqrt(max_geo_q) * sign(rel), sign(0) = 0  (branch-free)
-                    const float m = cur.gd[t][tl] < 0.f ? mq[t] : 0.f;
-                    rel = rel + m * (rel > 0.f ? 1.f : (rel < 0.f ? -1.f : 0.f));
+                    // unreachable point: rel += sqrt(max_geo_q) * sign(rel), sign(0) = 0.  m * sign(rel) is m with rel's
+                    // sign bit (m >= 0) unless rel is zero; the two conditions meet in one scalar AND of the compare masks
+                    const float ms = __uint_as_float((__float_as_uint(rel) & 0x80000000u) | __float_as_uint(mq[t]));
+                    rel = rel + ((cur.gd[t][tl] < 0.f && rel != 0.f) ? ms : 0.f);
                 }
-                if (g == 3) rel = 1.0f;  // the bias row
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#ifdef MH_EXP_NOMFMA  // dev experiment: the loop without its matrix instructions (results are garbage)
+                acc[0] = w5[t] * rel; acc[1] = wf[t][0] * cur.pc[tl]; acc[2] = wf[t][1] * cur.pc[tl]; acc[3] = wf[t][2] * cur.pc[tl];
+#else
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w5[t], rel, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][0], cur.f[tl].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][1], cur.f[tl].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][2], cur.f[tl].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][3], cur.f[tl].w, acc, 0, 0, 0);
+                if constexpr (SPLIT) {  // the six piece pairs, smallest first
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[t], cur.fh[tl], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[t], cur.fl[tl], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wm[t], cur.fm[tl], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wm[t], cur.fh[tl], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[t], cur.fm[tl], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[t], cur.fh[tl], acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][0], cur.f[tl].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][1], cur.f[tl].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][2], cur.f[tl].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][3], cur.f[tl].w, acc, 0, 0, 0);
+                }
+#endif
+#ifdef MH_EXP_NOVALU  // dev experiment: the loop without the activation / contraction arithmetic
+                part[tl] = acc[0];
+                continue;
+#endif
                 float s = 0.f;
+                // (mh_relu: ONE v_max; fmaxf costs a second instruction that canonicalises its operand first, 32 of the
+                // loop's ~290 vector instructions)
 #pragma unroll
-                for (int r = 0; r < 4; r++) s = fmaf(ww[t][r], fmaxf(acc[r], 0.f), s);
+                for (int r = 0; r < 4; r++) s = fmaf(ww[t][r], mh_relu(acc[r]), s);
                 part[tl] = s;
             }
             // butterfly over the four row groups: afterwards lane (g,j) holds the full sum of tile g
@@ -160,7 +244,9 @@ extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const
                                    const float* b2, int ldp, int N, int nq, int C, float* out, void* stream);
 extern "C" int gf_mask_head_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
                                      const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
-                                     const float* b2, int ldp, int N, int nq, int E, int C, float* out, void* stream);
+                                     const float* b2, int ldp, int N, int nq, int E, int C, void* split_ws, float* out,
+                                     void* stream);
+extern "C" size_t gf_mask_head_split_bytes(int N) { return (size_t)(N > 0 ? N : 0) * 16 * 3 * sizeof(unsigned short); }
 extern "C" int gf_mask_head(const float* feat, const float* coords, const float* geo, const float* qxyz,
                             const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
                             const float* b2, int N, int nq, int C, float* out, void* stream) {
@@ -172,15 +258,18 @@ extern "C" int gf_mask_head(const float* feat, const float* coords, const float*
 extern "C" int gf_mask_head_packed(const float* feat, const float* coords, const float* geo, const float* qxyz,
                                    const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
                                    const float* b2, int ldp, int N, int nq, int C, float* out, void* stream) {
-    return gf_mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2, ldp, N, nq, 1, C, out, stream);
+    return gf_mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2, ldp, N, nq, 1, C, nullptr, out, stream);
 }
 
 // E episodes over one scene in ONE launch (test_fs.py:157-174 re-queries a cached scene once per
 // (label, run)): parameters [E * nq, ...] and logits [E * nq, N], episode-major; geo [nq, N], qxyz [nq, 3],
 // sqrt_max_geo [nq], feat and coords are the scene's and shared by all episodes.
+// split_ws (optional, gf_mask_head_split_bytes(N), 8-byte aligned): with it the 16-channel feature product runs as six
+// bf16 MFMAs over the exact three-piece split of both operands (fp32-accurate, see above); without it on the fp32 MFMA.
 extern "C" int gf_mask_head_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
                                      const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
-                                     const float* b2, int ldp, int N, int nq_scene, int E, int C, float* out, void* stream) {
+                                     const float* b2, int ldp, int N, int nq_scene, int E, int C, void* split_ws, float* out,
+                                     void* stream) {
     GF_CHECK_ARG(ldp >= 0, "gf_mask_head: negative parameter stride");
     GF_CHECK_ARG(C == 16, "gf_mask_head: only the 16-channel mask head (m=16) is implemented, got C=%d", C);
     GF_CHECK_ARG(N >= 0 && nq_scene >= 0 && E >= 1, "gf_mask_head: bad sizes");
@@ -197,12 +286,20 @@ extern "C" int gf_mask_head_episodes(const float* feat, const float* coords, con
     const long long waves = (long long)qgroups * chunks;
     dim3 grid((unsigned)((waves + 3) / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (geo)
-        GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1,
-                     b1, w2, b2, ldp, N, nq, qmod, chunks, out);
-    else
-        GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, w1,
-                     b1, w2, b2, ldp, N, nq, qmod, chunks, out);
+    const unsigned short* fs = (const unsigned short*)split_ws;
+    if (fs) {
+        GF_CHECK_ARG(((uintptr_t)fs % 8) == 0, "gf_mask_head: split_ws must be 8-byte aligned");
+        const int n16 = N * 16;
+        hipLaunchKernelGGL(k_mh_split, dim3(gf_div_up(n16, 256)), dim3(256), 0, st, feat, n16, (unsigned short*)split_ws);
+    }
+#define MH_LAUNCH(GEO_, SPLIT_)                                                                                          \
+    GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<GEO_, SPLIT_>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, \
+                 w1, b1, w2, b2, ldp, N, nq, qmod, chunks, fs, out)
+    if (geo && fs) MH_LAUNCH(true, true);
+    else if (geo) MH_LAUNCH(true, false);
+    else if (fs) MH_LAUNCH(false, true);
+    else MH_LAUNCH(false, false);
+#undef MH_LAUNCH
     GF_CHECK_LAUNCH("gf_mask_head");
     return GF_OK;
 }

@@ -9,6 +9,8 @@ from __future__ import annotations
 import contextlib
 import threading
 
+import os
+
 import torch
 
 from . import _lib
@@ -288,7 +290,15 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
 
 
 # ---- fused heads -------------------------------------------------------------------------
-def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
+def _mask_head_split_ws(N, device, split):
+    """Scratch for the features' three bf16 pieces (gf_mask_head_episodes: fp32-accurate products on the bf16 matrix
+    pipe); split=False keeps the fp32 MFMA (GF_MASK_HEAD_SPLIT=0: dev knob for A/B runs)."""
+    if not split or os.environ.get("GF_MASK_HEAD_SPLIT", "1") == "0":
+        return None
+    return scratch("mask_head_split", _lib.load().gf_mask_head_split_bytes(N) // 8 + 1, torch.int64, device)
+
+
+def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2, split=True):
     """Fused dynamic-conv mask head: logits [nq,N].  feat [N,16], coords [N,3], geo [nq,N] or None,
     qxyz [nq,3], sqrt_max_geo [nq] or None, w1 [nq,16,19], b1 [nq,16], w2 [nq,16], b2 [nq]."""
     for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
@@ -296,30 +306,19 @@ def mask_head(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, b2):
     N, C = feat.shape
     nq = qxyz.shape[0]
     out = torch.empty((nq, N), dtype=torch.float32, device=feat.device)
-    check(_lib.load().gf_mask_head(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), ptr(w1), ptr(b1),
-                                   ptr(w2), ptr(b2), N, nq, C, ptr(out), stream_ptr()), "gf_mask_head")
+    check(_lib.load().gf_mask_head_episodes(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), ptr(w1), ptr(b1),
+                                            ptr(w2), ptr(b2), 0, N, nq, 1, C, ptr(_mask_head_split_ws(N, feat.device, split)),
+                                            ptr(out), stream_ptr()), "gf_mask_head")
     return out
 
 
-def mask_head_packed(feat, coords, geo, qxyz, sqrt_max_geo, params):
+def mask_head_packed(feat, coords, geo, qxyz, sqrt_max_geo, params, split=True):
     """mask_head with the per-query parameters read in place from the controller's output params [nq, 16*19+16+16+1]
     (column blocks w1 | w2 | b1 | b2, parse_dynamic_params of geoformer.py:264-284)."""
-    for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (params, "params")):
-        _f32c(t, name)
-    N, C = feat.shape
-    nq, ld = params.shape
-    if ld != C * (C + 3) + C + C + 1:
-        raise RuntimeError(f"mask_head_packed: params has {ld} columns, expected {C * (C + 3) + 2 * C + 1}")
-    base = params.data_ptr()
-    o_w2, o_b1, o_b2 = C * (C + 3), C * (C + 3) + C, C * (C + 3) + 2 * C
-    out = torch.empty((nq, N), dtype=torch.float32, device=feat.device)
-    check(_lib.load().gf_mask_head_packed(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), base,
-                                          base + 4 * o_b1, base + 4 * o_w2, base + 4 * o_b2, ld, N, nq, C, ptr(out),
-                                          stream_ptr()), "gf_mask_head")
-    return out
+    return mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, params.unsqueeze(0), split=split)[0]
 
 
-def mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, params):
+def mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, params, split=True):
     """E episodes over one scene in ONE launch (gf_mask_head_episodes): params [E, nq, 337] -> logits [E, nq, N];
     feat / coords / geo [nq,N] / qxyz [nq,3] / sqrt_max_geo [nq] are the scene's and shared by the episodes."""
     for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (params, "params")):
@@ -332,8 +331,9 @@ def mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, params):
     o_w2, o_b1, o_b2 = C * (C + 3), C * (C + 3) + C, C * (C + 3) + 2 * C
     out = torch.empty((E, nq, N), dtype=torch.float32, device=feat.device)
     check(_lib.load().gf_mask_head_episodes(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(sqrt_max_geo), base,
-                                            base + 4 * o_b1, base + 4 * o_w2, base + 4 * o_b2, ld, N, nq, E, C, ptr(out),
-                                            stream_ptr()), "gf_mask_head_episodes")
+                                            base + 4 * o_b1, base + 4 * o_w2, base + 4 * o_b2, ld, N, nq, E, C,
+                                            ptr(_mask_head_split_ws(N, feat.device, split)), ptr(out), stream_ptr()),
+          "gf_mask_head_episodes")
     return out
 
 

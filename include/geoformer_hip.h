@@ -450,10 +450,14 @@ int gf_mask_head_packed(const float* feat, const float* coords, const float* geo
  * (test_fs.py:157-174; GeoFormerFS.get_mask_prediction, model/geoformer/geoformer_fs.py:326-355 once per call).
  * Parameters [E*nq, ...] and logits out fp32 [E*nq, N] are episode-major (row e*nq + q); feat / coords are the
  * scene's, geo [nq,N], qxyz [nq,3] and sqrt_max_geo [nq] the scene's queries', shared by every episode.  Row e*nq + q
- * of `out` equals what gf_mask_head_packed writes to row q for episode e's parameters. */
+ * of `out` equals what gf_mask_head_packed writes to row q for episode e's parameters (split_ws = NULL).
+ * split_ws: NULL, or gf_mask_head_split_bytes(N) bytes of scratch (8-byte aligned): the 16-channel feature product then
+ * runs on the bf16 matrix pipe over the EXACT three-piece bf16 split of both fp32 operands (six of the nine piece products;
+ * what is dropped is below 3 * 2^-24 of the result: one fp32 rounding), 1.3x faster; NULL keeps the fp32 MFMA. */
+size_t gf_mask_head_split_bytes(int N);
 int gf_mask_head_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
                           const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* b2,
-                          int ldp, int N, int nq, int E, int C, float* out, void* stream);
+                          int ldp, int N, int nq, int E, int C, void* split_ws, float* out, void* stream);
 
 /* Backward of the fused mask head (training): given gout = dL/dlogits fp32 [nq,N], writes the gradient of the packed
  * per-query parameters (w1 | w2 | b1 | b2 columns, row stride ldp >= 337; the w1/b1/w2 pointers point into the packed
