@@ -86,6 +86,7 @@ def _declare(lib):
         "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, I, P]),
         "gf_geodesic_bfs_queue_words": (c_size_t, [I]),
         "gf_dev_bfs_pipe": (I, [I]),
+        "gf_dev_cross_attn_bf3": (I, [I]),
         "gf_dev_bfs_qcap_max": (I, [I]),
         "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
         "gf_mask_head_packed": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P]),

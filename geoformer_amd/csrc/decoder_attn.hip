@@ -24,6 +24,8 @@
 // carries an online-softmax state (max, sum, weighted sum) for its 16 channels over the contexts it
 // sees; the 16 x 16 partial states per channel are merged once at the end (channel maximum, rescale, row sums).  MFMA-bound: 3*2*64*64 flop
 // per pair = 12.9 GFLOP per layer at 256 x 2048, against ~1 MB of input.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -223,7 +225,224 @@ __global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn(
     }
 }
 
-extern "C" size_t gf_decoder_wpack_floats(void) { return (size_t)3 * 16 * 64 * 4; }
+// ------------------------------------------------------------------------------------
+// Round 4: the same layer with its three 64 x 64 products on the bf16 matrix pipe at fp32 accuracy
+// (k_decoder_cross_attn_bf3).  An fp32 number is exactly the sum of three bf16 numbers (x = hi + mid + lo by
+// truncation, 8 + 8 + 8 significant bits), a product of two fp32 numbers therefore the sum of nine bf16 products, of
+// which the six largest carry everything above 3 * 2^-24 of it -- one fp32 rounding -- and each of which the MFMA adds
+// exactly into its fp32 accumulator.  v_mfma_f32_16x16x32_bf16 takes K = 32 channels in 16 cycles where
+// v_mfma_f32_16x16x4_f32 takes K = 4 in 32: a 16-row block of one product is 2 K-steps x 6 piece pairs = 12
+// instructions (192 cycles) instead of 16 (512).  The weights' pieces are packed once (k_decoder_pack_bf3) and sit in LDS
+// in A-operand lane order; an activation's pieces are cut from the accumulator registers that hold it (the K index is
+// only a summation index: a lane's 8 values of a K-step are rows 4g..4g+3 of two 16-row blocks), ~5.5 vector
+// instructions per value.  Same mapping, soft-max and merge as k_decoder_cross_attn<16>.
+// ------------------------------------------------------------------------------------
+#define DA_WPACK_F32 (3 * 16 * 64 * 4)
+#define DA_WPACK_BF3_U4 (3 * 4 * 2 * 3 * 64)
+__device__ __forceinline__ void da_split3(float x, unsigned& h, unsigned& m, unsigned& l) {  // bf16 patterns in the HIGH halves
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);  // exact
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));  // exact, at most 8 significant bits: its low half is zero
+}
+typedef __bf16 da_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned da_u32x4 __attribute__((ext_vector_type(4)));
+struct DaPieces {
+    da_u32x4 p[2][3];  // [K-step][hi, mid, lo]
+};
+// the three-piece split of a lane's 16 values x[kb][s] (kb = 16-row block, s = row 4g+s) as B operands of the two K-steps
+__device__ __forceinline__ void da_split_pack(const float (&x)[4][4], DaPieces& P) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        unsigned pc[3][8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) da_split3(x[2 * h + (e >> 2)][e & 3], pc[0][e], pc[1][e], pc[2][e]);
+#pragma unroll
+        for (int piece = 0; piece < 3; piece++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)  // bytes {hi half of element 2i+1, hi half of element 2i}
+                P.p[h][piece][i] = __builtin_amdgcn_perm(pc[piece][2 * i + 1], pc[piece][2 * i], 0x07060302u);
+    }
+}
+// acc += W_m[rb-block] . X over both K-steps, six piece pairs each, smallest first (Wp3: the block's 2 x 3 operands in LDS)
+__device__ __forceinline__ f32x4 da_gemm_bf3(const uint4* __restrict__ sW3, int m, int rb, int lane, const DaPieces& X, f32x4 acc) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint4* w = sW3 + (size_t)(((m * 4 + rb) * 2 + h) * 3) * 64 + lane;
+        const da_bf16x8 ah = __builtin_bit_cast(da_bf16x8, w[0]), am = __builtin_bit_cast(da_bf16x8, w[64]),
+                        al = __builtin_bit_cast(da_bf16x8, w[128]);
+        const da_bf16x8 xh = __builtin_bit_cast(da_bf16x8, X.p[h][0]), xm = __builtin_bit_cast(da_bf16x8, X.p[h][1]),
+                        xl = __builtin_bit_cast(da_bf16x8, X.p[h][2]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+#ifndef DA_BF3_WAVES
+#define DA_BF3_WAVES 16
+#endif
+__global__ __launch_bounds__(DA_BF3_WAVES * 64) void k_decoder_cross_attn_bf3(
+    const float* __restrict__ geo_ctx, const float* __restrict__ max_geo, const float* __restrict__ qloc,
+    const float* __restrict__ cloc, const float* __restrict__ lo, const float* __restrict__ hi,
+    const float* __restrict__ gaussB, const float* __restrict__ Q1, const float* __restrict__ K1,
+    const float* __restrict__ Kv, const uint4* __restrict__ Wp3, int nq, int nc, float* __restrict__ out,
+    float* __restrict__ stat_m, float* __restrict__ stat_l) {
+    constexpr int WAVES = DA_BF3_WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char da_smem[];
+    uint4* sW3 = reinterpret_cast<uint4*>(da_smem);  // [3][4 rb][2 h][3 pieces][64 lanes]
+    __shared__ float4 sQ1[16];
+    __shared__ float4 sB[3][2][4];
+    __shared__ float sRed[3][WAVES][DA_D];
+    const int qi = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, j = lane & 15;
+    for (int t = tid; t < DA_WPACK_BF3_U4; t += WAVES * 64) sW3[t] = Wp3[t];
+    if (tid < 16) sQ1[tid] = *reinterpret_cast<const float4*>(Q1 + ((size_t)b * nq + qi) * DA_D + tid * 4);
+    if (tid >= 64 && tid < 64 + 24) {
+        const int e = tid - 64, axis = e >> 3, half = (e >> 2) & 1, gg = e & 3;
+        sB[axis][half][gg] = *reinterpret_cast<const float4*>(gaussB + axis * 32 + half * 16 + 4 * gg);
+    }
+    geo_ctx += ((size_t)b * nq + qi) * nc;
+    cloc += (size_t)b * nc * 3;
+    K1 += (size_t)b * nc * DA_D;
+    Kv += (size_t)b * nc * DA_D;
+    const float mg = max_geo[(size_t)b * nq + qi];
+    const float qx = qloc[((size_t)b * nq + qi) * 3 + 0], qy = qloc[((size_t)b * nq + qi) * 3 + 1],
+                qz = qloc[((size_t)b * nq + qi) * 3 + 2];
+    const float lx = lo[b * 3 + 0], ly = lo[b * 3 + 1], lz = lo[b * 3 + 2];
+    const float sx = hi[b * 3 + 0] - lx, sy = hi[b * 3 + 1] - ly, sz = hi[b * 3 + 2] - lz;
+    float sm[4][4], sl[4][4], sa[4][4];  // online softmax: running max, sum, weighted sum
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            sm[rb][r] = -3.0e38f;
+            sl[rb][r] = 0.f;
+            sa[rb][r] = 0.f;
+        }
+    __syncthreads();
+
+    const int ntiles = (nc + 15) >> 4;
+    for (int t = w; t < ntiles; t += WAVES) {
+        const int ctx = t * 16 + j;
+        const bool valid = ctx < nc;
+        const int cc = valid ? ctx : nc - 1;
+        // --- relative embedding channels of this lane (as k_decoder_cross_attn) ---
+        const float gd = geo_ctx[cc];
+        float g0 = gd, g1 = gd, g2 = gd;
+        if (gd < 0.f) {
+            g0 = mg + fabsf(qx - cloc[cc * 3 + 0]);
+            g1 = mg + fabsf(qy - cloc[cc * 3 + 1]);
+            g2 = mg + fabsf(qz - cloc[cc * 3 + 2]);
+        }
+        const float t0 = ((g0 - lx) / sx) * 6.2831855f, t1 = ((g1 - ly) / sy) * 6.2831855f,
+                    t2 = ((g2 - lz) / sz) * 6.2831855f;
+        DaPieces RP;
+        {
+            float R[4][4];  // R[kb][s]: channel kb*16 + 4g + s
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const float4 b0 = sB[0][half][g], b1 = sB[1][half][g], b2v = sB[2][half][g];
+                const float p[4] = {fmaf(t2, b2v.x, fmaf(t1, b1.x, t0 * b0.x)), fmaf(t2, b2v.y, fmaf(t1, b1.y, t0 * b0.y)),
+                                    fmaf(t2, b2v.z, fmaf(t1, b1.z, t0 * b0.z)), fmaf(t2, b2v.w, fmaf(t1, b1.w, t0 * b0.w))};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float sn, cs;
+                    __sincosf(p[e], &sn, &cs);
+                    R[half][e] = sn;
+                    R[2 + half][e] = cs;
+                }
+            }
+            da_split_pack(R, RP);
+        }
+        // --- H^T = W1 . R^T, + Q1_i - K1_j, ReLU;  v^T = Wv . R^T ---
+        float H[4][4];
+        f32x4 V[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            f32x4 acc = da_gemm_bf3(sW3, 0, rb, lane, RP, (f32x4){0.f, 0.f, 0.f, 0.f});
+            const float4 k1 = *reinterpret_cast<const float4*>(K1 + (size_t)cc * DA_D + rb * 16 + 4 * g);
+            const float4 q1 = sQ1[rb * 4 + g];
+            H[rb][0] = fmaxf(acc[0] + q1.x - k1.x, 0.f);
+            H[rb][1] = fmaxf(acc[1] + q1.y - k1.y, 0.f);
+            H[rb][2] = fmaxf(acc[2] + q1.z - k1.z, 0.f);
+            H[rb][3] = fmaxf(acc[3] + q1.w - k1.w, 0.f);
+            V[rb] = da_gemm_bf3(sW3, 2, rb, lane, RP, (f32x4){0.f, 0.f, 0.f, 0.f});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        DaPieces HP;
+        da_split_pack(H, HP);
+        // --- sim^T = W2 . H^T, online softmax ---
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            const f32x4 s = da_gemm_bf3(sW3, 1, rb, lane, HP, (f32x4){0.f, 0.f, 0.f, 0.f});
+            const float4 kv = *reinterpret_cast<const float4*>(Kv + (size_t)cc * DA_D + rb * 16 + 4 * g);
+            const float kvv[4] = {kv.x, kv.y, kv.z, kv.w};
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float x = s[r] * 0.125f;
+                    const float val = V[rb][r] + kvv[r];
+                    const float mn = fmaxf(sm[rb][r], x);
+                    const float corr = __expf(sm[rb][r] - mn), p = __expf(x - mn);
+                    sl[rb][r] = sl[rb][r] * corr + p;
+                    sa[rb][r] = sa[rb][r] * corr + p * val;
+                    sm[rb][r] = mn;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // --- merge: channel maximum over all lanes, rescale, then plain sums (as k_decoder_cross_attn) ---
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float m = da_row_max(sm[rb][r]);
+            if (j == 0) sRed[0][w][rb * 16 + 4 * g + r] = m;
+        }
+    __syncthreads();
+    if (tid < DA_D) {
+        float m = sRed[0][0][tid];
+#pragma unroll
+        for (int u = 1; u < WAVES; u++) m = fmaxf(m, sRed[0][u][tid]);
+        sRed[0][0][tid] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c = rb * 16 + 4 * g + r;
+            const float f = __expf(sm[rb][r] - sRed[0][0][c]);
+            const float l = da_row_sum(sl[rb][r] * f), a = da_row_sum(sa[rb][r] * f);
+            if (j == 0) {
+                sRed[1][w][c] = l;
+                sRed[2][w][c] = a;
+            }
+        }
+    __syncthreads();
+    if (tid < DA_D) {
+        float L = 0.f, A = 0.f;
+#pragma unroll
+        for (int u = 0; u < WAVES; u++) {
+            L += sRed[1][u][tid];
+            A += sRed[2][u][tid];
+        }
+        out[((size_t)b * nq + qi) * DA_D + tid] = A / L;
+        if (stat_m) {
+            stat_m[((size_t)b * nq + qi) * DA_D + tid] = sRed[0][0][tid];
+            stat_l[((size_t)b * nq + qi) * DA_D + tid] = L;
+        }
+    }
+}
+
+// Wpack = [fp32 pack: 3 x 16 x 64 float4 | bf16 three-piece pack for k_decoder_cross_attn_bf3: 3 x 4 x 2 x 3 x 64 uint4]
+extern "C" size_t gf_decoder_wpack_floats(void) { return (size_t)DA_WPACK_F32 + (size_t)DA_WPACK_BF3_U4 * 4; }
 
 // Wpack[m][rb][kb][lane][s] = W_m[rb*16 + (lane&15)][kb*16 + 4*(lane>>4) + s]   (m: 0 = W1, 1 = W2, 2 = Wv; W is [out,in])
 __global__ void k_decoder_pack(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ Wv,
@@ -235,9 +454,41 @@ __global__ void k_decoder_pack(const float* __restrict__ W1, const float* __rest
     Wp[t] = W[(rb * 16 + (lane & 15)) * DA_D + kb * 16 + 4 * (lane >> 4) + s];
 }
 
+// The bf16 pack: Wp3[(((m*4 + rb)*2 + h)*3 + piece)*64 + lane] = 8 bf16 = the piece (0 hi, 1 mid, 2 lo of the exact
+// three-piece split, da_split3) of W_m[rb*16 + (lane&15)][kb*16 + 4*(lane>>4) + s] for e = 0..7, kb = 2h + (e >> 2), s = e & 3:
+// the A operand of v_mfma_f32_16x16x32_bf16 for output rows rb*16.., channels of K-step h.
+__global__ void k_decoder_pack_bf3(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ Wv,
+                                   uint4* __restrict__ Wp3) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // one (m, rb, h, lane): three uint4
+    if (t >= 3 * 4 * 2 * 64) return;
+    const int lane = t & 63, h = (t >> 6) & 1, rb = (t >> 7) & 3, m = t >> 9;
+    const float* W = m == 0 ? W1 : (m == 1 ? W2 : Wv);
+    unsigned pc[3][8];
+    for (int e = 0; e < 8; e++) {
+        const int kb = 2 * h + (e >> 2), sidx = e & 3;
+        da_split3(W[(rb * 16 + (lane & 15)) * DA_D + kb * 16 + 4 * (lane >> 4) + sidx], pc[0][e], pc[1][e], pc[2][e]);
+    }
+    for (int piece = 0; piece < 3; piece++) {
+        uint4 v;
+        v.x = (pc[piece][1] & 0xffff0000u) | (pc[piece][0] >> 16);
+        v.y = (pc[piece][3] & 0xffff0000u) | (pc[piece][2] >> 16);
+        v.z = (pc[piece][5] & 0xffff0000u) | (pc[piece][4] >> 16);
+        v.w = (pc[piece][7] & 0xffff0000u) | (pc[piece][6] >> 16);
+        Wp3[((size_t)(((m * 4 + rb) * 2 + h) * 3 + piece)) * 64 + lane] = v;
+    }
+}
+
 extern "C" int gf_decoder_pack_weights(const float* W1, const float* W2, const float* Wv, float* Wpack, void* stream) {
     hipLaunchKernelGGL(k_decoder_pack, dim3(48), dim3(256), 0, (hipStream_t)stream, W1, W2, Wv, Wpack);
+    hipLaunchKernelGGL(k_decoder_pack_bf3, dim3(6), dim3(256), 0, (hipStream_t)stream, W1, W2, Wv,
+                       reinterpret_cast<uint4*>(Wpack + DA_WPACK_F32));
     GF_CHECK_LAUNCH("gf_decoder_pack_weights");
+    return GF_OK;
+}
+
+static int g_da_bf3 = -1;
+extern "C" int gf_dev_cross_attn_bf3(int on) {  // 1 / 0 / -1 (default, GF_CROSS_ATTN_BF3)
+    g_da_bf3 = on < 0 ? -1 : (on != 0);
     return GF_OK;
 }
 
@@ -252,6 +503,23 @@ extern "C" int gf_decoder_cross_attn_cfg(const float* geo_ctx, const float* max_
     GF_CHECK_ARG(wg_waves == 16 || wg_waves == 8, "gf_decoder_cross_attn_cfg: %d waves per workgroup (16 or 8)", wg_waves);
     if (B == 0 || nq == 0) return GF_OK;
     (void)b2;  // a per-channel constant cancels in the per-channel soft-max over the contexts
+    if (g_da_bf3 < 0) {  // GF_CROSS_ATTN_BF3=0: the fp32-MFMA kernel for the 16-wave shape too (dev knob for A/B runs)
+        const char* e = getenv("GF_CROSS_ATTN_BF3");
+        g_da_bf3 = e ? (atoi(e) != 0) : 1;
+    }
+    if (wg_waves == 16 && g_da_bf3) {
+        static bool attr = false;
+        const size_t lds = (size_t)DA_WPACK_BF3_U4 * sizeof(uint4);
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)k_decoder_cross_attn_bf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        GF_LAUNCH_OP(GF_OP_CROSS_ATTN, k_decoder_cross_attn_bf3, dim3(nq, B), dim3(DA_BF3_WAVES * 64), lds, (hipStream_t)stream, geo_ctx,
+                     max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const uint4*>(Wpack + DA_WPACK_F32), nq, nc,
+                     out, stat_m, stat_l);
+        GF_CHECK_LAUNCH("gf_decoder_cross_attn");
+        return GF_OK;
+    }
     if (wg_waves == 16)
         GF_LAUNCH_OP(GF_OP_CROSS_ATTN, k_decoder_cross_attn<16>, dim3(nq, B), dim3(16 * 64), 0, (hipStream_t)stream, geo_ctx,
                      max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const float4*>(Wpack), nq, nc, out,

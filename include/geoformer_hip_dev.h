@@ -82,6 +82,11 @@ void* gf_dev_event_create(void);
 int gf_dev_event_destroy(void* event);
 int gf_dev_event_elapsed_us(void* start, void* stop, float* us);
 
+/* Cross-attention kernel of the 16-wave shape: 1 = the three 64 x 64 products as fp32-accurate bf16 MFMAs over the exact
+ * three-piece split (k_decoder_cross_attn_bf3, default), 0 = fp32 MFMAs (k_decoder_cross_attn<16>), -1 = default /
+ * GF_CROSS_ATTN_BF3. */
+int gf_dev_cross_attn_bf3(int on);
+
 /* Geodesic BFS kernel choice: 1 = distances pipelined two hops behind the level search (k_geodesic_bfs_pipe),
  * 0 = read back and re-bid per hop (k_geodesic_bfs_lds, the default), -1 = default / GF_BFS_PIPE.  Results are identical. */
 int gf_dev_bfs_pipe(int on);

@@ -514,3 +514,50 @@ def test_decoder_cross_attention_fused_backward(hip, B, nq, nc):
                             ("dWv", gWv, tWv)):
         g_, w_ = got.grad.cpu().numpy(), want.grad.numpy()
         assert np.abs(g_ - w_).max() < 1e-4 * max(1.0, np.abs(w_).max()), (name, np.abs(g_ - w_).max(), np.abs(w_).max())
+
+
+@pytest.mark.parametrize("B,nq,nc", [(1, 256, 2048), (2, 33, 700)])
+def test_decoder_cross_attention_bf16_split_kernel_is_fp32_accurate(hip, B, nq, nc):
+    """k_decoder_cross_attn_bf3 (round 4: the three 64 x 64 products as bf16 MFMAs over the EXACT three-piece split of both
+    fp32 operands, six of the nine piece products) against float64 and against the fp32-MFMA kernel, at the benchmark's
+    shape (256 queries x 2048 contexts) and at a ragged one: it must be as close to float64 as the fp32 kernel is (the
+    dropped products are below 3 * 2^-24 of a product: one fp32 rounding), and the two kernels agree to 2e-6 relative."""
+    from geoformer_amd import _lib, pointops
+
+    lib = _lib.load()
+    rng = np.random.default_rng(B * 1000 + nq + nc)
+    d = 64
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    geo = f32(rng.uniform(0, 6, (B, nq, nc)))
+    geo[rng.uniform(size=geo.shape) < 0.25] = -1.0
+    max_geo = f32(np.where(geo.max(2) < 0, geo.max(), geo.max(2)))
+    qloc, cloc = f32(rng.uniform(-3, 3, (B, nq, 3))), f32(rng.uniform(-3, 3, (B, nc, 3)))
+    lo, hi = f32(rng.uniform(-3.5, -3, (B, 3))), f32(rng.uniform(6, 7, (B, 3)))
+    gaussB = f32(rng.standard_normal((3, 32)))
+    Q1, K1, Kv = (f32(rng.standard_normal(s) * 0.7) for s in ((B, nq, d), (B, nc, d), (B, nc, d)))
+    W1, W2, Wv = (f32(rng.standard_normal((d, d)) / 8) for _ in range(3))
+    t = lambda a: torch.from_numpy(a.astype(np.float64)).cuda()  # noqa: E731  (float64 on the device: 67 M pairs)
+    g3 = t(geo)[..., None].repeat(1, 1, 1, 3)
+    rel = (t(qloc)[:, :, None, :] - t(cloc)[:, None, :, :]).abs()
+    g3 = torch.where(g3 < 0, t(max_geo)[:, :, None, None] + rel, g3)
+    nrm = (g3 - t(lo)[:, None, None, :]) / (t(hi) - t(lo))[:, None, None, :]
+    proj = (nrm * 6.2831855) @ t(gaussB)
+    R = torch.cat([proj.sin(), proj.cos()], -1)
+    H = torch.relu(R @ t(W1).t() + t(Q1)[:, :, None, :] - t(K1)[:, None, :, :])
+    a = torch.softmax((H @ t(W2).t()) / 8.0, dim=2)
+    ref = (a * (R @ t(Wv).t() + t(Kv)[:, None, :, :])).sum(2).cpu().numpy()
+    dv = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
+    wpack = pointops.decoder_pack_weights(dv(W1), dv(W2), dv(Wv))
+    outs = {}
+    for on in (0, 1):
+        lib.gf_dev_cross_attn_bf3(on)
+        try:
+            outs[on] = pointops.decoder_cross_attn(dv(geo), dv(max_geo), dv(qloc), dv(cloc), dv(lo), dv(hi), dv(gaussB), dv(Q1),
+                                                   dv(K1), dv(Kv), wpack, torch.zeros(d, device="cuda")).cpu().numpy()
+        finally:
+            lib.gf_dev_cross_attn_bf3(-1)
+    e32, e3 = np.abs(outs[0] - ref).max(), np.abs(outs[1] - ref).max()
+    scale = np.abs(ref).max()
+    assert e32 < 1e-4 and e3 < 1e-4, (e32, e3)
+    assert e3 <= max(2.0 * e32, 4e-6 * scale), (e32, e3, scale)  # no worse than the fp32 kernel's own rounding
+    assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale, (np.abs(outs[0] - outs[1]).max(), scale)
