@@ -22,14 +22,20 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _close(got, ref):
-    """1e-4 abs (BASELINE.json north_star), or 32 fp32 ulps of the tensor's largest magnitude where that is more:
-    71 convolutions deep the activations of the randomly initialised U-Net reach |x| ~ 60-70 and two fp32
+def _close(got, ref, ulps=32):
+    """1e-4 abs (BASELINE.json north_star), or `ulps` fp32 epsilons of the tensor's largest magnitude where that is
+    more: 71 convolutions deep the activations of the randomly initialised U-Net reach |x| ~ 60-70 and two fp32
     evaluations with different summation orders drift apart by ~1e-4 there (tools/parity_by_stage.py: the
-    difference doubles level by level, mean 1e-6, no single stage stands out)."""
+    difference doubles level by level, mean 1e-6, no single stage stands out).  ONE bound, stated in DESIGN.md 2 and
+    used by bench.py as well: an fp32 path against the float64 arbiter 32 epsilons; the DIFFERENCE of two fp32 paths
+    (GPU against the oracle-backed host forward) 64 = the sum of two such errors (`_close_2fp32`)."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    tol = max(1e-4, 32 * 1.1920929e-07 * float(np.abs(ref).max()))
+    tol = max(1e-4, ulps * 1.1920929e-07 * float(np.abs(ref).max()))
     return float(np.abs(got - ref).max()) < tol
+
+
+def _close_2fp32(got, ref):
+    return _close(got, ref, ulps=64)
 
 
 @pytest.fixture(scope="module")
@@ -433,9 +439,11 @@ def _forward_gpu_against_host(s150k, close, state=None):
 
 
 def test_forward_s150k_matches_oracle_backed_forward(hip, oracle, s150k):
-    """The random-init benchmark model (activations up to |x| ~ 60): every stage to max(1e-4, 32 fp32 epsilons of the
-    tensor's largest magnitude) -- `_close`; the float64 arbiter below shows each fp32 path that close to double."""
-    _forward_gpu_against_host(s150k, _close)
+    """The random-init benchmark model (activations up to |x| ~ 60): two fp32 evaluations, so every stage to max(1e-4,
+    64 fp32 epsilons of the tensor's largest magnitude) -- `_close_2fp32`, the bound bench.py's parity_s150k states; the
+    float64 arbiter below holds EACH fp32 path to 32 epsilons of double (measured there: GPU 20, host 25 on the mask
+    logits, 31-32 between the two here)."""
+    _forward_gpu_against_host(s150k, _close_2fp32)
 
 
 def test_forward_s150k_calibrated_weights_hold_1e4_absolute(hip, oracle, s150k):
@@ -683,11 +691,11 @@ def test_fs_5shot_episode_full_size_matches_oracle_backend(hip, oracle):
         ref = episode("cpu", preds=got["preds"])
     assert ref["flips"].get("n", 0) <= 8 and ref["flips"].get("gap", 0.0) < 2e-4, ref["flips"]
     assert (got["embs"] - ref["embs"]).abs().max() < 1e-4  # the five support embeddings
-    assert _close(got["sem"].numpy(), ref["sem"].numpy())
+    assert _close_2fp32(got["sem"].numpy(), ref["sem"].numpy())  # (GPU against host: two fp32 paths)
     assert torch.equal(got["fg"], ref["fg"]) and got["fg"].numel() > 30_000
     assert torch.equal(got["inds"], ref["inds"])  # FPS over ALL foreground points of the query scene
     assert got["ml"].shape == ref["ml"].shape
-    assert _close(got["ml"].numpy(), ref["ml"].numpy())
+    assert _close_2fp32(got["ml"].numpy(), ref["ml"].numpy())
     assert got["scores"].shape == ref["scores"].shape
     if len(ref["scores"]):
         assert (got["scores"] - ref["scores"]).abs().max() < 1e-4
