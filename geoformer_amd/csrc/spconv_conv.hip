@@ -448,7 +448,10 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
 // together, the gathers follow as one dependent round trip (two batches of FLAT_PF steps in flight, the later ones
 // behind the MFMAs), then the LDS reduction over the waves and the store: three round trips.
 #define FLAT_PF 4
-#define FLAT_MAXB 6  // batches per wave: K * NCH <= 16 * FLAT_PF * FLAT_MAXB = 384 steps per item (27 x 14: the 224 -> 112 layer)
+#define FLAT_MAXB 6  // most batches per wave: K * NCH <= 16 * FLAT_PF * FLAT_MAXB = 384 steps per item (27 x 14: the 224 -> 112 layer)
+#define FLAT_MAXB_SMALL 4  // the instance for items of at most 256 steps (every layer but the 2C -> C ones of the two deepest
+                           // levels with a tail): the per-step index / address setup is unrolled MAXB * PF times, and six
+                           // batches of it cost every flat launch ~1 us (8.6 -> 9.6 us at level 5, PMC of round 4)
 // One convolution of the flat form.  `in2` (optional): the input rows are the CONCATENATION (in[:, :Cin1], in2[:, :Cin - Cin1])
 // -- the skip concatenation of UBlock.forward (geoformer_modules.py:116) read in place, Cin1 a multiple of 16.
 struct FlatOp {
@@ -465,9 +468,9 @@ struct FlatOp {
 // COH: the item runs inside a persistent launch next to items of EARLIER layers computed by other workgroups in the same
 // launch (k_conv_chain): gathered rows and residual rows are read past L1 (sc1) and the output is stored write-through
 // (sc1), the hand-off form of MI355X_MICROARCH.md "Valid forms" / cdna_hip_programming.md guideline 16 R1.
-template <bool COH>
+template <bool COH, int MAXB_>
 __device__ __forceinline__ void conv_flat_item(const FlatOp& A, int item, float4* s_red, float (*s_aff)[CONV_MAX_CIN]) {
-    constexpr int PF = FLAT_PF, MAXB = FLAT_MAXB;
+    constexpr int PF = FLAT_PF, MAXB = MAXB_;
     constexpr int AUX = COH ? 16 : 0;  // sc1
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const float* __restrict__ in = A.in;
@@ -628,6 +631,7 @@ __device__ __forceinline__ void conv_flat_item(const FlatOp& A, int item, float4
     }
 }
 
+template <int MAXB_>
 __global__ __launch_bounds__(1024, 1) void k_conv_flat(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                        const int32_t* __restrict__ nbr, int K, int M_out, int ld, int Cin,
                                                        int Cout, int NCH, int NCB, unsigned in_bytes,
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv_flat(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];
     const FlatOp A{in, nullptr, Wp, nbr, in_scale, in_shift, residual, out_scale, out_shift, out, K, M_out, ld, Cin, Cin, Cout,
                    NCH, NCB, in_bytes, 0u, 0, 0};
-    conv_flat_item<false>(A, (int)blockIdx.x, s_red, s_aff);
+    conv_flat_item<false, MAXB_>(A, (int)blockIdx.x, s_red, s_aff);
 }
 
 // ------------------------------------------------------------------------------------
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv_chain(const ChainArgs C, unsig
         const FlatOp& A = C.op[j];
         const int items = A.items;
         for (int item = (int)blockIdx.x; item < items; item += G) {
-            conv_flat_item<true>(A, item, s_red, s_aff);
+            conv_flat_item<true, FLAT_MAXB>(A, item, s_red, s_aff);
             __syncthreads();  // (s_red / s_aff are reused by the next item)
         }
         if (j + 1 == C.nops) break;
@@ -1656,8 +1660,14 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
     if (knobs.g16 >= 0) g16 = g16 && knobs.g16 != 0;
     else g16 = g16 && !split;
     if (flat && (nbr != nullptr || K == 1) && out2 == nullptr) {
-        hipLaunchKernelGGL(k_conv_flat, dim3((unsigned)((long long)ngroups * ncb)), dim3(1024), 0, st, a.in, a.Wp, a.nbr, a.K,
-                           a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
+        if (K * nch <= 16 * FLAT_PF * FLAT_MAXB_SMALL)
+            hipLaunchKernelGGL(k_conv_flat<FLAT_MAXB_SMALL>, dim3((unsigned)((long long)ngroups * ncb)), dim3(1024), 0, st, a.in,
+                               a.Wp, a.nbr, a.K, a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.in_bytes, a.sc, a.sh, a.res, a.osc,
+                               a.osh, a.out);
+        else
+            hipLaunchKernelGGL(k_conv_flat<FLAT_MAXB>, dim3((unsigned)((long long)ngroups * ncb)), dim3(1024), 0, st, a.in, a.Wp,
+                               a.nbr, a.K, a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh,
+                               a.out);
         GF_CHECK_LAUNCH("gf_conv_fwd");
         return GF_OK;
     }
