@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_uint, c_void_p
 
 from ._build import LIB_PATH
 
@@ -121,6 +121,11 @@ def _declare(lib):
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),
         "gf_backbone_transformer_num_params": (I, [I]),
         "gf_backbone_transformer": (I, [P, P, P, I, I, I, I, P, P, P, P]),
+        "gf_backbone_transformer_train_save_bytes": (c_size_t, [I, I]),
+        "gf_backbone_transformer_train_work_bytes": (c_size_t, [I, I, I]),
+        "gf_backbone_transformer_grad_floats": (c_longlong, [I, I]),
+        "gf_backbone_transformer_train_fwd": (I, [P, P, I, I, I, I, P, F, c_uint, P, P, P]),
+        "gf_backbone_transformer_train_bwd": (I, [P, P, I, I, I, I, P, F, c_uint, P, P, P, P, P]),
         "gf_decoder_wpack_floats": (c_size_t, []),
         "gf_decoder_pack_weights": (I, [P, P, P, P, P]),
         "gf_decoder_cross_attn": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P]),

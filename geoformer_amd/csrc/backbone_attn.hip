@@ -390,3 +390,877 @@ extern "C" int gf_backbone_transformer(const float* feats, const int* coords, co
     GF_CHECK_LAUNCH("gf_backbone_transformer");
     return GF_OK;
 }
+
+// =====================================================================================================================
+// Training: the same forward keeping what the backward needs, and the backward -- (n_layers + 2) + (2 n_layers + 2)
+// launches for what the framework modules run as ~250 small ones per level and step (forward and backward of
+// before_transformer_linear -> TransformerEncoder -> after_transformer_linear over a few hundred voxels per scene:
+// the host's launch rate was all that took time, 3.3 ms per level of the batch-4 training step).
+//
+// Dropout (transformer.py:97,116,128,159-160: attention weights, hidden layer, the two residual branches; p = 0.1):
+// the keep decision of an element is a hash of (seed, site, row, column) -- bt_keep below -- so the backward
+// recomputes the masks instead of storing them, and a test can build the very same masks on the host.  The seed is
+// drawn by the caller per call.  p = 0 (modules in eval mode with gradients enabled): every element is kept.
+//
+// Backward, per layer from the last: a token kernel (k_bt_bwd_tok: everything local to a token -- the residual /
+// dropout / FFN / Norm / projection chain between two attentions, on 16-token tiles in LDS), an attention kernel
+// (k_bt_bwd_attn: dq per query tile and dk, dv per key tile, probabilities recomputed from the saved log-sum-exp,
+// sum_j dP_ij P_ij = dO_i . O_i also under dropout) and at the end ONE launch for every weight, bias and Norm gradient
+// (k_bt_wgrad: dW = A^T B over all tokens on the fp32 matrix pipe, column sums; fixed summation order).
+// =====================================================================================================================
+struct BtDrop {
+    uint32_t seed, thresh;
+    float inv;
+};
+
+__device__ __forceinline__ uint32_t bt_fmix(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+// 1 / (1 - p) if the element is kept, else 0.  site = 4 * layer + {0 attention weights, 1 attention branch, 2 hidden
+// layer, 3 feed-forward branch}; row = token index in the batch; column = channel, or 4 * key + head
+__device__ __forceinline__ float bt_keep(const BtDrop& d, uint32_t site, uint32_t row, uint32_t col) {
+    uint32_t h = bt_fmix(d.seed ^ (row * 64u + site));
+    h = bt_fmix(h + col * 0x9E3779B1u);
+    return (h >> 8) >= d.thresh ? d.inv : 0.f;
+}
+
+struct BtSave {  // what the forward keeps: [M, .] arrays indexed by the token's row in the batch
+    float *X[BT_MAXL + 1], *QKV[BT_MAXL], *O[BT_MAXL], *XMID[BT_MAXL], *H[BT_MAXL], *LSE[BT_MAXL], *REL;
+    int *offs, *tile_scene, *tile_first;
+};
+#define BT_REL_LD 16
+#define BT_INTS_HEAD (4096 + 8)
+
+static size_t bt_save_floats(int M, int nl) {
+    const size_t m = (size_t)M;
+    return m * BT_D * (nl + 1) + (size_t)nl * m * (3 * BT_D + BT_D + BT_D + BT_FF + BT_H) + m * BT_REL_LD;
+}
+static size_t bt_save_ints(int M) { return (size_t)(M / 16) + 3 * BT_INTS_HEAD; }
+
+static BtSave bt_save_layout(void* save, int M, int nl) {
+    BtSave S;
+    float* p = (float*)save;
+    const size_t m = (size_t)M;
+    for (int l = 0; l <= BT_MAXL; l++) S.X[l] = nullptr;
+    for (int l = 0; l <= nl; l++) { S.X[l] = p; p += m * BT_D; }
+    for (int l = 0; l < BT_MAXL; l++) S.QKV[l] = S.O[l] = S.XMID[l] = S.H[l] = S.LSE[l] = nullptr;
+    for (int l = 0; l < nl; l++) {
+        S.QKV[l] = p; p += m * 3 * BT_D;
+        S.O[l] = p; p += m * BT_D;
+        S.XMID[l] = p; p += m * BT_D;
+        S.H[l] = p; p += m * BT_FF;
+        S.LSE[l] = p; p += m * BT_H;
+    }
+    S.REL = p; p += m * BT_REL_LD;
+    int* q = (int*)p;
+    S.offs = q; q += BT_INTS_HEAD;
+    S.tile_first = q; q += BT_INTS_HEAD;
+    S.tile_scene = q;
+    return S;
+}
+
+// scene offsets from the sorted batch column of the coordinates, then the tile tables (one launch, no host round trip)
+__global__ void k_bt_offsets_tiles(const int* __restrict__ coords, int M, int n_scenes, int max_tiles,
+                                   int* __restrict__ offs, int* __restrict__ tile_scene, int* __restrict__ tile_first) {
+    if (blockIdx.x != 0) return;
+    for (int s = threadIdx.x; s <= n_scenes; s += blockDim.x) {
+        int lo = 0, hi = M;  // first row whose scene id is >= s
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (coords[(size_t)mid * 4] < s) lo = mid + 1; else hi = mid;
+        }
+        offs[s] = s == n_scenes ? M : lo;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int t = 0;
+    for (int s = 0; s < n_scenes; s++) {
+        tile_first[s] = t;
+        const int nt = (offs[s + 1] - offs[s] + 15) >> 4;
+        for (int i = 0; i < nt && t < max_tiles; i++) tile_scene[t++] = s;
+    }
+    for (; t < max_tiles; t++) tile_scene[t] = -1;
+}
+
+// out[r][col] = sum_o A[r][o] W[o][col]: the product with a row-major nn.Linear weight [out, in] summed over its OUT
+// index (gradient towards a layer's input).  A: LDS tile of 16 rows (rows that do not exist hold zeros), K = number of
+// summed rows of W, N = columns produced (multiple of 16)
+template <typename Epi>
+__device__ __forceinline__ void bt_tile_gemm_t(const float* A, int lda, int K, const float* __restrict__ W, int ldw,
+                                               int N, int wave, int nwaves, int lane, Epi epi) {
+    const int j = lane & 15, g = lane >> 4;
+    const int KC = K >> 4;
+    for (int ct = wave; ct < (N >> 4); ct += nwaves) {
+        const float* xa = A + (size_t)j * lda + 4 * g;
+        const float* wb = W + (size_t)(4 * g) * ldw + ct * 16 + j;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int kc = 0; kc < KC; kc++) {
+            const float4 a = *reinterpret_cast<const float4*>(xa + kc * 16);
+            const float* w = wb + (size_t)kc * 16 * ldw;
+            const float4 b = make_float4(w[0], w[ldw], w[2 * (size_t)ldw], w[3 * (size_t)ldw]);
+            acc = mfma4(a, b, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) epi(4 * g + i, ct * 16 + j, acc[i]);
+    }
+}
+
+// backward of Norm over the rows of a tile: x, dy in LDS; out(r, c, dx_c, dx_c+1); the normalised rows go to XH
+// (zeros for rows that do not exist) for the alpha gradient
+template <typename Out>
+__device__ __forceinline__ void bt_tile_norm_bwd(const float (*X)[BT_LD], const float (*G)[BT_LD], float (*XH)[BT_LD],
+                                                 int nvalid, const float* __restrict__ alpha, int wave, int nwaves,
+                                                 int lane, Out out) {
+    const float a0 = alpha[2 * lane], a1 = alpha[2 * lane + 1];
+    for (int r = wave; r < 16; r += nwaves) {
+        if (r >= nvalid) {
+            XH[r][2 * lane] = 0.f;
+            XH[r][2 * lane + 1] = 0.f;
+            continue;
+        }
+        const float2 v = *reinterpret_cast<const float2*>(&X[r][2 * lane]);
+        float s = v.x + v.y;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float mu = s / (float)BT_D;
+        const float dx = v.x - mu, dy = v.y - mu;
+        float q = dx * dx + dy * dy;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float sd = sqrtf(q / (float)(BT_D - 1));
+        const float den = sd + 1e-6f;
+        const float2 gy = *reinterpret_cast<const float2*>(&G[r][2 * lane]);
+        const float g0 = gy.x * a0, g1 = gy.y * a1;
+        float sg = g0 + g1, sgx = g0 * dx + g1 * dy;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            sg += __shfl_xor(sg, d, 64);
+            sgx += __shfl_xor(sgx, d, 64);
+        }
+        const float mg = sg / (float)BT_D;
+        const float k = sd > 0.f ? sgx / (den * den * sd * (float)(BT_D - 1)) : 0.f;
+        out(r, 2 * lane, (g0 - mg) / den - dx * k, (g1 - mg) / den - dy * k);
+        XH[r][2 * lane] = dx / den;
+        XH[r][2 * lane + 1] = dy / den;
+    }
+}
+
+// per-tile partial sums of the Norm gradients: dalpha[c] = sum_r dy[r][c] xhat[r][c], dbeta[c] = sum_r dy[r][c]
+__device__ __forceinline__ void bt_tile_norm_partials(const float (*G)[BT_LD], const float (*XH)[BT_LD], int nvalid,
+                                                      float* __restrict__ dst) {
+    if (threadIdx.x < 2 * BT_D) {
+        const int c = threadIdx.x & (BT_D - 1);
+        const bool is_alpha = threadIdx.x < BT_D;
+        float s = 0.f;
+        for (int r = 0; r < nvalid; r++) s += is_alpha ? G[r][c] * XH[r][c] : G[r][c];
+        dst[threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(BT_THREADS) void k_bt_train_pre(const float* __restrict__ feats,
+                                                             const int* __restrict__ coords, int c, BtParams P,
+                                                             BtSave S) {
+    __shared__ float sX[16][BT_LD], sT[16][BT_LD];
+    __shared__ int psum[3];
+    const int sc = S.tile_scene[blockIdx.x];
+    if (sc < 0) return;
+    const int s0 = S.offs[sc], T = S.offs[sc + 1] - s0;
+    const int t0 = (blockIdx.x - S.tile_first[sc]) * 16;
+    const int nvalid = min(16, T - t0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = BT_THREADS / 64;
+    const int* xyz = coords + (size_t)s0 * 4;
+    if (threadIdx.x < 3) psum[threadIdx.x] = 0;
+    __syncthreads();
+    {
+        int a0 = 0, a1 = 0, a2 = 0;
+        for (int t = threadIdx.x; t < T; t += BT_THREADS) {
+            a0 += xyz[t * 4 + 1];
+            a1 += xyz[t * 4 + 2];
+            a2 += xyz[t * 4 + 3];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            a0 += __shfl_xor(a0, d, 64);
+            a1 += __shfl_xor(a1, d, 64);
+            a2 += __shfl_xor(a2, d, 64);
+        }
+        if (lane == 0 && wave * 64 < T) {
+            atomicAdd(&psum[0], a0);
+            atomicAdd(&psum[1], a1);
+            atomicAdd(&psum[2], a2);
+        }
+    }
+    __syncthreads();
+    const float ft = (float)T;
+    const int* tz = xyz + (size_t)t0 * 4;
+    if (threadIdx.x < nvalid * BT_REL_LD) {
+        const int r = threadIdx.x >> 4, a = threadIdx.x & 15;
+        S.REL[((size_t)s0 + t0 + r) * BT_REL_LD + a] = a < 3 ? (float)(T * tz[r * 4 + 1 + a] - psum[a]) / ft : 0.f;
+    }
+    bt_tile_gemm<false>(feats + ((size_t)s0 + t0) * c, c, nvalid, c, P.bw, P.bb, BT_D, wave, nw, lane,
+                        [&](int r, int col, float v) {
+                            const float r0 = (float)(T * tz[r * 4 + 1] - psum[0]) / ft;
+                            const float r1 = (float)(T * tz[r * 4 + 2] - psum[1]) / ft;
+                            const float r2 = (float)(T * tz[r * 4 + 3] - psum[2]) / ft;
+                            const float pe = fmaf(P.pw[col * 3 + 2], r2, fmaf(P.pw[col * 3 + 1], r1, P.pw[col * 3] * r0));
+                            sX[r][col] = v + (pe + P.pb[col]);
+                        });
+    __syncthreads();
+    float* X = S.X[0] + ((size_t)s0 + t0) * BT_D;
+    for (int i = threadIdx.x; i < nvalid * BT_D; i += BT_THREADS) X[i] = sX[i >> 7][i & 127];
+    bt_tile_norm(sX, nvalid, P.L[0].n1a, P.L[0].n1b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+        sT[r][c2] = v0;
+        sT[r][c2 + 1] = v1;
+    });
+    __syncthreads();
+    bt_tile_qkv(sT, nvalid, P.L[0], S.QKV[0] + ((size_t)s0 + t0) * (3 * BT_D), wave, nw, lane);
+}
+
+__global__ __launch_bounds__(BT_THREADS) void k_bt_train_layer(int c, int li, BtParams P, BtSave S, BtDrop dr,
+                                                               float* __restrict__ out) {
+    __shared__ float sX[16][BT_LD], sT[16][BT_LD], sO[16][BT_LD];
+    const int sc = S.tile_scene[blockIdx.x];
+    if (sc < 0) return;
+    const int s0 = S.offs[sc], T = S.offs[sc + 1] - s0;
+    const int t0 = (blockIdx.x - S.tile_first[sc]) * 16;
+    const int nvalid = min(16, T - t0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = BT_THREADS / 64;
+    const int j = lane & 15, g = lane >> 4;
+    const float* QKV = S.QKV[li] + (size_t)s0 * (3 * BT_D);
+    const BtLayer& L = P.L[li];
+    const uint32_t site = 4u * li, grow = (uint32_t)(s0 + t0);
+    if (wave < BT_H) {
+        const int h = wave;
+        const int QT = (T + 15) >> 4;
+        const float scale = 0.17677669529663687f;  // 1 / sqrt(32)
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int qrow = t0 + j;
+        float4 bq0 = z4, bq1 = z4;
+        if (qrow < T) {
+            const float* qp = QKV + (size_t)qrow * (3 * BT_D) + h * BT_DK + 4 * g;
+            bq0 = *reinterpret_cast<const float4*>(qp);
+            bq1 = *reinterpret_cast<const float4*>(qp + 16);
+        }
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, l = 0.f;
+        for (int kt = 0; kt < QT; kt++) {
+            float4 a0 = z4, a1 = z4;
+            float v0[4], v1[4];
+            const int krow = kt * 16 + j;
+            if (krow < T) {
+                const float* kp = QKV + (size_t)krow * (3 * BT_D) + BT_D + h * BT_DK + 4 * g;
+                a0 = *reinterpret_cast<const float4*>(kp);
+                a1 = *reinterpret_cast<const float4*>(kp + 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int key = kt * 16 + 4 * g + i;
+                const float* vp = QKV + (size_t)key * (3 * BT_D) + 2 * BT_D + h * BT_DK + j;
+                v0[i] = key < T ? vp[0] : 0.f;
+                v1[i] = key < T ? vp[16] : 0.f;
+            }
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            s = mfma4(a0, bq0, s);
+            s = mfma4(a1, bq1, s);
+            float scv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) scv[i] = (kt * 16 + 4 * g + i) < T ? s[i] * scale : -INFINITY;
+            float mx = fmaxf(fmaxf(scv[0], scv[1]), fmaxf(scv[2], scv[3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m, mx);
+            const float corr = expf(m - mnew);
+            float p[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) p[i] = expf(scv[i] - mnew);
+            l = l * corr + ((p[0] + p[1]) + (p[2] + p[3]));
+            o0 *= corr;
+            o1 *= corr;
+            m = mnew;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float pd = p[i] * bt_keep(dr, site, grow + j, (uint32_t)(kt * 16 + 4 * g + i) * 4u + h);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[i], pd, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[i], pd, o1, 0, 0, 0);
+            }
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            sO[j][h * BT_DK + 4 * g + i] = o0[i] / l;
+            sO[j][h * BT_DK + 16 + 4 * g + i] = o1[i] / l;
+        }
+        if (g == 0 && qrow < T) S.LSE[li][((size_t)s0 + qrow) * BT_H + h] = m + logf(l);
+    }
+    __syncthreads();
+    {
+        float* Og = S.O[li] + ((size_t)s0 + t0) * BT_D;
+        for (int i = threadIdx.x; i < nvalid * BT_D; i += BT_THREADS) Og[i] = sO[i >> 7][i & 127];
+    }
+    // x += dropout(out(O))
+    const float* xg = S.X[li] + ((size_t)s0 + t0) * BT_D;
+    bt_tile_gemm<false>(&sO[0][0], BT_LD, nvalid, BT_D, L.ow, L.ob, BT_D, wave, nw, lane, [&](int r, int col, float v) {
+        sX[r][col] = xg[r * BT_D + col] + v * bt_keep(dr, site + 1, grow + r, col);
+    });
+    __syncthreads();
+    {
+        float* Xm = S.XMID[li] + ((size_t)s0 + t0) * BT_D;
+        for (int i = threadIdx.x; i < nvalid * BT_D; i += BT_THREADS) Xm[i] = sX[i >> 7][i & 127];
+    }
+    bt_tile_norm(sX, nvalid, L.n2a, L.n2b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+        sT[r][c2] = v0;
+        sT[r][c2 + 1] = v1;
+    });
+    __syncthreads();
+    // x += dropout(ff2(dropout(relu(ff1(.)))));  the hidden tile reuses sO; H keeps the hidden layer before its dropout
+    float* Hg = S.H[li] + ((size_t)s0 + t0) * BT_FF;
+    bt_tile_gemm<true>(&sT[0][0], BT_LD, nvalid, BT_D, L.f1w, L.f1b, BT_FF, wave, nw, lane,
+                       [&](int r, int col, float v) {
+                           Hg[r * BT_FF + col] = v;
+                           sO[r][col] = v * bt_keep(dr, site + 2, grow + r, col);
+                       });
+    __syncthreads();
+    bt_tile_gemm<false>(&sO[0][0], BT_LD, nvalid, BT_FF, L.f2w, L.f2b, BT_D, wave, nw, lane,
+                        [&](int r, int col, float v) { sX[r][col] += v * bt_keep(dr, site + 3, grow + r, col); });
+    __syncthreads();
+    {
+        float* Xo = S.X[li + 1] + ((size_t)s0 + t0) * BT_D;
+        for (int i = threadIdx.x; i < nvalid * BT_D; i += BT_THREADS) Xo[i] = sX[i >> 7][i & 127];
+    }
+    if (li + 1 < P.nl) {
+        bt_tile_norm(sX, nvalid, P.L[li + 1].n1a, P.L[li + 1].n1b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+            sT[r][c2] = v0;
+            sT[r][c2 + 1] = v1;
+        });
+        __syncthreads();
+        bt_tile_qkv(sT, nvalid, P.L[li + 1], S.QKV[li + 1] + ((size_t)s0 + t0) * (3 * BT_D), wave, nw, lane);
+    } else {
+        bt_tile_norm(sX, nvalid, P.na, P.nb, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+            sT[r][c2] = v0;
+            sT[r][c2 + 1] = v1;
+        });
+        __syncthreads();
+        float* y = out + ((size_t)s0 + t0) * c;
+        bt_tile_gemm<false>(&sT[0][0], BT_LD, nvalid, BT_D, P.aw, P.ab, c, wave, nw, lane,
+                            [&](int r, int col, float v) { y[(size_t)r * c + col] = v; });
+    }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------
+struct BtWork {  // [M, .] arrays of the backward, per layer: operands of the weight gradients and what the kernels hand on
+    float *DF[BT_MAXL], *HD[BT_MAXL], *DHDN[BT_MAXL], *X2B[BT_MAXL], *DA[BT_MAXL], *DO[BT_MAXL], *DD[BT_MAXL],
+        *DQKV[BT_MAXL], *X2A[BT_MAXL], *PN[BT_MAXL];
+    float *YN, *PNF, *DX0, *DXMID;
+};
+#define BT_QLD (3 * BT_D + 4)
+
+static size_t bt_work_floats(int M, int nl, int max_tiles) {
+    const size_t m = (size_t)M, t = (size_t)max_tiles;
+    return (size_t)nl * (m * (BT_D + BT_FF + BT_FF + BT_D + BT_D + BT_D + BT_H + 3 * BT_D + BT_D) + t * 4 * BT_D) +
+           m * BT_D * 3 + t * 2 * BT_D;
+}
+static BtWork bt_work_layout(void* ws, int M, int nl, int max_tiles) {
+    BtWork W;
+    float* p = (float*)ws;
+    const size_t m = (size_t)M, t = (size_t)max_tiles;
+    for (int l = 0; l < BT_MAXL; l++)
+        W.DF[l] = W.HD[l] = W.DHDN[l] = W.X2B[l] = W.DA[l] = W.DO[l] = W.DD[l] = W.DQKV[l] = W.X2A[l] = W.PN[l] = nullptr;
+    for (int l = 0; l < nl; l++) {
+        W.DF[l] = p; p += m * BT_D;
+        W.HD[l] = p; p += m * BT_FF;
+        W.DHDN[l] = p; p += m * BT_FF;
+        W.X2B[l] = p; p += m * BT_D;
+        W.DA[l] = p; p += m * BT_D;
+        W.DO[l] = p; p += m * BT_D;
+        W.DD[l] = p; p += m * BT_H;
+        W.DQKV[l] = p; p += m * 3 * BT_D;
+        W.X2A[l] = p; p += m * BT_D;
+        W.PN[l] = p; p += t * 4 * BT_D;
+    }
+    W.YN = p; p += m * BT_D;
+    W.DX0 = p; p += m * BT_D;
+    W.DXMID = p; p += m * BT_D;
+    W.PNF = p;
+    return W;
+}
+
+// stage n_layers: after-linear and final Norm backward, then the feed-forward / attention-output half of the last layer;
+// stage l in 1 .. n_layers-1: the q/k/v projections and Norm 1 of layer l, then that half of layer l-1;
+// stage 0: the q/k/v projections and Norm 1 of layer 0, then the position term and before-linear
+__global__ __launch_bounds__(BT_THREADS) void k_bt_bwd_tok(const float* __restrict__ dY, int c, int stage, BtParams P,
+                                                           BtSave S, BtWork Wk, BtDrop dr, float* __restrict__ dfeats) {
+    __shared__ float sD[16][BT_LD], sA[16][BT_LD], sB[16][BT_LD], sC[16][BT_LD];
+    __shared__ float sQ[16][BT_QLD];
+    const int sc = S.tile_scene[blockIdx.x];
+    const int nl = P.nl;
+    if (sc < 0) {  // a tile that does not exist: its partial Norm sums must read as zero
+        if (threadIdx.x < 2 * BT_D) {
+            if (stage == nl) Wk.PNF[(size_t)blockIdx.x * 2 * BT_D + threadIdx.x] = 0.f;
+            if (stage < nl) Wk.PN[stage][((size_t)blockIdx.x * 4 + 2) * BT_D + threadIdx.x] = 0.f;
+            if (stage > 0) Wk.PN[stage - 1][(size_t)blockIdx.x * 4 * BT_D + threadIdx.x] = 0.f;
+        }
+        return;
+    }
+    const int s0 = S.offs[sc], T = S.offs[sc + 1] - s0;
+    const int t0 = (blockIdx.x - S.tile_first[sc]) * 16;
+    const int nvalid = min(16, T - t0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = BT_THREADS / 64;
+    const size_t row0 = (size_t)s0 + t0;
+    auto load_tile = [&](float (*dst)[BT_LD], const float* src) {
+        for (int i = threadIdx.x; i < 16 * BT_D; i += BT_THREADS) {
+            const int r = i >> 7, col = i & 127;
+            dst[r][col] = r < nvalid ? src[(row0 + r) * BT_D + col] : 0.f;
+        }
+    };
+    if (stage == nl) {
+        for (int i = threadIdx.x; i < 16 * c; i += BT_THREADS) {
+            const int r = i / c, col = i - r * c;
+            sQ[r][col] = r < nvalid ? dY[(row0 + r) * c + col] : 0.f;
+        }
+        for (int i = threadIdx.x; i < 16 * BT_D; i += BT_THREADS) sD[i >> 7][i & 127] = 0.f;
+        load_tile(sA, S.X[nl]);
+        __syncthreads();
+        bt_tile_norm(sA, nvalid, P.na, P.nb, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+            *reinterpret_cast<float2*>(&Wk.YN[(row0 + r) * BT_D + c2]) = make_float2(v0, v1);
+        });
+        bt_tile_gemm_t(&sQ[0][0], BT_QLD, c, P.aw, BT_D, BT_D, wave, nw, lane, [&](int r, int col, float v) { sC[r][col] = v; });
+        __syncthreads();
+        bt_tile_norm_bwd(sA, sC, sB, nvalid, P.na, wave, nw, lane, [&](int r, int c2, float d0, float d1) {
+            sD[r][c2] = d0;
+            sD[r][c2 + 1] = d1;
+        });
+        __syncthreads();
+        bt_tile_norm_partials(sC, sB, nvalid, Wk.PNF + (size_t)blockIdx.x * 2 * BT_D);
+        __syncthreads();
+    } else {
+        const int l = stage;
+        const BtLayer& L = P.L[l];
+        for (int i = threadIdx.x; i < 16 * 3 * BT_D; i += BT_THREADS) {
+            const int r = i / (3 * BT_D), col = i - r * (3 * BT_D);
+            sQ[r][col] = r < nvalid ? Wk.DQKV[l][(row0 + r) * (3 * BT_D) + col] : 0.f;
+        }
+        load_tile(sA, S.X[l]);
+        load_tile(sD, Wk.DXMID);
+        __syncthreads();
+        bt_tile_norm(sA, nvalid, L.n1a, L.n1b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+            *reinterpret_cast<float2*>(&Wk.X2A[l][(row0 + r) * BT_D + c2]) = make_float2(v0, v1);
+        });
+        bt_tile_gemm_t(&sQ[0][0], BT_QLD, BT_D, L.qw, BT_D, BT_D, wave, nw, lane, [&](int r, int col, float v) { sC[r][col] = v; });
+        bt_tile_gemm_t(&sQ[0][BT_D], BT_QLD, BT_D, L.kw, BT_D, BT_D, wave, nw, lane, [&](int r, int col, float v) { sC[r][col] += v; });
+        bt_tile_gemm_t(&sQ[0][2 * BT_D], BT_QLD, BT_D, L.vw, BT_D, BT_D, wave, nw, lane, [&](int r, int col, float v) { sC[r][col] += v; });
+        __syncthreads();
+        bt_tile_norm_bwd(sA, sC, sB, nvalid, L.n1a, wave, nw, lane, [&](int r, int c2, float d0, float d1) {
+            sD[r][c2] += d0;
+            sD[r][c2 + 1] += d1;
+        });
+        __syncthreads();
+        bt_tile_norm_partials(sC, sB, nvalid, Wk.PN[l] + ((size_t)blockIdx.x * 4 + 2) * BT_D);
+        __syncthreads();
+    }
+    if (stage > 0) {
+        const int l = stage - 1;
+        const BtLayer& L = P.L[l];
+        const uint32_t site = 4u * l, grow = (uint32_t)row0;
+        // feed-forward branch: x_out = x_mid + keep3 * ff2(keep2 * relu(ff1(Norm2(x_mid))))
+        for (int i = threadIdx.x; i < 16 * BT_D; i += BT_THREADS) {
+            const int r = i >> 7, col = i & 127;
+            const float v = r < nvalid ? sD[r][col] * bt_keep(dr, site + 3, grow + r, col) : 0.f;
+            sA[r][col] = v;
+            if (r < nvalid) Wk.DF[l][(row0 + r) * BT_D + col] = v;
+        }
+        __syncthreads();
+        bt_tile_gemm_t(&sA[0][0], BT_LD, BT_D, L.f2w, BT_FF, BT_FF, wave, nw, lane, [&](int r, int col, float v) { sB[r][col] = v; });
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * BT_FF; i += BT_THREADS) {
+            const int r = i >> 6, col = i & 63;
+            float d = 0.f;
+            if (r < nvalid) {
+                const float h = S.H[l][(row0 + r) * BT_FF + col];
+                const float k = bt_keep(dr, site + 2, grow + r, col);
+                Wk.HD[l][(row0 + r) * BT_FF + col] = h * k;
+                d = h > 0.f ? sB[r][col] * k : 0.f;
+                Wk.DHDN[l][(row0 + r) * BT_FF + col] = d;
+            }
+            sB[r][col] = d;
+        }
+        load_tile(sA, S.XMID[l]);
+        __syncthreads();
+        bt_tile_gemm_t(&sB[0][0], BT_LD, BT_FF, L.f1w, BT_D, BT_D, wave, nw, lane, [&](int r, int col, float v) { sC[r][col] = v; });
+        bt_tile_norm(sA, nvalid, L.n2a, L.n2b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+            *reinterpret_cast<float2*>(&Wk.X2B[l][(row0 + r) * BT_D + c2]) = make_float2(v0, v1);
+        });
+        __syncthreads();
+        bt_tile_norm_bwd(sA, sC, sB, nvalid, L.n2a, wave, nw, lane, [&](int r, int c2, float d0, float d1) {
+            sD[r][c2] += d0;
+            sD[r][c2 + 1] += d1;
+        });
+        __syncthreads();
+        bt_tile_norm_partials(sC, sB, nvalid, Wk.PN[l] + (size_t)blockIdx.x * 4 * BT_D);
+        // attention branch: x_mid = x + keep1 * out(O)
+        for (int i = threadIdx.x; i < 16 * BT_D; i += BT_THREADS) {
+            const int r = i >> 7, col = i & 127;
+            const float d = sD[r][col];
+            const float v = r < nvalid ? d * bt_keep(dr, site + 1, grow + r, col) : 0.f;
+            sA[r][col] = v;
+            if (r < nvalid) {
+                Wk.DXMID[(row0 + r) * BT_D + col] = d;
+                Wk.DA[l][(row0 + r) * BT_D + col] = v;
+            }
+        }
+        __syncthreads();
+        bt_tile_gemm_t(&sA[0][0], BT_LD, BT_D, L.ow, BT_D, BT_D, wave, nw, lane, [&](int r, int col, float v) { sC[r][col] = v; });
+        __syncthreads();
+        for (int r = wave; r < nvalid; r += nw) {
+            const float2 d = *reinterpret_cast<const float2*>(&sC[r][2 * lane]);
+            const float2 o = *reinterpret_cast<const float2*>(&S.O[l][(row0 + r) * BT_D + 2 * lane]);
+            *reinterpret_cast<float2*>(&Wk.DO[l][(row0 + r) * BT_D + 2 * lane]) = d;
+            float pr = d.x * o.x + d.y * o.y;
+#pragma unroll
+            for (int q = 8; q >= 1; q >>= 1) pr += __shfl_xor(pr, q, 64);
+            if ((lane & 15) == 0) Wk.DD[l][(row0 + r) * BT_H + (lane >> 4)] = pr;
+        }
+    } else {
+        for (int i = threadIdx.x; i < nvalid * BT_D; i += BT_THREADS) Wk.DX0[row0 * BT_D + i] = sD[i >> 7][i & 127];
+        bt_tile_gemm_t(&sD[0][0], BT_LD, BT_D, P.bw, c, c, wave, nw, lane, [&](int r, int col, float v) {
+            if (r < nvalid) dfeats[(row0 + r) * c + col] = v;
+        });
+    }
+}
+
+// dq for the tile's tokens as queries (waves 0..3, one head each), dk and dv for them as keys (waves 4..7)
+__global__ __launch_bounds__(BT_THREADS) void k_bt_bwd_attn(int li, BtSave S, BtWork Wk, BtDrop dr) {
+    const int sc = S.tile_scene[blockIdx.x];
+    if (sc < 0) return;
+    const int s0 = S.offs[sc], T = S.offs[sc + 1] - s0;
+    const int t0 = (blockIdx.x - S.tile_first[sc]) * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int h = wave & 3;
+    const float* QKV = S.QKV[li] + (size_t)s0 * (3 * BT_D);
+    const float* dO = Wk.DO[li] + (size_t)s0 * BT_D;
+    const float* LSE = S.LSE[li] + (size_t)s0 * BT_H;
+    const float* DD = Wk.DD[li] + (size_t)s0 * BT_H;
+    float* dQKV = Wk.DQKV[li] + (size_t)s0 * (3 * BT_D);
+    const int NT = (T + 15) >> 4;
+    const float scale = 0.17677669529663687f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t site = 4u * li;
+    const int own = t0 + j;  // this lane's column: a query (waves 0..3) or a key (waves 4..7)
+    auto row4 = [&](const float* base, int ld, int row, int off, float4& lo, float4& hi) {
+        lo = z4;
+        hi = z4;
+        if (row < T) {
+            const float* p = base + (size_t)row * ld + off + h * BT_DK + 4 * g;
+            lo = *reinterpret_cast<const float4*>(p);
+            hi = *reinterpret_cast<const float4*>(p + 16);
+        }
+    };
+    if (wave < BT_H) {
+        float4 bq0, bq1, bd0, bd1;
+        row4(QKV, 3 * BT_D, own, 0, bq0, bq1);
+        row4(dO, BT_D, own, 0, bd0, bd1);
+        const float lse_q = own < T ? LSE[(size_t)own * BT_H + h] : 0.f;
+        const float dd_q = own < T ? DD[(size_t)own * BT_H + h] : 0.f;
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < NT; kt++) {
+            float4 a0, a1, va0, va1;
+            row4(QKV, 3 * BT_D, kt * 16 + j, BT_D, a0, a1);
+            row4(QKV, 3 * BT_D, kt * 16 + j, 2 * BT_D, va0, va1);
+            float k0[4], k1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int key = kt * 16 + 4 * g + i;
+                const float* kp = QKV + (size_t)key * (3 * BT_D) + BT_D + h * BT_DK + j;
+                k0[i] = key < T ? kp[0] : 0.f;
+                k1[i] = key < T ? kp[16] : 0.f;
+            }
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = mfma4(a0, bq0, s);
+            s = mfma4(a1, bq1, s);
+            dp = mfma4(va0, bd0, dp);
+            dp = mfma4(va1, bd1, dp);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int key = kt * 16 + 4 * g + i;
+                const float p = key < T ? expf(s[i] * scale - lse_q) : 0.f;
+                const float keep = bt_keep(dr, site, (uint32_t)(s0 + own), (uint32_t)key * 4u + h);
+                const float ds = p * (dp[i] * keep - dd_q);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[i], ds, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[i], ds, o1, 0, 0, 0);
+            }
+        }
+        if (own < T) {
+            float* dq = dQKV + (size_t)own * (3 * BT_D) + h * BT_DK + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                dq[i] = o0[i] * scale;
+                dq[16 + i] = o1[i] * scale;
+            }
+        }
+    } else {
+        float4 bk0, bk1, bv0, bv1;
+        row4(QKV, 3 * BT_D, own, BT_D, bk0, bk1);
+        row4(QKV, 3 * BT_D, own, 2 * BT_D, bv0, bv1);
+        f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+        for (int qt = 0; qt < NT; qt++) {
+            float4 aq0, aq1, ad0, ad1;
+            row4(QKV, 3 * BT_D, qt * 16 + j, 0, aq0, aq1);
+            row4(dO, BT_D, qt * 16 + j, 0, ad0, ad1);
+            float q0[4], q1[4], e0[4], e1[4], lse[4], dd[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int qr = qt * 16 + 4 * g + i;
+                const bool ok = qr < T;
+                const float* qp = QKV + (size_t)qr * (3 * BT_D) + h * BT_DK + j;
+                const float* ep = dO + (size_t)qr * BT_D + h * BT_DK + j;
+                q0[i] = ok ? qp[0] : 0.f;
+                q1[i] = ok ? qp[16] : 0.f;
+                e0[i] = ok ? ep[0] : 0.f;
+                e1[i] = ok ? ep[16] : 0.f;
+                lse[i] = ok ? LSE[(size_t)qr * BT_H + h] : 0.f;
+                dd[i] = ok ? DD[(size_t)qr * BT_H + h] : 0.f;
+            }
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = mfma4(aq0, bk0, s);
+            s = mfma4(aq1, bk1, s);
+            dp = mfma4(ad0, bv0, dp);
+            dp = mfma4(ad1, bv1, dp);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int qr = qt * 16 + 4 * g + i;
+                const float p = qr < T ? expf(s[i] * scale - lse[i]) : 0.f;
+                const float keep = bt_keep(dr, site, (uint32_t)(s0 + qr), (uint32_t)own * 4u + h);
+                const float pd = p * keep;
+                const float ds = p * (dp[i] * keep - dd[i]);
+                dv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[i], pd, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[i], pd, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(q0[i], ds, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q1[i], ds, dk1, 0, 0, 0);
+            }
+        }
+        if (own < T) {
+            float* dk = dQKV + (size_t)own * (3 * BT_D) + BT_D + h * BT_DK + 4 * g;
+            float* dv = dk + BT_D;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                dk[i] = dk0[i] * scale;
+                dk[16 + i] = dk1[i] * scale;
+                dv[i] = dv0[i];
+                dv[16 + i] = dv1[i];
+            }
+        }
+    }
+}
+
+// every weight / bias / Norm gradient of the call in one launch: dst[o][i] = sum_t A[t][o] B[t][i] (a workgroup per
+// 16 x 16 tile, its four waves take interleaved token groups, summed in a fixed order) and column sums
+struct BtGemmJob {
+    const float *A, *B;
+    float* dst;
+    int lda, ldb, O, I, ldd, ivalid;
+};
+struct BtColJob {
+    const float* src;
+    float* dst;
+    int ld, n, rows, pad;
+};
+#define BT_MAX_GEMM 28
+#define BT_MAX_COL 48
+struct BtWJobs {
+    int ng, nc;
+    int gstart[BT_MAX_GEMM + 1], cstart[BT_MAX_COL + 1];
+    BtGemmJob g[BT_MAX_GEMM];
+    BtColJob c[BT_MAX_COL];
+};
+static_assert(sizeof(BtWJobs) <= 3800, "kernel argument block");
+
+__global__ __launch_bounds__(256) void k_bt_wgrad(BtWJobs J, int M) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    if (b < J.gstart[J.ng]) {
+        int k = 0;
+        while (b >= J.gstart[k + 1]) k++;
+        const BtGemmJob& G = J.g[k];
+        const int tile = b - J.gstart[k], nti = (G.I + 15) >> 4;
+        const int to = tile / nti, ti = tile - to * nti;
+        const int j = lane & 15, g = lane >> 4;
+        const float* ap = G.A + to * 16 + j;
+        const float* bp = G.B + ti * 16 + j;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int tb = w * 4; tb < M; tb += 16) {  // uniform trip count: every lane takes part in the matrix instruction
+            const int t = tb + g;
+            const float a = t < M ? ap[(size_t)t * G.lda] : 0.f;
+            const float bb = t < M ? bp[(size_t)t * G.ldb] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(&red[w][lane * 4]) = acc;
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float v = ((red[0][lane * 4 + i] + red[1][lane * 4 + i]) + red[2][lane * 4 + i]) + red[3][lane * 4 + i];
+                const int o = to * 16 + 4 * g + i, ii = ti * 16 + j;
+                if (o < G.O && ii < G.ivalid) G.dst[(size_t)o * G.ldd + ii] = v;
+            }
+        }
+    } else {
+        const int cb = b - J.gstart[J.ng];
+        int k = 0;
+        while (cb >= J.cstart[k + 1]) k++;
+        const BtColJob& C = J.c[k];
+        const int col = (cb - J.cstart[k]) * 64 + lane;
+        float s = 0.f;
+        if (col < C.n)
+            for (int r = w; r < C.rows; r += 4) s += C.src[(size_t)r * C.ld + col];
+        red[w][lane] = s;
+        __syncthreads();
+        if (w == 0 && col < C.n) C.dst[col] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    }
+}
+
+static int bt_unpack(const float* const* params, int n_layers, BtParams& P, const char* who) {
+    GF_CHECK_ARG(params != nullptr, "%s: params is null", who);
+    const int np = 8 + 16 * n_layers;
+    for (int i = 0; i < np; i++) GF_CHECK_ARG(params[i] != nullptr, "%s: params[%d] is null", who, i);
+    int k = 0;
+    P.bw = params[k++];
+    P.bb = params[k++];
+    P.pw = params[k++];
+    P.pb = params[k++];
+    for (int l = 0; l < n_layers; l++) {
+        const float** f = reinterpret_cast<const float**>(&P.L[l]);
+        for (int i = 0; i < 16; i++) f[i] = params[k++];
+    }
+    for (int l = n_layers; l < BT_MAXL; l++) P.L[l] = P.L[0];
+    P.na = params[k++];
+    P.nb = params[k++];
+    P.aw = params[k++];
+    P.ab = params[k++];
+    P.nl = n_layers;
+    return GF_OK;
+}
+
+static BtDrop bt_drop(float p, unsigned seed) {
+    BtDrop d;
+    d.seed = seed;
+    d.thresh = p <= 0.f ? 0u : (uint32_t)((double)p * 16777216.0);
+    d.inv = p <= 0.f ? 1.f : 1.f / (1.f - p);
+    return d;
+}
+
+static int bt_train_check(const char* who, int n_scenes, int M, int c, int n_layers, float p) {
+    GF_CHECK_ARG(c > 0 && c % 16 == 0 && c <= 3 * BT_D, "%s: channel width %d must be a multiple of 16, at most %d", who,
+                 c, 3 * BT_D);
+    GF_CHECK_ARG(n_layers >= 1 && n_layers <= BT_MAXL, "%s: 1..%d layers, got %d", who, BT_MAXL, n_layers);
+    GF_CHECK_ARG(n_scenes >= 1 && n_scenes <= 4096 && M >= 1 && M < (1 << 26), "%s: bad sizes", who);
+    GF_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout probability %g", who, (double)p);
+    return GF_OK;
+}
+
+extern "C" size_t gf_backbone_transformer_train_save_bytes(int M, int n_layers) {
+    return bt_save_floats(M > 0 ? M : 0, n_layers) * sizeof(float) + bt_save_ints(M > 0 ? M : 0) * sizeof(int);
+}
+extern "C" size_t gf_backbone_transformer_train_work_bytes(int M, int n_layers, int n_scenes) {
+    const int m = M > 0 ? M : 0;
+    return bt_work_floats(m, n_layers, m / 16 + n_scenes) * sizeof(float);
+}
+extern "C" long long gf_backbone_transformer_grad_floats(int c, int n_layers) {
+    return (long long)BT_D * c + BT_D + 3 * BT_D + BT_D +
+           (long long)n_layers * (2 * BT_D + 4 * (BT_D * BT_D + BT_D) + 2 * BT_D + BT_FF * BT_D + BT_FF + BT_D * BT_FF + BT_D) +
+           2 * BT_D + (long long)c * BT_D + c;
+}
+
+extern "C" int gf_backbone_transformer_train_fwd(const float* feats, const int* coords, int n_scenes, int M, int c,
+                                                 int n_layers, const float* const* params, float p, unsigned seed,
+                                                 void* save, float* out, void* stream) {
+    int rc = bt_train_check("gf_backbone_transformer_train_fwd", n_scenes, M, c, n_layers, p);
+    if (rc != GF_OK) return rc;
+    BtParams P;
+    rc = bt_unpack(params, n_layers, P, "gf_backbone_transformer_train_fwd");
+    if (rc != GF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const BtSave S = bt_save_layout(save, M, n_layers);
+    const BtDrop dr = bt_drop(p, seed);
+    const int max_tiles = M / 16 + n_scenes;
+    hipLaunchKernelGGL(k_bt_offsets_tiles, dim3(1), dim3(256), 0, st, coords, M, n_scenes, max_tiles, S.offs, S.tile_scene,
+                       S.tile_first);
+    hipLaunchKernelGGL(k_bt_train_pre, dim3(max_tiles), dim3(BT_THREADS), 0, st, feats, coords, c, P, S);
+    for (int l = 0; l < n_layers; l++)
+        hipLaunchKernelGGL(k_bt_train_layer, dim3(max_tiles), dim3(BT_THREADS), 0, st, c, l, P, S, dr, out);
+    GF_CHECK_LAUNCH("gf_backbone_transformer_train_fwd");
+    return GF_OK;
+}
+
+extern "C" int gf_backbone_transformer_train_bwd(const float* feats, const float* dout, int n_scenes, int M, int c,
+                                                 int n_layers, const float* const* params, float p, unsigned seed,
+                                                 void* save, void* work, float* dfeats, float* grads, void* stream) {
+    int rc = bt_train_check("gf_backbone_transformer_train_bwd", n_scenes, M, c, n_layers, p);
+    if (rc != GF_OK) return rc;
+    BtParams P;
+    rc = bt_unpack(params, n_layers, P, "gf_backbone_transformer_train_bwd");
+    if (rc != GF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const BtSave S = bt_save_layout(save, M, n_layers);
+    const int max_tiles = M / 16 + n_scenes;
+    const BtWork W = bt_work_layout(work, M, n_layers, max_tiles);
+    const BtDrop dr = bt_drop(p, seed);
+    for (int stage = n_layers; stage >= 0; stage--) {
+        hipLaunchKernelGGL(k_bt_bwd_tok, dim3(max_tiles), dim3(BT_THREADS), 0, st, dout, c, stage, P, S, W, dr, dfeats);
+        if (stage > 0) hipLaunchKernelGGL(k_bt_bwd_attn, dim3(max_tiles), dim3(BT_THREADS), 0, st, stage - 1, S, W, dr);
+    }
+    // gradients in the order of the parameter table
+    BtWJobs J;
+    J.ng = J.nc = 0;
+    int gt = 0, ct = 0;
+    auto gemm = [&](const float* A, int lda, const float* B, int ldb, int O, int I, int ivalid, float* dst, int ldd) {
+        BtGemmJob& g = J.g[J.ng];
+        g.A = A; g.B = B; g.dst = dst; g.lda = lda; g.ldb = ldb; g.O = O; g.I = I; g.ldd = ldd; g.ivalid = ivalid;
+        J.gstart[J.ng++] = gt;
+        gt += (O / 16) * ((I + 15) / 16);
+    };
+    auto cols = [&](const float* src, int ld, int n, int rows, float* dst) {
+        BtColJob& q = J.c[J.nc];
+        q.src = src; q.dst = dst; q.ld = ld; q.n = n; q.rows = rows; q.pad = 0;
+        J.cstart[J.nc++] = ct;
+        ct += (n + 63) / 64;
+    };
+    float* g = grads;
+    gemm(W.DX0, BT_D, feats, c, BT_D, c, c, g, c); g += (size_t)BT_D * c;                       // before.W
+    cols(W.DX0, BT_D, BT_D, M, g); g += BT_D;                                                   // before.b
+    gemm(W.DX0, BT_D, S.REL, BT_REL_LD, BT_D, BT_REL_LD, 3, g, 3); g += 3 * BT_D;               // position.W
+    cols(W.DX0, BT_D, BT_D, M, g); g += BT_D;                                                   // position.b
+    for (int l = 0; l < n_layers; l++) {
+        cols(W.PN[l] + 2 * BT_D, 4 * BT_D, BT_D, max_tiles, g); g += BT_D;                      // norm1.alpha
+        cols(W.PN[l] + 3 * BT_D, 4 * BT_D, BT_D, max_tiles, g); g += BT_D;                      // norm1.bias
+        for (int k = 0; k < 3; k++) {                                                           // q, k, v
+            gemm(W.DQKV[l] + k * BT_D, 3 * BT_D, W.X2A[l], BT_D, BT_D, BT_D, BT_D, g, BT_D); g += BT_D * BT_D;
+            cols(W.DQKV[l] + k * BT_D, 3 * BT_D, BT_D, M, g); g += BT_D;
+        }
+        gemm(W.DA[l], BT_D, S.O[l], BT_D, BT_D, BT_D, BT_D, g, BT_D); g += BT_D * BT_D;         // out.W
+        cols(W.DA[l], BT_D, BT_D, M, g); g += BT_D;
+        cols(W.PN[l], 4 * BT_D, BT_D, max_tiles, g); g += BT_D;                                 // norm2.alpha
+        cols(W.PN[l] + BT_D, 4 * BT_D, BT_D, max_tiles, g); g += BT_D;                          // norm2.bias
+        gemm(W.DHDN[l], BT_FF, W.X2B[l], BT_D, BT_FF, BT_D, BT_D, g, BT_D); g += BT_FF * BT_D;  // ff1.W [64,128]
+        cols(W.DHDN[l], BT_FF, BT_FF, M, g); g += BT_FF;
+        gemm(W.DF[l], BT_D, W.HD[l], BT_FF, BT_D, BT_FF, BT_FF, g, BT_FF); g += BT_D * BT_FF;   // ff2.W [128,64]
+        cols(W.DF[l], BT_D, BT_D, M, g); g += BT_D;
+    }
+    cols(W.PNF, 2 * BT_D, BT_D, max_tiles, g); g += BT_D;                                       // norm.alpha
+    cols(W.PNF + BT_D, 2 * BT_D, BT_D, max_tiles, g); g += BT_D;                                // norm.bias
+    gemm(dout, c, W.YN, BT_D, c, BT_D, BT_D, g, BT_D); g += (size_t)c * BT_D;                   // after.W [c,128]
+    cols(dout, c, c, M, g); g += c;
+    J.gstart[J.ng] = gt;
+    J.cstart[J.nc] = ct;
+    hipLaunchKernelGGL(k_bt_wgrad, dim3(gt + ct), dim3(256), 0, st, J, M);
+    GF_CHECK_LAUNCH("gf_backbone_transformer_train_bwd");
+    return GF_OK;
+}

@@ -33,6 +33,12 @@ def _fusable(t, *bns):
         all(not bn.training for bn in bns)
 
 
+def _train_transformer_ok(t, transformer):
+    from .. import pointops
+
+    return pointops.backbone_transformer_train_supported(t.features, t._coords(), transformer)
+
+
 class ResidualBlock(SparseModule):
     """out = conv_branch(x) + i_branch(x); i_branch is Identity or a 1x1x1 conv when the widths differ.
     conv_branch = [BN, ReLU, SubM3, BN, ReLU, SubM3] (pre-activation)."""
@@ -180,6 +186,14 @@ class UBlock(nn.Module):
             output = self.blocks_tail(output)
         if self.before_transformer_linear is not None and _fusable(output) and output.features.shape[1] % 16 == 0:
             output.features = self._transformer_fused(output)
+        elif self.before_transformer_linear is not None and torch.is_grad_enabled() and output.features.is_cuda and \
+                _train_transformer_ok(output, self.transformer):
+            # training on the GPU: forward and backward of the stack as a handful of native launches
+            from .. import pointops
+
+            output.features = pointops.backbone_transformer_train(
+                output.features.contiguous(), output._coords(), output.batch_size, self.before_transformer_linear,
+                self.transformer, self.after_transformer_linear)
         elif self.before_transformer_linear is not None:
             feats = self.before_transformer_linear(output.features)
             feats = self.transformer(xyz=output.indices[:, 1:].float(), features=feats, batch_ids=output.indices[:, 0],

@@ -11,6 +11,7 @@ import threading
 
 import os
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -626,6 +627,107 @@ def backbone_transformer(feats, coords, scene_offsets, n_scenes, params, n_layer
     check(lib.gf_backbone_transformer(ptr(feats), ptr(coords), ptr(scene_offsets), n_scenes, M, c, n_layers, params,
                                       ptr(scratch), ptr(out), stream_ptr()), "gf_backbone_transformer")
     return out
+
+
+def backbone_transformer_tensors(before, transformer, after):
+    """The parameters of the voxel transformer stack in the order of gf_backbone_transformer's table."""
+    ts = [before.weight, before.bias, transformer.position_linear.weight, transformer.position_linear.bias]
+    for layer in transformer.layers:
+        a, ff = layer.attn_1, layer.ff
+        ts += [layer.norm_1.alpha, layer.norm_1.bias, a.q_linear.weight, a.q_linear.bias, a.k_linear.weight,
+               a.k_linear.bias, a.v_linear.weight, a.v_linear.bias, a.out.weight, a.out.bias, layer.norm_2.alpha,
+               layer.norm_2.bias, ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias]
+    return ts + [transformer.norm.alpha, transformer.norm.bias, after.weight, after.bias]
+
+
+def dropout_keep_reference(seed, p, site, rows, cols):
+    """The keep factor (0 or 1/(1-p)) gf_backbone_transformer_train_* uses for element (row, col) of a dropout site, as
+    the header states it -- for tests that rebuild the masks.  rows, cols: integer tensors (broadcast together)."""
+    M32 = 0xFFFFFFFF
+
+    def fmix(x):
+        x = x ^ (x >> 16)
+        x = (x * 0x85EBCA6B) & M32
+        x = x ^ (x >> 13)
+        x = (x * 0xC2B2AE35) & M32
+        return x ^ (x >> 16)
+
+    rows, cols = rows.to(torch.int64), cols.to(torch.int64)
+    h = fmix((int(seed) & M32) ^ ((rows * 64 + int(site)) & M32))
+    h = fmix((h + ((cols * 0x9E3779B1) & M32)) & M32)
+    if p <= 0:
+        return torch.ones_like(h, dtype=torch.float32)
+    keep = (h >> 8) >= int(float(p) * 16777216.0)
+    return keep.to(torch.float32) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+
+class _VoxelTransformerTrainFn(torch.autograd.Function):
+    """before-linear -> per-scene voxel transformer (with its dropouts) -> after-linear of a deep U-Net level, forward and
+    backward in csrc/backbone_attn.hip (gf_backbone_transformer_train_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, n_scenes, n_layers, p, seed, *params):
+        import ctypes
+
+        lib = _lib.load()
+        M, c = feats.shape
+        feats = _f32c(feats.contiguous(), "feats")
+        params = [_f32c(t.detach().contiguous(), "transformer parameter") for t in params]
+        table = (ctypes.c_void_p * len(params))(*[t.data_ptr() for t in params])
+        out = torch.empty_like(feats)
+        save = torch.empty(lib.gf_backbone_transformer_train_save_bytes(M, n_layers) // 4, dtype=torch.float32,
+                           device=feats.device)
+        check(lib.gf_backbone_transformer_train_fwd(ptr(feats), ptr(coords), n_scenes, M, c, n_layers, table, float(p),
+                                                    int(seed), ptr(save), ptr(out), stream_ptr()),
+              "gf_backbone_transformer_train_fwd")
+        ctx.save_for_backward(feats, save, *params)
+        ctx.cfg = (n_scenes, n_layers, float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+
+        lib = _lib.load()
+        feats, save, *params = ctx.saved_tensors
+        n_scenes, n_layers, p, seed = ctx.cfg
+        M, c = feats.shape
+        dout = _f32c(dout.contiguous(), "dout")
+        table = (ctypes.c_void_p * len(params))(*[t.data_ptr() for t in params])
+        work = torch.empty(lib.gf_backbone_transformer_train_work_bytes(M, n_layers, n_scenes) // 4, dtype=torch.float32,
+                           device=feats.device)
+        grads = torch.empty(lib.gf_backbone_transformer_grad_floats(c, n_layers), dtype=torch.float32, device=feats.device)
+        dfeats = torch.empty_like(feats)
+        check(lib.gf_backbone_transformer_train_bwd(ptr(feats), ptr(dout), n_scenes, M, c, n_layers, table, p, seed,
+                                                    ptr(save), ptr(work), ptr(dfeats), ptr(grads), stream_ptr()),
+              "gf_backbone_transformer_train_bwd")
+        outs, o = [], 0
+        for t in params:
+            outs.append(grads[o:o + t.numel()].view(t.shape))
+            o += t.numel()
+        assert o == grads.numel()
+        return (dfeats, None, None, None, None, None) + tuple(outs)
+
+
+def backbone_transformer_train_supported(feats, coords, transformer):
+    return (feats.is_cuda and feats.dtype == torch.float32 and feats.shape[0] > 0 and feats.shape[1] % 16 == 0
+            and feats.shape[1] <= 384 and coords.dtype == torch.int32 and coords.is_contiguous()
+            and transformer.d_model == 128 and 1 <= len(transformer.layers) <= 4
+            and len({float(m.p) for m in transformer.modules() if isinstance(m, torch.nn.Dropout)}) == 1
+            and all(l.attn_1.h == 4 and l.ff.linear_1.out_features == 64 for l in transformer.layers)
+            and os.environ.get("GF_FUSED_VOXEL_TRANSFORMER", "1") != "0")
+
+
+def backbone_transformer_train(feats, coords, n_scenes, before, transformer, after, seed=None):
+    """Training forward of a deep level's voxel transformer stack with a native backward.  The dropouts are active when
+    the transformer module is in training mode (p of its modules); `seed` defaults to a draw from the framework's CPU
+    generator, so torch.manual_seed fixes the masks."""
+    layer0 = transformer.layers[0]
+    p = float(layer0.dropout_1.p) if transformer.training else 0.0
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    ts = backbone_transformer_tensors(before, transformer, after)
+    return _VoxelTransformerTrainFn.apply(feats, coords, int(n_scenes), len(transformer.layers), p, seed, *ts)
 
 
 def decoder_pack_weights(W1, W2, Wv):

@@ -620,6 +620,32 @@ int gf_backbone_transformer(const float* feats, const int* coords, const int* sc
                             int c, int n_layers, const float* const* params, void* scratch, float* out,
                             void* stream);
 
+/* Training form of the same stack (what train.py:63-75 runs through the framework modules of
+ * geoformer_modules.py:64-68,120-127 and transformer.py:62-188 with their dropouts, p = transformer.py's 0.1): the
+ * forward keeps what the backward needs in `save`, the backward returns the gradient of the input rows and of every
+ * parameter -- n_layers + 2 and 2 n_layers + 2 launches instead of ~250 framework launches per level and step.
+ *   coords int32 [M,4] with the scene id in column 0, ascending (scene offsets are found on the device);
+ *   p: dropout probability of the four dropout sites of a layer (0: every element kept -- modules in eval mode);
+ *   seed: the call's dropout seed (the same value must be passed to the backward): an element is kept iff
+ *     (h >> 8) >= (uint32)(p * 2^24),  h = fmix32(fmix32(seed ^ (row * 64 + site)) + col * 0x9E3779B1),
+ *     fmix32 = MurmurHash3's finaliser, site = 4 * layer + {0 attention weights, 1 attention branch, 2 hidden layer,
+ *     3 feed-forward branch}, row = the token's row in the batch, col = the channel (attention weights: 4 * key's
+ *     index in its scene + head); kept elements are scaled by 1 / (1 - p);
+ *   save: gf_backbone_transformer_train_save_bytes(M, n_layers) bytes, written by the forward, read by the backward;
+ *   work: gf_backbone_transformer_train_work_bytes(M, n_layers, n_scenes) bytes of scratch for the backward;
+ *   dfeats fp32 [M,c]; grads: gf_backbone_transformer_grad_floats(c, n_layers) floats, the parameters' gradients
+ *   back to back in the order of the parameter table, each in its parameter's layout (every value is written).
+ *   c % 16 == 0, c <= 384.  Summation orders are fixed: the same inputs give the same bits. */
+size_t gf_backbone_transformer_train_save_bytes(int M, int n_layers);
+size_t gf_backbone_transformer_train_work_bytes(int M, int n_layers, int n_scenes);
+long long gf_backbone_transformer_grad_floats(int c, int n_layers);
+int gf_backbone_transformer_train_fwd(const float* feats, const int* coords, int n_scenes, int M, int c, int n_layers,
+                                      const float* const* params, float p, unsigned seed, void* save, float* out,
+                                      void* stream);
+int gf_backbone_transformer_train_bwd(const float* feats, const float* dout, int n_scenes, int M, int c, int n_layers,
+                                      const float* const* params, float p, unsigned seed, void* save, void* work,
+                                      float* dfeats, float* grads, void* stream);
+
 /* ===================================================================================
  * Decoder cross-attention (TransformerDecoderLayer.forward_pre_rel, model/transformer_detr.py:443-454
  * with the relative embedding of GeoFormer.forward_decoder, model/geoformer/geoformer.py:619-651), fused

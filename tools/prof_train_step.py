@@ -1,6 +1,8 @@
 """Dev tool: the config-3 training step (batch 4, full epoch) a few times, for rocprofv3 --kernel-trace --stats."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import geoformer_amd
+geoformer_amd.configure_runtime()
 import numpy as np, torch
 from geoformer_amd import scene
 from geoformer_amd.model import GeoFormer, InstSetCriterion, load_config
