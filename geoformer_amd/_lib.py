@@ -121,6 +121,16 @@ def _declare(lib):
         "gf_backbone_transformer_scratch_bytes": (c_size_t, [I]),
         "gf_backbone_transformer_num_params": (I, [I]),
         "gf_backbone_transformer": (I, [P, P, P, I, I, I, I, P, P, P, P]),
+        "gf_decoder_pre_train_save_bytes": (c_size_t, [I, I]),
+        "gf_decoder_pre_train_work_bytes": (c_size_t, [I, I]),
+        "gf_decoder_pre_grad_floats": (c_longlong, []),
+        "gf_decoder_pre_train_fwd": (I, [P, P, I, I, P, F, c_uint, I, P, P, P, P]),
+        "gf_decoder_pre_train_bwd": (I, [P, P, P, P, P, I, I, P, F, c_uint, I, P, P, P, P, P, P]),
+        "gf_decoder_post_train_save_bytes": (c_size_t, [I, I, I]),
+        "gf_decoder_post_train_work_bytes": (c_size_t, [I, I, I]),
+        "gf_decoder_post_grad_floats": (c_longlong, [I]),
+        "gf_decoder_post_train_fwd": (I, [P, P, I, I, I, P, F, c_uint, I, P, P, P, P]),
+        "gf_decoder_post_train_bwd": (I, [P, P, P, P, I, I, I, P, F, c_uint, I, P, P, P, P, P, P]),
         "gf_backbone_transformer_train_save_bytes": (c_size_t, [I, I]),
         "gf_backbone_transformer_train_work_bytes": (c_size_t, [I, I, I]),
         "gf_backbone_transformer_grad_floats": (c_longlong, [I, I]),

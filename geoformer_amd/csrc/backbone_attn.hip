@@ -21,6 +21,7 @@
 // directly the B operand of O^T = V^T P^T (online soft-max over 16-key tiles, one tile of look-ahead).
 // Norm = alpha * (x - mean) / (std_unbiased + eps) + bias  (transformer.py:62-76).
 #include "common.h"
+#include "train_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -408,26 +409,10 @@ extern "C" int gf_backbone_transformer(const float* feats, const int* coords, co
 // sum_j dP_ij P_ij = dO_i . O_i also under dropout) and at the end ONE launch for every weight, bias and Norm gradient
 // (k_bt_wgrad: dW = A^T B over all tokens on the fp32 matrix pipe, column sums; fixed summation order).
 // =====================================================================================================================
-struct BtDrop {
-    uint32_t seed, thresh;
-    float inv;
-};
-
-__device__ __forceinline__ uint32_t bt_fmix(uint32_t x) {
-    x ^= x >> 16;
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 13;
-    x *= 0xC2B2AE35u;
-    x ^= x >> 16;
-    return x;
-}
-// 1 / (1 - p) if the element is kept, else 0.  site = 4 * layer + {0 attention weights, 1 attention branch, 2 hidden
-// layer, 3 feed-forward branch}; row = token index in the batch; column = channel, or 4 * key + head
-__device__ __forceinline__ float bt_keep(const BtDrop& d, uint32_t site, uint32_t row, uint32_t col) {
-    uint32_t h = bt_fmix(d.seed ^ (row * 64u + site));
-    h = bt_fmix(h + col * 0x9E3779B1u);
-    return (h >> 8) >= d.thresh ? d.inv : 0.f;
-}
+typedef GfDrop BtDrop;
+// site = 4 * layer + {0 attention weights, 1 attention branch, 2 hidden layer, 3 feed-forward branch}; row = token index
+// in the batch; column = channel, or 4 * key + head
+#define bt_keep gf_drop_keep
 
 struct BtSave {  // what the forward keeps: [M, .] arrays indexed by the token's row in the batch
     float *X[BT_MAXL + 1], *QKV[BT_MAXL], *O[BT_MAXL], *XMID[BT_MAXL], *H[BT_MAXL], *LSE[BT_MAXL], *REL;
@@ -1059,36 +1044,15 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_bwd_attn(int li, BtSave S, Bt
     }
 }
 
-// every weight / bias / Norm gradient of the call in one launch: dst[o][i] = sum_t A[t][o] B[t][i] (a workgroup per
-// 16 x 16 tile, its four waves take interleaved token groups, summed in a fixed order) and column sums
-struct BtGemmJob {
-    const float *A, *B;
-    float* dst;
-    int lda, ldb, O, I, ldd, ivalid;
-};
-struct BtColJob {
-    const float* src;
-    float* dst;
-    int ld, n, rows, pad;
-};
-#define BT_MAX_GEMM 28
-#define BT_MAX_COL 48
-struct BtWJobs {
-    int ng, nc;
-    int gstart[BT_MAX_GEMM + 1], cstart[BT_MAX_COL + 1];
-    BtGemmJob g[BT_MAX_GEMM];
-    BtColJob c[BT_MAX_COL];
-};
-static_assert(sizeof(BtWJobs) <= 3800, "kernel argument block");
-
-__global__ __launch_bounds__(256) void k_bt_wgrad(BtWJobs J, int M) {
+// every weight / bias / Norm gradient of a call in one launch (train_common.h)
+__global__ __launch_bounds__(256) void k_bt_wgrad(GfWJobs J, int M) {
     __shared__ float red[4][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int b = blockIdx.x;
     if (b < J.gstart[J.ng]) {
         int k = 0;
         while (b >= J.gstart[k + 1]) k++;
-        const BtGemmJob& G = J.g[k];
+        const GfGemmJob& G = J.g[k];
         const int tile = b - J.gstart[k], nti = (G.I + 15) >> 4;
         const int to = tile / nti, ti = tile - to * nti;
         const int j = lane & 15, g = lane >> 4;
@@ -1116,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_bt_wgrad(BtWJobs J, int M) {
         const int cb = b - J.gstart[J.ng];
         int k = 0;
         while (cb >= J.cstart[k + 1]) k++;
-        const BtColJob& C = J.c[k];
+        const GfColJob& C = J.c[k];
         const int col = (cb - J.cstart[k]) * 64 + lane;
         float s = 0.f;
         if (col < C.n)
@@ -1147,14 +1111,6 @@ static int bt_unpack(const float* const* params, int n_layers, BtParams& P, cons
     P.ab = params[k++];
     P.nl = n_layers;
     return GF_OK;
-}
-
-static BtDrop bt_drop(float p, unsigned seed) {
-    BtDrop d;
-    d.seed = seed;
-    d.thresh = p <= 0.f ? 0u : (uint32_t)((double)p * 16777216.0);
-    d.inv = p <= 0.f ? 1.f : 1.f / (1.f - p);
-    return d;
 }
 
 static int bt_train_check(const char* who, int n_scenes, int M, int c, int n_layers, float p) {
@@ -1189,7 +1145,7 @@ extern "C" int gf_backbone_transformer_train_fwd(const float* feats, const int* 
     if (rc != GF_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const BtSave S = bt_save_layout(save, M, n_layers);
-    const BtDrop dr = bt_drop(p, seed);
+    const BtDrop dr = gf_drop_make(p, seed);
     const int max_tiles = M / 16 + n_scenes;
     hipLaunchKernelGGL(k_bt_offsets_tiles, dim3(1), dim3(256), 0, st, coords, M, n_scenes, max_tiles, S.offs, S.tile_scene,
                        S.tile_first);
@@ -1212,27 +1168,17 @@ extern "C" int gf_backbone_transformer_train_bwd(const float* feats, const float
     const BtSave S = bt_save_layout(save, M, n_layers);
     const int max_tiles = M / 16 + n_scenes;
     const BtWork W = bt_work_layout(work, M, n_layers, max_tiles);
-    const BtDrop dr = bt_drop(p, seed);
+    const BtDrop dr = gf_drop_make(p, seed);
     for (int stage = n_layers; stage >= 0; stage--) {
         hipLaunchKernelGGL(k_bt_bwd_tok, dim3(max_tiles), dim3(BT_THREADS), 0, st, dout, c, stage, P, S, W, dr, dfeats);
         if (stage > 0) hipLaunchKernelGGL(k_bt_bwd_attn, dim3(max_tiles), dim3(BT_THREADS), 0, st, stage - 1, S, W, dr);
     }
     // gradients in the order of the parameter table
-    BtWJobs J;
-    J.ng = J.nc = 0;
-    int gt = 0, ct = 0;
+    GfWJobBuilder jb;
     auto gemm = [&](const float* A, int lda, const float* B, int ldb, int O, int I, int ivalid, float* dst, int ldd) {
-        BtGemmJob& g = J.g[J.ng];
-        g.A = A; g.B = B; g.dst = dst; g.lda = lda; g.ldb = ldb; g.O = O; g.I = I; g.ldd = ldd; g.ivalid = ivalid;
-        J.gstart[J.ng++] = gt;
-        gt += (O / 16) * ((I + 15) / 16);
+        jb.gemm(A, lda, B, ldb, O, I, ivalid, dst, ldd);
     };
-    auto cols = [&](const float* src, int ld, int n, int rows, float* dst) {
-        BtColJob& q = J.c[J.nc];
-        q.src = src; q.dst = dst; q.ld = ld; q.n = n; q.rows = rows; q.pad = 0;
-        J.cstart[J.nc++] = ct;
-        ct += (n + 63) / 64;
-    };
+    auto cols = [&](const float* src, int ld, int n, int rows, float* dst) { jb.cols(src, ld, n, rows, dst); };
     float* g = grads;
     gemm(W.DX0, BT_D, feats, c, BT_D, c, c, g, c); g += (size_t)BT_D * c;                       // before.W
     cols(W.DX0, BT_D, BT_D, M, g); g += BT_D;                                                   // before.b
@@ -1258,9 +1204,13 @@ extern "C" int gf_backbone_transformer_train_bwd(const float* feats, const float
     cols(W.PNF + BT_D, 2 * BT_D, BT_D, max_tiles, g); g += BT_D;                                // norm.bias
     gemm(dout, c, W.YN, BT_D, c, BT_D, BT_D, g, BT_D); g += (size_t)c * BT_D;                   // after.W [c,128]
     cols(dout, c, c, M, g); g += c;
-    J.gstart[J.ng] = gt;
-    J.cstart[J.nc] = ct;
-    hipLaunchKernelGGL(k_bt_wgrad, dim3(gt + ct), dim3(256), 0, st, J, M);
     GF_CHECK_LAUNCH("gf_backbone_transformer_train_bwd");
+    return jb.launch(M, st);
+}
+
+int gf_wgrad_launch(const GfWJobs& J, int M, hipStream_t st) {
+    const int blocks = J.gstart[J.ng] + J.cstart[J.nc];
+    if (blocks > 0) hipLaunchKernelGGL(k_bt_wgrad, dim3(blocks), dim3(256), 0, st, J, M);
+    GF_CHECK_LAUNCH("gf_wgrad_launch");
     return GF_OK;
 }

@@ -1,0 +1,78 @@
+// Tile helpers of the decoder's token-side kernels (decoder_layer.hip: inference, decoder_layer_train.hip: training):
+// d_model 64, 4 heads x 16 channels; products on v_mfma_f32_16x16x4_f32 with operands loaded straight from row-major
+// activations (LDS tiles or global rows) and nn.Linear weights [out,in] (operand scheme of backbone_attn.hip).
+#pragma once
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DL_D 64
+#define DL_H 4
+#define DL_DK 16
+#define DL_THREADS 1024
+#define DL_MAXFF 256
+
+__device__ __forceinline__ f32x4 dl_mfma4(float4 a, float4 b, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    return acc;
+}
+
+#define DL_LD 68     // padded LDS row (floats): 16 rows x float4 reads without bank conflicts
+#define DL_LDH 260
+
+// one 16-row tile: out(r, col, act(sum_k A[r][k] W[col][k] + b[col])) for the column tiles ct = wave, wave+nw, ...
+// A may live in LDS or global memory (row stride lda); rows >= nvalid read as zero and are not emitted
+template <bool RELU, typename Epi>
+__device__ __forceinline__ void dl_tile_gemm(const float* A, int lda, int nvalid, int K, const float* __restrict__ W,
+                                             const float* __restrict__ bias, int N, int wave, int nwaves, int lane,
+                                             Epi epi) {
+    const int j = lane & 15, g = lane >> 4;
+    const int KC = K >> 4;
+    for (int ct = wave; ct < (N >> 4); ct += nwaves) {
+        const float* xa = A + (size_t)j * lda + 4 * g;
+        const float* wb = W + (size_t)(ct * 16 + j) * K + 4 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int kc = 0; kc < KC; kc++) {
+            float4 a = j < nvalid ? *reinterpret_cast<const float4*>(xa + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 b = *reinterpret_cast<const float4*>(wb + kc * 16);
+            acc = dl_mfma4(a, b, acc);
+        }
+        const int col = ct * 16 + j;
+        const float bs = bias[col];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * g + i;
+            if (r >= nvalid) continue;
+            float v = acc[i] + bs;
+            if (RELU) v = fmaxf(v, 0.f);
+            epi(r, col, v);
+        }
+    }
+}
+
+// torch.nn.LayerNorm over 64 channels (biased variance, eps inside the root) of the rows of an LDS tile;
+// one wave per row, one channel per lane
+template <typename Out>
+__device__ __forceinline__ void dl_tile_layernorm(const float (*S)[DL_LD], int nvalid, const float* __restrict__ w,
+                                                  const float* __restrict__ b, int wave, int nwaves, int lane,
+                                                  Out out) {
+    const float wl = w[lane], bl = b[lane];
+    for (int r = wave; r < nvalid; r += nwaves) {
+        const float v = S[r][lane];
+        float s = v;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float mu = s / (float)DL_D;
+        const float dv = v - mu;
+        float q = dv * dv;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)DL_D + 1e-5f);
+        out(r, lane, dv * rstd * wl + bl);
+    }
+}
+

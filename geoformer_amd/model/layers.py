@@ -599,15 +599,54 @@ class TransformerDecoder(nn.Module):
                                          q1 if pre is not None else None)
         return inter
 
+    def _train_fused_dropout(self):
+        """The one dropout probability of the layers (0 in eval mode), or None when they differ (framework route)."""
+        ps = set()
+        for l in self.layers:
+            ps |= {float(l.self_attn.dropout), float(l.dropout1.p), float(l.dropout2.p), float(l.dropout3.p),
+                   float(l.dropout.p)}
+            if not isinstance(l.activation, nn.ReLU) or not isinstance(l.norm1, nn.LayerNorm):
+                return None
+        if len(ps) != 1:
+            return None
+        return ps.pop() if self.layers[0].self_attn.training else 0.0
+
+    def _forward_train_fused(self, tgt, memory, query_pos, rp, p):
+        """Training on the GPU: per layer the token-side stages as native forward / backward launches
+        (csrc/decoder_layer_train.hip) around the fused cross-attention -- ~20 launches per layer and step instead of
+        ~95.  The dropout masks are hashed from one seed per call, drawn from the framework's CPU generator."""
+        from .. import pointops
+
+        x = tgt.permute(1, 0, 2).contiguous()  # [B, nq, d] token rows
+        qp = query_pos.permute(1, 0, 2).contiguous()
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        inter = []
+        for l, layer in enumerate(self.layers):
+            pre, post = pointops.decoder_stage_tensors(layer, self.norm)
+            w1, w2, wv = layer.attn_mlp[0], layer.attn_mlp[2], layer.v_mlp[0]
+            t2n, q1 = pointops.decoder_pre_train(x, qp, l, p, seed, pre)
+            K1 = _SplitKLinearFn.apply(memory, w1.weight, None).permute(1, 0, 2)
+            Kv = wv(memory).permute(1, 0, 2)
+            ca = pointops.decoder_cross_attn_train(rp.geo_ctx, rp.max_geo, rp.query_locs, rp.context_locs, rp.lo, rp.hi,
+                                                   rp.gauss_B, q1, K1, Kv, w1.weight, w2.weight, wv.weight)
+            x, it = pointops.decoder_post_train(ca, t2n, l, p, seed, post)
+            inter.append(it)
+        return torch.stack(inter).permute(0, 2, 1, 3)  # [L, nq, B, d]
+
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None, relative_pos=None, transpose_swap=False,
                 return_attn_weights=False):
-        if (isinstance(relative_pos, RelPosSpec) and tgt_mask is None and tgt_key_padding_mask is None
-                and query_pos is not None and self.norm is not None and self.return_intermediate
-                and tgt.shape[-1] == 64 and self.layers[0].nhead == 4 and self.layers[0].linear1.out_features % 16 == 0
-                and self.layers[0].linear1.out_features <= 256 and not self.layers[0].self_attn.training
-                and not torch.is_grad_enabled()):
+        shapes_ok = (isinstance(relative_pos, RelPosSpec) and tgt_mask is None and tgt_key_padding_mask is None
+                     and query_pos is not None and self.norm is not None and self.return_intermediate
+                     and tgt.shape[-1] == 64 and self.layers[0].nhead == 4
+                     and self.layers[0].linear1.out_features % 16 == 0 and self.layers[0].linear1.out_features <= 256)
+        if shapes_ok and not self.layers[0].self_attn.training and not torch.is_grad_enabled():
             return self._forward_fused(tgt, memory, query_pos, relative_pos)
+        if (shapes_ok and torch.is_grad_enabled() and tgt.is_cuda and tgt.dtype == torch.float32
+                and os.environ.get("GF_FUSED_DECODER_TRAIN", "1") != "0"):
+            p = self._train_fused_dropout()
+            if p is not None:
+                return self._forward_train_fused(tgt, memory, query_pos, relative_pos, p)
         output, inter = tgt, []
         for layer in self.layers:
             output, _ = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,

@@ -500,6 +500,116 @@ def decoder_stage_tables(layer, final_norm):
     return mk(post), mk(pre)
 
 
+def decoder_stage_tensors(layer, final_norm):
+    """(pre, post) parameter lists of one decoder layer in gf_decoder_token_stage's table order."""
+    sa = layer.self_attn
+    pre = [layer.norm1.weight, layer.norm1.bias, sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight,
+           sa.out_proj.bias, layer.norm2.weight, layer.norm2.bias, layer.attn_mlp[0].weight, layer.attn_mlp[0].bias]
+    post = [layer.out_mlp[0].weight, layer.out_mlp[0].bias, layer.norm3.weight, layer.norm3.bias, layer.linear1.weight,
+            layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, final_norm.weight, final_norm.bias]
+    return pre, post
+
+
+def _ptr_table(ts):
+    import ctypes
+
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _split_grads(grads, params):
+    outs, o = [], 0
+    for t in params:
+        outs.append(grads[o:o + t.numel()].view(t.shape))
+        o += t.numel()
+    assert o == grads.numel()
+    return outs
+
+
+class _DecoderPreTrainFn(torch.autograd.Function):
+    """norm1 -> self-attention -> residual -> norm2 -> query half of the cross-attention's first linear, with the layer's
+    dropouts: forward and backward in csrc/decoder_layer_train.hip.  x, qpos [B,T,64] -> (t2n, q1)."""
+
+    @staticmethod
+    def forward(ctx, x, qpos, layer, p, seed, *params):
+        lib = _lib.load()
+        B, T, _ = x.shape
+        x, qpos = _f32c(x.contiguous(), "x"), _f32c(qpos.contiguous(), "qpos")
+        params = [_f32c(t.detach().contiguous(), "decoder parameter") for t in params]
+        t2n, q1 = torch.empty_like(x), torch.empty_like(x)
+        save = torch.empty(lib.gf_decoder_pre_train_save_bytes(T, B) // 4, dtype=torch.float32, device=x.device)
+        check(lib.gf_decoder_pre_train_fwd(ptr(x), ptr(qpos), T, B, _ptr_table(params), float(p), int(seed), int(layer),
+                                           ptr(save), ptr(t2n), ptr(q1), stream_ptr()), "gf_decoder_pre_train_fwd")
+        ctx.save_for_backward(x, qpos, t2n, save, *params)
+        ctx.cfg = (int(layer), float(p), int(seed))
+        ctx.set_materialize_grads(False)
+        return t2n, q1
+
+    @staticmethod
+    def backward(ctx, d_t2n, d_q1):
+        lib = _lib.load()
+        x, qpos, t2n, save, *params = ctx.saved_tensors
+        layer, p, seed = ctx.cfg
+        B, T, _ = x.shape
+        if d_t2n is None and d_q1 is None:
+            return (None,) * (5 + len(params))
+        d_t2n = None if d_t2n is None else _f32c(d_t2n.contiguous(), "d_t2n")
+        d_q1 = None if d_q1 is None else _f32c(d_q1.contiguous(), "d_q1")
+        work = torch.empty(lib.gf_decoder_pre_train_work_bytes(T, B) // 4, dtype=torch.float32, device=x.device)
+        grads = torch.empty(lib.gf_decoder_pre_grad_floats(), dtype=torch.float32, device=x.device)
+        dx, dqpos = torch.empty_like(x), torch.empty_like(x)
+        check(lib.gf_decoder_pre_train_bwd(ptr(x), ptr(qpos), ptr(t2n), ptr(d_t2n), ptr(d_q1), T, B, _ptr_table(params), p,
+                                           seed, layer, ptr(save), ptr(work), ptr(dx), ptr(dqpos), ptr(grads),
+                                           stream_ptr()), "gf_decoder_pre_train_bwd")
+        return (dx, dqpos, None, None, None) + tuple(_split_grads(grads, params))
+
+
+class _DecoderPostTrainFn(torch.autograd.Function):
+    """out_mlp -> residual with the normed query -> norm3 -> FFN -> residual -> decoder.norm, with the layer's dropouts.
+    ca, t2n [B,T,64] -> (x3, inter)."""
+
+    @staticmethod
+    def forward(ctx, ca, t2n, layer, p, seed, *params):
+        lib = _lib.load()
+        B, T, _ = ca.shape
+        ca, t2n = _f32c(ca.contiguous(), "ca"), _f32c(t2n.contiguous(), "t2n")
+        params = [_f32c(t.detach().contiguous(), "decoder parameter") for t in params]
+        ff = params[4].shape[0]
+        x3, inter = torch.empty_like(ca), torch.empty_like(ca)
+        save = torch.empty(lib.gf_decoder_post_train_save_bytes(T, B, ff) // 4, dtype=torch.float32, device=ca.device)
+        check(lib.gf_decoder_post_train_fwd(ptr(ca), ptr(t2n), T, B, ff, _ptr_table(params), float(p), int(seed), int(layer),
+                                            ptr(save), ptr(x3), ptr(inter), stream_ptr()), "gf_decoder_post_train_fwd")
+        ctx.save_for_backward(ca, x3, save, *params)
+        ctx.cfg = (int(layer), float(p), int(seed), ff)
+        ctx.set_materialize_grads(False)
+        return x3, inter
+
+    @staticmethod
+    def backward(ctx, d_x3, d_inter):
+        lib = _lib.load()
+        ca, x3, save, *params = ctx.saved_tensors
+        layer, p, seed, ff = ctx.cfg
+        B, T, _ = ca.shape
+        if d_x3 is None and d_inter is None:
+            return (None,) * (5 + len(params))
+        d_x3 = None if d_x3 is None else _f32c(d_x3.contiguous(), "d_x3")
+        d_inter = None if d_inter is None else _f32c(d_inter.contiguous(), "d_inter")
+        work = torch.empty(lib.gf_decoder_post_train_work_bytes(T, B, ff) // 4, dtype=torch.float32, device=ca.device)
+        grads = torch.empty(lib.gf_decoder_post_grad_floats(ff), dtype=torch.float32, device=ca.device)
+        d_ca, d_t2n = torch.empty_like(ca), torch.empty_like(ca)
+        check(lib.gf_decoder_post_train_bwd(ptr(ca), ptr(x3), ptr(d_x3), ptr(d_inter), T, B, ff, _ptr_table(params), p, seed,
+                                            layer, ptr(save), ptr(work), ptr(d_ca), ptr(d_t2n), ptr(grads), stream_ptr()),
+              "gf_decoder_post_train_bwd")
+        return (d_ca, d_t2n, None, None, None) + tuple(_split_grads(grads, params))
+
+
+def decoder_pre_train(x, qpos, layer_index, p, seed, pre_params):
+    return _DecoderPreTrainFn.apply(x, qpos, layer_index, p, seed, *pre_params)
+
+
+def decoder_post_train(ca, t2n, layer_index, p, seed, post_params):
+    return _DecoderPostTrainFn.apply(ca, t2n, layer_index, p, seed, *post_params)
+
+
 def decoder_token_stage(attn_out, tgt_in, query_pos, nq, B, nhead, ff, post, pre, state, inter_out, q1_out):
     """One fused token-side stage between two cross-attentions (include/geoformer_hip.h)."""
     check(_lib.load().gf_decoder_token_stage(ptr(attn_out), ptr(tgt_in), ptr(query_pos), nq, B, 64, nhead, ff, post,

@@ -551,6 +551,38 @@ int gf_decoder_token_stage(const float* attn_out, const float* tgt_in, const flo
                            int nhead, int ff, const float* const* post_params, const float* const* pre_params,
                            void* state, float* inter_out, float* q1_out, void* stream);
 
+/* Training form of the decoder's token-side stages (what train.py:63-75 runs through TransformerDecoderLayer
+ * .forward_pre_rel, model/transformer_detr.py:425-463, with its dropouts): forward with hashed dropout masks and a native
+ * backward, 2 + 1 launches forward and 4 + 2 backward per layer instead of ~95 framework launches.  All tensors fp32
+ * [B, T, 64] row-major (row = b * T + t); d_model 64, 4 heads.
+ *   pre  (x, query_pos) -> (t2n, q1):  t2 = norm1(x); q = k = t2 + query_pos;
+ *                                      x1 = x + drop(out_proj(MHA(q, k, t2))); t2n = norm2(x1); q1 = W1 t2n + b1
+ *   post (ca, t2n) -> (x3, inter):     x2 = relu(out_mlp(ca)) + drop(t2n);
+ *                                      x3 = x2 + drop(linear2(drop(relu(linear1(norm3(x2)))))); inter = norm(x3)
+ *   params: HOST arrays of 10 DEVICE pointers in gf_decoder_token_stage's pre / post order.
+ *   Dropout: element kept iff the hash of gf_backbone_transformer_train_fwd's comment says so, with
+ *     site = 8 * layer + {0 attention weights, 1 attention branch, 2 the normed query added after the cross-attention,
+ *     3 hidden layer, 4 feed-forward branch}, row = b * T + t, col = channel (attention weights: 4 * key + head).
+ *   save / work: the *_save_bytes / *_work_bytes sizes; grads: *_grad_floats floats, the 10 parameters' gradients back
+ *   to back in table order (every value written; post: the last two are this layer's share of decoder.norm's).
+ *   Backward inputs that are NULL count as zero (at least one must be given).  Fixed summation orders. */
+size_t gf_decoder_pre_train_save_bytes(int T, int B);
+size_t gf_decoder_pre_train_work_bytes(int T, int B);
+long long gf_decoder_pre_grad_floats(void);
+int gf_decoder_pre_train_fwd(const float* x, const float* qpos, int T, int B, const float* const* params, float p,
+                             unsigned seed, int layer, void* save, float* t2n, float* q1, void* stream);
+int gf_decoder_pre_train_bwd(const float* x, const float* qpos, const float* t2n, const float* d_t2n, const float* d_q1,
+                             int T, int B, const float* const* params, float p, unsigned seed, int layer, void* save,
+                             void* work, float* dx, float* dqpos, float* grads, void* stream);
+size_t gf_decoder_post_train_save_bytes(int T, int B, int ff);
+size_t gf_decoder_post_train_work_bytes(int T, int B, int ff);
+long long gf_decoder_post_grad_floats(int ff);
+int gf_decoder_post_train_fwd(const float* ca, const float* t2n, int T, int B, int ff, const float* const* params,
+                              float p, unsigned seed, int layer, void* save, float* x3, float* inter, void* stream);
+int gf_decoder_post_train_bwd(const float* ca, const float* x3, const float* d_x3, const float* d_inter, int T, int B,
+                              int ff, const float* const* params, float p, unsigned seed, int layer, void* save,
+                              void* work, float* d_ca, float* d_t2n, float* grads, void* stream);
+
 /* ===================================================================================
  * Proposal extraction of the eval forward (GeoFormer.generate_proposal,
  * model/geoformer/geoformer.py:193-262), fused

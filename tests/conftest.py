@@ -22,7 +22,7 @@ def pytest_configure(config):
 _FILE_ORDER = [
     "test_oracle_kats", "test_oracle_spconv", "test_oracle_golden", "test_host_logic", "test_model_host_logic",
     "test_gpu_pointops", "test_gpu_spconv", "test_gpu_geodesic", "test_gpu_heads", "test_gpu_dormant_ops",
-    "test_gpu_dropin", "test_gpu_bn_train", "test_gpu_voxel_transformer_train", "test_gpu_unet_exec", "test_gpu_model",
+    "test_gpu_dropin", "test_gpu_bn_train", "test_gpu_voxel_transformer_train", "test_gpu_decoder_train", "test_gpu_unet_exec", "test_gpu_model",
     "test_criterion_golden",
     "test_training_golden", "test_gpu_feeder", "test_gpu_serving", "test_route_a", "test_parallel_gloo",
     "test_training_step", "test_gpu_fullsize",
