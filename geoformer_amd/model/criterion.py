@@ -298,6 +298,48 @@ class InstSetCriterion(nn.Module):
             loss = loss + loss_dict[k]
         return loss, loss_dict
 
+    def _all_layer_losses_device(self, preds, matches):
+        """The losses of ALL decoder layers over the device matches at once: the same terms as _layer_loss_device per
+        layer (criterion.py:137-196: dice + focal over the matched pairs, class cross-entropy over the queries, each
+        summed over the scenes and divided by the batch size), collected with a handful of launches -- per (layer, scene)
+        only the fused pair-loss call remains; the scalar chains of the per-layer formulation (~45 small launches per
+        layer forward and as many backward) bounded this part of the step on the host.  Returns ([L] losses, the last
+        layer's terms)."""
+        L, B = len(preds), self.batch_size
+        live = [b for b in range(B) if matches[b] is not None]
+        if not live or any(w != 1 for w in self.loss_weight.values()):
+            return None
+        if any(preds[l]["mask_logits"][b].dtype != torch.float32 for l in range(L) for b in live):
+            return None
+        dev = preds[-1]["cls_logits"].device
+        pair = torch.stack([_PairLossFn.apply(preds[l]["mask_logits"][b], matches[b]) for l in range(L) for b in live])
+        pair = pair.view(L, len(live), 2).sum(1)  # [L, 2]: dice, focal summed over the scenes
+        tgts = []
+        for b in range(B):
+            m = matches[b]
+            if m is None:
+                tgts.append(torch.zeros(self.n_queries, dtype=torch.long, device=dev))
+                continue
+            tgt = getattr(m, "cls_target", None)
+            if tgt is None:
+                valid = m.match_q >= 0
+                cls_label = torch.zeros(self.n_queries + 1, device=dev)
+                cls_label.scatter_(0, torch.where(valid, m.match_q, self.n_queries).long(), m.sem_labels)
+                tgt = m.cls_target = cls_label[:-1].long()
+            tgts.append(tgt)
+        tgt = torch.stack(tgts)  # [B, nq]
+        logits = torch.stack([p["cls_logits"] for p in preds])  # [L, B, nq, C]
+        C = logits.shape[-1]
+        ce = F.cross_entropy(logits.reshape(-1, C), tgt.unsqueeze(0).expand(L, B, self.n_queries).reshape(-1),
+                             reduction="none").view(L, B, self.n_queries).mean(2)  # [L, B]
+        if len(live) < B:
+            keep = torch.zeros(B, device=dev)
+            keep[live] = 1
+            ce = ce * keep
+        terms = torch.cat([pair, ce.sum(1, keepdim=True)], 1) / B  # [L, 3]: dice, focal, class
+        ld = {"dice_loss": terms[-1, 0], "focal_loss": terms[-1, 1], "cls_loss": terms[-1, 2]}
+        return terms.sum(1), ld
+
     def _forward_device(self, model_outputs, semantic_loss, semantic_labels, instance_labels):
         cfg = self.cfg
         preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
@@ -319,10 +361,15 @@ class InstSetCriterion(nn.Module):
                                             instance_masked[s:s + n_b], semantic_masked[s:s + n_b], lo, K, self.n_queries))
             s += n_b
         self.device_matches = matches
-        main, ld = self._layer_loss_device(preds[-1], matches)
-        loss = semantic_loss + main
-        for l in range(cfg.dec_nlayers - 1):  # auxiliary losses reuse the matching of the last layer
-            loss = loss + self._layer_loss_device(preds[l], matches)[0]
+        batched = self._all_layer_losses_device(preds, matches) if _fused_pair_loss() else None
+        if batched is not None:
+            per_layer, ld = batched
+            loss = semantic_loss + per_layer.sum()
+        else:
+            main, ld = self._layer_loss_device(preds[-1], matches)
+            loss = semantic_loss + main
+            for l in range(cfg.dec_nlayers - 1):  # auxiliary losses reuse the matching of the last layer
+                loss = loss + self._layer_loss_device(preds[l], matches)[0]
         live = [m for m in matches if m is not None]
         zero = torch.zeros(1, dtype=torch.int32, device=loss.device)
         num_gt = torch.cat([m.n_match for m in live]).sum() if live else zero.sum()

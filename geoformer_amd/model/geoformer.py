@@ -561,6 +561,7 @@ class GeoFormer(nn.Module):
         # them before the grouping.  One scene / inference: the streams of the docstring.
         multi = batch_size > 1 and early is None and not epilogue and os.environ.get("GF_SCENE_STREAMS", "1") != "0"
         scene_streams = []
+        bfs_one_stream = multi and os.environ.get("GF_TRAIN_BFS_STREAMS", "scene") == "one"
 
         def host_draw(b, n_b):
             """The reference's host draw of scene b (same values, same generator state), restated natively, into a pinned
@@ -596,9 +597,10 @@ class GeoFormer(nn.Module):
                 sb = sides.get((locs_float_.device, main.cuda_stream, "scene", b))
                 if sb is None:
                     sb = sides[(locs_float_.device, main.cuda_stream, "scene", b)] = torch.cuda.Stream(device=locs_float_.device)
-                side_b = sides.get((locs_float_.device, main.cuda_stream, "bfs", b))
+                bk = 0 if bfs_one_stream else b
+                side_b = sides.get((locs_float_.device, main.cuda_stream, "bfs", bk))
                 if side_b is None:
-                    side_b = sides[(locs_float_.device, main.cuda_stream, "bfs", b)] = torch.cuda.Stream(device=locs_float_.device)
+                    side_b = sides[(locs_float_.device, main.cuda_stream, "bfs", bk)] = torch.cuda.Stream(device=locs_float_.device)
                 sb.wait_stream(main)
                 scene_streams.append(sb)
             else:
@@ -654,7 +656,7 @@ class GeoFormer(nn.Module):
             side_b.wait_event(first_ready)
             with torch.cuda.stream(side_b):
                 D, I, deg = graphs[b][:3]
-                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), batch_size) if split else 1024)
+                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), 1 if bfs_one_stream else batch_size) if split else 1024)
                 g.record_stream(main)
                 src.record_stream(side_b)
                 geo[b] = g
