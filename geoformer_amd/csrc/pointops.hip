@@ -310,10 +310,12 @@ __device__ __forceinline__ unsigned dpp_max_step(unsigned v, unsigned o) { retur
 
 // wave-uniform maximum of a 32-bit unsigned value: 4 DPP steps inside each row of 16, 4 readlanes
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));   // quad xor 1
-    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));   // quad xor 2
-    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
-    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror
+    // (old = 0 with bound_ctrl: the identity of max, so the compiler folds the move into v_max_u32_dpp -- one
+    // instruction per step instead of v_mov + v_mov_dpp + v_max)
+    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // quad xor 1
+    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // quad xor 2
+    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v = dpp_max_step(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row_mirror
     const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
     const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
     const unsigned a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
@@ -648,42 +650,73 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             float cdist = __uint_as_float((unsigned)(mine0 >> 32));
             bool alive = mine0 != 0ull;
             int nacc = 0;
-#pragma unroll 1
-            for (int t = 0; t < FPS_K; t++) {
-                const unsigned long long my = alive ? (((unsigned long long)__float_as_uint(cdist) << 32) |
-                                                      ((unsigned long long)ckey << 1)) : 0ull;
-                const unsigned long long best = wave_max_u64(my);
-                if (t == 0) {
-                    if (best == 0ull) {  // nothing eligible anywhere: index 0 like the reference
-                        if (lane == 0) {
-                            s_xyz[par][0] = xyz[0];
-                            s_xyz[par][1] = xyz[1];
-                            s_xyz[par][2] = xyz[2];
-                            if (wg == 0) idxs[done] = 0;
-                        }
-                        nacc = 1;
-                        break;
-                    }
-                } else if (best == 0ull || best < Bcode || (best >> 32) == 0ull || done + t >= m) {
-                    // (a candidate at distance 0 never overtakes the accepted picks, which sit at 0 with lower keys)
-                    break;
-                }
-                const bool own = alive && my == best;
-                const int ol = __builtin_ctzll(__ballot(own));
+            // lane t keeps pick t (coordinates, index): written out once after the loop instead of four single-lane
+            // stores per accepted pick inside the serial chain
+            float kx = 0.f, ky = 0.f, kz = 0.f;
+            int kidx = 0;
+            bool direct = false;
+            const unsigned clo = ckey << 1;  // low word of this lane's code (the high word is its current distance)
+            const unsigned Bhi = (unsigned)(Bcode >> 32), Blo = (unsigned)Bcode;
+            auto take = [&](int ol, unsigned best_lo, int t) {  // the candidate of lane ol is pick t of this exchange
                 const float bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vx[0]), ol));
                 const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vy[0]), ol));
                 const float bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vz[0]), ol));
-                if (lane == 0) {
-                    s_xyz[par][t * 3 + 0] = bx;
-                    s_xyz[par][t * 3 + 1] = by;
-                    s_xyz[par][t * 3 + 2] = bz;
-                    if (wg == 0)
-                        idxs[done + t] = (int)((FPS_KEY_NONE - (unsigned)((best >> 1) & 0x7fffffffull)) & 0x3fffffu);
-                }
-                if (own) alive = false;
+                const bool keeper = lane == t;
+                kx = keeper ? bx : kx;
+                ky = keeper ? by : ky;
+                kz = keeper ? bz : kz;
+                kidx = keeper ? (int)((FPS_KEY_NONE - ((best_lo >> 1) & 0x7fffffffu)) & 0x3fffffu) : kidx;
+                if (lane == ol) alive = false;
                 const float dx = vx[0] - bx, dy = vy[0] - by, dz = vz[0] - bz;
                 cdist = fminf(cdist, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-                nacc = t + 1;
+            };
+            {
+                // first pick of the exchange: the best code whatever its distance (a live candidate at distance 0 counts)
+                const unsigned long long my = alive ? (((unsigned long long)__float_as_uint(cdist) << 32) | clo) : 0ull;
+                const unsigned long long best = wave_max_u64(my);
+                if (best == 0ull) {  // nothing eligible anywhere: index 0 like the reference
+                    if (lane == 0) {
+                        s_xyz[par][0] = xyz[0];
+                        s_xyz[par][1] = xyz[1];
+                        s_xyz[par][2] = xyz[2];
+                        if (wg == 0) idxs[done] = 0;
+                    }
+                    direct = true;
+                } else {
+                    take(__builtin_ctzll(__ballot(alive && my == best)), (unsigned)best, 0);
+                }
+                nacc = 1;
+            }
+            if (!direct) {
+                // further picks: the best candidate under its UPDATED distance while that is positive (a candidate at
+                // distance 0 never overtakes the accepted picks, which sit at 0 with lower keys) and its code is not
+                // below B.  The reduction runs on the 32-bit distances; the key word is read from the owner's lane
+                // (a second reduction only when two candidates share the largest distance).
+#pragma unroll 1
+                for (int t = 1; t < FPS_K && done + t < m; t++) {
+                    const unsigned hi = alive ? __float_as_uint(cdist) : 0u;
+                    const unsigned md = wave_max_u32(hi);
+                    if (md == 0u) break;
+                    const unsigned long long owners = __ballot(hi == md);
+                    int ol;
+                    unsigned blo;
+                    if (__popcll(owners) == 1) {
+                        ol = __builtin_ctzll(owners);
+                        blo = (unsigned)__builtin_amdgcn_readlane((int)clo, ol);
+                    } else {
+                        blo = wave_max_u32(hi == md ? clo : 0u);
+                        ol = __builtin_ctzll(__ballot(hi == md && clo == blo));
+                    }
+                    if (md < Bhi || (md == Bhi && blo < Blo)) break;
+                    take(ol, blo, t);
+                    nacc = t + 1;
+                }
+            }
+            if (!direct && lane < nacc) {
+                s_xyz[par][lane * 3 + 0] = kx;
+                s_xyz[par][lane * 3 + 1] = ky;
+                s_xyz[par][lane * 3 + 2] = kz;
+                if (wg == 0) idxs[done + lane] = kidx;
             }
             if (lane == 0) s_pick[par][0] = nacc;
             const unsigned long long ft7 = FT();
