@@ -330,8 +330,10 @@ class GeoFormer(nn.Module):
         the natural bound), so that the framework's caching allocator holds device blocks large enough for every scene
         up to that size.  Without it a scene larger than any seen before makes the allocator call hipMalloc for its
         largest buffers in the middle of the forward -- 20-30 ms per call on a fast host, several times that on a slow
-        one (bench.py secondary.fresh_scenes: 5.5 against 9.3 ms per never-before-seen scene on such a box).  Uses the
-        process's numpy generator state and restores it."""
+        one (bench.py secondary.fresh_scenes: 5.5 against 9.3 ms per never-before-seen scene on such a box).  The
+        foreground-sized buffers follow the scene's content, not its point count: bound generously (a 1.3x bound left 6
+        small hipMalloc calls to 24 fresh scenes of up to 1.28x, the yaml's 250 000 two).  Uses the process's numpy
+        generator state and restores it."""
         import numpy as np
 
         from .. import scene
@@ -343,9 +345,19 @@ class GeoFormer(nn.Module):
         was_training = self.training
         try:
             torch.nn.Module.train(self, False)
-            self(b, epoch, training=False)
-            if dev.type == "cuda":
-                torch.cuda.synchronize(dev)
+            with torch.no_grad():
+                if dev.type == "cuda":
+                    # two scenes of that size back to back, the first one's outputs still alive while the second runs --
+                    # what a serving loop that collects scene i's proposals after issuing scene i+1 holds at its peak
+                    outs = [self(b, epoch, training=False, defer_proposals=True) for _ in range(2)]
+                    for o in outs:
+                        ps = o.get("proposal_scores") if isinstance(o, dict) else None
+                        if ps is not None and hasattr(ps, "get"):
+                            ps.get()
+                    del outs
+                    torch.cuda.synchronize(dev)
+                else:
+                    self(b, epoch, training=False)
         finally:
             np.random.set_state(state)
             if was_training:
