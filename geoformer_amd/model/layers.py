@@ -621,12 +621,19 @@ class TransformerDecoder(nn.Module):
         qp = query_pos.permute(1, 0, 2).contiguous()
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         inter = []
+        # the context side of every layer's cross-attention (K1_l = memory W1_l^T, Kv_l = memory Wv_l^T + bv_l) as ONE
+        # product with the stacked weights: a forward GEMM and a backward pair instead of two each per layer, and the
+        # gradient towards the context features is one product instead of eight accumulated ones
+        d = memory.shape[-1]
+        wk = torch.cat([w for layer in self.layers for w in (layer.attn_mlp[0].weight, layer.v_mlp[0].weight)], 0)
+        bk = torch.cat([b for layer in self.layers for b in (torch.zeros_like(layer.v_mlp[0].bias), layer.v_mlp[0].bias)])
+        kk = _SplitKLinearFn.apply(memory, wk, bk).split(d, dim=-1)  # 2 L pieces [nc, B, d]
         for l, layer in enumerate(self.layers):
             pre, post = pointops.decoder_stage_tensors(layer, self.norm)
             w1, w2, wv = layer.attn_mlp[0], layer.attn_mlp[2], layer.v_mlp[0]
             t2n, q1 = pointops.decoder_pre_train(x, qp, l, p, seed, pre)
-            K1 = _SplitKLinearFn.apply(memory, w1.weight, None).permute(1, 0, 2)
-            Kv = wv(memory).permute(1, 0, 2)
+            K1 = kk[2 * l].permute(1, 0, 2)
+            Kv = kk[2 * l + 1].permute(1, 0, 2)
             ca = pointops.decoder_cross_attn_train(rp.geo_ctx, rp.max_geo, rp.query_locs, rp.context_locs, rp.lo, rp.hi,
                                                    rp.gauss_B, q1, K1, Kv, w1.weight, w2.weight, wv.weight)
             x, it = pointops.decoder_post_train(ca, t2n, l, p, seed, post)
