@@ -93,6 +93,7 @@ def _declare(lib):
         "gf_mask_head_episodes": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P]),
         "gf_mask_head_split_bytes": (c_size_t, [I]),
         "gf_mask_head_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P]),
+        "gf_mask_head_bwd_episodes": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P]),
         "gf_mask_head_bwd_scratch_floats": (c_size_t, [I, I]),
         "gf_softmax_dim1_fwd": (I, [P, I, I, I, F, P, P]),
         "gf_softmax_dim1_bwd": (I, [P, P, I, I, I, F, P, P]),

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_mask_head_bwd_feat(const float* __re
                                                                const float* __restrict__ mx, const float* __restrict__ w1,
                                                                const float* __restrict__ b1, const float* __restrict__ w2,
                                                                const float* __restrict__ gout, int ldp, int N, int nq,
-                                                               int qsplit, float* __restrict__ dfeat) {
+                                                               int qmod, int qsplit, float* __restrict__ dfeat) {
     const int ld_w1 = ldp ? ldp : 16 * 19, ld_v = ldp ? ldp : 16;
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -366,14 +366,15 @@ __global__ __launch_bounds__(256, 2) void k_mask_head_bwd_feat(const float* __re
             ww[s] = w2[(size_t)q * ld_v + 4 * g + s];
         }
         const float w5 = g < 3 ? W[j * 19 + g] : b1[(size_t)q * ld_v + j];
-        const float qcA = g < 3 ? qxyz[q * 3 + g] : 0.f;
-        const float mq = USE_GEO ? mx[q] : 0.f;
+        const int qs = q % qmod;  // the scene-side query of this parameter row (episodes share geo / qxyz / mx)
+        const float qcA = g < 3 ? qxyz[qs * 3 + g] : 0.f;
+        const float mq = USE_GEO ? mx[qs] : 0.f;
         float goA[4], gdA[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int pa = p0 + 16 * t + j;
             goA[t] = pa < N ? gout[(size_t)q * N + pa] : 0.f;
-            gdA[t] = USE_GEO ? geo[(size_t)q * N + min(pa, N - 1)] : 0.f;
+            gdA[t] = USE_GEO ? geo[(size_t)qs * N + min(pa, N - 1)] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 4; t++) {
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void k_mask_head_bwd_param(const float* __r
                                                                 const float* __restrict__ mx, const float* __restrict__ w1,
                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
                                                                 const float* __restrict__ gout, int ldp, int N, int nq,
-                                                                int chunks, float* __restrict__ partial) {
+                                                                int qmod, int chunks, float* __restrict__ partial) {
     const int ld_w1 = ldp ? ldp : 16 * 19, ld_v = ldp ? ldp : 16;
     const int lane = threadIdx.x & 63, g = lane >> 4, j = lane & 15;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -437,9 +438,10 @@ __global__ __launch_bounds__(256, 2) void k_mask_head_bwd_param(const float* __r
         for (int s = 0; s < 4; s++) wf[u][s] = W[j * 19 + 3 + 4 * g + s];
         w5[u] = g < 3 ? W[j * 19 + g] : b1[(size_t)q * ld_v + j];
         w2j[u] = w2[(size_t)q * ld_v + j];
-        qcA[u] = g < 3 ? qxyz[q * 3 + g] : 0.f;
-        qcB[u] = j < 3 ? qxyz[q * 3 + j] : 0.f;
-        mq[u] = USE_GEO ? mx[q] : 0.f;
+        const int qs = q % qmod;
+        qcA[u] = g < 3 ? qxyz[qs * 3 + g] : 0.f;
+        qcB[u] = j < 3 ? qxyz[qs * 3 + j] : 0.f;
+        mq[u] = USE_GEO ? mx[qs] : 0.f;
         accW[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         accWc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         pw2[u] = 0.f;
@@ -460,13 +462,14 @@ __global__ __launch_bounds__(256, 2) void k_mask_head_bwd_param(const float* __r
 #pragma unroll
         for (int u = 0; u < MHB_Q; u++) {
             const int q = min(qg * MHB_Q + u, nq - 1);
-            const float gdA = USE_GEO ? geo[(size_t)q * N + pa] : 0.f;
+            const int qs = q % qmod;
+            const float gdA = USE_GEO ? geo[(size_t)qs * N + pa] : 0.f;
             float goB[4], gdB[4];
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int pb = pt + 4 * g + s;
                 goB[s] = pb < N ? gout[(size_t)q * N + pb] : 0.f;
-                gdB[s] = USE_GEO ? geo[(size_t)q * N + min(pb, N - 1)] : 0.f;
+                gdB[s] = USE_GEO ? geo[(size_t)qs * N + min(pb, N - 1)] : 0.f;
             }
             float rel = qcA[u] - pcA;
             if (USE_GEO) rel = rel + (gdA < 0.f ? mq[u] : 0.f) * (rel > 0.f ? 1.f : (rel < 0.f ? -1.f : 0.f));
@@ -539,10 +542,28 @@ extern "C" size_t gf_mask_head_bwd_scratch_floats(int N, int nq) {
 
 // dparams fp32 [nq, ldp] in the packed column order (w1 | w2 | b1 | b2, ldp >= 337) is OVERWRITTEN; dfeat fp32 [N,16]
 // must be zero on entry when the queries are split (always pass it zeroed); scratch: gf_mask_head_bwd_scratch_floats.
+extern "C" int gf_mask_head_bwd_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                                         const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                                         const float* gout, int ldp, int N, int nq_scene, int E, int C, float* dparams,
+                                         float* dfeat, float* scratch, void* stream);
 extern "C" int gf_mask_head_bwd(const float* feat, const float* coords, const float* geo, const float* qxyz,
                                 const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
                                 const float* gout, int ldp, int N, int nq, int C, float* dparams, float* dfeat,
                                 float* scratch, void* stream) {
+    return gf_mask_head_bwd_episodes(feat, coords, geo, qxyz, sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, 1, C, dparams,
+                                     dfeat, scratch, stream);
+}
+
+// E episodes over one scene (the decoder layers of a training step: same features, coordinates, geodesic rows and
+// query positions, E sets of generated parameters): parameters / gout / dparams have E * nq_scene rows, episode-major;
+// dfeat is the sum over all of them.  scratch: gf_mask_head_bwd_scratch_floats(N, E * nq_scene).
+extern "C" int gf_mask_head_bwd_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                                         const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                                         const float* gout, int ldp, int N, int nq_scene, int E, int C, float* dparams,
+                                         float* dfeat, float* scratch, void* stream) {
+    GF_CHECK_ARG(E >= 1 && nq_scene >= 0 && (long long)nq_scene * E < (1ll << 30), "gf_mask_head_bwd: %d episodes x %d queries",
+                 E, nq_scene);
+    const int nq = nq_scene * E, qmod = nq_scene > 0 ? nq_scene : 1;
     GF_CHECK_ARG(ldp >= 337, "gf_mask_head_bwd: packed parameters expected (row stride >= 337), got %d", ldp);
     GF_CHECK_ARG(C == 16, "gf_mask_head_bwd: only the 16-channel mask head (m=16) is implemented, got C=%d", C);
     GF_CHECK_ARG(N >= 0 && nq >= 0, "gf_mask_head_bwd: bad sizes");
@@ -561,10 +582,10 @@ extern "C" int gf_mask_head_bwd(const float* feat, const float* coords, const fl
         dim3 grid((unsigned)((waves + 3) / 4));
         if (geo)
             GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_FEAT, (k_mask_head_bwd_feat<true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz,
-                         sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
+                         sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qmod, qsplit, dfeat);
         else
             GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_FEAT, (k_mask_head_bwd_feat<false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz,
-                         sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qsplit, dfeat);
+                         sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qmod, qsplit, dfeat);
     }
     // parameter gradients: (query group, point chunk) per wave
     const int qgroups = (nq + MHB_Q - 1) / MHB_Q;
@@ -578,10 +599,10 @@ extern "C" int gf_mask_head_bwd(const float* feat, const float* coords, const fl
         dim3 grid((unsigned)((waves + 3) / 4));
         if (geo)
             GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_PARAM, (k_mask_head_bwd_param<true>), grid, dim3(256), 0, st, feat, coords, geo,
-                         qxyz, sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
+                         qxyz, sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qmod, chunks, scratch);
         else
             GF_LAUNCH_OP(GF_OP_MASK_HEAD_BWD_PARAM, (k_mask_head_bwd_param<false>), grid, dim3(256), 0, st, feat, coords, geo,
-                         qxyz, sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, chunks, scratch);
+                         qxyz, sqrt_max_geo, w1, b1, w2, gout, ldp, N, nq, qmod, chunks, scratch);
     }
     hipLaunchKernelGGL(k_mask_head_bwd_reduce, dim3(gf_div_up((long long)nq * 337, 256)), dim3(256), 0, st, scratch, chunks,
                        nq, ldp, dparams);

@@ -899,7 +899,7 @@ class GeoFormer(nn.Module):
         # mask features less per batch-4 step
         fused_train = (mask_features.is_cuda and torch.is_grad_enabled() and self.output_dim == 16 and self.use_coords
                        and os.environ.get("GF_FUSED_BWD", "1") != "0")
-        per_scene = {}
+        per_scene, train_ctrl = {}, {}
         if fused_train:
             for b in range(batch):
                 s, e = offs[b], offs[b + 1]
@@ -940,18 +940,23 @@ class GeoFormer(nn.Module):
                     ml = self._mask_head_packed(geo_dists[b], mask_features[s:e], controllers[b], n_queries,
                                                 locs_float_[s:e], fps_sampling_locs[b])
                 elif fused_train:
-                    # training: the same fused kernel forward, and a fused recompute-based backward for the mask
-                    # features and the generated parameters (csrc/mask_head.hip k_mask_head_bwd) instead of PyTorch
-                    # autograd over [nq, N, 16] intermediates
-                    mf_b, locs_b, g, fps_b, mx = per_scene[b]
-                    ml = pointops.mask_head_train(mf_b, ctrl[b].contiguous(), locs_b, g, fps_b, mx)
-                    ml = ml.reshape(1, n_queries, e - s)
+                    # training: the mask head runs after this loop, once per scene for ALL layers (episodes of
+                    # gf_mask_head_episodes / gf_mask_head_bwd_episodes): one forward launch and one backward triple per
+                    # scene instead of one per (layer, scene), the features' gradient summed inside the kernel
+                    train_ctrl.setdefault(b, []).append(ctrl[b])
+                    mask_logits_list.append(None)
+                    continue
                 else:
                     weights, biases = self.parse_dynamic_params(controllers[b], self.output_dim)
                     ml = self.mask_heads_forward(geo_dists[b], mask_features[s:e], weights, biases, n_queries,
                                                  locs_float_[s:e], fps_sampling_locs[b], use_geo=self.use_coords)
                 mask_logits_list.append(ml.squeeze(0))
             outputs.append({"cls_logits": cls_logits, "mask_logits": mask_logits_list})
+        for b, ctrls in train_ctrl.items():
+            mf_b, locs_b, g, fps_b, mx = per_scene[b]
+            logits = pointops.mask_head_train_episodes(mf_b, torch.stack(ctrls), locs_b, g, fps_b, mx)  # [L, nq, N_b]
+            for l, ml in enumerate(logits.unbind(0)):
+                outputs[l]["mask_logits"][b] = ml
         return outputs
 
     def generate_proposal(self, mask_logits, cls_logits, fg_idxs, batch_offsets, batch_offsets_,

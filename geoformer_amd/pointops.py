@@ -364,6 +364,39 @@ class _MaskHeadFn(torch.autograd.Function):
         return dfeat, dparams, None, None, None, None
 
 
+class _MaskHeadEpisodesFn(torch.autograd.Function):
+    """E parameter sets over one scene (the decoder layers of a training step): one forward launch and one backward
+    triple for all of them; the features' gradient is summed over the episodes inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, feat, params, coords, geo, qxyz, sqrt_max_geo):
+        ctx.save_for_backward(feat, params, coords, geo, qxyz, sqrt_max_geo)
+        return mask_head_episodes(feat, coords, geo, qxyz, sqrt_max_geo, params)
+
+    @staticmethod
+    def backward(ctx, gout):
+        feat, params, coords, geo, qxyz, mx = ctx.saved_tensors
+        N, C = feat.shape
+        E, nq, ld = params.shape
+        lib = _lib.load()
+        dparams = torch.empty_like(params)
+        dfeat = torch.zeros_like(feat)
+        scratch = torch.empty(lib.gf_mask_head_bwd_scratch_floats(N, E * nq), dtype=torch.float32, device=feat.device)
+        base = params.data_ptr()
+        o_w2, o_b1 = C * (C + 3), C * (C + 3) + C
+        check(lib.gf_mask_head_bwd_episodes(ptr(feat), ptr(coords), ptr(geo), ptr(qxyz), ptr(mx), base, base + 4 * o_b1,
+                                            base + 4 * o_w2, ptr(gout.contiguous()), ld, N, nq, E, C, ptr(dparams),
+                                            ptr(dfeat), ptr(scratch), stream_ptr()), "gf_mask_head_bwd_episodes")
+        return dfeat, dparams, None, None, None, None
+
+
+def mask_head_train_episodes(feat, params, coords, geo, qxyz, sqrt_max_geo):
+    """logits [E,nq,N] with autograd through feat [N,16] and params [E,nq,337]."""
+    for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (params, "params")):
+        _f32c(t, name)
+    return _MaskHeadEpisodesFn.apply(feat, params, coords, geo, qxyz, sqrt_max_geo)
+
+
 def mask_head_train(feat, params, coords, geo, qxyz, sqrt_max_geo):
     """logits [nq,N] with autograd through feat [N,16] and params [nq,337] (fused forward AND backward)."""
     for t, name in ((feat, "feat"), (coords, "coords"), (qxyz, "qxyz"), (params, "params")):

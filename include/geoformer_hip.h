@@ -468,6 +468,14 @@ size_t gf_mask_head_bwd_scratch_floats(int N, int nq);
 int gf_mask_head_bwd(const float* feat, const float* coords, const float* geo, const float* qxyz,
                      const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2, const float* gout,
                      int ldp, int N, int nq, int C, float* dparams, float* dfeat, float* scratch, void* stream);
+/* The same for E episodes over one scene (the decoder layers of a training step, geoformer.py:286-324 once per layer:
+ * same features / coordinates / geodesic rows / query positions, E sets of generated parameters): parameters, gout and
+ * dparams have E * nq rows, episode-major; dfeat is the sum over all of them; scratch:
+ * gf_mask_head_bwd_scratch_floats(N, E * nq). */
+int gf_mask_head_bwd_episodes(const float* feat, const float* coords, const float* geo, const float* qxyz,
+                              const float* sqrt_max_geo, const float* w1, const float* b1, const float* w2,
+                              const float* gout, int ldp, int N, int nq, int E, int C, float* dparams, float* dfeat,
+                              float* scratch, void* stream);
 
 /* ===================================================================================
  * Per-point MLP chains of the eval forward, fused: mask_tower (geoformer.py:64-71), semantic head

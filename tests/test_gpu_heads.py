@@ -469,6 +469,41 @@ def test_mask_head_fused_backward(hip, N, nq, use_geo):
     assert np.abs(gp - rp).max() < 2e-5 * max(1.0, np.abs(rp).max()), (np.abs(gp - rp).max(), np.abs(rp).max())
 
 
+@pytest.mark.parametrize("N,nq,E,use_geo", [(5037, 24, 4, True), (140_000, 3, 2, True), (3000, 16, 3, False)])
+def test_mask_head_episodes_backward_equals_the_sum_of_single_calls(hip, N, nq, E, use_geo):
+    """gf_mask_head_bwd_episodes (the decoder layers of a training step as E parameter sets over one scene: one launch
+    triple, the feature gradient summed inside the kernel) against E calls of gf_mask_head_bwd, which the test above pins
+    to float64: logits and parameter gradients per episode, feature gradient = the sum over the episodes."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(N + 13 * nq + E)
+    d = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    feat = d(rng.standard_normal((N, 16)).astype(np.float32))
+    coords_np = rng.uniform(-3, 3, (N, 3)).astype(np.float32)
+    coords = d(coords_np)
+    qxyz = d(coords_np[rng.integers(0, N, nq)].copy())
+    geo = mx = None
+    if use_geo:
+        g = rng.uniform(0, 5, (nq, N)).astype(np.float32)
+        g[rng.uniform(size=g.shape) < 0.3] = -1.0
+        m = g.max(1)
+        geo, mx = d(g), d(np.sqrt(np.where(m < 0, m.max(), m)).astype(np.float32))
+    params = d((rng.standard_normal((E, nq, 337)) * 0.3).astype(np.float32))
+    gout = d((rng.standard_normal((E, nq, N)) * (rng.uniform(size=(E, nq, N)) < 0.5)).astype(np.float32))
+    f, p = feat.clone().requires_grad_(), params.clone().requires_grad_()
+    out = pointops.mask_head_train_episodes(f, p, coords, geo, qxyz, mx)
+    (out * gout).sum().backward()
+    ref_f = torch.zeros_like(feat, dtype=torch.float64)
+    for e in range(E):
+        f1, p1 = feat.clone().requires_grad_(), params[e].clone().requires_grad_()
+        o1 = pointops.mask_head_train(f1, p1, coords, geo, qxyz, mx)
+        (o1 * gout[e]).sum().backward()
+        assert torch.equal(out[e], o1)
+        assert (p.grad[e] - p1.grad).abs().max().item() <= 1e-5 * max(1.0, p1.grad.abs().max().item())
+        ref_f += f1.grad.double()
+    assert (f.grad.double() - ref_f).abs().max().item() <= 2e-5 * max(1.0, ref_f.abs().max().item())
+
+
 @pytest.mark.parametrize("B,nq,nc", [(2, 24, 100), (1, 7, 16), (3, 40, 333)])
 def test_decoder_cross_attention_fused_backward(hip, B, nq, nc):
     """gf_decoder_cross_attn_bwd (recompute-based, MFMA) against float64 autograd of the formulation of
