@@ -533,7 +533,9 @@ __global__ __launch_bounds__(BFS_THREADS) void k_geodesic_bfs(const float* __res
 // (parent<<6|rank, distance) -> barrier -> one load of the winning pair -> store.  The 64-bit minimum
 // orders by (parent, rank) first, so the distance that rides in the low word is the winner's.
 #define BFS_LDS_MAX_N (1 << 19)
+#ifndef BFS_LDS_BYTES
 #define BFS_LDS_BYTES (150 * 1024)
+#endif
 // workgroup barrier that orders LDS traffic only: global stores (the distances, never read back by this kernel) and
 // loads requested ahead of their use stay in flight across it -- __syncthreads() waits for every one (vmcnt(0))
 __device__ __forceinline__ void bfs_lds_barrier() {
