@@ -1872,7 +1872,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(const float* __restrict__ in
 // now is L2 bandwidth: a wave per (offset, 16 x 16 tile pair, slice) reads 2 KB per (group, offset) pair -- 700 MB per
 // tile pair, 7.7 TB/s at 91 us -- because the gradient rows are read again for every offset and both operands again
 // for every tile pair; one wave per slice for all tile pairs (and several offsets, one accumulator each) would read
-// 1.8x (16 -> 16) to 3.6x (32 -> 32) less.  Not built yet.
+// 1.8x (16 -> 16) to 3.6x (32 -> 32) less.  Built in round 4 (a wave per (slice, block of 9 offsets, 16 input channels)
+// with 9 x NCO accumulators: the gradient rows loaded once per group visit, per present offset only the input tile
+// gathered; loads for all nine offsets issued unconditionally so that the waits stay counted ones) and 2x SLOWER at
+// every shape (193 / 287 / 555 / 997 us): with the closing atomics compiled out this kernel loses 1-3 %, and with 1.6-2.6x
+// less traffic the other one loses a factor of two -- it is the number of vector-memory INSTRUCTIONS per useful (group,
+// offset) pair that binds (3 here; 4.6-5.6 there because the absent offsets' index and gather instructions are still
+// issued), the limit the first paragraph above names, not L2 bandwidth.  A form that wins would have to issue loads for
+// present offsets only without giving up the counted waits of the software pipeline.  Not in the tree.
 #ifndef WGT_ROWS
 #define WGT_ROWS 1024  // rows per slice: more, shorter waves beat fewer, longer ones (2048: +80 %, 4096: +180 %)
 #endif
