@@ -86,3 +86,45 @@ def test_legacy_choice_sequence(lib):
         np.random.choice(5, 6, replace=False)
     with pytest.raises(ValueError):
         pointops.legacy_choice(5, 6)
+
+
+def test_dropout_keep_reference_is_the_hash_the_header_states():
+    """pointops.dropout_keep_reference (what the GPU tests feed to the float64 references of the training transformer
+    kernels) against a scalar transcription of the rule in include/geoformer_hip.h: kept iff (h >> 8) >= (uint32)(p 2^24),
+    h = fmix32(fmix32(seed ^ (row * 64 + site)) + col * 0x9E3779B1), fmix32 = MurmurHash3's finaliser."""
+    import numpy as np
+    import torch
+
+    from geoformer_amd import pointops
+
+    M = 0xFFFFFFFF
+
+    def fmix(x):
+        x ^= x >> 16
+        x = (x * 0x85EBCA6B) & M
+        x ^= x >> 13
+        x = (x * 0xC2B2AE35) & M
+        return x ^ (x >> 16)
+
+    def keep(seed, p, site, row, col):
+        h = fmix((seed & M) ^ ((row * 64 + site) & M))
+        h = fmix((h + ((col * 0x9E3779B1) & M)) & M)
+        return (h >> 8) >= int(float(p) * 16777216.0)
+
+    # MurmurHash3 fmix32 known answers (h = 1, 0xdeadbeef)
+    assert fmix(1) == 0x514E28B7 and fmix(0) == 0
+    rng = np.random.default_rng(3)
+    for seed, p, site in ((1234567, 0.1, 0), (2 ** 31 - 2, 0.1, 13), (42, 0.5, 7)):
+        rows = torch.from_numpy(rng.integers(0, 1 << 20, (5, 1)))
+        cols = torch.from_numpy(rng.integers(0, 1 << 12, (1, 7)))
+        got = pointops.dropout_keep_reference(seed, p, site, rows.expand(5, 7), cols.expand(5, 7))
+        for i in range(5):
+            for j in range(7):
+                k = keep(seed, p, site, int(rows[i, 0]), int(cols[0, j]))
+                assert (float(got[i, j]) != 0.0) == k
+                if k:
+                    assert abs(float(got[i, j]) - 1.0 / (1.0 - p)) < 1e-6
+    big = pointops.dropout_keep_reference(7, 0.1, 3, torch.arange(4096).view(-1, 1).expand(4096, 64),
+                                          torch.arange(64).view(1, -1).expand(4096, 64))
+    assert abs(float((big == 0).float().mean()) - 0.1) < 0.005
+    assert float(pointops.dropout_keep_reference(7, 0.0, 3, torch.arange(8), torch.arange(8)).min()) == 1.0
