@@ -140,6 +140,27 @@ class FSInstSetCriterion(nn.Module):
             loss = loss + loss_dict[k]
         return loss, loss_dict
 
+    def _all_layer_losses_device(self, preds, matches):
+        """The dice + focal terms of ALL decoder layers at once (the same sums as _layer_loss_device per layer, in a
+        different order): per (layer, scene) only the fused pair-loss call remains, the scalar chains around it are one
+        stack and one reduction (InstSetCriterion._all_layer_losses_device)."""
+        from .criterion import _PairLossFn, _fused_pair_loss
+
+        L = len(preds)
+        live = [b for b in range(self.batch_size) if matches[b] is not None]
+        if not live or not _fused_pair_loss() or any(w != 1 for w in self.loss_weight.values()):
+            return None
+        if set(self.loss_weight) != {"dice_loss", "focal_loss"}:
+            return None
+        for l in range(L):
+            for b in live:
+                ml = preds[l]["mask_logits"][b]
+                if ml is None or not ml.is_cuda or ml.dtype != torch.float32:
+                    return None
+        pair = torch.stack([_PairLossFn.apply(preds[l]["mask_logits"][b], matches[b]) for l in range(L) for b in live])
+        terms = pair.view(L, len(live), 2).sum(1) / self.batch_size  # [L, 2]: dice, focal
+        return terms.sum(1), {"dice_loss": terms[-1, 0], "focal_loss": terms[-1, 1]}
+
     def _forward_device(self, model_outputs, batch_inputs, epoch):
         cfg = self.cfg
         preds, fg_idxs = model_outputs["mask_predictions"], model_outputs["fg_idxs"]
@@ -168,10 +189,15 @@ class FSInstSetCriterion(nn.Module):
                                                               fewshot=True))
             s += n_b
         self.device_matches = matches
-        main, ld = self._layer_loss_device(preds[-1], matches)
-        loss = loss + main
-        for l in range(cfg.dec_nlayers - 1):
-            loss = loss + self._layer_loss_device(preds[l], matches)[0]
+        batched = self._all_layer_losses_device(preds, matches)
+        if batched is not None:
+            per_layer, ld = batched
+            loss = loss + per_layer.sum()
+        else:
+            main, ld = self._layer_loss_device(preds[-1], matches)
+            loss = loss + main
+            for l in range(cfg.dec_nlayers - 1):
+                loss = loss + self._layer_loss_device(preds[l], matches)[0]
         live = [m for m in matches if m is not None]
         num_gt = torch.cat([m.n_match for m in live]).sum().float()
         status = torch.cat([m.status for m in live]).amax().float()
