@@ -21,7 +21,8 @@ from torch.nn import functional as F
 from .. import pointops, spconv, unet_exec, unet_train
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
-from .layers import (BatchNorm1d, BigLinear, GenericMLP, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec, TransformerDecoder,
+from .layers import (BatchNorm1d, BigLinear, GenericMLP, LazyRelPos, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec,
+                     TransformerDecoder,
                      TransformerDecoderLayer, scene_counts)
 from .set_abstraction import PointnetSAModuleVotesSeparate
 
@@ -808,8 +809,12 @@ class GeoFormer(nn.Module):
             qpr = self._pointwise_chain("qproj", [self.query_projection], context_feats)
             if e2d is not None and qpr is not None:
                 ctx = pointops.pointwise_mlp(context_feats[0].contiguous(), e2d)  # [nc, dec_dim]
-                rel = self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists, pre_enc_inds)
-                hit = self._early().pop("qpos", None)  # computed beside the BFS (joined above)
+                # (built by the decoder after its first token stage is queued: the join with the BFS stream sits there)
+                rel = LazyRelPos(lambda: self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists,
+                                                                          pre_enc_inds))
+                if os.environ.get("GF_LAZY_RELPOS", "1") == "0":  # dev knob: the join in front of the decoder's first stage
+                    rel = rel.get()
+                hit = self._early().pop("qpos", None)  # computed beside the BFS on the third stream (own event)
                 if hit is not None and hit[0].shape == query_locs.shape:
                     torch.cuda.current_stream().wait_event(hit[2])
                     qpos = hit[1]

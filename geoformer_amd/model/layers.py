@@ -451,6 +451,20 @@ class RelPosSpec:
         self.lo, self.hi, self.gauss_B = lo, hi, gauss_B
 
 
+class LazyRelPos:
+    """A RelPosSpec that is built on first use: the fused inference decoder asks for it only after its first token
+    stage and its context-side product are queued, so those launches do not wait for the geodesic search (building the
+    spec joins the stream the search runs on)."""
+
+    def __init__(self, fn):
+        self.fn, self.value = fn, None
+
+    def get(self):
+        if self.value is None:
+            self.value = self.fn()
+        return self.value
+
+
 class TransformerDecoderLayer(nn.Module):
     def __init__(self, d_model, nhead=4, dim_feedforward=256, dropout=0.1, dropout_attn=None, activation="relu",
                  normalize_before=True, use_rel=False, norm_fn_name="ln"):
@@ -590,6 +604,8 @@ class TransformerDecoder(nn.Module):
         q1 = torch.empty((B, nq, d), dtype=torch.float32, device=tgt.device)
         tgt_c, qp = tgt.contiguous(), query_pos.contiguous()
         pointops.decoder_token_stage(None, tgt_c, qp, nq, B, 4, ff, None, c["tables"][0][1], state, None, q1)
+        if isinstance(rp, LazyRelPos):  # (everything above needs no geodesic distance)
+            rp = rp.get()
         for l in range(L):
             attn = pointops.decoder_cross_attn(rp.geo_ctx, rp.max_geo, rp.query_locs, rp.context_locs, rp.lo, rp.hi,
                                                rp.gauss_B, q1, kk[2 * l].view(B, nc, d), kk[2 * l + 1].view(B, nc, d),
@@ -643,12 +659,16 @@ class TransformerDecoder(nn.Module):
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None, relative_pos=None, transpose_swap=False,
                 return_attn_weights=False):
-        shapes_ok = (isinstance(relative_pos, RelPosSpec) and tgt_mask is None and tgt_key_padding_mask is None
+        if isinstance(relative_pos, LazyRelPos) and (torch.is_grad_enabled() or self.layers[0].self_attn.training):
+            relative_pos = relative_pos.get()
+        shapes_ok = (isinstance(relative_pos, (RelPosSpec, LazyRelPos)) and tgt_mask is None and tgt_key_padding_mask is None
                      and query_pos is not None and self.norm is not None and self.return_intermediate
                      and tgt.shape[-1] == 64 and self.layers[0].nhead == 4
                      and self.layers[0].linear1.out_features % 16 == 0 and self.layers[0].linear1.out_features <= 256)
         if shapes_ok and not self.layers[0].self_attn.training and not torch.is_grad_enabled():
             return self._forward_fused(tgt, memory, query_pos, relative_pos)
+        if isinstance(relative_pos, LazyRelPos):
+            relative_pos = relative_pos.get()
         if (shapes_ok and torch.is_grad_enabled() and tgt.is_cuda and tgt.dtype == torch.float32
                 and os.environ.get("GF_FUSED_DECODER_TRAIN", "1") != "0"):
             p = self._train_fused_dropout()
