@@ -54,6 +54,12 @@ void gf_set_error(const char* fmt, ...);
 int gf_rules_down2_chain_range(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels, int l_begin,
                                int l_end, int32_t* ws, int32_t* counts, hipStream_t st);
 
+// exclusive int32 scan (geodesic.hip): start[0..n] (start[n] = total), cursor[0..n) = start; block_sums and block_off
+// hold gf_iscan_blocks(n) words each
+int gf_iscan_blocks(int n);
+void gf_iscan(const int32_t* v, int n, int32_t* start, int32_t* cursor, int32_t* block_sums, int32_t* block_off,
+              hipStream_t st);
+
 static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- a chain of small sparse convolutions in one persistent launch (spconv_conv.hip: k_conv_chain; used by

@@ -113,6 +113,17 @@ __global__ void k_grid_fill(const float* __restrict__ xyz, int n, float inv_cell
     sorted[pos] = make_float4(x, y, z, __int_as_float(i));
 }
 
+// exclusive scan of v[0..n) -> start[0..n] (start[n] = total) and cursor = start; block_sums / block_off: gf_iscan_blocks(n)
+// words each.  Three launches.  (common.h; also used by geodesic_ms.hip)
+int gf_iscan_blocks(int n) { return (n + ISCAN_IPB - 1) / ISCAN_IPB; }
+void gf_iscan(const int32_t* v, int n, int32_t* start, int32_t* cursor, int32_t* block_sums, int32_t* block_off,
+              hipStream_t st) {
+    const int nb = gf_iscan_blocks(n);
+    hipLaunchKernelGGL(k_iscan_block_sums, dim3(nb), dim3(SCAN_THREADS), 0, st, v, n, block_sums);
+    hipLaunchKernelGGL(k_iscan_top, dim3(1), dim3(SCAN_THREADS), 0, st, block_sums, nb, block_off);
+    hipLaunchKernelGGL(k_iscan_apply, dim3(nb), dim3(SCAN_THREADS), 0, st, v, n, block_off, start, cursor);
+}
+
 #define KNN_WAVES 4
 #define KNN_CAP 1024  // in-radius candidates per query point held in LDS
 __global__ __launch_bounds__(KNN_WAVES * 64) void k_knn_radius(const float* __restrict__ xyz, int n, int k,

@@ -290,6 +290,25 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     return geo
 
 
+def geodesic_bfs_ms(D, I, src, radius, max_step):
+    """geo [nq,n] fp32 like geodesic_bfs, by the multi-source search (csrc/geodesic_ms.hip: every query a bit lane, one
+    launch per hop over the whole device; bit-identical results)."""
+    _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
+    n, K = D.shape
+    nq = src.shape[0]
+    dev = D.device
+    geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
+    if nq == 0 or n == 0:
+        return geo
+    lib = _lib.load()
+    nbytes = int(lib.gf_geodesic_ms_scratch_bytes(n, K, nq, int(max_step)))
+    ws = scratch("bfs_ms", nbytes // 8 + 64, torch.int64, dev)
+    base = (ws.data_ptr() + 255) & ~255
+    check(lib.gf_geodesic_bfs_ms(ptr(D), ptr(I), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), base,
+                                 nbytes, stream_ptr()), "gf_geodesic_bfs_ms")
+    return geo
+
+
 # ---- fused heads -------------------------------------------------------------------------
 def _mask_head_split_ws(N, device, split):
     """Scratch for the features' three bf16 pieces (gf_mask_head_episodes: fp32-accurate products on the bf16 matrix

@@ -427,6 +427,16 @@ int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, in
                         float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, int wg_threads,
                         void* stream);
 
+/* The same search for ALL nq sources at once (csrc/geodesic_ms.hip): the queries are bit lanes of per-vertex frontier /
+ * visited masks, a hop is ONE launch over every (vertex, mask word) that walks the vertex's in-neighbours in ascending
+ * (parent, rank) order -- the first one whose frontier bit is set is the entry cal_geodesic_vectorize keeps
+ * (geodesic_utils.py:131-136) -- so results are bit-identical to gf_geodesic_bfs; rows need not be sorted by distance.
+ *   D fp32 [n,K], I int32 [n,K] (column 0 skipped), src int32 [nq], geo fp32 [nq,n] out
+ *   scratch: gf_geodesic_ms_scratch_bytes(n, K, nq, max_step) bytes, 256-byte aligned; scratch_bytes is checked. */
+size_t gf_geodesic_ms_scratch_bytes(int n, int K, int nq, int max_step);
+int gf_geodesic_bfs_ms(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
+                       int max_step, float* geo, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ===================================================================================
  * Mask head (GeoFormer.mask_heads_forward, model/geoformer/geoformer.py:286-324), fused
  * =================================================================================== */
