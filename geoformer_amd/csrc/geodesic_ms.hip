@@ -7,27 +7,39 @@
 // hop's frontier of q that lists u inside the radius, then its lowest rank r; geo[q][u] = geo[q][v] + D[v][r].
 // The per-query kernels of geodesic.hip walk each query's frontier top-down and resolve that minimum with one 8-byte
 // atomicMin per edge and query (4 GB of scattered traffic for 0.24 GB of algorithmic bytes, 1 workgroup per query
-// walking <= 256 hops of ~5 us).  Here the search is turned around (bottom-up) and the queries are bit lanes:
+// walking <= 256 hops of ~4 us).  Here the search is turned around (bottom-up) and the queries are bit lanes:
 //
-//   F[h][u]   W = ceil(nq/32) words: bit q set iff u is in query q's frontier of hop h
-//   vis[u]    W words: bit q set iff geo[q][u] is assigned
+//   R[h][u]   ceil(nq/64) 64-bit words: bit q set iff query q has reached u within h hops (cumulative)
 //   in-list   of u: every (v, r) with I[v][r] = u, r >= 1, D[v][r] <= radius, sorted by (v, r) -- a reverse CSR of the
-//             kNN graph, built once per scene (count / scan / fill / rank-sort), the edge length stored beside it
-//   hop h     one thread per (u, word w): walk u's in-list in order; new = F[h-1][v].w & open; every new bit q gets
-//             dist[u][q] = dist[v][q] + edge and closes; F[h][u].w = all bits taken, vis[u].w |= taken
+//             kNN graph, built once per scene (count / scan / fill / rank-sort), the edge length stored beside it; the
+//             first 16 entries also as fixed-width rows (parent ids and edge lengths), padded with the id n, whose
+//             mask row is all zero
+//   hop h     one thread per (u, word): R[h][u] = R[h-1][u] | OR of the parents' R[h-1] words.  A bit that a parent has
+//             and u has not is NEW, and that parent reached it exactly in hop h-1 (had it been earlier, u would have it
+//             by now): so "the first in-neighbour, ascending (v, r), that has the bit" is exactly the entry the
+//             reference keeps, and dist[u][q] = dist[v][q] + edge for it.  No frontier and no visited array: one
+//             cumulative mask, double-buffered.
 //
-// "First in-neighbour in ascending (v, r) whose frontier bit is set" is exactly the entry the reference keeps, so the
-// distances are the same fp32 sums along the same parent chains: bit-identical (tests/test_gpu_geodesic.py against
-// the oracle, which the reference's own Python pins).  Every graph row is fetched once per hop for ALL queries, no
-// atomics on the data path, and a hop is n*W independent threads (480 000 for the eval forward) instead of 256
-// workgroups in lockstep with their own rings.  Distances are kept vertex-major ([n][32 W]: a vertex's words sit in
-// one line next to its masks' order) during the search and transposed to the caller's [nq][n] at the end, where the
-// unreached entries get their -1 from the vis masks -- no 61 MB fill before the search.
+// The distances are the same fp32 sums along the same parent chains: bit-identical (tests/test_gpu_geodesic.py against
+// the oracle, which the reference's own Python pins).  Every graph row is fetched once per hop for ALL queries, there
+// is no atomic on the data path, and a hop is n * ceil(nq/64) independent threads.  Distances are kept vertex-major
+// ([n][64 W]) during the search and transposed to the caller's [nq][n] at the end, where the unreached entries get
+// their -1 from the masks -- no 61 MB fill before the search.
+//
+// What a hop costs (profiles/r5_bfs_ms_notes.md): 1.5 us of launch boundary + the kernel; the kernel was first bound by
+// VALU issue, not by memory (L1-miss latency 360 cycles by TCP_TCC_READ_REQ_LATENCY, 1.36 M vector instructions per hop:
+// 16 unrolled parent slots x 8 word lanes per vertex of address arithmetic and select chains).  Hence: 64-bit words
+// (half the lanes), 32-bit offsets from uniform bases, the plain OR as the common path, and the search for the
+// contributing parent only in lanes that took a bit.
+#include <cstdlib>
 #include "common.h"
 
 #define MS_THREADS 256
 #define MS_ELL 16          // in-neighbours per vertex kept in fixed-width rows (the rest, rare, is read from the CSR)
-#define MS_FLAG_SHARDS 64  // "this hop reached something" flag, sharded so the stores of a hop do not queue on one word
+// Is the search over?  No hop sets a flag (7 500 waves storing into a few words is a hot spot of its own); a small
+// kernel compares the two mask buffers every MS_CHECK_EVERY hops and leaves `alive` at zero when they are equal: the
+// hops behind it return at once.
+#define MS_CHECK_EVERY 16
 
 // ------------------------------------------------------------------------------------
 // reverse CSR
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_sort(const int32_t* __restric
             ell_v[(size_t)g * MS_ELL + rank] = k0 >> 6;
             ell_d[(size_t)g * MS_ELL + rank] = d0;
         } else if (live) {
-            ell_v[(size_t)g * MS_ELL + l] = 0xffffffffu;  // (l >= d: the padding)
+            ell_v[(size_t)g * MS_ELL + l] = (uint32_t)n;  // (l >= d: the padding: the id whose mask row is zero)
             ell_d[(size_t)g * MS_ELL + l] = 0.f;
         }
         return;
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_sort(const int32_t* __restric
             ell_v[(size_t)g * MS_ELL + rank] = k0 >> 6;
             ell_d[(size_t)g * MS_ELL + rank] = d0;
         } else if (live) {
-            ell_v[(size_t)g * MS_ELL + l] = 0xffffffffu;
+            ell_v[(size_t)g * MS_ELL + l] = (uint32_t)n;
             ell_d[(size_t)g * MS_ELL + l] = 0.f;
         }
         return;
@@ -123,276 +135,420 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_sort(const int32_t* __restric
 // ------------------------------------------------------------------------------------
 // the search
 // ------------------------------------------------------------------------------------
-// hop 0: F[0][u].w = the queries whose source is u; vis = the same (+ the bits beyond nq, so that a finished word
-// reads "nothing open"); dist[src[q]][q] = 0
+typedef unsigned long long ms_word;
+
+// hop 0: R[0][u] = the queries whose source is u (+ the bits beyond nq, which then never read as new);
+// dist[src[q]][q] = 0; row n (the padding parent) stays zero in both buffers
 __global__ __launch_bounds__(MS_THREADS) void k_ms_init(const int32_t* __restrict__ src, int nq, int n, int W, int S,
-                                                        uint32_t* __restrict__ F0, uint32_t* __restrict__ vis,
+                                                        ms_word* __restrict__ R0, ms_word* __restrict__ R1,
                                                         float* __restrict__ dist_t) {
     const int t = blockIdx.x * MS_THREADS + threadIdx.x;
+    if (t >= (n + 1) * W) return;
     const int u = t / W, w = t - u * W;
-    uint32_t bits = 0;
-    const int q0 = w * 32;
-    if (t < n * W) {
-        for (int b = 0; b < 32; b++) {
+    ms_word bits = 0;
+    if (u < n) {
+        const int q0 = w * 64;
+        for (int b = 0; b < 64; b++) {
             const int q = q0 + b;
             if (q < nq && src[q] == u) {
-                bits |= 1u << b;
+                bits |= 1ull << b;
                 dist_t[(size_t)u * S + q] = 0.0f;
             }
         }
-        const int rem = nq - q0;  // >= 1: W = ceil(nq / 32)
-        const uint32_t invalid = rem >= 32 ? 0u : ~((1u << rem) - 1u);
-        F0[t] = bits;
-        vis[t] = bits | invalid;
+        const int rem = nq - q0;  // >= 1: W = ceil(nq / 64)
+        if (rem < 64) bits |= ~((1ull << rem) - 1ull);
     }
+    R0[t] = bits;
+    if (u == n) R1[t] = 0;
 }
 
-template <int WC>  // WC > 0: W known at compile time
-__global__ __launch_bounds__(MS_THREADS) void k_ms_hop(const int32_t* __restrict__ rstart,
+// One hop.  Thread t = (vertex u, 64-bit word w).  W64 > 0: words per vertex known at compile time.
+template <int W64>
+__global__ __launch_bounds__(MS_THREADS) void k_ms_hop(const uint32_t* __restrict__ ell_v,
+                                                       const float* __restrict__ ell_d,
+                                                       const int32_t* __restrict__ rstart,
                                                        const uint32_t* __restrict__ rkey,
                                                        const float* __restrict__ rdist,
-                                                       const uint32_t* __restrict__ Fcur, uint32_t* __restrict__ Fnext,
-                                                       uint32_t* __restrict__ vis, float* __restrict__ dist_t, int n,
-                                                       int Wrt, int S, const int32_t* __restrict__ flag_prev,
-                                                       int32_t* __restrict__ flag_cur) {
-    const int W = WC > 0 ? WC : Wrt;
-    if (flag_prev) {  // the previous hop reached nothing: the search is over (uniform over the launch)
-        const int f = flag_prev[threadIdx.x & (MS_FLAG_SHARDS - 1)];
-        if (!__any(f != 0)) return;
-    }
+                                                       const ms_word* __restrict__ Rcur, ms_word* __restrict__ Rnext,
+                                                       float* __restrict__ dist_t, int n, int Wrt,
+                                                       const int32_t* __restrict__ alive
+#ifdef MS_TRACE
+                                                       , unsigned long long* __restrict__ trace
+#endif
+                                                       ) {
+#ifdef MS_TRACE
+#define MS_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (trace && (threadIdx.x & 63) == 0) trace[(size_t)(blockIdx.x * (MS_THREADS / 64) + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MS_STAMP(i) do {} while (0)
+#endif
+    MS_STAMP(0);
+    if (alive && *alive == 0) return;  // an earlier k_ms_check found the last hop empty: the search is over
+    const uint32_t W = W64 > 0 ? (uint32_t)W64 : (uint32_t)Wrt;
+    const uint32_t S = W * 64u;
     // blocks b, b + 8, b + 16, ... share an XCD (and its L2): give each XCD one contiguous range of vertices, whose
     // in-neighbours are mostly its own, instead of every eighth block of the whole scene (speed only)
-    const int per_xcd = gridDim.x >> 3;
-    const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int t = vb * MS_THREADS + threadIdx.x;
-    uint32_t taken = 0;
-    if (t < n * W) {
-        const int u = t / W, w = t - u * W;
-        uint32_t open = ~vis[t];
-        if (open) {
-            int e = rstart[u];
-            const int end = rstart[u + 1];
-            float* du = dist_t + (size_t)u * S + w * 32;
-            constexpr int B = 8;
-            for (; e < end; e += B) {
-                uint32_t key[B], f[B];
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t vb = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t t = vb * MS_THREADS + threadIdx.x;
+    if (t >= (uint32_t)n * W) return;
+    const uint32_t u = t / W, w = t - u * W;
+    // level 1: the word itself and the vertex's first 8 parents, requested together
+    const uint4* ev = reinterpret_cast<const uint4*>(ell_v + u * MS_ELL);
+    const ms_word own = Rcur[t];
+    const uint4 p0 = ev[0], p1 = ev[1];
+    uint32_t pv[MS_ELL];
+    pv[0] = p0.x; pv[1] = p0.y; pv[2] = p0.z; pv[3] = p0.w;
+    pv[4] = p1.x; pv[5] = p1.y; pv[6] = p1.z; pv[7] = p1.w;
+    MS_STAMP(1);
+    // level 2: the parents' words, all in flight at once (a padding parent reads row n: zero)
+    ms_word f[MS_ELL];
 #pragma unroll
-#ifdef MS_EXP_NOKEY
-                for (int j = 0; j < B; j++) key[j] = (uint32_t)(e + j) << 6;
+#if defined(MS_EXP_OWNF)
+    for (int j = 0; j < 8; j++) f[j] = Rcur[(pv[j] != (uint32_t)n ? u : (uint32_t)n) * W + w];
+#elif defined(MS_EXP_STATICF)
+    for (int j = 0; j < 8; j++) f[j] = reinterpret_cast<const ms_word*>(ell_d)[(pv[j] >> 1) * W + w] & 1ull;
 #else
-                for (int j = 0; j < B; j++) key[j] = rkey[min(e + j, end - 1)];
+    for (int j = 0; j < 8; j++) f[j] = Rcur[pv[j] * W + w];
 #endif
+    const bool more = __any(pv[7] != (uint32_t)n);  // (wave-uniform: most waves stop at 8 parents)
+    if (more) {
+        const uint4 p2 = ev[2], p3 = ev[3];
+        pv[8] = p2.x; pv[9] = p2.y; pv[10] = p2.z; pv[11] = p2.w;
+        pv[12] = p3.x; pv[13] = p3.y; pv[14] = p3.z; pv[15] = p3.w;
 #pragma unroll
-#ifdef MS_EXP_NOF
-                for (int j = 0; j < B; j++) f[j] = (key[j] == 0xfffffff0u) ? Fcur[0] : 0u;
-#else
-                for (int j = 0; j < B; j++) f[j] = Fcur[(size_t)(key[j] >> 6) * W + w];
-#endif
+        for (int j = 8; j < 16; j++) f[j] = Rcur[pv[j] * W + w];
+    } else {
 #pragma unroll
-                for (int j = 0; j < B; j++) {
-                    uint32_t nw = (e + j < end) ? (f[j] & open) : 0u;
-                    if (nw) {
-                        const float ed = rdist[e + j];
-                        const float* dv = dist_t + (size_t)(key[j] >> 6) * S + w * 32;
-                        open &= ~nw;
-                        taken |= nw;
-                        do {
-                            const int b = __builtin_ctz(nw);
-                            nw &= nw - 1;
-                            du[b] = ed + dv[b];
-                        } while (nw);
-                    }
-                }
-                if (!open) break;
-            }
-            if (taken) vis[t] = ~open;
+        for (int j = 8; j < 16; j++) {
+            pv[j] = (uint32_t)n;
+            f[j] = 0;
         }
-        Fnext[t] = taken;
     }
-    if (__any(taken != 0) && (threadIdx.x & 63) == 0) flag_cur[vb & (MS_FLAG_SHARDS - 1)] = 1;
-}
-
-// The same hop over fixed-width in-lists (W = 4 or 8 words).  What a hop costs is the DEPTH of its chain of dependent
-// loads, each a trip to the memory side (the masks were written by the previous launch, on other XCDs): in k_ms_hop
-// vis / rstart -> keys -> masks -> distances; here the 16 parents of a vertex sit at a fixed address, so vis and the
-// parents are requested together and the masks follow: two levels for the (vertex, word) pairs -- most of them -- that
-// take nothing in this hop.  Every lane of a vertex's group reads the same 64-byte parent row (four 16-byte loads).
-template <int W>
-__global__ __launch_bounds__(MS_THREADS) void k_ms_hop_ell(const uint32_t* __restrict__ ell_v,
-                                                           const float* __restrict__ ell_d,
-                                                           const int32_t* __restrict__ rstart,
-                                                           const uint32_t* __restrict__ rkey,
-                                                           const float* __restrict__ rdist,
-                                                           const uint32_t* __restrict__ Fcur,
-                                                           uint32_t* __restrict__ Fnext, uint32_t* __restrict__ vis,
-                                                           float* __restrict__ dist_t, int n, int S,
-                                                           const int32_t* __restrict__ flag_prev,
-                                                           int32_t* __restrict__ flag_cur) {
-    if (flag_prev) {
-        const int f = flag_prev[threadIdx.x & (MS_FLAG_SHARDS - 1)];
-        if (!__any(f != 0)) return;
-    }
-    const int per_xcd = gridDim.x >> 3;
-    const int vb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int t = vb * MS_THREADS + threadIdx.x;
-    uint32_t taken = 0;
-    if (t < n * W) {
-        const int u = t / W, w = t - u * W;
-        // level 1: the word's visited bits and the vertex's 16 parents, requested together (no branch may separate the
-        // requests: the compiler would wait for the first before it issues the second)
-        const uint4* ev = reinterpret_cast<const uint4*>(ell_v + (size_t)u * MS_ELL);
-        const uint32_t vw = vis[t];
-        const uint4 p0 = ev[0], p1 = ev[1], p2 = ev[2], p3 = ev[3];
-        uint32_t pv[MS_ELL] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w,
-                               p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
-        // level 2: the parents' frontier words, all in flight at once; a missing parent reads the vertex's own word
-        // (an address that is valid and warm) and is masked afterwards
-        uint32_t f[MS_ELL];
-#ifdef MS_EXP_STATIC
-        const uint32_t* Fsrc = reinterpret_cast<const uint32_t*>(ell_d);
+    MS_STAMP(2);
+    ms_word acc = own;
 #pragma unroll
-        for (int j = 0; j < 8; j++) f[j] = Fsrc[(size_t)(pv[j] != 0xffffffffu ? pv[j] : (uint32_t)u) * W + w] & (pv[j] == 0xfffffff0u ? 1u : 0u);
-#else
-#pragma unroll
-        for (int j = 0; j < 8; j++) f[j] = Fcur[(size_t)(pv[j] != 0xffffffffu ? pv[j] : (uint32_t)u) * W + w];
-#endif
-        const bool more = __any(pv[8] != 0xffffffffu);  // (wave-uniform: most waves stop at 8 parents)
+    for (int j = 0; j < MS_ELL; j++) acc |= f[j];
+    ms_word taken = acc & ~own;
+    float* du = dist_t + (size_t)u * S + w * 64u;
+    if (__any(taken != 0)) {
+        // the first parent (ascending) that has one of the new bits, and what it hands over; found by a select chain in
+        // descending order over registers (a lane-dependent index into pv[] / f[] would move them to scratch memory)
+        uint32_t v0 = u, j0 = 0;
+        ms_word n0 = 0;
         if (more) {
 #pragma unroll
-            for (int j = 8; j < 16; j++) f[j] = Fcur[(size_t)(pv[j] != 0xffffffffu ? pv[j] : (uint32_t)u) * W + w];
-        } else {
-#pragma unroll
-            for (int j = 8; j < 16; j++) f[j] = 0u;
-        }
-        // which bits each parent hands over: pure ALU, in list order (an earlier parent closes the bit for the later
-        // ones).  The first two parents that hand something over are kept as items (v, bits, slot) in plain registers
-        // (compile-time slots only: a lane-dependent index into pv[] would move the array to scratch memory).
-        uint32_t open = ~vw;
-        uint32_t nwj[MS_ELL];
-        uint32_t m = 0;  // bit j: parent j hands something over
-#pragma unroll
-        for (int j = 0; j < MS_ELL; j++) {
-            const uint32_t nw = (pv[j] != 0xffffffffu ? f[j] : 0u) & open;
-            open &= ~nw;
-            taken |= nw;
-            nwj[j] = nw;
-            m |= (nw != 0 ? 1u : 0u) << j;
-        }
-        const uint32_t m1 = m & (m - 1);
-        const uint32_t rest = m1 & (m1 - 1);  // a third, fourth ... handing parent (rare), done one by one below
-        const int j0 = m ? __builtin_ctz(m) : MS_ELL, j1 = m1 ? __builtin_ctz(m1) : MS_ELL;
-        const int cnt = (int)m;
-        uint32_t v0 = (uint32_t)u, v1 = (uint32_t)u, n0 = 0, n1 = 0;
-#pragma unroll
-        for (int j = 0; j < MS_ELL; j++) {
-            v0 = (j == j0) ? pv[j] : v0;
-            n0 = (j == j0) ? nwj[j] : n0;
-            v1 = (j == j1) ? pv[j] : v1;
-            n1 = (j == j1) ? nwj[j] : n1;
-        }
-        // the distances of the new bits.  A wave's lanes that took something did so from different parents: walking
-        // the 16 parents with a load -> wait -> store inside each step costs a trip to memory per step (that WAS the
-        // hop: 5 of its 7 us).  Here the wave requests every lane's first two items together.
-#if defined(MS_EXP_SMALLWR)
-        float* du = dist_t + (size_t)(u & 1023) * S + w * 32;
-#else
-        float* du = dist_t + (size_t)u * S + w * 32;
-#endif
-#if defined(MS_DBG_A)
-        if (cnt != 0) {
-#else
-        if (__any(cnt != 0)) {
-#endif
-            const int b0 = n0 ? __builtin_ctz(n0) : 0;
-            const int b1 = n1 ? __builtin_ctz(n1) : 0;
-            const float e0 = ell_d[(size_t)u * MS_ELL + (j0 & (MS_ELL - 1))], e1 = ell_d[(size_t)u * MS_ELL + (j1 & (MS_ELL - 1))];
-            // (a lane without an item reads dist_t[0]: one line for the whole wave instead of a line of its own)
-#if defined(MS_EXP_SMALLRD)
-            const size_t a0 = n0 ? (size_t)(v0 & 1023u) * S + w * 32 + b0 : (size_t)0;
-            const size_t a1 = n1 ? (size_t)(v1 & 1023u) * S + w * 32 + b1 : a0;
-#else
-            const size_t a0 = n0 ? (size_t)v0 * S + w * 32 + b0 : (size_t)0;
-            const size_t a1 = n1 ? (size_t)v1 * S + w * 32 + b1 : a0;
-#endif
-#if defined(MS_EXP_NORD)
-            const float d0 = (float)a0, d1 = (float)a1;
-#else
-            const float d0 = dist_t[a0], d1 = dist_t[a1];
-#endif
-#if defined(MS_DBG_B)
-            if (n0) du[b0] = ell_d[(size_t)u * MS_ELL + (j0 & (MS_ELL - 1))] + dist_t[(size_t)v0 * S + w * 32 + b0];
-            if (n1) du[b1] = ell_d[(size_t)u * MS_ELL + (j1 & (MS_ELL - 1))] + dist_t[(size_t)v1 * S + w * 32 + b1];
-#elif defined(MS_EXP_NOWR)
-            if (n0 && e0 + d0 == 12345.f) du[b0] = e0 + d0;
-            if (n1 && e1 + d1 == 12345.f) du[b1] = e1 + d1;
-#else
-            if (n0) du[b0] = e0 + d0;
-            if (n1) du[b1] = e1 + d1;
-#endif
-            // further bits of the same two parents (rare: two queries of one word reach u from the same parent)
-            uint32_t r0 = n0 & (n0 - 1), r1 = n1 & (n1 - 1);
-            while (r0) {
-                const int b = __builtin_ctz(r0);
-                r0 &= r0 - 1;
-                du[b] = e0 + dist_t[(size_t)v0 * S + w * 32 + b];
-            }
-            while (r1) {
-                const int b = __builtin_ctz(r1);
-                r1 &= r1 - 1;
-                du[b] = e1 + dist_t[(size_t)v1 * S + w * 32 + b];
-            }
-#if defined(MS_DBG_C)
-            if (rest != 0) {
-#else
-            if (__any(rest != 0)) {
-#endif
-                uint32_t op2 = ~vw;  // replay the list: the bits parent j hands over are f[j] & (what was open before j)
-#pragma unroll
-                for (int j = 0; j < MS_ELL; j++) {
-                    uint32_t nw = (pv[j] != 0xffffffffu ? f[j] : 0u) & op2;
-                    op2 &= ~nw;
-                    if ((rest >> j) & 1u) {
-                        const float ed = ell_d[(size_t)u * MS_ELL + j];
-                        const float* dv = dist_t + (size_t)pv[j] * S + w * 32;
-                        do {
-                            const int b = __builtin_ctz(nw);
-                            nw &= nw - 1;
-                            du[b] = ed + dv[b];
-                        } while (nw);
-                    }
-                }
+            for (int j = MS_ELL - 1; j >= 8; j--) {
+                const ms_word c = f[j] & taken;
+                v0 = c ? pv[j] : v0;
+                j0 = c ? (uint32_t)j : j0;
+                n0 = c ? c : n0;
             }
         }
-        if (open && pv[MS_ELL - 1] != 0xffffffffu) {  // a long in-list: the rest from the CSR
-            int e = rstart[u] + MS_ELL;
-            const int end = rstart[u + 1];
-            for (; e < end && open; e++) {
-                const uint32_t v = rkey[e] >> 6;
-                uint32_t nw = Fcur[(size_t)v * W + w] & open;
-                if (nw) {
-                    const float ed = rdist[e];
-                    const float* dv = dist_t + (size_t)v * S + w * 32;
-                    open &= ~nw;
-                    taken |= nw;
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {
+            const ms_word c = f[j] & taken;
+            v0 = c ? pv[j] : v0;
+            j0 = c ? (uint32_t)j : j0;
+            n0 = c ? c : n0;
+        }
+        // its distance: edge length and the parent's value requested together (a lane without an item reads element 0
+        // of each array: one line for the whole wave)
+        MS_STAMP(3);
+        const uint32_t b0 = n0 ? (uint32_t)__builtin_ctzll(n0) : 0u;
+        const float e0 = ell_d[n0 ? u * MS_ELL + j0 : 0u];
+        const float d0 = dist_t[n0 ? (size_t)v0 * S + w * 64u + b0 : (size_t)0];
+        MS_STAMP(4);
+        if (n0) du[b0] = e0 + d0;
+        ms_word r0 = n0 & (n0 - 1);  // further bits of the same parent (two queries of one word reach u from it: rare)
+        while (r0) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(r0);
+            r0 &= r0 - 1;
+            du[b] = e0 + dist_t[(size_t)v0 * S + w * 64u + b];
+        }
+        // bits handed over by later parents (rare): in list order, one by one
+        ms_word rem = taken & ~n0;
+        if (__any(rem != 0)) {
+#pragma unroll
+            for (int j = 1; j < MS_ELL; j++) {
+                ms_word c = f[j] & rem;
+                if (c) {
+                    rem &= ~c;
+                    const float ed = ell_d[u * MS_ELL + j];
+                    const float* dv = dist_t + (size_t)pv[j] * S + w * 64u;
                     do {
-                        const int b = __builtin_ctz(nw);
-                        nw &= nw - 1;
+                        const uint32_t b = (uint32_t)__builtin_ctzll(c);
+                        c &= c - 1;
                         du[b] = ed + dv[b];
-                    } while (nw);
+                    } while (c);
                 }
             }
         }
-        if (taken) vis[t] = ~open;
-        Fnext[t] = taken;
     }
-#if !defined(MS_EXP_NOFLAG)
-    if (__any(taken != 0) && (threadIdx.x & 63) == 0) flag_cur[vb & (MS_FLAG_SHARDS - 1)] = 1;
+    MS_STAMP(5);
+    if (~acc != 0 && pv[MS_ELL - 1] != (uint32_t)n) {  // a long in-list: the rest from the CSR
+        int e = rstart[u] + MS_ELL;
+        const int end = rstart[u + 1];
+        for (; e < end && ~acc != 0; e++) {
+            const uint32_t v = rkey[e] >> 6;
+            ms_word c = Rcur[v * W + w] & ~acc;
+            if (c) {
+                const float ed = rdist[e];
+                const float* dv = dist_t + (size_t)v * S + w * 64u;
+                acc |= c;
+                do {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(c);
+                    c &= c - 1;
+                    du[b] = ed + dv[b];
+                } while (c);
+            }
+        }
+    }
+#if defined(MS_EXP_NOSTORE)
+    if (taken) Rnext[t] = acc;
+#else
+    Rnext[t] = acc;
 #endif
+    MS_STAMP(6);
 }
 
-// geo[q][u] = vis[u] bit q ? dist[u][q] : -1 : 64 vertices x 64 queries per block through LDS
+// ------------------------------------------------------------------------------------
+// tiles: MS_TV consecutive vertices per workgroup, the parents' words staged in LDS
+// ------------------------------------------------------------------------------------
+// What the hop above waits for is the texture-address unit: 8 parents x 4 word lanes per vertex of 8-byte gathers, 14
+// waves per compute unit all at it at once (cycle stamps: 1 900 cycles for the first level of loads, 3 300 for the
+// parents' words, against a mean L1-miss latency of 360).  Parents of neighbouring vertices are mostly the same
+// vertices, so a workgroup that owns MS_TV consecutive vertices fetches every row it needs ONCE -- its own rows as one
+// contiguous block, the rows of parents outside the tile (its "halo", a static list built once per scene) by one
+// gather -- into LDS, and the per-parent reads become LDS reads through 16-bit local slots.
+#define MS_TV 256
+#define MS_HCAP 1536                 // halo rows a tile holds in LDS; parents beyond it are read from memory (slot 0xfffe)
+#define MS_ZROW (MS_TV + MS_HCAP)    // the LDS row that stays zero: the padding parent
+#define MS_HASH 8192                 // >= 2 x the most parents a tile can have outside itself (MS_TV x 16)
+#define MS_SLOT_FAR 0xfffeu
+
+// per tile: the distinct out-of-tile parents of its vertices (halo_gid, nhalo) and every vertex's 16 local slots
+__global__ __launch_bounds__(MS_TV) void k_ms_tiles(const uint32_t* __restrict__ ell_v, int n,
+                                                    uint16_t* __restrict__ slot16, uint32_t* __restrict__ halo_gid,
+                                                    int32_t* __restrict__ nhalo) {
+    __shared__ uint32_t s_key[MS_HASH];
+    __shared__ uint16_t s_idx[MS_HASH];
+    __shared__ int s_cnt;
+    const int tile = blockIdx.x, lu = threadIdx.x;
+    const uint32_t base = (uint32_t)tile * MS_TV, u = base + lu;
+    for (int i = lu; i < MS_HASH; i += MS_TV) s_key[i] = 0xffffffffu;
+    if (lu == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t pv[MS_ELL];
+#pragma unroll
+    for (int j = 0; j < MS_ELL; j++) pv[j] = u < (uint32_t)n ? ell_v[(size_t)u * MS_ELL + j] : (uint32_t)n;
+#pragma unroll
+    for (int j = 0; j < MS_ELL; j++) {
+        const uint32_t v = pv[j];
+        if (v != (uint32_t)n && (v < base || v >= base + MS_TV)) {
+            uint32_t hpos = (v * 2654435761u) >> 19;  // 13 bits
+            for (;;) {
+                const uint32_t old = atomicCAS(&s_key[hpos], 0xffffffffu, v);
+                if (old == 0xffffffffu || old == v) break;
+                hpos = (hpos + 1) & (MS_HASH - 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lu; i < MS_HASH; i += MS_TV) {
+        const uint32_t key = s_key[i];
+        if (key != 0xffffffffu) {
+            const int idx = atomicAdd(&s_cnt, 1);
+            s_idx[i] = idx < MS_HCAP ? (uint16_t)(MS_TV + idx) : (uint16_t)MS_SLOT_FAR;
+            if (idx < MS_HCAP) halo_gid[(size_t)tile * MS_HCAP + idx] = key;
+        }
+    }
+    __syncthreads();
+    if (lu == 0) nhalo[tile] = s_cnt < MS_HCAP ? s_cnt : MS_HCAP;
+    uint16_t sl[MS_ELL];
+#pragma unroll
+    for (int j = 0; j < MS_ELL; j++) {
+        const uint32_t v = pv[j];
+        uint16_t r = (uint16_t)MS_ZROW;
+        if (v != (uint32_t)n) {
+            if (v >= base && v < base + MS_TV) {
+                r = (uint16_t)(v - base);
+            } else {
+                uint32_t hpos = (v * 2654435761u) >> 19;
+                while (s_key[hpos] != v) hpos = (hpos + 1) & (MS_HASH - 1);
+                r = s_idx[hpos];
+            }
+        }
+        sl[j] = r;
+    }
+    uint4* out = reinterpret_cast<uint4*>(slot16 + (size_t)u * MS_ELL);  // (slot16 has tiles * MS_TV rows)
+    out[0] = make_uint4(sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), sl[4] | (sl[5] << 16), sl[6] | (sl[7] << 16));
+    out[1] = make_uint4(sl[8] | (sl[9] << 16), sl[10] | (sl[11] << 16), sl[12] | (sl[13] << 16), sl[14] | (sl[15] << 16));
+}
+
+// One hop over tiles.  Workgroup = tile, thread = (local vertex, 64-bit word); W words per vertex (1..4).
+template <int W>
+__global__ __launch_bounds__(MS_TV* W) void k_ms_hop_tile(const uint16_t* __restrict__ slot16,
+                                                          const uint32_t* __restrict__ halo_gid,
+                                                          const int32_t* __restrict__ nhalo,
+                                                          const uint32_t* __restrict__ ell_v,
+                                                          const float* __restrict__ ell_d,
+                                                          const int32_t* __restrict__ rstart,
+                                                          const uint32_t* __restrict__ rkey,
+                                                          const float* __restrict__ rdist,
+                                                          const ms_word* __restrict__ Rcur, ms_word* __restrict__ Rnext,
+                                                          float* __restrict__ dist_t, int n,
+                                                          const int32_t* __restrict__ alive) {
+    constexpr int THREADS = MS_TV * W;
+    constexpr int HIT = (MS_HCAP * W + THREADS - 1) / THREADS;  // halo (row, word) items per thread
+    extern __shared__ ms_word s_rows[];                          // [(MS_ZROW + 1) * W] words, then the halo's vertex ids
+    uint32_t* s_gid = reinterpret_cast<uint32_t*>(s_rows + (size_t)(MS_ZROW + 1) * W);
+    if (alive && *alive == 0) return;
+    constexpr uint32_t S = W * 64u;
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lu = tid / W, w = tid - lu * W;
+    const uint32_t base = tile * MS_TV, u = base + lu;
+    const bool live = u < (uint32_t)n;
+    const int nh = nhalo[tile];
+    // level 1: own word (one contiguous block per tile), the vertex's 16 slots, the halo's vertex ids
+    const ms_word own = live ? Rcur[u * W + w] : 0ull;
+    const uint4* sp = reinterpret_cast<const uint4*>(slot16 + (size_t)u * MS_ELL);
+    const uint4 q0 = sp[0], q1 = sp[1];
+    uint32_t hg[HIT];
+#pragma unroll
+    for (int i = 0; i < HIT; i++) {
+        const uint32_t item = tid + i * THREADS, h = item / W;
+        hg[i] = h < (uint32_t)nh ? halo_gid[(size_t)tile * MS_HCAP + h] : (uint32_t)n;
+    }
+    // level 2: the halo's rows (a row is W consecutive lanes' words)
+    ms_word hr[HIT];
+#pragma unroll
+    for (int i = 0; i < HIT; i++) {
+        const uint32_t item = tid + i * THREADS, ww = item - (item / W) * W;
+        hr[i] = Rcur[hg[i] * W + ww];  // (beyond the halo: row n, zero)
+    }
+    s_rows[lu * W + w] = own;
+    if (tid < W) s_rows[(size_t)MS_ZROW * W + tid] = 0ull;
+#pragma unroll
+    for (int i = 0; i < HIT; i++) {
+        const uint32_t item = tid + i * THREADS, h = item / W, ww = item - h * W;
+        if (h < (uint32_t)nh) {
+            s_rows[(MS_TV + h) * W + ww] = hr[i];
+            if (ww == 0) s_gid[h] = hg[i];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    uint32_t sl[MS_ELL];
+    sl[0] = q0.x & 0xffffu; sl[1] = q0.x >> 16; sl[2] = q0.y & 0xffffu; sl[3] = q0.y >> 16;
+    sl[4] = q0.z & 0xffffu; sl[5] = q0.z >> 16; sl[6] = q0.w & 0xffffu; sl[7] = q0.w >> 16;
+    sl[8] = q1.x & 0xffffu; sl[9] = q1.x >> 16; sl[10] = q1.y & 0xffffu; sl[11] = q1.y >> 16;
+    sl[12] = q1.z & 0xffffu; sl[13] = q1.z >> 16; sl[14] = q1.w & 0xffffu; sl[15] = q1.w >> 16;
+    ms_word f[MS_ELL];
+    bool far = false;
+#pragma unroll
+    for (int j = 0; j < MS_ELL; j++) {
+        far = far || sl[j] == MS_SLOT_FAR;
+        f[j] = s_rows[(sl[j] == MS_SLOT_FAR ? (uint32_t)MS_ZROW : sl[j]) * W + w];
+    }
+    if (__any(far)) {  // parents beyond the halo capacity (a tile with > MS_HCAP outside parents): from memory
+#pragma unroll
+        for (int j = 0; j < MS_ELL; j++)
+            if (sl[j] == MS_SLOT_FAR) f[j] = Rcur[ell_v[u * MS_ELL + j] * W + w];
+    }
+    ms_word acc = own;
+#pragma unroll
+    for (int j = 0; j < MS_ELL; j++) acc |= f[j];
+    const ms_word taken = acc & ~own;
+    float* du = dist_t + (size_t)u * S + w * 64u;
+    if (__any(taken != 0)) {
+        // the first two parents (ascending) that hand a new bit over, and what they hand over; select chains in
+        // descending order over registers (a lane-dependent index into f[] would move it to scratch memory)
+        uint32_t s0 = MS_ZROW, j0 = 0, s1 = MS_ZROW, j1 = 0;
+        ms_word n0 = 0, n1 = 0;
+#pragma unroll
+        for (int j = MS_ELL - 1; j >= 0; j--) {
+            const ms_word c = f[j] & taken;
+            // (j becomes the first; the previous first becomes the second)
+            s1 = c ? s0 : s1; j1 = c ? j0 : j1; n1 = c ? n0 : n1;
+            s0 = c ? sl[j] : s0; j0 = c ? (uint32_t)j : j0; n0 = c ? c : n0;
+        }
+        n1 &= ~n0;  // (what the second hands over excludes the first's bits; it may be empty: then a later one may own
+                    //  bits -- the loop below)
+        // the parents' vertex ids: own tile or halo (LDS), beyond the halo from memory
+        const uint32_t v0 = s0 < MS_TV ? base + s0 : (s0 == MS_SLOT_FAR ? ell_v[u * MS_ELL + j0] : s_gid[s0 < MS_ZROW ? s0 - MS_TV : 0]);
+        const uint32_t v1 = s1 < MS_TV ? base + s1 : (s1 == MS_SLOT_FAR ? ell_v[u * MS_ELL + j1] : s_gid[s1 < MS_ZROW ? s1 - MS_TV : 0]);
+        const uint32_t b0 = n0 ? (uint32_t)__builtin_ctzll(n0) : 0u, b1 = n1 ? (uint32_t)__builtin_ctzll(n1) : 0u;
+        // edge lengths and the parents' values requested together (a lane without an item reads element 0)
+        const float e0 = ell_d[n0 ? u * MS_ELL + j0 : 0u], e1 = ell_d[n1 ? u * MS_ELL + j1 : 0u];
+        const float d0 = dist_t[n0 ? (size_t)v0 * S + w * 64u + b0 : (size_t)0];
+        const float d1 = dist_t[n1 ? (size_t)v1 * S + w * 64u + b1 : (size_t)0];
+        if (n0) du[b0] = e0 + d0;
+        if (n1) du[b1] = e1 + d1;
+        ms_word r0 = n0 & (n0 - 1), r1 = n1 & (n1 - 1);  // further bits of the same parents (rare)
+        while (r0) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(r0);
+            r0 &= r0 - 1;
+            du[b] = e0 + dist_t[(size_t)v0 * S + w * 64u + b];
+        }
+        while (r1) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(r1);
+            r1 &= r1 - 1;
+            du[b] = e1 + dist_t[(size_t)v1 * S + w * 64u + b];
+        }
+        // bits handed over by a third, fourth ... parent (rare): in list order, one by one
+        ms_word rem = taken & ~(n0 | n1);
+        if (__any(rem != 0)) {
+#pragma unroll
+            for (int j = 2; j < MS_ELL; j++) {
+                ms_word c = f[j] & rem;
+                if (c) {
+                    rem &= ~c;
+                    const float ed = ell_d[u * MS_ELL + j];
+                    const float* dv = dist_t + (size_t)ell_v[u * MS_ELL + j] * S + w * 64u;
+                    do {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(c);
+                        c &= c - 1;
+                        du[b] = ed + dv[b];
+                    } while (c);
+                }
+            }
+        }
+    }
+    if (~acc != 0 && sl[MS_ELL - 1] != MS_ZROW) {  // a long in-list: the rest from the CSR
+        int e = rstart[u] + MS_ELL;
+        const int end = rstart[u + 1];
+        for (; e < end && ~acc != 0; e++) {
+            const uint32_t v = rkey[e] >> 6;
+            ms_word c = Rcur[v * W + w] & ~acc;
+            if (c) {
+                const float ed = rdist[e];
+                const float* dv = dist_t + (size_t)v * S + w * 64u;
+                acc |= c;
+                do {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(c);
+                    c &= c - 1;
+                    du[b] = ed + dv[b];
+                } while (c);
+            }
+        }
+    }
+    Rnext[u * W + w] = acc;
+}
+
+// alive_out = (the two mask buffers differ: the last hop reached something); runs only while alive_in says the search
+// was on at the previous check
+__global__ __launch_bounds__(MS_THREADS) void k_ms_check(const ms_word* __restrict__ Ra, const ms_word* __restrict__ Rb,
+                                                         int nwords, const int32_t* __restrict__ alive_in,
+                                                         int32_t* __restrict__ alive_out) {
+    if (alive_in && *alive_in == 0) return;
+    ms_word acc = 0;
+    for (int i = blockIdx.x * MS_THREADS + threadIdx.x; i < nwords; i += gridDim.x * MS_THREADS) acc |= Ra[i] ^ Rb[i];
+    if (__any(acc != 0) && (threadIdx.x & 63) == 0) *alive_out = 1;
+}
+
+// geo[q][u] = R[u] bit q ? dist[u][q] : -1 : 64 vertices x 64 queries per block through LDS
 __global__ __launch_bounds__(MS_THREADS) void k_ms_transpose(const float* __restrict__ dist_t,
-                                                             const uint32_t* __restrict__ vis, int n, int nq, int W,
+                                                             const ms_word* __restrict__ R, int n, int nq, int W,
                                                              int S, float* __restrict__ geo) {
     __shared__ float tile[64][65];
     const int u0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
@@ -402,8 +558,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_transpose(const float* __rest
         const int u = u0 + r, q = q0 + tx;
         float val = -1.0f;
         if (u < n && q < nq) {
-            const uint32_t m = vis[(size_t)u * W + (q >> 5)];
-            if ((m >> (q & 31)) & 1u) val = dist_t[(size_t)u * S + q];
+            const ms_word m = R[(size_t)u * W + (q >> 6)];
+            if ((m >> (q & 63)) & 1ull) val = dist_t[(size_t)u * S + q];
         }
         tile[r][tx] = val;
     }
@@ -420,15 +576,17 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_transpose(const float* __rest
 // ------------------------------------------------------------------------------------
 static size_t ms_align(size_t b) { return (b + 255) & ~(size_t)255; }
 struct MsLayout {
-    size_t rcount, rstart, rcur, bsum, tkey, tdist, rkey, rdist, ell_v, ell_d, F0, F1, vis, flags, dist_t, total;
+    size_t rcount, rstart, rcur, bsum, tkey, tdist, rkey, rdist, ell_v, ell_d, slot16, halo_gid, nhalo, R0, R1, flags,
+        dist_t, total;
+    int tiles;
     int W, S;
     size_t E;
 };
 static MsLayout ms_layout(int n, int K, int nq, int max_step) {
     MsLayout L;
-    L.W = (nq + 31) / 32;
+    L.W = (nq + 63) / 64;
     if (L.W < 1) L.W = 1;
-    L.S = L.W * 32;
+    L.S = L.W * 64;
     L.E = (size_t)n * (size_t)(K - 1);
     size_t o = 0;
     L.rcount = o; o += ms_align((size_t)(n + 1) * 4);
@@ -441,15 +599,43 @@ static MsLayout ms_layout(int n, int K, int nq, int max_step) {
     L.rdist = o; o += ms_align(L.E * 4);
     L.ell_v = o; o += ms_align((size_t)n * MS_ELL * 4);
     L.ell_d = o; o += ms_align((size_t)n * MS_ELL * 4);
-    L.F0 = o; o += ms_align((size_t)n * L.W * 4);
-    L.F1 = o; o += ms_align((size_t)n * L.W * 4);
-    L.vis = o; o += ms_align((size_t)n * L.W * 4);
-    L.flags = o; o += ms_align((size_t)(max_step + 2) * MS_FLAG_SHARDS * 4);
+    L.tiles = (n + MS_TV - 1) / MS_TV;
+    L.slot16 = o; o += ms_align((size_t)L.tiles * MS_TV * MS_ELL * 2);
+    L.halo_gid = o; o += ms_align((size_t)L.tiles * MS_HCAP * 4);
+    L.nhalo = o; o += ms_align((size_t)L.tiles * 4);
+    L.R0 = o; o += ms_align((size_t)(n + 1) * L.W * 8);
+    L.R1 = o; o += ms_align((size_t)(n + 1) * L.W * 8);
+    L.flags = o; o += ms_align((size_t)(max_step / MS_CHECK_EVERY + 2) * 4);
     L.dist_t = o; o += ms_align((size_t)n * L.S * 4);
     L.total = o;
     return L;
 }
 
+// dev knob: GF_BFS_MS_TILES=0 keeps the gather form of the hop (k_ms_hop)
+static int g_ms_tiles = -1;
+static bool ms_tiles_on() {
+    if (g_ms_tiles < 0) {
+        const char* e = getenv("GF_BFS_MS_TILES");
+        g_ms_tiles = e ? (atoi(e) != 0) : 1;
+    }
+    return g_ms_tiles != 0;
+}
+extern "C" int gf_dev_bfs_ms_tiles(int on) {
+    g_ms_tiles = on < 0 ? -1 : (on != 0);
+    return GF_OK;
+}
+#ifdef MS_TRACE
+static unsigned long long* g_ms_trace = nullptr;
+static int g_ms_trace_hop = -1;
+extern "C" int gf_dev_ms_trace(void* buf, int hop) {
+    g_ms_trace = (unsigned long long*)buf;
+    g_ms_trace_hop = hop;
+    return 0;
+}
+#define MS_TRACE_ARG , (h == g_ms_trace_hop ? g_ms_trace : (unsigned long long*)nullptr)
+#else
+#define MS_TRACE_ARG
+#endif
 extern "C" size_t gf_geodesic_ms_scratch_bytes(int n, int K, int nq, int max_step) {
     if (n < 1 || K < 2 || nq < 1 || max_step < 0) return 0;
     return ms_layout(n, K, nq, max_step).total;
@@ -464,7 +650,9 @@ extern "C" int gf_geodesic_bfs_ms(const float* D, const int32_t* I, int n, int K
     const MsLayout L = ms_layout(n, K, nq, max_step);
     GF_CHECK_ARG(D && I && src && geo && scratch, "gf_geodesic_bfs_ms: null pointer");
     GF_CHECK_ARG(scratch_bytes >= L.total, "gf_geodesic_bfs_ms: scratch of %zu bytes, %zu needed", scratch_bytes, L.total);
-    GF_CHECK_ARG((size_t)n * L.W < (size_t)0x7fffffff, "gf_geodesic_bfs_ms: n * words overflows");
+    // 32-bit offsets inside the kernels: mask words, in-list rows
+    GF_CHECK_ARG((size_t)(n + 1) * L.W < ((size_t)1 << 29) && (size_t)n * MS_ELL < ((size_t)1 << 30),
+                 "gf_geodesic_bfs_ms: n * words overflows the 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)scratch;
     int32_t* rcount = (int32_t*)(base + L.rcount);
@@ -477,39 +665,61 @@ extern "C" int gf_geodesic_bfs_ms(const float* D, const int32_t* I, int n, int K
     float* rdist = (float*)(base + L.rdist);
     uint32_t* ell_v = (uint32_t*)(base + L.ell_v);
     float* ell_d = (float*)(base + L.ell_d);
-    uint32_t* F[2] = {(uint32_t*)(base + L.F0), (uint32_t*)(base + L.F1)};
-    uint32_t* vis = (uint32_t*)(base + L.vis);
+    uint16_t* slot16 = (uint16_t*)(base + L.slot16);
+    uint32_t* halo_gid = (uint32_t*)(base + L.halo_gid);
+    int32_t* nhalo = (int32_t*)(base + L.nhalo);
+    ms_word* R[2] = {(ms_word*)(base + L.R0), (ms_word*)(base + L.R1)};
     int32_t* flags = (int32_t*)(base + L.flags);
     float* dist_t = (float*)(base + L.dist_t);
     const int W = L.W, S = L.S;
 
     GF_TRY(hipMemsetAsync(rcount, 0, (size_t)(n + 1) * 4, st));
-    GF_TRY(hipMemsetAsync(flags, 0, (size_t)(max_step + 2) * MS_FLAG_SHARDS * 4, st));
+    GF_TRY(hipMemsetAsync(flags, 0, (size_t)(max_step / MS_CHECK_EVERY + 2) * 4, st));
     const int rows_grid = gf_div_up(n, MS_THREADS / 64);
     hipLaunchKernelGGL(k_ms_count, dim3(rows_grid), dim3(MS_THREADS), 0, st, D, I, n, K, radius, rcount);
     gf_iscan(rcount, n, rstart, rcur, bsum, bsum + gf_iscan_blocks(n), st);
     hipLaunchKernelGGL(k_ms_fill, dim3(rows_grid), dim3(MS_THREADS), 0, st, D, I, n, K, radius, rcur, tkey, tdist);
     hipLaunchKernelGGL(k_ms_sort, dim3(gf_div_up((long long)n * 16, MS_THREADS)), dim3(MS_THREADS), 0, st, rstart, n,
                        tkey, tdist, rkey, rdist, ell_v, ell_d);
+    const bool tiled = W >= 1 && W <= 4 && ms_tiles_on();
+    if (tiled) hipLaunchKernelGGL(k_ms_tiles, dim3(L.tiles), dim3(MS_TV), 0, st, ell_v, n, slot16, halo_gid, nhalo);
+    const size_t tile_lds = (size_t)(MS_ZROW + 1) * W * sizeof(ms_word) + (size_t)MS_HCAP * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_ms_init, dim3(gf_div_up((long long)(n + 1) * W, MS_THREADS)), dim3(MS_THREADS), 0, st, src, nq, n,
+                       W, S, R[0], R[1], dist_t);
     const int grid = (gf_div_up((long long)n * W, MS_THREADS) + 7) & ~7;  // (a multiple of 8: k_ms_hop's XCD mapping)
-    hipLaunchKernelGGL(k_ms_init, dim3(grid), dim3(MS_THREADS), 0, st, src, nq, n, W, S, F[0], vis, dist_t);
     for (int h = 1; h <= max_step; h++) {
-        const int32_t* fp = h >= 2 ? flags + (size_t)(h - 1) * MS_FLAG_SHARDS : nullptr;
-        int32_t* fc = flags + (size_t)h * MS_FLAG_SHARDS;
-        const uint32_t* Fc = F[(h - 1) & 1];
-        uint32_t* Fn = F[h & 1];
-        if (W == 8)
-            hipLaunchKernelGGL(k_ms_hop_ell<8>, dim3(grid), dim3(MS_THREADS), 0, st, ell_v, ell_d, rstart, rkey, rdist, Fc,
-                               Fn, vis, dist_t, n, S, fp, fc);
-        else if (W == 4)
-            hipLaunchKernelGGL(k_ms_hop_ell<4>, dim3(grid), dim3(MS_THREADS), 0, st, ell_v, ell_d, rstart, rkey, rdist, Fc,
-                               Fn, vis, dist_t, n, S, fp, fc);
+        // flags[c]: the search was still on at check c (after hop c * MS_CHECK_EVERY); the hops up to the first check run
+        // unconditionally
+        const int c = (h - 1) / MS_CHECK_EVERY;
+        const int32_t* alive = c >= 1 ? flags + c : nullptr;
+        const ms_word* Rc = R[(h - 1) & 1];
+        ms_word* Rn = R[h & 1];
+        if (tiled) {
+#define MS_LAUNCH_TILE(WW)                                                                                              \
+    hipLaunchKernelGGL(k_ms_hop_tile<WW>, dim3(L.tiles), dim3(MS_TV* WW), tile_lds, st, slot16, halo_gid, nhalo, ell_v,  \
+                       ell_d, rstart, rkey, rdist, Rc, Rn, dist_t, n, alive)
+            if (W == 4) MS_LAUNCH_TILE(4);
+            else if (W == 3) MS_LAUNCH_TILE(3);
+            else if (W == 2) MS_LAUNCH_TILE(2);
+            else MS_LAUNCH_TILE(1);
+        } else if (W == 4)
+            hipLaunchKernelGGL(k_ms_hop<4>, dim3(grid), dim3(MS_THREADS), 0, st, ell_v, ell_d, rstart, rkey, rdist, Rc, Rn,
+                               dist_t, n, W, alive MS_TRACE_ARG);
+        else if (W == 2)
+            hipLaunchKernelGGL(k_ms_hop<2>, dim3(grid), dim3(MS_THREADS), 0, st, ell_v, ell_d, rstart, rkey, rdist, Rc, Rn,
+                               dist_t, n, W, alive MS_TRACE_ARG);
         else
-            hipLaunchKernelGGL(k_ms_hop<0>, dim3(grid), dim3(MS_THREADS), 0, st, rstart, rkey, rdist, Fc, Fn, vis, dist_t,
-                               n, W, S, fp, fc);
+            hipLaunchKernelGGL(k_ms_hop<0>, dim3(grid), dim3(MS_THREADS), 0, st, ell_v, ell_d, rstart, rkey, rdist, Rc, Rn,
+                               dist_t, n, W, alive MS_TRACE_ARG);
+        if (h % MS_CHECK_EVERY == 0 && h < max_step) {
+            const int cc = h / MS_CHECK_EVERY;
+            hipLaunchKernelGGL(k_ms_check, dim3(64), dim3(MS_THREADS), 0, st, Rc, (const ms_word*)Rn, n * W,
+                               cc >= 2 ? flags + cc - 1 : nullptr, flags + cc);
+        }
     }
-    hipLaunchKernelGGL(k_ms_transpose, dim3(gf_div_up(n, 64), gf_div_up(nq, 64)), dim3(MS_THREADS), 0, st, dist_t, vis,
-                       n, nq, W, S, geo);
+    // (a search that ended early left both buffers equal; otherwise the last hop wrote R[max_step & 1])
+    hipLaunchKernelGGL(k_ms_transpose, dim3(gf_div_up(n, 64), gf_div_up(nq, 64)), dim3(MS_THREADS), 0, st, dist_t,
+                       (const ms_word*)R[max_step & 1], n, nq, W, S, geo);
     GF_CHECK_LAUNCH("gf_geodesic_bfs_ms");
     return GF_OK;
 }

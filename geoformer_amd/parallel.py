@@ -39,12 +39,32 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-def init_distributed(backend=None):
-    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+# Run the collectives of SyncBatchNorm1d even in a process group of ONE rank (tests: the RCCL calls of the data-parallel
+# step executed on the one GPU a test box has; tests/test_gpu_rccl.py).  BucketedGradReducer has its own switch.
+FORCE_EXCHANGE = False
+
+
+def _exchanging():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_EXCHANGE)
+
+
+def init_distributed(backend=None, force=False):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  One process needs no
+    group; force=True creates the one-rank group anyway (the RCCL path on a single GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 or dist.is_initialized():
+    if dist.is_initialized() or (world == 1 and not force):
         return world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" IS RCCL on ROCm
     dist.init_process_group(backend)
     return world
@@ -53,13 +73,16 @@ def init_distributed(backend=None):
 class BucketedGradReducer:
     """Gradient averaging over one flat buffer; buckets start from gradient hooks while the backward runs."""
 
-    def __init__(self, module, bucket_bytes=8 << 20, only_trainable=True, overlap=None):
-        """overlap: start a bucket's all-reduce from the gradient hooks while the backward runs.  Default: on, unless the
+    def __init__(self, module, bucket_bytes=8 << 20, only_trainable=True, overlap=None, always_exchange=False):
+        """always_exchange: hooks, packing and the all-reduces also run in a process group of ONE rank (the step a
+        multi-GPU job executes, on the one GPU a test has; without a process group there is nothing to call).
+        overlap: start a bucket's all-reduce from the gradient hooks while the backward runs.  Default: on, unless the
         module holds SyncBatchNorm1d layers -- their backward collectives share the communicator, and a rank whose
         first bucket completes late would order the two kinds differently from its peers."""
         if overlap is None:
             overlap = not any(isinstance(m, SyncBatchNorm1d) for m in module.modules())
         self.overlap = bool(overlap)
+        self.always_exchange = bool(always_exchange)
         params = [p for p in module.parameters() if (p.requires_grad or not only_trainable)]
         self.params = params[::-1]  # backward order: the last layers' gradients arrive first
         n = sum(p.numel() for p in self.params)
@@ -93,6 +116,10 @@ class BucketedGradReducer:
     def world(self):
         return dist.get_world_size() if dist.is_initialized() else 1
 
+    def exchanging(self):
+        """Is there somebody to exchange with (or a one-rank group with always_exchange)?"""
+        return dist.is_initialized() and (dist.get_world_size() > 1 or self.always_exchange)
+
     @torch.no_grad()
     def prepare(self):
         """Call before every backward (instead of ``zero_grad``): every ``p.grad`` is dropped, so autograd hands each
@@ -104,9 +131,9 @@ class BucketedGradReducer:
             p.grad = None
         # the hooks exist only while there is somebody to exchange with (one process: ~400 Python calls per backward
         # on the autograd thread for nothing)
-        if self.world() > 1 and not self._hooks:
+        if self.exchanging() and not self._hooks:
             self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-        elif self.world() == 1 and self._hooks:
+        elif not self.exchanging() and self._hooks:
             self.remove_hooks()
         self._ready = [0] * len(self.ranges)
         self._next = 0
@@ -118,7 +145,7 @@ class BucketedGradReducer:
         """The gradients of bucket b into their slice of the flat buffer (one concatenation; zeros where a parameter got
         no gradient), and the parameters' ``grad`` re-pointed at the slice so that the optimizer reads the averaged values.
         One process: nothing to exchange -- the gradients stay where autograd put them."""
-        if self.world() == 1:
+        if not self.exchanging():
             return
         s, e = self.ranges[b]
         idxs = self.members[b]
@@ -137,7 +164,7 @@ class BucketedGradReducer:
     def _launch(self, b):
         self._pack(b)
         s, e = self.ranges[b]
-        if self.world() > 1:
+        if self.exchanging():
             self._works.append(dist.all_reduce(self.flat[s:e], async_op=True))
 
     @torch.no_grad()
@@ -163,7 +190,7 @@ class BucketedGradReducer:
         while self._next < len(self.ranges):
             self._launch(self._next)
             self._next += 1
-        if world == 1:
+        if not self.exchanging():
             return
         flags = torch.tensor(self.used, dtype=torch.float32, device=self.flat.device)
         self._works.append(dist.all_reduce(flags, op=dist.ReduceOp.MAX, async_op=True))
@@ -202,7 +229,7 @@ class _SyncBNFn(torch.autograd.Function):
         else:  # an empty rank still takes part, with count 0
             mean_l, m2_l = x.new_zeros(C), x.new_zeros(C)
         local = torch.cat([x.new_full((1,), float(n_local)), mean_l, m2_l])
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _exchanging():
             flat = x.new_empty(dist.get_world_size() * (2 * C + 1))  # (flat: gloo takes the concatenated form only)
             dist.all_gather_into_tensor(flat, local)
             allst = flat.view(dist.get_world_size(), 2 * C + 1)
@@ -228,7 +255,7 @@ class _SyncBNFn(torch.autograd.Function):
         gw_local = (gy * xhat).sum(red)
         gb_local = gy.sum(red)
         packed = torch.cat([gb_local, gw_local])
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if _exchanging():
             dist.all_reduce(packed)  # statistics of the GLOBAL batch; weight/bias grads stay local (the reducer sums them)
         sum_dy, sum_dy_xhat = packed[:C], packed[C:]
         gx = (gy - sum_dy.view(shape) / n - xhat * (sum_dy_xhat.view(shape) / n)) * (weight * invstd).view(shape)

@@ -120,7 +120,8 @@ def run(args, device, batches=None):
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     cfg, m, crit = build(args, device)
-    red = parallel.BucketedGradReducer(m, bucket_bytes=int(args.bucket_mb * (1 << 20)))
+    red = parallel.BucketedGradReducer(m, bucket_bytes=int(args.bucket_mb * (1 << 20)),
+                                       always_exchange=bool(getattr(args, "always_exchange", False)))
     opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3,
                            fused=device.type == "cuda")  # one launch per step on the GPU (the foreach form: ~5 ms of host time)
     nb = 2
