@@ -60,6 +60,12 @@ int gf_iscan_blocks(int n);
 void gf_iscan(const int32_t* v, int n, int32_t* start, int32_t* cursor, int32_t* block_sums, int32_t* block_off,
               hipStream_t st);
 
+// the whole chain with every stage as one launch over all levels (spconv_rules.hip); gf_rules_level_parallel(): the
+// default, unless GF_RULES_SERIAL=1
+int gf_rules_down2_chain_all(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels, int32_t* ws,
+                             int32_t* counts, hipStream_t st);
+bool gf_rules_level_parallel();
+
 static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- a chain of small sparse convolutions in one persistent launch (spconv_conv.hip: k_conv_chain; used by

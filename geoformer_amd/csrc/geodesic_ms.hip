@@ -611,12 +611,15 @@ static MsLayout ms_layout(int n, int K, int nq, int max_step) {
     return L;
 }
 
-// dev knob: GF_BFS_MS_TILES=0 keeps the gather form of the hop (k_ms_hop)
+// dev knob: GF_BFS_MS_TILES=1 takes the LDS-tile form of the hop (k_ms_hop_tile).  Measured slower than the gather
+// form on vertices in scene order (8.7 against 7.3 us per hop, S150k foreground, 256 queries): a tile of 256
+// consecutive vertices is a strip, its halo ~4 tiles' worth of rows, so the tile fetches MORE bytes per hop than the
+// gather's L1-shared lines; it would need spatially compact tiles (a Morton re-ordering of the vertices) to pay.
 static int g_ms_tiles = -1;
 static bool ms_tiles_on() {
     if (g_ms_tiles < 0) {
         const char* e = getenv("GF_BFS_MS_TILES");
-        g_ms_tiles = e ? (atoi(e) != 0) : 1;
+        g_ms_tiles = e ? (atoi(e) != 0) : 0;
     }
     return g_ms_tiles != 0;
 }

@@ -12,6 +12,7 @@
 // against oracle/gf_oracle.c (orc_rules_subm3 / orc_rules_down2).
 #include <stdarg.h>
 
+#include <cstdlib>
 #include "common.h"
 
 // ------------------------------------------------------------------------------------
@@ -448,6 +449,9 @@ struct DownPlan {
     size_t words[DOWN_MAX_LEVELS];
     long long off[DOWN_MAX_LEVELS][DOWN_FIELDS];  // int32-element offsets into the workspace
     long long bitmaps_begin, bitmaps_end, child_begin, child_end, total;
+    // (for the level-parallel build: the one-hot `up` tables of the levels below the first start as -1 everywhere and
+    //  their group masks as 0, so both sit next to the blocks the two memsets clear anyway)
+    long long zero_end, ff_end;
 };
 
 static inline long long pad64(long long n) { return (n + 63) / 64 * 64; }
@@ -474,15 +478,19 @@ static int plan_down_chain(int M0, int B, int X, int Y, int Z, int nlevels, Down
     P.bitmaps_begin = cur;
     for (int l = 0; l < P.nl; l++) { P.off[l][0] = cur; cur += pad64((long long)P.words[l]); }
     P.bitmaps_end = cur;
+    for (int l = 1; l < P.nl; l++) { P.off[l][9] = cur; cur += pad64(P.cap[l] / 16); }
+    P.zero_end = cur;
     P.child_begin = cur;
     for (int l = 0; l < P.nl; l++) { P.off[l][4] = cur; cur += pad64(8ll * P.cap[l + 1]); }
     P.child_end = cur;
+    for (int l = 1; l < P.nl; l++) { P.off[l][7] = cur; cur += pad64(8ll * P.cap[l]); }
+    P.ff_end = cur;
     for (int l = 0; l < P.nl; l++) {
         const long long ci = P.cap[l], co = P.cap[l + 1];
         const long long sz[DOWN_FIELDS] = {0, (long long)P.words[l], (long long)(gf_index_scratch_bytes(P.words[l]) + 3) / 4,
                                            4 * co, 0, ci, ci, 8 * ci, co / 16, ci / 16};
         for (int f = 0; f < DOWN_FIELDS; f++) {
-            if (f == 0 || f == 4) continue;
+            if (f == 0 || f == 4 || (l >= 1 && (f == 7 || f == 9))) continue;
             P.off[l][f] = cur;
             cur += pad64(sz[f]);
         }
@@ -545,7 +553,250 @@ int gf_rules_down2_chain_range(const int32_t* coords, int M0, int B, int X, int 
     return GF_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// The same chain with every STAGE as one launch over all levels.  A coarse level's voxel set is a function of the first
+// level's coordinates alone (halve l + 1 times, dropping a voxel at the first level whose cropped grid it leaves), and a
+// level's rows are the set bits of the level above's bitmap in rank order -- so the bitmaps of all levels are set from
+// the first level's rows, scanned side by side, and every level's tables are filled by enumerating the bits of its
+// input bitmap: 6 launches instead of 6 per level (36 dependent launches of 2-9 us each held the second level's
+// convolutions back by ~260 us per forward: profiles/r4_b_forward_full_timeline.txt).  Same tables bit for bit
+// (tests/test_gpu_spconv.py::test_down_rules_chain_bit_exact).
+// ------------------------------------------------------------------------------------
+struct DownAll {
+    int nl, B, M0;
+    int shape[DOWN_MAX_LEVELS + 1][3];
+    int cap[DOWN_MAX_LEVELS + 1];
+    unsigned words[DOWN_MAX_LEVELS];
+    int32_t* f[DOWN_MAX_LEVELS][DOWN_FIELDS];
+    int scan_begin[DOWN_MAX_LEVELS + 1];  // blocks of the popcount / prefix launches, per level
+    int fill_begin[DOWN_MAX_LEVELS + 1];  // blocks of the fill launch
+    int gm_begin[DOWN_MAX_LEVELS + 1];    // blocks of the group-mask launch
+    const int32_t* coords0;
+    int32_t* counts;
+};
+
+__global__ void k_down_bits_all(DownAll A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool valid = i < A.M0;
+    int b = 0, x = 0, y = 0, z = 0;
+    if (valid) {
+        const int4 c = reinterpret_cast<const int4*>(A.coords0)[i];
+        b = c.x; x = c.y; y = c.z; z = c.w;
+    }
+    for (int l = 0; l < A.nl; l++) {
+        x >>= 1; y >>= 1; z >>= 1;
+        const int OX = A.shape[l + 1][0], OY = A.shape[l + 1][1], OZ = A.shape[l + 1][2];
+        valid = valid && x < OX && y < OY && z < OZ;  // dropped for good: candidate output outside out_shape
+        const unsigned long long lin = valid ? (((unsigned long long)b * OX + x) * OY + y) * OZ + z : 0ull;
+        bitmap_set_coalesced((uint32_t*)A.f[l][0], lin, valid);
+    }
+}
+
+__device__ __forceinline__ int down_all_level(const int* begin, int nl, int blk) {
+    int l = 0;
+    while (l + 1 < nl && blk >= begin[l + 1]) l++;
+    return l;
+}
+
+__global__ void k_block_popc_all(DownAll A) {
+    const int l = down_all_level(A.scan_begin, A.nl, blockIdx.x);
+    const uint32_t* bitmap = (const uint32_t*)A.f[l][0];
+    const size_t words = A.words[l];
+    int32_t* block_sums = A.f[l][2];
+    const int blk = blockIdx.x - A.scan_begin[l];
+    size_t base = (size_t)blk * SCAN_WPB + (size_t)threadIdx.x * SCAN_WPT;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_WPT; j++)
+        if (base + j < words) s += __popc(bitmap[base + j]);
+    int tot;
+    block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blk] = tot;
+}
+
+// one block per level: exclusive scan of that level's block sums; the total is the next level's voxel count
+__global__ void k_scan_block_sums_all(DownAll A) {
+    __shared__ int carry_s;
+    const int l = blockIdx.x;
+    const int nblocks = A.scan_begin[l + 1] - A.scan_begin[l];
+    const int32_t* block_sums = A.f[l][2];
+    int32_t* block_off = A.f[l][2] + nblocks;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += SCAN_THREADS) {
+        int i = base + threadIdx.x;
+        int v = i < nblocks ? block_sums[i] : 0;
+        int tot;
+        int ex = block_excl_scan(v, &tot);
+        int carry = carry_s;
+        if (i < nblocks) block_off[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        block_off[nblocks] = carry_s;  // (the slot run_scan keeps the total in)
+        A.counts[l + 1] = carry_s;
+    }
+}
+
+__global__ void k_word_prefix_all(DownAll A) {
+    const int l = down_all_level(A.scan_begin, A.nl, blockIdx.x);
+    const uint32_t* bitmap = (const uint32_t*)A.f[l][0];
+    const size_t words = A.words[l];
+    const int nblocks = A.scan_begin[l + 1] - A.scan_begin[l];
+    const int32_t* block_off = A.f[l][2] + nblocks;
+    int32_t* prefix = A.f[l][1];
+    const int blk = blockIdx.x - A.scan_begin[l];
+    size_t base = (size_t)blk * SCAN_WPB + (size_t)threadIdx.x * SCAN_WPT;
+    int c[SCAN_WPT];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_WPT; j++) {
+        c[j] = (base + j < words) ? __popc(bitmap[base + j]) : 0;
+        s += c[j];
+    }
+    int tot;
+    int ex = block_excl_scan(s, &tot) + block_off[blk];
+#pragma unroll
+    for (int j = 0; j < SCAN_WPT; j++) {
+        if (base + j < words) prefix[base + j] = ex;
+        ex += c[j];
+    }
+}
+
+// what k_down_fill writes for input row i of level l with coordinates (b, x, y, z); `up` rows start as -1 and
+// gmask_up as 0 for the levels below the first (memsets), so only the one live entry / bit is written there
+__device__ __forceinline__ void down_fill_row(const DownAll& A, int l, int i, int b, int x, int y, int z) {
+    const int ox = x >> 1, oy = y >> 1, oz = z >> 1;
+    const int k = ((x & 1) * 2 + (y & 1)) * 2 + (z & 1);
+    const GfIndex oix{(const uint32_t*)A.f[l][0], A.f[l][1], nullptr, A.shape[l + 1][0], A.shape[l + 1][1], A.shape[l + 1][2]};
+    const int r = gf_index_lookup(oix, b, ox, oy, oz);
+    const int ld = A.cap[l + 1], ld_up = A.cap[l];
+    A.f[l][5][i] = r;
+    A.f[l][6][i] = k;
+    if (r >= 0) {
+        A.f[l][4][(size_t)k * ld + r] = i;
+        reinterpret_cast<int4*>(A.f[l][3])[r] = make_int4(b, ox, oy, oz);  // same value from every child
+        A.f[l][7][(size_t)k * ld_up + i] = r;
+        atomicOr((uint32_t*)A.f[l][9] + (i >> 4), 1u << k);
+    }
+}
+
+__global__ void k_down_fill_all(DownAll A) {
+    const int l = down_all_level(A.fill_begin, A.nl, blockIdx.x);
+    const int blk = blockIdx.x - A.fill_begin[l];
+    if (l == 0) {
+        // the first level's rows come in the caller's order: one thread per row, as k_down_fill
+        const int i = blk * blockDim.x + threadIdx.x;
+        const int ld = A.cap[1], ld_up = A.cap[0];
+        uint32_t mask = 0;
+        if (i < A.M0) {
+            const int4 c = reinterpret_cast<const int4*>(A.coords0)[i];
+            const int ox = c.y >> 1, oy = c.z >> 1, oz = c.w >> 1;
+            const int k = ((c.y & 1) * 2 + (c.z & 1)) * 2 + (c.w & 1);
+            const GfIndex oix{(const uint32_t*)A.f[0][0], A.f[0][1], nullptr, A.shape[1][0], A.shape[1][1], A.shape[1][2]};
+            const int r = gf_index_lookup(oix, c.x, ox, oy, oz);
+            A.f[0][5][i] = r;
+            A.f[0][6][i] = k;
+            if (r >= 0) {
+                A.f[0][4][(size_t)k * ld + r] = i;
+                reinterpret_cast<int4*>(A.f[0][3])[r] = make_int4(c.x, ox, oy, oz);
+                mask = 1u << k;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) A.f[0][7][(size_t)kk * ld_up + i] = (kk == k) ? r : -1;
+        } else if (i < ld_up) {
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) A.f[0][7][(size_t)kk * ld_up + i] = -1;
+        }
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) mask |= __shfl_xor(mask, d, 64);
+        if ((threadIdx.x & 15) == 0 && i < ld_up) ((uint32_t*)A.f[0][9])[i >> 4] = mask;
+        return;
+    }
+    // a level below: its rows are the set bits of the level above's output bitmap, in rank order; one thread per word
+    const unsigned w = (unsigned)blk * blockDim.x + threadIdx.x;
+    if (w >= A.words[l - 1]) return;
+    uint32_t word = ((const uint32_t*)A.f[l - 1][0])[w];
+    if (!word) return;
+    int i = A.f[l - 1][1][w];
+    const int SX = A.shape[l][0], SY = A.shape[l][1], SZ = A.shape[l][2];
+    (void)SX;
+    while (word) {
+        const int bit = __builtin_ctz(word);
+        word &= word - 1;
+        unsigned long long lin = (unsigned long long)w * 32 + bit;
+        const int z = (int)(lin % SZ); lin /= SZ;
+        const int y = (int)(lin % SY); lin /= SY;
+        const int x = (int)(lin % SX);
+        const int b = (int)(lin / SX);
+        down_fill_row(A, l, i, b, x, y, z);
+        i++;
+    }
+}
+
+__global__ void k_table_gmask_all(DownAll A) {
+    const int l = down_all_level(A.gm_begin, A.nl, blockIdx.x);
+    const int o = (blockIdx.x - A.gm_begin[l]) * blockDim.x + threadIdx.x;
+    const int ld = A.cap[l + 1];
+    const int32_t* tbl = A.f[l][4];
+    uint32_t mask = 0;
+    if (o < ld)
+        for (int k = 0; k < 8; k++)
+            if (tbl[(size_t)k * ld + o] >= 0) mask |= 1u << k;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) mask |= __shfl_xor(mask, d, 64);
+    if ((threadIdx.x & 15) == 0 && o < ld) ((uint32_t*)A.f[l][8])[o >> 4] = mask;
+}
+
+// dev knob: GF_RULES_SERIAL=1 builds the chain level by level (the round-4 form) for A/B runs
+static int g_rules_serial = -1;
+bool gf_rules_level_parallel() {
+    if (g_rules_serial < 0) {
+        const char* e = getenv("GF_RULES_SERIAL");
+        g_rules_serial = e ? (atoi(e) != 0) : 0;
+    }
+    return g_rules_serial == 0;
+}
+
+int gf_rules_down2_chain_all(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels, int32_t* ws,
+                             int32_t* counts, hipStream_t st) {
+    GF_CHECK_ARG(coords && ws && counts, "gf_rules_down2_chain: null argument");
+    GF_CHECK_ARG(M0 >= 0 && B > 0 && nlevels >= 0 && nlevels <= DOWN_MAX_LEVELS, "gf_rules_down2_chain: bad sizes");
+    DownPlan P;
+    GF_CHECK_ARG(plan_down_chain(M0, B, X, Y, Z, nlevels, P) == 0, "gf_rules_down2_chain: grid too large");
+    if (P.nl == 0 || M0 == 0) return GF_OK;
+    GF_TRY(hipMemsetAsync(ws + P.bitmaps_begin, 0, (size_t)(P.zero_end - P.bitmaps_begin) * 4, st));
+    GF_TRY(hipMemsetAsync(ws + P.child_begin, 0xff, (size_t)(P.ff_end - P.child_begin) * 4, st));
+    DownAll A;
+    A.nl = P.nl; A.B = B; A.M0 = M0; A.coords0 = coords; A.counts = counts;
+    for (int l = 0; l <= P.nl; l++) {
+        A.cap[l] = P.cap[l];
+        for (int a = 0; a < 3; a++) A.shape[l][a] = P.shape[l][a];
+    }
+    A.scan_begin[0] = A.fill_begin[0] = A.gm_begin[0] = 0;
+    for (int l = 0; l < P.nl; l++) {
+        A.words[l] = (unsigned)P.words[l];
+        for (int f = 0; f < DOWN_FIELDS; f++) A.f[l][f] = ws + P.off[l][f];
+        A.scan_begin[l + 1] = A.scan_begin[l] + (int)scan_blocks(P.words[l]);
+        const long long items = l == 0 ? (long long)P.cap[0] : (long long)P.words[l - 1];
+        A.fill_begin[l + 1] = A.fill_begin[l] + gf_div_up(items, 256);
+        A.gm_begin[l + 1] = A.gm_begin[l] + gf_div_up(P.cap[l + 1], 256);
+    }
+    hipLaunchKernelGGL(k_down_bits_all, dim3(gf_div_up(M0, 256)), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_block_popc_all, dim3(A.scan_begin[P.nl]), dim3(SCAN_THREADS), 0, st, A);
+    hipLaunchKernelGGL(k_scan_block_sums_all, dim3(P.nl), dim3(SCAN_THREADS), 0, st, A);
+    hipLaunchKernelGGL(k_word_prefix_all, dim3(A.scan_begin[P.nl]), dim3(SCAN_THREADS), 0, st, A);
+    hipLaunchKernelGGL(k_down_fill_all, dim3(A.fill_begin[P.nl]), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_table_gmask_all, dim3(A.gm_begin[P.nl]), dim3(256), 0, st, A);
+    GF_CHECK_LAUNCH("gf_rules_down2_chain");
+    return GF_OK;
+}
+
 extern "C" int gf_rules_down2_chain(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels,
                                     int32_t* ws, int32_t* counts, void* stream) {
+    if (gf_rules_level_parallel())
+        return gf_rules_down2_chain_all(coords, M0, B, X, Y, Z, nlevels, ws, counts, (hipStream_t)stream);
     return gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nlevels, 0, nlevels, ws, counts, (hipStream_t)stream);
 }

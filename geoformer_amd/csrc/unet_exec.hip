@@ -571,13 +571,21 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         // the whole chain is queued at once (it carries its counts on the device); two events mark the points the
         // host waits for
         if (forked) GF_TRY(hipStreamWaitEvent(ss, t_ev.fork, 0));
-        UN_TRY(gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nl, 0, 1, cws, d_counts, ss));
-        GF_TRY(hipMemcpyAsync(host_counts + 1, d_counts + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ss));
-        GF_TRY(hipEventRecord(t_ev.chain, ss));
-        if (nl > 1) {
-            UN_TRY(gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nl, 1, nl, cws, d_counts, ss));
-            GF_TRY(hipMemcpyAsync(host_counts + 2, d_counts + 2, sizeof(int32_t) * (nl - 1), hipMemcpyDeviceToHost, ss));
-            GF_TRY(hipEventRecord(t_ev.chain2, ss));
+        if (gf_rules_level_parallel()) {
+            // every stage one launch over all levels: all counts and tables are there after six launches
+            UN_TRY(gf_rules_down2_chain_all(coords, M0, B, X, Y, Z, nl, cws, d_counts, ss));
+            GF_TRY(hipMemcpyAsync(host_counts + 1, d_counts + 1, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ss));
+            GF_TRY(hipEventRecord(t_ev.chain, ss));
+            if (nl > 1) GF_TRY(hipEventRecord(t_ev.chain2, ss));
+        } else {
+            UN_TRY(gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nl, 0, 1, cws, d_counts, ss));
+            GF_TRY(hipMemcpyAsync(host_counts + 1, d_counts + 1, sizeof(int32_t), hipMemcpyDeviceToHost, ss));
+            GF_TRY(hipEventRecord(t_ev.chain, ss));
+            if (nl > 1) {
+                UN_TRY(gf_rules_down2_chain_range(coords, M0, B, X, Y, Z, nl, 1, nl, cws, d_counts, ss));
+                GF_TRY(hipMemcpyAsync(host_counts + 2, d_counts + 2, sizeof(int32_t) * (nl - 1), hipMemcpyDeviceToHost, ss));
+                GF_TRY(hipEventRecord(t_ev.chain2, ss));
+            }
         }
         // ---- end of phase A (level 1 and the whole rulebook chain queued): the caller's hand-over BEFORE this call's
         // first host wait -- the hand-over serves another scene's read-back, which must not sit behind a wait for THIS

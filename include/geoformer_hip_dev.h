@@ -93,6 +93,9 @@ int gf_dev_bfs_pipe(int on);
 /* Upper bound of the BFS kernels' LDS queue capacity (entries per level, >= 64; 0 = what the LDS share allows): tests
  * set it so that scene-sized graphs exercise the queues' overflow into global memory. */
 int gf_dev_bfs_qcap_max(int qcap);
+/* Form of the multi-source search's hop (gf_geodesic_bfs_ms): 1 = LDS tiles (k_ms_hop_tile), 0 = plain gather
+ * (k_ms_hop, default), -1 = default / GF_BFS_MS_TILES.  Results are identical. */
+int gf_dev_bfs_ms_tiles(int on);
 
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);

@@ -126,3 +126,75 @@ def test_bfs_duplicates_short_walks_and_dense_ball(hip, oracle):
     geo = geo.cpu().numpy()
     assert (geo[:, off:off + 9000] == ref).all()
     assert (geo[:, :off] == -1).all() and (geo[:, off + 9000:] == -1).all()
+
+
+def _ms_forms(lib):
+    """Both forms of the multi-source hop: the plain gather (default) and LDS tiles (GF_BFS_MS_TILES=1)."""
+    lib.gf_dev_bfs_ms_tiles.argtypes = [__import__("ctypes").c_int]
+    for tiles in (1, 0):
+        lib.gf_dev_bfs_ms_tiles(tiles)
+        yield tiles
+    lib.gf_dev_bfs_ms_tiles(-1)
+
+
+@pytest.mark.parametrize("n,nq,max_step", [(6000, 16, 256), (20000, 64, 128), (20000, 100, 40), (20000, 128, 5),
+                                           (12000, 256, 256), (6000, 300, 64)])
+def test_bfs_multi_source_matches_oracle(hip, oracle, n, nq, max_step):
+    """gf_geodesic_bfs_ms (csrc/geodesic_ms.hip: all queries as bit lanes of cumulative reach masks, one launch per
+    hop) against the oracle, bit for bit, for 1..5 mask words per vertex (nq = 300 takes the runtime-width gather
+    kernel), hop limits that end the search early and late, duplicate sources, and both forms of the hop."""
+    from geoformer_amd import pointops
+
+    xyz = _pts(n, 5 + n)
+    n = xyz.shape[0]  # (the generator returns about the number of points asked for)
+    k, radius = 64, 0.05
+    D, I = _ref_graph(oracle, xyz, k, radius)
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, n, nq)
+    src[-1] = src[0]  # two queries from one vertex
+    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, max_step)
+    gd, gi, deg = pointops.knn_radius(_dev(xyz), k, radius)
+    for tiles in _ms_forms(hip):
+        geo = pointops.geodesic_bfs_ms(gd, gi, _dev(src.astype(np.int32)), radius, max_step).cpu().numpy()
+        assert ((geo >= 0) == (ref >= 0)).all(), tiles
+        assert (geo == ref).all(), tiles
+    # an unsorted, unpadded table (every row the brute-force 64 nearest, beyond the radius too): rows need not be
+    # distance-sorted or radius-limited for this kernel
+    perm = rng.permutation(k - 1) + 1
+    Dp = np.ascontiguousarray(D[:, np.r_[0, perm]].astype(np.float32))
+    Ip = np.ascontiguousarray(I[:, np.r_[0, perm]].astype(np.int32))
+    ref_p = oracle.geodesic(Dp[:, 1:], Ip[:, 1:].astype(np.int64), src, radius, max_step)
+    geo = pointops.geodesic_bfs_ms(_dev(Dp), _dev(Ip), _dev(src.astype(np.int32)), radius, max_step).cpu().numpy()
+    assert (geo == ref_p).all()
+
+
+def test_bfs_multi_source_long_in_lists_and_duplicates(hip, oracle):
+    """In-lists longer than the 16 fixed-width slots (a dense cube: every vertex has ~63 in-neighbours, the rest comes
+    from the reverse CSR), 100 copies of one point, rows whose column 0 is not the vertex itself -- against the oracle,
+    both forms of the hop; and the per-query kernel on the same inputs."""
+    from geoformer_amd import pointops
+
+    k, radius = 64, 0.05
+    rng = np.random.default_rng(9)
+    xyz = (rng.random((9000, 3)) * 0.09).astype(np.float32)
+    D, I = _ref_graph(oracle, xyz, k, radius)
+    inr = D <= np.float32(radius)
+    Dm = np.where(inr, D, np.inf).astype(np.float32)
+    Im = np.where(inr, I, -1).astype(np.int32)
+    src = rng.integers(0, 9000, 70)
+    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 64)
+    for tiles in _ms_forms(hip):
+        geo = pointops.geodesic_bfs_ms(_dev(Dm), _dev(Im), _dev(src.astype(np.int32)), radius, 64).cpu().numpy()
+        assert (geo == ref).all(), tiles
+    xyz = _pts(20000, 77)
+    xyz[1000:1100] = xyz[5]
+    D, I = _ref_graph(oracle, xyz, k, radius)
+    src = rng.integers(0, xyz.shape[0], 48)
+    src[:3] = [5, 1003, 1099]
+    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 256)
+    gd, gi, deg = pointops.knn_radius(_dev(xyz), k, radius)
+    for tiles in _ms_forms(hip):
+        geo = pointops.geodesic_bfs_ms(gd, gi, _dev(src.astype(np.int32)), radius, 256).cpu().numpy()
+        assert (geo == ref).all(), tiles
+    old = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), radius, 256, wg_threads=512).cpu().numpy()
+    assert (old == ref).all()
