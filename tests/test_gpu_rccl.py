@@ -130,15 +130,18 @@ def test_train_dp_step_forced_exchange_matches_plain_step(rccl_group):
     #  receiving a gradient -- covered by the toy test above; here every bucket must have gone through the exchange)
     assert early >= 0
     n_with = 0
+    gmax = max(float(g.abs().max()) for g in g0.values() if g is not None)
     for n in g0:
         assert (g0[n] is None) == (g1[n] is None), n
         if g0[n] is None:
             continue
         n_with += 1
         scale = float(g0[n].abs().max()) + 1e-12
-        assert float((g0[n] - g1[n]).abs().max()) <= 2e-4 * scale + 1e-7, n
+        # (a gradient that is zero in exact arithmetic -- the key bias of a softmax attention -- is round-off on both
+        #  sides: bounded against the step's largest gradient instead of against itself)
+        assert float((g0[n] - g1[n]).abs().max()) <= 2e-4 * scale + 1e-6 * gmax, n
         # the first Adam step moves a weight by lr * g / (|g| + eps): equal wherever the gradient is not round-off itself
-        big = g0[n].abs() > 1e-5 * scale + 1e-9
+        big = g0[n].abs() > 1e-5 * scale + 1e-4 * gmax
         assert float(((p0[n] - p1[n]).abs() * big).max()) <= 2e-5, n
         assert float((p0[n] - p1[n]).abs().max()) <= 2.01e-3, n
     assert n_with > 100
