@@ -83,7 +83,7 @@ def _declare(lib):
         "gf_knn_radius": (I, [P, I, I, F, I, P, P, P, P, P]),
         "gf_knn_error_flag": (P, [P, I]),
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
-        "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, I, P]),
+        "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, P]),
         "gf_geodesic_bfs_queue_words": (c_size_t, [I]),
         "gf_geodesic_ms_scratch_bytes": (c_size_t, [I, I, I, I]),
         "gf_geodesic_bfs_ms": (I, [P, P, I, I, P, I, F, I, P, P, c_size_t, P]),
@@ -214,7 +214,7 @@ def load():
     _check_hw_queues(torch)
     lib = ctypes.CDLL(LIB_PATH)
     EXPORTS = _declare(lib)
-    if lib.gf_abi_version() != 2:
+    if lib.gf_abi_version() != 3:
         raise GeoFormerHipError("libgeoformer_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -1337,12 +1337,18 @@ extern "C" size_t gf_geodesic_bfs_queue_words(int n) {
 // 1024 threads -- one per compute unit -- need a second round, and 512 is the fastest (two queries can share a unit).
 extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K,
                                    const int32_t* src, int nq, float radius, int max_step, float* geo, void* keys_ws,
-                                   void* queue_ws, int wg_threads, void* stream) {
+                                   void* queue_ws, size_t queue_words, int wg_threads, void* stream) {
     GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs: bad arguments");
     GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs: n=%d exceeds the 26-bit parent field", n);
     GF_CHECK_ARG(wg_threads == 1024 || wg_threads == 512 || wg_threads == 256,
                  "gf_geodesic_bfs: wg_threads=%d (256, 512 or 1024)", wg_threads);
     if (nq == 0) return GF_OK;
+    // queue_words: int32 words of queue_ws PER QUERY as the caller allocated them (4 n for the LDS kernel and the
+    // global-memory kernel, 10 n for the pipelined one): checked here, so a workspace sized under another setting of the
+    // GF_BFS_PIPE knob is never overrun -- the pipelined kernel is only taken when its 10 n words are there
+    GF_CHECK_ARG(queue_words >= (size_t)4 * (size_t)n, "gf_geodesic_bfs: queue workspace of %zu words per query, %zu needed",
+                 queue_words, (size_t)4 * (size_t)n);
+    const bool pipe_fits = queue_words >= (size_t)10 * (size_t)n;
     const int nw = (n + 31) / 32;
     const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
     // the two bitmaps must fit the workgroup's LDS share: a large scene moves to the next larger workgroup (and
@@ -1357,7 +1363,7 @@ extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32
         if (g_bfs_qcap_max > 0 && qcap > g_bfs_qcap_max) qcap = g_bfs_qcap_max < 64 ? 64 : g_bfs_qcap_max;
         const size_t lds = bm + (size_t)qcap * 2 * sizeof(int2);
         hipStream_t st = (hipStream_t)stream;
-        if (bfs_pipe_on() && wg_threads >= 512) {
+        if (bfs_pipe_on() && pipe_fits && wg_threads >= 512) {
             if (wg_threads == 512)
                 launch_bfs_pipe<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
             else
@@ -1383,7 +1389,9 @@ extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32
 extern "C" int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src,
                                int nq, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
                                void* stream) {
-    return gf_geodesic_bfs_cfg(D, I, deg, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, 1024, stream);
+    // (the legacy entry's contract: nq * 4 n words)
+    return gf_geodesic_bfs_cfg(D, I, deg, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, (size_t)4 * (size_t)(n > 0 ? n : 0),
+                               1024, stream);
 }
 
 // ------------------------------------------------------------------------------------

@@ -369,9 +369,14 @@ class GeoFormer(nn.Module):
         pointer tables).  They are re-derived automatically when a parameter's version counter changes
         (optimizer steps, load_state_dict, in-place ops); call this after editing parameters through ``.data``,
         which leaves the counter untouched."""
-        from .. import sparse
+        from .. import pointops, sparse
 
         sparse._PACK_CACHE.clear()
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            # the grow-only per-stream scratch blocks too (~0.8 GB per stream after a 150k-point scene): nothing else
+            # returns them; behind a synchronise, since queued kernels may still use them
+            torch.cuda.synchronize()
+            pointops.release_scratch()
         for mod in self.modules():
             for key in ("_gf_chains", "_gf_chain_walks", "_gf_block", "_gf_block_t", "_gf_affine", "_gf_chain",
                         "_gf_chain_walk", "_gf_tr_params", "_gf_fused", "_gf_fused_params", "_wpack_key", "_wpack"):

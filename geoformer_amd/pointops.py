@@ -273,6 +273,24 @@ def scratch(name, numel, dtype, device):
     return t[:numel]
 
 
+def release_scratch(device=None):
+    """Drop the grow-only scratch blocks (of one device, or of all): ~0.8 GB per stream that ran a 150k-point scene
+    (U-Net workspace, BFS keys and queues, mask-head split).  Nothing else frees them -- `torch.cuda.empty_cache()` does
+    not see tensors that are still referenced.  Called by `invalidate_fused_caches()` of the models and by a serving
+    loop's teardown; the caller makes sure no kernel that uses them is still queued (synchronise first)."""
+    if device is not None:
+        dev = torch.device(device)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    for key in list(_SCRATCH):
+        if device is None or key[0] == idx:
+            del _SCRATCH[key]
+
+
+def scratch_bytes():
+    """Bytes the scratch blocks hold right now (all devices and streams)."""
+    return sum(t.numel() * t.element_size() for t in _SCRATCH.values() if t is not None)
+
+
 def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     """geo [nq,n] fp32 for the sources `src` (int32 [nq]) over the kNN rows D/I (column 0 skipped).
     wg_threads: 1024 = one query per compute unit; 256 / 512 = several per unit (to run beside another kernel)."""
@@ -285,9 +303,10 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
     lib = _lib.load()
     keys = scratch("bfs_keys", nq * n, torch.int64, dev)
-    queues = scratch("bfs_queues", nq * int(lib.gf_geodesic_bfs_queue_words(n)), torch.int32, dev)
+    qwords = int(lib.gf_geodesic_bfs_queue_words(n))
+    queues = scratch("bfs_queues", nq * qwords, torch.int32, dev)
     check(lib.gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step),
-                                          ptr(geo), ptr(keys), ptr(queues), int(wg_threads), stream_ptr()),
+                                          ptr(geo), ptr(keys), ptr(queues), qwords, int(wg_threads), stream_ptr()),
           "gf_geodesic_bfs")
     return geo
 

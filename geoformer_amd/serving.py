@@ -124,3 +124,14 @@ class StaggeredForward:
         for lane in self.lanes:
             cur.wait_stream(lane)
         return list(self._done)
+
+    def close(self):
+        """Teardown of a serving loop: drain, wait for the device and return the grow-only per-stream scratch blocks
+        (pointops.release_scratch: ~0.8 GB per lane after a 150k-point scene) to the allocator.  Returns the scenes the
+        drain completed."""
+        from . import pointops
+
+        done = list(self.drain())
+        torch.cuda.synchronize(self.device)
+        pointops.release_scratch(self.device)
+        return done

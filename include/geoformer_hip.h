@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 2
+#define GF_ABI_VERSION 3
 
 typedef enum {
     GF_OK = 0,
@@ -422,10 +422,12 @@ int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n,
                     float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, void* stream);
 /* Same, with the workgroup size per query chosen by the caller: wg_threads = 1024 (one query per compute unit,
  * fastest when the launch has the device to itself), 512 or 256 (several queries share a compute unit, so the
- * launch fits beside another resident kernel -- the host runs it next to furthest point sampling). */
+ * launch fits beside another resident kernel -- the host runs it next to furthest point sampling).
+ * queue_words: int32 words of queue_ws per query as allocated (>= gf_geodesic_bfs_queue_words(n) of the moment of the
+ * allocation; checked: at least 4 n, and the pipelined kernel is only chosen when 10 n are there).  (ABI 3.) */
 int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
-                        float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, int wg_threads,
-                        void* stream);
+                        float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words,
+                        int wg_threads, void* stream);
 
 /* The same search for ALL nq sources at once (csrc/geodesic_ms.hip): the queries are bit lanes of per-vertex frontier /
  * visited masks, a hop is ONE launch over every (vertex, mask word) that walks the vertex's in-neighbours in ascending

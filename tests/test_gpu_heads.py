@@ -596,3 +596,49 @@ def test_decoder_cross_attention_bf16_split_kernel_is_fp32_accurate(hip, B, nq, 
     assert e32 < 1e-4 and e3 < 1e-4, (e32, e3)
     assert e3 <= max(2.0 * e32, 4e-6 * scale), (e32, e3, scale)  # no worse than the fp32 kernel's own rounding
     assert np.abs(outs[0] - outs[1]).max() <= 4e-6 * scale, (np.abs(outs[0] - outs[1]).max(), scale)
+
+
+@pytest.mark.parametrize("N,nq", [(60000, 256), (3001, 33)])
+def test_mask_head_bf16_split_kernel_is_fp32_accurate(hip, N, nq):
+    """The mask head's default path (split=True: the [nq x 16] x [16 x 19] products as bf16 MFMAs over the exact
+    three-piece split of the features, like k_decoder_cross_attn_bf3) against float64 and against the fp32-MFMA path
+    (split=False), at the benchmark's shape (256 queries x 60 000 points) and a ragged one: as close to float64 as the
+    fp32 kernel is, both within the 32-fp32-eps-of-the-largest-magnitude gate of the whole-forward parity tests, and the
+    two paths agree to 4e-6 relative -- so a regression of the split kernel cannot hide inside a widened bound."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(N + nq)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    feat = f32(rng.standard_normal((N, 16)) * 2.0)
+    coords = f32(rng.uniform(-3, 3, (N, 3)))
+    qxyz = coords[rng.integers(0, N, nq)].copy()
+    geo = f32(rng.uniform(0, 5, (nq, N)))
+    geo[rng.uniform(size=geo.shape) < 0.3] = -1.0
+    geo[0] = -1.0
+    w1 = f32(rng.standard_normal((nq, 16, 19)) * 0.5)
+    b1 = f32(rng.standard_normal((nq, 16)))
+    w2 = f32(rng.standard_normal((nq, 16)) * 0.5)
+    b2 = f32(rng.standard_normal(nq))
+    m = geo.max(1)
+    mx = f32(np.sqrt(np.where(m < 0, m.max(), m)))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda().double()  # noqa: E731  (float64 on the device)
+    rel = t(qxyz)[:, None, :] - t(coords)[None]
+    rel = torch.where((t(geo) < 0)[..., None], rel + t(mx)[:, None, None] * torch.sign(rel), rel)
+    ref = torch.empty((nq, N), dtype=torch.float64, device="cuda")
+    for q0 in range(0, nq, 32):  # (chunks: nq x N x 19 doubles would be 2.3 GB)
+        q1 = min(q0 + 32, nq)
+        x = torch.cat([rel[q0:q1], t(feat)[None].expand(q1 - q0, N, 16)], 2)
+        h = torch.relu(torch.einsum("qck,qnk->qnc", t(w1[q0:q1]), x) + t(b1[q0:q1])[:, None, :])
+        ref[q0:q1] = torch.einsum("qc,qnc->qn", t(w2[q0:q1]), h) + t(b2[q0:q1])[:, None]
+    ref = ref.cpu().numpy()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    outs = {}
+    for split in (False, True):
+        outs[split] = pointops.mask_head(d(feat), d(coords), d(geo), d(qxyz), d(mx), d(w1), d(b1), d(w2), d(b2),
+                                         split=split).cpu().numpy()
+    scale = float(np.abs(ref).max())
+    e32, e3 = float(np.abs(outs[False] - ref).max()), float(np.abs(outs[True] - ref).max())
+    eps32 = float(np.finfo(np.float32).eps)
+    assert e32 <= 32 * eps32 * scale and e3 <= 32 * eps32 * scale, (e32, e3, scale)
+    assert e3 <= max(2.0 * e32, 4e-6 * scale), (e32, e3, scale)
+    assert float(np.abs(outs[False] - outs[True]).max()) <= 4e-6 * scale

@@ -1,4 +1,5 @@
 # Dev tool: rocprofv3 kernel trace + stats of bench.py (no CPU leg); summary of the top kernels -> gpurun_out/<tag>/
+export GPU_MAX_HW_QUEUES=16  # (in this shell: under rocprofv3 the profiler brings the GPU up before python starts)
 R=$GRAFT_REPO_ROOT; tag=${1:-bt}; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/$tag; mkdir -p $R/gpurun_out/$tag
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/prof -- python3 $R/bench.py --steps 24 --warmup 8 --no-cpu-baseline --no-secondary > $R/gpurun_out/$tag/bench.log 2>&1

@@ -1,4 +1,5 @@
 # Dev tool: kernel trace of a short bench run + timeline of its last forward.  usage: forward_timeline.sh <tag> [ENV=val ...]
+export GPU_MAX_HW_QUEUES=16  # (in this shell: under rocprofv3 the profiler brings the GPU up before python starts)
 R=$GRAFT_REPO_ROOT; tag=$1; shift
 for kv in "$@"; do export "$kv"; done
 cd /tmp; export TMPDIR=/tmp

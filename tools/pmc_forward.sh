@@ -1,4 +1,5 @@
 # Dev tool: hardware counters of the forward's kernels, one rocprofv3 --pmc pass per counter group over
+export GPU_MAX_HW_QUEUES=16  # (in this shell: under rocprofv3 the profiler brings the GPU up before python starts)
 # tools/prof_forward.py (FETCH_SIZE and WRITE_SIZE do not fit one pass; --pmc is never combined with other trace
 # domains than --kernel-trace).  Kernels are grouped by name and, for the conv kernels, by grid size (= U-Net level).
 #   bash tools/pmc_forward.sh <tag> [regex of kernel names]   -> gpurun_out/<tag>/summary.md

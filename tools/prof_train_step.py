@@ -202,7 +202,7 @@ if os.environ.get("BFSCAP"):
             queues = torch.zeros((nq, 10, n), dtype=torch.int32, device=dev)
             for _ in range(2):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); s.record()
-                check(lib.gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), ptr(keys), ptr(queues), wg, stream_ptr()), "bfs")
+                check(lib.gf_geodesic_bfs_cfg(ptr(D), ptr(I), ptr(deg), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), ptr(keys), ptr(queues), queues.numel() // max(nq, 1), wg, stream_ptr()), "bfs")
                 e.record(); torch.cuda.synchronize()
             t = queues.view(nq, -1)[:, :24].contiguous().view(torch.int64).cpu().numpy().astype(np.float64)
             hops = np.maximum(t[:, 5], 1)

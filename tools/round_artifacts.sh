@@ -1,4 +1,5 @@
 # Dev tool: the round's artifacts in one GPU call: GPU test suite, bench line, rocprofv3 kernel stats of bench.py, per-level
+export GPU_MAX_HW_QUEUES=16  # (in this shell: under rocprofv3 the profiler brings the GPU up before python starts)
 # conv table, forward timeline -> gpurun_out/<tag>/   (copy what is to be judged into profiles/)
 tag=${1:-art}; mkdir -p gpurun_out/$tag
 timeout 900 python -m pytest tests -m gpu -q > gpurun_out/$tag/gputest.txt 2>&1; tail -3 gpurun_out/$tag/gputest.txt

@@ -1,4 +1,5 @@
 # Dev tool: the config-3 training step with the fused BatchNorm pair on and off, then a rocprofv3 kernel-stats pass
+export GPU_MAX_HW_QUEUES=16  # (in this shell: under rocprofv3 the profiler brings the GPU up before python starts)
 R=$GRAFT_REPO_ROOT; tag=${1:-tp}; mkdir -p $R/gpurun_out/$tag; cd $R
 for v in 1 0; do
   GF_FUSED_BN=$v timeout 300 python tools/prof_train_step.py 6 2>&1 | grep "^step" | sed "s/^/GF_FUSED_BN=$v /" | tee -a gpurun_out/$tag/steps.txt

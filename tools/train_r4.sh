@@ -1,4 +1,5 @@
 # Dev tool: the batch-4 training step at the end of round 4: stage times, host-bound check, launch counts, kernel trace + timeline
+export GPU_MAX_HW_QUEUES=16  # (in this shell: under rocprofv3 the profiler brings the GPU up before python starts)
 R=$GRAFT_REPO_ROOT; tag=${1:-r4_trn}; mkdir -p $R/gpurun_out/$tag; cd $R
 PHASES=1 HOSTBOUND=1 OPCOUNT=1 timeout 400 python3 tools/prof_train_step.py 6 > gpurun_out/$tag/phases.txt 2>&1
 BWDNAMES=bwd timeout 300 python3 tools/prof_train_step.py 2 > gpurun_out/$tag/bwdnames.txt 2>&1
