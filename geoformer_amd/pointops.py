@@ -311,10 +311,13 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     return geo
 
 
-def geodesic_bfs_ms(D, I, src, radius, max_step):
+def geodesic_bfs_ms(D, I, src, radius, max_step, xyz=None, return_flag=False):
     """geo [nq,n] fp32 like geodesic_bfs, by the multi-source search (csrc/geodesic_ms.hip: every query a bit lane, one
-    launch per hop over the whole device; bit-identical results)."""
+    launch per hop over the whole device; bit-identical results).  xyz [n,3] (optional): the vertices' coordinates --
+    the search then works in a spatial order with the tile form of the hop."""
     _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
+    if xyz is not None:
+        _f32c(xyz, "xyz")
     n, K = D.shape
     nq = src.shape[0]
     dev = D.device
@@ -325,8 +328,12 @@ def geodesic_bfs_ms(D, I, src, radius, max_step):
     nbytes = int(lib.gf_geodesic_ms_scratch_bytes(n, K, nq, int(max_step)))
     ws = scratch("bfs_ms", nbytes // 8 + 64, torch.int64, dev)
     base = (ws.data_ptr() + 255) & ~255
-    check(lib.gf_geodesic_bfs_ms(ptr(D), ptr(I), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), base,
-                                 nbytes, stream_ptr()), "gf_geodesic_bfs_ms")
+    check(lib.gf_geodesic_bfs_ms(ptr(D), ptr(I), ptr(xyz), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo),
+                                 base, nbytes, stream_ptr()), "gf_geodesic_bfs_ms")
+    if return_flag:
+        # (the one-launch form's time-out word: int32 [1] view into the scratch, valid until the next call on this stream)
+        off = (int(lib.gf_geodesic_ms_error_flag(base, n, K, nq, int(max_step))) - ws.data_ptr()) // 4
+        return geo, ws.view(torch.int32)[off:off + 1]
     return geo
 
 

@@ -434,10 +434,15 @@ int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, in
  * (parent, rank) order -- the first one whose frontier bit is set is the entry cal_geodesic_vectorize keeps
  * (geodesic_utils.py:131-136) -- so results are bit-identical to gf_geodesic_bfs; rows need not be sorted by distance.
  *   D fp32 [n,K], I int32 [n,K] (column 0 skipped), src int32 [nq], geo fp32 [nq,n] out
+ *   xyz fp32 [n,3] or NULL: with the coordinates the search works in a spatial (Morton) order of the vertices and a hop is
+ *   one workgroup per tile of 256 neighbouring vertices with the parents' mask words staged in LDS (same results)
  *   scratch: gf_geodesic_ms_scratch_bytes(n, K, nq, max_step) bytes, 256-byte aligned; scratch_bytes is checked. */
 size_t gf_geodesic_ms_scratch_bytes(int n, int K, int nq, int max_step);
-int gf_geodesic_bfs_ms(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
-                       int max_step, float* geo, void* scratch, size_t scratch_bytes, void* stream);
+/* Device word inside `scratch` that the one-launch form of the search (GF_BFS_MS_PERSIST) sets to 1 when one of its
+ * bounded waits timed out (a workgroup never became resident): the distances of that call are then invalid. */
+const int32_t* gf_geodesic_ms_error_flag(void* scratch, int n, int K, int nq, int max_step);
+int gf_geodesic_bfs_ms(const float* D, const int32_t* I, const float* xyz, int n, int K, const int32_t* src, int nq,
+                       float radius, int max_step, float* geo, void* scratch, size_t scratch_bytes, void* stream);
 
 /* ===================================================================================
  * Mask head (GeoFormer.mask_heads_forward, model/geoformer/geoformer.py:286-324), fused

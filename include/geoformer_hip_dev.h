@@ -96,6 +96,9 @@ int gf_dev_bfs_qcap_max(int qcap);
 /* Form of the multi-source search's hop (gf_geodesic_bfs_ms): 1 = LDS tiles (k_ms_hop_tile), 0 = plain gather
  * (k_ms_hop, default), -1 = default / GF_BFS_MS_TILES.  Results are identical. */
 int gf_dev_bfs_ms_tiles(int on);
+/* 1 = the whole multi-source search as ONE launch of resident tile workgroups that exchange their rows through memory
+ * (k_ms_persist; needs the coordinates), 0 = one launch per hop (default), -1 = default / GF_BFS_MS_PERSIST. */
+int gf_dev_bfs_ms_persist(int on);
 
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);

@@ -30,9 +30,14 @@ for seed, nfg, nq, ms in cases:
     t_old, g_old = timeit(lambda: pointops.geodesic_bfs(gd, gi, deg, src, 0.05, ms, wg_threads=512))
     t_old1k, _ = timeit(lambda: pointops.geodesic_bfs(gd, gi, deg, src, 0.05, ms, wg_threads=1024))
     t_new, g_new = timeit(lambda: pointops.geodesic_bfs_ms(gd, gi, src, 0.05, ms))
-    eq = torch.equal(g_old, g_new)
+    t_til, g_til = timeit(lambda: pointops.geodesic_bfs_ms(gd, gi, src, 0.05, ms, xyz=xyz))
+    lib.gf_dev_bfs_ms_persist(1)
+    t_per, (g_per, flag) = timeit(lambda: pointops.geodesic_bfs_ms(gd, gi, src, 0.05, ms, xyz=xyz, return_flag=True))
+    lib.gf_dev_bfs_ms_persist(-1)
+    print("   one launch (persistent tiles):", round(t_per, 1), "us, timeout flag", int(flag.item()), "equal", torch.equal(g_old, g_per))
+    eq = torch.equal(g_old, g_new) and torch.equal(g_old, g_til)
     hops = int((g_new >= 0).any(0).sum().item())
-    print(f"seed {seed} n {nfg} nq {nq} max_step {ms}: per-query 512thr {t_old:8.1f} us, 1024thr {t_old1k:8.1f} us | multi-source {t_new:8.1f} us"
+    print(f"seed {seed} n {nfg} nq {nq} max_step {ms}: per-query 512thr {t_old:8.1f} us, 1024thr {t_old1k:8.1f} us | multi-source gather {t_new:8.1f} us, spatial tiles {t_til:8.1f} us"
           f" | equal {eq} | mean degree {deg.float().mean().item():.1f} reached/query {(g_new >= 0).sum(1).float().mean().item():.0f}")
     if not eq:
         bad = (g_old != g_new)

@@ -11,5 +11,5 @@ gd, gi, deg = pointops.knn_radius(xyz, 64, 0.05)
 perm = torch.from_numpy(np.random.default_rng(1).permutation(nfg)[:50000]).cuda()
 src = pointops.furthest_point_sampling(xyz[perm][None].contiguous(), nq)[0].int().contiguous()
 for _ in range(3):
-    g = pointops.geodesic_bfs_ms(gd, gi, src, 0.05, ms)
+    g = pointops.geodesic_bfs_ms(gd, gi, src, 0.05, ms, xyz=xyz)
 torch.cuda.synchronize()
