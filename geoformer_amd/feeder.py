@@ -35,7 +35,11 @@ class DeviceFeeder:
     raw_batches: iterable of host batch dicts in ``scene.collate_raw`` layout (a dict that already carries
     ``voxel_locs`` is only uploaded)."""
 
-    def __init__(self, raw_batches, device, mode: int = 4):
+    def __init__(self, raw_batches, device, mode: int = 4, reserve_points=None):
+        """reserve_points: the largest batch (points) the loop will see.  Pinned staging buffers are sized for it at
+        their first allocation, for all three slots: growing one later is a `pin_memory()` of tens of milliseconds in the
+        middle of the loop (bench.py's test_py_shape leg: one 45-55 ms step in sixteen)."""
+        self.reserve_points = int(reserve_points) if reserve_points else 0
         self.src = iter(raw_batches)
         dev = torch.device(device)
         self.device = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
@@ -51,8 +55,17 @@ class DeviceFeeder:
         buf = self.pinned.get((key, self.slot))
         n = t.numel()
         if buf is None or buf.dtype != t.dtype or buf.numel() < n:
-            buf = torch.empty(max(n, 1), dtype=t.dtype).pin_memory()
-            self.pinned[(key, self.slot)] = buf
+            # per-point tensors are sized for the reserve (or 1.3 x this batch), for every slot at once
+            rows = t.shape[0] if t.dim() >= 1 else 1
+            per_row = n // max(rows, 1)
+            cap = max(n, 1)
+            if rows > 1024:
+                cap = max(int(1.3 * n), per_row * self.reserve_points)
+            for sl in range(3):
+                old = self.pinned.get((key, sl))
+                if old is None or old.dtype != t.dtype or old.numel() < cap:
+                    self.pinned[(key, sl)] = torch.empty(cap, dtype=t.dtype).pin_memory()
+            buf = self.pinned[(key, self.slot)]
         view = buf[:n].view(t.shape)
         # numpy's memcpy, not Tensor.copy_: a CPU-side torch copy wakes torch's intra-op thread pool, whose spinning
         # workers slow the launching thread several times over on a many-core host
