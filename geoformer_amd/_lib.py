@@ -87,6 +87,7 @@ def _declare(lib):
         "gf_geodesic_bfs_queue_words": (c_size_t, [I]),
         "gf_geodesic_ms_scratch_bytes": (c_size_t, [I, I, I, I]),
         "gf_geodesic_bfs_ms": (I, [P, P, P, I, I, P, I, F, I, P, P, c_size_t, P]),
+        "gf_geodesic_bfs_ms_sets": (I, [P, P, I, I, P, I, I, P, P, F, I, P, c_size_t, P]),
         "gf_dev_bfs_ms_tiles": (I, [I]),
         "gf_dev_bfs_ms_persist": (I, [I]),
         "gf_geodesic_ms_error_flag": (P, [P, I, I, I, I]),

@@ -212,9 +212,11 @@ typedef unsigned long long ms_word;
 
 // hop 0: R[0][u] = the queries whose source is u (+ the bits beyond nq, which then never read as new);
 // dist[src[q]][q] = 0; row n (the padding parent) stays zero in both buffers
-__global__ __launch_bounds__(MS_THREADS) void k_ms_init(const int32_t* __restrict__ src, int nq, int n, int W, int S,
-                                                        const int32_t* __restrict__ perm, ms_word* __restrict__ R0,
-                                                        ms_word* __restrict__ R1, float* __restrict__ dist_t) {
+// (nsets source sets: bit q has one source per set -- the scenes of a batch, whose graphs do not touch)
+__global__ __launch_bounds__(MS_THREADS) void k_ms_init(const int32_t* __restrict__ src, int nq, int nsets, int n, int W,
+                                                        int S, const int32_t* __restrict__ perm,
+                                                        ms_word* __restrict__ R0, ms_word* __restrict__ R1,
+                                                        float* __restrict__ dist_t) {
     const int t = blockIdx.x * MS_THREADS + threadIdx.x;
     if (t >= (n + 1) * W) return;
     const int u = t / W, w = t - u * W;
@@ -224,7 +226,10 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_init(const int32_t* __restric
         const int uo = perm ? perm[u] : u;  // the vertex this working position holds
         for (int b = 0; b < 64; b++) {
             const int q = q0 + b;
-            if (q < nq && src[q] == uo) {
+            bool hit = false;
+            if (q < nq)
+                for (int k = 0; k < nsets; k++) hit = hit || src[(size_t)k * nq + q] == uo;
+            if (hit) {
                 bits |= 1ull << b;
                 dist_t[(size_t)u * S + q] = 0.0f;
             }
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_check(const ms_word* __restri
 // geo[q][u] = R[u] bit q ? dist[u][q] : -1 : 64 vertices x 64 queries per block through LDS
 __global__ __launch_bounds__(MS_THREADS) void k_ms_transpose(const float* __restrict__ dist_t,
                                                              const ms_word* __restrict__ R, int n, int nq, int W,
-                                                             int S, const int32_t* __restrict__ inv,
+                                                             int S, const int32_t* __restrict__ inv, int u_off,
                                                              float* __restrict__ geo) {
     __shared__ float tile[64][65];
     const int u0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_transpose(const float* __rest
         const int u = u0 + r, q = q0 + tx;
         float val = -1.0f;
         if (u < n && q < nq) {
-            const size_t row = inv ? (size_t)inv[u] : (size_t)u;
+            const size_t row = inv ? (size_t)inv[u + u_off] : (size_t)(u + u_off);  // (n = this set's vertices)
             const ms_word m = R[row * W + (q >> 6)];
             if ((m >> (q & 63)) & 1ull) val = dist_t[row * S + q];
         }
@@ -1070,9 +1075,33 @@ extern "C" size_t gf_geodesic_ms_scratch_bytes(int n, int K, int nq, int max_ste
     return ms_layout(n, K, nq, max_step).total;
 }
 
+static int ms_run(const float* D, const int32_t* I, const float* xyz, int n, int K, const int32_t* src, int nq, int nsets,
+                  const int32_t* set_off, float* const* geos, float radius, int max_step, void* scratch,
+                  size_t scratch_bytes, void* stream);
+
 extern "C" int gf_geodesic_bfs_ms(const float* D, const int32_t* I, const float* xyz, int n, int K, const int32_t* src,
                                   int nq, float radius, int max_step, float* geo, void* scratch, size_t scratch_bytes,
                                   void* stream) {
+    const int32_t off[2] = {0, n};
+    float* geos[1] = {geo};
+    return ms_run(D, I, xyz, n, K, src, nq, 1, off, geos, radius, max_step, scratch, scratch_bytes, stream);
+}
+
+// Several graphs that do not touch (the scenes of a batch) searched together: D / I are the scenes' rows concatenated,
+// the indices in I GLOBAL (scene offset added); src int32 [nsets][nq] global vertex ids; set_off host int32 [nsets + 1];
+// geos host array of nsets device pointers, geos[k] fp32 [nq][set_off[k+1] - set_off[k]].  One hop launch serves all.
+extern "C" int gf_geodesic_bfs_ms_sets(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, int nsets,
+                                       const int32_t* set_off, float* const* geos, float radius, int max_step,
+                                       void* scratch, size_t scratch_bytes, void* stream) {
+    GF_CHECK_ARG(nsets >= 1 && nsets <= 64 && set_off && geos && set_off[0] == 0 && set_off[nsets] == n,
+                 "gf_geodesic_bfs_ms_sets: bad set table");
+    return ms_run(D, I, nullptr, n, K, src, nq, nsets, set_off, geos, radius, max_step, scratch, scratch_bytes, stream);
+}
+
+static int ms_run(const float* D, const int32_t* I, const float* xyz, int n, int K, const int32_t* src, int nq, int nsets,
+                  const int32_t* set_off, float* const* geos, float radius, int max_step, void* scratch,
+                  size_t scratch_bytes, void* stream) {
+    float* geo = geos[0];
     GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs_ms: bad arguments");
     GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs_ms: n=%d exceeds the 26-bit parent field", n);
     if (nq == 0) return GF_OK;
@@ -1145,8 +1174,8 @@ extern "C" int gf_geodesic_bfs_ms(const float* D, const int32_t* I, const float*
         hipLaunchKernelGGL(k_ms_nbr, dim3(gf_div_up(L.tiles, MS_THREADS)), dim3(MS_THREADS), 0, st, (const uint32_t*)adj,
                            L.adj_words, L.tiles, nbr, nnbr);
     const size_t tile_lds = (size_t)(MS_ZROW + 1) * W * sizeof(ms_word) + (size_t)MS_HCAP * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_ms_init, dim3(gf_div_up((long long)(n + 1) * W, MS_THREADS)), dim3(MS_THREADS), 0, st, src, nq, n,
-                       W, S, (const int32_t*)perm, R[0], R[1], dist_t);
+    hipLaunchKernelGGL(k_ms_init, dim3(gf_div_up((long long)(n + 1) * W, MS_THREADS)), dim3(MS_THREADS), 0, st, src, nq,
+                       nsets, n, W, S, (const int32_t*)perm, R[0], R[1], dist_t);
     const int grid = (gf_div_up((long long)n * W, MS_THREADS) + 7) & ~7;  // (a multiple of 8: k_ms_hop's XCD mapping)
     if (persist) {
         GF_TRY(hipMemsetAsync(hopc, 0, (size_t)L.tiles * 4, st));
@@ -1191,8 +1220,14 @@ extern "C" int gf_geodesic_bfs_ms(const float* D, const int32_t* I, const float*
         }
     }
     // (a search that ended early left both buffers equal; otherwise the last hop wrote R[max_step & 1])
-    hipLaunchKernelGGL(k_ms_transpose, dim3(gf_div_up(n, 64), gf_div_up(nq, 64)), dim3(MS_THREADS), 0, st, dist_t,
-                       (const ms_word*)R[max_step & 1], n, nq, W, S, (const int32_t*)inv, geo);
+    for (int k = 0; k < nsets; k++) {
+        const int nk = set_off[k + 1] - set_off[k];
+        if (nk <= 0) continue;
+        GF_CHECK_ARG(geos[k] != nullptr, "gf_geodesic_bfs_ms: null output");
+        hipLaunchKernelGGL(k_ms_transpose, dim3(gf_div_up(nk, 64), gf_div_up(nq, 64)), dim3(MS_THREADS), 0, st, dist_t,
+                           (const ms_word*)R[max_step & 1], nk, nq, W, S, (const int32_t*)inv, set_off[k], geos[k]);
+    }
+    (void)geo;
     GF_CHECK_LAUNCH("gf_geodesic_bfs_ms");
     return GF_OK;
 }

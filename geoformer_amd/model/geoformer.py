@@ -580,6 +580,8 @@ class GeoFormer(nn.Module):
         multi = batch_size > 1 and early is None and not epilogue and os.environ.get("GF_SCENE_STREAMS", "1") != "0"
         scene_streams = []
         bfs_one_stream = multi and os.environ.get("GF_TRAIN_BFS_STREAMS", "scene") == "one"
+        bfs_batched = multi and nq >= 32 and os.environ.get("GF_TRAIN_BFS_BATCHED", "0") == "1"
+        bfs_pending = []
 
         def host_draw(b, n_b):
             """The reference's host draw of scene b (same values, same generator state), restated natively, into a pinned
@@ -671,16 +673,21 @@ class GeoFormer(nn.Module):
                     grid_done.record(aux)
                 grid = (grid, grid_done)
             # (the BFS waits for the query picks only -- not for the rest of the sampling queued behind them)
-            side_b.wait_event(first_ready)
-            with torch.cuda.stream(side_b):
-                D, I, deg = graphs[b][:3]
-                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), 1 if bfs_one_stream else batch_size) if split else 1024)
-                g.record_stream(main)
-                src.record_stream(side_b)
-                geo[b] = g
-                ev = torch.cuda.Event()
-                ev.record(side_b)
-                geo_ready[b] = ev
+            if bfs_batched:
+                # a training batch: the scenes' searches go out together, as ONE multi-source search (below)
+                g = None
+                bfs_pending.append((b, src, first_ready))
+            else:
+                side_b.wait_event(first_ready)
+                with torch.cuda.stream(side_b):
+                    D, I, deg = graphs[b][:3]
+                    g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), 1 if bfs_one_stream else batch_size) if split else 1024)
+                    g.record_stream(main)
+                    src.record_stream(side_b)
+                    geo[b] = g
+                    ev = torch.cuda.Event()
+                    ev.record(side_b)
+                    geo_ready[b] = ev
             if multi:
                 for t in (xyz_b, idx, first, sampling_indices):
                     if t is not None:
@@ -693,6 +700,22 @@ class GeoFormer(nn.Module):
             # small launches that only need the distances / the query picks ride beside the sampling instead of
             # sitting between the decoder and the mask head on the main stream
             self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready)
+        if bfs_pending:
+            # all scenes of the batch as one multi-source search (csrc/geodesic_ms.hip: the queries are bit lanes, a hop
+            # is one launch whatever the number of vertices): 128 hops x ~11 us for four scenes against four per-query
+            # launches of ~5 ms each that fight for the compute units
+            for _, _, ev in bfs_pending:
+                side.wait_event(ev)
+            with torch.cuda.stream(side):
+                gs = pointops.geodesic_bfs_ms_batch([graphs[b][:2] for b, _, _ in bfs_pending],
+                                                    [sr for _, sr, _ in bfs_pending], 0.05, max_step)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                for (b, sr, _), g in zip(bfs_pending, gs):
+                    g.record_stream(main)
+                    sr.record_stream(side)
+                    geo[b] = g
+                    geo_ready[b] = ev
         for sb in scene_streams:
             main.wait_stream(sb)
         # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)

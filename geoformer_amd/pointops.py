@@ -337,6 +337,39 @@ def geodesic_bfs_ms(D, I, src, radius, max_step, xyz=None, return_flag=False):
     return geo
 
 
+def geodesic_bfs_ms_batch(graphs, srcs, radius, max_step):
+    """The multi-source search over several scenes at once (a training batch): graphs = [(D_b [n_b,K], I_b [n_b,K]), ...],
+    srcs = [int32 [nq], ...] local vertex ids.  Returns [geo_b fp32 [nq, n_b], ...].  One hop launch serves all scenes:
+    the search's cost is per hop, not per vertex."""
+    import ctypes
+
+    import numpy as np
+
+    nb = len(graphs)
+    K = graphs[0][0].shape[1]
+    nq = srcs[0].shape[0]
+    dev = graphs[0][0].device
+    sizes = [int(g[0].shape[0]) for g in graphs]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    n = int(offs[-1])
+    geos = [torch.empty((nq, s), dtype=torch.float32, device=dev) for s in sizes]
+    if n == 0 or nq == 0:
+        return geos
+    D = torch.cat([g[0] for g in graphs])
+    I = torch.cat([torch.where(g[1] >= 0, g[1] + int(offs[b]), g[1]) for b, g in enumerate(graphs)])
+    src = torch.stack([s.int() + int(offs[b]) for b, s in enumerate(srcs)]).contiguous()
+    lib = _lib.load()
+    nbytes = int(lib.gf_geodesic_ms_scratch_bytes(n, K, nq, int(max_step)))
+    ws = scratch("bfs_ms", nbytes // 8 + 64, torch.int64, dev)
+    base = (ws.data_ptr() + 255) & ~255
+    gp = (ctypes.c_void_p * nb)(*[g.data_ptr() for g in geos])
+    check(lib.gf_geodesic_bfs_ms_sets(ptr(D), ptr(I), n, K, ptr(src), nq, nb, offs.ctypes.data, ctypes.cast(gp, ctypes.c_void_p),
+                                      float(radius), int(max_step), base, nbytes, stream_ptr()), "gf_geodesic_bfs_ms_sets")
+    for t in (D, I, src):
+        t.record_stream(torch.cuda.current_stream(dev))
+    return geos
+
+
 # ---- fused heads -------------------------------------------------------------------------
 def _mask_head_split_ws(N, device, split):
     """Scratch for the features' three bf16 pieces (gf_mask_head_episodes: fp32-accurate products on the bf16 matrix

@@ -438,6 +438,12 @@ int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, in
  *   one workgroup per tile of 256 neighbouring vertices with the parents' mask words staged in LDS (same results)
  *   scratch: gf_geodesic_ms_scratch_bytes(n, K, nq, max_step) bytes, 256-byte aligned; scratch_bytes is checked. */
 size_t gf_geodesic_ms_scratch_bytes(int n, int K, int nq, int max_step);
+/* Several graphs that do not touch (the scenes of a batch) in one search: D / I = the scenes' rows concatenated, I holding
+ * GLOBAL vertex ids; src int32 [nsets][nq] global ids (bit q has one source per set); set_off HOST int32 [nsets + 1];
+ * geos HOST array of nsets device pointers, geos[k] fp32 [nq][set_off[k+1] - set_off[k]].  Scratch as for n vertices. */
+int gf_geodesic_bfs_ms_sets(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, int nsets,
+                            const int32_t* set_off, float* const* geos, float radius, int max_step, void* scratch,
+                            size_t scratch_bytes, void* stream);
 /* Device word inside `scratch` that the one-launch form of the search (GF_BFS_MS_PERSIST) sets to 1 when one of its
  * bounded waits timed out (a workgroup never became resident): the distances of that call are then invalid. */
 const int32_t* gf_geodesic_ms_error_flag(void* scratch, int n, int K, int nq, int max_step);

@@ -198,3 +198,37 @@ def test_bfs_multi_source_long_in_lists_and_duplicates(hip, oracle):
         assert (geo == ref).all(), tiles
     old = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), radius, 256, wg_threads=512).cpu().numpy()
     assert (old == ref).all()
+
+
+def test_bfs_multi_source_one_launch_and_batched_scenes(hip, oracle):
+    """The two further forms of the multi-source search against the oracle: (i) ONE launch of resident tile workgroups
+    that exchange their rows through memory (GF_BFS_MS_PERSIST; spatial working order from the coordinates; its bounded
+    waits must not time out), (ii) several scenes searched together (gf_geodesic_bfs_ms_sets: one hop launch serves all
+    scenes of a batch)."""
+    from geoformer_amd import pointops
+
+    hip.gf_dev_bfs_ms_persist.argtypes = [__import__("ctypes").c_int]
+    k, radius = 64, 0.05
+    graphs, srcs, refs, xyzs = [], [], [], []
+    for n, nq_seed in ((20000, 3), (9000, 4), (14000, 5)):
+        xyz = _pts(n, 31 + n)
+        n = xyz.shape[0]
+        D, I = _ref_graph(oracle, xyz, k, radius)
+        src = np.random.default_rng(nq_seed).integers(0, n, 128)
+        refs.append(oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 96))
+        gd, gi, deg = pointops.knn_radius(_dev(xyz), k, radius)
+        graphs.append((gd, gi)); srcs.append(_dev(src.astype(np.int32))); xyzs.append(_dev(xyz))
+    hip.gf_dev_bfs_ms_persist(1)
+    try:
+        for (gd, gi), src, xyz, ref in zip(graphs, srcs, xyzs, refs):
+            geo, flag = pointops.geodesic_bfs_ms(gd, gi, src, radius, 96, xyz=xyz, return_flag=True)
+            assert int(flag.item()) == 0, "a wait of the one-launch search timed out"
+            assert (geo.cpu().numpy() == ref).all()
+    finally:
+        hip.gf_dev_bfs_ms_persist(-1)
+    # the Morton working order with one launch per hop (tiles)
+    geo = pointops.geodesic_bfs_ms(graphs[0][0], graphs[0][1], srcs[0], radius, 96, xyz=xyzs[0])
+    assert (geo.cpu().numpy() == refs[0]).all()
+    geos = pointops.geodesic_bfs_ms_batch(graphs, srcs, radius, 96)
+    for g, ref in zip(geos, refs):
+        assert (g.cpu().numpy() == ref).all()
