@@ -730,6 +730,14 @@ def secondary_test_py_loops(model, batches, dev, args):
         # the second leg lets the 40 best-scored proposals of a scene through (threshold 0, top 40, NMS cut 0) so that
         # the NMS and the copy of the picked masks move a trained net's kind of volume
         model.cfg.TEST_SCORE_THRESH = 0.0 if forced else cfg_thresh
+        if forced:
+            # (one-time costs of the NMS path -- the intersection kernel's scratch, the framework's sort / matmul set-up --
+            #  stay out: the two untimed scenes below may pass no proposal at all)
+            wm = (torch.rand((40, int(1.3 * args.points)), device=dev) < 0.01).int()
+            postprocess.matrix_non_max_suppression(wm, torch.rand(40, device=dev), torch.randint(4, 13, (40,), device=dev),
+                                                   final_score_thresh=0.0)
+            wm[:8].cpu()
+            del wm
         picked, nsteps, t1 = 0, 0, None
         per_step = []
         try:
