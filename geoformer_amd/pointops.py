@@ -297,7 +297,7 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
     n, K = D.shape
     nq = src.shape[0]
-    if os.environ.get("GF_BFS_MS", "0") == "1" and nq >= 32:
+    if os.environ.get("GF_BFS_MS", "0") == "1" and nq >= 32 and n >= int(os.environ.get("GF_BFS_MS_MIN_N", "0")):
         return geodesic_bfs_ms(D, I, src, radius, max_step)
     dev = D.device
     geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
