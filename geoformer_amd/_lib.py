@@ -79,17 +79,22 @@ def _declare(lib):
         "gf_fps_scratch_bytes": (c_size_t, [I]),
         "gf_furthest_point_sampling": (I, [P, I, I, I, P, P, P]),
         "gf_furthest_point_sampling_resume": (I, [P, I, I, I, I, P, P, P]),
+        "gf_fps_scratch_reset": (I, [P, I, P]),
+        "gf_fps_gate_word": (P, [P, I]),
+        "gf_furthest_point_sampling_gated": (I, [P, I, I, P, P, I, I, P]),
         "gf_knn_scratch_bytes": (c_size_t, [I]),
         "gf_knn_radius": (I, [P, I, I, F, I, P, P, P, P, P]),
         "gf_knn_error_flag": (P, [P, I]),
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
         "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, P]),
+        "gf_geodesic_bfs_gated": (I, [P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, P, I, P, P]),
         "gf_geodesic_bfs_queue_words": (c_size_t, [I]),
         "gf_geodesic_ms_scratch_bytes": (c_size_t, [I, I, I, I]),
         "gf_geodesic_bfs_ms": (I, [P, P, P, I, I, P, I, F, I, P, P, c_size_t, P]),
         "gf_geodesic_bfs_ms_sets": (I, [P, P, I, I, P, I, I, P, P, F, I, P, c_size_t, P]),
         "gf_dev_bfs_ms_tiles": (I, [I]),
         "gf_dev_bfs_ms_persist": (I, [I]),
+        "gf_dev_fps_lds_pad": (I, [I]),
         "gf_geodesic_ms_error_flag": (P, [P, I, I, I, I]),
         "gf_dev_bfs_pipe": (I, [I]),
         "gf_dev_cross_attn_bf3": (I, [I]),
@@ -217,7 +222,7 @@ def load():
     _check_hw_queues(torch)
     lib = ctypes.CDLL(LIB_PATH)
     EXPORTS = _declare(lib)
-    if lib.gf_abi_version() != 3:
+    if lib.gf_abi_version() != 4:
         raise GeoFormerHipError("libgeoformer_hip.so ABI version mismatch")
     _lib = lib
     return lib

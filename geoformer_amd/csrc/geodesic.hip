@@ -560,9 +560,15 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                                                                   const int32_t* __restrict__ src, float radius,
                                                                   int max_step, float* __restrict__ geo,
                                                                   unsigned long long* __restrict__ keys,
-                                                                  int2* __restrict__ queues, int qcap) {
+                                                                  int2* __restrict__ queues, int qcap,
+                                                                  const int* __restrict__ gate, int gate_at,
+                                                                  int* __restrict__ gate_err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_cnt[2];  // next-frontier counters of even / odd hops (reset a hop ahead: one barrier less)
+    __shared__ int s_src;
+#ifdef BFS_PRIO
+    __builtin_amdgcn_s_setprio(BFS_PRIO);
+#endif
     const int nw = (n + 31) >> 5;
     unsigned* visited = reinterpret_cast<unsigned*>(smem);
     unsigned* touched = visited + nw;
@@ -582,8 +588,31 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
         visited[t] = 0u;
         touched[t] = 0u;
     }
-    const int s = src[q];
-    __syncthreads();
+    int s;
+    if (gate) {
+        // The sources are still being drawn: src is the output of a sampling launch that runs BESIDE this one
+        // (gf_furthest_point_sampling_gated) and publishes gate[0] = picks stored, behind a release fence, once the first
+        // gate_at of them are there.  The distance / key rows above are initialised meanwhile.  The wait is bounded
+        // (one second of the 100 MHz wall clock): on a time-out the flag word is set and the search runs on whatever
+        // the source slot holds -- an error the host reads back, never a hang.
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_at) {
+                __builtin_amdgcn_s_sleep(64);
+                if (wall_clock64() - t0 > 100000000ull) {
+                    atomicExch(gate_err, 1);
+                    break;
+                }
+            }
+            int v = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_src = min(max(v, 0), n - 1);
+        }
+        __syncthreads();
+        s = s_src;
+    } else {
+        s = src[q];
+        __syncthreads();
+    }
     if (tid == 0) {
         g[s] = 0.0f;
         visited[s >> 5] = 1u << (s & 31);
@@ -1278,7 +1307,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 512 ? BFS_PIPE_WPS : 4) void k_
 template <int THREADS>
 static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, const int32_t* I, int n, int K,
                            const int32_t* src, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
-                           int qcap) {
+                           int qcap, const int* gate = nullptr, int gate_at = 0, int* gate_err = nullptr) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_geodesic_bfs_lds<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1286,7 +1315,7 @@ static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, c
         attr_set = true;
     }
     GF_LAUNCH_OP(GF_OP_BFS, k_geodesic_bfs_lds<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
-                 geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
+                 geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap, gate, gate_at, gate_err);
 }
 template <int THREADS>
 static void launch_bfs_pipe(int nq, size_t lds, hipStream_t st, const float* D, const int32_t* I, int n, int K,
@@ -1335,13 +1364,34 @@ extern "C" size_t gf_geodesic_bfs_queue_words(int n) {
 // more threads per query is faster when the launch has the chip to itself (S150k eval graphs, 256 queries: 1.06 ms at
 // 1024, 1.25 ms at 512, 2.0 ms at 256).  Beside furthest point sampling (13 compute units busy) the 256 queries at
 // 1024 threads -- one per compute unit -- need a second round, and 512 is the fastest (two queries can share a unit).
+static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
+                   float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
+                   const int* gate, int gate_at, int* gate_err, void* stream);
 extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K,
                                    const int32_t* src, int nq, float radius, int max_step, float* geo, void* keys_ws,
                                    void* queue_ws, size_t queue_words, int wg_threads, void* stream) {
+    return bfs_cfg(D, I, deg, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads, nullptr, 0,
+                   nullptr, stream);
+}
+// The search launched BESIDE the sampling launch that is still drawing its sources (gf_furthest_point_sampling_gated):
+// every workgroup initialises its rows, then waits (bounded: one second) until gate[0] >= gate_at and reads its source
+// with an agent-scope load.  gate_err[0] is set to 1 by a workgroup that timed out (zero it before the launch).  Only the
+// LDS-resident kernel has the wait: a graph it cannot take (n > 2^19, K % 4 != 0) is refused.
+extern "C" int gf_geodesic_bfs_gated(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
+                                     int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words,
+                                     int wg_threads, const int* gate, int gate_at, int* gate_err, void* stream) {
+    GF_CHECK_ARG(gate && gate_err && gate_at >= 1, "gf_geodesic_bfs_gated: gate=%p gate_err=%p gate_at=%d", (const void*)gate,
+                 (void*)gate_err, gate_at);
+    return bfs_cfg(D, I, nullptr, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads, gate,
+                   gate_at, gate_err, stream);
+}
+static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
+                   float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
+                   const int* gate, int gate_at, int* gate_err, void* stream) {
     GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs: bad arguments");
     GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs: n=%d exceeds the 26-bit parent field", n);
-    GF_CHECK_ARG(wg_threads == 1024 || wg_threads == 512 || wg_threads == 256,
-                 "gf_geodesic_bfs: wg_threads=%d (256, 512 or 1024)", wg_threads);
+    GF_CHECK_ARG(wg_threads == 1024 || wg_threads == 768 || wg_threads == 512 || wg_threads == 256,
+                 "gf_geodesic_bfs: wg_threads=%d (256, 512, 768 or 1024)", wg_threads);
     if (nq == 0) return GF_OK;
     // queue_words: int32 words of queue_ws PER QUERY as the caller allocated them (4 n for the LDS kernel and the
     // global-memory kernel, 10 n for the pipelined one): checked here, so a workspace sized under another setting of the
@@ -1353,7 +1403,8 @@ extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32
     const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
     // the two bitmaps must fit the workgroup's LDS share: a large scene moves to the next larger workgroup (and
     // share) before it gives up the LDS-resident kernel altogether
-    while (wg_threads < 1024 && bm + 256 * 2 * sizeof(int2) > (size_t)BFS_LDS_BYTES * wg_threads / 1024) wg_threads *= 2;
+    while (wg_threads < 1024 && bm + 256 * 2 * sizeof(int2) > (size_t)BFS_LDS_BYTES * wg_threads / 1024)
+        wg_threads = wg_threads == 768 ? 1024 : wg_threads * 2;
     const size_t budget = (size_t)BFS_LDS_BYTES * wg_threads / 1024;
     if (n <= BFS_LDS_MAX_N && (K & 3) == 0 && bm + 64 * 2 * sizeof(int2) <= budget) {
         // rows must be distance-sorted and padded with (inf,-1) (gf_knn_radius / faiss order): the
@@ -1363,7 +1414,7 @@ extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32
         if (g_bfs_qcap_max > 0 && qcap > g_bfs_qcap_max) qcap = g_bfs_qcap_max < 64 ? 64 : g_bfs_qcap_max;
         const size_t lds = bm + (size_t)qcap * 2 * sizeof(int2);
         hipStream_t st = (hipStream_t)stream;
-        if (bfs_pipe_on() && pipe_fits && wg_threads >= 512) {
+        if (!gate && bfs_pipe_on() && pipe_fits && (wg_threads == 512 || wg_threads == 1024)) {
             if (wg_threads == 512)
                 launch_bfs_pipe<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
             else
@@ -1372,14 +1423,21 @@ extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32
             return GF_OK;
         }
         if (wg_threads == 256)
-            launch_bfs_lds<256>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
+            launch_bfs_lds<256>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
+                                 gate_err);
         else if (wg_threads == 512)
-            launch_bfs_lds<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
+            launch_bfs_lds<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
+                                 gate_err);
+        else if (wg_threads == 768)
+            launch_bfs_lds<768>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
+                                 gate_err);
         else
-            launch_bfs_lds<1024>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
+            launch_bfs_lds<1024>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
+                                 gate_err);
         GF_CHECK_LAUNCH("gf_geodesic_bfs");
         return GF_OK;
     }
+    GF_CHECK_ARG(!gate, "gf_geodesic_bfs_gated: n=%d K=%d needs the global-memory kernel, which has no gate", n, K);
     hipLaunchKernelGGL(k_geodesic_bfs, dim3(nq), dim3(BFS_THREADS), 0, (hipStream_t)stream, D, I, deg, n, K, src,
                        radius, max_step, geo, (unsigned*)keys_ws, (int32_t*)queue_ws);
     GF_CHECK_LAUNCH("gf_geodesic_bfs");

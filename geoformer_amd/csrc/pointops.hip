@@ -359,6 +359,20 @@ __device__ __forceinline__ void fps_static_for(F&& f) {
 #ifndef FPS_K
 #define FPS_K 16      // upper bound of the picks one exchange can deliver
 #endif
+#ifndef FPS_PIPE
+#define FPS_PIPE 1    // 1: wave 0 of a workgroup replays the exchanges and the point-holding waves absorb the picks of an
+#endif                //    exchange WHILE it does (below); the waves that share wave 0's SIMD (wave id % 4 == 0) hold no
+                      //    points: anything they issued would delay the replay's dependent chain by an issue slot per
+                      //    instruction (measured: 580 -> 950 cycles per pick).  0: every wave holds points, picks
+                      //    absorbed after the exchange.
+#define FPS_PW (FPS_PIPE ? FPS_WAVES - FPS_WAVES / 4 : FPS_WAVES)  // waves of a workgroup that hold points
+#ifndef FPS_POLL_SLEEP
+#define FPS_POLL_SLEEP 4  // x 64 cycles between two looks at the mailbox (1: the sampler alone 1 % faster, a search workgroup
+                          // on the same compute unit 4 % slower -- and the search is the longer launch of the forward)
+#endif
+#ifndef FPS_PACKED
+#define FPS_PACKED 0  // 1: the absorb step on packed fp32 instructions (two points per instruction)
+#endif
 #define FPS_NG (FPS_MAXG * FPS_KPUB / 64)  // granules a lane gathers
 #define FPS_TAG (1ull << 63)
 
@@ -411,23 +425,72 @@ extern "C" int gf_dev_fps_trace(void* p) {
 // 2047 cross-CU exchanges shrinks to ~370.  Each level (lane -> wave -> workgroup -> grid) forwards
 // a sorted prefix of its candidates with the last one flagged, and merging stops after consuming a
 // flagged entry (the source's next one is unknown), which keeps the result exact.
+// one pick absorbed by a lane's P points: tmp = min(tmp, |p - a|^2) in the reference's operation order
+// (dx*dx, then fma dy, then fma dz).  Two points per instruction where the ISA has packed fp32 (v_pk_add / v_pk_mul /
+// v_pk_fma_f32 are element-wise IEEE operations: same bits), the minimum per element.
+// LDS mailbox accesses of the pipelined absorb: relaxed workgroup-scope atomics keep the LDS address space (a volatile
+// access through a cast pointer becomes a FLAT instruction with sc0 sc1: +360 cycles per pick in the replay), the empty asm
+// keeps the compiler from reordering them, and the LDS executes one wave's instructions in order.
+#define FPS_LDS_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FPS_LDS_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FPS_ORDER() asm volatile("" ::: "memory")
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
 template <int P>
-__global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict__ xyz, int n, int m, int m0, int G,
+__device__ __forceinline__ void fps_absorb(const float (&px)[P], const float (&py)[P], const float (&pz)[P], float (&tmp)[P],
+                                           float ax, float ay, float az) {
+#if FPS_PACKED
+    const fps_f2 a2x = {ax, ax}, a2y = {ay, ay}, a2z = {az, az};
+#pragma unroll
+    for (int i = 0; i + 1 < P; i += 2) {
+        const fps_f2 dx = fps_f2{px[i], px[i + 1]} - a2x, dy = fps_f2{py[i], py[i + 1]} - a2y, dz = fps_f2{pz[i], pz[i + 1]} - a2z;
+        const fps_f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        tmp[i] = fminf(d.x, tmp[i]);
+        tmp[i + 1] = fminf(d.y, tmp[i + 1]);
+    }
+    if (P & 1) {
+        const float dx = px[P - 1] - ax, dy = py[P - 1] - ay, dz = pz[P - 1] - az;
+        tmp[P - 1] = fminf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), tmp[P - 1]);
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const float dx = px[i] - ax, dy = py[i] - ay, dz = pz[i] - az;
+        tmp[i] = fminf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), tmp[i]);
+    }
+#endif
+}
+
+#ifdef FPS_NUM_VGPR  // dev knob: a register cap, so that the workgroup fits beside another kernel's on its compute unit
+#define FPS_VGPR_CAP __attribute__((amdgpu_num_vgpr(FPS_NUM_VGPR)))
+#else
+#define FPS_VGPR_CAP
+#endif
+template <int P>
+__global__ __launch_bounds__(FPS_WAVES * 64) FPS_VGPR_CAP void k_fps(const float* __restrict__ xyz, int n, int m, int m0, int G,
                                                         int bs_log2, int batch0,
                                                         unsigned long long* __restrict__ slots,
-                                                        int32_t* __restrict__ idxs, int* __restrict__ err) {
+                                                        int32_t* __restrict__ idxs, int* __restrict__ err,
+                                                        int* __restrict__ gate, int gate_at) {
     static_assert(FPS_NG >= 1 && FPS_NG * 64 == FPS_MAXG * FPS_KPUB && FPS_KPUB <= FPS_K && FPS_WAVES * 2 <= 64,
                   "lane mappings of the exchange");
     __shared__ unsigned long long s_part[2][FPS_WAVES * 2];
     __shared__ int s_pick[2][FPS_K + 1];
     __shared__ float s_xyz[2][FPS_K * 3];
+    __shared__ unsigned s_prog[2];  // (FPS_PIPE) progress of the exchange being replayed: round << 8 | 0x80 (complete) | picks
     const int bi = batch0 + blockIdx.y, wg = blockIdx.x;
     xyz += (size_t)bi * n * 3;
     idxs += (size_t)bi * m;
     slots += (size_t)bi * 2 * FPS_MAXG * FPS_KPUB;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int gtid = wg * (FPS_WAVES * 64) + threadIdx.x;
-    const int stride = G * FPS_WAVES * 64;
+    // FPS_PIPE: wave 0 is the workgroup's coordinator (merge, exchange, replay) and owns no points
+    const bool holder = !FPS_PIPE || (wid & 3) != 0;
+    const int hid = FPS_PIPE ? wid - 1 - (wid >> 2) : wid;  // index among the workgroup's point-holding waves
+    const int gtid = (wg * FPS_PW + hid) * 64 + lane;
+    const int stride = G * FPS_PW * 64;
+    if (FPS_PIPE) {
+        if (threadIdx.x < 2) s_prog[threadIdx.x] = 0u;
+        if (!holder && lane < 4) s_part[lane >> 1][wid * 2 + (lane & 1)] = 0ull;  // these waves never forward a candidate
+    }
 
     float px[P], py[P], pz[P], tmp[P];
     unsigned key[P];
@@ -439,7 +502,7 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
         px[i] = py[i] = pz[i] = 0.f;
         tmp[i] = 1e10f;
         key[i] = FPS_KEY_NONE;
-        if (k < n) {
+        if (holder && k < n) {
             px[i] = xyz[(size_t)k * 3 + 0];
             py[i] = xyz[(size_t)k * 3 + 1];
             pz[i] = xyz[(size_t)k * 3 + 2];
@@ -494,15 +557,46 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
 #ifdef FPS_TRACE
     unsigned long long ftr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#if FPS_PIPE
+    // The picks of an exchange are absorbed WHILE wave 0 replays it: wave 0 posts every accepted pick to LDS (coordinates,
+    // then s_prog) and the point-holding waves, which used to idle at a barrier until the whole exchange was known and
+    // then absorbed its ~12 picks on the critical path (17 % of the kernel + 20 % waiting for the slowest wave, by cycle
+    // stamps), follow it pick by pick.  Only the pick before the loop (the start point / the resumed sequence's last one)
+    // is absorbed the old way.
+    if (holder) {
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            if (elig & (1u << i)) {
+                const float dx = px[i] - nx[0], dy = py[i] - ny[0], dz = pz[i] - nz[0];
+                tmp[i] = fminf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)), tmp[i]);
+            }
+        }
+    } else {
+        __builtin_amdgcn_s_setprio(3);  // the replay is the kernel's serial chain
+    }
+    __syncthreads();  // (s_prog zeroed)
+#endif
+    // gate (optional, one point set): gate[0] = number of picks stored, published by workgroup 0's wave 0 the first time
+    // that number reaches gate_at (and at the end): a kernel launched beside this one (the geodesic search, which needs
+    // the first n_query picks only) waits for it instead of for this launch.  Every pick index is stored by this very
+    // wave, so its release fence covers them.
+    auto post_gate = [&](int before, int after) {
+        if (gate && wg == 0 && wid == 0 && before < gate_at && after >= gate_at) {
+            __threadfence();
+            if (lane == 0) __hip_atomic_store(gate, after, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    post_gate(0, done);
     for (int round = 1; done < m; round++) {
         const int par = round & 1;
         const unsigned long long ft0 = FT();
-        // 1) absorb the new picks, track this lane's best
+        // 1) absorb the new picks (FPS_PIPE: done already), track this lane's best
         unsigned bd = 0u, bk = FPS_KEY_NONE;
 #pragma unroll
         for (int i = 0; i < P; i++) {
             if (elig & (1u << i)) {
                 float d2 = tmp[i];
+#if !FPS_PIPE
 #pragma unroll
                 for (int a = 0; a < FPS_K; a++) {
                     if (a < nnew) {
@@ -511,6 +605,7 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                     }
                 }
                 tmp[i] = d2;
+#endif
                 const unsigned db = __float_as_uint(d2);
                 if (db > bd || (db == bd && key[i] < bk)) {
                     bd = db;
@@ -521,6 +616,7 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
         const unsigned long long ft1 = FT();
         FTA(0, ft0, ft1);
         // 2) wave top-2: best, then the owner of the best exposes its runner-up
+        if (holder) {
         unsigned d1 = bd, k1 = bk;
         wave_best(d1, k1);
         unsigned cd = bd, ck = bk;
@@ -546,6 +642,7 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             else if (c1 != 0ull) c1 |= 1ull;
             s_part[par][wid * 2 + 0] = c1;
             s_part[par][wid * 2 + 1] = c2;
+        }
         }
         const unsigned long long ft2 = FT();
         FTA(1, ft1, ft2);
@@ -667,6 +764,15 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                 kz = keeper ? bz : kz;
                 kidx = keeper ? (int)((FPS_KEY_NONE - ((best_lo >> 1) & 0x7fffffffu)) & 0x3fffffu) : kidx;
                 if (lane == ol) alive = false;
+#if FPS_PIPE
+                if (lane == 0) {  // posted at once: the other waves absorb it while the replay goes on (LDS keeps a wave's order)
+                    FPS_LDS_ST(&s_xyz[par][t * 3 + 0], bx);
+                    FPS_LDS_ST(&s_xyz[par][t * 3 + 1], by);
+                    FPS_LDS_ST(&s_xyz[par][t * 3 + 2], bz);
+                    FPS_ORDER();
+                    FPS_LDS_ST(&s_prog[par], ((unsigned)round << 8) | (unsigned)(t + 1));
+                }
+#endif
                 const float dx = vx[0] - bx, dy = vy[0] - by, dz = vz[0] - bz;
                 cdist = fminf(cdist, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
             };
@@ -676,9 +782,9 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                 const unsigned long long best = wave_max_u64(my);
                 if (best == 0ull) {  // nothing eligible anywhere: index 0 like the reference
                     if (lane == 0) {
-                        s_xyz[par][0] = xyz[0];
-                        s_xyz[par][1] = xyz[1];
-                        s_xyz[par][2] = xyz[2];
+                        FPS_LDS_ST(&s_xyz[par][0], xyz[0]);
+                        FPS_LDS_ST(&s_xyz[par][1], xyz[1]);
+                        FPS_LDS_ST(&s_xyz[par][2], xyz[2]);
                         if (wg == 0) idxs[done] = 0;
                     }
                     direct = true;
@@ -712,16 +818,62 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
                     nacc = t + 1;
                 }
             }
+#if FPS_PIPE
+            if (!direct && lane < nacc && wg == 0) idxs[done + lane] = kidx;
+            post_gate(done, done + nacc);
+            FPS_ORDER();
+            if (lane == 0) FPS_LDS_ST(&s_prog[par], ((unsigned)round << 8) | 0x80u | (unsigned)nacc);
+            nnew = nacc;
+            (void)kx; (void)ky; (void)kz;
+#else
             if (!direct && lane < nacc) {
                 s_xyz[par][lane * 3 + 0] = kx;
                 s_xyz[par][lane * 3 + 1] = ky;
                 s_xyz[par][lane * 3 + 2] = kz;
                 if (wg == 0) idxs[done + lane] = kidx;
             }
+            post_gate(done, done + nacc);
             if (lane == 0) s_pick[par][0] = nacc;
+#endif
             const unsigned long long ft7 = FT();
             FTA(6, ft6, ft7);
         }
+#if FPS_PIPE
+        else if (holder) {
+            // the point-holding waves follow the replay: absorb every pick as soon as wave 0 has posted it.  s_prog
+            // carries the round, so a value two rounds old reads as "nothing yet"; wave 0 cannot start the next replay
+            // into this buffer before every wave has left this loop (the barrier of the round in between).
+            // (no eligibility test in here: an ineligible slot's distance is never read)
+            const unsigned tag = (unsigned)round << 8;
+            int seen = 0;
+            for (;;) {
+                const unsigned c = FPS_LDS_LD(&s_prog[par]);
+                FPS_ORDER();
+                const bool cur = (c & 0xffffff00u) == tag;
+                const int cnt = cur ? (int)(c & 0x7fu) : 0;
+                for (int a = seen; a < cnt; a++) {
+                    const float ax = FPS_LDS_LD(&s_xyz[par][a * 3 + 0]), ay = FPS_LDS_LD(&s_xyz[par][a * 3 + 1]),
+                                az = FPS_LDS_LD(&s_xyz[par][a * 3 + 2]);
+                    fps_absorb<P>(px, py, pz, tmp, ax, ay, az);
+                }
+                seen = cnt;
+                if (cur && (c & 0x80u)) break;
+                __builtin_amdgcn_s_sleep(FPS_POLL_SLEEP);
+            }
+            nnew = seen;
+        } else {
+            // a wave on wave 0's SIMD: sleeps through the replay, only needs the number of picks
+            const unsigned tag = (unsigned)round << 8;
+            unsigned c;
+            for (;;) {
+                c = FPS_LDS_LD(&s_prog[par]);
+                if ((c & 0xffffff80u) == (tag | 0x80u)) break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            nnew = (int)(c & 0x7fu);
+        }
+        (void)s_pick;
+#else
         const unsigned long long ft8 = FT();
         __syncthreads();
         const unsigned long long ft9 = FT();
@@ -733,23 +885,46 @@ __global__ __launch_bounds__(FPS_WAVES * 64) void k_fps(const float* __restrict_
             ny[a] = s_xyz[par][a * 3 + 1];
             nz[a] = s_xyz[par][a * 3 + 2];
         }
+#endif
         done += nnew;
 #ifdef FPS_TRACE
         ftr[8] += 1;
         ftr[9] += nnew;
 #endif
     }
+    post_gate(gate_at - 1, gate_at > m ? gate_at : m);  // (a gate beyond the last pick opens at the end)
 #ifdef FPS_TRACE
     if (g_fps_trace && wg == 0 && threadIdx.x == 0)
         for (int i = 0; i < 10; i++) g_fps_trace[i] = ftr[i];
 #endif
 }
 
+// Bytes of dynamic LDS the sampling workgroups claim without using them (dev knob gf_dev_fps_lds_pad / GF_FPS_LDS_PAD,
+// read once): a workgroup of another kernel that needs more than the rest of the compute unit's 160 KB cannot become
+// co-resident with a sampling workgroup.
+static int g_fps_lds_pad = -1;
+static int fps_lds_pad() {
+    if (g_fps_lds_pad < 0) {
+        const char* e = getenv("GF_FPS_LDS_PAD");
+        g_fps_lds_pad = e ? atoi(e) : 0;
+        if (g_fps_lds_pad < 0) g_fps_lds_pad = 0;
+    }
+    return g_fps_lds_pad;
+}
+extern "C" int gf_dev_fps_lds_pad(int bytes) {
+    g_fps_lds_pad = bytes;
+    return GF_OK;
+}
 template <int P>
 static void launch_fps(int G, int nb, hipStream_t st, const float* xyz, int n, int m, int m0, int bs_log2, int batch0,
-                       unsigned long long* slots, int32_t* idxs, int* err) {
-    GF_LAUNCH_OP(GF_OP_FPS, (k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), 0, st, xyz, n, m, m0, G, bs_log2, batch0, slots,
-                 idxs, err);
+                       unsigned long long* slots, int32_t* idxs, int* err, int* gate, int gate_at, int pad) {
+    static int attr_pad = 0;
+    if (pad > attr_pad) {
+        (void)hipFuncSetAttribute((const void*)k_fps<P>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+        attr_pad = pad;
+    }
+    GF_LAUNCH_OP(GF_OP_FPS, (k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), pad, st, xyz, n, m, m0, G, bs_log2, batch0,
+                 slots, idxs, err, gate, gate_at);
 }
 
 extern "C" size_t gf_fps_scratch_bytes(int b) {
@@ -764,8 +939,29 @@ extern "C" int gf_furthest_point_sampling(const float* xyz, int b, int n, int m,
     return gf_furthest_point_sampling_resume(xyz, b, n, m, 0, idxs, scratch, stream);
 }
 
+static int fps_run(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs, void* scratch, int* gate, int gate_at,
+                   int pad, bool zero_scratch, void* stream);
 extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs,
                                                  void* scratch, void* stream) {
+    return fps_run(xyz, b, n, m, m_known, idxs, scratch, nullptr, 0, fps_lds_pad(), true, stream);
+}
+extern "C" int gf_fps_scratch_reset(void* scratch, int b, void* stream) {
+    GF_CHECK_ARG(scratch && b >= 0, "gf_fps_scratch_reset: bad arguments");
+    GF_TRY(hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), (hipStream_t)stream));
+    return GF_OK;
+}
+extern "C" int* gf_fps_gate_word(void* scratch, int b) {
+    // inside the scratch's 64-byte tail: [0] the sampler's error word, [2] the gate, [4] a waiter's time-out word
+    return (int*)((unsigned long long*)scratch + (size_t)b * 2 * FPS_MAXG * FPS_KPUB) + 2;
+}
+extern "C" int gf_furthest_point_sampling_gated(const float* xyz, int n, int m, int32_t* idxs, void* scratch, int gate_at,
+                                                int lds_pad_bytes, void* stream) {
+    GF_CHECK_ARG(gate_at >= 1 && lds_pad_bytes >= 0 && lds_pad_bytes <= 120 * 1024,
+                 "gf_furthest_point_sampling_gated: gate_at=%d lds_pad_bytes=%d", gate_at, lds_pad_bytes);
+    return fps_run(xyz, 1, n, m, 0, idxs, scratch, gf_fps_gate_word(scratch, 1), gate_at, lds_pad_bytes, false, stream);
+}
+static int fps_run(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs, void* scratch, int* gate, int gate_at,
+                   int pad, bool zero_scratch, void* stream) {
     GF_CHECK_ARG(b >= 0 && n >= 1 && m >= 0, "gf_furthest_point_sampling: bad sizes b=%d n=%d m=%d", b, n, m);
     GF_CHECK_ARG(m_known >= 0 && m_known <= m, "gf_furthest_point_sampling_resume: m_known=%d not in [0, m=%d]", m_known,
                  m);
@@ -776,7 +972,7 @@ extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n,
     // reference launch geometry decides ties: bs = largest power of two <= n, capped at 512
     int bs_log2 = 0;
     while ((2 << bs_log2) <= n && bs_log2 < 9) bs_log2++;
-    const int per_wg = FPS_WAVES * 64;
+    const int per_wg = FPS_PW * 64;  // lanes that hold points
     int G = (2 * n + per_wg * 5 - 1) / (per_wg * 5);  // ~2.5 points per lane (40 000 points: 16 workgroups; 13 at 3 per lane cost the forward 1.8 %)
     static const int g_env = [] { const char* e = getenv("GF_FPS_G"); return e ? atoi(e) : 0; }();  // read once
     if (g_env > 0) G = g_env;
@@ -786,17 +982,19 @@ extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n,
     GF_CHECK_ARG(P <= 16, "gf_furthest_point_sampling: n=%d too large (max %d)", n, FPS_MAXG * per_wg * 16);
     unsigned long long* slots = (unsigned long long*)scratch;
     int* err = (int*)(slots + (size_t)b * 2 * FPS_MAXG * FPS_KPUB);
-    GF_TRY(hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), st));
+    if (zero_scratch) GF_TRY(hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), st));
     const int per_launch = 1024 / (G * FPS_WAVES) > 0 ? 1024 / (G * FPS_WAVES) : 1;  // all cooperating waves resident
     for (int b0 = 0; b0 < b; b0 += per_launch) {
         const int nb = (b - b0) < per_launch ? (b - b0) : per_launch;
-        if (P <= 1) launch_fps<1>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
-        else if (P <= 2) launch_fps<2>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
-        else if (P <= 4) launch_fps<4>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
-        else if (P <= 6) launch_fps<6>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
-        else if (P <= 8) launch_fps<8>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
-        else if (P <= 12) launch_fps<12>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
-        else launch_fps<16>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        if (P <= 1) launch_fps<1>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else if (P <= 2) launch_fps<2>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else if (P <= 3) launch_fps<3>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else if (P <= 4) launch_fps<4>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else if (P <= 5) launch_fps<5>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else if (P <= 6) launch_fps<6>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else if (P <= 8) launch_fps<8>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else if (P <= 12) launch_fps<12>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        else launch_fps<16>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
     }
     GF_CHECK_LAUNCH("gf_furthest_point_sampling");
     return GF_OK;

@@ -48,6 +48,9 @@ voxelization = _Voxelization.apply
 import threading
 import weakref
 
+_BFS_GATE = os.environ.get("GF_BFS_GATE", "0") == "1"  # the sampling / search stretch as one gated pair of launches
+_GATE_PAD_KB = int(os.environ.get("GF_GATE_PAD_KB", "88"))  # LDS the gated sampler claims per workgroup (0: none) ...
+_GATE_PAD_MAX_N = int(os.environ.get("GF_GATE_PAD_MAX_N", "80000"))  # ... for foregrounds up to this many points
 _BFS_WG = int(os.environ.get("GF_BFS_WG", "0"))  # threads per query of the BFS launched beside the sampling (0: by the number of queries)
 
 
@@ -580,7 +583,11 @@ class GeoFormer(nn.Module):
         multi = batch_size > 1 and early is None and not epilogue and os.environ.get("GF_SCENE_STREAMS", "1") != "0"
         scene_streams = []
         bfs_one_stream = multi and os.environ.get("GF_TRAIN_BFS_STREAMS", "scene") == "one"
-        bfs_batched = multi and nq >= 32 and os.environ.get("GF_TRAIN_BFS_BATCHED", "0") == "1"
+        # one scene: the gated form of the stretch (below); GF_BFS_GATE=0: two sampling launches, the search after the first
+        gated = split and batch_size == 1 and _BFS_GATE and nq >= 1
+        bfs_mode = os.environ.get("GF_TRAIN_BFS_BATCHED", "0")  # 1: one multi-source search for the batch; 2: one per scene
+        bfs_batched = multi and nq >= 32 and bfs_mode == "1"
+        bfs_ms_scene = multi and nq >= 32 and bfs_mode == "2"
         bfs_pending = []
 
         def host_draw(b, n_b):
@@ -637,16 +644,31 @@ class GeoFormer(nn.Module):
                     xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
                 xyz_ready = torch.cuda.Event()
                 xyz_ready.record(sb)
-                first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
-                src = first[0, :nq].contiguous()
-                first_ready = torch.cuda.Event()
-                first_ready.record(sb)
-                # the rest of the sampling is the stretch's long pole: queued right behind the first picks, before the
-                # host spends ~60 us on everything below (the stream idled that long between the two launches)
-                idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+                gate = None
+                if gated:
+                    # ONE sampling launch; the search is launched beside it right away and waits INSIDE its kernel for
+                    # the first nq picks (csrc/pointops.hip post_gate / csrc/geodesic.hip): no second sampling launch,
+                    # the search's row initialisation runs under the first picks, and -- sparse foregrounds -- the
+                    # sampler's workgroups claim enough LDS that no search workgroup shares their compute units (a
+                    # search on a shared unit is the launch's straggler: 1.60 -> 1.47 ms at 60k points; dense
+                    # foregrounds lose more by two searches sharing a unit instead: no pad there)
+                    pad_kb = _GATE_PAD_KB if n_b <= _GATE_PAD_MAX_N else 0
+                    idx, gate, first_ready = pointops.furthest_point_sampling_gated(xyz_b, npoint_sa, nq, lds_pad=pad_kb * 1024)
+                    first = idx
+                    src = idx[0, :nq]
+                    self._gf_last_gate = gate
+                else:
+                    first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
+                    src = first[0, :nq].contiguous()
+                    first_ready = torch.cuda.Event()
+                    first_ready.record(sb)
+                    # the rest of the sampling is the stretch's long pole: queued right behind the first picks, before the
+                    # host spends ~60 us on everything below (the stream idled that long between the two launches)
+                    idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
                 fps_done = torch.cuda.Event()
                 fps_done.record(sb)
                 fps_done_evs.append(fps_done)
+                picks_ready = fps_done if gated else first_ready  # for readers of the picks outside the gated kernel
             if early is not None and b == 0:
                 # work of the caller that does not depend on the sampling (early() -> (.., .., kNN graphs)): queued on
                 # the third stream now that the first sampling launch is out
@@ -681,7 +703,12 @@ class GeoFormer(nn.Module):
                 side_b.wait_event(first_ready)
                 with torch.cuda.stream(side_b):
                     D, I, deg = graphs[b][:3]
-                    g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), 1 if bfs_one_stream else batch_size) if split else 1024)
+                    if gate is not None:
+                        g = pointops.geodesic_bfs_gated(D, I, src, 0.05, max_step, gate, nq, wg_threads=_bfs_wg(int(src.shape[0])))
+                    elif bfs_ms_scene:
+                        g = pointops.geodesic_bfs_ms(D, I, src, 0.05, max_step)
+                    else:
+                        g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), 1 if bfs_one_stream else batch_size) if split else 1024)
                     g.record_stream(main)
                     src.record_stream(side_b)
                     geo[b] = g
@@ -699,7 +726,7 @@ class GeoFormer(nn.Module):
                 continue
             # small launches that only need the distances / the query picks ride beside the sampling instead of
             # sitting between the decoder and the mask head on the main stream
-            self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, first_ready)
+            self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, picks_ready)
         if bfs_pending:
             # all scenes of the batch as one multi-source search (csrc/geodesic_ms.hip: the queries are bit lanes, a hop
             # is one launch whatever the number of vertices): 128 hops x ~11 us for four scenes against four per-query
@@ -777,6 +804,15 @@ class GeoFormer(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(aux)
                     early["qpos"] = (q_locs, qpos, ev)
+
+    def check_gate(self):
+        """True unless a search workgroup of the last gated sampling / search pair gave up waiting for its source (one
+        second: the sampling launch beside it never published the picks).  Synchronises; for tests and the end of a run."""
+        gate = self.__dict__.get("_gf_last_gate")
+        if gate is None:
+            return True
+        torch.cuda.synchronize(gate.device)
+        return int(gate[2].item()) == 0
 
     def _early(self):
         """Results computed beside the BFS for the forward running on the CALLER's stream (per-stream dict)."""

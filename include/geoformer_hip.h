@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 3
+#define GF_ABI_VERSION 4
 
 typedef enum {
     GF_OK = 0,
@@ -395,6 +395,20 @@ int gf_furthest_point_sampling(const float* xyz, int b, int n, int m, int32_t* i
  * needs 256 of 2048) start while the rest is still being drawn. */
 int gf_furthest_point_sampling_resume(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs,
                                       void* scratch, void* stream);
+/* One launch with a GATE (one point set; ABI 4): workgroup 0 publishes gate[0] = number of picks stored -- agent scope,
+ * behind a release fence -- the first time that number reaches gate_at, and again at the end.  A kernel launched beside
+ * this one that needs the first gate_at picks only (gf_geodesic_bfs_gated: 256 of 2048) waits for the word instead of for
+ * the launch; idxs is then read with agent-scope loads.  Protocol:
+ *     gf_fps_scratch_reset(scratch, 1, stream);   <- zeroes the scratch incl. the gate; record an event HERE and let the
+ *                                                    waiter's stream wait for it (not for the sampling launch)
+ *     gf_furthest_point_sampling_gated(...);      <- does NOT zero the scratch
+ * gf_fps_gate_word(scratch, 1) -> int* w inside the scratch: w[0] the gate, w[2] a word for the waiter's time-out flag.
+ * lds_pad_bytes: dynamic LDS every sampling workgroup claims without using it, so that workgroups of the waiting kernel
+ * cannot become co-resident on the sampler's compute units (the search is 20-30 % slower on a shared unit); 0 = none. */
+int gf_fps_scratch_reset(void* scratch, int b, void* stream);
+int* gf_fps_gate_word(void* scratch, int b);
+int gf_furthest_point_sampling_gated(const float* xyz, int n, int m, int32_t* idxs, void* scratch, int gate_at,
+                                     int lds_pad_bytes, void* stream);
 
 /* ===================================================================================
  * Geodesic stage (model/geoformer/geodesic_utils.py)
@@ -428,6 +442,13 @@ int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n,
 int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
                         float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words,
                         int wg_threads, void* stream);
+/* The search launched BESIDE the sampling launch that is still drawing its sources (gf_furthest_point_sampling_gated;
+ * ABI 4): src points into that launch's output; every workgroup initialises its rows, then waits -- bounded: one second,
+ * then gate_err[0] = 1 and the search runs on whatever the slot holds -- until gate[0] >= gate_at and reads its source
+ * with an agent-scope load.  Zero gate_err before the launch.  LDS-resident kernel only (n <= 2^19, K % 4 == 0). */
+int gf_geodesic_bfs_gated(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
+                          int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
+                          const int* gate, int gate_at, int* gate_err, void* stream);
 
 /* The same search for ALL nq sources at once (csrc/geodesic_ms.hip): the queries are bit lanes of per-vertex frontier /
  * visited masks, a hop is ONE launch over every (vertex, mask word) that walks the vertex's in-neighbours in ascending

@@ -99,6 +99,9 @@ int gf_dev_bfs_ms_tiles(int on);
 /* 1 = the whole multi-source search as ONE launch of resident tile workgroups that exchange their rows through memory
  * (k_ms_persist; needs the coordinates), 0 = one launch per hop (default), -1 = default / GF_BFS_MS_PERSIST. */
 int gf_dev_bfs_ms_persist(int on);
+/* bytes of dynamic LDS every sampling (k_fps) workgroup claims without using them: keeps workgroups of other kernels that
+   need more than the remainder of the 160 KB off the sampler's compute units (also GF_FPS_LDS_PAD, read once) */
+int gf_dev_fps_lds_pad(int bytes);
 
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);

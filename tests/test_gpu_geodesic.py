@@ -232,3 +232,38 @@ def test_bfs_multi_source_one_launch_and_batched_scenes(hip, oracle):
     geos = pointops.geodesic_bfs_ms_batch(graphs, srcs, radius, 96)
     for g, ref in zip(geos, refs):
         assert (g.cpu().numpy() == ref).all()
+
+
+def test_gated_sampling_and_search_equal_the_two_launch_form(hip):
+    """One sampling launch with a gate + the search launched BESIDE it on a second stream (it waits for the first nq picks
+    inside the kernel) == sampling, then search.  With and without the LDS pad that keeps the search off the sampler's
+    compute units; the time-out word stays clear."""
+    import numpy as np
+    import torch
+
+    from geoformer_amd import pointops, scene
+
+    p = scene.make_scene(60_000, 77)["xyz"]
+    xyz = torch.from_numpy(np.ascontiguousarray(p[:24_000])).cuda()
+    n = xyz.shape[0]
+    gd, gi, deg = pointops.knn_radius(xyz, 64, 0.05)
+    pts = xyz[None].contiguous()
+    nq, m = 96, 512
+    ref_idx = pointops.furthest_point_sampling(pts, m)
+    ref_geo = pointops.geodesic_bfs(gd, gi, deg, ref_idx[0, :nq].contiguous(), 0.05, 64, wg_threads=512)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for pad in (0, 88 * 1024):
+        for wg in (512, 1024):
+            idx, gate, reset_ev = pointops.furthest_point_sampling_gated(pts, m, nq, lds_pad=pad)
+            side.wait_event(reset_ev)
+            with torch.cuda.stream(side):
+                geo = pointops.geodesic_bfs_gated(gd, gi, idx[0, :nq], 0.05, 64, gate, nq, wg_threads=wg)
+            torch.cuda.synchronize()
+            assert torch.equal(idx, ref_idx)
+            assert int(gate[0].item()) >= nq and int(gate[2].item()) == 0
+            assert torch.equal(geo, ref_geo), (pad, wg)
+    # a gate beyond the last pick opens at the end of the launch
+    idx, gate, reset_ev = pointops.furthest_point_sampling_gated(pts, 64, 1000)
+    torch.cuda.synchronize()
+    assert torch.equal(idx, ref_idx[:, :64]) and int(gate[0].item()) == 1000

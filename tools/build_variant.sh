@@ -1,11 +1,11 @@
 #!/bin/bash
 # Dev tool: build an experimental variant of the library with extra -D flags for ONE source file.
-#   tools/build_variant.sh <name> <source.hip> [-DFOO=1 ...]   ->  geoformer_amd/lib/variants/<name>.so
-# then run with GF_LIB_PATH=geoformer_amd/lib/variants/<name>.so
+#   tools/build_variant.sh <name> <source.hip> [-DFOO=1 ...]   ->  geoformer_amd/lib/exp/<name>.so
+# then run with GF_LIB_PATH=geoformer_amd/lib/exp/<name>.so
 set -e
 name=$1; src=$2; shift 2
 root=$(cd "$(dirname "$0")/.." && pwd)
-out=$root/geoformer_amd/lib/variants; mkdir -p $out/obj_$name
+out=$root/geoformer_amd/lib/exp; mkdir -p $out/obj_$name
 base=$(basename $src .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -fno-gpu-rdc -Wno-unused-result \
   -I$root/include -I$root/geoformer_amd/csrc "$@" -c $root/geoformer_amd/csrc/$base.hip -o $out/obj_$name/$base.o
