@@ -55,6 +55,15 @@ __device__ __forceinline__ float mh_relu(float x) { return __int_as_float(max(__
 // 6 x 16 cycles instead of 4 x 32.  The features' three pieces are written once per scene by k_mh_split (every query
 // shares them), the generated weights are split once per wave.
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short mh_s8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mh_bf16x8 __attribute__((ext_vector_type(8)));
+// Two 16-channel piece products in ONE v_mfma_f32_16x16x32_bf16 (16 cycles, the same as the K = 16 form): the K index
+// is a summation index, so lane group g carries channels 4g..4g+3 of the first pair in elements 0-3 and of the second pair
+// in elements 4-7 -- a1 . b1 + a2 . b2 of the lane's 4-channel slices.
+__device__ __forceinline__ f32x4 mh_mfma2(bf16x4 a1, bf16x4 a2, bf16x4 b1, bf16x4 b2, f32x4 acc) {
+    const mh_s8 a = __builtin_shufflevector(a1, a2, 0, 1, 2, 3, 4, 5, 6, 7), b = __builtin_shufflevector(b1, b2, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mh_bf16x8, a), __builtin_bit_cast(mh_bf16x8, b), acc, 0, 0, 0);
+}
 __device__ __forceinline__ void mh_split3(float x, unsigned& h, unsigned& m, unsigned& l) {  // the pieces as bf16 bit patterns
     const unsigned hb = __float_as_uint(x) & 0xffff0000u;
     const float r1 = x - __uint_as_float(hb);  // exact
@@ -85,7 +94,10 @@ __global__ void k_mh_split(const float* __restrict__ feat, int n16, unsigned sho
     fs[2 * (size_t)n16 + i] = (unsigned short)l;
 }
 
-template <bool USE_GEO, bool SPLIT>
+// TINY: fewer than 64 points (point indices clamped per lane).  Otherwise the last block of the scene is shifted back to
+// end at the last point (p0 = N - 64: the overlap is computed and stored twice, same values), so that no index needs a
+// clamp and a block's sixteen loads are constant offsets from six running addresses.
+template <bool USE_GEO, bool SPLIT, bool TINY>
 __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restrict__ feat, const float* __restrict__ coords,
                                                       const float* __restrict__ geo, const float* __restrict__ qxyz,
                                                       const float* __restrict__ mx, const float* __restrict__ w1,
@@ -153,10 +165,10 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
     };
     const size_t n16 = (size_t)N * 16;
     auto fetch = [&](int blk, Block& B) {
-        const int p0 = blk * 64;
+        const int p0 = TINY ? blk * 64 : min(blk * 64, N - 64);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int pc = min(p0 + 16 * t + j, N - 1);
+            const int pc = TINY ? min(p0 + 16 * t + j, N - 1) : p0 + 16 * t + j;
             if constexpr (SPLIT) {
                 const size_t e = (size_t)pc * 16 + 4 * g;
                 B.fh[t] = *reinterpret_cast<const bf16x4*>(fs + e);
@@ -171,11 +183,10 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
                 B.gd[u][t] = USE_GEO ? geo[(size_t)qrow[u] * N + pc] : 0.f;
         }
     };
-    Block cur, nxt;
-    if (blk0 < blk1) fetch(blk0, cur);
-    for (int blk = blk0; blk < blk1; blk++) {
-        const int p0 = blk * 64;
-        if (blk + 1 < blk1) fetch(blk + 1, nxt);
+    // (two blocks per trip, the buffers alternating: `cur = nxt` at the end of a one-block loop was 42 register moves
+    //  per block, a sixth of its vector instructions)
+    auto compute = [&](const Block& cur, int blk) {
+        const int p0 = TINY ? blk * 64 : min(blk * 64, N - 64);
 #pragma unroll
         for (int t = 0; t < MH_Q; t++) {
             const int q = qg * MH_Q + t;
@@ -194,13 +205,10 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
                 acc[0] = w5[t] * rel; acc[1] = wf[t][0] * cur.pc[tl]; acc[2] = wf[t][1] * cur.pc[tl]; acc[3] = wf[t][2] * cur.pc[tl];
 #else
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w5[t], rel, acc, 0, 0, 0);
-                if constexpr (SPLIT) {  // the six piece pairs, smallest first
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[t], cur.fh[tl], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[t], cur.fl[tl], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wm[t], cur.fm[tl], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wm[t], cur.fh[tl], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[t], cur.fm[tl], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[t], cur.fh[tl], acc, 0, 0, 0);
+                if constexpr (SPLIT) {  // the six piece pairs, smallest first, two per instruction
+                    acc = mh_mfma2(wl[t], wh[t], cur.fh[tl], cur.fl[tl], acc);  // lo.hi + hi.lo
+                    acc = mh_mfma2(wm[t], wm[t], cur.fm[tl], cur.fh[tl], acc);  // mid.mid + mid.hi
+                    acc = mh_mfma2(wh[t], wh[t], cur.fm[tl], cur.fh[tl], acc);  // hi.mid + hi.hi
                 } else {
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][0], cur.f[tl].x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][1], cur.f[tl].y, acc, 0, 0, 0);
@@ -235,7 +243,16 @@ __global__ __launch_bounds__(256, MH_MINB) void k_mask_head(const float* __restr
                 if (p < N && q < nq) out[(size_t)q * N + p] = tot;
             }
         }
-        cur = nxt;
+    };
+    Block bufA, bufB;
+    if (blk0 < blk1) fetch(blk0, bufA);
+    for (int blk = blk0; blk < blk1; blk += 2) {
+        if (blk + 1 < blk1) fetch(blk + 1, bufB);
+        compute(bufA, blk);
+        if (blk + 1 < blk1) {
+            if (blk + 2 < blk1) fetch(blk + 2, bufA);
+            compute(bufB, blk + 1);
+        }
     }
 }
 
@@ -293,8 +310,14 @@ extern "C" int gf_mask_head_episodes(const float* feat, const float* coords, con
         hipLaunchKernelGGL(k_mh_split, dim3(gf_div_up(n16, 256)), dim3(256), 0, st, feat, n16, (unsigned short*)split_ws);
     }
 #define MH_LAUNCH(GEO_, SPLIT_)                                                                                          \
-    GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<GEO_, SPLIT_>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, sqrt_max_geo, \
-                 w1, b1, w2, b2, ldp, N, nq, qmod, chunks, fs, out)
+    do {                                                                                                                 \
+        if (N < 64)                                                                                                      \
+            GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<GEO_, SPLIT_, true>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, \
+                         sqrt_max_geo, w1, b1, w2, b2, ldp, N, nq, qmod, chunks, fs, out);                               \
+        else                                                                                                             \
+            GF_LAUNCH_OP(GF_OP_MASK_HEAD, (k_mask_head<GEO_, SPLIT_, false>), grid, dim3(256), 0, st, feat, coords, geo, qxyz, \
+                         sqrt_max_geo, w1, b1, w2, b2, ldp, N, nq, qmod, chunks, fs, out);                               \
+    } while (0)
     if (geo && fs) MH_LAUNCH(true, true);
     else if (geo) MH_LAUNCH(true, false);
     else if (fs) MH_LAUNCH(false, true);
