@@ -87,7 +87,7 @@ def _declare(lib):
         "gf_knn_error_flag": (P, [P, I]),
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
         "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, P]),
-        "gf_geodesic_bfs_gated": (I, [P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, P, I, P, P]),
+        "gf_geodesic_bfs_gated": (I, [P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, I, P, I, P, P]),
         "gf_geodesic_bfs_queue_words": (c_size_t, [I]),
         "gf_geodesic_ms_scratch_bytes": (c_size_t, [I, I, I, I]),
         "gf_geodesic_bfs_ms": (I, [P, P, P, I, I, P, I, F, I, P, P, c_size_t, P]),
@@ -95,6 +95,7 @@ def _declare(lib):
         "gf_dev_bfs_ms_tiles": (I, [I]),
         "gf_dev_bfs_ms_persist": (I, [I]),
         "gf_dev_fps_lds_pad": (I, [I]),
+        "gf_dev_bfs_lds_cap": (I, [I]),
         "gf_geodesic_ms_error_flag": (P, [P, I, I, I, I]),
         "gf_dev_bfs_pipe": (I, [I]),
         "gf_dev_cross_attn_bf3": (I, [I]),

@@ -1354,6 +1354,21 @@ extern "C" int gf_dev_bfs_qcap_max(int qcap) {
     g_bfs_qcap_max = qcap > 0 ? qcap : 0;
     return GF_OK;
 }
+// dev knob: upper bound of a search workgroup's LDS (bytes; 0 = none): e.g. 79 KB lets two 768-thread workgroups share
+// a compute unit (GF_BFS_LDS_CAP, read once)
+static int g_bfs_lds_cap = -1;
+static size_t bfs_lds_cap() {
+    if (g_bfs_lds_cap < 0) {
+        const char* e = getenv("GF_BFS_LDS_CAP");
+        g_bfs_lds_cap = e ? atoi(e) : 0;
+        if (g_bfs_lds_cap < 0) g_bfs_lds_cap = 0;
+    }
+    return (size_t)g_bfs_lds_cap;
+}
+extern "C" int gf_dev_bfs_lds_cap(int bytes) {
+    g_bfs_lds_cap = bytes < 0 ? -1 : bytes;
+    return GF_OK;
+}
 // int32 words of queue_ws per query
 extern "C" size_t gf_geodesic_bfs_queue_words(int n) {
     // two queues of (vertex, distance) overflow: 4 n; the pipelined kernel adds its slow-path scratch: 10 n
@@ -1366,28 +1381,31 @@ extern "C" size_t gf_geodesic_bfs_queue_words(int n) {
 // 1024 threads -- one per compute unit -- need a second round, and 512 is the fastest (two queries can share a unit).
 static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
                    float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
-                   const int* gate, int gate_at, int* gate_err, void* stream);
+                   size_t lds_cap, const int* gate, int gate_at, int* gate_err, void* stream);
 extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K,
                                    const int32_t* src, int nq, float radius, int max_step, float* geo, void* keys_ws,
                                    void* queue_ws, size_t queue_words, int wg_threads, void* stream) {
-    return bfs_cfg(D, I, deg, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads, nullptr, 0,
-                   nullptr, stream);
+    return bfs_cfg(D, I, deg, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads,
+                   bfs_lds_cap(), nullptr, 0, nullptr, stream);
 }
 // The search launched BESIDE the sampling launch that is still drawing its sources (gf_furthest_point_sampling_gated):
 // every workgroup initialises its rows, then waits (bounded: one second) until gate[0] >= gate_at and reads its source
 // with an agent-scope load.  gate_err[0] is set to 1 by a workgroup that timed out (zero it before the launch).  Only the
 // LDS-resident kernel has the wait: a graph it cannot take (n > 2^19, K % 4 != 0) is refused.
+// lds_cap_bytes: upper bound of a workgroup's LDS (0: the workgroup size's share of 150 KB); 64 KB lets two 768-thread
+// workgroups share a compute unit, which is how 256 queries fit the 240 units the sampler leaves free in ONE round.
 extern "C" int gf_geodesic_bfs_gated(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
                                      int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words,
-                                     int wg_threads, const int* gate, int gate_at, int* gate_err, void* stream) {
-    GF_CHECK_ARG(gate && gate_err && gate_at >= 1, "gf_geodesic_bfs_gated: gate=%p gate_err=%p gate_at=%d", (const void*)gate,
-                 (void*)gate_err, gate_at);
-    return bfs_cfg(D, I, nullptr, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads, gate,
-                   gate_at, gate_err, stream);
+                                     int wg_threads, int lds_cap_bytes, const int* gate, int gate_at, int* gate_err,
+                                     void* stream) {
+    GF_CHECK_ARG(gate && gate_err && gate_at >= 1 && lds_cap_bytes >= 0, "gf_geodesic_bfs_gated: gate=%p gate_err=%p gate_at=%d",
+                 (const void*)gate, (void*)gate_err, gate_at);
+    return bfs_cfg(D, I, nullptr, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads,
+                   lds_cap_bytes ? (size_t)lds_cap_bytes : bfs_lds_cap(), gate, gate_at, gate_err, stream);
 }
 static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
                    float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
-                   const int* gate, int gate_at, int* gate_err, void* stream) {
+                   size_t lds_cap, const int* gate, int gate_at, int* gate_err, void* stream) {
     GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs: bad arguments");
     GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs: n=%d exceeds the 26-bit parent field", n);
     GF_CHECK_ARG(wg_threads == 1024 || wg_threads == 768 || wg_threads == 512 || wg_threads == 256,
@@ -1405,7 +1423,8 @@ static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, 
     // share) before it gives up the LDS-resident kernel altogether
     while (wg_threads < 1024 && bm + 256 * 2 * sizeof(int2) > (size_t)BFS_LDS_BYTES * wg_threads / 1024)
         wg_threads = wg_threads == 768 ? 1024 : wg_threads * 2;
-    const size_t budget = (size_t)BFS_LDS_BYTES * wg_threads / 1024;
+    size_t budget = (size_t)BFS_LDS_BYTES * wg_threads / 1024;
+    if (lds_cap && lds_cap < budget && bm + 256 * 2 * sizeof(int2) <= lds_cap) budget = lds_cap;
     if (n <= BFS_LDS_MAX_N && (K & 3) == 0 && bm + 64 * 2 * sizeof(int2) <= budget) {
         // rows must be distance-sorted and padded with (inf,-1) (gf_knn_radius / faiss order): the
         // LDS variant relies on that to stop scanning a row early

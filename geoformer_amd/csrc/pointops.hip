@@ -854,7 +854,11 @@ __global__ __launch_bounds__(FPS_WAVES * 64) FPS_VGPR_CAP void k_fps(const float
                 for (int a = seen; a < cnt; a++) {
                     const float ax = FPS_LDS_LD(&s_xyz[par][a * 3 + 0]), ay = FPS_LDS_LD(&s_xyz[par][a * 3 + 1]),
                                 az = FPS_LDS_LD(&s_xyz[par][a * 3 + 2]);
+#ifndef FPS_EXP_NOABSORB  // dev experiment (wrong picks): what the absorbing waves cost a neighbour on the compute unit
                     fps_absorb<P>(px, py, pz, tmp, ax, ay, az);
+#else
+                    (void)ax; (void)ay; (void)az;
+#endif
                 }
                 seen = cnt;
                 if (cur && (c & 0x80u)) break;

@@ -48,9 +48,16 @@ voxelization = _Voxelization.apply
 import threading
 import weakref
 
-_BFS_GATE = os.environ.get("GF_BFS_GATE", "0") == "1"  # the sampling / search stretch as one gated pair of launches
+# GF_BFS_GATE=1: the sampling / search stretch of a one-scene inference forward as a gated pair of launches (below) instead
+# of two sampling launches with the search after the first.  In the gated form the search runs at _GATE_WG threads per
+# query with at most _GATE_LDS_KB of LDS -- two workgroups per compute unit, so the 256 queries fit beside the sampler in
+# one round.  Measured: a forward that is waited for 1.7 % shorter (4.96 against 5.05 ms), bench.py's loop unchanged
+# (210.2 against 210.0 scenes/s over three alternating pairs): opt-in.
+_BFS_GATE = os.environ.get("GF_BFS_GATE", "0") == "1"
 _GATE_PAD_KB = int(os.environ.get("GF_GATE_PAD_KB", "88"))  # LDS the gated sampler claims per workgroup (0: none) ...
 _GATE_PAD_MAX_N = int(os.environ.get("GF_GATE_PAD_MAX_N", "80000"))  # ... for foregrounds up to this many points
+_GATE_WG = int(os.environ.get("GF_GATE_WG", "768"))
+_GATE_LDS_KB = int(os.environ.get("GF_GATE_LDS_KB", "64"))
 _BFS_WG = int(os.environ.get("GF_BFS_WG", "0"))  # threads per query of the BFS launched beside the sampling (0: by the number of queries)
 
 
@@ -146,6 +153,12 @@ def cal_geodesic(pre_enc_inds, locs_float_, batch_offsets_, max_step=128, neighb
         src = pre_enc_inds[b][:n_queries].int().contiguous()
         out.append(pointops.geodesic_bfs(D, I, deg, src, radius, max_step))
     return out
+
+
+def _stream_key_of(device, stream):
+    """_stream_key() of an explicit (device, torch stream)."""
+    idx = torch.device(device).index
+    return (torch.cuda.current_device() if idx is None else idx, stream.cuda_stream)
 
 
 def _stream_key(device=None):
@@ -584,7 +597,9 @@ class GeoFormer(nn.Module):
         scene_streams = []
         bfs_one_stream = multi and os.environ.get("GF_TRAIN_BFS_STREAMS", "scene") == "one"
         # one scene: the gated form of the stretch (below); GF_BFS_GATE=0: two sampling launches, the search after the first
-        gated = split and batch_size == 1 and _BFS_GATE and nq >= 1
+        # (only where the search is dispatched well behind the sampling launch -- the kNN graph it needs is built in
+        #  between -- and only when its queries do not fit one per compute unit anyway)
+        gated = split and batch_size == 1 and _BFS_GATE and early is not None and nq > 224 and not torch.is_grad_enabled()
         bfs_mode = os.environ.get("GF_TRAIN_BFS_BATCHED", "0")  # 1: one multi-source search for the batch; 2: one per scene
         bfs_batched = multi and nq >= 32 and bfs_mode == "1"
         bfs_ms_scene = multi and nq >= 32 and bfs_mode == "2"
@@ -653,7 +668,8 @@ class GeoFormer(nn.Module):
                     # search on a shared unit is the launch's straggler: 1.60 -> 1.47 ms at 60k points; dense
                     # foregrounds lose more by two searches sharing a unit instead: no pad there)
                     pad_kb = _GATE_PAD_KB if n_b <= _GATE_PAD_MAX_N else 0
-                    idx, gate, first_ready = pointops.furthest_point_sampling_gated(xyz_b, npoint_sa, nq, lds_pad=pad_kb * 1024)
+                    idx, gate, first_ready = pointops.furthest_point_sampling_gated(
+                        xyz_b, npoint_sa, nq, lds_pad=pad_kb * 1024, prepared=self.__dict__.pop("_gf_gate_prep", None))
                     first = idx
                     src = idx[0, :nq]
                     self._gf_last_gate = gate
@@ -704,7 +720,9 @@ class GeoFormer(nn.Module):
                 with torch.cuda.stream(side_b):
                     D, I, deg = graphs[b][:3]
                     if gate is not None:
-                        g = pointops.geodesic_bfs_gated(D, I, src, 0.05, max_step, gate, nq, wg_threads=_bfs_wg(int(src.shape[0])))
+                        g = pointops.geodesic_bfs_gated(D, I, src, 0.05, max_step, gate, nq, wg_threads=_BFS_WG or _GATE_WG,
+                                                        lds_cap=_GATE_LDS_KB * 1024)
+                        self._post_gate_flag(gate, _stream_key_of(locs_float_.device, main))
                     elif bfs_ms_scene:
                         g = pointops.geodesic_bfs_ms(D, I, src, 0.05, max_step)
                     else:
@@ -804,6 +822,24 @@ class GeoFormer(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(aux)
                     early["qpos"] = (q_locs, qpos, ev)
+
+    def _post_gate_flag(self, gate, key):
+        """(on the search's stream, behind the gated search) the search's time-out word to a pinned host word of the
+        CALLER's stream `key`, without a wait: the next forward -- or check_gate() -- looks at it."""
+        flags = self.__dict__.setdefault("_gf_gate_flags", {})
+        host = flags.get(key)
+        if host is None:
+            host = flags[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(gate[2:3], non_blocking=True)
+
+    def _check_gate_flag(self):
+        """The previous gated forward on this stream: did a search workgroup give up waiting for its source?  (Its copy
+        of the flag completed before that forward's last read-back; a host read, no device wait.)"""
+        host = self.__dict__.get("_gf_gate_flags", {}).get(_stream_key())
+        if host is not None and int(host[0]) != 0:
+            host.zero_()
+            raise RuntimeError("geodesic search: a workgroup of the previous forward's gated search timed out waiting for "
+                               "the sampling launch beside it (its distances are invalid); GF_BFS_GATE=0 disables the gated form")
 
     def check_gate(self):
         """True unless a search workgroup of the last gated sampling / search pair gave up waiting for its source (one
@@ -1136,6 +1172,10 @@ class GeoFormer(nn.Module):
             if backbone_done is not None:
                 backbone_done.record()
             yield backbone_done
+        if fused_fg and _BFS_GATE and batch_size == 1 and locs_float.is_cuda and not training and cfg.n_query_points > 224:
+            self._check_gate_flag()
+            # (the gated sampling launch's buffers and reset, queued while the host has nothing else to do)
+            self._gf_gate_prep = pointops.fps_gated_prepare(locs_float.device, self.set_aggregator.npoint)
         if fused_fg:
             fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = fg_pending.get()
         else:

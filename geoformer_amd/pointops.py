@@ -150,33 +150,45 @@ def furthest_point_sampling(xyz, m, known=None):
     return idx
 
 
-def furthest_point_sampling_gated(xyz, m, gate_at, lds_pad=88 * 1024):
+def fps_gated_prepare(device, m):
+    """Everything of furthest_point_sampling_gated that needs neither the points nor their number: output, scratch, the
+    scratch's reset (queued on the current stream) and the event the waiter orders itself behind.  A forward calls this
+    BEFORE it blocks on the foreground count, so that between the host's draw and the sampling launch -- the device idles
+    there -- only the launch itself is left."""
+    lib = _lib.load()
+    idx = torch.empty((1, int(m)), dtype=torch.int32, device=device)
+    ws = torch.empty(lib.gf_fps_scratch_bytes(1) // 8 + 1, dtype=torch.int64, device=device)
+    check(lib.gf_fps_scratch_reset(ptr(ws), 1, stream_ptr()), "gf_fps_scratch_reset")
+    reset_event = torch.cuda.Event()
+    reset_event.record()
+    off = (int(lib.gf_fps_gate_word(ptr(ws), 1)) - ws.data_ptr()) // 4
+    return idx, ws, ws.view(torch.int32)[off:off + 4], reset_event
+
+
+def furthest_point_sampling_gated(xyz, m, gate_at, lds_pad=88 * 1024, prepared=None):
     """One sampling launch over ONE point set [1,n,3] that tells a kernel running beside it when its first `gate_at`
     picks are stored (gf_furthest_point_sampling_gated).  Returns (idx int32 [1,m], gate int32 [4] -- a view into the
     launch's scratch: gate[0] = picks published, gate[2] = the waiter's time-out flag --, reset_event): the waiter's
     stream waits for `reset_event` (the gate is zero from there on), NOT for the launch, and hands `gate` to
     geodesic_bfs_gated.  lds_pad: LDS the sampling workgroups claim so that the waiter's workgroups stay off their
-    compute units."""
+    compute units.  prepared: the result of fps_gated_prepare(device, m) on this stream (else made here)."""
     _f32c(xyz, "xyz")
     b, n, _ = xyz.shape
     if b != 1:
         raise RuntimeError("furthest_point_sampling_gated: one point set")
-    lib = _lib.load()
-    idx = torch.empty((1, m), dtype=torch.int32, device=xyz.device)
-    scratch = torch.empty(lib.gf_fps_scratch_bytes(1) // 8 + 1, dtype=torch.int64, device=xyz.device)
-    check(lib.gf_fps_scratch_reset(ptr(scratch), 1, stream_ptr()), "gf_fps_scratch_reset")
-    reset_event = torch.cuda.Event()
-    reset_event.record()
-    check(lib.gf_furthest_point_sampling_gated(ptr(xyz), n, m, ptr(idx), ptr(scratch), int(gate_at), int(lds_pad),
-                                               stream_ptr()), "gf_furthest_point_sampling_gated")
-    off = (int(lib.gf_fps_gate_word(ptr(scratch), 1)) - scratch.data_ptr()) // 4
-    return idx, scratch.view(torch.int32)[off:off + 4], reset_event
+    if prepared is None or prepared[0].shape[1] != m or prepared[0].device != xyz.device:
+        prepared = fps_gated_prepare(xyz.device, m)
+    idx, ws, gate, reset_event = prepared
+    check(_lib.load().gf_furthest_point_sampling_gated(ptr(xyz), n, m, ptr(idx), ptr(ws), int(gate_at), int(lds_pad),
+                                                       stream_ptr()), "gf_furthest_point_sampling_gated")
+    return idx, gate, reset_event
 
 
-def geodesic_bfs_gated(D, I, src, radius, max_step, gate, gate_at, wg_threads=512):
+def geodesic_bfs_gated(D, I, src, radius, max_step, gate, gate_at, wg_threads=512, lds_cap=0):
     """geodesic_bfs whose sources are still being drawn by a furthest_point_sampling_gated launch on ANOTHER stream: src is
     a view of that launch's output (its first nq picks), gate the tensor it returned.  The current stream must have
-    waited for the sampler's reset_event.  gate[2] != 0 afterwards: a workgroup gave up waiting (one second)."""
+    waited for the sampler's reset_event.  gate[2] != 0 afterwards: a workgroup gave up waiting (one second).
+    lds_cap: upper bound (bytes) of a workgroup's LDS -- 768 threads with 64 KB: two workgroups per compute unit."""
     _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
     n, K = D.shape
     nq = src.shape[0]
@@ -189,7 +201,7 @@ def geodesic_bfs_gated(D, I, src, radius, max_step, gate, gate_at, wg_threads=51
     qwords = int(lib.gf_geodesic_bfs_queue_words(n))
     queues = scratch("bfs_queues", nq * qwords, torch.int32, dev)
     check(lib.gf_geodesic_bfs_gated(ptr(D), ptr(I), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), ptr(keys),
-                                    ptr(queues), qwords, int(wg_threads), gate.data_ptr(), int(gate_at),
+                                    ptr(queues), qwords, int(wg_threads), int(lds_cap), gate.data_ptr(), int(gate_at),
                                     gate.data_ptr() + 8, stream_ptr()), "gf_geodesic_bfs_gated")
     gate.record_stream(torch.cuda.current_stream(dev))
     return geo

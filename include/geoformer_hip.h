@@ -445,10 +445,12 @@ int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, in
 /* The search launched BESIDE the sampling launch that is still drawing its sources (gf_furthest_point_sampling_gated;
  * ABI 4): src points into that launch's output; every workgroup initialises its rows, then waits -- bounded: one second,
  * then gate_err[0] = 1 and the search runs on whatever the slot holds -- until gate[0] >= gate_at and reads its source
- * with an agent-scope load.  Zero gate_err before the launch.  LDS-resident kernel only (n <= 2^19, K % 4 == 0). */
+ * with an agent-scope load.  Zero gate_err before the launch.  LDS-resident kernel only (n <= 2^19, K % 4 == 0).
+ * lds_cap_bytes: upper bound of a workgroup's LDS (0: wg_threads' share of 150 KB): with 768 threads and 64 KB two
+ * workgroups share a compute unit, so 256 queries fit the 240 units the sampler leaves free in one round. */
 int gf_geodesic_bfs_gated(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
                           int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
-                          const int* gate, int gate_at, int* gate_err, void* stream);
+                          int lds_cap_bytes, const int* gate, int gate_at, int* gate_err, void* stream);
 
 /* The same search for ALL nq sources at once (csrc/geodesic_ms.hip): the queries are bit lanes of per-vertex frontier /
  * visited masks, a hop is ONE launch over every (vertex, mask word) that walks the vertex's in-neighbours in ascending

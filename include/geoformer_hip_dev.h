@@ -102,6 +102,9 @@ int gf_dev_bfs_ms_persist(int on);
 /* bytes of dynamic LDS every sampling (k_fps) workgroup claims without using them: keeps workgroups of other kernels that
    need more than the remainder of the 160 KB off the sampler's compute units (also GF_FPS_LDS_PAD, read once) */
 int gf_dev_fps_lds_pad(int bytes);
+/* upper bound (bytes, 0 = none) of the LDS a geodesic-search workgroup takes: 79 KB lets two 768-thread workgroups share a
+   compute unit (also GF_BFS_LDS_CAP, read once) */
+int gf_dev_bfs_lds_cap(int bytes);
 
 /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
 int gf_dev_conv_occupancy(int block);
