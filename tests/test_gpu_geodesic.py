@@ -263,6 +263,14 @@ def test_gated_sampling_and_search_equal_the_two_launch_form(hip):
             assert torch.equal(idx, ref_idx)
             assert int(gate[0].item()) >= nq and int(gate[2].item()) == 0
             assert torch.equal(geo, ref_geo), (pad, wg)
+        # the forward's gated shape: buffers prepared ahead, 768 threads per query, LDS capped so that two share a unit
+        prep = pointops.fps_gated_prepare(pts.device, m)
+        idx, gate, reset_ev = pointops.furthest_point_sampling_gated(pts, m, nq, lds_pad=pad, prepared=prep)
+        side.wait_event(reset_ev)
+        with torch.cuda.stream(side):
+            geo = pointops.geodesic_bfs_gated(gd, gi, idx[0, :nq], 0.05, 64, gate, nq, wg_threads=768, lds_cap=64 * 1024)
+        torch.cuda.synchronize()
+        assert torch.equal(idx, ref_idx) and int(gate[2].item()) == 0 and torch.equal(geo, ref_geo), pad
     # a gate beyond the last pick opens at the end of the launch
     idx, gate, reset_ev = pointops.furthest_point_sampling_gated(pts, 64, 1000)
     torch.cuda.synchronize()
