@@ -286,13 +286,44 @@ __device__ __forceinline__ f32x4 da_gemm_bf3(const uint4* __restrict__ sW3, int 
 #ifndef DA_BF3_WAVES
 #define DA_BF3_WAVES 16
 #endif
-__global__ __launch_bounds__(DA_BF3_WAVES * 64) void k_decoder_cross_attn_bf3(
+#ifndef DA_BF3_NT2_DEFAULT
+#define DA_BF3_NT2_DEFAULT 0
+#endif
+// NT tiles of 16 contexts per trip of a wave: every weight operand read from LDS serves NT products (a wave used to
+// re-read all 73 KB of packed weights for every tile: 2.9 GB of ds_read_b128 per launch, the LDS 43 % busy), and the NT
+// accumulator chains are independent, so consecutive MFMAs do not wait for each other.  <16, 1> is the round-4 shape
+// (128 registers, four waves per SIMD); <8, 2> holds two tiles' pieces (two waves per SIMD).
+template <int NT>
+__device__ __forceinline__ void da_gemm_bf3_n(const uint4* __restrict__ sW3, int m, int rb, int lane, const DaPieces (&X)[NT],
+                                              f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint4* w = sW3 + (size_t)(((m * 4 + rb) * 2 + h) * 3) * 64 + lane;
+        const da_bf16x8 ah = __builtin_bit_cast(da_bf16x8, w[0]), am = __builtin_bit_cast(da_bf16x8, w[64]),
+                        al = __builtin_bit_cast(da_bf16x8, w[128]);
+        // six piece pairs, smallest first; the tiles alternate inside a pair
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, __builtin_bit_cast(da_bf16x8, X[u].p[h][0]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(da_bf16x8, X[u].p[h][2]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(da_bf16x8, X[u].p[h][1]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, __builtin_bit_cast(da_bf16x8, X[u].p[h][0]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(da_bf16x8, X[u].p[h][1]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NT; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, __builtin_bit_cast(da_bf16x8, X[u].p[h][0]), acc[u], 0, 0, 0);
+    }
+}
+
+template <int WAVES, int NT>
+__global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn_bf3(
     const float* __restrict__ geo_ctx, const float* __restrict__ max_geo, const float* __restrict__ qloc,
     const float* __restrict__ cloc, const float* __restrict__ lo, const float* __restrict__ hi,
     const float* __restrict__ gaussB, const float* __restrict__ Q1, const float* __restrict__ K1,
     const float* __restrict__ Kv, const uint4* __restrict__ Wp3, int nq, int nc, float* __restrict__ out,
     float* __restrict__ stat_m, float* __restrict__ stat_l) {
-    constexpr int WAVES = DA_BF3_WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char da_smem[];
     uint4* sW3 = reinterpret_cast<uint4*>(da_smem);  // [3][4 rb][2 h][3 pieces][64 lanes]
     __shared__ float4 sQ1[16];
@@ -327,28 +358,31 @@ __global__ __launch_bounds__(DA_BF3_WAVES * 64) void k_decoder_cross_attn_bf3(
     __syncthreads();
 
     const int ntiles = (nc + 15) >> 4;
-    for (int t = w; t < ntiles; t += WAVES) {
-        const int ctx = t * 16 + j;
-        const bool valid = ctx < nc;
-        const int cc = valid ? ctx : nc - 1;
-        // --- relative embedding channels of this lane (as k_decoder_cross_attn) ---
-        const float gd = geo_ctx[cc];
-        float g0 = gd, g1 = gd, g2 = gd;
-        if (gd < 0.f) {
-            g0 = mg + fabsf(qx - cloc[cc * 3 + 0]);
-            g1 = mg + fabsf(qy - cloc[cc * 3 + 1]);
-            g2 = mg + fabsf(qz - cloc[cc * 3 + 2]);
-        }
-        const float t0 = ((g0 - lx) / sx) * 6.2831855f, t1 = ((g1 - ly) / sy) * 6.2831855f,
-                    t2 = ((g2 - lz) / sz) * 6.2831855f;
-        DaPieces RP;
-        {
+    for (int t0 = w * NT; t0 < ntiles; t0 += WAVES * NT) {
+        bool valid[NT];
+        int cc[NT];
+        DaPieces RP[NT];
+#pragma unroll
+        for (int u = 0; u < NT; u++) {
+            const int ctx = (t0 + u) * 16 + j;
+            valid[u] = ctx < nc;
+            cc[u] = valid[u] ? ctx : nc - 1;
+            // --- relative embedding channels of this lane (as k_decoder_cross_attn) ---
+            const float gd = geo_ctx[cc[u]];
+            float g0 = gd, g1 = gd, g2 = gd;
+            if (gd < 0.f) {
+                g0 = mg + fabsf(qx - cloc[cc[u] * 3 + 0]);
+                g1 = mg + fabsf(qy - cloc[cc[u] * 3 + 1]);
+                g2 = mg + fabsf(qz - cloc[cc[u] * 3 + 2]);
+            }
+            const float t0f = ((g0 - lx) / sx) * 6.2831855f, t1f = ((g1 - ly) / sy) * 6.2831855f,
+                        t2f = ((g2 - lz) / sz) * 6.2831855f;
             float R[4][4];  // R[kb][s]: channel kb*16 + 4g + s
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const float4 b0 = sB[0][half][g], b1 = sB[1][half][g], b2v = sB[2][half][g];
-                const float p[4] = {fmaf(t2, b2v.x, fmaf(t1, b1.x, t0 * b0.x)), fmaf(t2, b2v.y, fmaf(t1, b1.y, t0 * b0.y)),
-                                    fmaf(t2, b2v.z, fmaf(t1, b1.z, t0 * b0.z)), fmaf(t2, b2v.w, fmaf(t1, b1.w, t0 * b0.w))};
+                const float p[4] = {fmaf(t2f, b2v.x, fmaf(t1f, b1.x, t0f * b0.x)), fmaf(t2f, b2v.y, fmaf(t1f, b1.y, t0f * b0.y)),
+                                    fmaf(t2f, b2v.z, fmaf(t1f, b1.z, t0f * b0.z)), fmaf(t2f, b2v.w, fmaf(t1f, b1.w, t0f * b0.w))};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     float sn, cs;
@@ -357,41 +391,59 @@ __global__ __launch_bounds__(DA_BF3_WAVES * 64) void k_decoder_cross_attn_bf3(
                     R[2 + half][e] = cs;
                 }
             }
-            da_split_pack(R, RP);
+            da_split_pack(R, RP[u]);
         }
         // --- H^T = W1 . R^T, + Q1_i - K1_j, ReLU;  v^T = Wv . R^T ---
-        float H[4][4];
-        f32x4 V[4];
+        float H[NT][4][4];
+        f32x4 V[NT][4];
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) {
-            f32x4 acc = da_gemm_bf3(sW3, 0, rb, lane, RP, (f32x4){0.f, 0.f, 0.f, 0.f});
-            const float4 k1 = *reinterpret_cast<const float4*>(K1 + (size_t)cc * DA_D + rb * 16 + 4 * g);
+            f32x4 acc[NT], vv[NT];
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                vv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            da_gemm_bf3_n<NT>(sW3, 0, rb, lane, RP, acc);
             const float4 q1 = sQ1[rb * 4 + g];
-            H[rb][0] = fmaxf(acc[0] + q1.x - k1.x, 0.f);
-            H[rb][1] = fmaxf(acc[1] + q1.y - k1.y, 0.f);
-            H[rb][2] = fmaxf(acc[2] + q1.z - k1.z, 0.f);
-            H[rb][3] = fmaxf(acc[3] + q1.w - k1.w, 0.f);
-            V[rb] = da_gemm_bf3(sW3, 2, rb, lane, RP, (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                const float4 k1 = *reinterpret_cast<const float4*>(K1 + (size_t)cc[u] * DA_D + rb * 16 + 4 * g);
+                H[u][rb][0] = fmaxf(acc[u][0] + q1.x - k1.x, 0.f);
+                H[u][rb][1] = fmaxf(acc[u][1] + q1.y - k1.y, 0.f);
+                H[u][rb][2] = fmaxf(acc[u][2] + q1.z - k1.z, 0.f);
+                H[u][rb][3] = fmaxf(acc[u][3] + q1.w - k1.w, 0.f);
+            }
+            da_gemm_bf3_n<NT>(sW3, 2, rb, lane, RP, vv);
+#pragma unroll
+            for (int u = 0; u < NT; u++) V[u][rb] = vv[u];
             __builtin_amdgcn_sched_barrier(0);
         }
-        DaPieces HP;
-        da_split_pack(H, HP);
+        DaPieces HP[NT];
+#pragma unroll
+        for (int u = 0; u < NT; u++) da_split_pack(H[u], HP[u]);
         // --- sim^T = W2 . H^T, online softmax ---
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) {
-            const f32x4 s = da_gemm_bf3(sW3, 1, rb, lane, HP, (f32x4){0.f, 0.f, 0.f, 0.f});
-            const float4 kv = *reinterpret_cast<const float4*>(Kv + (size_t)cc * DA_D + rb * 16 + 4 * g);
-            const float kvv[4] = {kv.x, kv.y, kv.z, kv.w};
-            if (valid) {
+            f32x4 s[NT];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float x = s[r] * 0.125f;
-                    const float val = V[rb][r] + kvv[r];
-                    const float mn = fmaxf(sm[rb][r], x);
-                    const float corr = __expf(sm[rb][r] - mn), p = __expf(x - mn);
-                    sl[rb][r] = sl[rb][r] * corr + p;
-                    sa[rb][r] = sa[rb][r] * corr + p * val;
-                    sm[rb][r] = mn;
+            for (int u = 0; u < NT; u++) s[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            da_gemm_bf3_n<NT>(sW3, 1, rb, lane, HP, s);
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                const float4 kv = *reinterpret_cast<const float4*>(Kv + (size_t)cc[u] * DA_D + rb * 16 + 4 * g);
+                const float kvv[4] = {kv.x, kv.y, kv.z, kv.w};
+                if (valid[u]) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float x = s[u][r] * 0.125f;
+                        const float val = V[u][rb][r] + kvv[r];
+                        const float mn = fmaxf(sm[rb][r], x);
+                        const float corr = __expf(sm[rb][r] - mn), p = __expf(x - mn);
+                        sl[rb][r] = sl[rb][r] * corr + p;
+                        sa[rb][r] = sa[rb][r] * corr + p * val;
+                        sm[rb][r] = mn;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -508,15 +560,23 @@ extern "C" int gf_decoder_cross_attn_cfg(const float* geo_ctx, const float* max_
         g_da_bf3 = e ? (atoi(e) != 0) : 1;
     }
     if (wg_waves == 16 && g_da_bf3) {
-        static bool attr = false;
+        // shape: 0 (default) = sixteen waves, one tile per trip; 1 = eight waves, two tiles per trip (GF_CROSS_ATTN_NT2)
+        static const int nt2 = [] { const char* e = getenv("GF_CROSS_ATTN_NT2"); return e ? atoi(e) : DA_BF3_NT2_DEFAULT; }();
         const size_t lds = (size_t)DA_WPACK_BF3_U4 * sizeof(uint4);
+        static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)k_decoder_cross_attn_bf3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)k_decoder_cross_attn_bf3<DA_BF3_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)k_decoder_cross_attn_bf3<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        GF_LAUNCH_OP(GF_OP_CROSS_ATTN, k_decoder_cross_attn_bf3, dim3(nq, B), dim3(DA_BF3_WAVES * 64), lds, (hipStream_t)stream, geo_ctx,
-                     max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, reinterpret_cast<const uint4*>(Wpack + DA_WPACK_F32), nq, nc,
-                     out, stat_m, stat_l);
+        if (nt2)
+            GF_LAUNCH_OP(GF_OP_CROSS_ATTN, (k_decoder_cross_attn_bf3<8, 2>), dim3(nq, B), dim3(8 * 64), lds, (hipStream_t)stream,
+                         geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
+                         reinterpret_cast<const uint4*>(Wpack + DA_WPACK_F32), nq, nc, out, stat_m, stat_l);
+        else
+            GF_LAUNCH_OP(GF_OP_CROSS_ATTN, (k_decoder_cross_attn_bf3<DA_BF3_WAVES, 1>), dim3(nq, B), dim3(DA_BF3_WAVES * 64), lds,
+                         (hipStream_t)stream, geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
+                         reinterpret_cast<const uint4*>(Wpack + DA_WPACK_F32), nq, nc, out, stat_m, stat_l);
         GF_CHECK_LAUNCH("gf_decoder_cross_attn");
         return GF_OK;
     }
