@@ -46,6 +46,8 @@ def _declare(lib):
         "gf_dev_conv_g16p_wpb": (I, [I]),
         "gf_dev_conv_knobs": (I, [I, I, I, I, I]),
         "gf_dev_conv_knob_flat": (I, [I, I]),
+        "gf_dev_conv_knob_rw": (I, [I, I]),
+        "gf_dev_conv_rw_bounds": (I, [P, I]),
         "gf_dev_conv_occupancy": (I, [I]),
         "gf_resblock_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),

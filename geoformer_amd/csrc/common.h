@@ -84,6 +84,12 @@ int gf_conv_chain_supported(const GfChainOp& op);
 // counter: one zeroed device word per call.  Every op must pass gf_conv_chain_supported; nops <= GF_CHAIN_MAX_OPS.
 int gf_conv_chain(const GfChainOp* ops, int nops, unsigned* counter, hipStream_t st);
 
+// ---- register-weight convolution of the middle U-Net levels (spconv_rw.hip; dispatched by gf_conv_fwd) ----
+int gf_conv_rw_supported(int K, int M_in, int M_out, int Cin, int Cout, bool has_nbr, bool aligned, int* forced);
+int gf_conv_rw(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in, int M_out, int ld,
+               int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, const float* out_scale,
+               const float* out_shift, float* out, float* out2, hipStream_t st);
+
 // ---- dev hook: events BOUND to the next launch of an operator's main kernel (include/geoformer_hip_dev.h:
 // gf_dev_op_kernel_events).  hipExtLaunchKernelGGL's start / stop events are the dispatch's own begin / end timestamps,
 // i.e. what a profiler's kernel trace reports for that kernel -- no host time, no neighbouring launches inside.

@@ -1659,6 +1659,16 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
                (residual == nullptr || (((uintptr_t)residual) % 16) == 0) && in_bytes64 <= 0xffffff00ull;
     if (knobs.g16 >= 0) g16 = g16 && knobs.g16 != 0;
     else g16 = g16 && !split;
+    // register-weight kernel (spconv_rw.hip): the middle levels, and wherever the dev knob forces it
+    {
+        int forced = 0;
+        const bool aligned = vec && (((uintptr_t)out) % 16) == 0 && (residual == nullptr || (((uintptr_t)residual) % 16) == 0) &&
+                             (out2 == nullptr || (((uintptr_t)out2) % 16) == 0) && ld >= M_out;
+        if (gf_conv_rw_supported(K, M_in, M_out, Cin, Cout, nbr != nullptr && gmask != nullptr, aligned, &forced) && (forced || !flat) &&
+            (forced || !(g16 && nch == 1)))
+            return gf_conv_rw(in, Wp, nbr, gmask, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
+                              out_shift, out, out2, st);
+    }
     if (flat && (nbr != nullptr || K == 1) && out2 == nullptr) {
         if (K * nch <= 16 * FLAT_PF * FLAT_MAXB_SMALL)
             hipLaunchKernelGGL(k_conv_flat<FLAT_MAXB_SMALL>, dim3((unsigned)((long long)ngroups * ncb)), dim3(1024), 0, st, a.in,

@@ -214,11 +214,12 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
 
 
 def dev_conv_knobs(split=-1, wide=-1, pair=-1, ldsw=0, block=0, g16=-1, g16_ldsw=-1, g16_gpw=0, g16_pipe=-1, flat=-1,
-                   flat_items=0):
+                   flat_items=0, rw=-1, rw_items=0):
     """Dev hook (include/geoformer_hip_dev.h): force gf_conv_fwd's launch shape; no arguments = size-based choice."""
     check(_lib.load().gf_dev_conv_knobs(split, wide, pair, ldsw, block), "gf_dev_conv_knobs")
     check(_lib.load().gf_dev_conv_knobs_g16(g16, g16_ldsw, g16_gpw, g16_pipe), "gf_dev_conv_knobs_g16")
     check(_lib.load().gf_dev_conv_knob_flat(flat, flat_items), "gf_dev_conv_knob_flat")
+    check(_lib.load().gf_dev_conv_knob_rw(rw, rw_items), "gf_dev_conv_knob_rw")
 
 
 def dev_conv_g16p_wpb(wpb=0):
