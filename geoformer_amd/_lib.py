@@ -39,6 +39,9 @@ def _declare(lib):
         "gf_conv_pack_weights_t": (I, [P, I, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
         "gf_conv_dual_supported": (I, [I, I, I, I, I]),
+        "gf_rules_flat_words": (c_size_t, [I, I]),
+        "gf_rules_flat_steps": (I, [P, P, I, I, I, I, P, P]),
+        "gf_conv_fwd_flat": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_fwd_dual": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_dev_conv_fwd_timed": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
         "gf_dev_conv_knobs_g16": (I, [I, I, I, I]),
@@ -46,8 +49,7 @@ def _declare(lib):
         "gf_dev_conv_g16p_wpb": (I, [I]),
         "gf_dev_conv_knobs": (I, [I, I, I, I, I]),
         "gf_dev_conv_knob_flat": (I, [I, I]),
-        "gf_dev_conv_knob_rw": (I, [I, I]),
-        "gf_dev_conv_rw_bounds": (I, [P, I]),
+        "gf_dev_conv_knob_lw": (I, [I, I]),
         "gf_dev_conv_occupancy": (I, [I]),
         "gf_resblock_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),

@@ -84,10 +84,31 @@ int gf_conv_chain_supported(const GfChainOp& op);
 // counter: one zeroed device word per call.  Every op must pass gf_conv_chain_supported; nops <= GF_CHAIN_MAX_OPS.
 int gf_conv_chain(const GfChainOp* ops, int nops, unsigned* counter, hipStream_t st);
 
-// ---- register-weight convolution of the middle U-Net levels (spconv_rw.hip; dispatched by gf_conv_fwd) ----
-int gf_conv_rw_supported(int K, int M_in, int M_out, int Cin, int Cout, bool has_nbr, bool aligned, int* forced);
-int gf_conv_rw(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, int K, int M_in, int M_out, int ld,
-               int Cin, int Cout, const float* in_scale, const float* in_shift, const float* residual, const float* out_scale,
+// ---- LDS-weight convolution over a flat step table (spconv_lw.hip; dispatched by gf_conv_fwd when a flat table is given) ----
+// flat step table (spconv_rules.hip gf_rules_flat_steps writes it):
+//   header   [0] steps S, [1] bins NB, [2] groups, [3] K, [4] rounds J = ceil(groups / NB)
+//   sizes    [GF_FLAT_HIST + n] groups with n present offsets; [GF_FLAT_BSTART + n] first sorted position of that size
+//            (sizes descending); [GF_FLAT_BCUR + n] the fill kernel's cursor
+//   goff     [GF_FLAT_GOFF + g] first step of group g (g <= groups); behind it ppos[g]: the group's sorted position
+//   desc     int4 per (round j, bin b) at gf_flat_desc_at(): {group or -1, first step, steps, offset mask}: the groups
+//            sorted by size (descending) and dealt to the NB bins in snake order, so every bin (= one SIMD's waves of the
+//            conv kernel) carries the same number of steps to within a few
+//   steps    one 64-byte record of 16 input rows per (16-row group, present offset) in group-major, offset-ascending order,
+//            GF_FLAT_PAD records of -1 behind the last
+#define GF_FLAT_HIST 8
+#define GF_FLAT_BSTART 40
+#define GF_FLAT_BCUR 72
+#define GF_FLAT_GOFF 128
+#define GF_FLAT_BINS 1024  // default number of bins: four SIMDs of 256 compute units
+#define GF_FLAT_PAD 32     // records of -1 behind the last step (the conv kernel's loads run ahead)
+__host__ __device__ static inline size_t gf_flat_ppos_at(int ngroups) { return GF_FLAT_GOFF + (size_t)ngroups + 1; }
+__host__ __device__ static inline size_t gf_flat_desc_at(int ngroups) { return (GF_FLAT_GOFF + 2 * (size_t)ngroups + 1 + 63) / 64 * 64; }
+__host__ __device__ static inline size_t gf_flat_steps_at(int ngroups, int nbins) {
+    return gf_flat_desc_at(ngroups) + (size_t)((ngroups + nbins - 1) / nbins + 1) * nbins * 4;
+}
+int gf_conv_lw_supported(int K, int M_in, int M_out, int Cin, int Cout, bool aligned, int* forced);
+int gf_conv_lw(const float* in, const float* Wp, const uint32_t* gmask, const int32_t* flat, int K, int M_in, int M_out, int Cin,
+               int Cout, const float* in_scale, const float* in_shift, const float* residual, const float* out_scale,
                const float* out_shift, float* out, float* out2, hipStream_t st);
 
 // ---- dev hook: events BOUND to the next launch of an operator's main kernel (include/geoformer_hip_dev.h:

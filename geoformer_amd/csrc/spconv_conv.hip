@@ -1605,7 +1605,7 @@ extern "C" int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int bl
 }
 
 static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
-                         const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
+                         const int32_t* steps, const int32_t* fsteps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
                          const float* in_scale, const float* in_shift, const float* residual,
                          const float* out_scale, const float* out_shift, float* out, float* out2, void* stream) {
     GF_CHECK_ARG(K >= 1 && K <= 32, "gf_conv_fwd: K=%d out of range [1,32]", K);
@@ -1659,15 +1659,15 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
                (residual == nullptr || (((uintptr_t)residual) % 16) == 0) && in_bytes64 <= 0xffffff00ull;
     if (knobs.g16 >= 0) g16 = g16 && knobs.g16 != 0;
     else g16 = g16 && !split;
-    // register-weight kernel (spconv_rw.hip): the middle levels, and wherever the dev knob forces it
-    {
+    // LDS-weight kernel over the flat step table (spconv_lw.hip), where the caller built one
+    if (fsteps != nullptr && gmask != nullptr) {
         int forced = 0;
         const bool aligned = vec && (((uintptr_t)out) % 16) == 0 && (residual == nullptr || (((uintptr_t)residual) % 16) == 0) &&
-                             (out2 == nullptr || (((uintptr_t)out2) % 16) == 0) && ld >= M_out;
-        if (gf_conv_rw_supported(K, M_in, M_out, Cin, Cout, nbr != nullptr && gmask != nullptr, aligned, &forced) && (forced || !flat) &&
-            (forced || !(g16 && nch == 1)))
-            return gf_conv_rw(in, Wp, nbr, gmask, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
-                              out_shift, out, out2, st);
+                             (out2 == nullptr || (((uintptr_t)out2) % 16) == 0) &&
+                             (out_scale == nullptr || ((((uintptr_t)out_scale) | ((uintptr_t)out_shift)) % 16) == 0);
+        if (gf_conv_lw_supported(K, M_in, M_out, Cin, Cout, aligned, &forced) && (forced || !(g16 && nch == 1)))
+            return gf_conv_lw(in, Wp, gmask, fsteps, K, M_in, M_out, Cin, Cout, in_scale, in_shift, residual, out_scale, out_shift,
+                              out, out2, st);
     }
     if (flat && (nbr != nullptr || K == 1) && out2 == nullptr) {
         if (K * nch <= 16 * FLAT_PF * FLAT_MAXB_SMALL)
@@ -1747,8 +1747,21 @@ extern "C" int gf_conv_fwd(const float* in, const float* Wp, const int32_t* nbr,
                            const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout,
                            const float* in_scale, const float* in_shift, const float* residual,
                            const float* out_scale, const float* out_shift, float* out, void* stream) {
-    return conv_fwd_impl(in, Wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
+    return conv_fwd_impl(in, Wp, nbr, gmask, steps, nullptr, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
                          out_shift, out, nullptr, stream);
+}
+
+// gf_conv_fwd with the relation's flat step table (gf_rules_flat_steps; may be NULL) and an optional second output
+// (out_act, as gf_conv_fwd_dual; NULL = one output).  With a flat table the shapes whose packed weights fit the LDS take
+// the LDS-weight kernel (spconv_lw.hip); everything else is gf_conv_fwd / gf_conv_fwd_dual.
+extern "C" int gf_conv_fwd_flat(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask,
+                                const int32_t* steps, const int32_t* flat, int K, int M_in, int M_out, int ld, int Cin, int Cout,
+                                const float* in_scale, const float* in_shift, const float* residual,
+                                const float* out_scale, const float* out_shift, float* out, float* out_act, void* stream) {
+    GF_CHECK_ARG(out_act == nullptr || (out_scale != nullptr && out_shift != nullptr && ((uintptr_t)out_act % 16) == 0),
+                 "gf_conv_fwd_flat: the second output needs its scale / shift and 16-byte alignment");
+    return conv_fwd_impl(in, Wp, nbr, gmask, steps, flat, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
+                         out_shift, out, out_act, stream);
 }
 
 // gf_conv_fwd with TWO outputs: out = the raw sums (+ residual), out_act = max(out*out_scale + out_shift, 0).  The next
@@ -1771,7 +1784,7 @@ extern "C" int gf_conv_fwd_dual(const float* in, const float* Wp, const int32_t*
     GF_CHECK_ARG(out_act != nullptr && out_scale != nullptr && out_shift != nullptr,
                  "gf_conv_fwd_dual: the second output needs its scale / shift");
     GF_CHECK_ARG(((uintptr_t)out_act % 16) == 0, "gf_conv_fwd_dual: out_act must be 16-byte aligned");
-    return conv_fwd_impl(in, Wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
+    return conv_fwd_impl(in, Wp, nbr, gmask, steps, nullptr, K, M_in, M_out, ld, Cin, Cout, in_scale, in_shift, residual, out_scale,
                          out_shift, out, out_act, stream);
 }
 

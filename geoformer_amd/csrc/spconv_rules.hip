@@ -343,6 +343,146 @@ extern "C" int gf_rules_subm3(const int32_t* coords, int M, const int32_t* d_M, 
 }
 
 // ------------------------------------------------------------------------------------
+// Flat step table of a [K, ld] relation for the LDS-weight conv kernel (spconv_lw.hip, k_conv_lw): one 64-byte record
+// of 16 input rows per (16-row group, PRESENT offset), group-major and offset-ascending -- the order the kernel's
+// consumer walks with its mask iterator, so its gathers and index loads are linear in the step number and can run any
+// distance ahead of the MFMAs -- plus the groups SORTED BY SIZE and dealt to NB bins in snake order: a level of a scanned
+// room has ~3 groups of 6-27 steps per SIMD, and contiguous equal-cost chunks of whole groups left the slowest SIMD with
+// 1.7x the mean (profiles/r6_conv_lw_notes.md).  Layout: common.h (GF_FLAT_*).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_flat_scan(const uint32_t* __restrict__ gmask, int ngroups, int nbins, int K,
+                                                    int32_t* __restrict__ flat) {
+    __shared__ int s_wave[16];
+    __shared__ int s_cnt[16][32];   // groups of size n seen by wave w (its lanes' ranks inside the size come from here)
+    __shared__ int s_base[16][32];  // sorted position of wave w's first group of size n
+    int32_t* goff = flat + GF_FLAT_GOFF;
+    int32_t* ppos = flat + gf_flat_ppos_at(ngroups);
+    const uint32_t kmask = K >= 32 ? 0xffffffffu : ((1u << K) - 1u);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t < 512) (&s_cnt[0][0])[t] = 0;
+    __syncthreads();
+    const int per = (ngroups + 1023) / 1024;
+    const int lo = min(ngroups, t * per), hi = min(ngroups, lo + per);
+    int sum = 0;
+    for (int g = lo; g < hi; g++) {
+        const int n = __popc(gmask[g] & kmask);
+        sum += n;
+        // rank among the wave's groups of this size (LDS atomic on a wave-private counter: no cross-wave contention; the
+        // same ranking with one global atomic per group took 35-70 us on 9000 groups -- ~20 addresses, serialised at L2)
+        ppos[g] = atomicAdd(&s_cnt[wv][n & 31], 1);
+    }
+    int inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    if (t < 32) {  // thread n: the sizes' totals over the waves
+        int c = 0;
+        for (int w = 0; w < 16; w++) {
+            s_base[w][t] = c;
+            c += s_cnt[w][t];
+        }
+        flat[GF_FLAT_HIST + t] = c;
+        s_cnt[0][t] = c;  // (the counts are no longer needed: row 0 carries the totals to thread 0)
+    }
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int i = 0; i < 16; i++) {
+            const int v = s_wave[i];
+            s_wave[i] = acc;
+            acc += v;
+        }
+        goff[ngroups] = acc;
+        flat[0] = acc;
+        flat[1] = nbins;
+        flat[2] = ngroups;
+        flat[3] = K;
+        flat[4] = (ngroups + nbins - 1) / nbins;
+        int pos = 0;
+        for (int n = 31; n >= 0; n--) {  // sorted positions: sizes descending
+            flat[GF_FLAT_BSTART + n] = pos;
+            flat[GF_FLAT_BCUR + n] = 0;
+            const int c = s_cnt[0][n];
+            s_cnt[0][n] = pos;
+            pos += c;
+        }
+    }
+    __syncthreads();
+    int before = s_wave[wv] + inc - sum;  // steps of all groups in front of this thread's first one
+    for (int g = lo; g < hi; g++) {
+        goff[g] = before;
+        const int n = __popc(gmask[g] & kmask);
+        before += n;
+        ppos[g] += s_cnt[0][n & 31] + s_base[wv][n & 31];
+    }
+    // slots of the last round that no group takes
+    int32_t* desc = flat + gf_flat_desc_at(ngroups);
+    const int rounds = (ngroups + nbins - 1) / nbins;
+    for (int i = t; i < nbins; i += 1024) {
+        if (rounds > 0) reinterpret_cast<int4*>(desc)[(size_t)(rounds - 1) * nbins + i] = make_int4(-1, 0, 0, 0);
+        reinterpret_cast<int4*>(desc)[(size_t)rounds * nbins + i] = make_int4(-1, 0, 0, 0);
+    }
+}
+
+// one thread per (group, row): the group's present offsets in ascending order; row 0 also files the group's descriptor
+// under its sorted position
+__global__ void k_flat_fill(const int32_t* __restrict__ nbr, const uint32_t* __restrict__ gmask, int ngroups, int nbins, int M,
+                            int ld, int K, int32_t* __restrict__ flat) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = t >> 4, r = t & 15;
+    if (g >= ngroups) return;
+    const int32_t* goff = flat + GF_FLAT_GOFF;
+    int32_t* steps = flat + gf_flat_steps_at(ngroups, nbins);
+    const uint32_t kmask = K >= 32 ? 0xffffffffu : ((1u << K) - 1u);
+    const uint32_t mask = gmask[g] & kmask;
+    uint32_t m = mask;
+    const int s0 = goff[g];
+    int s = s0;
+    const int o = g * 16 + r;
+    while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1;
+        steps[(size_t)s * 16 + r] = o < M ? nbr[(size_t)k * ld + o] : -1;
+        s++;
+    }
+    if (g == ngroups - 1)
+        for (int p = 0; p < GF_FLAT_PAD; p++) steps[(size_t)(s + p) * 16 + r] = -1;
+    if (r == 0) {
+        const int p = flat[gf_flat_ppos_at(ngroups) + g];
+        const int j = p / nbins, x = p - j * nbins;
+        const int b = (j & 1) ? nbins - 1 - x : x;
+        int32_t* desc = flat + gf_flat_desc_at(ngroups);
+        reinterpret_cast<int4*>(desc)[(size_t)j * nbins + b] = make_int4(g, s0, s - s0, (int)mask);
+    }
+}
+
+extern "C" size_t gf_rules_flat_words(int K, int ld) {
+    const int ngroups = ld / 16;
+    return gf_flat_steps_at(ngroups, GF_FLAT_BINS) + ((size_t)K * ngroups + GF_FLAT_PAD) * 16;
+}
+
+extern "C" int gf_rules_flat_steps(const int32_t* nbr, const uint32_t* gmask, int K, int M, int ld, int nbins,
+                                   int32_t* flat, void* stream) {
+    GF_CHECK_ARG(nbr && gmask && flat, "gf_rules_flat_steps: null argument");
+    GF_CHECK_ARG(K >= 1 && K <= 31 && M >= 0 && ld >= M && (ld % 16) == 0, "gf_rules_flat_steps: K=%d M=%d ld=%d", K, M, ld);
+    if (nbins <= 0) nbins = GF_FLAT_BINS;
+    GF_CHECK_ARG(nbins % 4 == 0 && nbins <= GF_FLAT_BINS, "gf_rules_flat_steps: %d bins (a multiple of 4, at most %d)", nbins,
+                 GF_FLAT_BINS);
+    const int ngroups = (M + 15) / 16;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_flat_scan, dim3(1), dim3(1024), 0, st, gmask, ngroups, nbins, K, flat);
+    if (ngroups > 0)
+        hipLaunchKernelGGL(k_flat_fill, dim3(gf_div_up((long long)ngroups * 16, 256)), dim3(256), 0, st, nbr, gmask, ngroups, nbins,
+                           M, ld, K, flat);
+    GF_CHECK_LAUNCH("gf_rules_flat_steps");
+    return GF_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // strided 2x2x2 / stride 2
 // ------------------------------------------------------------------------------------
 __global__ void k_down_bits(const int32_t* __restrict__ coords, int Mcap, const int32_t* __restrict__ d_M, int OX,

@@ -63,16 +63,18 @@ struct LevelTables {  // submanifold table of one level
     int32_t* nbr = nullptr;
     uint32_t* gmask = nullptr;
     int32_t* steps = nullptr;
+    int32_t* flat = nullptr;  // flat step table (gf_rules_flat_steps) of the levels the LDS-weight conv kernel serves
     int ld = 0;
 };
 
 // events of the side-stream fork/join and the two host waits: per host thread, created once
 struct EvPair {
-    hipEvent_t fork = nullptr, chain = nullptr, chain2 = nullptr, rules = nullptr;
+    hipEvent_t fork = nullptr, chain = nullptr, chain2 = nullptr, rules = nullptr, tbl0 = nullptr, flat0 = nullptr, tbl1 = nullptr, flat1 = nullptr;
 };
 thread_local EvPair t_ev;
 
 constexpr int kStepsMinRows = 6000 * 16;  // gf_conv_fwd takes the counted-loop kernel from 6000 groups up
+constexpr int kFlatMinRows = 1500 * 16;   // gf_conv_fwd_flat takes the LDS-weight kernel from 1500 groups up (spconv_lw.hip)
 
 struct LevelBufs {  // feature buffers of one level, [rows, C] each (cat: [rows, 2C])
     float *x, *tmp, *idn, *o0, *o1, *o2, *up, *tr, *cat, *a0, *a1;
@@ -224,12 +226,14 @@ static size_t unet_layout(const GfUnetParams* P, int M0, int B, int X, int Y, in
     a.take<int32_t>((size_t)27 * ld0);
     a.take<uint32_t>(ld0 / 16);
     a.take<int32_t>(gf_rules_steps_words(ld0));
+    if (ld0 >= kFlatMinRows) a.take<int32_t>(gf_rules_flat_words(27, ld0));
     a.take<int32_t>((size_t)total);
     a.take<int32_t>(GF_UNET_MAX_LEVELS + 1);
     a.take<unsigned>((size_t)kChainCounters * 64);
     for (int l = 1; l <= nl; l++) {
         a.take<int32_t>((size_t)27 * caps[l]);
         a.take<uint32_t>(caps[l] / 16);
+        if (caps[l] >= kFlatMinRows) a.take<int32_t>(gf_rules_flat_words(27, caps[l]));
     }
     // features: per level at its capacity (the call itself carves them at the real row counts, which are smaller)
     for (int l = 0; l <= nl; l++) {
@@ -301,6 +305,10 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     if (forked && !t_ev.fork) {
         GF_TRY(hipEventCreateWithFlags(&t_ev.fork, hipEventDisableTiming));
         GF_TRY(hipEventCreateWithFlags(&t_ev.rules, hipEventDisableTiming));
+        GF_TRY(hipEventCreateWithFlags(&t_ev.tbl0, hipEventDisableTiming));
+        GF_TRY(hipEventCreateWithFlags(&t_ev.flat0, hipEventDisableTiming));
+        GF_TRY(hipEventCreateWithFlags(&t_ev.tbl1, hipEventDisableTiming));
+        GF_TRY(hipEventCreateWithFlags(&t_ev.flat1, hipEventDisableTiming));
     }
     if (!t_ev.chain) {
         GF_TRY(hipEventCreateWithFlags(&t_ev.chain, hipEventDisableTiming));
@@ -322,6 +330,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         int32_t* s = a.take<int32_t>(gf_rules_steps_words(ld0));
         T[0].steps = ld0 >= kStepsMinRows ? s : nullptr;
     }
+    if (ld0 >= kFlatMinRows) T[0].flat = a.take<int32_t>(gf_rules_flat_words(27, ld0));
     int32_t* cws = a.take<int32_t>((size_t)chain_elems);
     int32_t* d_counts = a.take<int32_t>(GF_UNET_MAX_LEVELS + 1);
     unsigned* chain_counters = a.take<unsigned>((size_t)kChainCounters * 64);
@@ -329,6 +338,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         T[l].ld = caps[l];
         T[l].nbr = a.take<int32_t>((size_t)27 * caps[l]);
         T[l].gmask = a.take<uint32_t>(caps[l] / 16);
+        if (caps[l] >= kFlatMinRows) T[l].flat = a.take<int32_t>(gf_rules_flat_words(27, caps[l]));
     }
 
     int rc;
@@ -354,6 +364,24 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     }
     UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, st));
     UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, st));
+    // the first level's flat step table (its one reader is the up pass's 32 -> 16 convolution, the last block of the call):
+    // built on the side stream BEHIND the deeper levels' tables, i.e. beside the second level's convolutions -- beside the
+    // first level's own it cost them 18 -> 31 us per launch (profiles/r6_conv_lw_notes.md)
+    if (T[0].flat && M0 < kFlatMinRows) T[0].flat = nullptr;
+    bool flat0_pending = false, flat1_pending = false;
+    auto build_flat0 = [&]() -> int {
+        if (!T[0].flat) return GF_OK;
+        if (forked) {
+            GF_TRY(hipStreamWaitEvent(ss, t_ev.tbl0, 0));  // (recorded below, right behind gf_rules_subm3 of the first level)
+            const int r_ = gf_rules_flat_steps(T[0].nbr, T[0].gmask, 27, M0, ld0, 0, T[0].flat, ss);
+            if (r_ != GF_OK) return r_;
+            GF_TRY(hipEventRecord(t_ev.flat0, ss));
+            flat0_pending = true;
+            return GF_OK;
+        }
+        return gf_rules_flat_steps(T[0].nbr, T[0].gmask, 27, M0, ld0, 0, T[0].flat, st);
+    };
+    if (forked) GF_TRY(hipEventRecord(t_ev.tbl0, st));
 
     // feature buffers are carved after the counts are known for the levels below the first; level 1 now
     int M[GF_UNET_MAX_LEVELS];
@@ -443,7 +471,21 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
             if (r_ != GF_OK) return r_;
         }
         const bool rec = pb.mode == 2 || ((pb.mode == 1 || pb.mode == 3) && l == 0 && (kind == 1 || kind == 2) && Cin == 16 && Cout == 16);
+        // (a submanifold convolution of a level with a flat step table hands it over: gf_conv_fwd_flat)
+        const int32_t* fl = (K == 27 && nbr != nullptr && nbr == T[l].nbr) ? T[l].flat : nullptr;
+        if (fl && !gf_conv_lw_supported(K, M_in, M_out, Cin, Cout, true, nullptr)) fl = nullptr;  // (no wait for a table nobody reads)
+        if (fl && l == 0 && flat0_pending) {
+            GF_TRY(hipStreamWaitEvent(st, t_ev.flat0, 0));
+            flat0_pending = false;
+        }
+        if (fl && l == 1 && flat1_pending) {
+            GF_TRY(hipStreamWaitEvent(st, t_ev.flat1, 0));
+            flat1_pending = false;
+        }
         auto launch = [&]() -> int {
+            if (fl)
+                return gf_conv_fwd_flat(in, wp, nbr, gmask, steps, fl, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp,
+                                        out_act, st);
             if (out_act)
                 return gf_conv_fwd_dual(in, wp, nbr, gmask, steps, K, M_in, M_out, ld, Cin, Cout, sc, sh, res, osc, osh, outp,
                                         out_act, st);
@@ -549,8 +591,22 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     auto subm_tables = [&](int l, hipStream_t s_) -> int {
         if (M[l] == 0) return GF_OK;
         const long long* o = offs + (l - 1) * 10;
-        return gf_rules_subm3(lcoords[l], M[l], nullptr, shapes[3 * l], shapes[3 * l + 1], shapes[3 * l + 2],
-                              (const uint32_t*)(cws + o[0]), cws + o[1], nullptr, T[l].nbr, T[l].ld, T[l].gmask, nullptr, s_);
+        const int r_ = gf_rules_subm3(lcoords[l], M[l], nullptr, shapes[3 * l], shapes[3 * l + 1], shapes[3 * l + 2],
+                                      (const uint32_t*)(cws + o[0]), cws + o[1], nullptr, T[l].nbr, T[l].ld, T[l].gmask, nullptr, s_);
+        if (r_ != GF_OK) return r_;
+        if (T[l].flat && M[l] < kFlatMinRows) T[l].flat = nullptr;
+        if (!T[l].flat) return GF_OK;
+        if (l == 1 && forked && s_ == st) {
+            // the second level's flat table beside its strided convolution (which does not read it), not in front of it
+            GF_TRY(hipEventRecord(t_ev.tbl1, st));
+            GF_TRY(hipStreamWaitEvent(ss, t_ev.tbl1, 0));
+            const int r2 = gf_rules_flat_steps(T[l].nbr, T[l].gmask, 27, M[l], T[l].ld, 0, T[l].flat, ss);
+            if (r2 != GF_OK) return r2;
+            GF_TRY(hipEventRecord(t_ev.flat1, ss));
+            flat1_pending = true;
+            return GF_OK;
+        }
+        return gf_rules_flat_steps(T[l].nbr, T[l].gmask, 27, M[l], T[l].ld, 0, T[l].flat, s_);
     };
     auto take_counts = [&](int l0, int l1) -> int {
         for (int l = l0; l <= l1; l++) {
@@ -572,12 +628,19 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
                     caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x, nullptr,
                     l + 1);
     };
+    // a level whose C -> C convolutions run the LDS-weight kernel (both outputs): a block's second convolution also writes
+    // the next block's activated input, whose first convolution then has no prologue (as the first level does, dual0)
+    auto lw_dual = [&](int l) -> bool {
+        return l > 0 && T[l].flat != nullptr && gf_conv_lw_supported(27, M[l], M[l], P->level[l].C, P->level[l].C, true, nullptr) != 0;
+    };
     auto two_blocks = [&](int l) -> int {
         const GfUnetLevelParams& L = P->level[l];
-        int r = resblock(L.blocks[0], l, L.C, Bf[l].x, Bf[l].o0, nullptr, nullptr);
+        const bool dual = lw_dual(l);
+        const NextAct n1{L.blocks[1].s0, L.blocks[1].t0, Bf[l].a1};
+        int r = resblock(L.blocks[0], l, L.C, Bf[l].x, Bf[l].o0, nullptr, nullptr, nullptr, dual ? &n1 : nullptr);
         if (r != GF_OK) return r;
         blocks_done[l] = true;
-        return resblock(L.blocks[1], l, L.C, Bf[l].o0, Bf[l].o1, nullptr, nullptr);
+        return resblock(L.blocks[1], l, L.C, Bf[l].o0, Bf[l].o1, nullptr, nullptr, dual ? Bf[l].a1 : nullptr, nullptr);
     };
     if (nl > 0) {
         // the whole chain is queued at once (it carries its counts on the device); two events mark the points the
@@ -618,6 +681,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
             GF_TRY(hipEventRecord(t_ev.rules, ss));
             GF_TRY(hipStreamWaitEvent(st, t_ev.rules, 0));
         }
+        UN_TRY(build_flat0());
         for (int l = 2; l <= nl; l++) carve(l);
         if (chain_on) {  // the run of deepest levels whose convolutions all are flat-form launches
             chain_from = nl + 1;
@@ -629,6 +693,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         }
     }
 
+    if (nl <= 1) UN_TRY(build_flat0());
     // ---- down pass ----
     for (int l = 1; l < nl; l++) {
         if (!blocks_done[l]) UN_TRY(two_blocks(l));
@@ -655,7 +720,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
                 hipLaunchKernelGGL(k_concat2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)Bf[l].o1,
                                    (const float4*)Bf[l].up, M[l], c4, (float4*)Bf[l].cat);
             }
-            const bool dual = l == 0 && dual0;  // tail[0]'s second conv writes tail[1]'s activated input as well
+            const bool dual = (l == 0 && dual0) || lw_dual(l);  // tail[0]'s second conv writes tail[1]'s activated input as well
             const NextAct nt{L.tail[1].s0, L.tail[1].t0, Bf[l].a1};
             if (chained)
                 UN_TRY(resblock(L.tail[0], l, 2 * L.C, Bf[l].o1, Bf[l].o0, nullptr, nullptr, nullptr, nullptr, Bf[l].up));

@@ -21,6 +21,7 @@ def _round16(n: int) -> int:
 
 
 STEPS_MIN_ROWS = 6000 * 16  # gf_conv_fwd takes the counted-loop kernel from 6000 groups up (csrc/spconv_conv.hip)
+FLAT_MIN_ROWS = 1500 * 16  # gf_conv_fwd_flat takes the LDS-weight kernel from 1500 groups up (csrc/spconv_lw.hip)
 
 
 @dataclass
@@ -42,6 +43,7 @@ class SubmRules:
     M: int
     K: int = 27
     steps: Optional[torch.Tensor] = None  # int32: step table [ld/16, 7, 16, 4] + chunk boundaries (gf_rules_subm3)
+    flat: Optional[torch.Tensor] = None  # int32: flat step table (gf_rules_flat_steps) for the LDS-weight conv kernel
 
     def pairs(self):
         """Canonical spconv pair lists: for each offset k the (in,out) pairs in ascending out."""
@@ -111,7 +113,16 @@ def subm_rules(coords: torch.Tensor, index: LevelIndex) -> SubmRules:
                            ptr(nbr), ld, ptr(gmask), ptr(steps), stream_ptr()),
         "gf_rules_subm3",
     )
-    return SubmRules(nbr, gmask, ld, M, 27, steps)
+    flat = flat_steps(nbr, gmask, 27, M, ld) if ld >= FLAT_MIN_ROWS else None
+    return SubmRules(nbr, gmask, ld, M, 27, steps, flat)
+
+
+def flat_steps(nbr: torch.Tensor, gmask: torch.Tensor, K: int, M: int, ld: int, nbins: int = 0) -> torch.Tensor:
+    """Flat step table of a [K, ld] relation (include/geoformer_hip.h: gf_rules_flat_steps)."""
+    lib = _lib.load()
+    flat = torch.empty(lib.gf_rules_flat_words(K, ld), dtype=torch.int32, device=nbr.device)
+    check(lib.gf_rules_flat_steps(ptr(nbr), ptr(gmask), K, M, ld, nbins, ptr(flat), stream_ptr()), "gf_rules_flat_steps")
+    return flat
 
 
 def down_rules(coords: torch.Tensor, batch: int, shape) -> DownRules:
@@ -175,7 +186,7 @@ def pack_weights(weight: torch.Tensor) -> torch.Tensor:
 
 def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tensor], gmask: Optional[torch.Tensor],
              K: int, M_out: int, ld: int, in_scale=None, in_shift=None, residual=None, out=None,
-             events=None, steps=None, out_scale=None, out_shift=None, packed=None) -> torch.Tensor:
+             events=None, steps=None, out_scale=None, out_shift=None, packed=None, flat=None) -> torch.Tensor:
     """out[o] = sum_k act(feats[nbr[k,o]]) @ weight[k] (+ residual), optionally followed by the epilogue activation
     max(out*out_scale + out_shift, 0).  weight is [K,Cin,Cout] fp32; packed = (wp, Cin, Cout): weights that are
     packed already (weight is ignored)."""
@@ -205,6 +216,14 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
             "gf_dev_conv_fwd_timed",
         )
         return out
+    if flat is not None:
+        check(
+            lib.gf_conv_fwd_flat(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), ptr(steps), ptr(flat), K, feats.shape[0], M_out, ld,
+                                 Cin, Cout, ptr(in_scale), ptr(in_shift), ptr(residual), ptr(out_scale), ptr(out_shift),
+                                 ptr(out), None, stream_ptr()),
+            "gf_conv_fwd_flat",
+        )
+        return out
     check(
         lib.gf_conv_fwd(ptr(feats), ptr(wp), ptr(nbr), ptr(gmask), ptr(steps), K, feats.shape[0], M_out, ld, Cin, Cout, ptr(in_scale),
                         ptr(in_shift), ptr(residual), ptr(out_scale), ptr(out_shift), ptr(out), stream_ptr()),
@@ -214,12 +233,12 @@ def conv_fwd(feats: torch.Tensor, weight: torch.Tensor, nbr: Optional[torch.Tens
 
 
 def dev_conv_knobs(split=-1, wide=-1, pair=-1, ldsw=0, block=0, g16=-1, g16_ldsw=-1, g16_gpw=0, g16_pipe=-1, flat=-1,
-                   flat_items=0, rw=-1, rw_items=0):
+                   flat_items=0, lw=-1, lw_items=0):
     """Dev hook (include/geoformer_hip_dev.h): force gf_conv_fwd's launch shape; no arguments = size-based choice."""
     check(_lib.load().gf_dev_conv_knobs(split, wide, pair, ldsw, block), "gf_dev_conv_knobs")
     check(_lib.load().gf_dev_conv_knobs_g16(g16, g16_ldsw, g16_gpw, g16_pipe), "gf_dev_conv_knobs_g16")
     check(_lib.load().gf_dev_conv_knob_flat(flat, flat_items), "gf_dev_conv_knob_flat")
-    check(_lib.load().gf_dev_conv_knob_rw(rw, rw_items), "gf_dev_conv_knob_rw")
+    check(_lib.load().gf_dev_conv_knob_lw(lw, lw_items), "gf_dev_conv_knob_lw")
 
 
 def dev_conv_g16p_wpb(wpb=0):

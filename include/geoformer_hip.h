@@ -135,6 +135,17 @@ int gf_conv_pack_weights(const float* W, int K, int Cin, int Cout, float* Wp, vo
  * comment: weights W[K-1-k]^T over the same table), 0 for the child <-> up tables. */
 int gf_conv_pack_weights_t(const float* W, int K, int Cin, int Cout, int flip, float* Wp, void* stream);
 
+/* FLAT STEP TABLE of a [K,ld] relation (nbr + gmask as gf_rules_subm3 / gf_rules_down2 write them; the reference's
+ * spconv keeps this as its indice pairs, spconv/ops.py get_indice_pairs via geoformer_modules.py:52-129): one 64-byte
+ * record of 16 input rows per (16-row group, PRESENT offset), group-major and offset-ascending, behind a header, the
+ * per-group step offsets and a bin table: the groups sorted by their number of steps (descending) and dealt to `nbins`
+ * bins (0 = the default 1024 = one per SIMD; gf_conv_fwd_flat expects the default) in snake order, one
+ * {group, first step, steps, offset mask} descriptor per (round, bin).  gf_conv_fwd_flat's LDS-weight kernel walks a
+ * bin's records linearly.  K <= 31.  flat: int32 [gf_rules_flat_words(K, ld)] out. */
+size_t gf_rules_flat_words(int K, int ld);
+int gf_rules_flat_steps(const int32_t* nbr, const uint32_t* gmask, int K, int M, int ld, int nbins, int32_t* flat,
+                        void* stream);
+
 /* Forward gather-GEMM (output-stationary): out[o,:] = sum_k act(in[nbr[k][o],:]) @ W[k] (+ residual[o,:])
  *   in fp32 [M_in,Cin]   Wp = packed W (gf_conv_pack_weights)   out fp32 [M_out,Cout]
  *   (M_in bounds the buffer descriptor the gathers go through)
@@ -161,6 +172,15 @@ int gf_conv_fwd_dual(const float* in, const float* Wp, const int32_t* nbr, const
                      int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale, const float* in_shift,
                      const float* residual, const float* out_scale, const float* out_shift, float* out, float* out_act,
                      void* stream);
+
+/* gf_conv_fwd with the relation's flat step table (gf_rules_flat_steps; NULL = none) and an optional second output
+ * (out_act as gf_conv_fwd_dual; NULL = one output).  With a table, the shapes whose packed weights fit the LDS
+ * (K = 27, 16 / 32 output channels, 16-channel multiples in) run the LDS-weight kernel, which also has both outputs;
+ * every other shape is gf_conv_fwd / gf_conv_fwd_dual (same results to fp32 summation order). */
+int gf_conv_fwd_flat(const float* in, const float* Wp, const int32_t* nbr, const uint32_t* gmask, const int32_t* steps,
+                     const int32_t* flat, int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* in_scale,
+                     const float* in_shift, const float* residual, const float* out_scale, const float* out_shift,
+                     float* out, float* out_act, void* stream);
 
 /* Pre-activation residual block (ResidualBlock, model/geoformer/geoformer_modules.py:10-35) in eval mode, one
  * call:  out = conv1(relu(bn1(conv0(relu(bn0(x)))))) + (Wpi ? x . Wi : x).

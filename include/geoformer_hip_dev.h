@@ -38,12 +38,9 @@ int gf_dev_conv_knobs_g16(int use, int ldsw, int gpw, int pipe);
  * default bound of 256). */
 int gf_dev_conv_knob_flat(int use, int max_items);
 
-/* The register-weight kernel of the middle levels (k_conv_rw, spconv_rw.hip): use 0 / 1 (whenever the shape allows:
- * 16-channel multiples, K = 27 or 8, a [K,ld] table) or -1 (size-based: at least `min_items` (16-row group, column
- * block) items -- 0 = the default 1024 -- and at least 32 input channels). */
-int gf_dev_conv_knob_rw(int use, int min_items);
-/* Range boundaries of k_conv_rw computed by the caller: n + 1 device ints (first group of every range); NULL = off. */
-int gf_dev_conv_rw_bounds(const int32_t* bounds, int n);
+/* The LDS-weight kernel over a flat step table (k_conv_lw, spconv_lw.hip; only where gf_conv_fwd_flat is given such a
+ * table): use 0 / 1 (whenever the shape allows) or -1 (size-based: at least `min_groups` 16-row groups, 0 = default). */
+int gf_dev_conv_knob_lw(int use, int min_groups);
 
 /* Number of equal-cost chunks (= waves of the pipelined kernel) the NEXT rulebooks are built with: a multiple of 4,
  * at most 4096; 0 = default (3072 = 12 waves per compute unit). */

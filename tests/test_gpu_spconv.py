@@ -238,3 +238,113 @@ def test_wgrad_without_table_is_xt_g(hip, M, Cin, Cout):
     assert float((dW[0].double() - want).abs().max()) <= tol
     check(lib.gf_conv_wgrad_masked_acc(ptr(x), ptr(gy), None, None, 1, M, 0, Cin, Cout, ptr(dW), stream_ptr()), "wgrad")
     assert float((dW[0].double() - 2 * want).abs().max()) <= 2 * tol
+
+
+def _flat_reference(nbr, M, K=27):
+    """The flat step table's step records restated in numpy: per 16-row group the present offsets, ascending."""
+    ng = (M + 15) // 16
+    pad = np.full((K, ng * 16), -1, np.int32)
+    pad[:, :M] = nbr[:, :M]
+    recs, goff, masks = [], [0], []
+    for g in range(ng):
+        blk = pad[:, g * 16:(g + 1) * 16]
+        ks = [k for k in range(K) if (blk[k] >= 0).any()]
+        masks.append(sum(1 << k for k in ks))
+        recs += [blk[k] for k in ks]
+        goff.append(goff[-1] + len(ks))
+    return np.array(recs, np.int32).reshape(-1, 16), np.array(goff), np.array(masks, np.uint32)
+
+
+@pytest.mark.parametrize("M,shape,nbins", [(3000, (40, 36, 30), 0), (30000, (90, 80, 60), 0), (777, (20, 22, 18), 64), (40, (8, 8, 8), 0)])
+def test_flat_step_table(hip, oracle, M, shape, nbins):
+    """gf_rules_flat_steps against the neighbour table it restates: step records and per-group offsets bit for bit;
+    the bin table: every group exactly once, sizes descending along the sorted positions, snake order, bins balanced."""
+    from geoformer_amd import sparse
+
+    rng = np.random.default_rng(M)
+    coords = random_voxels(rng, M, shape, 1, surface=True)
+    M = coords.shape[0]
+    nbr = oracle.rules_subm3(coords, shape)
+    c = _dev(coords)
+    rules = sparse.subm_rules(c, sparse.build_index(c, 1, shape))
+    flat = sparse.flat_steps(rules.nbr, rules.gmask, 27, M, rules.ld, nbins).cpu().numpy()
+    recs, goff, masks = _flat_reference(nbr, M)
+    ng = (M + 15) // 16
+    S = int(goff[-1])
+    nb = nbins if nbins else 1024
+    rounds = (ng + nb - 1) // nb
+    assert tuple(flat[:5]) == (S, nb, ng, 27, rounds)
+    assert (rules.gmask.cpu().numpy().view(np.uint32)[:ng] == masks).all()
+    sizes = np.diff(goff)
+    assert (flat[8: 8 + 32] == np.bincount(sizes, minlength=32)).all()
+    assert (flat[128: 128 + ng + 1] == goff).all()
+    ppos = flat[128 + ng + 1: 128 + 2 * ng + 1]
+    assert (np.sort(ppos) == np.arange(ng)).all()
+    d_at = (128 + 2 * ng + 1 + 63) // 64 * 64
+    desc = flat[d_at: d_at + (rounds + 1) * nb * 4].reshape(rounds + 1, nb, 4)
+    s_at = d_at + (rounds + 1) * nb * 4
+    got = flat[s_at: s_at + (S + 32) * 16].reshape(-1, 16)
+    assert (got[:S] == recs).all()
+    assert (got[S:] == -1).all()
+    # sorted positions: round j runs over the bins forwards (even) or backwards (odd)
+    order = np.concatenate([desc[j] if j % 2 == 0 else desc[j, ::-1] for j in range(rounds + 1)])
+    filled = order[:, 0] >= 0
+    assert filled[:ng].all() and not filled[ng:].any()
+    gs = order[:ng, 0]
+    assert (np.sort(gs) == np.arange(ng)).all()
+    assert (order[:ng, 1] == goff[gs]).all() and (order[:ng, 2] == sizes[gs]).all()
+    assert (order[:ng, 3].view(np.uint32) == masks[gs]).all()
+    assert (np.diff(order[:ng, 2]) <= 0).all()
+    load = np.where(desc[:, :, 0] >= 0, desc[:, :, 2], 0).sum(0)
+    assert load.max() - load.min() <= 27
+
+
+@pytest.mark.parametrize("Cin,Cout", [(16, 16), (32, 16), (16, 32), (32, 32), (64, 32), (48, 32), (64, 16)])
+def test_lds_weight_conv_parity(hip, oracle, Cin, Cout):
+    """k_conv_lw (forced through the dev knob on a small input) over the flat step table: every combination of fused
+    prologue / residual / epilogue activation / second output against the oracle."""
+    from geoformer_amd import _lib, sparse
+    from geoformer_amd._lib import ptr, stream_ptr
+
+    rng = np.random.default_rng(Cin * 31 + Cout)
+    shape, B = (40, 36, 30), 2
+    coords = random_voxels(rng, 3000, shape, B, surface=True)
+    M = coords.shape[0]
+    feats = rng.standard_normal((M, Cin)).astype(np.float32)
+    W = (rng.standard_normal((27, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cin).astype(np.float32)
+    shift = (0.3 * rng.standard_normal(Cin)).astype(np.float32)
+    osc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    osh = (0.3 * rng.standard_normal(Cout)).astype(np.float32)
+    res = rng.standard_normal((M, Cout)).astype(np.float32)
+    nbr = oracle.rules_subm3(coords, shape)
+    c = _dev(coords)
+    rules = sparse.subm_rules(c, sparse.build_index(c, B, shape))
+    flat = sparse.flat_steps(rules.nbr, rules.gmask, 27, M, rules.ld)
+    x, w, s, t, r, a, b = (_dev(v) for v in (feats, W, scale, shift, res, osc, osh))
+    act_in = np.maximum(feats * scale + shift, 0).astype(np.float32)
+    try:
+        sparse.dev_conv_knobs(lw=1)
+        for aff in (False, True):
+            for resid in (False, True):
+                ref = oracle.conv_fwd(act_in if aff else feats, W, nbr, M) + (res if resid else 0)
+                kw = dict(in_scale=s, in_shift=t) if aff else {}
+                if resid:
+                    kw["residual"] = r
+                got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, flat=flat, **kw)
+                assert np.abs(got.cpu().numpy() - ref).max() < 1e-4, (aff, resid)
+                got = sparse.conv_fwd(x, w, rules.nbr, rules.gmask, 27, M, rules.ld, flat=flat, out_scale=a, out_shift=b, **kw)
+                assert np.abs(got.cpu().numpy() - np.maximum(ref * osc + osh, 0)).max() < 1e-4, (aff, resid, "act")
+        # both outputs (the raw sums and the activated copy) in one launch
+        lib = _lib.load()
+        wp = sparse.pack_weights(w)
+        out = torch.empty(M, Cout, device="cuda")
+        out_act = torch.empty(M, Cout, device="cuda")
+        sparse.check(lib.gf_conv_fwd_flat(ptr(x), ptr(wp), ptr(rules.nbr), ptr(rules.gmask), None, ptr(flat), 27, M, M, rules.ld,
+                                          Cin, Cout, None, None, ptr(r), ptr(a), ptr(b), ptr(out), ptr(out_act), stream_ptr()),
+                     "gf_conv_fwd_flat")
+        ref = oracle.conv_fwd(feats, W, nbr, M) + res
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+        assert np.abs(out_act.cpu().numpy() - np.maximum(ref * osc + osh, 0)).max() < 1e-4
+    finally:
+        sparse.dev_conv_knobs()

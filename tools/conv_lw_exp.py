@@ -1,6 +1,6 @@
-"""Dev tool (experiment): the register-weight conv kernel (k_conv_rw, csrc/spconv_rw.hip) against the size-based
-default of gf_conv_fwd on the submanifold tables of S150k levels 1-4: back-to-back launches over rotating buffers,
-result against a float64 gather-matmul on the device."""
+"""Dev tool (experiment): the LDS-weight conv kernel over the flat step table (k_conv_lw, csrc/spconv_lw.hip) against
+the size-based default of gf_conv_fwd on the submanifold tables of S150k levels 1-2: back-to-back launches over
+rotating buffers, result against a float64 gather-matmul on the device."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,7 +9,7 @@ geoformer_amd.configure_runtime()
 from geoformer_amd import sparse, scene
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-levels = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2,3,4".split(","))]
+levels = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2".split(","))]
 batch = scene.make_batch([scene.make_scene(150_000, 1234)])
 coords = batch["voxel_locs"].int().cuda().contiguous()
 shape = tuple(int(s) for s in batch["spatial_shape"])
@@ -39,6 +39,7 @@ def ref64(x, W, nbr, M, scale=None, shift=None, res=None, osc=None, osh=None):
     return out
 
 
+sparse.FLAT_MIN_ROWS = 0
 lv_coords, lv_shape = coords, shape
 for lv in range(1, max(levels) + 1):
     M = lv_coords.shape[0]
@@ -46,13 +47,13 @@ for lv in range(1, max(levels) + 1):
         C = CH[lv - 1]
         rules = sparse.subm_rules(lv_coords, sparse.build_index(lv_coords, 1, lv_shape))
         nbr = rules.nbr
-        R = int((nbr[:, :M] >= 0).sum())
-        steps = int(sum(bin(int(v) & 0x7ffffff).count("1") for v in rules.gmask.cpu().numpy()))
-        print(f"== level {lv}: M={M} groups={(M + 15) // 16} rules={R} steps={steps} C={C}", flush=True)
+        steps = int(rules.flat[0])
+        print(f"== level {lv}: M={M} groups={(M + 15) // 16} steps={steps} C={C}", flush=True)
         NB = 4
         cfgs = ((C, C, False, True, False), (C, C, True, False, True), (2 * C, C, True, False, True))
-        if os.environ.get("RW_CFG"): cfgs = tuple(cfgs[int(i)] for i in os.environ["RW_CFG"].split(","))
+        if os.environ.get("LW_CFG"): cfgs = tuple(cfgs[int(i)] for i in os.environ["LW_CFG"].split(","))
         for (cin, cout, aff, resid, oact) in cfgs:
+            if cout > 32: continue
             xs = [torch.randn(M, cin, device="cuda") for _ in range(NB)]
             W = torch.randn(27, cin, cout, device="cuda") / np.sqrt(9 * cin)
             rs = [torch.randn(M, cout, device="cuda") for _ in range(NB)]
@@ -65,28 +66,17 @@ for lv in range(1, max(levels) + 1):
             r64 = ref64(xs[0], W, nbr, M, sc if aff else None, sh if aff else None, rs[0] if resid else None,
                         osc if oact else None, osh if oact else None)
             mflop = 2.0 * steps * 16 * cin * cout
-            ncb = cout // 16
-            nr = (2048 if cin == 16 else 1024) // ncb
-            gm = rules.gmask.cpu().numpy()[: (M + 15) // 16]
-            npres = np.array([bin(int(v) & 0x7ffffff).count("1") for v in gm])
-            a_, b_ = (float(x) for x in os.environ.get("RW_COST", "1,6").split(","))
-            cost = np.cumsum(a_ * npres + b_)
-            cuts = np.searchsorted(cost, cost[-1] * np.arange(1, nr) / nr)
-            bounds = torch.tensor(np.concatenate([[0], cuts, [len(gm)]]).astype(np.int32), device="cuda")
-            for name, knobs, env in ((("default", dict(rw=0), None),) if not os.environ.get("RW_ONLY") else ()) + (("rw", dict(rw=1), None), ("rw-bal", dict(rw=1), bounds)):
-                sparse.dev_conv_knobs(**knobs)
-                from geoformer_amd import _lib
-                _lib.load().gf_dev_conv_rw_bounds(env.data_ptr() if env is not None else None, nr if env is not None else 0)
+            for name, flat in (("default", None), ("lw", rules.flat)):
+                sparse.dev_conv_knobs(lw=1 if flat is not None else 0)
                 def run(i):
                     k = dict(kw)
                     if resid: k["residual"] = rs[i % NB]
-                    return sparse.conv_fwd(xs[i % NB], W, nbr, rules.gmask, 27, M, rules.ld, out=outs[i % NB], steps=rules.steps, **k)
+                    return sparse.conv_fwd(xs[i % NB], W, nbr, rules.gmask, 27, M, rules.ld, out=outs[i % NB], steps=rules.steps, flat=flat, **k)
                 o = run(0).clone()
                 err = float((o.double() - r64).abs().max())
                 us = timeit(run)
                 print(f"  {cin:3d}->{cout:3d} aff={int(aff)} res={int(resid)} oact={int(oact)}  {name:8s} {us:7.2f} us  padded-MFMA {mflop / us / 1e6 / 157.3:5.2f} of peak  err {err:.1e}", flush=True)
             sparse.dev_conv_knobs()
-            _lib.load().gf_dev_conv_rw_bounds(None, 0)
     if lv < max(levels):
         d = sparse.down_rules(lv_coords, 1, lv_shape)
         lv_coords, lv_shape = d.out_coords.contiguous(), d.out_shape
