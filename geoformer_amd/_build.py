@@ -71,11 +71,10 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         f"-I{INCLUDE_DIR}",
         f"-I{CSRC_DIR}",
     ]
-    # per-file extra device flags.  geodesic_ms.hip: ROCm 7.2's gfx950 backend folds the hop kernel's chain of
-    # "bits = f & open; open &= ~bits" updates into v_bitop3_b32 instructions with WRONG truth tables (reach sets came out
-    # 16x too large; identical source built without the instruction is bit-exact against the oracle: DESIGN 4.3), so the
-    # instruction is switched off for that file (the host pass prints "not a recognized feature": harmless).
-    extra = {"geodesic_ms.hip": ["-Xclang", "-target-feature", "-Xclang", "-bitop3-insts"]}
+    # per-file extra device flags (none at present).  ROCm 7.2's gfx950 backend was seen folding a chain of
+    # "bits = f & open; open &= ~bits" updates into v_bitop3_b32 with wrong truth tables (round 5, in a kernel that is no
+    # longer in the tree: HISTORY.md 7); `check_bitop3()` below lists the kernels whose ISA holds the instruction.
+    extra = {}
     jobs = []
     objs = []
     for s in srcs:

@@ -50,7 +50,6 @@ def _declare(lib):
         "gf_dev_conv_knobs": (I, [I, I, I, I, I]),
         "gf_dev_conv_knob_flat": (I, [I, I]),
         "gf_dev_conv_knob_lw": (I, [I, I]),
-        "gf_dev_conv_occupancy": (I, [I]),
         "gf_resblock_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, P, P, P, P, P, P, P]),
         "gf_conv_wgrad": (I, [P, P, P, I, I, I, I, I, P, P]),
         "gf_conv_wgrad_masked": (I, [P, P, P, P, I, I, I, I, I, P, P]),
@@ -61,7 +60,6 @@ def _declare(lib):
         "gf_pair_losses_bwd": (I, [P, P, P, P, I, I, I, P, P, P, P]),
         "gf_unet_ws_bytes": (c_size_t, [P, I, I, I, I, I]),
         "gf_dev_unet_probe": (I, [I]),
-        "gf_dev_unet_chain": (I, [I]),
         "gf_dev_unet_probe_read": (I, [I, P, P]),
         "gf_dev_unet_probe_read2": (I, [I, P, P, P]),
         "gf_dev_conv_kernel_events": (I, [P, P]),
@@ -83,25 +81,12 @@ def _declare(lib):
         "gf_fps_scratch_bytes": (c_size_t, [I]),
         "gf_furthest_point_sampling": (I, [P, I, I, I, P, P, P]),
         "gf_furthest_point_sampling_resume": (I, [P, I, I, I, I, P, P, P]),
-        "gf_fps_scratch_reset": (I, [P, I, P]),
-        "gf_fps_gate_word": (P, [P, I]),
-        "gf_furthest_point_sampling_gated": (I, [P, I, I, P, P, I, I, P]),
         "gf_knn_scratch_bytes": (c_size_t, [I]),
         "gf_knn_radius": (I, [P, I, I, F, I, P, P, P, P, P]),
         "gf_knn_error_flag": (P, [P, I]),
         "gf_geodesic_bfs": (I, [P, P, P, I, I, P, I, F, I, P, P, P, P]),
         "gf_geodesic_bfs_cfg": (I, [P, P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, P]),
-        "gf_geodesic_bfs_gated": (I, [P, P, I, I, P, I, F, I, P, P, P, c_size_t, I, I, P, I, P, P]),
         "gf_geodesic_bfs_queue_words": (c_size_t, [I]),
-        "gf_geodesic_ms_scratch_bytes": (c_size_t, [I, I, I, I]),
-        "gf_geodesic_bfs_ms": (I, [P, P, P, I, I, P, I, F, I, P, P, c_size_t, P]),
-        "gf_geodesic_bfs_ms_sets": (I, [P, P, I, I, P, I, I, P, P, F, I, P, c_size_t, P]),
-        "gf_dev_bfs_ms_tiles": (I, [I]),
-        "gf_dev_bfs_ms_persist": (I, [I]),
-        "gf_dev_fps_lds_pad": (I, [I]),
-        "gf_dev_bfs_lds_cap": (I, [I]),
-        "gf_geodesic_ms_error_flag": (P, [P, I, I, I, I]),
-        "gf_dev_bfs_pipe": (I, [I]),
         "gf_dev_cross_attn_bf3": (I, [I]),
         "gf_dev_bfs_qcap_max": (I, [I]),
         "gf_mask_head": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
@@ -227,7 +212,7 @@ def load():
     _check_hw_queues(torch)
     lib = ctypes.CDLL(LIB_PATH)
     EXPORTS = _declare(lib)
-    if lib.gf_abi_version() != 4:
+    if lib.gf_abi_version() != 5:
         raise GeoFormerHipError("libgeoformer_hip.so ABI version mismatch")
     _lib = lib
     return lib

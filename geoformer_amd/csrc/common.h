@@ -68,22 +68,6 @@ bool gf_rules_level_parallel();
 
 static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// ---- a chain of small sparse convolutions in one persistent launch (spconv_conv.hip: k_conv_chain; used by
-// unet_exec.hip for the deep U-Net levels).  Same operands as gf_conv_fwd, plus `in2`: the input rows are the
-// concatenation (in[:, :Cin1], in2[:, :Cin - Cin1]). ----
-struct GfChainOp {
-    const float *in, *in2, *Wp;
-    const int32_t* nbr;
-    const float *in_scale, *in_shift, *residual, *out_scale, *out_shift;
-    float* out;
-    int K, M_in, M_out, ld, Cin, Cin1, Cout;
-};
-#define GF_CHAIN_MAX_OPS 16
-// 1 if gf_conv_chain takes this layer (the flat form's shape limits, at most 256 items)
-int gf_conv_chain_supported(const GfChainOp& op);
-// counter: one zeroed device word per call.  Every op must pass gf_conv_chain_supported; nops <= GF_CHAIN_MAX_OPS.
-int gf_conv_chain(const GfChainOp* ops, int nops, unsigned* counter, hipStream_t st);
-
 // ---- LDS-weight convolution over a flat step table (spconv_lw.hip; dispatched by gf_conv_fwd when a flat table is given) ----
 // flat step table (spconv_rules.hip gf_rules_flat_steps writes it):
 //   header   [0] steps S, [1] bins NB, [2] groups, [3] K, [4] rounds J = ceil(groups / NB)

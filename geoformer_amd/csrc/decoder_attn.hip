@@ -286,9 +286,6 @@ __device__ __forceinline__ f32x4 da_gemm_bf3(const uint4* __restrict__ sW3, int 
 #ifndef DA_BF3_WAVES
 #define DA_BF3_WAVES 16
 #endif
-#ifndef DA_BF3_NT2_DEFAULT
-#define DA_BF3_NT2_DEFAULT 0
-#endif
 // NT tiles of 16 contexts per trip of a wave: every weight operand read from LDS serves NT products (a wave used to
 // re-read all 73 KB of packed weights for every tile: 2.9 GB of ds_read_b128 per launch, the LDS 43 % busy), and the NT
 // accumulator chains are independent, so consecutive MFMAs do not wait for each other.  <16, 1> is the round-4 shape
@@ -555,28 +552,18 @@ extern "C" int gf_decoder_cross_attn_cfg(const float* geo_ctx, const float* max_
     GF_CHECK_ARG(wg_waves == 16 || wg_waves == 8, "gf_decoder_cross_attn_cfg: %d waves per workgroup (16 or 8)", wg_waves);
     if (B == 0 || nq == 0) return GF_OK;
     (void)b2;  // a per-channel constant cancels in the per-channel soft-max over the contexts
-    if (g_da_bf3 < 0) {  // GF_CROSS_ATTN_BF3=0: the fp32-MFMA kernel for the 16-wave shape too (dev knob for A/B runs)
-        const char* e = getenv("GF_CROSS_ATTN_BF3");
-        g_da_bf3 = e ? (atoi(e) != 0) : 1;
-    }
-    if (wg_waves == 16 && g_da_bf3) {
-        // shape: 0 (default) = sixteen waves, one tile per trip; 1 = eight waves, two tiles per trip (GF_CROSS_ATTN_NT2)
-        static const int nt2 = [] { const char* e = getenv("GF_CROSS_ATTN_NT2"); return e ? atoi(e) : DA_BF3_NT2_DEFAULT; }();
+    // (gf_dev_cross_attn_bf3(0): the fp32-MFMA kernel for the 16-wave shape too -- the split-vs-fp32 test's dev knob.  An
+    //  eight-wave, two-tiles-per-trip instance of the bf16 kernel measured 85-86 against 84 us: HISTORY.md 7; removed.)
+    if (wg_waves == 16 && g_da_bf3 != 0) {
         const size_t lds = (size_t)DA_WPACK_BF3_U4 * sizeof(uint4);
         static bool attr = false;
         if (!attr) {
             (void)hipFuncSetAttribute((const void*)k_decoder_cross_attn_bf3<DA_BF3_WAVES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)k_decoder_cross_attn_bf3<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        if (nt2)
-            GF_LAUNCH_OP(GF_OP_CROSS_ATTN, (k_decoder_cross_attn_bf3<8, 2>), dim3(nq, B), dim3(8 * 64), lds, (hipStream_t)stream,
-                         geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
-                         reinterpret_cast<const uint4*>(Wpack + DA_WPACK_F32), nq, nc, out, stat_m, stat_l);
-        else
-            GF_LAUNCH_OP(GF_OP_CROSS_ATTN, (k_decoder_cross_attn_bf3<DA_BF3_WAVES, 1>), dim3(nq, B), dim3(DA_BF3_WAVES * 64), lds,
-                         (hipStream_t)stream, geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
-                         reinterpret_cast<const uint4*>(Wpack + DA_WPACK_F32), nq, nc, out, stat_m, stat_l);
+        GF_LAUNCH_OP(GF_OP_CROSS_ATTN, (k_decoder_cross_attn_bf3<DA_BF3_WAVES, 1>), dim3(nq, B), dim3(DA_BF3_WAVES * 64), lds,
+                     (hipStream_t)stream, geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv,
+                     reinterpret_cast<const uint4*>(Wpack + DA_WPACK_F32), nq, nc, out, stat_m, stat_l);
         GF_CHECK_LAUNCH("gf_decoder_cross_attn");
         return GF_OK;
     }

@@ -560,12 +560,9 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
                                                                   const int32_t* __restrict__ src, float radius,
                                                                   int max_step, float* __restrict__ geo,
                                                                   unsigned long long* __restrict__ keys,
-                                                                  int2* __restrict__ queues, int qcap,
-                                                                  const int* __restrict__ gate, int gate_at,
-                                                                  int* __restrict__ gate_err) {
+                                                                  int2* __restrict__ queues, int qcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_cnt[2];  // next-frontier counters of even / odd hops (reset a hop ahead: one barrier less)
-    __shared__ int s_src;
 #ifdef BFS_PRIO
     __builtin_amdgcn_s_setprio(BFS_PRIO);
 #endif
@@ -588,31 +585,8 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
         visited[t] = 0u;
         touched[t] = 0u;
     }
-    int s;
-    if (gate) {
-        // The sources are still being drawn: src is the output of a sampling launch that runs BESIDE this one
-        // (gf_furthest_point_sampling_gated) and publishes gate[0] = picks stored, behind a release fence, once the first
-        // gate_at of them are there.  The distance / key rows above are initialised meanwhile.  The wait is bounded
-        // (one second of the 100 MHz wall clock): on a time-out the flag word is set and the search runs on whatever
-        // the source slot holds -- an error the host reads back, never a hang.
-        if (tid == 0) {
-            const unsigned long long t0 = wall_clock64();
-            while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_at) {
-                __builtin_amdgcn_s_sleep(64);
-                if (wall_clock64() - t0 > 100000000ull) {
-                    atomicExch(gate_err, 1);
-                    break;
-                }
-            }
-            int v = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_src = min(max(v, 0), n - 1);
-        }
-        __syncthreads();
-        s = s_src;
-    } else {
-        s = src[q];
-        __syncthreads();
-    }
+    const int s = src[q];
+    __syncthreads();
     if (tid == 0) {
         g[s] = 0.0f;
         visited[s >> 5] = 1u << (s & 31);
@@ -879,435 +853,10 @@ __global__ __launch_bounds__(THREADS) void k_geodesic_bfs_lds(const float* __res
 #endif
 }
 
-// ------------------------------------------------------------------------------------
-// Round 4: the same search with the DISTANCES and the ROW FETCH taken off the hop's critical path
-// (k_geodesic_bfs_pipe).
-//
-// A hop of k_geodesic_bfs_lds is: expand the ring (bids = 64-bit minima carrying distance(parent) + edge) -> barrier ->
-// commit: read the winning key of every new vertex back from L2, store its distance, request its row -> barrier.  The
-// next hop cannot bid before the commit's read-back has returned (its bids carry the new distances) and cannot expand
-// before the rows requested at the commit have arrived: ~9700 cycles per hop at 1024 threads, 4400 of them the expansion.
-// But WHICH vertices a hop reaches, and who the winning parent of each is, does not depend on any distance: the level
-// sets need the LDS bitmaps only and the parent is decided by the key's high word (parent << 6 | rank).  Hence
-//   * the key's low word carries the parent's POSITION IN ITS LEVEL'S QUEUE instead of a distance, and the distances
-//     follow two hops behind as a software pipeline whose loads are requested a whole hop before they are used:
-//         mark(i-1)  S1(level i)   request key[v] of every vertex of the level (final: every wave has drained its bids
-//                                  before the barrier in front of this section)
-//         mark(i)    S2(level i)   key -> (parent u, rank r, parent's queue position); request the edge D[u][r]
-//         mark(i+1)  S3(level i)   distance = D[u][r] + distance(level i-1)[position]  (LDS; the oracle's d + base, the
-//                                  same two operands), kept per queue position for the level's children, stored to geo
-//   * the lane that first touches a vertex pulls the vertex's row towards the compute unit right there (a 4-byte
-//     LDS-DMA load per row array into a scratch word: no register, nothing waits for it), a good part of a hop before
-//     the row is read.
-// Levels, parents and the fp32 sums are those of k_geodesic_bfs_lds / the oracle bit for bit.  A lane holds SE entries
-// of two levels in registers (S1 -> S2 and S2 -> S3); the entries of a ring beyond SE * THREADS go through a blocking
-// slow path and a per-query scratch in global memory (rings that large: a few hops of the largest training scenes).
-// ------------------------------------------------------------------------------------
-#ifndef BFS_PIPE_WARM
-#define BFS_PIPE_WARM 0
-#endif
-#ifndef BFS_PIPE_WPS
-#define BFS_PIPE_WPS 6  // waves per SIMD the 512-thread form is compiled for (<= 80 registers: fits beside the sampler)
-#endif
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 512 ? BFS_PIPE_WPS : 4) void k_geodesic_bfs_pipe(const float* __restrict__ D, const int32_t* __restrict__ I,
-                                                               int n, int K, const int32_t* __restrict__ src, float radius,
-                                                               int max_step, float* __restrict__ geo,
-                                                               unsigned long long* __restrict__ keys,
-                                                               int32_t* __restrict__ ws, int qcap) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_cnt[2];
-    __shared__ int s_sink[THREADS];               // landing zone of the row-warming loads (never read)
-    constexpr int BFS_B = 4;                      // frontier vertices per 16-lane group and expansion batch
-    #ifndef BFS_PIPE_SE
-#define BFS_PIPE_SE 2
-#endif
-    constexpr int SE = BFS_PIPE_SE;               // level entries per lane whose distance pipeline lives in registers
-#ifndef BFS_PIPE_PFB
-#define BFS_PIPE_PFB 1
-#endif
-    constexpr int PFB = BFS_PIPE_PFB;             // expansion batches whose rows are requested in the mark section before
-    const int nw = (n + 31) >> 5;
-    unsigned* visited = reinterpret_cast<unsigned*>(smem);
-    unsigned* touched = visited + nw;
-    int* qv = reinterpret_cast<int*>(touched + nw);               // [2][qcap] vertex of (level & 1, position)
-    float* qd = reinterpret_cast<float*>(qv + 2 * (size_t)qcap);  // [2][qcap] its distance (written two hops later)
-    const int q = blockIdx.x;
-    float* g = geo + (size_t)q * n;
-    unsigned long long* key = keys + (size_t)q * n;
-    // per-query global space (10 n words): queue overflow past qcap (vertex, distance) x 2 levels, slow-path scratch x 2
-    int32_t* gws = ws + (size_t)q * 10 * n;
-    int* gv = gws;                                              // [2][n]
-    float* gd = reinterpret_cast<float*>(gws + 2 * (size_t)n);  // [2][n]
-    int* xs = gws + 4 * (size_t)n;  // [2][3 n]: (vertex, parent position, edge bits) of slow-path entries
-    const int tid = threadIdx.x;
-    for (int t = tid; t < n; t += THREADS) {
-        g[t] = -1.0f;
-        key[t] = ~0ull;
-    }
-    for (int t = tid; t < nw; t += THREADS) {
-        visited[t] = 0u;
-        touched[t] = 0u;
-    }
-    for (int t = tid; t < 2 * qcap; t += THREADS) {  // (a stale queue entry read speculatively must be a valid vertex)
-        qv[t] = 0;
-        qd[t] = 0.f;
-    }
-    const int s = src[q];
-    __syncthreads();
-    if (tid == 0) {
-        g[s] = 0.0f;
-        visited[s >> 5] = 1u << (s & 31);
-        touched[s >> 5] = 1u << (s & 31);
-        qv[0] = s;
-        qd[0] = 0.0f;
-        s_cnt[0] = 0;
-        s_cnt[1] = 0;
-    }
-    __syncthreads();
-    const int l16 = tid & 15;
-    const int gsh = (tid & 48) | 15;
-    const int kc = l16 < K ? l16 : K - 1;
-    // Scattered global accesses as (uniform base, 32-bit byte offset): one address register per lane instead of a 64-bit
-    // pair built with two or three vector instructions per access (n <= 2^19, K <= 64: every offset is below 2^27)
-    auto ld_I = [&](unsigned idx) { return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(I) + idx * 4u); };
-    auto ld_D = [&](unsigned idx) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(D) + idx * 4u); };
-    auto key_at = [&](int v) { return reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(key) + (unsigned)v * 8u); };
-    auto g_at = [&](int v) { return reinterpret_cast<float*>(reinterpret_cast<char*>(g) + (unsigned)v * 4u); };
-    const unsigned uK = (unsigned)K;
-    // queue accessors: position < qcap in LDS, the rest in the query's global overflow (read past L1: sc1).  READS
-    // take a compile-time flag: a value that MAY come from global memory makes the compiler wait for every outstanding
-    // memory operation where the two paths join (first version: four serialised round trips per expansion batch), so
-    // the hop has its own instance for rings that reach into the overflow -- graphs far larger than a scene's.
-    auto qv_get = [&](auto spill, int slot, int pos) -> int {
-        if constexpr (!decltype(spill)::value) return qv[slot * qcap + pos];
-        if (pos < qcap) return qv[slot * qcap + pos];
-        return __hip_atomic_load(&gv[(size_t)slot * n + (pos - qcap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto qv_set = [&](int slot, int pos, int v) {
-        if (pos < qcap) qv[slot * qcap + pos] = v;
-        else gv[(size_t)slot * n + (pos - qcap)] = v;
-    };
-    auto qd_get = [&](auto spill, int slot, int pos) -> float {
-        if constexpr (!decltype(spill)::value) return qd[slot * qcap + pos];
-        if (pos < qcap) return qd[slot * qcap + pos];
-        return __hip_atomic_load(&gd[(size_t)slot * n + (pos - qcap)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto qd_set = [&](auto spill, int slot, int pos, float d) {
-        if constexpr (!decltype(spill)::value) {
-            qd[slot * qcap + pos] = d;
-        } else {
-            if (pos < qcap) qd[slot * qcap + pos] = d;
-            else gd[(size_t)slot * n + (pos - qcap)] = d;
-        }
-    };
-    // first touch of vertex v: pull the first 16 entries of its two rows towards this compute unit
-    auto warm = [&](int v) {
-#if BFS_PIPE_WARM
-        auto* lds = (__attribute__((address_space(3))) void*)&s_sink[tid & ~63];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(I + (size_t)v * K), lds, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(D + (size_t)v * K), lds, 4, 0, 0);
-#endif
-    };
-    // distance pipeline registers: stage A = S1 -> S2 (vertex, key), stage B = S2 -> S3 (vertex, parent position, edge)
-    int av[SE], bv[SE], bpp[SE];
-    unsigned long long akey[SE];
-    float bw[SE];
-#pragma unroll
-    for (int k = 0; k < SE; k++) {
-        av[k] = -1;
-        bv[k] = -1;
-        bpp[k] = 0;
-        akey[k] = 0ull;
-        bw[k] = 0.f;
-    }
-    int pv[PFB * BFS_B];
-    float pd[PFB * BFS_B];
-    bool have_pf = false;
-    int n_m2 = 0, n_m1 = 0, n_0 = 1;  // sizes of the levels step - 2, step - 1 and step (uniform)
-    int last_level = 0;     // deepest level that holds a vertex so far
-#ifdef BFS_PIPE_TRACE
-    // dev build (tools/bench_bfs_pipe.py): cycle stamps of thread 0 summed over the hops -- 0 expansion, 1 drain of the
-    // wave's memory operations, 2 barrier A, 3 mark section, 4 barrier B, 5 hops, 6 sum of ring sizes
-    unsigned long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long pm[5] = {0, 0, 0, 0, 0};
-#define PT() __builtin_amdgcn_s_memtime()
-#endif
-    for (int step = 0; step <= last_level + 1; step++) {
-#ifdef BFS_PIPE_TRACE
-        const unsigned long long pt0 = PT();
-#endif
-        const int ncur = n_0;
-        const int sc = step & 1, sn = sc ^ 1;  // queue slots of level `step` and of level step + 1
-        int* cnt = &s_cnt[step & 1];
-        const bool grow = step < max_step && ncur > 0;
-        if (grow) {
-            auto bid = [&](unsigned cand, int f, int v) {  // late entries of long rows (beyond the first 16)
-                const unsigned bit = 1u << (v & 31);
-                if (!(visited[v >> 5] & bit)) {
-                    __hip_atomic_fetch_min(key_at(v), ((unsigned long long)cand << 32) | (unsigned)f, __ATOMIC_RELAXED,
-                                           BFS_KEY_SCOPE);
-                    const unsigned old = atomicOr(&touched[v >> 5], bit);
-                    if (!(old & bit)) {
-                        qv_set(sn, atomicAdd(cnt, 1), v);
-                        warm(v);
-                    }
-                }
-            };
-            auto batch = [&](int base, auto pf, auto spill) {  // pf: integral_constant, slot of prefetched rows or -1
-                unsigned cand[BFS_B];
-                int v[BFS_B], fpos[BFS_B];
-                float d[BFS_B];
-#pragma unroll
-                for (int k = 0; k < BFS_B; k++) {
-                    const int f = (base + k * THREADS + tid) >> 4;
-                    const int fc = f < ncur ? f : ncur - 1;
-                    const int u = qv_get(spill, sc, fc);
-                    fpos[k] = fc;
-                    cand[k] = (((unsigned)u << 6) | (unsigned)l16) + 1u;
-                    if constexpr (decltype(pf)::value >= 0) {
-                        v[k] = pv[decltype(pf)::value * BFS_B + k];
-                        d[k] = pd[decltype(pf)::value * BFS_B + k];
-                    } else {
-                        v[k] = ld_I((unsigned)u * uK + (unsigned)kc);
-                        d[k] = ld_D((unsigned)u * uK + (unsigned)kc);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < BFS_B; k++) asm volatile("" : "+v"(v[k]), "+v"(d[k]));
-#pragma unroll
-                for (int k = 0; k < BFS_B; k++) {
-                    const int f = (base + k * THREADS + tid) >> 4;
-                    if (!(f < ncur && l16 < K && d[k] <= radius)) v[k] = -1;
-                }
-                unsigned long long mm = 0ull;
-                unsigned w[BFS_B];
-#pragma unroll
-                for (int k = 0; k < BFS_B; k++) {
-                    mm |= ((__ballot(v[k] >= 0) >> gsh) & 1ull) << k;
-                    w[k] = visited[v[k] >= 0 ? (v[k] >> 5) : 0];
-                }
-#pragma unroll
-                for (int k = 0; k < BFS_B; k++) {
-                    const unsigned bit = 1u << (v[k] & 31);
-                    const bool bids = v[k] >= 0 && l16 >= 1 && !(w[k] & bit);
-                    w[k] = 1u;
-                    if (bids) {
-                        __hip_atomic_fetch_min(key_at(v[k]), ((unsigned long long)cand[k] << 32) | (unsigned)fpos[k],
-                                               __ATOMIC_RELAXED, BFS_KEY_SCOPE);
-                        w[k] = atomicOr(&touched[v[k] >> 5], bit) & bit;
-                    }
-                }
-                unsigned long long fm[BFS_B];
-                int nfirst = 0;
-#pragma unroll
-                for (int k = 0; k < BFS_B; k++) {
-                    fm[k] = __ballot(w[k] == 0u);
-                    nfirst += __popcll(fm[k]);
-                }
-                if (nfirst) {
-#pragma unroll
-                    for (int k = 0; k < BFS_B; k++)
-                        if (w[k] == 0u) warm(v[k]);
-                    int pos = 0;
-                    if ((tid & 63) == 0) pos = atomicAdd(cnt, nfirst);
-                    pos = __builtin_amdgcn_readfirstlane(pos);
-#pragma unroll
-                    for (int k = 0; k < BFS_B; k++) {
-                        if (w[k] == 0u) {
-                            const int p = pos + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm[k] >> 32),
-                                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)fm[k], 0u));
-                            qv_set(sn, p, v[k]);
-                        }
-                        pos += __popcll(fm[k]);
-                    }
-                }
-                if (mm) {
-#pragma unroll
-                    for (int k = 0; k < BFS_B; k++) {
-                        if ((mm >> k) & 1ull) {
-                            const int f = (base + k * THREADS + tid) >> 4;
-                            const int u = qv_get(spill, sc, f);
-                            for (int r0 = 16; r0 < K; r0 += 16) {
-                                const int r = r0 + l16;
-                                int vv = -1;
-                                float dd = 0.f;
-                                if (r < K) {
-                                    vv = ld_I((unsigned)u * uK + (unsigned)r);
-                                    dd = ld_D((unsigned)u * uK + (unsigned)r);
-                                }
-                                const bool in2 = vv >= 0 && dd <= radius;
-                                if (in2) bid((((unsigned)u << 6) | (unsigned)r) + 1u, f, vv);
-                                if (!((__ballot(in2) >> gsh) & 1ull)) break;
-                            }
-                        }
-                    }
-                }
-            };
-            auto expand = [&](auto spill) {
-                int base = 0;
-                if (have_pf) {
-                    batch(0, std::integral_constant<int, 0>{}, spill);
-                    base = BFS_B * THREADS;
-                    if constexpr (PFB > 1) {
-                        if ((base >> 4) < ncur) {
-                            batch(base, std::integral_constant<int, (PFB > 1 ? 1 : 0)>{}, spill);
-                            base += BFS_B * THREADS;
-                        }
-                    }
-                    if constexpr (PFB > 2) {
-                        if ((base >> 4) < ncur) {
-                            batch(base, std::integral_constant<int, (PFB > 2 ? 2 : 0)>{}, spill);
-                            base += BFS_B * THREADS;
-                        }
-                    }
-                }
-                for (; (base >> 4) < ncur; base += BFS_B * THREADS) batch(base, std::integral_constant<int, -1>{}, spill);
-            };
-            if (ncur > qcap) expand(std::true_type{});
-            else expand(std::false_type{});
-        }
-        // every bid of this wave has been performed at L2 (and whatever it stored to the global overflow has landed):
-        // behind the barrier the keys of the new level are final
-#ifdef BFS_PIPE_TRACE
-        const unsigned long long pt1 = PT();
-#endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef BFS_PIPE_TRACE
-        const unsigned long long pt2 = PT();
-#endif
-        bfs_lds_barrier();
-#ifdef BFS_PIPE_TRACE
-        const unsigned long long pt3 = PT();
-#endif
-        // ---- mark section: the new level's visited bits and first rows; the distance pipeline ----
-        const int nn = grow ? *cnt : 0;
-        if (tid == 0) s_cnt[(step + 1) & 1] = 0;
-        if (nn > 0) last_level = step + 1;
-        auto mark_section = [&](auto spill) {
-            // Every LDS read of the section up front, in ONE round trip (the section used to be a chain of six): this
-            // lane's SE entries of the new level, the vertices whose rows it requests for the next expansion, and the
-            // parents' distances of the level S3 finishes.  Positions are clamped, not tested: a stale entry is a
-            // valid vertex (the queues are cleared at the start), its loads are harmless and its results unused.
-            const int sl = (step - 1) & 1, sp = sl ^ 1;  // queue slots of level step - 1 and of its parents' level
-            const bool s3 = step >= 2 && n_m1 > 0;
-            int ev[SE], pfv[PFB * BFS_B];
-            float pdist[SE];
-    #pragma unroll
-            for (int k = 0; k < SE; k++) {
-                const int t = k * THREADS + tid;
-                ev[k] = qv_get(spill, sn, decltype(spill)::value ? (t < nn ? t : 0) : (t < qcap ? t : qcap - 1));
-                const int pp = decltype(spill)::value ? bpp[k] : (bpp[k] < qcap ? bpp[k] : qcap - 1);
-                pdist[k] = qd_get(spill, sp, pp);
-            }
-            have_pf = nn > 0 && step + 1 < max_step;
-    #pragma unroll
-            for (int k = 0; k < PFB * BFS_B; k++) {
-                const int f = (k * THREADS + tid) >> 4;
-                pfv[k] = qv_get(spill, sn, f < nn ? f : (nn > 0 ? nn - 1 : 0));
-            }
-    #pragma unroll
-            for (int k = 0; k < SE; k++) asm volatile("" : "+v"(ev[k]), "+v"(pdist[k]));
-    #pragma unroll
-            for (int k = 0; k < PFB * BFS_B; k++) asm volatile("" : "+v"(pfv[k]));
-#ifdef BFS_PIPE_TRACE
-            pm[0] = PT();
-#endif
-            // rows of the new level's first PFB batches, into the registers of the lanes that expand them
-            if (have_pf) {
-    #pragma unroll
-                for (int k = 0; k < PFB * BFS_B; k++) {
-                    if (((k * THREADS) >> 4) < nn || k == 0) {  // (uniform: no row of a batch the ring does not reach)
-                        pv[k] = ld_I((unsigned)pfv[k] * uK + (unsigned)kc);
-                        pd[k] = ld_D((unsigned)pfv[k] * uK + (unsigned)kc);
-                    }
-                }
-            }
-            // S1 (level step + 1): key request -- and the level's visited bits
-    #pragma unroll
-            for (int k = 0; k < SE; k++) {
-                const int t = k * THREADS + tid;
-                const int vprev = av[k];
-                const unsigned long long kprev = akey[k];
-                av[k] = -1;
-                if (k * THREADS < nn && t < nn) {
-                    av[k] = ev[k];
-                    akey[k] = __hip_atomic_load(key_at(ev[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_fetch_or(&visited[ev[k] >> 5], 1u << (ev[k] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                // S3 (level step - 1): distance = edge + distance(parent), S2's registers
-                if (s3 && k * THREADS < n_m1 && bv[k] >= 0) {  // (first tests uniform)
-                    const float dist = bw[k] + pdist[k];
-                    qd_set(spill, sl, t, dist);
-                    *g_at(bv[k]) = dist;
-                }
-                // S2 (level step): key -> (parent position, edge request), S1's registers of the hop before
-                bv[k] = vprev;
-                if (step >= 1 && k * THREADS < ncur && vprev >= 0) {
-                    const unsigned kk = (unsigned)(kprev >> 32) - 1u;
-                    bpp[k] = (int)(unsigned)kprev;
-                    bw[k] = ld_D((kk >> 6) * uK + (kk & 63u));
-                }
-            }
-#ifdef BFS_PIPE_TRACE
-            pm[1] = pm[2] = pm[3] = PT();
-#endif
-            // rings beyond SE * THREADS entries: visited bits; S3 from the scratch; key and edge now (blocking), parked
-            // in the query's scratch until their S3
-            for (int t = SE * THREADS + tid; t < nn; t += THREADS) {
-                const int v = qv_get(spill, sn, t);
-                __hip_atomic_fetch_or(&visited[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (s3) {
-                for (int t = SE * THREADS + tid; t < n_m1; t += THREADS) {
-                    const int* e = xs + ((size_t)sl * n + t) * 3;
-                    const int v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int pp = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float w = __int_as_float(__hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    const float dist = w + qd_get(spill, sp, pp);
-                    qd_set(spill, sl, t, dist);
-                    g[v] = dist;
-                }
-            }
-            for (int t = SE * THREADS + tid; t < nn; t += THREADS) {
-                const int v = qv_get(spill, sn, t);
-                const unsigned long long kx = __hip_atomic_load(&key[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned kk = (unsigned)(kx >> 32) - 1u;
-                const float w = D[(size_t)(kk >> 6) * K + (kk & 63u)];
-                int* e = xs + ((size_t)sn * n + t) * 3;
-                e[0] = v;
-                e[1] = (int)(unsigned)kx;
-                e[2] = __float_as_int(w);
-            }
-        };
-        if (nn > qcap || ncur > qcap || n_m1 > qcap || n_m2 > qcap) mark_section(std::true_type{});
-        else mark_section(std::false_type{});
-#ifdef BFS_PIPE_TRACE
-        const unsigned long long pt4 = PT();
-#endif
-        bfs_lds_barrier();
-#ifdef BFS_PIPE_TRACE
-        const unsigned long long pt5 = PT();
-        tr[0] += pt1 - pt0; tr[1] += pt2 - pt1; tr[2] += pt3 - pt2; tr[3] += pt4 - pt3; tr[4] += pt5 - pt4;
-        tr[5]++; tr[6] += ncur;
-        tr[7] += pm[0] - pt3; tr[8] += pm[1] - pm[0]; tr[9] += pm[2] - pm[1]; tr[10] += pm[3] - pm[2]; tr[11] += pt4 - pm[3];
-#endif
-        n_m2 = n_m1;
-        n_m1 = n_0;
-        n_0 = nn;
-    }
-#ifdef BFS_PIPE_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0 && n >= 12)
-        for (int i = 0; i < 12; i++) reinterpret_cast<unsigned long long*>(xs)[i] = tr[i];
-#endif
-}
-
 template <int THREADS>
 static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, const int32_t* I, int n, int K,
                            const int32_t* src, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
-                           int qcap, const int* gate = nullptr, int gate_at = 0, int* gate_err = nullptr) {
+                           int qcap) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_geodesic_bfs_lds<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1315,38 +864,7 @@ static void launch_bfs_lds(int nq, size_t lds, hipStream_t st, const float* D, c
         attr_set = true;
     }
     GF_LAUNCH_OP(GF_OP_BFS, k_geodesic_bfs_lds<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
-                 geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap, gate, gate_at, gate_err);
-}
-template <int THREADS>
-static void launch_bfs_pipe(int nq, size_t lds, hipStream_t st, const float* D, const int32_t* I, int n, int K,
-                            const int32_t* src, float radius, int max_step, float* geo, void* keys_ws, void* queue_ws,
-                            int qcap) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_geodesic_bfs_pipe<THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  BFS_LDS_BYTES);
-        attr_set = true;
-    }
-    GF_LAUNCH_OP(GF_OP_BFS, k_geodesic_bfs_pipe<THREADS>, dim3(nq), dim3(THREADS), lds, st, D, I, n, K, src, radius, max_step,
-                 geo, (unsigned long long*)keys_ws, (int32_t*)queue_ws, qcap);
-}
-// Kernel choice: 0 (default) = k_geodesic_bfs_lds, 1 = the pipelined-distance kernel (GF_BFS_PIPE, read once;
-// gf_dev_bfs_pipe).  Measured (round 4): alone on the device the pipelined kernel is 3-13 % faster at 512
-// threads per query (1.16 against 1.23 ms on the S150k graphs, 3.4 against 3.9 ms on a 150 000-point foreground), in
-// the forward its launch is 8 % shorter -- and the forward is not: paired in one process over the eight benchmark scenes
-// +0.03 ms per scene (-0.07 on the two scenes whose search outlasts the sampling, +0.03..+0.14 on the others, where the
-// sampling beside it is what ends last and the extra memory instructions of the distance pipeline slow its exchanges).
-static int g_bfs_pipe = -1;
-static bool bfs_pipe_on() {
-    if (g_bfs_pipe < 0) {
-        const char* e = getenv("GF_BFS_PIPE");
-        g_bfs_pipe = e ? (atoi(e) != 0) : 0;
-    }
-    return g_bfs_pipe != 0;
-}
-extern "C" int gf_dev_bfs_pipe(int on) {
-    g_bfs_pipe = on < 0 ? -1 : (on != 0);
-    return GF_OK;
+                 geo, (unsigned long long*)keys_ws, (int2*)queue_ws, qcap);
 }
 // dev knob (tests): upper bound of the LDS queue capacity, so that small graphs exercise the global overflow
 static int g_bfs_qcap_max = 0;
@@ -1354,77 +872,32 @@ extern "C" int gf_dev_bfs_qcap_max(int qcap) {
     g_bfs_qcap_max = qcap > 0 ? qcap : 0;
     return GF_OK;
 }
-// dev knob: upper bound of a search workgroup's LDS (bytes; 0 = none): e.g. 79 KB lets two 768-thread workgroups share
-// a compute unit (GF_BFS_LDS_CAP, read once)
-static int g_bfs_lds_cap = -1;
-static size_t bfs_lds_cap() {
-    if (g_bfs_lds_cap < 0) {
-        const char* e = getenv("GF_BFS_LDS_CAP");
-        g_bfs_lds_cap = e ? atoi(e) : 0;
-        if (g_bfs_lds_cap < 0) g_bfs_lds_cap = 0;
-    }
-    return (size_t)g_bfs_lds_cap;
-}
-extern "C" int gf_dev_bfs_lds_cap(int bytes) {
-    g_bfs_lds_cap = bytes < 0 ? -1 : bytes;
-    return GF_OK;
-}
-// int32 words of queue_ws per query
-extern "C" size_t gf_geodesic_bfs_queue_words(int n) {
-    // two queues of (vertex, distance) overflow: 4 n; the pipelined kernel adds its slow-path scratch: 10 n
-    return (size_t)(bfs_pipe_on() ? 10 : 4) * (size_t)(n > 0 ? n : 0);
-}
+// int32 words of queue_ws per query: two queues of (vertex, distance) overflow
+extern "C" size_t gf_geodesic_bfs_queue_words(int n) { return (size_t)4 * (size_t)(n > 0 ? n : 0); }
 
 // wg_threads: threads (and, in proportion, LDS) per query.  The kernel spreads a ring's row entries over the lanes, so
 // more threads per query is faster when the launch has the chip to itself (S150k eval graphs, 256 queries: 1.06 ms at
 // 1024, 1.25 ms at 512, 2.0 ms at 256).  Beside furthest point sampling (13 compute units busy) the 256 queries at
 // 1024 threads -- one per compute unit -- need a second round, and 512 is the fastest (two queries can share a unit).
-static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
-                   float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
-                   size_t lds_cap, const int* gate, int gate_at, int* gate_err, void* stream);
+// (Rounds 4-5 also measured a 768-thread form with capped LDS, a distance-pipelined kernel, a launch gated on the
+// sampler beside it and six multi-source forms: none faster in the forward, HISTORY.md 4.3 / 7; removed in round 6.)
 extern "C" int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K,
                                    const int32_t* src, int nq, float radius, int max_step, float* geo, void* keys_ws,
                                    void* queue_ws, size_t queue_words, int wg_threads, void* stream) {
-    return bfs_cfg(D, I, deg, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads,
-                   bfs_lds_cap(), nullptr, 0, nullptr, stream);
-}
-// The search launched BESIDE the sampling launch that is still drawing its sources (gf_furthest_point_sampling_gated):
-// every workgroup initialises its rows, then waits (bounded: one second) until gate[0] >= gate_at and reads its source
-// with an agent-scope load.  gate_err[0] is set to 1 by a workgroup that timed out (zero it before the launch).  Only the
-// LDS-resident kernel has the wait: a graph it cannot take (n > 2^19, K % 4 != 0) is refused.
-// lds_cap_bytes: upper bound of a workgroup's LDS (0: the workgroup size's share of 150 KB); 64 KB lets two 768-thread
-// workgroups share a compute unit, which is how 256 queries fit the 240 units the sampler leaves free in ONE round.
-extern "C" int gf_geodesic_bfs_gated(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
-                                     int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words,
-                                     int wg_threads, int lds_cap_bytes, const int* gate, int gate_at, int* gate_err,
-                                     void* stream) {
-    GF_CHECK_ARG(gate && gate_err && gate_at >= 1 && lds_cap_bytes >= 0, "gf_geodesic_bfs_gated: gate=%p gate_err=%p gate_at=%d",
-                 (const void*)gate, (void*)gate_err, gate_at);
-    return bfs_cfg(D, I, nullptr, n, K, src, nq, radius, max_step, geo, keys_ws, queue_ws, queue_words, wg_threads,
-                   lds_cap_bytes ? (size_t)lds_cap_bytes : bfs_lds_cap(), gate, gate_at, gate_err, stream);
-}
-static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
-                   float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
-                   size_t lds_cap, const int* gate, int gate_at, int* gate_err, void* stream) {
     GF_CHECK_ARG(n >= 1 && K >= 2 && K <= 64 && nq >= 0 && max_step >= 0, "gf_geodesic_bfs: bad arguments");
     GF_CHECK_ARG(n < (1 << 26), "gf_geodesic_bfs: n=%d exceeds the 26-bit parent field", n);
-    GF_CHECK_ARG(wg_threads == 1024 || wg_threads == 768 || wg_threads == 512 || wg_threads == 256,
-                 "gf_geodesic_bfs: wg_threads=%d (256, 512, 768 or 1024)", wg_threads);
+    GF_CHECK_ARG(wg_threads == 1024 || wg_threads == 512 || wg_threads == 256, "gf_geodesic_bfs: wg_threads=%d (256, 512 or 1024)",
+                 wg_threads);
     if (nq == 0) return GF_OK;
-    // queue_words: int32 words of queue_ws PER QUERY as the caller allocated them (4 n for the LDS kernel and the
-    // global-memory kernel, 10 n for the pipelined one): checked here, so a workspace sized under another setting of the
-    // GF_BFS_PIPE knob is never overrun -- the pipelined kernel is only taken when its 10 n words are there
+    // queue_words: int32 words of queue_ws PER QUERY as the caller allocated them (gf_geodesic_bfs_queue_words): checked here
     GF_CHECK_ARG(queue_words >= (size_t)4 * (size_t)n, "gf_geodesic_bfs: queue workspace of %zu words per query, %zu needed",
                  queue_words, (size_t)4 * (size_t)n);
-    const bool pipe_fits = queue_words >= (size_t)10 * (size_t)n;
     const int nw = (n + 31) / 32;
     const size_t bm = ((size_t)2 * nw + ((2 * nw) & 1)) * sizeof(unsigned);
     // the two bitmaps must fit the workgroup's LDS share: a large scene moves to the next larger workgroup (and
     // share) before it gives up the LDS-resident kernel altogether
-    while (wg_threads < 1024 && bm + 256 * 2 * sizeof(int2) > (size_t)BFS_LDS_BYTES * wg_threads / 1024)
-        wg_threads = wg_threads == 768 ? 1024 : wg_threads * 2;
-    size_t budget = (size_t)BFS_LDS_BYTES * wg_threads / 1024;
-    if (lds_cap && lds_cap < budget && bm + 256 * 2 * sizeof(int2) <= lds_cap) budget = lds_cap;
+    while (wg_threads < 1024 && bm + 256 * 2 * sizeof(int2) > (size_t)BFS_LDS_BYTES * wg_threads / 1024) wg_threads *= 2;
+    const size_t budget = (size_t)BFS_LDS_BYTES * wg_threads / 1024;
     if (n <= BFS_LDS_MAX_N && (K & 3) == 0 && bm + 64 * 2 * sizeof(int2) <= budget) {
         // rows must be distance-sorted and padded with (inf,-1) (gf_knn_radius / faiss order): the
         // LDS variant relies on that to stop scanning a row early
@@ -1433,30 +906,15 @@ static int bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, 
         if (g_bfs_qcap_max > 0 && qcap > g_bfs_qcap_max) qcap = g_bfs_qcap_max < 64 ? 64 : g_bfs_qcap_max;
         const size_t lds = bm + (size_t)qcap * 2 * sizeof(int2);
         hipStream_t st = (hipStream_t)stream;
-        if (!gate && bfs_pipe_on() && pipe_fits && (wg_threads == 512 || wg_threads == 1024)) {
-            if (wg_threads == 512)
-                launch_bfs_pipe<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
-            else
-                launch_bfs_pipe<1024>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
-            GF_CHECK_LAUNCH("gf_geodesic_bfs");
-            return GF_OK;
-        }
         if (wg_threads == 256)
-            launch_bfs_lds<256>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
-                                 gate_err);
+            launch_bfs_lds<256>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
         else if (wg_threads == 512)
-            launch_bfs_lds<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
-                                 gate_err);
-        else if (wg_threads == 768)
-            launch_bfs_lds<768>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
-                                 gate_err);
+            launch_bfs_lds<512>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
         else
-            launch_bfs_lds<1024>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap, gate, gate_at,
-                                 gate_err);
+            launch_bfs_lds<1024>(nq, lds, st, D, I, n, K, src, radius, max_step, geo, keys_ws, queue_ws, qcap);
         GF_CHECK_LAUNCH("gf_geodesic_bfs");
         return GF_OK;
     }
-    GF_CHECK_ARG(!gate, "gf_geodesic_bfs_gated: n=%d K=%d needs the global-memory kernel, which has no gate", n, K);
     hipLaunchKernelGGL(k_geodesic_bfs, dim3(nq), dim3(BFS_THREADS), 0, (hipStream_t)stream, D, I, deg, n, K, src,
                        radius, max_step, geo, (unsigned*)keys_ws, (int32_t*)queue_ws);
     GF_CHECK_LAUNCH("gf_geodesic_bfs");

@@ -469,8 +469,7 @@ template <int P>
 __global__ __launch_bounds__(FPS_WAVES * 64) FPS_VGPR_CAP void k_fps(const float* __restrict__ xyz, int n, int m, int m0, int G,
                                                         int bs_log2, int batch0,
                                                         unsigned long long* __restrict__ slots,
-                                                        int32_t* __restrict__ idxs, int* __restrict__ err,
-                                                        int* __restrict__ gate, int gate_at) {
+                                                        int32_t* __restrict__ idxs, int* __restrict__ err) {
     static_assert(FPS_NG >= 1 && FPS_NG * 64 == FPS_MAXG * FPS_KPUB && FPS_KPUB <= FPS_K && FPS_WAVES * 2 <= 64,
                   "lane mappings of the exchange");
     __shared__ unsigned long long s_part[2][FPS_WAVES * 2];
@@ -576,17 +575,6 @@ __global__ __launch_bounds__(FPS_WAVES * 64) FPS_VGPR_CAP void k_fps(const float
     }
     __syncthreads();  // (s_prog zeroed)
 #endif
-    // gate (optional, one point set): gate[0] = number of picks stored, published by workgroup 0's wave 0 the first time
-    // that number reaches gate_at (and at the end): a kernel launched beside this one (the geodesic search, which needs
-    // the first n_query picks only) waits for it instead of for this launch.  Every pick index is stored by this very
-    // wave, so its release fence covers them.
-    auto post_gate = [&](int before, int after) {
-        if (gate && wg == 0 && wid == 0 && before < gate_at && after >= gate_at) {
-            __threadfence();
-            if (lane == 0) __hip_atomic_store(gate, after, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    post_gate(0, done);
     for (int round = 1; done < m; round++) {
         const int par = round & 1;
         const unsigned long long ft0 = FT();
@@ -820,7 +808,6 @@ __global__ __launch_bounds__(FPS_WAVES * 64) FPS_VGPR_CAP void k_fps(const float
             }
 #if FPS_PIPE
             if (!direct && lane < nacc && wg == 0) idxs[done + lane] = kidx;
-            post_gate(done, done + nacc);
             FPS_ORDER();
             if (lane == 0) FPS_LDS_ST(&s_prog[par], ((unsigned)round << 8) | 0x80u | (unsigned)nacc);
             nnew = nacc;
@@ -832,7 +819,6 @@ __global__ __launch_bounds__(FPS_WAVES * 64) FPS_VGPR_CAP void k_fps(const float
                 s_xyz[par][lane * 3 + 2] = kz;
                 if (wg == 0) idxs[done + lane] = kidx;
             }
-            post_gate(done, done + nacc);
             if (lane == 0) s_pick[par][0] = nacc;
 #endif
             const unsigned long long ft7 = FT();
@@ -896,39 +882,17 @@ __global__ __launch_bounds__(FPS_WAVES * 64) FPS_VGPR_CAP void k_fps(const float
         ftr[9] += nnew;
 #endif
     }
-    post_gate(gate_at - 1, gate_at > m ? gate_at : m);  // (a gate beyond the last pick opens at the end)
 #ifdef FPS_TRACE
     if (g_fps_trace && wg == 0 && threadIdx.x == 0)
         for (int i = 0; i < 10; i++) g_fps_trace[i] = ftr[i];
 #endif
 }
 
-// Bytes of dynamic LDS the sampling workgroups claim without using them (dev knob gf_dev_fps_lds_pad / GF_FPS_LDS_PAD,
-// read once): a workgroup of another kernel that needs more than the rest of the compute unit's 160 KB cannot become
-// co-resident with a sampling workgroup.
-static int g_fps_lds_pad = -1;
-static int fps_lds_pad() {
-    if (g_fps_lds_pad < 0) {
-        const char* e = getenv("GF_FPS_LDS_PAD");
-        g_fps_lds_pad = e ? atoi(e) : 0;
-        if (g_fps_lds_pad < 0) g_fps_lds_pad = 0;
-    }
-    return g_fps_lds_pad;
-}
-extern "C" int gf_dev_fps_lds_pad(int bytes) {
-    g_fps_lds_pad = bytes;
-    return GF_OK;
-}
 template <int P>
 static void launch_fps(int G, int nb, hipStream_t st, const float* xyz, int n, int m, int m0, int bs_log2, int batch0,
-                       unsigned long long* slots, int32_t* idxs, int* err, int* gate, int gate_at, int pad) {
-    static int attr_pad = 0;
-    if (pad > attr_pad) {
-        (void)hipFuncSetAttribute((const void*)k_fps<P>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-        attr_pad = pad;
-    }
-    GF_LAUNCH_OP(GF_OP_FPS, (k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), pad, st, xyz, n, m, m0, G, bs_log2, batch0,
-                 slots, idxs, err, gate, gate_at);
+                       unsigned long long* slots, int32_t* idxs, int* err) {
+    GF_LAUNCH_OP(GF_OP_FPS, (k_fps<P>), dim3(G, nb), dim3(FPS_WAVES * 64), 0, st, xyz, n, m, m0, G, bs_log2, batch0, slots,
+                 idxs, err);
 }
 
 extern "C" size_t gf_fps_scratch_bytes(int b) {
@@ -943,29 +907,10 @@ extern "C" int gf_furthest_point_sampling(const float* xyz, int b, int n, int m,
     return gf_furthest_point_sampling_resume(xyz, b, n, m, 0, idxs, scratch, stream);
 }
 
-static int fps_run(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs, void* scratch, int* gate, int gate_at,
-                   int pad, bool zero_scratch, void* stream);
+// (Round 5 also had a form of this launch that told a search kernel beside it when the first picks were stored, and an
+// LDS pad that kept other kernels off the sampler's compute units: no gain in the forward, HISTORY.md 7; removed.)
 extern "C" int gf_furthest_point_sampling_resume(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs,
                                                  void* scratch, void* stream) {
-    return fps_run(xyz, b, n, m, m_known, idxs, scratch, nullptr, 0, fps_lds_pad(), true, stream);
-}
-extern "C" int gf_fps_scratch_reset(void* scratch, int b, void* stream) {
-    GF_CHECK_ARG(scratch && b >= 0, "gf_fps_scratch_reset: bad arguments");
-    GF_TRY(hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), (hipStream_t)stream));
-    return GF_OK;
-}
-extern "C" int* gf_fps_gate_word(void* scratch, int b) {
-    // inside the scratch's 64-byte tail: [0] the sampler's error word, [2] the gate, [4] a waiter's time-out word
-    return (int*)((unsigned long long*)scratch + (size_t)b * 2 * FPS_MAXG * FPS_KPUB) + 2;
-}
-extern "C" int gf_furthest_point_sampling_gated(const float* xyz, int n, int m, int32_t* idxs, void* scratch, int gate_at,
-                                                int lds_pad_bytes, void* stream) {
-    GF_CHECK_ARG(gate_at >= 1 && lds_pad_bytes >= 0 && lds_pad_bytes <= 120 * 1024,
-                 "gf_furthest_point_sampling_gated: gate_at=%d lds_pad_bytes=%d", gate_at, lds_pad_bytes);
-    return fps_run(xyz, 1, n, m, 0, idxs, scratch, gf_fps_gate_word(scratch, 1), gate_at, lds_pad_bytes, false, stream);
-}
-static int fps_run(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs, void* scratch, int* gate, int gate_at,
-                   int pad, bool zero_scratch, void* stream) {
     GF_CHECK_ARG(b >= 0 && n >= 1 && m >= 0, "gf_furthest_point_sampling: bad sizes b=%d n=%d m=%d", b, n, m);
     GF_CHECK_ARG(m_known >= 0 && m_known <= m, "gf_furthest_point_sampling_resume: m_known=%d not in [0, m=%d]", m_known,
                  m);
@@ -978,27 +923,27 @@ static int fps_run(const float* xyz, int b, int n, int m, int m_known, int32_t* 
     while ((2 << bs_log2) <= n && bs_log2 < 9) bs_log2++;
     const int per_wg = FPS_PW * 64;  // lanes that hold points
     int G = (2 * n + per_wg * 5 - 1) / (per_wg * 5);  // ~2.5 points per lane (40 000 points: 16 workgroups; 13 at 3 per lane cost the forward 1.8 %)
-    static const int g_env = [] { const char* e = getenv("GF_FPS_G"); return e ? atoi(e) : 0; }();  // read once
-    if (g_env > 0) G = g_env;
     if (G < 1) G = 1;
     if (G > FPS_MAXG) G = FPS_MAXG;
     const int P = (n + G * per_wg - 1) / (G * per_wg);
-    GF_CHECK_ARG(P <= 16, "gf_furthest_point_sampling: n=%d too large (max %d)", n, FPS_MAXG * per_wg * 16);
+    GF_CHECK_ARG(P <= 22, "gf_furthest_point_sampling: n=%d too large (max %d)", n, FPS_MAXG * per_wg * 22);
     unsigned long long* slots = (unsigned long long*)scratch;
     int* err = (int*)(slots + (size_t)b * 2 * FPS_MAXG * FPS_KPUB);
-    if (zero_scratch) GF_TRY(hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), st));
+    GF_TRY(hipMemsetAsync(scratch, 0, gf_fps_scratch_bytes(b), st));
     const int per_launch = 1024 / (G * FPS_WAVES) > 0 ? 1024 / (G * FPS_WAVES) : 1;  // all cooperating waves resident
     for (int b0 = 0; b0 < b; b0 += per_launch) {
         const int nb = (b - b0) < per_launch ? (b - b0) : per_launch;
-        if (P <= 1) launch_fps<1>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else if (P <= 2) launch_fps<2>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else if (P <= 3) launch_fps<3>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else if (P <= 4) launch_fps<4>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else if (P <= 5) launch_fps<5>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else if (P <= 6) launch_fps<6>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else if (P <= 8) launch_fps<8>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else if (P <= 12) launch_fps<12>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
-        else launch_fps<16>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err, gate, gate_at, pad);
+        if (P <= 1) launch_fps<1>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 2) launch_fps<2>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 3) launch_fps<3>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 4) launch_fps<4>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 5) launch_fps<5>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 6) launch_fps<6>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 8) launch_fps<8>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 12) launch_fps<12>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 16) launch_fps<16>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else if (P <= 20) launch_fps<20>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
+        else launch_fps<22>(G, nb, st, xyz, n, m, m_known, bs_log2, b0, slots, idxs, err);
     }
     GF_CHECK_LAUNCH("gf_furthest_point_sampling");
     return GF_OK;

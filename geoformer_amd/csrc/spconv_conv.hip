@@ -166,7 +166,7 @@ struct StepIter {
     }
 };
 
-template <int NCBW, int SW, bool VEC, bool LDSW>
+template <int NCBW, int SW, bool VEC>
 __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW <= 2) ? 5 : 1) void k_conv_os(const float* __restrict__ in, const float4* __restrict__ Wp,
                                                  const int32_t* __restrict__ nbr, const uint32_t* __restrict__ gmask,
                                                  int K, int M_out, int ld, int Cin, int Cout, int NCH, int NCB,
@@ -197,14 +197,6 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, K * NCH * NCB * 1024, 0x00020000);
     const unsigned rowbytes = (unsigned)Cin * 4u;
-    // LDSW: the whole packed weight tensor (K*NCH*NCB KiB, <= 64 KiB) is staged once per workgroup; B
-    // operands then come from conflict-free ds_read_b128 instead of one more stream through L1/TA
-    extern __shared__ __attribute__((aligned(16))) float4 s_wp[];
-    if (LDSW) {
-        const int total = K * NCH * NCB * 64;
-        for (int t = threadIdx.x; t < total; t += blockDim.x) s_wp[t] = Wp[t];
-        __syncthreads();
-    }
     const float* sc_l = nullptr;
     const float* sh_l = nullptr;
     // SPLIT (all waves of the workgroup walk the same items): the prologue vectors are only REQUESTED here and land in
@@ -306,7 +298,7 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
         const unsigned inv_nch = (65536u + (unsigned)NCH - 1u) / (unsigned)NCH;  // s / NCH for s < 4096, NCH <= 16
         for (int s0 = SPLIT ? w : 0; s0 < nsteps; s0 += PF * sstride) {
             float4 a[PF];
-            float4 b[LDSW ? 1 : PF][NCBW];
+            float4 b[PF][NCBW];
             bool valid[PF];
             bool present[PF];
             int chv[PF];
@@ -345,9 +337,7 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
                     } else {
                         a[j] = load_a<VEC>(in, idx, Cin, chv[j]);
                     }
-                    if (LDSW) {
-                        chv[j] |= ((it.k * NCH + it.c) * NCB) << 12;  // weight block of this step (uniform)
-                    } else if (VEC) {
+                    if (VEC) {
                         const unsigned wblk = (unsigned)((it.k * NCH + it.c) * NCB + cb0);
 #pragma unroll
                         for (int cb = 0; cb < NCBW; cb++) {
@@ -369,15 +359,10 @@ __global__ CONV_WPE_ATTR __launch_bounds__(SW > 8 ? 1024 : 256, (SW <= 8 && NCBW
 #pragma unroll
             for (int j = 0; j < PF; j++) {
                 if (valid[j]) {
-                    if (sc_l) a[j] = activate_a(a[j], present[j], sc_l, sh_l, chv[j] & 0xfff);
+                    if (sc_l) a[j] = activate_a(a[j], present[j], sc_l, sh_l, chv[j]);
 #pragma unroll
                     for (int cb = 0; cb < NCBW; cb++) {
-                        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (LDSW) {
-                            if (cb0 + cb < NCB) bb = s_wp[((chv[j] >> 12) + cb0 + cb) * 64 + lane];
-                        } else {
-                            bb = b[j][cb];
-                        }
+                        const float4 bb = b[j][cb];
                         acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].x, bb.x, acc[cb], 0, 0, 0);
                         acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].y, bb.y, acc[cb], 0, 0, 0);
                         acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j].z, bb.z, acc[cb], 0, 0, 0);
@@ -465,13 +450,9 @@ struct FlatOp {
     unsigned in_bytes, in2_bytes;
     int items, pad_;
 };
-// COH: the item runs inside a persistent launch next to items of EARLIER layers computed by other workgroups in the same
-// launch (k_conv_chain): gathered rows and residual rows are read past L1 (sc1) and the output is stored write-through
-// (sc1), the hand-off form of MI355X_MICROARCH.md "Valid forms" / cdna_hip_programming.md guideline 16 R1.
-template <bool COH, int MAXB_>
+template <int MAXB_>
 __device__ __forceinline__ void conv_flat_item(const FlatOp& A, int item, float4* s_red, float (*s_aff)[CONV_MAX_CIN]) {
     constexpr int PF = FLAT_PF, MAXB = MAXB_;
-    constexpr int AUX = COH ? 16 : 0;  // sc1
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const float* __restrict__ in = A.in;
     const int K = A.K, M_out = A.M_out, ld = A.ld, Cin = A.Cin, Cout = A.Cout, NCH = A.NCH, NCB = A.NCB;
@@ -514,8 +495,7 @@ __device__ __forceinline__ void conv_flat_item(const FlatOp& A, int item, float4
             for (int j = 0; j < 4; j++) {
                 const int row = g * 16 + q * 4 + j;
                 if (row < M_out) {
-                    if (COH) res[j] = __hip_atomic_load(residual + (size_t)row * Cout + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else res[j] = residual[(size_t)row * Cout + col];
+                    res[j] = residual[(size_t)row * Cout + col];
                 }
             }
         }
@@ -553,10 +533,10 @@ __device__ __forceinline__ void conv_flat_item(const FlatOp& A, int item, float4
             u32x4 v;
             if (cc[e] < nch1) {  // (uniform)
                 const unsigned voff = idx[e] >= 0 ? (unsigned)idx[e] * rowbytes + (unsigned)(cc[e] * 64 + q * 16) : 0xffffffffu;
-                v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, AUX);
+                v = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
             } else {
                 const unsigned voff = idx[e] >= 0 ? (unsigned)idx[e] * rowbytes2 + (unsigned)((cc[e] - nch1) * 64 + q * 16) : 0xffffffffu;
-                v = __builtin_amdgcn_raw_buffer_load_b128(rs_in2, voff, 0, AUX);
+                v = __builtin_amdgcn_raw_buffer_load_b128(rs_in2, voff, 0, 0);
             }
             a[bt & 1][j] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
@@ -624,8 +604,7 @@ __device__ __forceinline__ void conv_flat_item(const FlatOp& A, int item, float4
                 float x = v[j];
                 if (residual) x += res[j];
                 if (out_scale) x = fmaxf(fmaf(x, osc, osh), 0.f);
-                if (COH) __hip_atomic_store(out + (size_t)row * Cout + col, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else out[(size_t)row * Cout + col] = x;
+                out[(size_t)row * Cout + col] = x;
             }
         }
     }
@@ -642,94 +621,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv_flat(const float* __restrict__
     __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];
     const FlatOp A{in, nullptr, Wp, nbr, in_scale, in_shift, residual, out_scale, out_shift, out, K, M_out, ld, Cin, Cin, Cout,
                    NCH, NCB, in_bytes, 0u, 0, 0};
-    conv_flat_item<false, MAXB_>(A, (int)blockIdx.x, s_red, s_aff);
-}
-
-// ------------------------------------------------------------------------------------
-// A CHAIN of flat-form convolutions in one persistent launch (round 4; VERDICT r3 "missing #3": the deep U-Net levels
-// are 37 dependent launches of 8-15 us for < 6 % of the bytes).  G workgroups walk the layers of the chain; layer j's
-// items (16-row group, column block) go to workgroups item % G; between two layers a grid barrier: every wave drains its
-// write-through stores, the workgroup's barrier, ONE lane adds to a device-scope counter and polls it (sc1 loads) until
-// every workgroup that had items in the layer has arrived.  What the next layer gathers was stored sc1 and is read sc1
-// (conv_flat_item<true>).  The chain's parameters travel in the kernel argument segment (<= GF_CHAIN_MAX_OPS layers), the
-// counter is zero at launch.  Identical arithmetic to the same layers as separate launches (same item code).
-// ------------------------------------------------------------------------------------
-struct ChainArgs {
-    int nops, G;
-    FlatOp op[GF_CHAIN_MAX_OPS];
-};
-__global__ __launch_bounds__(1024, 1) void k_conv_chain(const ChainArgs C, unsigned* __restrict__ counter) {
-    __shared__ float4 s_red[16 * 64];
-    __shared__ __attribute__((aligned(16))) float s_aff[2][CONV_MAX_CIN];
-    const int G = C.G;
-    unsigned target = 0;
-    for (int j = 0; j < C.nops; j++) {
-        const FlatOp& A = C.op[j];
-        const int items = A.items;
-        for (int item = (int)blockIdx.x; item < items; item += G) {
-            conv_flat_item<true, FLAT_MAXB>(A, item, s_red, s_aff);
-            __syncthreads();  // (s_red / s_aff are reused by the next item)
-        }
-        if (j + 1 == C.nops) break;
-        // ---- grid barrier ----
-        target += (unsigned)(items < G ? items : G);  // workgroups that had items in this layer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have landed
-        __syncthreads();
-        // a workgroup without items in any later layer arrives and leaves (the layers of a chain shrink with the level)
-        int last = j;
-        for (int jj = j + 1; jj < C.nops; jj++)
-            if ((int)blockIdx.x < C.op[jj].items) last = jj;
-        if (threadIdx.x == 0 && (int)blockIdx.x < items)
-            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (last == j) return;
-        if (threadIdx.x == 0) {
-            // (a workgroup whose next items are several layers away polls at a longer interval)
-            const bool soon = (int)blockIdx.x < C.op[j + 1].items;
-            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (soon) __builtin_amdgcn_s_sleep(1);
-                else __builtin_amdgcn_s_sleep(32);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-int gf_conv_chain_supported(const GfChainOp& o) {
-    if (o.M_out <= 0 || o.K < 1 || o.K > 32 || o.Cin < 16 || (o.Cin & 15) || o.Cout < 1) return 0;
-    if (o.in2 && (o.Cin1 <= 0 || (o.Cin1 & 15) || o.Cin1 >= o.Cin)) return 0;
-    if (o.nbr == nullptr && o.K != 1) return 0;
-    const int nch = o.Cin / 16, ncb = (o.Cout + 15) / 16;
-    const long long ngroups = (o.M_out + 15) / 16;
-    const int c1 = o.in2 ? o.Cin1 : o.Cin;
-    const unsigned long long b1 = (unsigned long long)o.M_in * c1 * 4ull, b2 = (unsigned long long)o.M_in * (o.Cin - c1) * 4ull;
-    if (nch > 16 || o.K * nch > 16 * FLAT_PF * FLAT_MAXB || ngroups * ncb > 256) return 0;
-    if (b1 >= 0xfffffff0ull || b2 >= 0xfffffff0ull) return 0;
-    if ((((uintptr_t)o.in) | ((uintptr_t)o.in2)) % 16) return 0;
-    if (o.in_scale && ((((uintptr_t)o.in_scale) | ((uintptr_t)o.in_shift)) % 16 || o.Cin > CONV_MAX_CIN - 16)) return 0;
-    return 1;
-}
-
-int gf_conv_chain(const GfChainOp* ops, int nops, unsigned* counter, hipStream_t st) {
-    GF_CHECK_ARG(ops && counter && nops >= 1 && nops <= GF_CHAIN_MAX_OPS, "gf_conv_chain: %d layers (1..%d)", nops, GF_CHAIN_MAX_OPS);
-    ChainArgs C;
-    C.nops = nops;
-    int G = 1;
-    for (int j = 0; j < nops; j++) {
-        const GfChainOp& o = ops[j];
-        GF_CHECK_ARG(gf_conv_chain_supported(o), "gf_conv_chain: layer %d is not a flat-form shape", j);
-        const int nch = o.Cin / 16, ncb = (o.Cout + 15) / 16;
-        const int items = ((o.M_out + 15) / 16) * ncb;
-        const int c1 = o.in2 ? o.Cin1 : o.Cin;
-        C.op[j] = FlatOp{o.in, o.in2, reinterpret_cast<const float4*>(o.Wp), o.nbr, o.in_scale, o.in_shift, o.residual,
-                         o.out_scale, o.out_shift, o.out, o.K, o.M_out, o.ld, o.Cin, c1, o.Cout, nch, ncb,
-                         (unsigned)((unsigned long long)o.M_in * c1 * 4ull), (unsigned)((unsigned long long)o.M_in * (o.Cin - c1) * 4ull),
-                         items, 0};
-        if (items > G) G = items;
-    }
-    C.G = G;  // (<= 256: every workgroup of the launch is resident at once, one per compute unit)
-    hipLaunchKernelGGL(k_conv_chain, dim3(G), dim3(1024), 0, st, C, counter);
-    GF_CHECK_LAUNCH("gf_conv_chain");
-    return GF_OK;
+    conv_flat_item<MAXB_>(A, (int)blockIdx.x, s_red, s_aff);
 }
 
 // Two 16-row groups per wave for the big 16-output-channel levels (level 1 of the U-Net: ~9000 groups).
@@ -1517,25 +1409,14 @@ extern "C" int gf_dev_conv_chunks(int n) {
     g_conv_chunks = n;
     return GF_OK;
 }
-template <int NCBW>
-static void launch_conv_ldsw(dim3 grid, int bs, size_t lds, hipStream_t st, const ConvArgs& a) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)k_conv_os<NCBW, 0, true, true>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);  // a failure shows at the launch
-        attr = true;
-    }
-    hipLaunchKernelGGL((k_conv_os<NCBW, 0, true, true>), grid, dim3(bs), lds, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
-                       a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
-}
 template <int NCBW, int SW>
 static void launch_conv(bool vec, dim3 grid, hipStream_t st, const ConvArgs& a) {
     const int bs = SW ? SW * 64 : g_conv_block;
     if (vec)
-        hipLaunchKernelGGL((k_conv_os<NCBW, SW, true, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+        hipLaunchKernelGGL((k_conv_os<NCBW, SW, true>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                            a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
     else
-        hipLaunchKernelGGL((k_conv_os<NCBW, SW, false, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
+        hipLaunchKernelGGL((k_conv_os<NCBW, SW, false>), grid, dim3(bs), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                            a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.NCB, a.nsplit, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
 }
 
@@ -1553,24 +1434,12 @@ static void dispatch_conv(int ncbw, bool vec, dim3 grid, hipStream_t st, const C
     }
 }
 
-// Dev knobs, read from the environment ONCE: a getenv() walks the whole environment block, and five of them per
-// launch cost the host ~10 us -- more than a small conv kernel runs -- in the launch-bound U-Net (71 convs per scene).
+// Dev knobs (include/geoformer_hip_dev.h: gf_dev_conv_knobs*): force a launch shape regardless of the level's size.
 struct ConvKnobs {
-    int split = -1, wide = -1, block = 0, ldsw = 0, pair = -1;  // -1 / 0: not set
-    int g16 = -1, g16_ldsw = -1, g16_gpw = 0;                   // counted-loop kernel: use / weights in LDS / groups per wave
-    int g16_pipe = -1;                                          // its pipelined form (one chunk of groups per wave)
-    int flat = -1, flat_items = 0;                              // flat-chain kernel: use / item bound of the size-based choice
-    ConvKnobs() {
-        if (const char* e = getenv("GF_CONV_SPLIT")) split = atoi(e) != 0;
-        if (const char* e = getenv("GF_CONV_WIDE")) wide = atoi(e) != 0;
-        if (const char* e = getenv("GF_CONV_BLOCK")) block = atoi(e) > 256 ? 256 : atoi(e);
-        if (const char* e = getenv("GF_CONV_LDSW")) ldsw = atoi(e) != 0;
-        if (const char* e = getenv("GF_CONV_PAIR")) pair = atoi(e) != 0;
-        if (const char* e = getenv("GF_CONV_G16")) g16 = atoi(e) != 0;
-        if (const char* e = getenv("GF_CONV_G16_LDSW")) g16_ldsw = atoi(e) != 0;
-        if (const char* e = getenv("GF_CONV_G16_GPW")) g16_gpw = atoi(e);
-        if (const char* e = getenv("GF_CONV_G16_PIPE")) g16_pipe = atoi(e) != 0;
-    }
+    int split = -1, wide = -1, block = 0, pair = -1;  // -1 / 0: not set
+    int g16 = -1, g16_ldsw = -1, g16_gpw = 0;         // counted-loop kernel: use / weights in LDS / groups per wave
+    int g16_pipe = -1;                                // its pipelined form (one chunk of groups per wave)
+    int flat = -1, flat_items = 0;                    // flat-chain kernel: use / item bound of the size-based choice
 };
 static ConvKnobs& conv_knobs_mut() {
     static ConvKnobs k;
@@ -1598,7 +1467,7 @@ extern "C" int gf_dev_conv_knobs(int split, int wide, int pair, int ldsw, int bl
     k.split = split < 0 ? -1 : (split != 0);
     k.wide = wide < 0 ? -1 : (wide != 0);
     k.pair = pair < 0 ? -1 : (pair != 0);
-    k.ldsw = ldsw > 0;
+    (void)ldsw;  // (the LDS-weight form of k_conv_os is gone: round 6)
     k.block = block <= 0 ? 0 : (block > 256 ? 256 : block);
     g_conv_block = k.block > 0 ? k.block : 256;
     return GF_OK;
@@ -1650,10 +1519,6 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
     dim3 grid((unsigned)blocks);
     hipStream_t st = (hipStream_t)stream;
     const size_t wbytes = (size_t)K * nch * ncb * 1024;
-    // LDS-resident weights: measured 10 % SLOWER than streaming them through L1 at C=16 (33.4 vs 30.3 us,
-    // S150k level 1), so it is opt-in (GF_CONV_LDSW=1) until the staging cost is amortised differently
-    bool ldsw = false;
-    if (knobs.ldsw) ldsw = !split && vec && ncb <= 2 && wbytes <= 64 * 1024;
     // counted-loop kernel over the step table: 16 output channels, one or two input chunks
     bool g16 = steps != nullptr && gmask != nullptr && vec && Cout == 16 && nch <= 2 && (((uintptr_t)out) % 16) == 0 &&
                (residual == nullptr || (((uintptr_t)residual) % 16) == 0) && in_bytes64 <= 0xffffff00ull;
@@ -1717,7 +1582,7 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
     GF_CHECK_ARG(nbr != nullptr || K == 1, "gf_conv_fwd: this launch shape needs the [K,ld] neighbour table");
     bool pair = !split && vec && ncb == 1 && nbr != nullptr && K <= 32 && nch <= 8 && in_bytes64 <= 0xfffff000ull - 4096ull;
     if (knobs.pair >= 0) pair = pair && knobs.pair != 0;
-    if (pair && !ldsw) {
+    if (pair) {
         const long long npairs = (ngroups + 1) / 2;
         long long pb = (npairs + 3) / 4;
         if (pb > 256 * 64) pb = 256 * 64;
@@ -1727,12 +1592,6 @@ static int conv_fwd_impl(const float* in, const float* Wp, const int32_t* nbr, c
         else
             hipLaunchKernelGGL(k_conv_pair<false>, dim3((unsigned)pb), dim3(256), 0, st, a.in, a.Wp, a.nbr, a.gmask, a.K,
                                a.M_out, a.ld, a.Cin, a.Cout, a.NCH, a.in_bytes, a.sc, a.sh, a.res, a.osc, a.osh, a.out);
-    } else if (ldsw) {
-        // 256-thread workgroups share one weight image: 4 waves per 27-54 KiB
-        const int bs = 256;
-        dim3 g2((unsigned)((nitems + 3) / 4));
-        if (ncb == 1) launch_conv_ldsw<1>(g2, bs, wbytes, st, a);
-        else launch_conv_ldsw<2>(g2, bs, wbytes, st, a);
     } else if (split && wide)
         launch_conv<1, 16>(vec, grid, st, a);
     else if (split)
@@ -2078,12 +1937,7 @@ static int conv_wgrad_masked_impl(const float* in, const float* dout, const int3
     const int nci = Cin / 16, nco = Cout / 16;
     const int nslices = (M_out + WGT_ROWS - 1) / WGT_ROWS;
     const long long nitems = (long long)K * nci * nco * nslices;
-    static int xcd_order = -1;
-    if (xcd_order < 0) {
-        const char* e = getenv("GF_WGRAD_XCD");
-        xcd_order = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (xcd_order && nslices >= 128) {  // (few slices: the order would leave XCDs without work)
+    if (nslices >= 128) {  // (few slices: the order would leave XCDs without work)
         const int wps = gf_div_up((long long)K * nci * nco, 4);  // workgroups per slice
         const long long wgs = (long long)gf_div_up(nslices, 8) * 8 * wps;
         GF_LAUNCH_OP(GF_OP_WGRAD, k_conv_wgrad_t, dim3((unsigned)wgs), dim3(256), 0, st, in, dout, nbr, gmask, K, M_out, ld, Cin,
@@ -2107,10 +1961,4 @@ extern "C" int gf_conv_wgrad_masked_acc(const float* in, const float* dout, cons
     return conv_wgrad_masked_impl(in, dout, nbr, gmask, K, M_out, ld, Cin, Cout, dW, false, stream);
 }
 
-extern "C" int gf_dev_conv_occupancy(int block) {
-    int n = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_conv_os<1, false, true, true>, block,
-                                                     27 * 1024) != hipSuccess)
-        return -1;
-    return n;
-}
+

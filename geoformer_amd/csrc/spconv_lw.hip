@@ -241,6 +241,8 @@ __global__ __launch_bounds__(64 * WPB) void k_conv_lw(const LwArgs A) {
     int g = __builtin_amdgcn_readlane(dsc.x, 0);
     uint32_t m = (uint32_t)__builtin_amdgcn_readlane(dsc.w, 0);
     request_res(0);
+    since = -1;  // (the prologue's D gathers went out BEFORE this request: the first gather behind it belongs to step D,
+                 //  whose counted wait runs when `since` would read D + 1)
     auto next_group = [&]() {
         ci++;
         g = __builtin_amdgcn_readlane(dsc.x, min(ci, 63));

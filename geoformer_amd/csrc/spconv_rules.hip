@@ -890,15 +890,9 @@ __global__ void k_table_gmask_all(DownAll A) {
     if ((threadIdx.x & 15) == 0 && o < ld) ((uint32_t*)A.f[l][8])[o >> 4] = mask;
 }
 
-// dev knob: GF_RULES_SERIAL=1 builds the chain level by level (the round-4 form) for A/B runs
-static int g_rules_serial = -1;
-bool gf_rules_level_parallel() {
-    if (g_rules_serial < 0) {
-        const char* e = getenv("GF_RULES_SERIAL");
-        g_rules_serial = e ? (atoi(e) != 0) : 0;
-    }
-    return g_rules_serial == 0;
-}
+// the chain is built with every stage as one launch over all levels; gf_rules_down2_chain_range (level by level, the
+// round-4 form) remains for callers that want a sub-range
+bool gf_rules_level_parallel() { return true; }
 
 int gf_rules_down2_chain_all(const int32_t* coords, int M0, int B, int X, int Y, int Z, int nlevels, int32_t* ws,
                              int32_t* counts, hipStream_t st) {

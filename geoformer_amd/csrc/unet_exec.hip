@@ -135,30 +135,7 @@ struct Probe {
 };
 thread_local Probe t_probe;
 constexpr int kProbeSlots = 4096;
-constexpr int kChainCounters = 16;  // persistent chain launches per call (each its own zeroed counter, 256 bytes apart)
-// The deep U-Net levels as persistent chain launches (k_conv_chain): 1 on, 0 (default) one launch per convolution.
-// GF_UNET_CHAIN, read once; gf_dev_unet_chain.  Built for VERDICT r3 "missing #3" and measured (round 4,
-// tools/ab_unet_chain.py, paired in one process over the eight benchmark scenes): the 26 convolutions of S150k levels 5-7
-// as three launches are bit-identical to the 26 launches and 0.08 ms SLOWER per forward (backbone 1.68 against 1.60 ms),
-// also with workgroups leaving the chain once they have no layer left: a layer's grid barrier (device-scope arrival +
-// poll, ~150-240 workgroups at level 5) and the write-through / L1-bypassing hand-off of its rows cost ~11 us per layer
-// where a dependent flat-form launch costs 8-9 -- MI355X_MICROARCH.md's price list says the same (kernel boundary
-// 1.5-1.9 us, counter barrier >= 4 us at one workgroup per compute unit).
-int g_unet_chain = -1;
-bool unet_chain_on() {
-    if (g_unet_chain < 0) {
-        const char* e = getenv("GF_UNET_CHAIN");
-        g_unet_chain = e ? (atoi(e) != 0) : 0;
-    }
-    return g_unet_chain != 0;
-}
-
 }  // namespace
-
-extern "C" int gf_dev_unet_chain(int on) {
-    g_unet_chain = on < 0 ? -1 : (on != 0);
-    return GF_OK;
-}
 
 extern "C" int gf_dev_unet_probe(int mode) {
     GF_CHECK_ARG(mode >= 0 && mode <= 3, "gf_dev_unet_probe: mode %d (0 off, 1 / 3 level-1 block convs, 2 every conv)", mode);
@@ -229,7 +206,6 @@ static size_t unet_layout(const GfUnetParams* P, int M0, int B, int X, int Y, in
     if (ld0 >= kFlatMinRows) a.take<int32_t>(gf_rules_flat_words(27, ld0));
     a.take<int32_t>((size_t)total);
     a.take<int32_t>(GF_UNET_MAX_LEVELS + 1);
-    a.take<unsigned>((size_t)kChainCounters * 64);
     for (int l = 1; l <= nl; l++) {
         a.take<int32_t>((size_t)27 * caps[l]);
         a.take<uint32_t>(caps[l] / 16);
@@ -333,7 +309,6 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     if (ld0 >= kFlatMinRows) T[0].flat = a.take<int32_t>(gf_rules_flat_words(27, ld0));
     int32_t* cws = a.take<int32_t>((size_t)chain_elems);
     int32_t* d_counts = a.take<int32_t>(GF_UNET_MAX_LEVELS + 1);
-    unsigned* chain_counters = a.take<unsigned>((size_t)kChainCounters * 64);
     for (int l = 1; l <= nl; l++) {
         T[l].ld = caps[l];
         T[l].nbr = a.take<int32_t>((size_t)27 * caps[l]);
@@ -393,83 +368,13 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     carve(0);
     float* x16 = a.take<float>((size_t)ld0 * 16);
 
-    // ---- the deep levels as persistent chain launches (k_conv_chain, spconv_conv.hip) ----
-    // From the first level whose every convolution is a flat-form launch (at most 256 (group, column block) items) down,
-    // convolutions are not launched one by one but collected and issued as chains: one launch per run of layers between
-    // two launches of another kind (the voxel transformers of the two deepest levels), a grid barrier between layers.
-    // The skip concatenation of those levels is not materialised: the two convolutions that read it gather from both
-    // sources.  Same item code, same sums as the separate launches (tests/test_gpu_unet_exec.py).
-    const bool chain_on = unet_chain_on();
-    int chain_from = GF_UNET_MAX_LEVELS + 1;  // first chained level (0-based); set once the voxel counts are known
-    std::vector<GfChainOp> chain;
-    std::vector<ProbeRec> chain_recs;
-    int chains_used = 0;
-    bool counters_cleared = false;
-    auto flush_chain = [&]() -> int {
-        if (chain.empty()) return GF_OK;
-        GF_CHECK_ARG(chains_used < kChainCounters, "gf_unet_fwd: more than %d chain launches", kChainCounters);
-        if (!counters_cleared) {
-            GF_TRY(hipMemsetAsync(chain_counters, 0, (size_t)kChainCounters * 64 * sizeof(unsigned), st));
-            counters_cleared = true;
-        }
-        Probe& pb = t_probe;
-        hipEvent_t ea = nullptr, eb = nullptr;
-        if (!chain_recs.empty()) {
-            ea = pb.ev();
-            eb = pb.ev();
-            GF_CHECK_ARG(ea && eb, "gf_unet_fwd: probe events");
-            GF_TRY(hipEventRecord(ea, st));
-        }
-        const int rc_ = gf_conv_chain(chain.data(), (int)chain.size(), chain_counters + (size_t)chains_used * 64, st);
-        chains_used++;
-        if (ea) {
-            GF_TRY(hipEventRecord(eb, st));
-            for (ProbeRec r : chain_recs) {
-                r.a = ea;
-                r.b = eb;
-                r.share = (int)chain.size();
-                pb.recs.push_back(r);
-            }
-        }
-        chain.clear();
-        chain_recs.clear();
-        return rc_;
-    };
     // every convolution of the call goes through here (kind: 0 input, 1 / 2 first / second conv of a block, 3 its
     // 1x1x1 identity branch, 4 strided, 5 inverse); the dev probe, when armed, brackets the launch with two events.
-    // lo: the level of the OUTPUT rows (decides whether the layer joins a chain); in2 / Cin1: second source of a
-    // concatenated input (chained levels only).
     auto conv = [&](int l, int kind, const float* in, const float* wp, const int32_t* nbr, const uint32_t* gmask,
                     const int32_t* steps, int K, int M_in, int M_out, int ld, int Cin, int Cout, const float* sc,
                     const float* sh, const float* res, const float* osc, const float* osh, float* outp,
-                    float* out_act = nullptr, int lo = -1, const float* in2 = nullptr, int Cin1 = 0) -> int {
+                    float* out_act = nullptr) -> int {
         Probe& pb = t_probe;
-        if (lo < 0) lo = l;
-        if (chain_on && lo >= chain_from && out_act == nullptr && M_out > 0) {
-            const GfChainOp op{in, in2, wp, nbr, sc, sh, res, osc, osh, outp, K, M_in, M_out, ld, Cin, in2 ? Cin1 : Cin, Cout};
-            if (gf_conv_chain_supported(op)) {
-                if ((int)chain.size() == GF_CHAIN_MAX_OPS) {
-                    const int r_ = flush_chain();
-                    if (r_ != GF_OK) return r_;
-                }
-                if (pb.mode == 2) {
-                    ProbeRec r{l, kind, K, Cin, Cout, M_in, M_out, res != nullptr, -1, nullptr, nullptr, nullptr, nullptr};
-                    if (nbr && pb.nslots < kProbeSlots) {
-                        r.slot = pb.nslots++;
-                        GF_TRY(hipMemsetAsync(pb.d_counts + r.slot, 0, sizeof(int), st));
-                        hipLaunchKernelGGL(k_count_rules, dim3(256), dim3(256), 0, st, nbr, K, ld, M_out, pb.d_counts + r.slot);
-                    }
-                    chain_recs.push_back(r);
-                }
-                chain.push_back(op);
-                return GF_OK;
-            }
-        }
-        GF_CHECK_ARG(in2 == nullptr, "gf_unet_fwd: a two-source convolution outside a chain");
-        {
-            const int r_ = flush_chain();  // (this launch may read what the pending layers write)
-            if (r_ != GF_OK) return r_;
-        }
         const bool rec = pb.mode == 2 || ((pb.mode == 1 || pb.mode == 3) && l == 0 && (kind == 1 || kind == 2) && Cin == 16 && Cout == 16);
         // (a submanifold convolution of a level with a flat step table hands it over: gf_conv_fwd_flat)
         const int32_t* fl = (K == 27 && nbr != nullptr && nbr == T[l].nbr) ? T[l].flat : nullptr;
@@ -526,18 +431,16 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         float* buf;
     };
     auto resblock = [&](const GfResBlockParams& rb, int l, int cin, const float* x, float* outp, const float* osc,
-                        const float* osh, const float* x_act = nullptr, const NextAct* next = nullptr,
-                        const float* x2 = nullptr) -> int {  // x2: the input is the concatenation (x, x2), cin / 2 channels each
+                        const float* osh, const float* x_act = nullptr, const NextAct* next = nullptr) -> int {
         const int C = P->level[l].C;
         const LevelTables& t = T[l];
         GF_CHECK_ARG(rb.wp0 && rb.wp1 && rb.s0 && rb.t0 && rb.s1 && rb.t1, "gf_unet_fwd: level %d: block parameters missing", l);
         GF_CHECK_ARG((rb.wpi != nullptr) == (cin != C), "gf_unet_fwd: level %d: identity-branch weights must exist iff the widths differ", l);
         GF_CHECK_ARG(!(next && osc), "gf_unet_fwd: a block has one epilogue activation");
         int r;
-        GF_CHECK_ARG(x2 == nullptr || (rb.wpi && !x_act && !next), "gf_unet_fwd: a concatenated input feeds a block with an identity branch");
         if (rb.wpi) {
             r = conv(l, 3, x, rb.wpi, nullptr, nullptr, nullptr, 1, M[l], M[l], 0, cin, C, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, Bf[l].idn, nullptr, -1, x2, cin / 2);
+                     nullptr, Bf[l].idn);
             if (r != GF_OK) return r;
         }
         if (x_act)
@@ -545,7 +448,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
                      rb.t1, Bf[l].tmp);
         else
             r = conv(l, 1, x, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, rb.s0, rb.t0, nullptr, rb.s1, rb.t1,
-                     Bf[l].tmp, nullptr, -1, x2, cin / 2);
+                     Bf[l].tmp);
         if (r != GF_OK) return r;
         if (next)
             return conv(l, 2, Bf[l].tmp, rb.wp1, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, C, C, nullptr, nullptr,
@@ -625,8 +528,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
                      "gf_unet_fwd: level %d: strided / inverse conv parameters missing", l);
         // BN + ReLU + SparseConv3d(k=2, s=2): child table of the chain
         return conv(l, 4, Bf[l].o1, L.down_wp, cws + o[4], (const uint32_t*)(cws + o[8]), nullptr, 8, M[l], M[l + 1],
-                    caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x, nullptr,
-                    l + 1);
+                    caps[l + 1], L.C, P->level[l + 1].C, L.down_s, L.down_t, nullptr, nullptr, nullptr, Bf[l + 1].x);
     };
     // a level whose C -> C convolutions run the LDS-weight kernel (both outputs): a block's second convolution also writes
     // the next block's activated input, whose first convolution then has no prologue (as the first level does, dual0)
@@ -683,14 +585,6 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         }
         UN_TRY(build_flat0());
         for (int l = 2; l <= nl; l++) carve(l);
-        if (chain_on) {  // the run of deepest levels whose convolutions all are flat-form launches
-            chain_from = nl + 1;
-            for (int l = nl; l >= 2; l--) {
-                const long long items = (long long)(r16(M[l]) / 16) * (P->level[l].C / 16);
-                if (items > 256) break;
-                chain_from = l;
-            }
-        }
     }
 
     if (nl <= 1) UN_TRY(build_flat0());
@@ -713,19 +607,14 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
             // BN + ReLU + SparseInverseConv3d: the one-hot `up` table of the chain; rows without a coarse cell stay zero
             UN_TRY(conv(l, 5, Bf[l + 1].o2, L.up_wp, cws + o[7], (const uint32_t*)(cws + o[9]), nullptr, 8, M[l + 1], M[l],
                         caps[l], P->level[l + 1].C, L.C, L.up_s, L.up_t, nullptr, nullptr, nullptr, Bf[l].up));
-            const bool chained = chain_on && l >= chain_from;  // the two readers of the concatenation gather from both sources
-            if (M[l] > 0 && !chained) {
-                UN_TRY(flush_chain());
+            if (M[l] > 0) {
                 const int c4 = L.C / 4, n = M[l] * 2 * c4;
                 hipLaunchKernelGGL(k_concat2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)Bf[l].o1,
                                    (const float4*)Bf[l].up, M[l], c4, (float4*)Bf[l].cat);
             }
             const bool dual = (l == 0 && dual0) || lw_dual(l);  // tail[0]'s second conv writes tail[1]'s activated input as well
             const NextAct nt{L.tail[1].s0, L.tail[1].t0, Bf[l].a1};
-            if (chained)
-                UN_TRY(resblock(L.tail[0], l, 2 * L.C, Bf[l].o1, Bf[l].o0, nullptr, nullptr, nullptr, nullptr, Bf[l].up));
-            else
-                UN_TRY(resblock(L.tail[0], l, 2 * L.C, Bf[l].cat, Bf[l].o0, nullptr, nullptr, nullptr, dual ? &nt : nullptr));
+            UN_TRY(resblock(L.tail[0], l, 2 * L.C, Bf[l].cat, Bf[l].o0, nullptr, nullptr, nullptr, dual ? &nt : nullptr));
             float* dst = last_tail_is_output ? out : Bf[l].o2;
             UN_TRY(resblock(L.tail[1], l, L.C, Bf[l].o0, dst, last_tail_is_output ? P->out_s : nullptr,
                             last_tail_is_output ? P->out_t : nullptr, dual ? Bf[l].a1 : nullptr, nullptr));
@@ -735,7 +624,6 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
             GF_CHECK_ARG(l > 0, "gf_unet_fwd: the voxel transformer needs batch-major rows (levels below the first)");
             GF_CHECK_ARG(L.tr_params != nullptr, "gf_unet_fwd: level %d: transformer parameters missing", l);
             if (M[l] > 0) {
-                UN_TRY(flush_chain());
                 hipLaunchKernelGGL(k_scene_offsets, dim3(gf_div_up(M[l] + 1, 256)), dim3(256), 0, st, lcoords[l], M[l], B,
                                    Bf[l].tr_offs);
                 UN_TRY(gf_backbone_transformer(cur, lcoords[l], Bf[l].tr_offs, B, M[l], L.C, L.tr_layers, L.tr_params,
@@ -748,7 +636,10 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
             Bf[l].o2 = const_cast<float*>(cur);
         }
     }
-    UN_TRY(flush_chain());
+    // a flat table nobody read (the dev knob switched its kernel off): its build on the side stream still has to be over
+    // before the caller reuses the workspace
+    if (flat0_pending) GF_TRY(hipStreamWaitEvent(st, t_ev.flat0, 0));
+    if (flat1_pending) GF_TRY(hipStreamWaitEvent(st, t_ev.flat1, 0));
 #undef UN_TRY
     GF_CHECK_LAUNCH("gf_unet_fwd");
     return GF_OK;

@@ -24,14 +24,6 @@ import torch
 from . import pointops, scene
 
 
-def _dormant(name, where):
-    def fn(*a, **k):
-        raise NotImplementedError(f"{name} ({where}) is not on GeoFormer's path and has no HIP kernel yet")
-
-    fn.__name__ = name
-    return fn
-
-
 # ------------------------------------------------------------------------------------------
 # PG_OP
 # ------------------------------------------------------------------------------------------

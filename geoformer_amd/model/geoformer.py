@@ -48,18 +48,6 @@ voxelization = _Voxelization.apply
 import threading
 import weakref
 
-# GF_BFS_GATE=1: the sampling / search stretch of a one-scene inference forward as a gated pair of launches (below) instead
-# of two sampling launches with the search after the first.  In the gated form the search runs at _GATE_WG threads per
-# query with at most _GATE_LDS_KB of LDS -- two workgroups per compute unit, so the 256 queries fit beside the sampler in
-# one round.  Measured: a forward that is waited for 1.7 % shorter (4.96 against 5.05 ms), bench.py's loop unchanged
-# (210.2 against 210.0 scenes/s over three alternating pairs): opt-in.
-_BFS_GATE = os.environ.get("GF_BFS_GATE", "0") == "1"
-_GATE_PAD_KB = int(os.environ.get("GF_GATE_PAD_KB", "88"))  # LDS the gated sampler claims per workgroup (0: none) ...
-_GATE_PAD_MAX_N = int(os.environ.get("GF_GATE_PAD_MAX_N", "80000"))  # ... for foregrounds up to this many points
-_GATE_WG = int(os.environ.get("GF_GATE_WG", "768"))
-_GATE_LDS_KB = int(os.environ.get("GF_GATE_LDS_KB", "64"))
-_BFS_WG = int(os.environ.get("GF_BFS_WG", "0"))  # threads per query of the BFS launched beside the sampling (0: by the number of queries)
-
 
 def _bfs_wg(nq, scenes=1):
     """1024 threads per query (the kernel's fastest layout: 1.06 against 1.25 ms at 512) when the workgroups of the
@@ -67,8 +55,6 @@ def _bfs_wg(nq, scenes=1):
     kernels leave free in one round: the train yaml's 128 queries on one scene, the few-shot model's; 512 (two queries
     share a unit) for the test yaml's 256 queries and for a training batch (4 x 128 queries: 56.3 -> 52.9 ms per step;
     256 threads: 57.1)."""
-    if _BFS_WG:
-        return _BFS_WG
     return 1024 if nq * scenes <= 224 else 512
 # Side streams of the sampling / BFS stretch, keyed by (device, caller stream, role): a process resource, not a model's --
 # a second model instance taking fresh streams from the framework's pool measured 6.0 against 4.5 ms per scene on the
@@ -593,18 +579,8 @@ class GeoFormer(nn.Module):
         # BFS to another, so the scenes' two latency-bound launches run beside each other instead of one scene after
         # the other (4 x (0.4 + 3.3) ms of a batch-4 step in which the device finishes last); the main stream joins
         # them before the grouping.  One scene / inference: the streams of the docstring.
-        multi = batch_size > 1 and early is None and not epilogue and os.environ.get("GF_SCENE_STREAMS", "1") != "0"
+        multi = batch_size > 1 and early is None and not epilogue
         scene_streams = []
-        bfs_one_stream = multi and os.environ.get("GF_TRAIN_BFS_STREAMS", "scene") == "one"
-        # one scene: the gated form of the stretch (below); GF_BFS_GATE=0: two sampling launches, the search after the first
-        # (only where the search is dispatched well behind the sampling launch -- the kNN graph it needs is built in
-        #  between -- and only when its queries do not fit one per compute unit anyway)
-        gated = split and batch_size == 1 and _BFS_GATE and early is not None and nq > 224 and not torch.is_grad_enabled()
-        bfs_mode = os.environ.get("GF_TRAIN_BFS_BATCHED", "0")  # 1: one multi-source search for the batch; 2: one per scene
-        bfs_batched = multi and nq >= 32 and bfs_mode == "1"
-        bfs_ms_scene = multi and nq >= 32 and bfs_mode == "2"
-        bfs_pending = []
-
         def host_draw(b, n_b):
             """The reference's host draw of scene b (same values, same generator state), restated natively, into a pinned
             buffer of this host thread (the upload that follows is an asynchronous copy)."""
@@ -639,10 +615,9 @@ class GeoFormer(nn.Module):
                 sb = sides.get((locs_float_.device, main.cuda_stream, "scene", b))
                 if sb is None:
                     sb = sides[(locs_float_.device, main.cuda_stream, "scene", b)] = torch.cuda.Stream(device=locs_float_.device)
-                bk = 0 if bfs_one_stream else b
-                side_b = sides.get((locs_float_.device, main.cuda_stream, "bfs", bk))
+                side_b = sides.get((locs_float_.device, main.cuda_stream, "bfs", b))
                 if side_b is None:
-                    side_b = sides[(locs_float_.device, main.cuda_stream, "bfs", bk)] = torch.cuda.Stream(device=locs_float_.device)
+                    side_b = sides[(locs_float_.device, main.cuda_stream, "bfs", b)] = torch.cuda.Stream(device=locs_float_.device)
                 sb.wait_stream(main)
                 scene_streams.append(sb)
             else:
@@ -659,32 +634,17 @@ class GeoFormer(nn.Module):
                     xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
                 xyz_ready = torch.cuda.Event()
                 xyz_ready.record(sb)
-                gate = None
-                if gated:
-                    # ONE sampling launch; the search is launched beside it right away and waits INSIDE its kernel for
-                    # the first nq picks (csrc/pointops.hip post_gate / csrc/geodesic.hip): no second sampling launch,
-                    # the search's row initialisation runs under the first picks, and -- sparse foregrounds -- the
-                    # sampler's workgroups claim enough LDS that no search workgroup shares their compute units (a
-                    # search on a shared unit is the launch's straggler: 1.60 -> 1.47 ms at 60k points; dense
-                    # foregrounds lose more by two searches sharing a unit instead: no pad there)
-                    pad_kb = _GATE_PAD_KB if n_b <= _GATE_PAD_MAX_N else 0
-                    idx, gate, first_ready = pointops.furthest_point_sampling_gated(
-                        xyz_b, npoint_sa, nq, lds_pad=pad_kb * 1024, prepared=self.__dict__.pop("_gf_gate_prep", None))
-                    first = idx
-                    src = idx[0, :nq]
-                    self._gf_last_gate = gate
-                else:
-                    first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
-                    src = first[0, :nq].contiguous()
-                    first_ready = torch.cuda.Event()
-                    first_ready.record(sb)
-                    # the rest of the sampling is the stretch's long pole: queued right behind the first picks, before the
-                    # host spends ~60 us on everything below (the stream idled that long between the two launches)
-                    idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+                first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
+                src = first[0, :nq].contiguous()
+                first_ready = torch.cuda.Event()
+                first_ready.record(sb)
+                # the rest of the sampling is the stretch's long pole: queued right behind the first picks, before the
+                # host spends ~60 us on everything below (the stream idled that long between the two launches)
+                idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
                 fps_done = torch.cuda.Event()
                 fps_done.record(sb)
                 fps_done_evs.append(fps_done)
-                picks_ready = fps_done if gated else first_ready  # for readers of the picks outside the gated kernel
+                picks_ready = first_ready
             if early is not None and b == 0:
                 # work of the caller that does not depend on the sampling (early() -> (.., .., kNN graphs)): queued on
                 # the third stream now that the first sampling launch is out
@@ -711,28 +671,17 @@ class GeoFormer(nn.Module):
                     grid_done.record(aux)
                 grid = (grid, grid_done)
             # (the BFS waits for the query picks only -- not for the rest of the sampling queued behind them)
-            if bfs_batched:
-                # a training batch: the scenes' searches go out together, as ONE multi-source search (below)
-                g = None
-                bfs_pending.append((b, src, first_ready))
-            else:
-                side_b.wait_event(first_ready)
-                with torch.cuda.stream(side_b):
-                    D, I, deg = graphs[b][:3]
-                    if gate is not None:
-                        g = pointops.geodesic_bfs_gated(D, I, src, 0.05, max_step, gate, nq, wg_threads=_BFS_WG or _GATE_WG,
-                                                        lds_cap=_GATE_LDS_KB * 1024)
-                        self._post_gate_flag(gate, _stream_key_of(locs_float_.device, main))
-                    elif bfs_ms_scene:
-                        g = pointops.geodesic_bfs_ms(D, I, src, 0.05, max_step)
-                    else:
-                        g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step, wg_threads=_bfs_wg(int(src.shape[0]), 1 if bfs_one_stream else batch_size) if split else 1024)
-                    g.record_stream(main)
-                    src.record_stream(side_b)
-                    geo[b] = g
-                    ev = torch.cuda.Event()
-                    ev.record(side_b)
-                    geo_ready[b] = ev
+            side_b.wait_event(first_ready)
+            with torch.cuda.stream(side_b):
+                D, I, deg = graphs[b][:3]
+                g = pointops.geodesic_bfs(D, I, deg, src, 0.05, max_step,
+                                          wg_threads=_bfs_wg(int(src.shape[0]), batch_size) if split else 1024)
+                g.record_stream(main)
+                src.record_stream(side_b)
+                geo[b] = g
+                ev = torch.cuda.Event()
+                ev.record(side_b)
+                geo_ready[b] = ev
             if multi:
                 for t in (xyz_b, idx, first, sampling_indices):
                     if t is not None:
@@ -745,22 +694,6 @@ class GeoFormer(nn.Module):
             # small launches that only need the distances / the query picks ride beside the sampling instead of
             # sitting between the decoder and the mask head on the main stream
             self._side_epilogue(b, batch_size, g, xyz_b, src, pc_dims, main, side, aux, picks_ready)
-        if bfs_pending:
-            # all scenes of the batch as one multi-source search (csrc/geodesic_ms.hip: the queries are bit lanes, a hop
-            # is one launch whatever the number of vertices): 128 hops x ~11 us for four scenes against four per-query
-            # launches of ~5 ms each that fight for the compute units
-            for _, _, ev in bfs_pending:
-                side.wait_event(ev)
-            with torch.cuda.stream(side):
-                gs = pointops.geodesic_bfs_ms_batch([graphs[b][:2] for b, _, _ in bfs_pending],
-                                                    [sr for _, sr, _ in bfs_pending], 0.05, max_step)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                for (b, sr, _), g in zip(bfs_pending, gs):
-                    g.record_stream(main)
-                    sr.record_stream(side)
-                    geo[b] = g
-                    geo_ready[b] = ev
         for sb in scene_streams:
             main.wait_stream(sb)
         # (the sampled features are only read after the sampling: gathered here, off the path to its first launch)
@@ -822,33 +755,6 @@ class GeoFormer(nn.Module):
                     ev = torch.cuda.Event()
                     ev.record(aux)
                     early["qpos"] = (q_locs, qpos, ev)
-
-    def _post_gate_flag(self, gate, key):
-        """(on the search's stream, behind the gated search) the search's time-out word to a pinned host word of the
-        CALLER's stream `key`, without a wait: the next forward -- or check_gate() -- looks at it."""
-        flags = self.__dict__.setdefault("_gf_gate_flags", {})
-        host = flags.get(key)
-        if host is None:
-            host = flags[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
-        host.copy_(gate[2:3], non_blocking=True)
-
-    def _check_gate_flag(self):
-        """The previous gated forward on this stream: did a search workgroup give up waiting for its source?  (Its copy
-        of the flag completed before that forward's last read-back; a host read, no device wait.)"""
-        host = self.__dict__.get("_gf_gate_flags", {}).get(_stream_key())
-        if host is not None and int(host[0]) != 0:
-            host.zero_()
-            raise RuntimeError("geodesic search: a workgroup of the previous forward's gated search timed out waiting for "
-                               "the sampling launch beside it (its distances are invalid); GF_BFS_GATE=0 disables the gated form")
-
-    def check_gate(self):
-        """True unless a search workgroup of the last gated sampling / search pair gave up waiting for its source (one
-        second: the sampling launch beside it never published the picks).  Synchronises; for tests and the end of a run."""
-        gate = self.__dict__.get("_gf_last_gate")
-        if gate is None:
-            return True
-        torch.cuda.synchronize(gate.device)
-        return int(gate[2].item()) == 0
 
     def _early(self):
         """Results computed beside the BFS for the forward running on the CALLER's stream (per-stream dict)."""
@@ -912,8 +818,6 @@ class GeoFormer(nn.Module):
                 # (built by the decoder after its first token stage is queued: the join with the BFS stream sits there)
                 rel = LazyRelPos(lambda: self.relative_position_embedding(context_locs, query_locs, pc_dims, geo_dists,
                                                                           pre_enc_inds))
-                if os.environ.get("GF_LAZY_RELPOS", "1") == "0":  # dev knob: the join in front of the decoder's first stage
-                    rel = rel.get()
                 hit = self._early().pop("qpos", None)  # computed beside the BFS on the third stream (own event)
                 if hit is not None and hit[0].shape == query_locs.shape:
                     torch.cuda.current_stream().wait_event(hit[2])
@@ -1172,10 +1076,6 @@ class GeoFormer(nn.Module):
             if backbone_done is not None:
                 backbone_done.record()
             yield backbone_done
-        if fused_fg and _BFS_GATE and batch_size == 1 and locs_float.is_cuda and not training and cfg.n_query_points > 224:
-            self._check_gate_flag()
-            # (the gated sampling launch's buffers and reset, queued while the host has nothing else to do)
-            self._gf_gate_prep = pointops.fps_gated_prepare(locs_float.device, self.set_aggregator.npoint)
         if fused_fg:
             fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = fg_pending.get()
         else:

@@ -150,63 +150,6 @@ def furthest_point_sampling(xyz, m, known=None):
     return idx
 
 
-def fps_gated_prepare(device, m):
-    """Everything of furthest_point_sampling_gated that needs neither the points nor their number: output, scratch, the
-    scratch's reset (queued on the current stream) and the event the waiter orders itself behind.  A forward calls this
-    BEFORE it blocks on the foreground count, so that between the host's draw and the sampling launch -- the device idles
-    there -- only the launch itself is left."""
-    lib = _lib.load()
-    idx = torch.empty((1, int(m)), dtype=torch.int32, device=device)
-    ws = torch.empty(lib.gf_fps_scratch_bytes(1) // 8 + 1, dtype=torch.int64, device=device)
-    check(lib.gf_fps_scratch_reset(ptr(ws), 1, stream_ptr()), "gf_fps_scratch_reset")
-    reset_event = torch.cuda.Event()
-    reset_event.record()
-    off = (int(lib.gf_fps_gate_word(ptr(ws), 1)) - ws.data_ptr()) // 4
-    return idx, ws, ws.view(torch.int32)[off:off + 4], reset_event
-
-
-def furthest_point_sampling_gated(xyz, m, gate_at, lds_pad=88 * 1024, prepared=None):
-    """One sampling launch over ONE point set [1,n,3] that tells a kernel running beside it when its first `gate_at`
-    picks are stored (gf_furthest_point_sampling_gated).  Returns (idx int32 [1,m], gate int32 [4] -- a view into the
-    launch's scratch: gate[0] = picks published, gate[2] = the waiter's time-out flag --, reset_event): the waiter's
-    stream waits for `reset_event` (the gate is zero from there on), NOT for the launch, and hands `gate` to
-    geodesic_bfs_gated.  lds_pad: LDS the sampling workgroups claim so that the waiter's workgroups stay off their
-    compute units.  prepared: the result of fps_gated_prepare(device, m) on this stream (else made here)."""
-    _f32c(xyz, "xyz")
-    b, n, _ = xyz.shape
-    if b != 1:
-        raise RuntimeError("furthest_point_sampling_gated: one point set")
-    if prepared is None or prepared[0].shape[1] != m or prepared[0].device != xyz.device:
-        prepared = fps_gated_prepare(xyz.device, m)
-    idx, ws, gate, reset_event = prepared
-    check(_lib.load().gf_furthest_point_sampling_gated(ptr(xyz), n, m, ptr(idx), ptr(ws), int(gate_at), int(lds_pad),
-                                                       stream_ptr()), "gf_furthest_point_sampling_gated")
-    return idx, gate, reset_event
-
-
-def geodesic_bfs_gated(D, I, src, radius, max_step, gate, gate_at, wg_threads=512, lds_cap=0):
-    """geodesic_bfs whose sources are still being drawn by a furthest_point_sampling_gated launch on ANOTHER stream: src is
-    a view of that launch's output (its first nq picks), gate the tensor it returned.  The current stream must have
-    waited for the sampler's reset_event.  gate[2] != 0 afterwards: a workgroup gave up waiting (one second).
-    lds_cap: upper bound (bytes) of a workgroup's LDS -- 768 threads with 64 KB: two workgroups per compute unit."""
-    _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
-    n, K = D.shape
-    nq = src.shape[0]
-    dev = D.device
-    geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
-    if nq == 0:
-        return geo
-    lib = _lib.load()
-    keys = scratch("bfs_keys", nq * n, torch.int64, dev)
-    qwords = int(lib.gf_geodesic_bfs_queue_words(n))
-    queues = scratch("bfs_queues", nq * qwords, torch.int32, dev)
-    check(lib.gf_geodesic_bfs_gated(ptr(D), ptr(I), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo), ptr(keys),
-                                    ptr(queues), qwords, int(wg_threads), int(lds_cap), gate.data_ptr(), int(gate_at),
-                                    gate.data_ptr() + 8, stream_ptr()), "gf_geodesic_bfs_gated")
-    gate.record_stream(torch.cuda.current_stream(dev))
-    return geo
-
-
 def select_foreground(scores, cls, equal, locs, batch_idxs, feats, feat_rows=None, deferred=False):
     """Fused foreground selection (csrc/foreground.hip): points whose arg-max class is >= cls (== cls with `equal`).
     Returns (fg_idxs int64 [n], locs_ [n,3], batch_idxs_ int32 [n], feats_ [n,F], scores_ [n,C]) -- views of
@@ -354,8 +297,6 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
     n, K = D.shape
     nq = src.shape[0]
-    if os.environ.get("GF_BFS_MS", "0") == "1" and nq >= 32 and n >= int(os.environ.get("GF_BFS_MS_MIN_N", "0")):
-        return geodesic_bfs_ms(D, I, src, radius, max_step)
     dev = D.device
     geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
     lib = _lib.load()
@@ -368,70 +309,11 @@ def geodesic_bfs(D, I, deg, src, radius, max_step, wg_threads=1024):
     return geo
 
 
-def geodesic_bfs_ms(D, I, src, radius, max_step, xyz=None, return_flag=False):
-    """geo [nq,n] fp32 like geodesic_bfs, by the multi-source search (csrc/geodesic_ms.hip: every query a bit lane, one
-    launch per hop over the whole device; bit-identical results).  xyz [n,3] (optional): the vertices' coordinates --
-    the search then works in a spatial order with the tile form of the hop."""
-    _f32c(D, "D"); _i32c(I, "I"); _i32c(src, "src")
-    if xyz is not None:
-        _f32c(xyz, "xyz")
-    n, K = D.shape
-    nq = src.shape[0]
-    dev = D.device
-    geo = torch.empty((nq, n), dtype=torch.float32, device=dev)
-    if nq == 0 or n == 0:
-        return geo
-    lib = _lib.load()
-    nbytes = int(lib.gf_geodesic_ms_scratch_bytes(n, K, nq, int(max_step)))
-    ws = scratch("bfs_ms", nbytes // 8 + 64, torch.int64, dev)
-    base = (ws.data_ptr() + 255) & ~255
-    check(lib.gf_geodesic_bfs_ms(ptr(D), ptr(I), ptr(xyz), n, K, ptr(src), nq, float(radius), int(max_step), ptr(geo),
-                                 base, nbytes, stream_ptr()), "gf_geodesic_bfs_ms")
-    if return_flag:
-        # (the one-launch form's time-out word: int32 [1] view into the scratch, valid until the next call on this stream)
-        off = (int(lib.gf_geodesic_ms_error_flag(base, n, K, nq, int(max_step))) - ws.data_ptr()) // 4
-        return geo, ws.view(torch.int32)[off:off + 1]
-    return geo
-
-
-def geodesic_bfs_ms_batch(graphs, srcs, radius, max_step):
-    """The multi-source search over several scenes at once (a training batch): graphs = [(D_b [n_b,K], I_b [n_b,K]), ...],
-    srcs = [int32 [nq], ...] local vertex ids.  Returns [geo_b fp32 [nq, n_b], ...].  One hop launch serves all scenes:
-    the search's cost is per hop, not per vertex."""
-    import ctypes
-
-    import numpy as np
-
-    nb = len(graphs)
-    K = graphs[0][0].shape[1]
-    nq = srcs[0].shape[0]
-    dev = graphs[0][0].device
-    sizes = [int(g[0].shape[0]) for g in graphs]
-    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
-    n = int(offs[-1])
-    geos = [torch.empty((nq, s), dtype=torch.float32, device=dev) for s in sizes]
-    if n == 0 or nq == 0:
-        return geos
-    D = torch.cat([g[0] for g in graphs])
-    I = torch.cat([torch.where(g[1] >= 0, g[1] + int(offs[b]), g[1]) for b, g in enumerate(graphs)])
-    src = torch.stack([s.int() + int(offs[b]) for b, s in enumerate(srcs)]).contiguous()
-    lib = _lib.load()
-    nbytes = int(lib.gf_geodesic_ms_scratch_bytes(n, K, nq, int(max_step)))
-    ws = scratch("bfs_ms", nbytes // 8 + 64, torch.int64, dev)
-    base = (ws.data_ptr() + 255) & ~255
-    gp = (ctypes.c_void_p * nb)(*[g.data_ptr() for g in geos])
-    check(lib.gf_geodesic_bfs_ms_sets(ptr(D), ptr(I), n, K, ptr(src), nq, nb, offs.ctypes.data, ctypes.cast(gp, ctypes.c_void_p),
-                                      float(radius), int(max_step), base, nbytes, stream_ptr()), "gf_geodesic_bfs_ms_sets")
-    for t in (D, I, src):
-        t.record_stream(torch.cuda.current_stream(dev))
-    return geos
-
-
 # ---- fused heads -------------------------------------------------------------------------
 def _mask_head_split_ws(N, device, split):
     """Scratch for the features' three bf16 pieces (gf_mask_head_episodes: fp32-accurate products on the bf16 matrix
-    pipe); split=False keeps the fp32 MFMA (GF_MASK_HEAD_SPLIT=0: dev knob for A/B runs)."""
-    if not split or os.environ.get("GF_MASK_HEAD_SPLIT", "1") == "0":
+    pipe); split=False keeps the fp32 MFMA."""
+    if not split:
         return None
     return scratch("mask_head_split", _lib.load().gf_mask_head_split_bytes(N) // 8 + 1, torch.int64, device)
 

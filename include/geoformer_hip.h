@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GF_ABI_VERSION 4
+#define GF_ABI_VERSION 5
 
 typedef enum {
     GF_OK = 0,
@@ -415,20 +415,6 @@ int gf_furthest_point_sampling(const float* xyz, int b, int n, int m, int32_t* i
  * needs 256 of 2048) start while the rest is still being drawn. */
 int gf_furthest_point_sampling_resume(const float* xyz, int b, int n, int m, int m_known, int32_t* idxs,
                                       void* scratch, void* stream);
-/* One launch with a GATE (one point set; ABI 4): workgroup 0 publishes gate[0] = number of picks stored -- agent scope,
- * behind a release fence -- the first time that number reaches gate_at, and again at the end.  A kernel launched beside
- * this one that needs the first gate_at picks only (gf_geodesic_bfs_gated: 256 of 2048) waits for the word instead of for
- * the launch; idxs is then read with agent-scope loads.  Protocol:
- *     gf_fps_scratch_reset(scratch, 1, stream);   <- zeroes the scratch incl. the gate; record an event HERE and let the
- *                                                    waiter's stream wait for it (not for the sampling launch)
- *     gf_furthest_point_sampling_gated(...);      <- does NOT zero the scratch
- * gf_fps_gate_word(scratch, 1) -> int* w inside the scratch: w[0] the gate, w[2] a word for the waiter's time-out flag.
- * lds_pad_bytes: dynamic LDS every sampling workgroup claims without using it, so that workgroups of the waiting kernel
- * cannot become co-resident on the sampler's compute units (the search is 20-30 % slower on a shared unit); 0 = none. */
-int gf_fps_scratch_reset(void* scratch, int b, void* stream);
-int* gf_fps_gate_word(void* scratch, int b);
-int gf_furthest_point_sampling_gated(const float* xyz, int n, int m, int32_t* idxs, void* scratch, int gate_at,
-                                     int lds_pad_bytes, void* stream);
 
 /* ===================================================================================
  * Geodesic stage (model/geoformer/geodesic_utils.py)
@@ -457,42 +443,11 @@ int gf_geodesic_bfs(const float* D, const int32_t* I, const int32_t* deg, int n,
 /* Same, with the workgroup size per query chosen by the caller: wg_threads = 1024 (one query per compute unit,
  * fastest when the launch has the device to itself), 512 or 256 (several queries share a compute unit, so the
  * launch fits beside another resident kernel -- the host runs it next to furthest point sampling).
- * queue_words: int32 words of queue_ws per query as allocated (>= gf_geodesic_bfs_queue_words(n) of the moment of the
- * allocation; checked: at least 4 n, and the pipelined kernel is only chosen when 10 n are there).  (ABI 3.) */
+ * queue_words: int32 words of queue_ws per query as allocated (checked: at least gf_geodesic_bfs_queue_words(n) = 4 n).
+ * (ABI 3.) */
 int gf_geodesic_bfs_cfg(const float* D, const int32_t* I, const int32_t* deg, int n, int K, const int32_t* src, int nq,
                         float radius, int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words,
                         int wg_threads, void* stream);
-/* The search launched BESIDE the sampling launch that is still drawing its sources (gf_furthest_point_sampling_gated;
- * ABI 4): src points into that launch's output; every workgroup initialises its rows, then waits -- bounded: one second,
- * then gate_err[0] = 1 and the search runs on whatever the slot holds -- until gate[0] >= gate_at and reads its source
- * with an agent-scope load.  Zero gate_err before the launch.  LDS-resident kernel only (n <= 2^19, K % 4 == 0).
- * lds_cap_bytes: upper bound of a workgroup's LDS (0: wg_threads' share of 150 KB): with 768 threads and 64 KB two
- * workgroups share a compute unit, so 256 queries fit the 240 units the sampler leaves free in one round. */
-int gf_geodesic_bfs_gated(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, float radius,
-                          int max_step, float* geo, void* keys_ws, void* queue_ws, size_t queue_words, int wg_threads,
-                          int lds_cap_bytes, const int* gate, int gate_at, int* gate_err, void* stream);
-
-/* The same search for ALL nq sources at once (csrc/geodesic_ms.hip): the queries are bit lanes of per-vertex frontier /
- * visited masks, a hop is ONE launch over every (vertex, mask word) that walks the vertex's in-neighbours in ascending
- * (parent, rank) order -- the first one whose frontier bit is set is the entry cal_geodesic_vectorize keeps
- * (geodesic_utils.py:131-136) -- so results are bit-identical to gf_geodesic_bfs; rows need not be sorted by distance.
- *   D fp32 [n,K], I int32 [n,K] (column 0 skipped), src int32 [nq], geo fp32 [nq,n] out
- *   xyz fp32 [n,3] or NULL: with the coordinates the search works in a spatial (Morton) order of the vertices and a hop is
- *   one workgroup per tile of 256 neighbouring vertices with the parents' mask words staged in LDS (same results)
- *   scratch: gf_geodesic_ms_scratch_bytes(n, K, nq, max_step) bytes, 256-byte aligned; scratch_bytes is checked. */
-size_t gf_geodesic_ms_scratch_bytes(int n, int K, int nq, int max_step);
-/* Several graphs that do not touch (the scenes of a batch) in one search: D / I = the scenes' rows concatenated, I holding
- * GLOBAL vertex ids; src int32 [nsets][nq] global ids (bit q has one source per set); set_off HOST int32 [nsets + 1];
- * geos HOST array of nsets device pointers, geos[k] fp32 [nq][set_off[k+1] - set_off[k]].  Scratch as for n vertices. */
-int gf_geodesic_bfs_ms_sets(const float* D, const int32_t* I, int n, int K, const int32_t* src, int nq, int nsets,
-                            const int32_t* set_off, float* const* geos, float radius, int max_step, void* scratch,
-                            size_t scratch_bytes, void* stream);
-/* Device word inside `scratch` that the one-launch form of the search (GF_BFS_MS_PERSIST) sets to 1 when one of its
- * bounded waits timed out (a workgroup never became resident): the distances of that call are then invalid. */
-const int32_t* gf_geodesic_ms_error_flag(void* scratch, int n, int K, int nq, int max_step);
-int gf_geodesic_bfs_ms(const float* D, const int32_t* I, const float* xyz, int n, int K, const int32_t* src, int nq,
-                       float radius, int max_step, float* geo, void* scratch, size_t scratch_bytes, void* stream);
-
 /* ===================================================================================
  * Mask head (GeoFormer.mask_heads_forward, model/geoformer/geoformer.py:286-324), fused
  * =================================================================================== */

@@ -57,10 +57,6 @@ int gf_dev_conv_g16p_wpb(int wpb);
  * 4 strided, 5 inverse), K, Cin, Cout, M_in, M_out, residual epilogue (0/1), rules (-1 when not counted);
  * us[i] = microseconds between the two events. */
 int gf_dev_unet_probe(int mode);
-/* The deep U-Net levels of gf_unet_fwd as persistent chain launches (k_conv_chain: a grid barrier between layers instead of a
- * launch) or one launch per convolution (default: the chains measured 0.08 ms slower per forward): 1 / 0, -1 = default /
- * GF_UNET_CHAIN.  Identical sums either way. */
-int gf_dev_unet_chain(int on);
 int gf_dev_unet_probe_read(int max_records, int* meta, float* us);
 /* The same plus, in mode 1, the launch's duration by two events BOUND TO THE KERNEL (hipExtLaunchKernelGGL: the
  * dispatch's own begin / end timestamps -- what a profiler's kernel trace reports), -1 where the launch did not take
@@ -91,27 +87,9 @@ int gf_dev_event_elapsed_us(void* start, void* stop, float* us);
  * GF_CROSS_ATTN_BF3. */
 int gf_dev_cross_attn_bf3(int on);
 
-/* Geodesic BFS kernel choice: 1 = distances pipelined two hops behind the level search (k_geodesic_bfs_pipe),
- * 0 = read back and re-bid per hop (k_geodesic_bfs_lds, the default), -1 = default / GF_BFS_PIPE.  Results are identical. */
-int gf_dev_bfs_pipe(int on);
 /* Upper bound of the BFS kernels' LDS queue capacity (entries per level, >= 64; 0 = what the LDS share allows): tests
  * set it so that scene-sized graphs exercise the queues' overflow into global memory. */
 int gf_dev_bfs_qcap_max(int qcap);
-/* Form of the multi-source search's hop (gf_geodesic_bfs_ms): 1 = LDS tiles (k_ms_hop_tile), 0 = plain gather
- * (k_ms_hop, default), -1 = default / GF_BFS_MS_TILES.  Results are identical. */
-int gf_dev_bfs_ms_tiles(int on);
-/* 1 = the whole multi-source search as ONE launch of resident tile workgroups that exchange their rows through memory
- * (k_ms_persist; needs the coordinates), 0 = one launch per hop (default), -1 = default / GF_BFS_MS_PERSIST. */
-int gf_dev_bfs_ms_persist(int on);
-/* bytes of dynamic LDS every sampling (k_fps) workgroup claims without using them: keeps workgroups of other kernels that
-   need more than the remainder of the 160 KB off the sampler's compute units (also GF_FPS_LDS_PAD, read once) */
-int gf_dev_fps_lds_pad(int bytes);
-/* upper bound (bytes, 0 = none) of the LDS a geodesic-search workgroup takes: 79 KB lets two 768-thread workgroups share a
-   compute unit (also GF_BFS_LDS_CAP, read once) */
-int gf_dev_bfs_lds_cap(int bytes);
-
-/* hipOccupancyMaxActiveBlocksPerMultiprocessor of the LDS-weight kernel at `block` threads (tools/conv_block_sweep.py). */
-int gf_dev_conv_occupancy(int block);
 
 #ifdef __cplusplus
 }

@@ -183,7 +183,7 @@ def test_down_up_full_size(oracle, s150k, hip):
     assert np.abs(got - oracle.conv_fwd(f2, W2, nbr2, oc.shape[0])).max() < 1e-4
 
 
-KNOBS = [dict(split=0, pair=1, g16=0), dict(split=0, pair=0, g16=0), dict(split=0, pair=0, ldsw=1, g16=0),
+KNOBS = [dict(split=0, pair=1, g16=0), dict(split=0, pair=0, g16=0),
          dict(split=1, wide=0, g16=0), dict(split=1, wide=1, g16=0), dict(split=0, pair=0, block=64, g16=0),
          dict(split=0, pair=0, block=128, g16=0),
          # the counted-loop kernels over the step table (16 output channels, Cin 16 / 32 only; other widths fall
@@ -281,14 +281,11 @@ def test_bfs_large_scenes(hip, oracle, n, nq, wg):
     assert (geo >= 0).sum(1).max() > n // 20  # the walk really spreads (not a trivially empty frontier)
 
 
-@pytest.mark.parametrize("pipe", [1, 0], ids=["pipelined-distances", "read-back-per-hop"])
 @pytest.mark.parametrize("wg,qcap", [(512, 0), (1024, 0), (512, 300), (1024, 64)])
-def test_bfs_kernels_queue_overflow_and_long_rings(hip, oracle, pipe, wg, qcap):
-    """Both LDS-resident kernels (k_geodesic_bfs_pipe: distances pipelined two hops behind the level search, round 4;
-    k_geodesic_bfs_lds) on a 90 000-point foreground against the oracle, bit for bit, with the LDS queue capacity as
-    the launch derives it and cut to 300 / 64 entries (gf_dev_bfs_qcap_max): rings of up to ~2 000 vertices then live
-    mostly in the global overflow, and -- at 512 threads per query -- reach past the SE * THREADS entries whose
-    distance pipeline a lane holds in registers (the blocking slow path through the query's scratch)."""
+def test_bfs_kernels_queue_overflow_and_long_rings(hip, oracle, wg, qcap):
+    """The LDS-resident search (k_geodesic_bfs_lds) on a 90 000-point foreground against the oracle, bit for bit, with the
+    LDS queue capacity as the launch derives it and cut to 300 / 64 entries (gf_dev_bfs_qcap_max): rings of up to ~2 000
+    vertices then live mostly in the global overflow."""
     from geoformer_amd import _lib, pointops
 
     lib = _lib.load()
@@ -298,13 +295,11 @@ def test_bfs_kernels_queue_overflow_and_long_rings(hip, oracle, pipe, wg, qcap):
     D, I = gd.cpu().numpy(), gi.cpu().numpy()
     src = np.random.default_rng(3).integers(0, n, 10)
     ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, 0.05, 256)
-    lib.gf_dev_bfs_pipe(pipe)
     lib.gf_dev_bfs_qcap_max(qcap)
     try:
         geo = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), 0.05, 256, wg_threads=wg).cpu().numpy()
         short = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), 0.05, 7, wg_threads=wg).cpu().numpy()
     finally:
-        lib.gf_dev_bfs_pipe(-1)
         lib.gf_dev_bfs_qcap_max(0)
     assert (geo == ref).all()
     assert (short == oracle.geodesic(D[:, 1:], I[:, 1:], src, 0.05, 7)).all()  # the max_step cut with levels in flight
@@ -456,8 +451,13 @@ def test_forward_s150k_calibrated_weights_hold_1e4_absolute(hip, oracle, s150k):
     _, batch, _, _ = s150k
     state, _ = calibrated_benchmark_state(batch)
 
+    seen = []
+
     def close_abs(got, ref):
-        return float(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).max()) < 1e-4
+        d = float(np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64)).max())
+        seen.append(d)
+        assert d < 1e-4, ("stage maxima so far", seen)
+        return True
 
     info = _forward_gpu_against_host(s150k, close_abs, state=state)
     print("calibrated S150k forward:", info)

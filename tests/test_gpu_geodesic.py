@@ -126,152 +126,3 @@ def test_bfs_duplicates_short_walks_and_dense_ball(hip, oracle):
     geo = geo.cpu().numpy()
     assert (geo[:, off:off + 9000] == ref).all()
     assert (geo[:, :off] == -1).all() and (geo[:, off + 9000:] == -1).all()
-
-
-def _ms_forms(lib):
-    """Both forms of the multi-source hop: the plain gather (default) and LDS tiles (GF_BFS_MS_TILES=1)."""
-    lib.gf_dev_bfs_ms_tiles.argtypes = [__import__("ctypes").c_int]
-    for tiles in (1, 0):
-        lib.gf_dev_bfs_ms_tiles(tiles)
-        yield tiles
-    lib.gf_dev_bfs_ms_tiles(-1)
-
-
-@pytest.mark.parametrize("n,nq,max_step", [(6000, 16, 256), (20000, 64, 128), (20000, 100, 40), (20000, 128, 5),
-                                           (12000, 256, 256), (6000, 300, 64)])
-def test_bfs_multi_source_matches_oracle(hip, oracle, n, nq, max_step):
-    """gf_geodesic_bfs_ms (csrc/geodesic_ms.hip: all queries as bit lanes of cumulative reach masks, one launch per
-    hop) against the oracle, bit for bit, for 1..5 mask words per vertex (nq = 300 takes the runtime-width gather
-    kernel), hop limits that end the search early and late, duplicate sources, and both forms of the hop."""
-    from geoformer_amd import pointops
-
-    xyz = _pts(n, 5 + n)
-    n = xyz.shape[0]  # (the generator returns about the number of points asked for)
-    k, radius = 64, 0.05
-    D, I = _ref_graph(oracle, xyz, k, radius)
-    rng = np.random.default_rng(1)
-    src = rng.integers(0, n, nq)
-    src[-1] = src[0]  # two queries from one vertex
-    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, max_step)
-    gd, gi, deg = pointops.knn_radius(_dev(xyz), k, radius)
-    for tiles in _ms_forms(hip):
-        geo = pointops.geodesic_bfs_ms(gd, gi, _dev(src.astype(np.int32)), radius, max_step).cpu().numpy()
-        assert ((geo >= 0) == (ref >= 0)).all(), tiles
-        assert (geo == ref).all(), tiles
-    # an unsorted, unpadded table (every row the brute-force 64 nearest, beyond the radius too): rows need not be
-    # distance-sorted or radius-limited for this kernel
-    perm = rng.permutation(k - 1) + 1
-    Dp = np.ascontiguousarray(D[:, np.r_[0, perm]].astype(np.float32))
-    Ip = np.ascontiguousarray(I[:, np.r_[0, perm]].astype(np.int32))
-    ref_p = oracle.geodesic(Dp[:, 1:], Ip[:, 1:].astype(np.int64), src, radius, max_step)
-    geo = pointops.geodesic_bfs_ms(_dev(Dp), _dev(Ip), _dev(src.astype(np.int32)), radius, max_step).cpu().numpy()
-    assert (geo == ref_p).all()
-
-
-def test_bfs_multi_source_long_in_lists_and_duplicates(hip, oracle):
-    """In-lists longer than the 16 fixed-width slots (a dense cube: every vertex has ~63 in-neighbours, the rest comes
-    from the reverse CSR), 100 copies of one point, rows whose column 0 is not the vertex itself -- against the oracle,
-    both forms of the hop; and the per-query kernel on the same inputs."""
-    from geoformer_amd import pointops
-
-    k, radius = 64, 0.05
-    rng = np.random.default_rng(9)
-    xyz = (rng.random((9000, 3)) * 0.09).astype(np.float32)
-    D, I = _ref_graph(oracle, xyz, k, radius)
-    inr = D <= np.float32(radius)
-    Dm = np.where(inr, D, np.inf).astype(np.float32)
-    Im = np.where(inr, I, -1).astype(np.int32)
-    src = rng.integers(0, 9000, 70)
-    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 64)
-    for tiles in _ms_forms(hip):
-        geo = pointops.geodesic_bfs_ms(_dev(Dm), _dev(Im), _dev(src.astype(np.int32)), radius, 64).cpu().numpy()
-        assert (geo == ref).all(), tiles
-    xyz = _pts(20000, 77)
-    xyz[1000:1100] = xyz[5]
-    D, I = _ref_graph(oracle, xyz, k, radius)
-    src = rng.integers(0, xyz.shape[0], 48)
-    src[:3] = [5, 1003, 1099]
-    ref = oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 256)
-    gd, gi, deg = pointops.knn_radius(_dev(xyz), k, radius)
-    for tiles in _ms_forms(hip):
-        geo = pointops.geodesic_bfs_ms(gd, gi, _dev(src.astype(np.int32)), radius, 256).cpu().numpy()
-        assert (geo == ref).all(), tiles
-    old = pointops.geodesic_bfs(gd, gi, deg, _dev(src.astype(np.int32)), radius, 256, wg_threads=512).cpu().numpy()
-    assert (old == ref).all()
-
-
-def test_bfs_multi_source_one_launch_and_batched_scenes(hip, oracle):
-    """The two further forms of the multi-source search against the oracle: (i) ONE launch of resident tile workgroups
-    that exchange their rows through memory (GF_BFS_MS_PERSIST; spatial working order from the coordinates; its bounded
-    waits must not time out), (ii) several scenes searched together (gf_geodesic_bfs_ms_sets: one hop launch serves all
-    scenes of a batch)."""
-    from geoformer_amd import pointops
-
-    hip.gf_dev_bfs_ms_persist.argtypes = [__import__("ctypes").c_int]
-    k, radius = 64, 0.05
-    graphs, srcs, refs, xyzs = [], [], [], []
-    for n, nq_seed in ((20000, 3), (9000, 4), (14000, 5)):
-        xyz = _pts(n, 31 + n)
-        n = xyz.shape[0]
-        D, I = _ref_graph(oracle, xyz, k, radius)
-        src = np.random.default_rng(nq_seed).integers(0, n, 128)
-        refs.append(oracle.geodesic(D[:, 1:], I[:, 1:], src, radius, 96))
-        gd, gi, deg = pointops.knn_radius(_dev(xyz), k, radius)
-        graphs.append((gd, gi)); srcs.append(_dev(src.astype(np.int32))); xyzs.append(_dev(xyz))
-    hip.gf_dev_bfs_ms_persist(1)
-    try:
-        for (gd, gi), src, xyz, ref in zip(graphs, srcs, xyzs, refs):
-            geo, flag = pointops.geodesic_bfs_ms(gd, gi, src, radius, 96, xyz=xyz, return_flag=True)
-            assert int(flag.item()) == 0, "a wait of the one-launch search timed out"
-            assert (geo.cpu().numpy() == ref).all()
-    finally:
-        hip.gf_dev_bfs_ms_persist(-1)
-    # the Morton working order with one launch per hop (tiles)
-    geo = pointops.geodesic_bfs_ms(graphs[0][0], graphs[0][1], srcs[0], radius, 96, xyz=xyzs[0])
-    assert (geo.cpu().numpy() == refs[0]).all()
-    geos = pointops.geodesic_bfs_ms_batch(graphs, srcs, radius, 96)
-    for g, ref in zip(geos, refs):
-        assert (g.cpu().numpy() == ref).all()
-
-
-def test_gated_sampling_and_search_equal_the_two_launch_form(hip):
-    """One sampling launch with a gate + the search launched BESIDE it on a second stream (it waits for the first nq picks
-    inside the kernel) == sampling, then search.  With and without the LDS pad that keeps the search off the sampler's
-    compute units; the time-out word stays clear."""
-    import numpy as np
-    import torch
-
-    from geoformer_amd import pointops, scene
-
-    p = scene.make_scene(60_000, 77)["xyz"]
-    xyz = torch.from_numpy(np.ascontiguousarray(p[:24_000])).cuda()
-    n = xyz.shape[0]
-    gd, gi, deg = pointops.knn_radius(xyz, 64, 0.05)
-    pts = xyz[None].contiguous()
-    nq, m = 96, 512
-    ref_idx = pointops.furthest_point_sampling(pts, m)
-    ref_geo = pointops.geodesic_bfs(gd, gi, deg, ref_idx[0, :nq].contiguous(), 0.05, 64, wg_threads=512)
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    for pad in (0, 88 * 1024):
-        for wg in (512, 1024):
-            idx, gate, reset_ev = pointops.furthest_point_sampling_gated(pts, m, nq, lds_pad=pad)
-            side.wait_event(reset_ev)
-            with torch.cuda.stream(side):
-                geo = pointops.geodesic_bfs_gated(gd, gi, idx[0, :nq], 0.05, 64, gate, nq, wg_threads=wg)
-            torch.cuda.synchronize()
-            assert torch.equal(idx, ref_idx)
-            assert int(gate[0].item()) >= nq and int(gate[2].item()) == 0
-            assert torch.equal(geo, ref_geo), (pad, wg)
-        # the forward's gated shape: buffers prepared ahead, 768 threads per query, LDS capped so that two share a unit
-        prep = pointops.fps_gated_prepare(pts.device, m)
-        idx, gate, reset_ev = pointops.furthest_point_sampling_gated(pts, m, nq, lds_pad=pad, prepared=prep)
-        side.wait_event(reset_ev)
-        with torch.cuda.stream(side):
-            geo = pointops.geodesic_bfs_gated(gd, gi, idx[0, :nq], 0.05, 64, gate, nq, wg_threads=768, lds_cap=64 * 1024)
-        torch.cuda.synchronize()
-        assert torch.equal(idx, ref_idx) and int(gate[2].item()) == 0 and torch.equal(geo, ref_geo), pad
-    # a gate beyond the last pick opens at the end of the launch
-    idx, gate, reset_ev = pointops.furthest_point_sampling_gated(pts, 64, 1000)
-    torch.cuda.synchronize()
-    assert torch.equal(idx, ref_idx[:, :64]) and int(gate[0].item()) == 1000

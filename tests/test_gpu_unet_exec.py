@@ -195,38 +195,3 @@ def test_unet_train_exec_sees_reallocated_tensors_and_replaced_modules(hip):
     # (ii) SyncBatchNorm conversion AFTER a first native forward: the structural answer is not a stale cache entry
     parallel.convert_sync_batchnorm(m)
     assert not unet_train.supported(m, m.preprocess_input(batch, 1))
-
-
-@pytest.mark.parametrize("scenes", [[("small", 8192, 5)], [("small", 6000, 7), ("small", 9000, 8)], [("room", 150000, 1234)],
-                                    [("room", 90000, 41), ("room", 60000, 42)]], ids=["s8k", "batch2", "s150k", "batch2-rooms"])
-def test_unet_exec_chain_launches_equal_separate_launches(hip, scenes):
-    """The deep U-Net levels as persistent chain launches (k_conv_chain: the layers of a run as ONE launch with grid
-    barriers between them, write-through stores and L1-bypassing gathers for the hand-off, the skip concatenation read
-    from its two sources) against the same layers as separate launches: the same item code on both sides, so the
-    backbone's output must be BIT-identical -- a stale read across a grid barrier would show here.  Repeated, so that
-    buffers and counters are reused with other contents in them."""
-    from geoformer_amd import _lib, scene
-
-    lib = _lib.load()
-    m = _model()
-    mk = {"small": scene.make_small_scene, "room": scene.make_scene}
-    outs = {}
-    for rep in range(3):
-        batch = scene.make_batch([mk[k](n, s + 100 * rep) for k, n, s in scenes])
-        batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
-        for on in (0, 1, 1, 0):
-            lib.gf_dev_unet_chain(on)
-            try:
-                f, _ = _backbone(m, batch, native=True)
-                f = f[0] if isinstance(f, tuple) else f
-                torch.cuda.synchronize()
-            finally:
-                lib.gf_dev_unet_chain(-1)
-            key = (rep, on)
-            if key in outs:
-                assert torch.equal(outs[key], f), (rep, on, "not reproducible")
-            outs[key] = f.clone()
-        assert torch.equal(outs[(rep, 0)], outs[(rep, 1)]), (rep, float((outs[(rep, 0)] - outs[(rep, 1)]).abs().max()))
-    f_ref, _ = _backbone(m, batch, native=False)  # and the module route, as in test_unet_exec_matches_module_route
-    f_ref = f_ref[0] if isinstance(f_ref, tuple) else f_ref
-    assert float((outs[(2, 1)] - f_ref).abs().max()) <= 2e-6 * max(1.0, float(f_ref.abs().max()))
