@@ -242,12 +242,14 @@ def all_convs_roofline(model, batches, reps=2):
         lib.gf_dev_unet_probe(0)
     recs = _read_probe()
     us = sum(r[9] for r in recs)
-    byt = fl = 0
+    byt = fl = comp = 0
     per_level = {}
     for level, kind, K, Cin, Cout, M_in, M_out, res, R, t, _tk in recs:
         R = M_out if R < 0 else R  # 1x1x1 convs: one rule per row
         bb = _conv_bytes(R, M_out, K, Cin, Cout, bool(res))
         byt += bb
+        # SURVEY.md 8(d)'s compulsory lower bound: every input element read once, every output element written once
+        comp += 4 * (M_in * Cin + M_out * Cout)
         fl += 2 * R * Cin * Cout
         pl = per_level.setdefault(level + 1, [0, 0.0, 0])
         pl[0] += bb; pl[1] += t; pl[2] += 1
@@ -255,6 +257,8 @@ def all_convs_roofline(model, batches, reps=2):
     return {"bound": "hbm", "achieved": round(byt / (us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "convs_per_forward": len(recs) // nf,
             "us_per_forward": round(us / nf, 1), "algorithmic_bytes_per_forward": byt // nf,
+            "compulsory_bytes_per_forward": comp // nf,
+            "compulsory_frac": round(comp / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
             "gflop_per_forward": round(fl / nf / 1e9, 2), "tflops": round(fl / (us * 1e-6) / 1e12, 2),
             "by_level": {str(l): {"convs": v[2] // nf, "us": round(v[1] / nf, 1), "GB/s": round(v[0] / (v[1] * 1e-6) / 1e9, 1)}
                          for l, v in sorted(per_level.items())},
@@ -722,7 +726,9 @@ def secondary_test_py_loops(model, batches, dev, args):
     # -- fresh host batches through the feeder
     nfresh = 16
     rs = np.random.RandomState(7)
-    sizes = rs.permutation(np.linspace(0.8, 1.2, nfresh + 2) * args.points).astype(int)
+    NWARM = 4  # untimed scenes per leg: pinned buffers, allocator blocks, and -- with instances -- whatever the first real
+    # proposals pay once (the first timed step of round 5's with-instances leg took 38 ms; two warm scenes did not cover it)
+    sizes = rs.permutation(np.linspace(0.8, 1.2, nfresh + NWARM) * args.points).astype(int)
     raws = [scene.collate_raw([scene.make_scene(int(n), 7000 + j)]) for j, n in enumerate(sizes)]
     cfg_thresh = model.cfg.TEST_SCORE_THRESH
     for name, forced in (("test_py_shape", False), ("test_py_shape_with_instances", True)):
@@ -742,7 +748,7 @@ def secondary_test_py_loops(model, batches, dev, args):
         per_step = []
         try:
             for j, batch in enumerate(feeder.DeviceFeeder(raws, dev, reserve_points=int(1.3 * args.points))):
-                if j == 2:  # (two untimed scenes: the feeder's pinned buffers and the allocator's blocks exist)
+                if j == NWARM:  # (untimed scenes: the feeder's pinned buffers and the allocator's blocks exist)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                 ts = time.perf_counter()
@@ -750,7 +756,7 @@ def secondary_test_py_loops(model, batches, dev, args):
                 with torch.no_grad():
                     out = model(batch, 300, training=False)
                     n_inst = consume(out, topk=40, final_thresh=0.0) if forced else consume(out)
-                if j >= 2:
+                if j >= NWARM:
                     picked += n_inst
                     nsteps += 1
                     per_step.append(round((time.perf_counter() - ts) * 1e3, 2))
@@ -760,7 +766,8 @@ def secondary_test_py_loops(model, batches, dev, args):
             model.cfg.TEST_SCORE_THRESH = cfg_thresh
         res[name] = {
             "value": round(nsteps / e1, 3), "unit": "scenes/s", "ms_per_step": round(e1 / nsteps * 1e3, 3), "steps": nsteps,
-            "points": [int(r["locs"].shape[0]) for r in raws[2:]],
+            "ms_per_step_median": round(float(np.median(per_step)), 3) if per_step else None,
+            "points": [int(r["locs"].shape[0]) for r in raws[NWARM:]],
             "instances_picked_per_scene": round(picked / max(nsteps, 1), 1),
             "ms_forward_and_consume_per_step": per_step,
             "config": "per step: pinned host batch of a never-before-seen size -> geoformer_amd.feeder.DeviceFeeder (H2D on a "
@@ -857,8 +864,10 @@ class StageTimer:
         return {k: round(v, 3) for k, v in t.items()}
 
 
-def cpu_forward(batch, bias_shift, seed, threads):
-    """One eval forward of `batch` through the build's model on the host with the oracle's C operators."""
+def cpu_forward(batch, bias_shift, seed, threads, timed=3):
+    """Eval forwards of `batch` through the build's model on the host with the oracle's C operators: one untimed (page
+    faults, OpenMP team start-up, the oracle's lazily built tables), then `timed` timed ones.  Returns the last output, the
+    list of wall times, the stage seconds of the MEDIAN run and the OpenMP thread count actually set."""
     from oracle import cpu_backend
     from oracle import oracle as orc
 
@@ -866,17 +875,24 @@ def cpu_forward(batch, bias_shift, seed, threads):
     L = orc.lib()
     L.orc_set_threads.restype = int
     omp = int(L.orc_set_threads(threads))
+    runs = []
     with cpu_backend.installed(), torch.no_grad():
         m = build_model("cpu", bias_shift=bias_shift)
-        st = StageTimer(m)
-        try:
-            np.random.seed(seed)
-            t = time.perf_counter()
-            out = m(batch, 300, training=False)
-            dt = time.perf_counter() - t
-        finally:
-            st.close()
-    return out, dt, st.stages(), omp
+        np.random.seed(seed)
+        m(batch, 300, training=False)  # untimed
+        for _ in range(max(1, timed)):
+            st = StageTimer(m)
+            try:
+                np.random.seed(seed)
+                t = time.perf_counter()
+                out = m(batch, 300, training=False)
+                dt = time.perf_counter() - t
+            finally:
+                st.close()
+            runs.append((dt, st.stages()))
+    order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+    med = runs[order[len(order) // 2]]
+    return out, [r[0] for r in runs], med[1], omp
 
 
 def cpu_baseline_and_parity(model, batch, dev, seed=4321):
@@ -885,13 +901,14 @@ def cpu_baseline_and_parity(model, batch, dev, seed=4321):
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, int(os.environ.get("GF_CPU_BASELINE_THREADS", "64"))))
     host_batch = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
-    outc, dt, stages, omp = cpu_forward(host_batch, model._bench_bias_shift, seed, threads)
+    outc, dts, stages, omp = cpu_forward(host_batch, model._bench_bias_shift, seed, threads)
+    dt = float(np.median(dts))
     n = int(host_batch["locs"].shape[0])
     base = {"value": round(1.0 / dt, 5), "unit": "scenes/s", "cores": omp, "kind": "port",
-            "sample": f"one eval forward of benchmark scene 0 ({n} points, N_fg={int(outc['fg_idxs'].shape[0])}); "
-                      f"oracle C operators on {omp} OpenMP threads, torch modules on {torch.get_num_threads()} "
-                      f"threads ({cores} host cores); {dt:.1f} s",
-            "seconds": round(dt, 2), "stage_seconds": stages}
+            "sample": f"eval forward of benchmark scene 0 ({n} points, N_fg={int(outc['fg_idxs'].shape[0])}): one untimed, "
+                      f"then {len(dts)} timed, MEDIAN quoted; oracle C operators on {omp} OpenMP threads, torch modules on "
+                      f"{torch.get_num_threads()} threads ({cores} host cores; GF_CPU_BASELINE_THREADS sets both)",
+            "seconds": round(dt, 2), "seconds_per_run": [round(x, 2) for x in dts], "stage_seconds": stages}
     np.random.seed(seed)
     with torch.no_grad():
         outg = model(batch, 300, training=False)
@@ -1003,6 +1020,9 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+        # N ranks share one host: every rank's framework threads get their share of the cores (a forward's host side is
+        # ~2.6 ms of Python per scene; 8 ranks x the default thread pool would fight for the same cores)
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
 
     from geoformer_amd import scene, serving
 
@@ -1077,21 +1097,34 @@ def main():
     torch.cuda.synchronize()
     # the probe's event pairs go around the level-1 conv launches of every PROBE_EVERY-th timed step (two event
     # records per launch, issued by the native executor itself)
+    from geoformer_amd import _lib as _gl
+
+    _gl.host_wait_s[0] = 0.0
+    _gl.load().gf_dev_host_wait_ns(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         probe.arm(i % PROBE_EVERY == 0)
         out = step(args.warmup + i)
     loop.finish()
+    t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     probe.close()
+    # host_busy: wall time of the loop's issue phase minus the time this thread was blocked in the package's own waits
+    # (foreground count, proposals, the executor's two voxel-count read-backs): what the host itself costs per scene
+    host_busy = t_issue - _gl.host_wait_s[0] - _gl.load().gf_dev_host_wait_ns(0) * 1e-9
+    busy_all = [host_busy]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        hb = torch.zeros(world, device=dev, dtype=torch.float64)
+        hb[rank] = host_busy
+        dist.all_reduce(hb)
+        busy_all = [float(x) for x in hb.tolist()]
 
     dp = None
     if world > 1 and not args.no_secondary:
@@ -1118,7 +1151,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"S150k eval forward, batch=1 per GPU, rotating over {ns} resident scenes, "
                                    "config/test_geoformer_scannet.yaml (nq=256, nc=2048, 4 decoder layers), "
-                                   "random-init weights; " +
+                                   "random-init weights; fp32 throughout, the decoder cross-attention and the mask head "
+                                   "on the bf16 matrix pipe over the EXACT three-piece bf16 split of their fp32 operands "
+                                   "(fp32-accurate against float64: tests/test_gpu_heads.py); " +
                                    ("two scenes in flight on two streams, staggered (geoformer_amd/serving.py): scene i's "
                                     "decoder + mask head run under scene i+1's sampling / BFS stretch, scene i+1's backbone "
                                     "starts when scene i's stretch has ended; all scenes complete inside the timed region"
@@ -1127,15 +1162,35 @@ def main():
                                     "collected after scene i+1 is issued; all scenes complete inside the timed region"),
                        "points": [int(b["locs"].shape[0]) for b in batches], "voxels": Ms, "n_fg_last": n_fg,
                        "parallelism": f"replicas x{world}"},
-            "roofline": probe.result(),
+            "roofline": None,
+            "host_busy_ms_per_step": {"per_rank": [round(x / args.steps * 1e3, 3) for x in busy_all],
+                                      "threads_per_rank": torch.get_num_threads(),
+                                      "note": "wall time of the timed loop's issue phase minus the time the host thread was blocked "
+                                              "in waits (foreground count, proposals, the U-Net executor's voxel counts): the "
+                                              "Python + launch cost of a scene; N ranks share one host's cores"},
         }
-        res["roofline_convs"] = all_convs_roofline(model, batches)
-        if res["roofline"] is not None and res["roofline_convs"] is not None:
-            # the headline object is the level-1 kernel (2-3 % of device time); the FAMILY figure beside it is the one
-            # the north star's ">= 50 % of the binding roofline" is about
-            res["roofline"]["family_frac"] = res["roofline_convs"].get("frac")
-            res["roofline"]["family_note"] = ("all sparse convolutions of a forward: sum of algorithmic bytes / sum of launch "
-                                              "durations against the HBM peak (roofline_convs)")
+        l1 = probe.result()
+        fam = res["roofline_convs"] = all_convs_roofline(model, batches)
+        if l1 is not None and l1.get("traffic"):
+            # what the level-1 launch really moves at the memory side (PMC: FETCH_SIZE x 2 + WRITE_SIZE), against the same clock
+            l1["actual_hbm_frac"] = round(l1["traffic"] / (l1["us_per_launch"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        if fam is not None:
+            # the headline object is the FAMILY -- the 71 sparse convolutions of a forward, the north star's ">= 50 % of the
+            # binding roofline" -- with the level-1 16 -> 16 launch (the family's best kernel, 2-3 % of device time) beside it
+            res["roofline"] = {
+                "bound": "hbm", "achieved": fam["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fam["frac"],
+                "traffic": None,
+                "traffic_note": "no PMC pass covers all 71 launches; level1_16to16.traffic is the level-1 launch's",
+                "kernel": "the sparse-convolution family: all 71 launches of a forward (k_conv_g16p / k_conv_lw / k_conv_os / "
+                          "k_conv_flat / k_conv_pair), sum of SURVEY 8(d) algorithmic bytes / sum of launch durations "
+                          "(events around every launch, untimed extra passes: roofline_convs)",
+                "us_per_forward": fam["us_per_forward"], "algorithmic_bytes": fam["algorithmic_bytes_per_forward"],
+                "compulsory_bytes": fam["compulsory_bytes_per_forward"], "compulsory_frac": fam["compulsory_frac"],
+                "compulsory_note": "4 (M_in Cin + M_out Cout) per launch: every element read / written once (SURVEY 8d)",
+                "level1_16to16": l1,
+            }
+        else:
+            res["roofline"] = l1
         res.update(op_rooflines(model, batches))
         if dp is not None:
             res.setdefault("secondary", {})["train_dp_step"] = dp

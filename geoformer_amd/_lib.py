@@ -60,6 +60,7 @@ def _declare(lib):
         "gf_pair_losses_bwd": (I, [P, P, P, P, I, I, I, P, P, P, P]),
         "gf_unet_ws_bytes": (c_size_t, [P, I, I, I, I, I]),
         "gf_dev_unet_probe": (I, [I]),
+        "gf_dev_host_wait_ns": (ctypes.c_ulonglong, [I]),
         "gf_dev_unet_probe_read": (I, [I, P, P]),
         "gf_dev_unet_probe_read2": (I, [I, P, P, P]),
         "gf_dev_conv_kernel_events": (I, [P, P]),
@@ -222,6 +223,19 @@ def check(status: int, what: str = ""):
     if status != 0:
         msg = load().gf_last_error()
         raise GeoFormerHipError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+# seconds the host has spent blocked in the package's own Python-level waits (per process; bench.py's host_busy figure)
+host_wait_s = [0.0]
+
+
+def timed_wait(event):
+    """event.synchronize() with its wall time added to host_wait_s."""
+    import time
+
+    t = time.perf_counter()
+    event.synchronize()
+    host_wait_s[0] += time.perf_counter() - t
 
 
 def ptr(t):

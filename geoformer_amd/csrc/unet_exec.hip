@@ -13,6 +13,7 @@
 //   * one host wait for the chain's voxel counts (an event behind an async copy into pinned memory), taken after
 //     the level-1 work has been queued,
 //   * the output BatchNorm + ReLU in the epilogue of the last convolution.
+#include <time.h>
 #include <vector>
 
 #include "common.h"
@@ -72,6 +73,17 @@ struct EvPair {
     hipEvent_t fork = nullptr, chain = nullptr, chain2 = nullptr, rules = nullptr, tbl0 = nullptr, flat0 = nullptr, tbl1 = nullptr, flat1 = nullptr;
 };
 thread_local EvPair t_ev;
+// nanoseconds this host thread spent blocked in the executor's own waits (gf_dev_host_wait_ns: bench.py's host_busy figure)
+thread_local unsigned long long t_wait_ns = 0;
+struct WaitClock {
+    timespec t0;
+    WaitClock() { clock_gettime(CLOCK_MONOTONIC, &t0); }
+    ~WaitClock() {
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        t_wait_ns += (unsigned long long)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+    }
+};
 
 constexpr int kStepsMinRows = 6000 * 16;  // gf_conv_fwd takes the counted-loop kernel from 6000 groups up
 constexpr int kFlatMinRows = 1500 * 16;   // gf_conv_fwd_flat takes the LDS-weight kernel from 1500 groups up (spconv_lw.hip)
@@ -136,6 +148,12 @@ struct Probe {
 thread_local Probe t_probe;
 constexpr int kProbeSlots = 4096;
 }  // namespace
+
+extern "C" unsigned long long gf_dev_host_wait_ns(int reset) {
+    const unsigned long long v = t_wait_ns;
+    if (reset) t_wait_ns = 0;
+    return v;
+}
 
 extern "C" int gf_dev_unet_probe(int mode) {
     GF_CHECK_ARG(mode >= 0 && mode <= 3, "gf_dev_unet_probe: mode %d (0 off, 1 / 3 level-1 block convs, 2 every conv)", mode);
@@ -564,7 +582,10 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         // first host wait -- the hand-over serves another scene's read-back, which must not sit behind a wait for THIS
         // scene's rulebooks (they crawl beside that scene's convolutions) -- then phase B behind the events it returns
         UN_TRY(hand_over(st));
-        GF_TRY(hipEventSynchronize(t_ev.chain));  // host wait 1: voxel count of the second level
+        {
+            WaitClock wc;
+            GF_TRY(hipEventSynchronize(t_ev.chain));  // host wait 1: voxel count of the second level
+        }
         UN_TRY(take_counts(1, 1));
         // main stream: second level's table, the first strided conv and that level's two blocks -- ~0.18 ms of device
         // work that needs nothing from the rest of the chain
@@ -576,7 +597,10 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     }
     UN_TRY(hand_over(st));  // (a single-level net: here)
     if (nl > 1) {
-        GF_TRY(hipEventSynchronize(t_ev.chain2));  // host wait 2: the levels below (the device is busy with level 2)
+        {
+            WaitClock wc;
+            GF_TRY(hipEventSynchronize(t_ev.chain2));  // host wait 2: the levels below (the device is busy with level 2)
+        }
         UN_TRY(take_counts(2, nl));
         for (int l = 2; l <= nl; l++) UN_TRY(subm_tables(l, ss));
         if (forked) {

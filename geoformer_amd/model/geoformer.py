@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 from torch.nn import functional as F
 
-from .. import pointops, spconv, unet_exec, unet_train
+from .. import _lib, pointops, spconv, unet_exec, unet_train
 from . import config as _config
 from .backbone import ResidualBlock, UBlock, conv1d_bn_relu, random_downsample
 from .layers import (BatchNorm1d, BigLinear, GenericMLP, LazyRelPos, PointwiseConv1d, PositionEmbeddingCoordsSine, RelPosSpec,
@@ -190,7 +190,7 @@ class PendingProposals:
     def get(self):
         if self.value is None:
             sel, cls, sc, logits, fg_idxs, logit_thresh, num_points = self.args
-            self.done.synchronize()
+            _lib.timed_wait(self.done)
             n, overflow = int(self.host[0]), int(self.host[1])
             with PendingProposals._lock:
                 PendingProposals._pinned.append(self.host)

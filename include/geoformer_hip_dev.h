@@ -57,6 +57,9 @@ int gf_dev_conv_g16p_wpb(int wpb);
  * 4 strided, 5 inverse), K, Cin, Cout, M_in, M_out, residual epilogue (0/1), rules (-1 when not counted);
  * us[i] = microseconds between the two events. */
 int gf_dev_unet_probe(int mode);
+/* Nanoseconds the calling host thread has spent blocked inside gf_unet_fwd's own waits (the two voxel-count read-backs)
+ * since the last reset: bench.py subtracts them (and the Python-side waits) from the loop's wall time -> host_busy_ms. */
+unsigned long long gf_dev_host_wait_ns(int reset);
 int gf_dev_unet_probe_read(int max_records, int* meta, float* us);
 /* The same plus, in mode 1, the launch's duration by two events BOUND TO THE KERNEL (hipExtLaunchKernelGGL: the
  * dispatch's own begin / end timestamps -- what a profiler's kernel trace reports), -1 where the launch did not take

@@ -143,6 +143,11 @@ def run(args, device, batches=None):
     if world > 1:
         dist.barrier()
     sync()
+    from geoformer_amd import _lib as _gl
+
+    wait_ns = _gl.load().gf_dev_host_wait_ns if device.type == "cuda" else (lambda reset: 0)
+    _gl.host_wait_s[0] = 0.0
+    wait_ns(1)
     t0 = time.perf_counter()
     early = 0
     loss = float("nan")
@@ -152,11 +157,20 @@ def run(args, device, batches=None):
         early += red.launched_in_backward
         if "n_fg" in info:
             n_fg.append(info["n_fg"])
+    # this rank's host share of a step: the loop's issue time minus the package's own blocking waits (N ranks share one
+    # host's cores: the first multi-GPU run reads here whether the Python side is what limits scaling)
+    host_busy = time.perf_counter() - t0 - _gl.host_wait_s[0] - wait_ns(0) * 1e-9
     sync()
     if world > 1:
         dist.barrier()
     sync()
     dt = parallel.max_over_ranks(time.perf_counter() - t0, device if device.type == "cuda" else None)
+    busy = [host_busy]
+    if world > 1:
+        hb = torch.zeros(world, dtype=torch.float64, device=device if device.type == "cuda" else "cpu")
+        hb[rank] = host_busy
+        dist.all_reduce(hb)
+        busy = [float(x) for x in hb.tolist()]
     host_ms = None
     if getattr(args, "host_split", 0):
         # untimed extra steps: when the host has queued a whole step against when the device has finished it
@@ -177,7 +191,9 @@ def run(args, device, batches=None):
             "grad_floats": red.numel(), "buckets": len(red.ranges),
             "buckets_started_inside_backward_per_step": round(early / max(args.steps, 1), 2),
             "fg_frac_target": getattr(args, "fg_frac", None), "fg_bias_shift": fg_shift,
-            "host_ms_per_step": host_ms, "n_fg_per_step": n_fg, "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}
+            "host_ms_per_step": host_ms,
+            "host_busy_ms_per_step_per_rank": [round(x / max(args.steps, 1) * 1e3, 2) for x in busy],
+            "threads_per_rank": torch.get_num_threads(), "n_fg_per_step": n_fg, "last_loss": loss, "backend": dist.get_backend() if world > 1 else "none", "data": "synthetic"}
 
 
 def default_args(**over):
@@ -217,6 +233,8 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     world = parallel.init_distributed("nccl")
+    if world > 1:  # the ranks share one host: every rank's framework threads get their share of its cores
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     res = run(args, device)
     if rank == 0:
         print(json.dumps(res), flush=True)
