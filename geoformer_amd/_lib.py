@@ -38,6 +38,12 @@ def _declare(lib):
         "gf_conv_pack_weights": (I, [P, I, I, I, P, P]),
         "gf_conv_pack_weights_t": (I, [P, I, I, I, I, P, P]),
         "gf_conv_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, P, P, P, P, P, P]),
+        "gf_feeder_create": (P, [I]),
+        "gf_feeder_submit": (I, [P, P]),
+        "gf_feeder_wait_issued": (I, [P, I]),
+        "gf_feeder_wait_copied": (I, [P, I]),
+        "gf_feeder_wait_head": (I, [P, I]),
+        "gf_feeder_destroy": (I, [P]),
         "gf_conv_dual_supported": (I, [I, I, I, I, I]),
         "gf_rules_flat_words": (c_size_t, [I, I]),
         "gf_rules_flat_steps": (I, [P, P, I, I, I, I, P, P]),
@@ -114,6 +120,7 @@ def _declare(lib):
         "gf_voxelize_idx_count": (I, [P, I, I, I, P, P, P, P]),
         "gf_voxelize_idx_fill": (I, [P, I, I, I, P, P, I, I, P, P, P]),
         "gf_host_legacy_choice": (I, [P, P, c_longlong, c_longlong, P]),
+        "gf_host_legacy_prefetch": (I, [P, I, c_longlong]),
         "gf_fg_scratch_bytes": (c_size_t, [I]),
         "gf_fg_select": (I, [P, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
@@ -223,6 +230,20 @@ def check(status: int, what: str = ""):
     if status != 0:
         msg = load().gf_last_error()
         raise GeoFormerHipError(f"{what} failed ({status}): {msg.decode() if msg else ''}")
+
+
+FEEDER_MAX_COPIES = 16
+
+
+class FeederJob(ctypes.Structure):
+    """GfFeederJob of include/geoformer_hip.h."""
+
+    _fields_ = [("slot", c_int), ("n_copies", c_int),
+                ("src", c_void_p * FEEDER_MAX_COPIES), ("pinned", c_void_p * FEEDER_MAX_COPIES),
+                ("dev", c_void_p * FEEDER_MAX_COPIES), ("bytes", c_size_t * FEEDER_MAX_COPIES),
+                ("coords_dev", c_void_p), ("N", c_int), ("ncol", c_int), ("mode", c_int), ("pad_", c_int),
+                ("scratch", c_void_p), ("input_map", c_void_p), ("head_dev", c_void_p), ("head_host", c_void_p),
+                ("stream", c_void_p)]
 
 
 # seconds the host has spent blocked in the package's own Python-level waits (per process; bench.py's host_busy figure)

@@ -6,16 +6,21 @@ The reference builds every batch on the host -- ``datasets/scannetv2_inst.py:389
 calls (train.py:63-75, test.py:56).  At the rate the MI355X forward consumes scenes (5-6 ms each) that host
 voxelisation (~8 ms per 150k-point scene even vectorised) and the blocking copies are the bottleneck of the loop.
 
-Here batch i+1 is started when batch i is handed over, in the consumer's own thread (a helper thread was tried first
-and halved the loop's rate: the forward is bound by the host's launch rate and a second Python thread takes the
-interpreter lock away from it for milliseconds at a time):
-  start(i+1): staged in pinned buffers, uploaded on a copy stream, first half of ``gf_voxelize_idx`` (voxel ids,
-              counts) queued behind the copies, the two sizes it produces on their way to a pinned word -- all
-              asynchronous, the device works on it beside scene i;
-  finish(i+1): (at the next hand-over) the sizes are there, the second half (maps) is queued, an event marks the batch.
+Here batch i+1 is started when batch i is handed over.  The consumer's thread only allocates the batch's device
+tensors and describes the job; the bytes are moved by ONE native worker thread of the library (csrc/feeder.hip: memcpy
+into pinned buffers, asynchronous uploads on a copy stream, first half of ``gf_voxelize_idx`` behind them, its two
+sizes on their way to a pinned word).  Rounds 2-5 did the staging memcpy on the consumer's own thread -- 0.8 ms per
+150k-point scene in which that thread launches nothing -- because a Python helper thread halved the loop's rate (the
+forward is bound by the host's launch rate and a second Python thread takes the interpreter lock away from it for
+milliseconds at a time); a native thread holds no interpreter lock.
+  start(i+1): device tensors allocated, job handed to the worker: returns at once;
+  finish(i+1): (at the next hand-over) the worker has long issued everything; the sizes are there, the second half
+               (maps) is queued, an event marks the batch.
 The consumer's stream waits for that event only.  No device-wide synchronisation, no blocking copy.
 """
 from __future__ import annotations
+
+import ctypes
 
 import torch
 
@@ -26,7 +31,7 @@ _STAGED = ("locs", "locs_float", "feats", "labels", "instance_labels", "offsets"
 
 
 class _InFlight:
-    __slots__ = ("out", "scratch", "input_map", "head_host", "head_ready", "copied", "N", "ncol")
+    __slots__ = ("out", "scratch", "input_map", "head", "head_host", "voxelise", "N", "ncol", "slot", "keep")
 
 
 class DeviceFeeder:
@@ -48,8 +53,23 @@ class DeviceFeeder:
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.pinned = {}  # (key, slot) -> pinned staging tensor, grown on demand
         self.slot = 0
-        self.busy = {}  # slot -> event after which its staging buffers may be rewritten
+        self.busy = set()  # slots whose job's uploads may still read the slot's staging buffers
+        self.handle = self.lib.gf_feeder_create(self.device.index)
+        if not self.handle:
+            raise _lib.GeoFormerHipError("gf_feeder_create: " + (self.lib.gf_last_error() or b"").decode())
         self.next = self._start()
+
+    def close(self):
+        """Stop the worker thread (after the last batch; also on garbage collection)."""
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            self.lib.gf_feeder_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _stage(self, key, t):
         buf = self.pinned.get((key, self.slot))
@@ -66,13 +86,7 @@ class DeviceFeeder:
                 if old is None or old.dtype != t.dtype or old.numel() < cap:
                     self.pinned[(key, sl)] = torch.empty(cap, dtype=t.dtype).pin_memory()
             buf = self.pinned[(key, self.slot)]
-        view = buf[:n].view(t.shape)
-        # numpy's memcpy, not Tensor.copy_: a CPU-side torch copy wakes torch's intra-op thread pool, whose spinning
-        # workers slow the launching thread several times over on a many-core host
-        import numpy as np
-
-        np.copyto(view.numpy(), t.numpy())
-        return view
+        return buf[:n].view(t.shape)  # (filled by the worker thread: csrc/feeder.hip)
 
     def _start(self):
         try:
@@ -80,24 +94,37 @@ class DeviceFeeder:
         except StopIteration:
             return None
         f = _InFlight()
-        ev = self.busy.get(self.slot)
-        if ev is not None:
-            ev.synchronize()  # two hand-overs ago: long done
+        f.slot = self.slot
+        if f.slot in self.busy:  # three hand-overs ago: long done
+            check(self.lib.gf_feeder_wait_copied(self.handle, f.slot), "gf_feeder_wait_copied")
+            self.busy.discard(f.slot)
+        job = _lib.FeederJob()
+        job.slot = f.slot
+        job.stream = self.copy_stream.cuda_stream
+        f.keep = []  # host tensors the worker reads: alive until the job has been issued
+        nc = 0
         with torch.cuda.stream(self.copy_stream):
             out = {}
             for k, v in raw.items():
                 if torch.is_tensor(v) and k in _STAGED:
-                    out[k] = self._stage(k, v.contiguous()).to(self.device, non_blocking=True)
+                    v = v.contiguous()
+                    if nc >= _lib.FEEDER_MAX_COPIES:
+                        raise RuntimeError("DeviceFeeder: more staged tensors than GF_FEEDER_MAX_COPIES")
+                    pin = self._stage(k, v)
+                    dev_t = torch.empty(v.shape, dtype=v.dtype, device=self.device)
+                    job.src[nc], job.pinned[nc], job.dev[nc] = v.data_ptr(), pin.data_ptr(), dev_t.data_ptr()
+                    job.bytes[nc] = v.numel() * v.element_size()
+                    nc += 1
+                    f.keep.append(v)
+                    out[k] = dev_t
                 elif torch.is_tensor(v):
                     out[k] = v.to(self.device, non_blocking=True)
                 else:
                     out[k] = v
+            job.n_copies = nc
             f.out = out
-            f.copied = torch.cuda.Event()
-            f.copied.record(self.copy_stream)
-            self.busy[self.slot] = f.copied
-            f.head_ready = None
-            if "voxel_locs" not in out:
+            f.voxelise = "voxel_locs" not in out
+            if f.voxelise:
                 coords = out["locs"]
                 if coords.dtype != torch.int64 or coords.dim() != 2:
                     raise RuntimeError("locs: expected an int64 [N,4] tensor")
@@ -105,24 +132,27 @@ class DeviceFeeder:
                 f.scratch = torch.empty(self.lib.gf_voxelize_idx_scratch_bytes(f.N) // 8 + 1, dtype=torch.int64,
                                         device=self.device)
                 f.input_map = torch.empty(f.N, dtype=torch.int32, device=self.device)
-                head = torch.empty(3, dtype=torch.int32, device=self.device)
-                check(self.lib.gf_voxelize_idx_count(ptr(coords), f.N, f.ncol, int(self.mode), ptr(f.scratch),
-                                                     ptr(f.input_map), ptr(head), self.copy_stream.cuda_stream),
-                      "gf_voxelize_idx_count")
-                f.head_host = self.pinned.get(("head", self.slot))
+                f.head = torch.empty(3, dtype=torch.int32, device=self.device)
+                f.head_host = self.pinned.get(("head", f.slot))
                 if f.head_host is None:
-                    f.head_host = self.pinned[("head", self.slot)] = torch.zeros(3, dtype=torch.int32).pin_memory()
-                f.head_host.copy_(head, non_blocking=True)
-                f.head_ready = torch.cuda.Event()
-                f.head_ready.record(self.copy_stream)
+                    f.head_host = self.pinned[("head", f.slot)] = torch.zeros(3, dtype=torch.int32).pin_memory()
+                job.coords_dev, job.N, job.ncol, job.mode = coords.data_ptr(), f.N, f.ncol, int(self.mode)
+                job.scratch, job.input_map = f.scratch.data_ptr(), f.input_map.data_ptr()
+                job.head_dev, job.head_host = f.head.data_ptr(), f.head_host.data_ptr()
+        check(self.lib.gf_feeder_submit(self.handle, ctypes.byref(job)), "gf_feeder_submit")
+        self.busy.add(f.slot)
         self.slot = (self.slot + 1) % 3
         return f
 
     def _finish(self, f):
         out = f.out
+        # the worker has queued the job's copies and kernels on the copy stream (normally long ago); only now may this
+        # thread queue anything behind them there
+        check(self.lib.gf_feeder_wait_issued(self.handle, f.slot), "gf_feeder (worker thread)")
+        f.keep = None
         with torch.cuda.stream(self.copy_stream):
-            if f.head_ready is not None:
-                f.head_ready.synchronize()
+            if f.voxelise:
+                check(self.lib.gf_feeder_wait_head(self.handle, f.slot), "gf_feeder_wait_head")
                 M, max_active, err = f.head_host.tolist()
                 if err:
                     raise _lib.GeoFormerHipError("gf_voxelize_idx: a coordinate lies outside [0, 65535] "
@@ -148,6 +178,7 @@ class DeviceFeeder:
 
     def __next__(self):
         if self.next is None:
+            self.close()
             raise StopIteration
         out = self._finish(self.next)
         self.next = self._start()  # the device works on it beside the scene just handed over

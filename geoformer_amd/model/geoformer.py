@@ -1077,6 +1077,10 @@ class GeoFormer(nn.Module):
                 backbone_done.record()
             yield backbone_done
         if fused_fg:
+            if batch_size == 1 and locs_float.is_cuda and cfg.n_downsampling and epoch > self.prepare_epochs:
+                # the host has nothing to do until the foreground count is back: the generator words the sampling draw
+                # will consume (they do not depend on the count) are drawn ahead now (csrc/host_draw.hip)
+                pointops.legacy_prefetch(int(1.4 * locs_float.shape[0]) + 4096)
             fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = fg_pending.get()
         else:
             fg = semantic_preds >= 4 if same_fold else semantic_preds == 3

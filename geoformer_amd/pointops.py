@@ -205,6 +205,18 @@ class PendingForeground:
         return tuple(b[:n] for b in self.bufs)
 
 
+def legacy_prefetch(nwords):
+    """Draw the next `nwords` outputs of numpy's global legacy generator ahead (into a per-thread native buffer, the
+    generator itself untouched): a legacy_choice that starts from the same state takes its words from there."""
+    import numpy as np
+
+    st = np.random.get_state()
+    if st[0] != "MT19937":
+        return
+    key = np.ascontiguousarray(st[1], dtype=np.uint32)
+    check(_lib.load().gf_host_legacy_prefetch(key.ctypes.data, int(st[2]), int(nwords)), "gf_host_legacy_prefetch")
+
+
 def legacy_choice(n, k, out=None):
     """``np.random.choice(n, k, replace=False)`` on numpy's global legacy generator -- same values, same generator
     state afterwards -- through the native restatement (csrc/host_draw.hip; about half the host time).

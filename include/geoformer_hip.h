@@ -59,6 +59,11 @@ int gf_fg_select(const float* scores, int N, int C, int cls, int mode, const flo
  *   set_state);  out int64[k] = permutation(n)[:k].
  * =================================================================================== */
 int gf_host_legacy_choice(uint32_t* key, int32_t* pos, long long n, long long k, long long* out);
+/* Draw the next `nwords` outputs of the state (key, pos) AHEAD into a per-thread buffer (the caller's state is not
+ * touched): a gf_host_legacy_choice that starts from exactly this state reads its words from there -- the draw of the
+ * forward's sampling indices (geoformer.py:575-577) then only pays the rejections and the swaps behind the count's
+ * read-back.  Too few words drawn ahead: the draw runs on the generator itself.  Same values, same final state. */
+int gf_host_legacy_prefetch(const uint32_t* key, int pos, long long nwords);
 
 /* ===================================================================================
  * Sparse convolution (stands in for spconv.ops.get_indice_pairs / indice_conv /
@@ -376,6 +381,35 @@ int gf_voxelize_idx_count(const long long* coords, int N, int ncol, int mode, vo
                           int32_t* d_M_maxActive, void* stream);
 int gf_voxelize_idx_fill(const long long* coords, int N, int ncol, int mode, void* scratch, const int32_t* input_map,
                          int M, int maxActive, long long* out_coords, int32_t* out_map, void* stream);
+
+/* The host side of feeding a scene (what the reference's drivers do with blocking `.cuda()` calls from their own thread,
+ * test.py:56 / train.py:63-75, after a host voxelize_idx in the dataset's collate, datasets/scannetv2_inst.py:389-455) on
+ * a NATIVE worker thread: per job, n_copies x (memcpy src -> pinned, hipMemcpyAsync pinned -> dev on `stream`), an event
+ * ("copied": the pinned buffers may be rewritten), then -- coords_dev != NULL -- gf_voxelize_idx_count on the uploaded
+ * coordinates, the read-back of its three words into head_host (pinned) and a second event ("head").  gf_feeder_submit
+ * returns at once; the caller's thread never touches the bytes.  slot 0..3 names the job's state and events; a slot takes
+ * a new job after gf_feeder_wait_issued(slot).  Waits release the interpreter lock when called through ctypes. */
+#define GF_FEEDER_MAX_COPIES 16
+typedef struct {
+    int slot, n_copies;
+    const void* src[GF_FEEDER_MAX_COPIES];
+    void* pinned[GF_FEEDER_MAX_COPIES];
+    void* dev[GF_FEEDER_MAX_COPIES];
+    size_t bytes[GF_FEEDER_MAX_COPIES];
+    const long long* coords_dev; /* device int64 [N,ncol]: one of the `dev` targets, or NULL (no voxelisation) */
+    int N, ncol, mode, pad_;
+    void* scratch;               /* gf_voxelize_idx_scratch_bytes(N) */
+    int32_t* input_map;          /* device int32 [N] */
+    int32_t* head_dev;           /* device int32 [3] */
+    int32_t* head_host;          /* pinned int32 [3] */
+    void* stream;
+} GfFeederJob;
+void* gf_feeder_create(int device);
+int gf_feeder_submit(void* feeder, const GfFeederJob* job);
+int gf_feeder_wait_issued(void* feeder, int slot); /* the job's calls are queued on its stream (or: its error status) */
+int gf_feeder_wait_copied(void* feeder, int slot); /* after wait_issued: the uploads have left the pinned buffers */
+int gf_feeder_wait_head(void* feeder, int slot);   /* after wait_issued: head_host holds {M, maxActive, error} */
+int gf_feeder_destroy(void* feeder);
 
 /* PG_OP.voxelize_fp (voxelize.cu:9-31): out[row,:] = sum_i mult * feats[rules[row,i],:], i in rule
  * order, mult = 1/count when average (mode 4).  rules int32 [M, 1+maxActive].  out fp32 [M,C]. */

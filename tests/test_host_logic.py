@@ -74,6 +74,37 @@ def test_legacy_choice_matches_numpy(lib, seed, n, k):
     assert (ref_after[1][1] == got_after[1][1]).all() and ref_after[1][2:] == got_after[1][2:]
 
 
+@pytest.mark.parametrize("seed,n,k,ahead", [(1, 60_000, 50_000, 90_000), (2, 60_000, 50_000, 30_000), (3, 5000, 5000, 100),
+                                             (4, 70_001, 3, 200_000), (5, 1234, 1234, 1), (6, 624, 100, 0)])
+def test_legacy_choice_with_words_drawn_ahead(lib, seed, n, k, ahead):
+    """gf_host_legacy_prefetch: the generator's outputs drawn ahead of the draw (enough, too few -- the draw then runs on
+    the generator itself --, none): same indices, same generator state as numpy's own draw, and a prefetch that no draw
+    picks up (another state in between) changes nothing."""
+    from geoformer_amd import pointops
+
+    def prime():
+        np.random.seed(seed)
+        np.random.rand(seed * 131)
+
+    prime()
+    ref = np.random.choice(n, k, replace=False)
+    ref_after = (np.random.randn(3), np.random.get_state())
+    prime()
+    pointops.legacy_prefetch(ahead)
+    got = pointops.legacy_choice(n, k)
+    got_after = (np.random.randn(3), np.random.get_state())
+    assert (got == ref).all() and (ref_after[0] == got_after[0]).all()
+    assert (ref_after[1][1] == got_after[1][1]).all() and ref_after[1][2:] == got_after[1][2:]
+    # a stale prefetch: the generator moves on before the draw
+    prime()
+    pointops.legacy_prefetch(ahead)
+    np.random.rand(5)
+    ref2_state = np.random.get_state()
+    ref2 = np.random.choice(n, k, replace=False)
+    np.random.set_state(ref2_state)
+    assert (pointops.legacy_choice(n, k) == ref2).all()
+
+
 def test_legacy_choice_sequence(lib):
     from geoformer_amd import pointops
 
