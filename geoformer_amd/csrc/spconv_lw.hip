@@ -379,11 +379,6 @@ static bool lw_shape(int nchw, int ncb) { return (nchw == 1 || nchw == 2) && (nc
 
 // 1 if the LDS-weight kernel takes this convolution (gf_conv_fwd's dispatch, given a flat table); `forced`: the dev knob said so
 int gf_conv_lw_supported(int K, int M_in, int M_out, int Cin, int Cout, bool aligned, int* forced) {
-    static bool env_read = false;
-    if (!env_read) {
-        env_read = true;
-        if (const char* e = getenv("GF_CONV_LW")) g_lw_use = atoi(e) != 0;
-    }
     if (forced) *forced = g_lw_use == 1;
     if (g_lw_use == 0) return 0;
     if (!aligned || K != 27) return 0;

@@ -72,7 +72,7 @@ __global__ void k_tr_pack_batch(PackTable tb, float* __restrict__ base) {
 }
 
 struct ConvGeom {  // one convolution op resolved against the step's levels
-    const int32_t *tbl, *btbl, *steps, *bsteps;
+    const int32_t *tbl, *btbl, *steps, *bsteps, *flat;  // flat: step table of a symmetric (submanifold) relation, or null
     const uint32_t *gmask, *bgmask;
     int K, rows_in, rows_out, ld, bld, flip;
 };
@@ -80,6 +80,7 @@ struct ConvGeom {  // one convolution op resolved against the step's levels
 inline bool conv_geom(const GfTrainOp& op, const GfTrainLevel* lv, ConvGeom& g) {
     const GfTrainLevel& L = lv[op.level];
     g.steps = g.bsteps = nullptr;
+    g.flat = nullptr;
     g.flip = 0;
     switch (op.table) {
     case 0:
@@ -93,6 +94,7 @@ inline bool conv_geom(const GfTrainOp& op, const GfTrainLevel* lv, ConvGeom& g) 
         g.tbl = g.btbl = L.nbr;
         g.gmask = g.bgmask = L.gmask;
         g.steps = g.bsteps = L.steps;
+        g.flat = L.flat;
         g.K = 27;
         g.rows_in = g.rows_out = L.M;
         g.ld = g.bld = L.ld;
@@ -175,8 +177,8 @@ extern "C" int gf_unet_train_fwd(const GfTrainOp* ops, int op_begin, int op_end,
             ConvGeom g;
             GF_CHECK_ARG(conv_geom(op, levels, g), "gf_unet_train_fwd: op %d: table %d", i, op.table);
             float* wpk = wp + op.wp_off;
-            int rc = gf_conv_fwd(act[op.src], wpk, g.tbl, g.gmask, g.steps, g.K, g.rows_in, g.rows_out, g.ld, op.Cin, op.Cout,
-                             nullptr, nullptr, op.aux >= 0 ? act[op.aux] : nullptr, nullptr, nullptr, act[op.dst], stream);
+            int rc = gf_conv_fwd_flat(act[op.src], wpk, g.tbl, g.gmask, g.steps, g.flat, g.K, g.rows_in, g.rows_out, g.ld, op.Cin, op.Cout,
+                                      nullptr, nullptr, op.aux >= 0 ? act[op.aux] : nullptr, nullptr, nullptr, act[op.dst], nullptr, stream);
             if (rc != GF_OK) return rc;
         } else if (op.kind == 2) {
             const long long M = rows_of(op, levels);
@@ -275,8 +277,9 @@ extern "C" int gf_unet_train_bwd(const GfTrainOp* ops, int op_begin, int op_end,
             }
             if (!op.no_dgrad) {
                 // (rows of the gradient = the forward's output rows; the residual epilogue adds what the source has)
-                int rc = gf_conv_fwd(gy, wt + wt_off[i - op_begin], g.btbl, g.bgmask, g.bsteps, g.K, g.rows_out, g.rows_in, g.bld, op.Cout, op.Cin, nullptr,
-                                 nullptr, ghas[op.src] ? grad[op.src] : nullptr, nullptr, nullptr, grad[op.src], stream);
+                // (a submanifold relation is its own transpose: the forward's flat step table serves the gradient too)
+                int rc = gf_conv_fwd_flat(gy, wt + wt_off[i - op_begin], g.btbl, g.bgmask, g.bsteps, g.flat, g.K, g.rows_out, g.rows_in, g.bld, op.Cout, op.Cin, nullptr,
+                                          nullptr, ghas[op.src] ? grad[op.src] : nullptr, nullptr, nullptr, grad[op.src], nullptr, stream);
                 if (rc != GF_OK) return rc;
                 if (!ghas[op.src]) ghas[op.src] = 1;
             }

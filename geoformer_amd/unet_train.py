@@ -35,7 +35,7 @@ class TrainOp(ctypes.Structure):
 class TrainLevel(ctypes.Structure):
     _fields_ = [("M", ctypes.c_int), ("ld", ctypes.c_int), ("nbr", _FP), ("gmask", _FP), ("steps", _FP),
                 ("M_coarse", ctypes.c_int), ("ld_down", ctypes.c_int), ("child", _FP), ("gmask_down", _FP),
-                ("ld_up", ctypes.c_int), ("pad_", ctypes.c_int), ("up", _FP), ("gmask_up", _FP)]
+                ("ld_up", ctypes.c_int), ("pad_", ctypes.c_int), ("up", _FP), ("gmask_up", _FP), ("flat", _FP)]
 
 
 BN_RELU, CONV, CAT = 0, 1, 2
@@ -345,6 +345,7 @@ def unet_forward(model, x, batch_size, signature=None):
         L = levels[l]
         L.M, L.ld, L.nbr, L.gmask = rows[l], s.ld, s.nbr.data_ptr(), s.gmask.data_ptr()
         L.steps = None if s.steps is None else s.steps.data_ptr()
+        L.flat = None if s.flat is None else s.flat.data_ptr()
         if l < nl - 1:
             r = chain[l]
             L.M_coarse, L.ld_down, L.child, L.gmask_down = rows[l + 1], r.ld, r.child.data_ptr(), r.gmask_down.data_ptr()

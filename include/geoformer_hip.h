@@ -243,6 +243,7 @@ typedef struct GfTrainLevel {
     int M_coarse, ld_down;                          /* the level below: rows, leading dimension of child */
     const int32_t* child; const uint32_t* gmask_down;
     int ld_up, pad_; const int32_t* up; const uint32_t* gmask_up;
+    const int32_t* flat;                            /* flat step table of the 27-offset relation (gf_rules_flat_steps) or NULL */
 } GfTrainLevel;
 /* floats of `scratch` a range of ops needs (BatchNorm partials + the transposed weight pack of the widest op) */
 size_t gf_unet_train_scratch_floats(const GfTrainOp* ops, int nops, const GfTrainLevel* levels);

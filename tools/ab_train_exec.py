@@ -1,10 +1,11 @@
 """Dev tool: the batch-4 training step with the native training-mode U-Net (csrc/unet_train.hip) and with the module
-tree, alternating inside ONE process (boxes and runs differ by several ms): median ms per step of each."""
+tree, alternating inside ONE process (boxes and runs differ by several ms): median ms per step of each.
+`ab_train_exec.py lw` alternates the LDS-weight convolution kernel (size-based choice against never) instead."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tools import train_dp
-from geoformer_amd import parallel
+from geoformer_amd import parallel, sparse
 
 dev = torch.device("cuda", 0)
 args = train_dp.default_args(batch_size=4, fg_frac=0.4)
@@ -19,7 +20,10 @@ t = {"1": [], "0": []}
 n = 0
 for r in range(rounds + 1):
     for v in ("1", "0"):
-        os.environ[knob] = v
+        if knob == "lw":
+            sparse.dev_conv_knobs(lw=-1 if v == "1" else 0)
+        else:
+            os.environ[knob] = v
         for i in range(per):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             train_dp.step(m, crit, red, opt, batches[n % 2], 200, n); n += 1
