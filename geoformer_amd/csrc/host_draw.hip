@@ -15,8 +15,17 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef DRAW_TIMING
+#include <stdio.h>
+#include <time.h>
+#endif
 
 #include "common.h"
+
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define GF_DRAW_AVX2 1
+#endif
 
 namespace {
 constexpr int MT_N = 624, MT_M = 397;
@@ -80,6 +89,92 @@ struct Prefetch {
     int nblocks = 0;
 };
 thread_local Prefetch t_pf;
+
+// the draw's two work arrays (swap partners, the permutation as 32-bit words), kept per thread and grown on demand: two
+// fresh allocations of 240 KB each are mapped pages the kernel has to fault in one by one -- at every draw
+struct DrawScratch {
+    uint32_t* J = nullptr;
+    uint32_t* x = nullptr;
+    size_t cap = 0;
+    ~DrawScratch() {
+        free(J);
+        free(x);
+    }
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        free(J);
+        free(x);
+        const size_t c = n + n / 4 + 4096;
+        J = (uint32_t*)malloc(c * sizeof(uint32_t));
+        x = (uint32_t*)malloc(c * sizeof(uint32_t));
+        cap = (J && x) ? c : 0;
+        return cap != 0;
+    }
+};
+thread_local DrawScratch t_ds;
+
+#ifdef GF_DRAW_AVX2
+// Pass 1, 32 words per trip.  Word t of a trip is accepted iff (w & mask) <= i_t, and i_t lies in [i - 31, i] (it drops by
+// one per acceptance): a value <= i - 32 is accepted and a value > i is rejected whatever came before it, so unless one of
+// the 32 falls into the band in between (32 * 32 / 2^bits of the trips) the trip is a plain stream compaction -- four
+// independent 8-lane compares against the SAME threshold (the loop-carried chain broadcast -> compare -> movemask ->
+// popcount -> subtract, ~12 cycles, is paid once per 32 words instead of once per 8), accepted lanes permuted to the front,
+// one unaligned store each.  A trip with a value in the band takes the scalar steps.  The caller's loop guarantees
+// i - lo >= 31 on entry of every trip (all acceptances stay under this mask).  Returns the words consumed (a multiple of 32).
+struct CompactLut {
+    alignas(32) uint32_t idx[256][8];
+    CompactLut() {
+        for (int m = 0; m < 256; m++) {
+            int c = 0;
+            for (int b = 0; b < 8; b++)
+                if (m >> b & 1) idx[m][c++] = (uint32_t)b;
+            for (; c < 8; c++) idx[m][c] = 0;
+        }
+    }
+};
+__attribute__((target("avx2,popcnt"))) int pass1_blocks_avx2(const uint32_t* __restrict__ b, int avail, uint32_t mask,
+                                                               uint32_t lo, uint32_t* i_io, uint32_t* __restrict__ Jq,
+                                                               size_t* q_io) {
+    static const CompactLut lut;
+    uint32_t i = *i_io;
+    size_t q = *q_io;
+    const __m256i vmask = _mm256_set1_epi32((int)mask);
+    int t = 0;
+    while (avail - t >= 32 && i >= lo + 31) {
+        // (values and thresholds are below 2^31: signed compares)
+        const __m256i hi = _mm256_set1_epi32((int)i), band_lo = _mm256_set1_epi32((int)i - 32);
+        __m256i v[4];
+        int rej[4], amb = 0;
+        for (int u = 0; u < 4; u++) {
+            v[u] = _mm256_and_si256(_mm256_loadu_si256((const __m256i*)(b + t + 8 * u)), vmask);
+            rej[u] = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(v[u], hi)));
+            amb |= rej[u] ^ _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(v[u], band_lo)));
+        }
+        if (amb) {  // a value inside (i - 32, i]: its fate depends on the words before it
+            for (int u = 0; u < 32; u++) {
+                const uint32_t x = b[t + u] & mask;
+                Jq[q] = x;
+                const uint32_t acc = x <= i;
+                q += acc;
+                i -= acc;
+            }
+        } else {
+            for (int u = 0; u < 4; u++) {
+                const int acc = ~rej[u] & 0xff;
+                const __m256i packed = _mm256_permutevar8x32_epi32(v[u], _mm256_load_si256((const __m256i*)lut.idx[acc]));
+                _mm256_storeu_si256((__m256i*)(Jq + q), packed);  // (up to 7 words past the accepted ones: scratch has the room)
+                const int c = __builtin_popcount((unsigned)acc);
+                q += (size_t)c;
+                i -= (uint32_t)c;
+            }
+        }
+        t += 32;
+    }
+    *i_io = i;
+    *q_io = q;
+    return t;
+}
+#endif
 }  // namespace
 
 extern "C" int gf_host_legacy_prefetch(const uint32_t* key, int pos, long long nwords) {
@@ -122,36 +217,55 @@ extern "C" int gf_host_legacy_prefetch(const uint32_t* key, int pos, long long n
 }
 
 // key[624], *pos: numpy's MT19937 state (pos == 624: the block is used up).  out[k] = permutation(n)[:k].
-static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long long k, long long* out, bool use_prefetch);
+static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long long k, long long* out, int32_t* out32,
+                              long long cap32, bool use_prefetch);
 extern "C" int gf_host_legacy_choice(uint32_t* key, int32_t* pos_io, long long n, long long k, long long* out) {
     GF_CHECK_ARG(key && pos_io && out, "gf_host_legacy_choice: null argument");
     GF_CHECK_ARG(n >= 1 && n <= 0x7fffffffLL && k >= 0 && k <= n, "gf_host_legacy_choice: n=%lld k=%lld", n, k);
     GF_CHECK_ARG(*pos_io >= 0 && *pos_io <= MT_N, "gf_host_legacy_choice: generator position %d", (int)*pos_io);
     const Prefetch& P = t_pf;
     if (P.pos0 == *pos_io && P.words && memcmp(P.key0, key, sizeof(P.key0)) == 0) {
-        const int rc = legacy_choice_impl(key, pos_io, n, k, out, true);
+        const int rc = legacy_choice_impl(key, pos_io, n, k, out, nullptr, 0, true);
         t_pf.pos0 = -1;  // (consumed)
         if (rc != 1) return rc;  // 1: the words drawn ahead did not suffice -- nothing was changed: the plain draw
     }
-    return legacy_choice_impl(key, pos_io, n, k, out, false);
+    return legacy_choice_impl(key, pos_io, n, k, out, nullptr, 0, false);
 }
 
-static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long long k, long long* out, bool use_prefetch) {
+// the same draw as 32-bit indices: out32[0..k); with room for n entries the permutation is shuffled in place there
+static int legacy_choice32(uint32_t* key, int32_t* pos_io, long long n, long long k, int32_t* out32, long long cap32) {
+    const Prefetch& P = t_pf;
+    if (P.pos0 == *pos_io && P.words && memcmp(P.key0, key, sizeof(P.key0)) == 0) {
+        const int rc = legacy_choice_impl(key, pos_io, n, k, nullptr, out32, cap32, true);
+        t_pf.pos0 = -1;
+        if (rc != 1) return rc;
+    }
+    return legacy_choice_impl(key, pos_io, n, k, nullptr, out32, cap32, false);
+}
+
+static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long long k, long long* out, int32_t* out32,
+                              long long cap32, bool use_prefetch) {
     int pos = *pos_io;
     uint32_t block[MT_N];
     const Prefetch& P = t_pf;
     size_t used = 0;  // words of the stream drawn ahead that pass 1 has consumed
     if (!use_prefetch && pos < MT_N) mt_temper_block(key, block);
-    uint32_t* J = (uint32_t*)malloc((size_t)(n + 1) * sizeof(uint32_t));
-    uint32_t* x = (uint32_t*)malloc((size_t)n * sizeof(uint32_t));  // 32-bit working set: half the cache footprint
-    if (!J || !x) {
-        free(J);
-        free(x);
+    if (!t_ds.reserve((size_t)n + 16)) {  // (+ the overhang of pass 1's 8-word stores)
         gf_set_error("gf_host_legacy_choice: out of memory");
         return GF_ERR_LAUNCH;
     }
-    // pass 1: the swap partner of every position, top down
+    uint32_t* J = t_ds.J;
+    // 32-bit working set: half the cache footprint (the caller's own buffer when it takes 32-bit indices and has the room)
+    uint32_t* x = (out32 && cap32 >= n) ? (uint32_t*)out32 : t_ds.x;
+#ifdef DRAW_TIMING
+    struct timespec ts0, ts1, ts2, ts3; clock_gettime(CLOCK_MONOTONIC, &ts0);
+#endif
+    // pass 1: the swap partner of every position, top down: Jq[q] belongs to position n - 1 - q
+#ifdef GF_DRAW_AVX2
+    static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+#endif
     uint32_t i = (uint32_t)(n - 1);
+    size_t q = 0;
     while (i >= 1) {
         uint32_t mask = i;
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
@@ -160,11 +274,7 @@ static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long 
             int avail;
             const uint32_t* b;
             if (use_prefetch) {
-                if (used >= P.nwords) {  // (drawn ahead too little: the caller starts over on the generator)
-                    free(J);
-                    free(x);
-                    return 1;
-                }
+                if (used >= P.nwords) return 1;  // (drawn ahead too little: the caller starts over on the generator)
                 const size_t left = P.nwords - used;
                 avail = left > 65536 ? 65536 : (int)left;
                 b = P.words + used;
@@ -176,24 +286,24 @@ static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long 
                 avail = MT_N - pos;
                 b = block + pos;
             }
+            int t0 = 0;
+#ifdef GF_DRAW_AVX2
+            if (avx2) t0 = pass1_blocks_avx2(b, avail, mask, lo, &i, J, &q);
+#endif
             // i drops by at most one per draw, so the next min(words left, i - lo + 1) draws cannot leave the mask's
             // range: a check-free inner loop (the only loop-carried chain is compare -> subtract)
             const uint32_t room = i - lo + 1;
-            const int m = room < (uint32_t)avail ? (int)room : avail;
-            for (int t = 0; t < m; t++) {
+            const int left_w = avail - t0;
+            const int m = room < (uint32_t)left_w ? (int)room : left_w;
+            for (int t = t0; t < t0 + m; t++) {
                 const uint32_t v = b[t] & mask;
-                J[i] = v;
-#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
-                // i -= (v <= i) as compare + add-with-carry: two cycles of loop-carried latency instead of the four of
-                // the compare / set / extend / subtract sequence the compiler emits (this loop is 80k iterations of
-                // nothing else)
-                asm("cmp %1, %0\n\tadc $-1, %0" : "+r"(i) : "r"(v) : "cc");
-#else
-                i -= (v <= i);
-#endif
+                J[q] = v;
+                const uint32_t acc = v <= i;
+                q += acc;
+                i -= acc;
             }
-            if (use_prefetch) used += (size_t)m;
-            else pos += m;
+            if (use_prefetch) used += (size_t)(t0 + m);
+            else pos += t0 + m;
         }
     }
     if (use_prefetch) {
@@ -208,18 +318,65 @@ static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long 
             pos = (int)(more - (adv - 1) * MT_N);
         }
     }
+#ifdef DRAW_TIMING
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+#endif
     // pass 2: the swaps
     for (long long t = 0; t < n; t++) x[t] = (uint32_t)t;
-    for (long long p = n - 1; p >= 1; p--) {
-        if (p >= 24) __builtin_prefetch(&x[J[p - 24]], 1, 1);
-        const uint32_t j = J[p];
+    for (long long p = n - 1, s = 0; p >= 1; p--, s++) {
+        if (p >= 24) __builtin_prefetch(&x[J[s + 24]], 1, 1);
+        const uint32_t j = J[s];
         const uint32_t tmp = x[j];
         x[j] = x[p];
         x[p] = tmp;
     }
-    for (long long t = 0; t < k; t++) out[t] = (long long)x[t];
-    free(J);
-    free(x);
+#ifdef DRAW_TIMING
+    clock_gettime(CLOCK_MONOTONIC, &ts2);
+#endif
+    if (out)
+        for (long long t = 0; t < k; t++) out[t] = (long long)x[t];
+    if (out32 && (uint32_t*)out32 != x) memcpy(out32, x, (size_t)k * sizeof(int32_t));
+#ifdef DRAW_TIMING
+    clock_gettime(CLOCK_MONOTONIC, &ts3);
+    { static int cnt = 0; if ((cnt++ % 50) == 0) fprintf(stderr, "draw n=%lld pass1 %.1f us pass2 %.1f us out %.1f us\n", n,
+        (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-3, (ts2.tv_sec - ts1.tv_sec) * 1e6 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-3,
+        (ts3.tv_sec - ts2.tv_sec) * 1e6 + (ts3.tv_nsec - ts2.tv_nsec) * 1e-3); }
+#endif
     *pos_io = pos;
+    return GF_OK;
+}
+
+// ---- draw + upload + gather in one call (round 6) ----
+// The eval forward's device idles from the moment the foreground count reaches the host until the first sampling launch:
+// the draw itself, then -- through the framework -- the upload of the indices, the gather of the drawn points and ~80 us
+// of interpreter time around them.  Here the host goes from the count to the queued gather in one native call: the draw
+// as 32-bit indices straight into the caller's pinned buffer, one asynchronous copy, one launch that writes the drawn
+// points' coordinates and the 64-bit copy of the indices the model keeps (geoformer.py:575-579: sampling_indices, xyz).
+__global__ void k_take_drawn(const int32_t* __restrict__ idx, int k, int n, const float* __restrict__ xyz_src,
+                             long long* __restrict__ idx64, float* __restrict__ xyz_dst) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k) return;
+    const int j = idx[t];
+    idx64[t] = j;
+    if ((unsigned)j >= (unsigned)n) return;  // (cannot happen: a permutation of 0..n-1)
+    xyz_dst[3 * t + 0] = xyz_src[3 * (size_t)j + 0];
+    xyz_dst[3 * t + 1] = xyz_src[3 * (size_t)j + 1];
+    xyz_dst[3 * t + 2] = xyz_src[3 * (size_t)j + 2];
+}
+
+extern "C" int gf_host_draw_sample(uint32_t* key, int32_t* pos_io, long long n, long long k, int32_t* pinned,
+                                   long long pinned_cap, int32_t* d_idx32, long long* d_idx64, const float* xyz_src,
+                                   float* xyz_dst, void* stream) {
+    GF_CHECK_ARG(key && pos_io && pinned && d_idx32 && d_idx64 && xyz_src && xyz_dst, "gf_host_draw_sample: null argument");
+    GF_CHECK_ARG(n >= 1 && n <= 0x7fffffffLL && k >= 1 && k <= n && pinned_cap >= k, "gf_host_draw_sample: n=%lld k=%lld cap=%lld",
+                 n, k, pinned_cap);
+    GF_CHECK_ARG(*pos_io >= 0 && *pos_io <= MT_N, "gf_host_draw_sample: generator position %d", (int)*pos_io);
+    const int rc = legacy_choice32(key, pos_io, n, k, pinned, pinned_cap);
+    if (rc != GF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    GF_TRY(hipMemcpyAsync(d_idx32, pinned, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_take_drawn, dim3((unsigned)gf_div_up(k, 256)), dim3(256), 0, st, d_idx32, (int)k, (int)n, xyz_src, d_idx64,
+                       xyz_dst);
+    GF_CHECK_LAUNCH("gf_host_draw_sample");
     return GF_OK;
 }

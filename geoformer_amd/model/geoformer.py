@@ -544,8 +544,43 @@ class GeoFormer(nn.Module):
             context_feats = self.set_aggregator.mlp(torch.cat(gfeat), torch.cat(gxyz)).transpose(1, 2)
             return context_locs, context_feats, pre_enc_inds
 
+    def _sampling_split(self):
+        """(n_query_points, the aggregator's npoint, whether the sampling is cut after the query picks)"""
+        nq = self.cfg.n_query_points
+        npoint_sa = self.set_aggregator.npoint
+        return nq, npoint_sa, os.environ.get("GF_OVERLAP", "1") != "2" and npoint_sa > nq
+
+    def _first_picks(self, xyz_b, sb):
+        """The sampling launches of one scene on stream `sb` (the current one): the query picks first, then -- queued right
+        behind them, before the host spends ~60 us on anything else -- the rest (the stretch's long pole).  Returns
+        (event: points ready, first picks, query picks, event: query picks ready, all picks, event: sampling done)."""
+        nq, npoint_sa, split = self._sampling_split()
+        xyz_ready = torch.cuda.Event()
+        xyz_ready.record(sb)
+        first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
+        src = first[0, :nq].contiguous()
+        first_ready = torch.cuda.Event()
+        first_ready.record(sb)
+        idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
+        fps_done = torch.cuda.Event()
+        fps_done.record(sb)
+        return xyz_ready, first, src, first_ready, idx, fps_done
+
+    def _sample_from_count(self, n, locs_rows, bufs):
+        """Eval forward of ONE scene: from the foreground count straight to the first sampling launch -- the device has
+        been idle since the count left it.  The draw, the upload of its indices and the gather of the drawn points are one
+        native call (pointops.draw_sample), the two sampling launches follow; everything else the forward does with the
+        count (views, offsets, the stage's streams) comes after.  Returns what _aggregate_geodesic_overlapped would have
+        produced for the scene at this point, or None (generator not drivable in place: that method's own route)."""
+        npoint = min(n, self.cfg.n_downsampling)
+        drawn = pointops.draw_sample(n, npoint, locs_rows, bufs)
+        if drawn is None:
+            return None
+        sampling_indices, xyz_b = drawn
+        return (sampling_indices, xyz_b) + self._first_picks(xyz_b, torch.cuda.current_stream())
+
     def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step,
-                                       pc_dims=None, sample=True, epilogue=True, early=None):
+                                       pc_dims=None, sample=True, epilogue=True, early=None, presampled=None):
         """Inference on the GPU.  Furthest point sampling (2047 serial rounds on 16 compute units) and the geodesic
         BFS (<= 256 serial hops, one workgroup per query) are the two long latency-bound launches of the forward, and
         the BFS only needs the first n_query_points picks.  So the sampling is cut after those picks, the BFS goes
@@ -558,9 +593,7 @@ class GeoFormer(nn.Module):
         epilogue=False: none of the small side-stream launches whose results GeoFormer.forward picks up later."""
         offs = _offsets_list(batch_offsets_)
         grad_ctx = self._grad_ctx("set_aggregator")  # like forward_aggregator: no graph through a frozen aggregator
-        nq = self.cfg.n_query_points
-        npoint_sa = self.set_aggregator.npoint
-        split = os.environ.get("GF_OVERLAP", "1") != "2" and npoint_sa > nq
+        nq, npoint_sa, split = self._sampling_split()
         main = torch.cuda.current_stream()
         sides = _SIDE_STREAMS  # process-wide, one set per caller stream: scenes in flight on
         side = sides.get((locs_float_.device, main.cuda_stream))   # different streams do not queue behind each other
@@ -623,26 +656,21 @@ class GeoFormer(nn.Module):
             else:
                 sb, side_b = main, side
             with torch.cuda.stream(sb):
-                if sample:
-                    # (one scene: the device idles on this draw)
-                    pin, npoint = draws[b] if b in draws else host_draw(b, n_b)
-                    sampling_indices = pin[:npoint].to(locs_float_.device, non_blocking=True)
+                if presampled is not None and b == 0 and not multi and sample:
+                    # (the caller went from the count to these launches directly: _sample_from_count)
+                    sampling_indices, xyz_b, xyz_ready, first, src, first_ready, idx, fps_done = presampled
                     self.last_sampling_indices = sampling_indices
-                    xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
                 else:
-                    sampling_indices = None
-                    xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
-                xyz_ready = torch.cuda.Event()
-                xyz_ready.record(sb)
-                first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
-                src = first[0, :nq].contiguous()
-                first_ready = torch.cuda.Event()
-                first_ready.record(sb)
-                # the rest of the sampling is the stretch's long pole: queued right behind the first picks, before the
-                # host spends ~60 us on everything below (the stream idled that long between the two launches)
-                idx = pointops.furthest_point_sampling(xyz_b, npoint_sa, known=first) if split else first
-                fps_done = torch.cuda.Event()
-                fps_done.record(sb)
+                    if sample:
+                        # (one scene: the device idles on this draw)
+                        pin, npoint = draws[b] if b in draws else host_draw(b, n_b)
+                        sampling_indices = pin[:npoint].to(locs_float_.device, non_blocking=True)
+                        self.last_sampling_indices = sampling_indices
+                        xyz_b = locs_float_[offs[b]:offs[b + 1]][sampling_indices].unsqueeze(0).contiguous()
+                    else:
+                        sampling_indices = None
+                        xyz_b = locs_float_[offs[b]:offs[b + 1]].unsqueeze(0).contiguous()
+                    xyz_ready, first, src, first_ready, idx, fps_done = self._first_picks(xyz_b, sb)
                 fps_done_evs.append(fps_done)
                 picks_ready = first_ready
             if early is not None and b == 0:
@@ -1077,11 +1105,22 @@ class GeoFormer(nn.Module):
                 backbone_done.record()
             yield backbone_done
         if fused_fg:
+            presampled = None
+            # inference on one scene: the sampling is launched from the count alone (below), before the views / offsets
+            from_count = (batch_size == 1 and not training and cfg.n_downsampling
+                          and os.environ.get("GF_OVERLAP", "1") != "0")
             if batch_size == 1 and locs_float.is_cuda and cfg.n_downsampling and epoch > self.prepare_epochs:
                 # the host has nothing to do until the foreground count is back: the generator words the sampling draw
-                # will consume (they do not depend on the count) are drawn ahead now (csrc/host_draw.hip)
+                # will consume (they do not depend on the count) are drawn ahead now (csrc/host_draw.hip), and the
+                # buffers of the draw are allocated
                 pointops.legacy_prefetch(int(1.4 * locs_float.shape[0]) + 4096)
-            fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = fg_pending.get()
+                if from_count:
+                    draw_bufs = pointops.draw_sample_buffers(int(cfg.n_downsampling), int(locs_float.shape[0]),
+                                                             locs_float.device)
+            n_fg = fg_pending.wait()
+            if from_count and n_fg > 0:
+                presampled = self._sample_from_count(n_fg, fg_pending.bufs[1], draw_bufs)
+            fg_idxs, locs_float_, batch_idxs_, output_feats_, semantic_scores_ = fg_pending.views()
         else:
             fg = semantic_preds >= 4 if same_fold else semantic_preds == 3
             fg_idxs = torch.nonzero(fg).view(-1)
@@ -1132,7 +1171,7 @@ class GeoFormer(nn.Module):
             # issued behind that launch on the third stream and runs beside it (the sampler keeps 16 CUs busy)
             contexts, geo_dists, (mask_features_, sem_prob, graphs) = self._aggregate_geodesic_overlapped(
                 locs_float_, output_feats_, batch_offsets_, batch_size, None, max_step, pc_dims, epilogue=True,
-                early=sampling_independent)
+                early=sampling_independent, presampled=presampled if fused_fg else None)
         else:
             mask_features_, sem_prob, graphs = sampling_independent()
             if graphs is not None and overlap:

@@ -196,25 +196,109 @@ class PendingForeground:
         self.done = torch.cuda.Event()
         self.done.record()
 
-    def get(self):
+    def wait(self):
+        """Block until the count is on the host; returns it.  (``views()`` afterwards: the five slices -- a caller with
+        something urgent to launch from the count alone does that in between.)"""
         _lib.timed_wait(self.done)  # (polling the pinned word instead: no difference, 219 scenes/s either way)
-        n = int(self.host[0])
+        self.n = int(self.host[0])
         with PendingForeground._lock:
             PendingForeground._pinned.append(self.host)
         self.host = None
-        return tuple(b[:n] for b in self.bufs)
+        return self.n
+
+    def views(self):
+        return tuple(b[:self.n] for b in self.bufs)
+
+    def get(self):
+        self.wait()
+        return self.views()
+
+
+_LEGACY_STATE = {}  # id(bit generator) -> (generator, address of its {uint32 key[624]; int pos}) or (generator, None)
+
+
+def _legacy_state():
+    """numpy's global legacy generator in place: (address of its MT19937 state -- ``uint32 key[624]; int pos``,
+    numpy/random/src/mt19937/mt19937.h -- , the generator's lock), or None when the global RandomState runs on another
+    bit generator or the layout does not check out against ``get_state()`` (then: the get_state / set_state route).
+    ``np.random.get_state()`` + ``set_state()`` are 20-40 us each -- on the forward's critical path, once per scene."""
+    import ctypes
+
+    import numpy as np
+
+    bg = np.random.mtrand._rand._bit_generator
+    hit = _LEGACY_STATE.get(id(bg))
+    if hit is None or hit[0] is not bg:
+        addr = None
+        if type(bg).__name__ == "MT19937":
+            try:
+                a = int(bg.ctypes.state_address)
+                st = np.random.get_state()
+                key = np.ctypeslib.as_array((ctypes.c_uint32 * 624).from_address(a))
+                if st[0] == "MT19937" and int(ctypes.c_int.from_address(a + 2496).value) == int(st[2]) and \
+                        bool((key == np.asarray(st[1], dtype=np.uint32)).all()):
+                    addr = a
+            except Exception:  # noqa: BLE001  (an interface this numpy does not have: the portable route)
+                addr = None
+        _LEGACY_STATE.clear()
+        hit = _LEGACY_STATE[id(bg)] = (bg, addr)
+    return None if hit[1] is None else (hit[1], bg.lock)
 
 
 def legacy_prefetch(nwords):
     """Draw the next `nwords` outputs of numpy's global legacy generator ahead (into a per-thread native buffer, the
     generator itself untouched): a legacy_choice that starts from the same state takes its words from there."""
+    import ctypes
+
     import numpy as np
 
+    direct = _legacy_state()
+    if direct is not None:
+        addr, lock = direct
+        with lock:
+            check(_lib.load().gf_host_legacy_prefetch(addr, int(ctypes.c_int.from_address(addr + 2496).value), int(nwords)),
+                  "gf_host_legacy_prefetch")
+        return
     st = np.random.get_state()
     if st[0] != "MT19937":
         return
     key = np.ascontiguousarray(st[1], dtype=np.uint32)
     check(_lib.load().gf_host_legacy_prefetch(key.ctypes.data, int(st[2]), int(nwords)), "gf_host_legacy_prefetch")
+
+
+_DRAW_PINS = {}  # (device index, stream) -> pinned int32 buffer of the fused draw (grow-only)
+
+
+def draw_sample_buffers(kmax, n_cap, device):
+    """Device outputs and the pinned staging buffer of ``draw_sample`` for at most `kmax` drawn indices out of at most
+    `n_cap` points, allocated ahead (the caller does this while it waits for the count the draw depends on)."""
+    key = (device.index, stream_ptr())
+    pin = _DRAW_PINS.get(key)
+    if pin is None or pin.numel() < max(n_cap, kmax):
+        pin = _DRAW_PINS[key] = torch.empty(max(n_cap + n_cap // 4, kmax, 65536), dtype=torch.int32).pin_memory()
+    return {"pin": pin, "idx32": torch.empty(kmax, dtype=torch.int32, device=device),
+            "idx64": torch.empty(kmax, dtype=torch.int64, device=device),
+            "xyz": torch.empty((1, kmax, 3), dtype=torch.float32, device=device), "kmax": kmax}
+
+
+def draw_sample(n, k, xyz_src, bufs):
+    """The reference's per-scene draw ``np.random.choice(n, k, replace=False)`` (geoformer.py:575-577) and what follows it
+    -- upload of the indices, gather of the drawn points -- as ONE native call (gf_host_draw_sample, csrc/host_draw.hip):
+    returns (sampling_indices int64 [k], xyz [1,k,3]) on the device, queued on the current stream; numpy's global
+    generator advances exactly as by the draw.  None when the generator cannot be driven in place (the caller then takes
+    legacy_choice's route).  xyz_src: [>= n, 3] fp32 contiguous."""
+    n, k = int(n), int(k)
+    direct = _legacy_state() if 1 <= k <= n <= 0x7fffffff and k <= bufs["kmax"] else None
+    if direct is None:
+        return None
+    _f32c(xyz_src, "xyz_src")
+    addr, lock = direct
+    pin = bufs["pin"]
+    with lock:
+        check(_lib.load().gf_host_draw_sample(addr, addr + 2496, n, k, pin.data_ptr(), pin.numel(), ptr(bufs["idx32"]),
+                                              ptr(bufs["idx64"]), ptr(xyz_src), ptr(bufs["xyz"]), stream_ptr()),
+              "gf_host_draw_sample")
+    return bufs["idx64"][:k], bufs["xyz"][:, :k]
 
 
 def legacy_choice(n, k, out=None):
@@ -227,6 +311,14 @@ def legacy_choice(n, k, out=None):
     import numpy as np
 
     n, k = int(n), int(k)
+    direct = _legacy_state() if 1 <= k <= n <= 0x7fffffff else None
+    if direct is not None:  # the generator's state advanced in place, under its lock
+        addr, lock = direct
+        if out is None or out.dtype != np.int64 or out.size < k or not out.flags.c_contiguous:
+            out = np.empty(k, dtype=np.int64)
+        with lock:
+            check(_lib.load().gf_host_legacy_choice(addr, addr + 2496, n, k, out.ctypes.data), "gf_host_legacy_choice")
+        return out[:k]
     st = np.random.get_state()
     if st[0] != "MT19937" or not (1 <= k <= n <= 0x7fffffff):
         return np.random.choice(n, k, replace=False)  # numpy's own argument errors / exotic sizes

@@ -64,6 +64,14 @@ int gf_host_legacy_choice(uint32_t* key, int32_t* pos, long long n, long long k,
  * forward's sampling indices (geoformer.py:575-577) then only pays the rejections and the swaps behind the count's
  * read-back.  Too few words drawn ahead: the draw runs on the generator itself.  Same values, same final state. */
 int gf_host_legacy_prefetch(const uint32_t* key, int pos, long long nwords);
+/* The draw and what geoformer.py:575-579 does with it, from the host's side in ONE call (the device idles between the
+ * arrival of the foreground count and the first sampling launch): the same draw as 32-bit indices into the caller's PINNED
+ * buffer `pinned` (pinned_cap entries, >= k; with >= n the shuffle runs in place there), one asynchronous copy to
+ * d_idx32[k], one launch that writes d_idx64[k] (the model's `sampling_indices`) and xyz_dst[k,3] = xyz_src[idx] (n rows).
+ * key / pos: the generator's state, advanced in place.  The pinned buffer may be rewritten once the copy has left it
+ * (stream order). */
+int gf_host_draw_sample(uint32_t* key, int32_t* pos, long long n, long long k, int32_t* pinned, long long pinned_cap,
+                        int32_t* d_idx32, long long* d_idx64, const float* xyz_src, float* xyz_dst, void* stream);
 
 /* ===================================================================================
  * Sparse convolution (stands in for spconv.ops.get_indice_pairs / indice_conv /

@@ -306,7 +306,15 @@ def test_two_host_threads_on_their_own_streams_share_one_model(hip):
 
     import geoformer_amd.pointops as po
 
+    orig_draw = po.draw_sample
+
+    def locked_draw(n, k, xyz_src, bufs):  # (the eval forward's route: draw + upload + gather in one native call)
+        with draw_lock:
+            np.random.seed(1)
+            return orig_draw(n, k, xyz_src, bufs)
+
     po.legacy_choice = locked_choice
+    po.draw_sample = locked_draw
     try:
         def worker(i):
             try:
@@ -327,6 +335,7 @@ def test_two_host_threads_on_their_own_streams_share_one_model(hip):
             t.join()
     finally:
         po.legacy_choice = orig_choice
+        po.draw_sample = orig_draw
     assert not errors, errors
     for i in range(2):
         for a, b in zip(serial[i], results[i]):

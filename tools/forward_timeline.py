@@ -4,7 +4,7 @@ import csv, sys
 f = sys.argv[1]
 kmin = float(sys.argv[2]) if len(sys.argv) > 2 else 25.0
 gmin = float(sys.argv[3]) if len(sys.argv) > 3 else 8.0
-rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][-44:], r['Stream_Id'])
+rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][-44:], r['Stream_Id'])
         for r in csv.DictReader(open(f))]
 rows.sort()
 vf = [i for i, r in enumerate(rows) if 'k_voxelize_fp' in r[2]]

@@ -5,7 +5,7 @@ f = sys.argv[1]
 marker = sys.argv[2] if len(sys.argv) > 2 else "k_voxelize_fp"
 kmin = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 back = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # which repetition, counted from the end
-rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][-48:], r['Stream_Id'])
+rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0][-48:], r['Stream_Id'])
         for r in csv.DictReader(open(f))]
 rows.sort()
 vf = [i for i, r in enumerate(rows) if marker in r[2]]
