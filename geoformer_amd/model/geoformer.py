@@ -674,30 +674,20 @@ class GeoFormer(nn.Module):
                 fps_done_evs.append(fps_done)
                 picks_ready = first_ready
             if early is not None and b == 0:
-                # work of the caller that does not depend on the sampling (early() -> (.., .., kNN graphs)): queued on
-                # the third stream now that the first sampling launch is out
+                # work of the caller that does not depend on the sampling, queued on the third stream now that the first
+                # sampling launch is out: first the kNN graphs alone (early(True)) -- the BFS launch below is the next
+                # thing the device will be waiting for (the query picks take ~0.27 ms; with everything else of this
+                # stretch issued first the host reached the BFS launch 0.33-0.48 ms after the count) -- the rest
+                # (early(False) -> (mask features, class probabilities)) behind that launch
                 aux.wait_event(xyz_ready)
                 with torch.cuda.stream(aux):
-                    early_out = early()
-                    graphs = early_out[2]
-                    for t in _tensors_of(early_out):
+                    graphs = early(True)
+                    for t in _tensors_of(graphs):
                         t.record_stream(main)
                         t.record_stream(side)
-                    early_done = torch.cuda.Event()
-                    early_done.record(aux)
-                side.wait_event(early_done)
-            grid = None
-            if xyz_b.shape[1] >= 4096 and not torch.is_grad_enabled():
-                # the ball query's point grid needs the points only: built on the side stream under the first picks
-                # (issued after their launch -- nothing may delay that one)
-                aux.wait_event(xyz_ready)
-                with torch.cuda.stream(aux):
-                    xyz_b.record_stream(aux)
-                    grid = pointops.point_grid_build(xyz_b, self.set_aggregator.radius)
-                    grid.record_stream(main)
-                    grid_done = torch.cuda.Event()
-                    grid_done.record(aux)
-                grid = (grid, grid_done)
+                    graphs_done = torch.cuda.Event()
+                    graphs_done.record(aux)
+                side.wait_event(graphs_done)
             # (the BFS waits for the query picks only -- not for the rest of the sampling queued behind them)
             side_b.wait_event(first_ready)
             with torch.cuda.stream(side_b):
@@ -710,6 +700,26 @@ class GeoFormer(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record(side_b)
                 geo_ready[b] = ev
+            if early is not None and b == 0:
+                with torch.cuda.stream(aux):
+                    early_out = tuple(early(False)) + (graphs,)
+                    for t in _tensors_of(early_out[:2]):
+                        t.record_stream(main)
+                        t.record_stream(side)
+                    early_done = torch.cuda.Event()
+                    early_done.record(aux)
+            grid = None
+            if xyz_b.shape[1] >= 4096 and not torch.is_grad_enabled():
+                # the ball query's point grid needs the points only: built on the third stream under the first picks
+                # (issued after their launch and after the BFS launch -- nothing may delay those)
+                aux.wait_event(xyz_ready)
+                with torch.cuda.stream(aux):
+                    xyz_b.record_stream(aux)
+                    grid = pointops.point_grid_build(xyz_b, self.set_aggregator.radius)
+                    grid.record_stream(main)
+                    grid_done = torch.cuda.Event()
+                    grid_done.record(aux)
+                grid = (grid, grid_done)
             if multi:
                 for t in (xyz_b, idx, first, sampling_indices):
                     if t is not None:
@@ -1143,9 +1153,12 @@ class GeoFormer(nn.Module):
             outputs["mask_predictions"] = None
             return outputs
 
-        def sampling_independent():
+        def sampling_independent(graphs_only=None):
             """Everything of this stretch that does not need the sampling: mask features, class probabilities (read
-            by the proposal scores at the very end), the kNN graphs."""
+            by the proposal scores at the very end), the kNN graphs.  graphs_only True / False: the graphs alone / the other
+            two alone (the inference path issues the BFS launch in between)."""
+            if graphs_only is True:
+                return knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)
             chain = self._pointwise_chain("mask_tower", [self.mask_tower], output_feats_)
             if chain is not None:
                 mf = pointops.pointwise_mlp(output_feats_.contiguous(), chain).unsqueeze(2)
@@ -1158,6 +1171,8 @@ class GeoFormer(nn.Module):
                 sp = F.softmax(semantic_scores_, dim=1)
                 if sp.is_cuda:
                     sp = (sp, sp.t().contiguous())  # + the class-major copy the proposal kernel reads
+            if graphs_only is False:
+                return mf, sp
             gr = None
             if locs_float_.is_cuda and nonempty:
                 gr = knn_graphs(locs_float_, batch_offsets_, batch_size, neighbor=64, radius=0.05)

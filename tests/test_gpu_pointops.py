@@ -141,3 +141,46 @@ def test_voxelize_idx_gpu_rejects_out_of_range(hip):
     c = torch.tensor([[0, 1, 2, 3], [0, 70000, 2, 3]], dtype=torch.int64).cuda()
     with pytest.raises(_lib.GeoFormerHipError):
         pointops.voxelize_idx(c, 4)
+
+
+@pytest.mark.parametrize("n,k,ahead", [(60_133, 50_000, 215_000), (30_000, 30_000, 0), (50_001, 50_000, 1000), (7, 7, 0),
+                                       (120_000, 50_000, 215_000)])
+def test_draw_sample_equals_numpy_draw_and_gather(hip, n, k, ahead):
+    """pointops.draw_sample (gf_host_draw_sample: the per-scene draw of geoformer.py:575-579 as 32-bit indices into pinned
+    memory + upload + gather, one native call) against numpy's own draw and an indexed copy: same indices, same points,
+    same generator state afterwards -- with the generator's words drawn ahead (enough / too few) and without; twice in a row
+    on the same buffers (the pinned buffer is rewritten in stream order)."""
+    from geoformer_amd import pointops
+
+    rng = np.random.default_rng(n)
+    xyz = torch.from_numpy(rng.standard_normal((n + 100, 3)).astype(np.float32)).cuda()
+    for rep in range(2):
+        np.random.seed(5 + rep)
+        np.random.rand(17 * rep)
+        ref = np.random.choice(n, k, replace=False)
+        ref_after = np.random.get_state()
+        np.random.seed(5 + rep)
+        np.random.rand(17 * rep)
+        bufs = pointops.draw_sample_buffers(50_000, n, xyz.device)
+        if ahead:
+            pointops.legacy_prefetch(ahead)
+        got = pointops.draw_sample(n, k, xyz, bufs)
+        assert got is not None
+        idx, pts = got
+        got_after = np.random.get_state()
+        assert idx.dtype == torch.int64 and tuple(idx.shape) == (k,) and tuple(pts.shape) == (1, k, 3) and pts.is_contiguous()
+        assert (idx.cpu().numpy() == ref).all()
+        assert torch.equal(pts[0], xyz[torch.from_numpy(ref).cuda()])
+        assert (ref_after[1] == got_after[1]).all() and ref_after[2:] == got_after[2:]
+
+
+def test_draw_sample_declines_what_it_cannot_do(hip):
+    """More indices than the buffers hold, k > n: None (the caller takes legacy_choice's route, numpy's own errors)."""
+    from geoformer_amd import pointops
+
+    xyz = torch.zeros((100, 3), device="cuda")
+    bufs = pointops.draw_sample_buffers(50, 100, xyz.device)
+    st = np.random.get_state()
+    assert pointops.draw_sample(100, 60, xyz, bufs) is None
+    assert pointops.draw_sample(10, 11, xyz, bufs) is None
+    assert (np.random.get_state()[1] == st[1]).all()

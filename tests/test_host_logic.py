@@ -51,12 +51,20 @@ def test_abi_version_and_error_channel(lib):
     assert b"gf_host_legacy_choice" in lib.gf_last_error()
 
 
+@pytest.mark.parametrize("route", ["in-place", "get/set_state"])
 @pytest.mark.parametrize("seed,n,k", [(0, 60108, 50000), (1, 10, 10), (2, 1, 1), (3, 2, 1), (4, 65536, 100),
-                                      (5, 65537, 65537), (6, 100000, 50000), (7, 3248, 3248), (8, 624, 3)])
-def test_legacy_choice_matches_numpy(lib, seed, n, k):
+                                      (5, 65537, 65537), (6, 100000, 50000), (7, 3248, 3248), (8, 624, 3),
+                                      (9, 31, 31), (10, 32, 5), (11, 33, 33), (12, 64, 64), (13, 131_073, 9),
+                                      (14, 300_001, 50_000)])
+def test_legacy_choice_matches_numpy(lib, seed, n, k, route, monkeypatch):
     """gf_host_legacy_choice == np.random.choice(n, k, replace=False) on the global legacy generator (the draw of
     geoformer.py:575-577): same indices, same generator state afterwards, wherever the generator stands."""
     from geoformer_amd import pointops
+
+    if route == "in-place":  # numpy's MT19937 state driven where it lives (no get_state / set_state round trip)
+        assert pointops._legacy_state() is not None
+    else:                    # ... and the portable route for a numpy whose state cannot be reached
+        monkeypatch.setattr(pointops, "_legacy_state", lambda: None)
 
     def prime():
         np.random.seed(seed)
