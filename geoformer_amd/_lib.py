@@ -78,6 +78,7 @@ def _declare(lib):
         "gf_dev_event_elapsed_us": (I, [P, P, P]),
         "gf_unet_fwd": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P]),
         "gf_unet_fwd_phased": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P, P, I, P, P]),
+        "gf_unet_fwd_ahead": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P, P, P, P, P, I]),
         "gf_voxelize_fp": (I, [P, P, I, I, I, I, P, P]),
         "gf_voxelize_bp": (I, [P, P, I, I, I, I, P, P]),
         "gf_gather_points": (I, [P, P, I, I, I, I, P, P]),
@@ -121,7 +122,7 @@ def _declare(lib):
         "gf_voxelize_idx_fill": (I, [P, I, I, I, P, P, I, I, P, P, P]),
         "gf_host_legacy_choice": (I, [P, P, c_longlong, c_longlong, P]),
         "gf_host_legacy_prefetch": (I, [P, I, c_longlong]),
-        "gf_host_draw_sample": (I, [P, P, c_longlong, c_longlong, P, c_longlong, P, P, P, P, P]),
+        "gf_host_draw_sample": (I, [P, P, c_longlong, c_longlong, P, c_longlong, P, P, P, P, I, P, P, P]),
         "gf_fg_scratch_bytes": (c_size_t, [I]),
         "gf_fg_select": (I, [P, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),

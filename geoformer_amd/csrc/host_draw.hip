@@ -366,7 +366,7 @@ __global__ void k_take_drawn(const int32_t* __restrict__ idx, int k, int n, cons
 
 extern "C" int gf_host_draw_sample(uint32_t* key, int32_t* pos_io, long long n, long long k, int32_t* pinned,
                                    long long pinned_cap, int32_t* d_idx32, long long* d_idx64, const float* xyz_src,
-                                   float* xyz_dst, void* stream) {
+                                   float* xyz_dst, int fps_m, int32_t* fps_idx, void* fps_scratch, void* stream) {
     GF_CHECK_ARG(key && pos_io && pinned && d_idx32 && d_idx64 && xyz_src && xyz_dst, "gf_host_draw_sample: null argument");
     GF_CHECK_ARG(n >= 1 && n <= 0x7fffffffLL && k >= 1 && k <= n && pinned_cap >= k, "gf_host_draw_sample: n=%lld k=%lld cap=%lld",
                  n, k, pinned_cap);
@@ -378,5 +378,10 @@ extern "C" int gf_host_draw_sample(uint32_t* key, int32_t* pos_io, long long n, 
     hipLaunchKernelGGL(k_take_drawn, dim3((unsigned)gf_div_up(k, 256)), dim3(256), 0, st, d_idx32, (int)k, (int)n, xyz_src, d_idx64,
                        xyz_dst);
     GF_CHECK_LAUNCH("gf_host_draw_sample");
+    // (... and the first sampling launch over the drawn points, when the caller wants it queued right behind them)
+    if (fps_m > 0) {
+        GF_CHECK_ARG(fps_idx && fps_scratch, "gf_host_draw_sample: sampling outputs missing");
+        return gf_furthest_point_sampling(xyz_dst, 1, (int)k, fps_m, fps_idx, fps_scratch, stream);
+    }
     return GF_OK;
 }

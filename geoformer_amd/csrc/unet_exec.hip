@@ -71,6 +71,8 @@ struct LevelTables {  // submanifold table of one level
 // events of the side-stream fork/join and the two host waits: per host thread, created once
 struct EvPair {
     hipEvent_t fork = nullptr, chain = nullptr, chain2 = nullptr, rules = nullptr, tbl0 = nullptr, flat0 = nullptr, tbl1 = nullptr, flat1 = nullptr;
+    hipEvent_t ws_done = nullptr;  // end of this thread's last call on its main stream: the tables may be rewritten
+    bool ws_done_recorded = false;
 };
 thread_local EvPair t_ev;
 // nanoseconds this host thread spent blocked in the executor's own waits (gf_dev_host_wait_ns: bench.py's host_busy figure)
@@ -253,10 +255,39 @@ extern "C" int gf_unet_fwd(const GfUnetParams* P, const float* feats, const int3
                               0, nullptr, nullptr);
 }
 
+static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
+                         void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream,
+                         void* const* gate_events, int n_gate, GfUnetBetween between, void* user,
+                         void* const* input_events, int n_input);
+
 extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X,
                                   int Y, int Z, void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream,
                                   void* side_stream, void* const* gate_events, int n_gate, GfUnetBetween between,
                                   void* user) {
+    return unet_fwd_impl(P, feats, coords, M0, B, X, Y, Z, ws, ws_bytes, host_counts, out, stream, side_stream, gate_events,
+                         n_gate, between, user, nullptr, -1);
+}
+
+// The rulebooks AHEAD of the caller's stream (round 6).  Index, tables and the down-sampling chain read the voxel
+// coordinates and nothing else, and they are ~0.15 ms at the head of a backbone whose convolutions wait for them.  When the
+// caller can say what the COORDINATES wait for -- input_events: n_input recorded events, none for coordinates that have
+// been resident all along -- every rulebook launch goes to the side stream behind those events (and behind the end of
+// this thread's previous call, which read the same workspace), NOT behind whatever `stream` still has queued: in a loop
+// of forwards they run under the previous scene's latency-bound sampling / BFS stretch and this scene's convolutions
+// start on finished tables.  Same launches, same results as gf_unet_fwd; needs a side stream (else: gf_unet_fwd).
+extern "C" int gf_unet_fwd_ahead(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y,
+                                 int Z, void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream,
+                                 void* side_stream, void* const* input_events, int n_input) {
+    GF_CHECK_ARG(n_input >= 0 && (n_input == 0 || input_events != nullptr), "gf_unet_fwd_ahead: %d input events without a list",
+                 n_input);
+    return unet_fwd_impl(P, feats, coords, M0, B, X, Y, Z, ws, ws_bytes, host_counts, out, stream, side_stream, nullptr, 0,
+                         nullptr, nullptr, input_events, side_stream ? n_input : -1);
+}
+
+static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
+                         void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream,
+                         void* const* gate_events, int n_gate, GfUnetBetween between, void* user,
+                         void* const* input_events, int n_input) {
     GF_CHECK_ARG(P && feats && coords && ws && host_counts && out, "gf_unet_fwd: null argument");
     GF_CHECK_ARG(n_gate >= 0 && (n_gate == 0 || gate_events != nullptr), "gf_unet_fwd_phased: %d gate events without a list", n_gate);
     // the hand-over between the phases happens exactly once on every path that gets past the argument checks below
@@ -303,7 +334,21 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         GF_TRY(hipEventCreateWithFlags(&t_ev.flat0, hipEventDisableTiming));
         GF_TRY(hipEventCreateWithFlags(&t_ev.tbl1, hipEventDisableTiming));
         GF_TRY(hipEventCreateWithFlags(&t_ev.flat1, hipEventDisableTiming));
+        GF_TRY(hipEventCreateWithFlags(&t_ev.ws_done, hipEventDisableTiming));
     }
+    // rulebooks ahead of `st`: the side stream waits for the coordinates' own events and for the previous call's readers
+    const bool ahead = forked && n_input >= 0;
+    auto fork_side = [&]() -> int {
+        if (!forked) return GF_OK;
+        if (!ahead) {
+            GF_TRY(hipStreamWaitEvent(ss, t_ev.fork, 0));
+            return GF_OK;
+        }
+        for (int e = 0; e < n_input; e++) GF_TRY(hipStreamWaitEvent(ss, (hipEvent_t)input_events[e], 0));
+        if (t_ev.ws_done_recorded) GF_TRY(hipStreamWaitEvent(ss, t_ev.ws_done, 0));
+        return GF_OK;
+    };
+    hipStream_t s_rules = ahead ? ss : st;  // where the first two levels' index / tables are built
     if (!t_ev.chain) {
         GF_TRY(hipEventCreateWithFlags(&t_ev.chain, hipEventDisableTiming));
         GF_TRY(hipEventCreateWithFlags(&t_ev.chain2, hipEventDisableTiming));
@@ -348,15 +393,16 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     // convolutions (where the 36-launch serial chain has to go, below) its two fat kernels overlap the first two of
     // them (rocprofv3: 20.5 instead of 18.7 us per level-1 launch)
     const bool chain_first = nl > 0 && gf_rules_level_parallel();
+    if (ahead) UN_TRY(fork_side());
     if (chain_first) {
-        if (forked) GF_TRY(hipStreamWaitEvent(ss, t_ev.fork, 0));
+        if (!ahead) UN_TRY(fork_side());
         UN_TRY(gf_rules_down2_chain_all(coords, M0, B, X, Y, Z, nl, cws, d_counts, ss));
         GF_TRY(hipMemcpyAsync(host_counts + 1, d_counts + 1, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ss));
         GF_TRY(hipEventRecord(t_ev.chain, ss));
         if (nl > 1) GF_TRY(hipEventRecord(t_ev.chain2, ss));
     }
-    UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, st));
-    UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, st));
+    UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, s_rules));
+    UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, s_rules));
     // the first level's flat step table (its one reader is the up pass's 32 -> 16 convolution, the last block of the call):
     // built on the side stream BEHIND the deeper levels' tables, i.e. beside the second level's convolutions -- beside the
     // first level's own it cost them 18 -> 31 us per launch (profiles/r6_conv_lw_notes.md)
@@ -374,7 +420,8 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         }
         return gf_rules_flat_steps(T[0].nbr, T[0].gmask, 27, M0, ld0, 0, T[0].flat, st);
     };
-    if (forked) GF_TRY(hipEventRecord(t_ev.tbl0, st));
+    if (forked) GF_TRY(hipEventRecord(t_ev.tbl0, s_rules));
+    if (ahead) GF_TRY(hipStreamWaitEvent(st, t_ev.tbl0, 0));  // (the first level's convolutions read its table)
 
     // feature buffers are carved after the counts are known for the levels below the first; level 1 now
     int M[GF_UNET_MAX_LEVELS];
@@ -517,6 +564,12 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         if (r_ != GF_OK) return r_;
         if (T[l].flat && M[l] < kFlatMinRows) T[l].flat = nullptr;
         if (!T[l].flat) return GF_OK;
+        if (l == 1 && ahead) {
+            // (ahead of the main stream: table and flat table on the side stream, the main stream waits for both)
+            const int r2 = gf_rules_flat_steps(T[l].nbr, T[l].gmask, 27, M[l], T[l].ld, 0, T[l].flat, s_);
+            if (r2 != GF_OK) return r2;
+            return GF_OK;
+        }
         if (l == 1 && forked && s_ == st) {
             // the second level's flat table beside its strided convolution (which does not read it), not in front of it
             GF_TRY(hipEventRecord(t_ev.tbl1, st));
@@ -565,7 +618,7 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     if (nl > 0) {
         // the whole chain is queued at once (it carries its counts on the device); two events mark the points the
         // host waits for
-        if (forked) GF_TRY(hipStreamWaitEvent(ss, t_ev.fork, 0));
+        if (!ahead) UN_TRY(fork_side());
         if (chain_first) {
             // (queued at the top of the call: every stage one launch over all levels, all counts and tables together)
         } else {
@@ -590,7 +643,11 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
         // main stream: second level's table, the first strided conv and that level's two blocks -- ~0.18 ms of device
         // work that needs nothing from the rest of the chain
         if (forked) GF_TRY(hipStreamWaitEvent(st, t_ev.chain, 0));
-        UN_TRY(subm_tables(1, st));
+        UN_TRY(subm_tables(1, s_rules));
+        if (ahead) {
+            GF_TRY(hipEventRecord(t_ev.tbl1, ss));
+            GF_TRY(hipStreamWaitEvent(st, t_ev.tbl1, 0));
+        }
         carve(1);
         UN_TRY(down_conv(0));
         UN_TRY(two_blocks(1));
@@ -664,6 +721,10 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
     // before the caller reuses the workspace
     if (flat0_pending) GF_TRY(hipStreamWaitEvent(st, t_ev.flat0, 0));
     if (flat1_pending) GF_TRY(hipStreamWaitEvent(st, t_ev.flat1, 0));
+    if (forked) {  // from here on nothing of this call reads the tables: a later call may build its own AHEAD of `st`
+        GF_TRY(hipEventRecord(t_ev.ws_done, st));
+        t_ev.ws_done_recorded = true;
+    }
 #undef UN_TRY
     GF_CHECK_LAUNCH("gf_unet_fwd");
     return GF_OK;

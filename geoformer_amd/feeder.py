@@ -171,6 +171,15 @@ class DeviceFeeder:
         for v in out.values():
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(cur)  # allocated on the copy stream, used on the consumer's
+        # what the batch's tensors wait for: the model starts the head of the backbone (voxel features, rulebooks) behind THIS
+        # event on the executor's side stream instead of behind everything the consumer's stream still has queued
+        # (GeoFormer._inputs_ahead)
+        from . import unet_exec
+        side = unet_exec.side_stream_for(self.device, cur)
+        for v in out.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(side)
+        out["inputs_event"] = (ready,)
         return out
 
     def __iter__(self):

@@ -419,12 +419,41 @@ class GeoFormer(nn.Module):
 
     # -- backbone ---------------------------------------------------------------------------
     def preprocess_input(self, batch_input, batch_size):
+        ahead = self._inputs_ahead(batch_input)
+        if ahead is not None:
+            # (everything up to the SparseConvTensor on the executor's side stream, behind the batch's own events: the
+            #  executor's rulebook launches follow on that stream, and the first convolution waits for the last of them)
+            main, side, evs = ahead
+            with torch.cuda.stream(side):
+                for e in evs:
+                    side.wait_event(e)
+                x = self._preprocess(batch_input, batch_size)
+            for t in (x.features, x.indices):
+                t.record_stream(main)
+            unet_exec.coords_ready_next(evs)
+            return x
+        return self._preprocess(batch_input, batch_size)
+
+    def _preprocess(self, batch_input, batch_size):
         feats = batch_input["feats"]
         if self.cfg.use_coords:
             feats = torch.cat((feats, batch_input["locs_float"]), 1).float()
         voxel_feats = voxelization(feats, batch_input["v2p_map"], self.cfg.mode)
-        return spconv.SparseConvTensor(voxel_feats, batch_input["voxel_locs"].int(), batch_input["spatial_shape"],
+        return spconv.SparseConvTensor(voxel_feats, batch_input["voxel_locs"].int().contiguous(), batch_input["spatial_shape"],
                                        batch_size)
+
+    def _inputs_ahead(self, batch_input):
+        """A batch that says what its tensors wait for -- ``batch_input["inputs_event"]``: a sequence of recorded events,
+        empty for tensors that have been resident all along (bench.py's scenes; DeviceFeeder hands over its own event) --
+        lets the head of the backbone (voxel features, int32 coordinates, every rulebook launch) start without waiting for
+        what the caller's stream still has queued: unet_exec.coords_ready_next / gf_unet_fwd_ahead.  Returns
+        (caller's stream, side stream, events) or None: the plain route."""
+        evs = batch_input.get("inputs_event") if isinstance(batch_input, dict) else None
+        locs = batch_input["voxel_locs"]
+        if evs is None or not locs.is_cuda or torch.is_grad_enabled() or os.environ.get("GF_UNET_EXEC", "1") == "0":
+            return None
+        main = torch.cuda.current_stream(locs.device)
+        return main, unet_exec.side_stream_for(locs.device, main), list(evs)
 
     def unet_features(self, x, batch_size):
         """input_conv -> unet -> output_layer on a SparseConvTensor (geoformer.py:398-401); returns it with the output
@@ -434,6 +463,9 @@ class GeoFormer(nn.Module):
         if os.environ.get("GF_UNET_EXEC", "1") != "0" and unet_exec.supported(self, x.features, x.spatial_shape):
             x.features = unet_exec.unet_forward(self, x.features.contiguous(), x._coords(), batch_size, x.spatial_shape)
             return x
+        if unet_exec.take_coords_ready() is not None:
+            # (a request of _inputs_ahead the executor will not serve: the module tree reads the coordinates on this stream)
+            torch.cuda.current_stream().wait_stream(unet_exec.side_stream_for(x.features.device))
         sig = unet_train.supported(self, x)
         if sig:
             # training: the same launches as the module tree below, forward and backward, issued by native code
@@ -550,14 +582,17 @@ class GeoFormer(nn.Module):
         npoint_sa = self.set_aggregator.npoint
         return nq, npoint_sa, os.environ.get("GF_OVERLAP", "1") != "2" and npoint_sa > nq
 
-    def _first_picks(self, xyz_b, sb):
+    def _first_picks(self, xyz_b, sb, first=None, xyz_ready=None):
         """The sampling launches of one scene on stream `sb` (the current one): the query picks first, then -- queued right
         behind them, before the host spends ~60 us on anything else -- the rest (the stretch's long pole).  Returns
-        (event: points ready, first picks, query picks, event: query picks ready, all picks, event: sampling done)."""
+        (event: points ready, first picks, query picks, event: query picks ready, all picks, event: sampling done).
+        first / xyz_ready: the first launch is already queued (pointops.draw_sample) / an event the points are ready by."""
         nq, npoint_sa, split = self._sampling_split()
-        xyz_ready = torch.cuda.Event()
-        xyz_ready.record(sb)
-        first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
+        if xyz_ready is None:
+            xyz_ready = torch.cuda.Event()
+            xyz_ready.record(sb)
+        if first is None:
+            first = pointops.furthest_point_sampling(xyz_b, nq if split else npoint_sa)
         src = first[0, :nq].contiguous()
         first_ready = torch.cuda.Event()
         first_ready.record(sb)
@@ -576,11 +611,20 @@ class GeoFormer(nn.Module):
         drawn = pointops.draw_sample(n, npoint, locs_rows, bufs)
         if drawn is None:
             return None
-        sampling_indices, xyz_b = drawn
-        return (sampling_indices, xyz_b) + self._first_picks(xyz_b, torch.cuda.current_stream())
+        sampling_indices, xyz_b = drawn[:2]
+        sb = torch.cuda.current_stream()
+        if len(drawn) == 3:
+            # the first sampling launch went out with the draw; what the side streams wait for before they touch the
+            # points is then the end of that launch (the kNN graphs read the foreground rows, not the drawn ones: they
+            # wait for `bufs["before"]`, recorded before the draw)
+            first_ready = torch.cuda.Event()
+            first_ready.record(sb)
+            return (sampling_indices, xyz_b) + self._first_picks(xyz_b, sb, first=drawn[2], xyz_ready=first_ready)
+        return (sampling_indices, xyz_b) + self._first_picks(xyz_b, sb)
 
     def _aggregate_geodesic_overlapped(self, locs_float_, output_feats_, batch_offsets_, batch_size, graphs, max_step,
-                                       pc_dims=None, sample=True, epilogue=True, early=None, presampled=None):
+                                       pc_dims=None, sample=True, epilogue=True, early=None, presampled=None,
+                                       presampled_before=None):
         """Inference on the GPU.  Furthest point sampling (2047 serial rounds on 16 compute units) and the geodesic
         BFS (<= 256 serial hops, one workgroup per query) are the two long latency-bound launches of the forward, and
         the BFS only needs the first n_query_points picks.  So the sampling is cut after those picks, the BFS goes
@@ -679,7 +723,9 @@ class GeoFormer(nn.Module):
                 # thing the device will be waiting for (the query picks take ~0.27 ms; with everything else of this
                 # stretch issued first the host reached the BFS launch 0.33-0.48 ms after the count) -- the rest
                 # (early(False) -> (mask features, class probabilities)) behind that launch
-                aux.wait_event(xyz_ready)
+                # (the graphs read the foreground rows: with the sampling launched from the count, `before` -- recorded
+                #  behind the foreground selection -- is all they wait for; xyz_ready is then the end of the first launch)
+                aux.wait_event(presampled_before if presampled_before is not None else xyz_ready)
                 with torch.cuda.stream(aux):
                     graphs = early(True)
                     for t in _tensors_of(graphs):
@@ -1125,8 +1171,10 @@ class GeoFormer(nn.Module):
                 # buffers of the draw are allocated
                 pointops.legacy_prefetch(int(1.4 * locs_float.shape[0]) + 4096)
                 if from_count:
+                    nq_, npoint_sa_, split_ = self._sampling_split()
                     draw_bufs = pointops.draw_sample_buffers(int(cfg.n_downsampling), int(locs_float.shape[0]),
-                                                             locs_float.device)
+                                                             locs_float.device, fps_m=nq_ if split_ else npoint_sa_)
+                    draw_bufs["before"] = fg_pending.done  # (recorded behind the foreground selection and the count's copy)
             n_fg = fg_pending.wait()
             if from_count and n_fg > 0:
                 presampled = self._sample_from_count(n_fg, fg_pending.bufs[1], draw_bufs)
@@ -1186,7 +1234,8 @@ class GeoFormer(nn.Module):
             # issued behind that launch on the third stream and runs beside it (the sampler keeps 16 CUs busy)
             contexts, geo_dists, (mask_features_, sem_prob, graphs) = self._aggregate_geodesic_overlapped(
                 locs_float_, output_feats_, batch_offsets_, batch_size, None, max_step, pc_dims, epilogue=True,
-                early=sampling_independent, presampled=presampled if fused_fg else None)
+                early=sampling_independent, presampled=presampled if fused_fg else None,
+                presampled_before=draw_bufs["before"] if (fused_fg and presampled is not None) else None)
         else:
             mask_features_, sem_prob, graphs = sampling_independent()
             if graphs is not None and overlap:

@@ -269,16 +269,22 @@ def legacy_prefetch(nwords):
 _DRAW_PINS = {}  # (device index, stream) -> pinned int32 buffer of the fused draw (grow-only)
 
 
-def draw_sample_buffers(kmax, n_cap, device):
+def draw_sample_buffers(kmax, n_cap, device, fps_m=0):
     """Device outputs and the pinned staging buffer of ``draw_sample`` for at most `kmax` drawn indices out of at most
-    `n_cap` points, allocated ahead (the caller does this while it waits for the count the draw depends on)."""
+    `n_cap` points, allocated ahead (the caller does this while it waits for the count the draw depends on).
+    fps_m > 0: also the outputs of a first furthest-point-sampling launch of fps_m picks over the drawn points."""
     key = (device.index, stream_ptr())
     pin = _DRAW_PINS.get(key)
     if pin is None or pin.numel() < max(n_cap, kmax):
         pin = _DRAW_PINS[key] = torch.empty(max(n_cap + n_cap // 4, kmax, 65536), dtype=torch.int32).pin_memory()
-    return {"pin": pin, "idx32": torch.empty(kmax, dtype=torch.int32, device=device),
+    bufs = {"pin": pin, "idx32": torch.empty(kmax, dtype=torch.int32, device=device),
             "idx64": torch.empty(kmax, dtype=torch.int64, device=device),
-            "xyz": torch.empty((1, kmax, 3), dtype=torch.float32, device=device), "kmax": kmax}
+            "xyz": torch.empty((1, kmax, 3), dtype=torch.float32, device=device), "kmax": kmax, "fps_m": 0}
+    if fps_m > 0:
+        bufs["fps_m"] = int(fps_m)
+        bufs["fps_idx"] = torch.empty((1, int(fps_m)), dtype=torch.int32, device=device)
+        bufs["fps_scratch"] = torch.empty(_lib.load().gf_fps_scratch_bytes(1) // 8 + 1, dtype=torch.int64, device=device)
+    return bufs
 
 
 def draw_sample(n, k, xyz_src, bufs):
@@ -286,7 +292,8 @@ def draw_sample(n, k, xyz_src, bufs):
     -- upload of the indices, gather of the drawn points -- as ONE native call (gf_host_draw_sample, csrc/host_draw.hip):
     returns (sampling_indices int64 [k], xyz [1,k,3]) on the device, queued on the current stream; numpy's global
     generator advances exactly as by the draw.  None when the generator cannot be driven in place (the caller then takes
-    legacy_choice's route).  xyz_src: [>= n, 3] fp32 contiguous."""
+    legacy_choice's route).  xyz_src: [>= n, 3] fp32 contiguous.  With buffers made for a first sampling launch
+    (``fps_m``) and k >= fps_m that launch is queued in the same call: a third result, its picks int32 [1, fps_m]."""
     n, k = int(n), int(k)
     direct = _legacy_state() if 1 <= k <= n <= 0x7fffffff and k <= bufs["kmax"] else None
     if direct is None:
@@ -294,10 +301,15 @@ def draw_sample(n, k, xyz_src, bufs):
     _f32c(xyz_src, "xyz_src")
     addr, lock = direct
     pin = bufs["pin"]
+    fps_m = bufs["fps_m"] if 0 < bufs["fps_m"] <= k else 0
     with lock:
         check(_lib.load().gf_host_draw_sample(addr, addr + 2496, n, k, pin.data_ptr(), pin.numel(), ptr(bufs["idx32"]),
-                                              ptr(bufs["idx64"]), ptr(xyz_src), ptr(bufs["xyz"]), stream_ptr()),
+                                              ptr(bufs["idx64"]), ptr(xyz_src), ptr(bufs["xyz"]), fps_m,
+                                              ptr(bufs["fps_idx"]) if fps_m else None,
+                                              ptr(bufs["fps_scratch"]) if fps_m else None, stream_ptr()),
               "gf_host_draw_sample")
+    if fps_m:
+        return bufs["idx64"][:k], bufs["xyz"][:, :k], bufs["fps_idx"]
     return bufs["idx64"][:k], bufs["xyz"][:, :k]
 
 

@@ -164,6 +164,29 @@ def take_phase():
     return req
 
 
+def side_stream_for(dev, main=None):
+    """The executor's side stream of the caller's current stream (created on first use)."""
+    main = main or torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get((dev, main.cuda_stream))
+    if side is None:
+        side = _SIDE_STREAMS[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+    return side
+
+
+def coords_ready_next(events):
+    """The NEXT unet_forward of this host thread runs as gf_unet_fwd_ahead: its coordinates wait for the recorded
+    torch.cuda.Event objects in `events` (possibly none) and for nothing else the caller's stream has queued, so the
+    rulebooks are built on the side stream right away -- in a loop of forwards under the previous scene's sampling / BFS
+    stretch.  ``take_coords_ready()`` clears a request no forward consumed."""
+    _tls.coords_ready = list(events or ())
+
+
+def take_coords_ready():
+    req = getattr(_tls, "coords_ready", None)
+    _tls.coords_ready = None
+    return req
+
+
 def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     """[M,16] output features of input_conv -> unet -> output_layer for voxel features [M,cin] / coords int32 [M,4]."""
     lib = _lib.load()
@@ -185,12 +208,17 @@ def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     if pinned is None:
         pinned = _tls.counts = torch.zeros(MAX_LEVELS + 1, dtype=torch.int32).pin_memory()
     main = torch.cuda.current_stream(dev)
-    sides = _SIDE_STREAMS  # process-wide (geoformer._SIDE_STREAMS: why)
-    side = sides.get((dev, main.cuda_stream))
-    if side is None:
-        side = sides[(dev, main.cuda_stream)] = torch.cuda.Stream(device=dev)
+    side = side_stream_for(dev, main)  # process-wide (geoformer._SIDE_STREAMS: why)
     req = take_phase()
-    if req is None:
+    ahead = take_coords_ready()
+    if ahead is not None and req is not None:
+        main.wait_stream(side)  # (the phased call keeps its own order: the coordinates' copy on the side stream first)
+        ahead = None
+    if req is None and ahead is not None:
+        evs = (ctypes.c_void_p * max(len(ahead), 1))(*[ctypes.c_void_p(e.cuda_event) for e in ahead])
+        rc = lib.gf_unet_fwd_ahead(plan.ref, voxel_feats.data_ptr(), coords.data_ptr(), M, batch_size, X, Y, Z, ws.data_ptr(),
+                                   nbytes, pinned.data_ptr(), out.data_ptr(), stream_ptr(), side.cuda_stream, evs, len(ahead))
+    elif req is None:
         rc = lib.gf_unet_fwd(plan.ref, voxel_feats.data_ptr(), coords.data_ptr(), M, batch_size, X, Y, Z, ws.data_ptr(),
                              nbytes, pinned.data_ptr(), out.data_ptr(), stream_ptr(), side.cuda_stream)
     else:

@@ -69,9 +69,11 @@ int gf_host_legacy_prefetch(const uint32_t* key, int pos, long long nwords);
  * buffer `pinned` (pinned_cap entries, >= k; with >= n the shuffle runs in place there), one asynchronous copy to
  * d_idx32[k], one launch that writes d_idx64[k] (the model's `sampling_indices`) and xyz_dst[k,3] = xyz_src[idx] (n rows).
  * key / pos: the generator's state, advanced in place.  The pinned buffer may be rewritten once the copy has left it
- * (stream order). */
+ * (stream order).  fps_m > 0: gf_furthest_point_sampling(xyz_dst, 1, k, fps_m, fps_idx, fps_scratch) is queued behind the
+ * gather in the same call (geoformer.py:580-581 / pointnet2_utils.furthest_point_sample on the drawn points). */
 int gf_host_draw_sample(uint32_t* key, int32_t* pos, long long n, long long k, int32_t* pinned, long long pinned_cap,
-                        int32_t* d_idx32, long long* d_idx64, const float* xyz_src, float* xyz_dst, void* stream);
+                        int32_t* d_idx32, long long* d_idx64, const float* xyz_src, float* xyz_dst, int fps_m,
+                        int32_t* fps_idx, void* fps_scratch, void* stream);
 
 /* ===================================================================================
  * Sparse convolution (stands in for spconv.ops.get_indice_pairs / indice_conv /
@@ -313,6 +315,16 @@ typedef int (*GfUnetBetween)(void* user, void** events_out, int max_events);
 int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
                        void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream,
                        void* const* gate_events, int n_gate, GfUnetBetween between, void* user);
+
+/* The same with the rulebooks AHEAD of `stream`: index, tables and the down-sampling chain read the voxel coordinates and
+ * nothing else.  input_events: the n_input (>= 0) recorded hipEvent_t the COORDINATES wait for (none: they have been
+ * resident all along); every rulebook launch goes to side_stream behind those events and behind the end of this host
+ * thread's previous gf_unet_fwd* call (which read the same workspace) -- not behind what `stream` still has queued.  In a
+ * loop of forwards they then run under the previous scene's sampling / BFS stretch (test.py:52-96 calls the model scene
+ * after scene).  `feats` and everything else keep `stream`'s order.  Same launches and results; side_stream NULL: gf_unet_fwd. */
+int gf_unet_fwd_ahead(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
+                      void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream,
+                      void* const* input_events, int n_input);
 
 /* ===================================================================================
  * Training criterion: Hungarian matching on the device (model/matcher.py:79-126 moves the cost matrix to the host

@@ -518,3 +518,53 @@ def test_forward_edge_case_scene_matches_oracle_backend(hip, oracle):
     assert (mg["cls_logits"].cpu() - mc["cls_logits"]).abs().max() < 1e-4
     for a, b in zip(mg["mask_logits"], mc["mask_logits"]):
         assert (a.cpu() - b).abs().max() < 1e-4 * max(1.0, float(b.abs().max()))
+
+
+def test_rulebooks_ahead_of_the_callers_stream_change_nothing(hip):
+    """batch["inputs_event"] (GeoFormer._inputs_ahead -> gf_unet_fwd_ahead): the backbone's rulebooks are built on the
+    executor's side stream behind the batch's own events instead of behind what the caller's stream has queued.  Scenes
+    of different sizes alternate on one stream with a long-running kernel queued in front of every forward (so the
+    rulebooks of scene i+1 really are built while scene i's tail and that kernel are still running, into the same
+    workspace): every output equals the plain route's bit for bit; an event list that is not empty is waited for."""
+    from geoformer_amd import scene
+    from geoformer_amd.model import GeoFormer, load_config
+    from tests.util import synthetic_state_dict
+
+    m = GeoFormer(load_config("test_geoformer_scannet.yaml"))
+    m.load_state_dict(synthetic_state_dict(m.state_dict(), 0))
+    m.cuda().eval()
+    hosts = [scene.make_batch([scene.make_small_scene(n, s)]) for n, s in ((24000, 5), (9000, 6), (16000, 7))]
+    plain = [_to_dev(h) for h in hosts]
+    busy = torch.randn(4096, 4096, device="cuda")
+
+    def run(b, seed):
+        np.random.seed(seed)
+        with torch.no_grad():
+            o = m(b, 300, training=False)
+        mp = o["mask_predictions"][-1]
+        return [o["semantic_scores"].clone(), o["fg_idxs"].clone(), mp["cls_logits"].clone(), mp["mask_logits"][0].clone()]
+
+    ref = [run(b, 10 + i) for i, b in enumerate(plain)]
+    torch.cuda.synchronize()
+    ahead = [dict(b, inputs_event=()) for b in plain]
+    for rep in range(3):
+        for i, b in enumerate(ahead):
+            for _ in range(6):
+                busy = busy @ busy * 1e-3  # ~ms of work in front of the forward on the caller's stream
+            got = run(b, 10 + i)
+            for a, g in zip(ref[i], got):
+                assert a.shape == g.shape and torch.equal(a, g), (rep, i)
+    # coordinates that ARE produced by pending work, on another stream: the batch names the event
+    other = torch.cuda.Stream()
+    for i, h in enumerate(hosts):
+        with torch.cuda.stream(other):
+            for _ in range(4):
+                busy2 = busy @ busy * 1e-3
+            locs = h["voxel_locs"].cuda(non_blocking=True) + (busy2[0, 0] * 0).long()  # (queued behind the matmuls)
+            ev = torch.cuda.Event()
+            ev.record(other)
+        b = dict(plain[i], voxel_locs=locs, inputs_event=(ev,))
+        locs.record_stream(torch.cuda.current_stream())
+        got = run(b, 10 + i)
+        for a, g in zip(ref[i], got):
+            assert torch.equal(a, g), i
