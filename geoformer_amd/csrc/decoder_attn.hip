@@ -342,8 +342,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn_bf3(
     const float qx = qloc[((size_t)b * nq + qi) * 3 + 0], qy = qloc[((size_t)b * nq + qi) * 3 + 1],
                 qz = qloc[((size_t)b * nq + qi) * 3 + 2];
     const float lx = lo[b * 3 + 0], ly = lo[b * 3 + 1], lz = lo[b * 3 + 2];
-    const float sx = hi[b * 3 + 0] - lx, sy = hi[b * 3 + 1] - ly, sz = hi[b * 3 + 2] - lz;
-    float sm[4][4], sl[4][4], sa[4][4];  // online softmax: running max, sum, weighted sum
+    // Round 6: the normalisation as one multiplication by a reciprocal taken once (three IEEE divisions per tile and lane
+    // were ~30 instructions), the phases kept in REVOLUTIONS -- v_sin_f32 / v_cos_f32 take revolutions, so the reference's
+    // "* 2 pi" and the intrinsic's "* 1 / (2 pi)" cancel instead of being executed --, and the soft-max in base 2 with
+    // log2(e) / 8 folded into one scale: ~10 % fewer vector instructions per tile and NO change in the launch's time
+    // (80.7 against 81.0 us; without the K1 / Kv loads 77.6: DESIGN.md 7) -- the kernel is not bound by its vector issue.
+    const float ix = 1.0f / (hi[b * 3 + 0] - lx), iy = 1.0f / (hi[b * 3 + 1] - ly), iz = 1.0f / (hi[b * 3 + 2] - lz);
+    constexpr float kScale2 = 0.125f * 1.44269504088896341f;  // sim / sqrt(64), in units of log2
+    float sm[4][4], sl[4][4], sa[4][4];  // online softmax: running max (log2 units), sum, weighted sum
 #pragma unroll
     for (int rb = 0; rb < 4; rb++)
 #pragma unroll
@@ -372,8 +378,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn_bf3(
                 g1 = mg + fabsf(qy - cloc[cc[u] * 3 + 1]);
                 g2 = mg + fabsf(qz - cloc[cc[u] * 3 + 2]);
             }
-            const float t0f = ((g0 - lx) / sx) * 6.2831855f, t1f = ((g1 - ly) / sy) * 6.2831855f,
-                        t2f = ((g2 - lz) / sz) * 6.2831855f;
+            const float t0f = (g0 - lx) * ix, t1f = (g1 - ly) * iy, t2f = (g2 - lz) * iz;  // normalised, in revolutions
             float R[4][4];  // R[kb][s]: channel kb*16 + 4g + s
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -382,10 +387,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn_bf3(
                                     fmaf(t2f, b2v.z, fmaf(t1f, b1.z, t0f * b0.z)), fmaf(t2f, b2v.w, fmaf(t1f, b1.w, t0f * b0.w))};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    float sn, cs;
-                    __sincosf(p[e], &sn, &cs);
-                    R[half][e] = sn;
-                    R[2 + half][e] = cs;
+                    R[half][e] = __builtin_amdgcn_sinf(p[e]);      // sin(2 pi p)
+                    R[2 + half][e] = __builtin_amdgcn_cosf(p[e]);  // cos(2 pi p)
                 }
             }
             da_split_pack(R, RP[u]);
@@ -433,10 +436,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn_bf3(
                 if (valid[u]) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float x = s[u][r] * 0.125f;
+                        const float x = s[u][r] * kScale2;
                         const float val = V[u][rb][r] + kvv[r];
                         const float mn = fmaxf(sm[rb][r], x);
-                        const float corr = __expf(sm[rb][r] - mn), p = __expf(x - mn);
+                        const float corr = __builtin_amdgcn_exp2f(sm[rb][r] - mn), p = __builtin_amdgcn_exp2f(x - mn);
                         sl[rb][r] = sl[rb][r] * corr + p;
                         sa[rb][r] = sa[rb][r] * corr + p * val;
                         sm[rb][r] = mn;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn_bf3(
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int c = rb * 16 + 4 * g + r;
-            const float f = __expf(sm[rb][r] - sRed[0][0][c]);
+            const float f = __builtin_amdgcn_exp2f(sm[rb][r] - sRed[0][0][c]);
             const float l = da_row_sum(sl[rb][r] * f), a = da_row_sum(sa[rb][r] * f);
             if (j == 0) {
                 sRed[1][w][c] = l;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_decoder_cross_attn_bf3(
         }
         out[((size_t)b * nq + qi) * DA_D + tid] = A / L;
         if (stat_m) {
-            stat_m[((size_t)b * nq + qi) * DA_D + tid] = sRed[0][0][tid];
+            stat_m[((size_t)b * nq + qi) * DA_D + tid] = sRed[0][0][tid] * 0.69314718055994531f;  // (natural units: the backward's)
             stat_l[((size_t)b * nq + qi) * DA_D + tid] = L;
         }
     }
