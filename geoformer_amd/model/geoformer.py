@@ -1013,10 +1013,28 @@ class GeoFormer(nn.Module):
                 # the class head on the second stream beside the mask head was measured with tools/ab_inprocess.py:
                 # no difference -- back-to-back small kernels cost ~1.5 us each, not the ~5 us a profiler shows.)
                 rows = pk2.contiguous()
-                cls_logits = pointops.pointwise_mlp(rows, sem_chain).reshape(batch, n_queries, -1)
+                packed = self.output_dim == 16 and self.use_coords
+                cls_done = None
+                if packed and rows.is_cuda and not torch.is_grad_enabled() and batch == 1:
+                    # the class head (a 25 us launch: three dependent 64-wide layers over 256 rows on four workgroups) is
+                    # not what the mask head waits for: on the third stream, beside the tower / controller / mask head
+                    # (tools/ab_inprocess.py, alternating forwards in one process: 4.37 -> 4.32 and 4.38 -> 4.34 ms)
+                    main = torch.cuda.current_stream(rows.device)
+                    aux = _SIDE_STREAMS.get((rows.device, main.cuda_stream, "aux"))
+                    if aux is not None:
+                        rows_ready = torch.cuda.Event()
+                        rows_ready.record(main)
+                        aux.wait_event(rows_ready)
+                        with torch.cuda.stream(aux):
+                            cls_logits = pointops.pointwise_mlp(rows, sem_chain).reshape(batch, n_queries, -1)
+                            cls_done = torch.cuda.Event()
+                            cls_done.record(aux)
+                        rows.record_stream(aux)
+                        cls_logits.record_stream(main)
+                if cls_done is None:
+                    cls_logits = pointops.pointwise_mlp(rows, sem_chain).reshape(batch, n_queries, -1)
                 emb = pointops.pointwise_mlp(rows, tow_chain)
                 controllers = F.linear(emb, self.controller.weight[:, :, 0], self.controller.bias)
-                packed = self.output_dim == 16 and self.use_coords
             else:
                 cls_logits = self.detr_sem_head(pk.permute(1, 2, 0)).transpose(1, 2)  # B x nq x classes
                 controllers = self.controller(self.before_embedding_tower(pk2.unsqueeze(2))).squeeze(2)
@@ -1044,6 +1062,8 @@ class GeoFormer(nn.Module):
                     ml = self.mask_heads_forward(geo_dists[b], mask_features[s:e], weights, biases, n_queries,
                                                  locs_float_[s:e], fps_sampling_locs[b], use_geo=self.use_coords)
                 mask_logits_list.append(ml.squeeze(0))
+            if packed and cls_done is not None:
+                torch.cuda.current_stream(cls_logits.device).wait_event(cls_done)  # (behind the mask head's launch)
             outputs.append({"cls_logits": cls_logits, "mask_logits": mask_logits_list})
         for b, ctrls in train_ctrl.items():
             mf_b, locs_b, g, fps_b, mx = per_scene[b]
