@@ -124,7 +124,8 @@ def _declare(lib):
         "gf_host_legacy_prefetch": (I, [P, I, c_longlong]),
         "gf_host_draw_sample": (I, [P, P, c_longlong, c_longlong, P, c_longlong, P, P, P, P, I, P, P, P]),
         "gf_fg_scratch_bytes": (c_size_t, [I]),
-        "gf_fg_select": (I, [P, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P]),
+        "gf_fg_select": (I, [P, I, I, I, I, P, P, P, P, I, P, P, P, P, P, P, P, P, P]),
+        "gf_host_wait_word": (I, [P, I, c_longlong]),
         "gf_proposal_stats": (I, [P, P, P, I, I, I, F, F, I, I, P, P, P, P, P]),
         "gf_proposal_stats_fs": (I, [P, P, I, I, F, F, I, F, P, P, P, P]),
         "gf_proposal_scatter": (I, [P, P, I, I, P, F, I, P, P]),

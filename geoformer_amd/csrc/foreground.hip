@@ -7,6 +7,8 @@
 // of the block counts, and an ordered compaction that writes the index list and the four gathered tensors in place
 // (outputs are allocated at capacity N, the caller slices them to the count).
 //   arg-max: first maximal class (strict '>' in ascending class order), as torch.max on a row without ties.
+#include <time.h>
+
 #include "common.h"
 
 #define FG_THREADS 256
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(FG_THREADS) void k_fg_flags(const float* __restrict
 
 // single workgroup: exclusive scan of the block counts, total -> *d_count
 __global__ __launch_bounds__(SCAN_THREADS) void k_fg_scan(const int32_t* __restrict__ block_counts, int nb,
-                                                         int32_t* __restrict__ block_offs, int32_t* __restrict__ d_count) {
+                                                         int32_t* __restrict__ block_offs, int32_t* __restrict__ d_count,
+                                                         int32_t* __restrict__ h_count) {
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -68,7 +71,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_fg_scan(const int32_t* __restr
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *d_count = carry_s;
+    if (threadIdx.x == 0) {
+        *d_count = carry_s;
+        if (h_count) {  // the host polls this word: out of the device now, not at the end of the launch
+            __hip_atomic_store(h_count, carry_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+        }
+    }
 }
 
 __global__ __launch_bounds__(FG_THREADS) void k_fg_compact(const unsigned char* __restrict__ flags, int N,
@@ -136,7 +145,7 @@ extern "C" int gf_fg_select(const float* scores, int N, int C, int cls, int mode
                             const int32_t* batch_idxs, const float* feats, const int32_t* feat_rows, int F,
                             void* scratch, long long* fg_idxs,
                             float* locs_out, int32_t* bidx_out, float* feats_out, float* scores_out, int32_t* d_count,
-                            void* stream) {
+                            int32_t* h_count, void* stream) {
     GF_CHECK_ARG(scores && scratch && fg_idxs && d_count, "gf_fg_select: null argument");
     GF_CHECK_ARG(N >= 0 && C >= 1 && (mode == 0 || mode == 1), "gf_fg_select: N=%d C=%d mode=%d", N, C, mode);
     GF_CHECK_ARG((locs_out == nullptr || locs) && (bidx_out == nullptr || batch_idxs) && (feats_out == nullptr || (feats && F >= 1)),
@@ -150,12 +159,33 @@ extern "C" int gf_fg_select(const float* scores, int N, int C, int cls, int mode
     int32_t* block_offs = block_counts + nb;
     if (N == 0) {
         GF_TRY(hipMemsetAsync(d_count, 0, sizeof(int32_t), st));
+        if (h_count) *h_count = 0;
         return GF_OK;
     }
     hipLaunchKernelGGL(k_fg_flags, dim3(nb), dim3(FG_THREADS), 0, st, scores, N, C, cls, mode, flags, block_counts);
-    hipLaunchKernelGGL(k_fg_scan, dim3(1), dim3(SCAN_THREADS), 0, st, block_counts, nb, block_offs, d_count);
+    hipLaunchKernelGGL(k_fg_scan, dim3(1), dim3(SCAN_THREADS), 0, st, block_counts, nb, block_offs, d_count, h_count);
     hipLaunchKernelGGL(k_fg_compact, dim3(nb), dim3(FG_THREADS), 0, st, flags, N, block_offs, scores, C, locs, batch_idxs,
                        feats, feat_rows, F, fg_idxs, locs_out, bidx_out, feats_out, scores_out);
     GF_CHECK_LAUNCH("gf_fg_select");
     return GF_OK;
+}
+
+// Host helper of the h_count protocol above: wait for a word a kernel stores to host memory, without a system call
+extern "C" int gf_host_wait_word(const volatile int32_t* word, int pending, long long timeout_us) {
+    if (!word) return pending;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0;; spins++) {
+        const int v = *word;
+        if (v != pending) return v;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 1023u) == 1023u) {
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const long long us = (long long)(t1.tv_sec - t0.tv_sec) * 1000000LL + (t1.tv_nsec - t0.tv_nsec) / 1000;
+            if (us >= timeout_us) return *word;
+        }
+    }
 }

@@ -9,8 +9,6 @@ from __future__ import annotations
 import contextlib
 import threading
 
-import os
-
 import numpy as np
 import torch
 
@@ -168,39 +166,62 @@ def select_foreground(scores, cls, equal, locs, batch_idxs, feats, feat_rows=Non
     feats_o = torch.empty((N, F), dtype=torch.float32, device=dev)
     scores_o = torch.empty((N, C), dtype=torch.float32, device=dev)
     cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    host = PendingForeground.take_word() if deferred else None  # (pinned, set to -1: the scan kernel stores the count there)
     check(lib.gf_fg_select(ptr(scores), N, C, int(cls), int(bool(equal)), ptr(locs), ptr(batch_idxs), ptr(feats),
                            ptr(feat_rows), F,
                            ptr(scratch), ptr(fg), ptr(locs_o), ptr(bidx_o), ptr(feats_o), ptr(scores_o), ptr(cnt),
-                           stream_ptr()), "gf_fg_select")
+                           ptr(host), stream_ptr()), "gf_fg_select")
     if not deferred:
         n = int(cnt.item())
         return fg[:n], locs_o[:n], bidx_o[:n], feats_o[:n], scores_o[:n]
-    return PendingForeground(cnt, (fg, locs_o, bidx_o, feats_o, scores_o))
+    return PendingForeground(cnt, (fg, locs_o, bidx_o, feats_o, scores_o), host)
 
 
 class PendingForeground:
-    """select_foreground(..., deferred=True): the launches and the asynchronous copy of the count are queued; ``get()``
-    waits for the count and returns the five views.  (The staggered serving loop queues a scene's selection with its
-    backbone and comes back for the count after it has queued the next scene's first launches.)"""
+    """select_foreground(..., deferred=True): the launches are queued; ``wait()`` returns the count, ``views()`` the five
+    slices.  The count reaches the host through a pinned word the scan kernel stores it to (gf_fg_select's h_count): no copy
+    command, no event, and BEFORE the gathers of the outputs have run -- the host polls the word natively
+    (gf_host_wait_word, interpreter lock released) and starts on what follows the count while the device finishes the
+    selection.  (The staggered serving loop queues a scene's selection with its backbone and comes back for the count after
+    it has queued the next scene's first launches.)"""
 
     _pinned = []
     _lock = threading.Lock()
 
-    def __init__(self, cnt, bufs):
+    @staticmethod
+    def take_word():
         with PendingForeground._lock:
             host = PendingForeground._pinned.pop() if PendingForeground._pinned else None
         if host is None:
             host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        host.copy_(cnt, non_blocking=True)
+        host[0] = -1
+        return host
+
+    def __init__(self, cnt, bufs, host=None):
+        self.polled = host is not None
+        if host is None:  # (no polled word: the count as an asynchronous copy behind the selection, waited for by event)
+            host = PendingForeground.take_word()
+            host.copy_(cnt, non_blocking=True)
         self.host, self.bufs, self.cnt = host, bufs, cnt
-        self.done = torch.cuda.Event()
+        self.done = torch.cuda.Event()  # behind the whole selection (what other streams wait for before they read it)
         self.done.record()
 
     def wait(self):
         """Block until the count is on the host; returns it.  (``views()`` afterwards: the five slices -- a caller with
         something urgent to launch from the count alone does that in between.)"""
-        _lib.timed_wait(self.done)  # (polling the pinned word instead: no difference, 219 scenes/s either way)
-        self.n = int(self.host[0])
+        import time
+
+        t = time.perf_counter()
+        if self.polled:
+            n = int(_lib.load().gf_host_wait_word(self.host.data_ptr(), -1, 5_000_000))
+            if n < 0:  # (five seconds without the store: the event and a plain read-back)
+                self.done.synchronize()
+                n = int(self.cnt.item())
+        else:
+            self.done.synchronize()
+            n = int(self.host[0])
+        _lib.host_wait_s[0] += time.perf_counter() - t
+        self.n = n
         with PendingForeground._lock:
             PendingForeground._pinned.append(self.host)
         self.host = None

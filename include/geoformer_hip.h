@@ -46,11 +46,18 @@ const char* gf_last_error(void);
  *   (the p2v map), fp32 [M,F] voxel rows read as feats[feat_rows[p]]  (sources, any may be NULL together with its
  *   output);  fg_idxs int64 [N], locs_out [N,3], bidx_out [N], feats_out [N,F],
  *   scores_out [N,C]: capacity N, the first *d_count rows are valid;  scratch: gf_fg_scratch_bytes(N).
+ *   h_count (may be NULL): a word of PINNED host memory the count is ALSO stored to, with system scope, by the scan that
+ *   finds it -- i.e. before the gathers of the four outputs run, and without a copy command or an event in between: the
+ *   caller sets it to a negative value before the call and polls it (gf_host_wait_word); everything it then queues on
+ *   `stream` is behind the gathers by stream order.  N = 0 stores 0 to it from the host.
  * =================================================================================== */
 size_t gf_fg_scratch_bytes(int N);
 int gf_fg_select(const float* scores, int N, int C, int cls, int mode, const float* locs, const int32_t* batch_idxs,
                  const float* feats, const int32_t* feat_rows, int F, void* scratch, long long* fg_idxs, float* locs_out,
-                 int32_t* bidx_out, float* feats_out, float* scores_out, int32_t* d_count, void* stream);
+                 int32_t* bidx_out, float* feats_out, float* scores_out, int32_t* d_count, int32_t* h_count, void* stream);
+/* Host helper: spin (pause instructions, no system call) until *word != pending or timeout_us have passed; returns the
+ * word's value (== pending: timed out).  `word`: host memory a device kernel stores to with system scope (h_count above). */
+int gf_host_wait_word(const volatile int32_t* word, int pending, long long timeout_us);
 
 /* ===================================================================================
  * Host helper (CPU code, no launch): the reference's per-scene sampling draw
