@@ -7,6 +7,7 @@ the current stream.  The module-shaped mirrors of the reference bindings live in
 from __future__ import annotations
 
 import contextlib
+import os
 import threading
 
 import numpy as np
