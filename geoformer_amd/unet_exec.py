@@ -211,8 +211,17 @@ def unet_forward(model, voxel_feats, coords, batch_size, spatial_shape):
     side = side_stream_for(dev, main)  # process-wide (geoformer._SIDE_STREAMS: why)
     req = take_phase()
     ahead = take_coords_ready()
-    if ahead is not None and req is not None:
-        main.wait_stream(side)  # (the phased call keeps its own order: the coordinates' copy on the side stream first)
+    # A workspace block that is NEW to this stream may alias memory the framework's allocator handed back while kernels of
+    # the caller's stream that use it are still queued (the allocator relies on stream order): only a block this stream has
+    # been using all along may be written AHEAD of the stream's queue.
+    fresh = getattr(_tls, "ws_ptrs", None)
+    if fresh is None:
+        fresh = _tls.ws_ptrs = {}
+    ws_key = (dev.index, main.cuda_stream)
+    ws_is_new = fresh.get(ws_key) != ws.data_ptr()
+    fresh[ws_key] = ws.data_ptr()
+    if ahead is not None and (req is not None or ws_is_new):
+        main.wait_stream(side)  # (the call keeps the stream's own order: the coordinates' copy on the side stream first)
         ahead = None
     if req is None and ahead is not None:
         evs = (ctypes.c_void_p * max(len(ahead), 1))(*[ctypes.c_void_p(e.cuda_event) for e in ahead])
