@@ -393,7 +393,16 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
     // convolutions (where the 36-launch serial chain has to go, below) its two fat kernels overlap the first two of
     // them (rocprofv3: 20.5 instead of 18.7 us per level-1 launch)
     const bool chain_first = nl > 0 && gf_rules_level_parallel();
-    if (ahead) UN_TRY(fork_side());
+    if (ahead) {
+        // the first level's index and table FIRST on the side stream -- they are what the first convolution waits for --, the
+        // chain behind them: with nothing of a previous scene to hide under (a loop that waits for every scene's results) the
+        // chain's ~0.11 ms would otherwise sit in front of the first convolution instead of beside the first level's
+        UN_TRY(fork_side());
+        UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, ss));
+        UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, ss));
+        GF_TRY(hipEventRecord(t_ev.tbl0, ss));
+        GF_TRY(hipStreamWaitEvent(st, t_ev.tbl0, 0));  // (the first level's convolutions read its table)
+    }
     if (chain_first) {
         if (!ahead) UN_TRY(fork_side());
         UN_TRY(gf_rules_down2_chain_all(coords, M0, B, X, Y, Z, nl, cws, d_counts, ss));
@@ -401,8 +410,10 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         GF_TRY(hipEventRecord(t_ev.chain, ss));
         if (nl > 1) GF_TRY(hipEventRecord(t_ev.chain2, ss));
     }
-    UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, s_rules));
-    UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, s_rules));
+    if (!ahead) {
+        UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, st));
+        UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, st));
+    }
     // the first level's flat step table (its one reader is the up pass's 32 -> 16 convolution, the last block of the call):
     // built on the side stream BEHIND the deeper levels' tables, i.e. beside the second level's convolutions -- beside the
     // first level's own it cost them 18 -> 31 us per launch (profiles/r6_conv_lw_notes.md)
@@ -420,8 +431,7 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         }
         return gf_rules_flat_steps(T[0].nbr, T[0].gmask, 27, M0, ld0, 0, T[0].flat, st);
     };
-    if (forked) GF_TRY(hipEventRecord(t_ev.tbl0, s_rules));
-    if (ahead) GF_TRY(hipStreamWaitEvent(st, t_ev.tbl0, 0));  // (the first level's convolutions read its table)
+    if (forked && !ahead) GF_TRY(hipEventRecord(t_ev.tbl0, st));
 
     // feature buffers are carved after the counts are known for the levels below the first; level 1 now
     int M[GF_UNET_MAX_LEVELS];

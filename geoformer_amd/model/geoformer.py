@@ -452,7 +452,14 @@ class GeoFormer(nn.Module):
         locs = batch_input["voxel_locs"]
         if evs is None or not locs.is_cuda or torch.is_grad_enabled() or os.environ.get("GF_UNET_EXEC", "1") == "0":
             return None
+        if unet_exec.phase_pending():
+            return None  # (the staggered loop's phased call orders its rulebooks itself)
         main = torch.cuda.current_stream(locs.device)
+        if main.query():
+            # nothing queued on the caller's stream (a loop that waits for every scene's results): there is nothing to get
+            # ahead of, and the cross-stream hand-overs of the route below only cost (-1.5 ... -2.7 % on bench.py's
+            # synchronous_no_deferral / test_py_shape legs with them, +1.0 % on the headline loop: alternating runs)
+            return None
         return main, unet_exec.side_stream_for(locs.device, main), list(evs)
 
     def unet_features(self, x, batch_size):
@@ -1015,10 +1022,12 @@ class GeoFormer(nn.Module):
                 rows = pk2.contiguous()
                 packed = self.output_dim == 16 and self.use_coords
                 cls_done = None
-                if packed and rows.is_cuda and not torch.is_grad_enabled() and batch == 1:
+                if packed and rows.is_cuda and not torch.is_grad_enabled() and batch == 1 and not pointops.co_resident():
                     # the class head (a 25 us launch: three dependent 64-wide layers over 256 rows on four workgroups) is
                     # not what the mask head waits for: on the third stream, beside the tower / controller / mask head
-                    # (tools/ab_inprocess.py, alternating forwards in one process: 4.37 -> 4.32 and 4.38 -> 4.34 ms)
+                    # (tools/ab_inprocess.py, alternating forwards in one process: 4.37 -> 4.32 and 4.38 -> 4.34 ms; NOT in a
+                    #  serving loop's last part, which runs beside the next scene's stretch on the other lane: there the
+                    #  extra stream cost the staggered loop 5 % -- 231 -> 220 scenes/s, bisected on one box)
                     main = torch.cuda.current_stream(rows.device)
                     aux = _SIDE_STREAMS.get((rows.device, main.cuda_stream, "aux"))
                     if aux is not None:

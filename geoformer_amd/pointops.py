@@ -1054,6 +1054,11 @@ def co_resident_launches():
         _launch_cfg.cross_attn_waves = old
 
 
+def co_resident():
+    """Whether this host thread is inside ``co_resident_launches`` (a serving loop's SplitForward.finish())."""
+    return getattr(_launch_cfg, "cross_attn_waves", 16) != 16
+
+
 def decoder_cross_attn(geo_ctx, max_geo, qloc, cloc, lo, hi, gaussB, Q1, K1, Kv, wpack, b2):
     """Fused vector cross-attention; shapes as in include/geoformer_hip.h.  Returns [B,nq,64]."""
     for t, name in ((geo_ctx, "geo_ctx"), (max_geo, "max_geo"), (qloc, "qloc"), (cloc, "cloc"), (lo, "lo"), (hi, "hi"),

@@ -157,6 +157,11 @@ def phase_next_forward(gate_events, between):
     _tls.phase = (list(gate_events or ()), between)
 
 
+def phase_pending():
+    """Whether a phase request is waiting for the next unet_forward of this host thread."""
+    return getattr(_tls, "phase", None) is not None
+
+
 def take_phase():
     """The pending phase request (gate events, callable) that no unet_forward has consumed, or None; clears it."""
     req = getattr(_tls, "phase", None)
