@@ -52,32 +52,40 @@ __device__ __forceinline__ f32x4 mfma4(float4 a, float4 b, f32x4 acc) {
     return acc;
 }
 
-// one 16-row tile: epi(r, col, act(sum_k A[r][k] W[col][k] + b[col])) for the column tiles ct = wave, wave+nw, ...
-// A in LDS or global memory (row stride lda); rows >= nvalid read as zero and are not emitted
+// one 16-row tile: epi(r, col, act(sum_k A[r][k] W[col][k] + b[col]) (+ addend[r][col])) for the column tiles ct = wave,
+// wave+nw, ...  A in LDS or global memory (row stride lda); rows >= nvalid read as zero and are not emitted.  The bias and the
+// epilogue's global operand (`addend`, row stride add_ld) are requested before the products (decoder_layer.h: why).
 template <bool RELU, typename Epi>
 __device__ __forceinline__ void bt_tile_gemm(const float* A, int lda, int nvalid, int K, const float* __restrict__ W,
                                              const float* __restrict__ bias, int N, int wave, int nwaves, int lane,
-                                             Epi epi) {
+                                             Epi epi, const float* __restrict__ addend = nullptr, int add_ld = 0) {
     const int j = lane & 15, g = lane >> 4;
     const int KC = K >> 4;
     for (int ct = wave; ct < (N >> 4); ct += nwaves) {
         const float* xa = A + (size_t)j * lda + 4 * g;
         const float* wb = W + (size_t)(ct * 16 + j) * K + 4 * g;
+        const int col = ct * 16 + j;
+        const float bs = bias[col];
+        float ad[4] = {0.f, 0.f, 0.f, 0.f};
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * g + i < nvalid) ad[i] = addend[(size_t)(4 * g + i) * add_ld + col];
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
         for (int kc = 0; kc < KC; kc++) {
             float4 a = j < nvalid ? *reinterpret_cast<const float4*>(xa + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 b = *reinterpret_cast<const float4*>(wb + kc * 16);
             acc = mfma4(a, b, acc);
         }
-        const int col = ct * 16 + j;
-        const float bs = bias[col];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = 4 * g + i;
             if (r >= nvalid) continue;
             float v = acc[i] + bs;
             if (RELU) v = fmaxf(v, 0.f);
+            if (addend) v += ad[i];
             epi(r, col, v);
         }
     }
@@ -90,14 +98,10 @@ __device__ __forceinline__ void bt_tile_norm(const float (*S)[BT_LD], int nvalid
     const float a0 = alpha[2 * lane], a1 = alpha[2 * lane + 1], b0 = beta[2 * lane], b1 = beta[2 * lane + 1];
     for (int r = wave; r < nvalid; r += nwaves) {
         const float2 v = *reinterpret_cast<const float2*>(&S[r][2 * lane]);
-        float s = v.x + v.y;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float s = gf_wave_sum(v.x + v.y);  // (the __shfl_xor butterfly without the LDS crossbar: common.h)
         const float mu = s / (float)BT_D;
         const float dx = v.x - mu, dy = v.y - mu;
-        float q = dx * dx + dy * dy;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float q = gf_wave_sum(dx * dx + dy * dy);
         const float den = sqrtf(q / (float)(BT_D - 1)) + 1e-6f;
         out(r, 2 * lane, a0 * dx / den + b0, a1 * dy / den + b1);
     }
@@ -140,12 +144,9 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_pre(const float* __restrict__
             a1 += xyz[t * 4 + 2];
             a2 += xyz[t * 4 + 3];
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            a0 += __shfl_xor(a0, d, 64);
-            a1 += __shfl_xor(a1, d, 64);
-            a2 += __shfl_xor(a2, d, 64);
-        }
+        a0 = gf_wave_sum_i(a0);
+        a1 = gf_wave_sum_i(a1);
+        a2 = gf_wave_sum_i(a2);
         if (lane == 0 && wave * 64 < T) {
             atomicAdd(&psum[0], a0);
             atomicAdd(&psum[1], a1);
@@ -238,8 +239,8 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_layer(const int* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; i++) scv[i] = (kt * 16 + 4 * g + i) < T ? s[i] * scale : -INFINITY;
             float mx = fmaxf(fmaxf(scv[0], scv[1]), fmaxf(scv[2], scv[3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, gf_shfl_xor<16>(mx));
+            mx = fmaxf(mx, gf_shfl_xor<32>(mx));
             const float mnew = fmaxf(m, mx);  // finite: key 0 of tile 0 always exists
             const float corr = expf(m - mnew);
             float p[4];
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_layer(const int* __restrict__
                 v1[i] = u1[i];
             }
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l += gf_shfl_xor<16>(l);
+        l += gf_shfl_xor<32>(l);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             sO[j][h * BT_DK + 4 * g + i] = o0[i] / l;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_layer(const int* __restrict__
     // x += out(O)
     const float* xg = X + (size_t)t0 * BT_D;
     bt_tile_gemm<false>(&sO[0][0], BT_LD, nvalid, BT_D, L.ow, L.ob, BT_D, wave, nw, lane,
-                        [&](int r, int col, float v) { sX[r][col] = xg[r * BT_D + col] + v; });
+                        [&](int r, int col, float v) { sX[r][col] = v; }, xg, BT_D);
     __syncthreads();
     bt_tile_norm(sX, nvalid, L.n2a, L.n2b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
         sT[r][c2] = v0;
@@ -510,24 +511,17 @@ __device__ __forceinline__ void bt_tile_norm_bwd(const float (*X)[BT_LD], const 
             continue;
         }
         const float2 v = *reinterpret_cast<const float2*>(&X[r][2 * lane]);
-        float s = v.x + v.y;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float s = gf_wave_sum(v.x + v.y);  // (the __shfl_xor butterfly without the LDS crossbar: common.h)
         const float mu = s / (float)BT_D;
         const float dx = v.x - mu, dy = v.y - mu;
-        float q = dx * dx + dy * dy;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float q = gf_wave_sum(dx * dx + dy * dy);
         const float sd = sqrtf(q / (float)(BT_D - 1));
         const float den = sd + 1e-6f;
         const float2 gy = *reinterpret_cast<const float2*>(&G[r][2 * lane]);
         const float g0 = gy.x * a0, g1 = gy.y * a1;
         float sg = g0 + g1, sgx = g0 * dx + g1 * dy;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            sg += __shfl_xor(sg, d, 64);
-            sgx += __shfl_xor(sgx, d, 64);
-        }
+        sg = gf_wave_sum(sg);
+        sgx = gf_wave_sum(sgx);
         const float mg = sg / (float)BT_D;
         const float k = sd > 0.f ? sgx / (den * den * sd * (float)(BT_D - 1)) : 0.f;
         out(r, 2 * lane, (g0 - mg) / den - dx * k, (g1 - mg) / den - dy * k);
@@ -569,12 +563,9 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_train_pre(const float* __rest
             a1 += xyz[t * 4 + 2];
             a2 += xyz[t * 4 + 3];
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            a0 += __shfl_xor(a0, d, 64);
-            a1 += __shfl_xor(a1, d, 64);
-            a2 += __shfl_xor(a2, d, 64);
-        }
+        a0 = gf_wave_sum_i(a0);
+        a1 = gf_wave_sum_i(a1);
+        a2 = gf_wave_sum_i(a2);
         if (lane == 0 && wave * 64 < T) {
             atomicAdd(&psum[0], a0);
             atomicAdd(&psum[1], a1);
@@ -657,8 +648,8 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_train_layer(int c, int li, Bt
 #pragma unroll
             for (int i = 0; i < 4; i++) scv[i] = (kt * 16 + 4 * g + i) < T ? s[i] * scale : -INFINITY;
             float mx = fmaxf(fmaxf(scv[0], scv[1]), fmaxf(scv[2], scv[3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, gf_shfl_xor<16>(mx));
+            mx = fmaxf(mx, gf_shfl_xor<32>(mx));
             const float mnew = fmaxf(m, mx);
             const float corr = expf(m - mnew);
             float p[4];
@@ -675,8 +666,8 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_train_layer(int c, int li, Bt
                 o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[i], pd, o1, 0, 0, 0);
             }
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l += gf_shfl_xor<16>(l);
+        l += gf_shfl_xor<32>(l);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             sO[j][h * BT_DK + 4 * g + i] = o0[i] / l;

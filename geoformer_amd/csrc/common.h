@@ -68,6 +68,57 @@ bool gf_rules_level_parallel();
 
 static inline int gf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// lane i <- lane i ^ D of a 64-lane wave WITHOUT the LDS crossbar (__shfl_xor is ds_bpermute_b32: ~120 cycles of latency per
+// step, and a wave reduction is six dependent steps): v_permlane32_swap / v_permlane16_swap (gfx950) for the two steps across
+// 16-lane rows, DPP row operations inside a row.  Same values as __shfl_xor(v, D, 64) -- a reduction keeps its order.
+template <int D>
+__device__ __forceinline__ float gf_shfl_xor(float v) {
+    static_assert(D == 32 || D == 16 || D == 8 || D == 4 || D == 2 || D == 1, "gf_shfl_xor: D = 1, 2, 4, 8, 16, 32");
+    const unsigned x = __float_as_uint(v);
+    if constexpr (D == 32) {
+        // swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second; with both = x the pair holds x[i ^ 32]
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return __uint_as_float((__lane_id() & 32) ? r[0] : r[1]);
+    } else if constexpr (D == 16) {
+        // swap: odd 16-lane rows of the first operand <-> even rows of the second
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return __uint_as_float((__lane_id() & 16) ? r[0] : r[1]);
+    } else if constexpr (D == 8) {
+        return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xF, 0xF, false));  // row_ror:8
+    } else if constexpr (D == 4) {
+        // banks 0, 2 (lanes 0-3, 8-11 of a row) read lane + 4 (row_shl:4), banks 1, 3 read lane - 4 (row_shr:4)
+        const int t = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xF, 0x5, false);
+        return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false));
+    } else if constexpr (D == 2) {
+        return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    } else {
+        return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    }
+}
+template <int D>
+__device__ __forceinline__ int gf_shfl_xor_i(int v) {  // (pure lane moves: the bit pattern travels unchanged)
+    return __float_as_int(gf_shfl_xor<D>(__int_as_float(v)));
+}
+__device__ __forceinline__ int gf_wave_sum_i(int s) {
+    s += gf_shfl_xor_i<32>(s);
+    s += gf_shfl_xor_i<16>(s);
+    s += gf_shfl_xor_i<8>(s);
+    s += gf_shfl_xor_i<4>(s);
+    s += gf_shfl_xor_i<2>(s);
+    s += gf_shfl_xor_i<1>(s);
+    return s;
+}
+// sum over the wave with the order of `for (d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d)`
+__device__ __forceinline__ float gf_wave_sum(float s) {
+    s += gf_shfl_xor<32>(s);
+    s += gf_shfl_xor<16>(s);
+    s += gf_shfl_xor<8>(s);
+    s += gf_shfl_xor<4>(s);
+    s += gf_shfl_xor<2>(s);
+    s += gf_shfl_xor<1>(s);
+    return s;
+}
+
 // ---- LDS-weight convolution over a flat step table (spconv_lw.hip; dispatched by gf_conv_fwd when a flat table is given) ----
 // flat step table (spconv_rules.hip gf_rules_flat_steps writes it):
 //   header   [0] steps S, [1] bins NB, [2] groups, [3] K, [4] rounds J = ceil(groups / NB)

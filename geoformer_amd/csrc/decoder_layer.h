@@ -23,32 +23,43 @@ __device__ __forceinline__ f32x4 dl_mfma4(float4 a, float4 b, f32x4 acc) {
 #define DL_LD 68     // padded LDS row (floats): 16 rows x float4 reads without bank conflicts
 #define DL_LDH 260
 
-// one 16-row tile: out(r, col, act(sum_k A[r][k] W[col][k] + b[col])) for the column tiles ct = wave, wave+nw, ...
-// A may live in LDS or global memory (row stride lda); rows >= nvalid read as zero and are not emitted
+// one 16-row tile: out(r, col, act(sum_k A[r][k] W[col][k] + b[col]) (+ addend[r][col])) for the column tiles ct = wave,
+// wave+nw, ...  A may live in LDS or global memory (row stride lda); rows >= nvalid read as zero and are not emitted.
+// A phase of the token-side kernels is one of these between two barriers, and what it costs is its dependent memory round
+// trips, not its 16-64 MFMAs (cycle stamps, round 6: ~5 000 cycles per phase whatever its size): the bias and the
+// epilogue's global operand (`addend`, row stride add_ld: a residual row the caller would otherwise read inside `epi`) are
+// therefore requested BEFORE the products, beside the weights, instead of one after the other behind them.
 template <bool RELU, typename Epi>
 __device__ __forceinline__ void dl_tile_gemm(const float* A, int lda, int nvalid, int K, const float* __restrict__ W,
                                              const float* __restrict__ bias, int N, int wave, int nwaves, int lane,
-                                             Epi epi) {
+                                             Epi epi, const float* __restrict__ addend = nullptr, int add_ld = 0) {
     const int j = lane & 15, g = lane >> 4;
     const int KC = K >> 4;
     for (int ct = wave; ct < (N >> 4); ct += nwaves) {
         const float* xa = A + (size_t)j * lda + 4 * g;
         const float* wb = W + (size_t)(ct * 16 + j) * K + 4 * g;
+        const int col = ct * 16 + j;
+        const float bs = bias[col];
+        float ad[4] = {0.f, 0.f, 0.f, 0.f};
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * g + i < nvalid) ad[i] = addend[(size_t)(4 * g + i) * add_ld + col];
+        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
         for (int kc = 0; kc < KC; kc++) {
             float4 a = j < nvalid ? *reinterpret_cast<const float4*>(xa + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 b = *reinterpret_cast<const float4*>(wb + kc * 16);
             acc = dl_mfma4(a, b, acc);
         }
-        const int col = ct * 16 + j;
-        const float bs = bias[col];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = 4 * g + i;
             if (r >= nvalid) continue;
             float v = acc[i] + bs;
             if (RELU) v = fmaxf(v, 0.f);
+            if (addend) v += ad[i];
             epi(r, col, v);
         }
     }
@@ -63,14 +74,12 @@ __device__ __forceinline__ void dl_tile_layernorm(const float (*S)[DL_LD], int n
     const float wl = w[lane], bl = b[lane];
     for (int r = wave; r < nvalid; r += nwaves) {
         const float v = S[r][lane];
-        float s = v;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        // (gf_wave_sum: the same butterfly as six __shfl_xor steps without the LDS crossbar -- a norm of 16 rows by four
+        //  waves was 48 dependent ds_bpermute round trips, ~5 300 cycles)
+        const float s = gf_wave_sum(v);
         const float mu = s / (float)DL_D;
         const float dv = v - mu;
-        float q = dv * dv;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float q = gf_wave_sum(dv * dv);
         const float rstd = 1.0f / sqrtf(q / (float)DL_D + 1e-5f);
         out(r, lane, dv * rstd * wl + bl);
     }

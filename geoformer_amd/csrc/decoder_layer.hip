@@ -28,6 +28,19 @@ struct DlPre {
 
 #define DL_TILE_THREADS 256
 
+#ifdef DL_TRACE
+// dev build (tools/trace_decoder_stage.py; -DDL_TRACE via tools/build_variant.sh): cycle stamps of thread 0 of every workgroup
+// at the phase boundaries -- stage A in words 0..8, stage B in words 16..22 of the workgroup's 32-word slot
+__device__ unsigned long long* g_dl_trace = nullptr;
+extern "C" int gf_dev_dl_trace(void* p) {
+    GF_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dl_trace), &p, sizeof(p)));
+    return GF_OK;
+}
+#define DL_STAMP(k) do { if (g_dl_trace && threadIdx.x == 0) g_dl_trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x)) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DL_STAMP(k) do { } while (0)
+#endif
+
 // Stage A, token-parallel (one workgroup per 16 tokens): the post part of a layer and the pre part of the next up
 // to the q/k/v projections of the self-attention.  State in global memory: X (running target), TGT2, QKV.
 __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float* __restrict__ attn_out,
@@ -44,20 +57,25 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float
     float* TGT2 = X + (size_t)T * DL_D;
     float* QKV = TGT2 + (size_t)T * DL_D;
     const int lds = B * DL_D;  // row stride of the [T,B,64] tensors
+    DL_STAMP(0);
     if (has_post) {
         // tgt = relu(out_mlp(attn)) + tgt2
         const float* tg = TGT2 + (size_t)t0 * DL_D;
         dl_tile_gemm<true>(attn_out + ((size_t)b * T + t0) * DL_D, DL_D, nvalid, DL_D, po.omw, po.omb, DL_D, wave, nw,
-                           lane, [&](int r, int c, float v) { sX[r][c] = v + tg[r * DL_D + c]; });
+                           lane, [&](int r, int c, float v) { sX[r][c] = v; }, tg, DL_D);
         __syncthreads();
+        DL_STAMP(1);
         dl_tile_layernorm(sX, nvalid, po.n3w, po.n3b, wave, nw, lane, [&](int r, int c, float v) { sT[r][c] = v; });
         __syncthreads();
+        DL_STAMP(2);
         dl_tile_gemm<true>(&sT[0][0], DL_LD, nvalid, DL_D, po.l1w, po.l1b, ff, wave, nw, lane,
                            [&](int r, int c, float v) { sH[r][c] = v; });
         __syncthreads();
+        DL_STAMP(3);
         dl_tile_gemm<false>(&sH[0][0], DL_LDH, nvalid, ff, po.l2w, po.l2b, DL_D, wave, nw, lane,
                             [&](int r, int c, float v) { sX[r][c] += v; });
         __syncthreads();
+        DL_STAMP(4);
         float* io = inter_out + (size_t)t0 * lds + b * DL_D;
         dl_tile_layernorm(sX, nvalid, po.fnw, po.fnb, wave, nw, lane,
                           [&](int r, int c, float v) { io[(size_t)r * lds + c] = v; });
@@ -66,6 +84,7 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float
             sX[i >> 6][i & 63] = tgt_in[(size_t)(t0 + (i >> 6)) * lds + b * DL_D + (i & 63)];
         __syncthreads();
     }
+    DL_STAMP(5);
     if (!has_pre) return;
     // t2 = norm1(tgt);  q = k = t2 + query_pos
     const float* qp = query_pos + (size_t)t0 * lds + b * DL_D;
@@ -76,12 +95,15 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float
     for (int i = threadIdx.x; i < nvalid * DL_D; i += DL_TILE_THREADS)
         X[(size_t)(t0 + (i >> 6)) * DL_D + (i & 63)] = sX[i >> 6][i & 63];
     __syncthreads();
+    DL_STAMP(6);
     // in_proj: rows 0..127 of the packed weight -> q, k (from t2 + pos), rows 128..191 -> v (from t2)
     float* qkv = QKV + (size_t)t0 * (3 * DL_D);
     dl_tile_gemm<false>(&sQ[0][0], DL_LD, nvalid, DL_D, pr.ipw, pr.ipb, 2 * DL_D, wave, nw, lane,
                         [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + c] = v; });
+    DL_STAMP(7);
     dl_tile_gemm<false>(&sT[0][0], DL_LD, nvalid, DL_D, pr.ipw + 2 * DL_D * DL_D, pr.ipb + 2 * DL_D, DL_D, wave, nw, lane,
                         [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + 2 * DL_D + c] = v; });
+    DL_STAMP(8);
 }
 
 // Stage B, query-tile-parallel (one workgroup per 16 queries, one wave per head): self-attention over all
@@ -97,6 +119,7 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
     float* X = state + (size_t)b * T * (5 * DL_D);
     float* TGT2 = X + (size_t)T * DL_D;
     const float* QKV = TGT2 + (size_t)T * DL_D;
+    DL_STAMP(16);
     {
         const int h = wave;  // 4 waves = 4 heads
         const int QT = (T + 15) >> 4;
@@ -106,6 +129,58 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
         if (qrow < T) bq = *reinterpret_cast<const float4*>(QKV + (size_t)qrow * (3 * DL_D) + h * DL_DK + 4 * g);
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         float m = -INFINITY, l = 0.f;
+        constexpr int QT_FAST = 16;  // up to 256 tokens (the test yaml's queries): every key tile's operands in registers
+        if (QT <= QT_FAST) {
+            // Two passes instead of the online soft-max below: with one wave per SIMD nothing hides the online form's chain
+            // -- product, maximum, exponentials, product, 16 times in a row: 33 000 cycles of this kernel's 45 000 (cycle
+            // stamps, round 6).  Here the K rows and V columns of ALL tiles are requested at once, the 16 score products
+            // are independent, the maximum is exact, and only the P.V accumulation is a chain.
+            float4 akt[QT_FAST];
+            float vt[QT_FAST][4];
+#pragma unroll
+            for (int kt = 0; kt < QT_FAST; kt++) {
+                akt[kt] = z4;
+                const int krow = kt * 16 + j;
+                if (kt < QT && krow < T)
+                    akt[kt] = *reinterpret_cast<const float4*>(QKV + (size_t)krow * (3 * DL_D) + DL_D + h * DL_DK + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int key = kt * 16 + 4 * g + i;
+                    vt[kt][i] = (kt < QT && key < T) ? QKV[(size_t)key * (3 * DL_D) + 2 * DL_D + h * DL_DK + j] : 0.f;
+                }
+            }
+            float sc[QT_FAST][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < QT_FAST; kt++) {
+                if (kt < QT) {  // (uniform)
+                    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                    s = dl_mfma4(akt[kt], bq, s);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        sc[kt][i] = (kt * 16 + 4 * g + i) < T ? s[i] * 0.25f : -INFINITY;  // 1/sqrt(16)
+                        mx = fmaxf(mx, sc[kt][i]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) sc[kt][i] = -INFINITY;
+                }
+            }
+            mx = fmaxf(mx, gf_shfl_xor<16>(mx));
+            mx = fmaxf(mx, gf_shfl_xor<32>(mx));  // finite: key 0 exists
+#pragma unroll
+            for (int kt = 0; kt < QT_FAST; kt++) {
+                if (kt < QT) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        // (v_exp_f32 on the base-2 argument: the library expf is ~30 instructions, 64 of them per lane)
+                        const float pi = __builtin_amdgcn_exp2f((sc[kt][i] - mx) * 1.4426950408889634f);
+                        l += pi;
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[kt][i], pi, o, 0, 0, 0);
+                    }
+                }
+            }
+        } else {
         // operands of key tile 0, then one tile of look-ahead
         float4 ak = z4;
         float v[4];
@@ -136,8 +211,8 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
 #pragma unroll
             for (int i = 0; i < 4; i++) sc[i] = (kt * 16 + 4 * g + i) < T ? s[i] * 0.25f : -INFINITY;  // 1/sqrt(16)
             float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, gf_shfl_xor<16>(mx));
+            mx = fmaxf(mx, gf_shfl_xor<32>(mx));
             const float mnew = fmaxf(m, mx);
             const float corr = expf(m - mnew);
             float p[4];
@@ -152,17 +227,20 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
 #pragma unroll
             for (int i = 0; i < 4; i++) v[i] = v_n[i];
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        }
+        l += gf_shfl_xor<16>(l);
+        l += gf_shfl_xor<32>(l);
 #pragma unroll
         for (int i = 0; i < 4; i++) sO[j][h * DL_DK + 4 * g + i] = o[i] / l;
     }
     __syncthreads();
+    DL_STAMP(17);
     // tgt += out_proj(O)
     const float* xg = X + (size_t)t0 * DL_D;
     dl_tile_gemm<false>(&sO[0][0], DL_LD, nvalid, DL_D, pr.opw, pr.opb, DL_D, wave, nw, lane,
-                        [&](int r, int c, float v) { sX[r][c] = xg[r * DL_D + c] + v; });
+                        [&](int r, int c, float v) { sX[r][c] = v; }, xg, DL_D);
     __syncthreads();
+    DL_STAMP(18);
     float* xo = X + (size_t)t0 * DL_D;
     for (int i = threadIdx.x; i < nvalid * DL_D; i += DL_TILE_THREADS) xo[i] = sX[i >> 6][i & 63];
     float* tg = TGT2 + (size_t)t0 * DL_D;
@@ -171,9 +249,11 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
         tg[r * DL_D + c] = v;
     });
     __syncthreads();
+    DL_STAMP(19);
     float* q1 = q1_out + ((size_t)b * T + t0) * DL_D;
     dl_tile_gemm<false>(&sT[0][0], DL_LD, nvalid, DL_D, pr.w1w, pr.w1b, DL_D, wave, nw, lane,
                         [&](int r, int c, float v) { q1[r * DL_D + c] = v; });
+    DL_STAMP(20);
 }
 
 extern "C" size_t gf_decoder_token_state_bytes(int nq, int B) {
