@@ -65,13 +65,83 @@ __device__ __forceinline__ void dl_tile_gemm(const float* A, int lda, int nvalid
     }
 }
 
+// The same product with its weight operands ALREADY in registers: a token-side kernel is a chain of small products between
+// barriers, one wave per SIMD, and every phase used to open with its own weight fetch (~1 500-2 000 cycles of a ~4 500-cycle
+// phase: cycle stamps, round 6).  dl_w_load requests a phase's operands -- NT column tiles per wave x KC 16-channel steps,
+// + bias -- any number of phases ahead (the kernels do it at entry, all phases at once: one round trip for the lot);
+// dl_tile_gemm_w consumes them.  Same arithmetic and order as dl_tile_gemm.
+template <int NT, int KC>
+struct DlW {
+    float4 b[NT][KC];
+    float bias[NT];
+};
+template <int NT, int KC>
+__device__ __forceinline__ void dl_w_load(DlW<NT, KC>& w, const float* __restrict__ W, const float* __restrict__ bias, int N,
+                                          int K, int wave, int nwaves, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int ct = wave + t * nwaves;
+        const bool on = ct < (N >> 4);
+        const float* wb = W + (size_t)((on ? ct : 0) * 16 + j) * K + 4 * g;
+        w.bias[t] = on ? bias[ct * 16 + j] : 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++)
+            w.b[t][kc] = (on && kc < (K >> 4)) ? *reinterpret_cast<const float4*>(wb + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <bool RELU, int NT, int KC, typename Epi>
+__device__ __forceinline__ void dl_tile_gemm_w(const float* A, int lda, int nvalid, int K, int N, int wave, int nwaves, int lane,
+                                               const DlW<NT, KC>& w, Epi epi, const float* __restrict__ addend = nullptr,
+                                               int add_ld = 0) {
+    const int j = lane & 15, g = lane >> 4;
+    const float* xa = A + (size_t)j * lda + 4 * g;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int ct = wave + t * nwaves;
+        if (ct >= (N >> 4)) break;
+        const int col = ct * 16 + j;
+        float ad[4] = {0.f, 0.f, 0.f, 0.f};
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * g + i < nvalid) ad[i] = addend[(size_t)(4 * g + i) * add_ld + col];
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            if (kc < (K >> 4)) {
+                float4 a = j < nvalid ? *reinterpret_cast<const float4*>(xa + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = dl_mfma4(a, w.b[t][kc], acc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * g + i;
+            if (r >= nvalid) continue;
+            float v = acc[i] + w.bias[t];
+            if (RELU) v = fmaxf(v, 0.f);
+            if (addend) v += ad[i];
+            epi(r, col, v);
+        }
+    }
+}
+
 // torch.nn.LayerNorm over 64 channels (biased variance, eps inside the root) of the rows of an LDS tile;
 // one wave per row, one channel per lane
+template <typename Out>
+__device__ __forceinline__ void dl_tile_layernorm_p(const float (*S)[DL_LD], int nvalid, float wl, float bl, int wave,
+                                                    int nwaves, int lane, Out out);
 template <typename Out>
 __device__ __forceinline__ void dl_tile_layernorm(const float (*S)[DL_LD], int nvalid, const float* __restrict__ w,
                                                   const float* __restrict__ b, int wave, int nwaves, int lane,
                                                   Out out) {
-    const float wl = w[lane], bl = b[lane];
+    dl_tile_layernorm_p(S, nvalid, w[lane], b[lane], wave, nwaves, lane, out);
+}
+// (wl, bl: the lane's channel of the norm's weight and bias, loaded by the caller -- ahead of the phase, if it likes)
+template <typename Out>
+__device__ __forceinline__ void dl_tile_layernorm_p(const float (*S)[DL_LD], int nvalid, float wl, float bl, int wave,
+                                                    int nwaves, int lane, Out out) {
     for (int r = wave; r < nvalid; r += nwaves) {
         const float v = S[r][lane];
         // (gf_wave_sum: the same butterfly as six __shfl_xor steps without the LDS crossbar -- a norm of 16 rows by four

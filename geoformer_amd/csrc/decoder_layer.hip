@@ -58,27 +58,48 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float
     float* QKV = TGT2 + (size_t)T * DL_D;
     const int lds = B * DL_D;  // row stride of the [T,B,64] tensors
     DL_STAMP(0);
+    // every phase's weights, biases and norm parameters requested NOW (one wave per SIMD: 512 registers each, and no phase
+    // then opens with a fetch of its own -- decoder_layer.h)
+    constexpr int NTF = DL_MAXFF / 16 / (DL_TILE_THREADS / 64);  // linear1's column tiles per wave at the widest FFN
+    DlW<1, DL_D / 16> w_om;
+    DlW<NTF, DL_D / 16> w_l1;
+    DlW<1, DL_MAXFF / 16> w_l2;
+    DlW<2, DL_D / 16> w_qk;
+    DlW<1, DL_D / 16> w_v;
+    float n3w = 0.f, n3b = 0.f, fnw = 0.f, fnb = 0.f, n1w = 0.f, n1b = 0.f;
+    if (has_post) {
+        dl_w_load(w_om, po.omw, po.omb, DL_D, DL_D, wave, nw, lane);
+        n3w = po.n3w[lane]; n3b = po.n3b[lane];
+        dl_w_load(w_l1, po.l1w, po.l1b, ff, DL_D, wave, nw, lane);
+        dl_w_load(w_l2, po.l2w, po.l2b, DL_D, ff, wave, nw, lane);
+        fnw = po.fnw[lane]; fnb = po.fnb[lane];
+    }
+    if (has_pre) {
+        n1w = pr.n1w[lane]; n1b = pr.n1b[lane];
+        dl_w_load(w_qk, pr.ipw, pr.ipb, 2 * DL_D, DL_D, wave, nw, lane);
+        dl_w_load(w_v, pr.ipw + 2 * DL_D * DL_D, pr.ipb + 2 * DL_D, DL_D, DL_D, wave, nw, lane);
+    }
     if (has_post) {
         // tgt = relu(out_mlp(attn)) + tgt2
         const float* tg = TGT2 + (size_t)t0 * DL_D;
-        dl_tile_gemm<true>(attn_out + ((size_t)b * T + t0) * DL_D, DL_D, nvalid, DL_D, po.omw, po.omb, DL_D, wave, nw,
-                           lane, [&](int r, int c, float v) { sX[r][c] = v; }, tg, DL_D);
+        dl_tile_gemm_w<true>(attn_out + ((size_t)b * T + t0) * DL_D, DL_D, nvalid, DL_D, DL_D, wave, nw, lane, w_om,
+                             [&](int r, int c, float v) { sX[r][c] = v; }, tg, DL_D);
         __syncthreads();
         DL_STAMP(1);
-        dl_tile_layernorm(sX, nvalid, po.n3w, po.n3b, wave, nw, lane, [&](int r, int c, float v) { sT[r][c] = v; });
+        dl_tile_layernorm_p(sX, nvalid, n3w, n3b, wave, nw, lane, [&](int r, int c, float v) { sT[r][c] = v; });
         __syncthreads();
         DL_STAMP(2);
-        dl_tile_gemm<true>(&sT[0][0], DL_LD, nvalid, DL_D, po.l1w, po.l1b, ff, wave, nw, lane,
-                           [&](int r, int c, float v) { sH[r][c] = v; });
+        dl_tile_gemm_w<true>(&sT[0][0], DL_LD, nvalid, DL_D, ff, wave, nw, lane, w_l1,
+                             [&](int r, int c, float v) { sH[r][c] = v; });
         __syncthreads();
         DL_STAMP(3);
-        dl_tile_gemm<false>(&sH[0][0], DL_LDH, nvalid, ff, po.l2w, po.l2b, DL_D, wave, nw, lane,
-                            [&](int r, int c, float v) { sX[r][c] += v; });
+        dl_tile_gemm_w<false>(&sH[0][0], DL_LDH, nvalid, ff, DL_D, wave, nw, lane, w_l2,
+                              [&](int r, int c, float v) { sX[r][c] += v; });
         __syncthreads();
         DL_STAMP(4);
         float* io = inter_out + (size_t)t0 * lds + b * DL_D;
-        dl_tile_layernorm(sX, nvalid, po.fnw, po.fnb, wave, nw, lane,
-                          [&](int r, int c, float v) { io[(size_t)r * lds + c] = v; });
+        dl_tile_layernorm_p(sX, nvalid, fnw, fnb, wave, nw, lane,
+                            [&](int r, int c, float v) { io[(size_t)r * lds + c] = v; });
     } else {
         for (int i = threadIdx.x; i < nvalid * DL_D; i += DL_TILE_THREADS)
             sX[i >> 6][i & 63] = tgt_in[(size_t)(t0 + (i >> 6)) * lds + b * DL_D + (i & 63)];
@@ -88,7 +109,7 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float
     if (!has_pre) return;
     // t2 = norm1(tgt);  q = k = t2 + query_pos
     const float* qp = query_pos + (size_t)t0 * lds + b * DL_D;
-    dl_tile_layernorm(sX, nvalid, pr.n1w, pr.n1b, wave, nw, lane, [&](int r, int c, float v) {
+    dl_tile_layernorm_p(sX, nvalid, n1w, n1b, wave, nw, lane, [&](int r, int c, float v) {
         sT[r][c] = v;
         sQ[r][c] = v + qp[(size_t)r * lds + c];
     });
@@ -98,12 +119,56 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_a(const float
     DL_STAMP(6);
     // in_proj: rows 0..127 of the packed weight -> q, k (from t2 + pos), rows 128..191 -> v (from t2)
     float* qkv = QKV + (size_t)t0 * (3 * DL_D);
-    dl_tile_gemm<false>(&sQ[0][0], DL_LD, nvalid, DL_D, pr.ipw, pr.ipb, 2 * DL_D, wave, nw, lane,
-                        [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + c] = v; });
+    dl_tile_gemm_w<false>(&sQ[0][0], DL_LD, nvalid, DL_D, 2 * DL_D, wave, nw, lane, w_qk,
+                          [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + c] = v; });
     DL_STAMP(7);
-    dl_tile_gemm<false>(&sT[0][0], DL_LD, nvalid, DL_D, pr.ipw + 2 * DL_D * DL_D, pr.ipb + 2 * DL_D, DL_D, wave, nw, lane,
-                        [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + 2 * DL_D + c] = v; });
+    dl_tile_gemm_w<false>(&sT[0][0], DL_LD, nvalid, DL_D, DL_D, wave, nw, lane, w_v,
+                          [&](int r, int c, float v) { qkv[(size_t)r * (3 * DL_D) + 2 * DL_D + c] = v; });
     DL_STAMP(8);
+}
+
+// self-attention of one head over at most QTN x 16 tokens for a wave's 16 queries, two passes (see the call): adds to o
+// (channels x queries, this lane's four) and l (this lane's part of the row sums)
+template <int QTN>
+__device__ __forceinline__ void dl_attn_two_pass(const float* __restrict__ QKV, int T, int h, int j, int g, float4 bq,
+                                                 f32x4& o, float& l) {
+    float4 akt[QTN];
+    float vt[QTN][4];
+    const int last = T - 1;
+#pragma unroll
+    for (int kt = 0; kt < QTN; kt++) {
+        const int krow = min(kt * 16 + j, last);
+        akt[kt] = *reinterpret_cast<const float4*>(QKV + (size_t)krow * (3 * DL_D) + DL_D + h * DL_DK + 4 * g);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int key = min(kt * 16 + 4 * g + i, last);
+            vt[kt][i] = QKV[(size_t)key * (3 * DL_D) + 2 * DL_D + h * DL_DK + j];
+        }
+    }
+    float sc[QTN][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < QTN; kt++) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        s = dl_mfma4(akt[kt], bq, s);  // (a clamped row beyond T: a finite product, masked below)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            sc[kt][i] = (kt * 16 + 4 * g + i) < T ? s[i] * 0.25f : -INFINITY;  // 1/sqrt(16)
+            mx = fmaxf(mx, sc[kt][i]);
+        }
+    }
+    mx = fmaxf(mx, gf_shfl_xor<16>(mx));
+    mx = fmaxf(mx, gf_shfl_xor<32>(mx));  // finite: key 0 exists
+#pragma unroll
+    for (int kt = 0; kt < QTN; kt++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            // (v_exp_f32 on the base-2 argument: the library expf is ~30 instructions, 64 of them per lane; a masked key: 0)
+            const float pi = __builtin_amdgcn_exp2f((sc[kt][i] - mx) * 1.4426950408889634f);
+            l += pi;
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[kt][i], pi, o, 0, 0, 0);
+        }
+    }
 }
 
 // Stage B, query-tile-parallel (one workgroup per 16 queries, one wave per head): self-attention over all
@@ -120,6 +185,11 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
     float* TGT2 = X + (size_t)T * DL_D;
     const float* QKV = TGT2 + (size_t)T * DL_D;
     DL_STAMP(16);
+    // (the two products behind the self-attention: operands requested now)
+    DlW<1, DL_D / 16> w_op, w_w1;
+    dl_w_load(w_op, pr.opw, pr.opb, DL_D, DL_D, wave, nw, lane);
+    dl_w_load(w_w1, pr.w1w, pr.w1b, DL_D, DL_D, wave, nw, lane);
+    const float n2w = pr.n2w[lane], n2b = pr.n2b[lane];
     {
         const int h = wave;  // 4 waves = 4 heads
         const int QT = (T + 15) >> 4;
@@ -129,57 +199,13 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
         if (qrow < T) bq = *reinterpret_cast<const float4*>(QKV + (size_t)qrow * (3 * DL_D) + h * DL_DK + 4 * g);
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
         float m = -INFINITY, l = 0.f;
-        constexpr int QT_FAST = 16;  // up to 256 tokens (the test yaml's queries): every key tile's operands in registers
-        if (QT <= QT_FAST) {
+        if (QT <= 16) {
             // Two passes instead of the online soft-max below: with one wave per SIMD nothing hides the online form's chain
             // -- product, maximum, exponentials, product, 16 times in a row: 33 000 cycles of this kernel's 45 000 (cycle
-            // stamps, round 6).  Here the K rows and V columns of ALL tiles are requested at once, the 16 score products
-            // are independent, the maximum is exact, and only the P.V accumulation is a chain.
-            float4 akt[QT_FAST];
-            float vt[QT_FAST][4];
-#pragma unroll
-            for (int kt = 0; kt < QT_FAST; kt++) {
-                akt[kt] = z4;
-                const int krow = kt * 16 + j;
-                if (kt < QT && krow < T)
-                    akt[kt] = *reinterpret_cast<const float4*>(QKV + (size_t)krow * (3 * DL_D) + DL_D + h * DL_DK + 4 * g);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int key = kt * 16 + 4 * g + i;
-                    vt[kt][i] = (kt < QT && key < T) ? QKV[(size_t)key * (3 * DL_D) + 2 * DL_D + h * DL_DK + j] : 0.f;
-                }
-            }
-            float sc[QT_FAST][4];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < QT_FAST; kt++) {
-                if (kt < QT) {  // (uniform)
-                    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-                    s = dl_mfma4(akt[kt], bq, s);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        sc[kt][i] = (kt * 16 + 4 * g + i) < T ? s[i] * 0.25f : -INFINITY;  // 1/sqrt(16)
-                        mx = fmaxf(mx, sc[kt][i]);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) sc[kt][i] = -INFINITY;
-                }
-            }
-            mx = fmaxf(mx, gf_shfl_xor<16>(mx));
-            mx = fmaxf(mx, gf_shfl_xor<32>(mx));  // finite: key 0 exists
-#pragma unroll
-            for (int kt = 0; kt < QT_FAST; kt++) {
-                if (kt < QT) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        // (v_exp_f32 on the base-2 argument: the library expf is ~30 instructions, 64 of them per lane)
-                        const float pi = __builtin_amdgcn_exp2f((sc[kt][i] - mx) * 1.4426950408889634f);
-                        l += pi;
-                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vt[kt][i], pi, o, 0, 0, 0);
-                    }
-                }
-            }
+            // stamps, round 6).  dl_attn_two_pass: the K rows and V columns of ALL tiles requested at once (clamped
+            // addresses, masked afterwards: no branch per load), independent score products, an exact maximum.
+            if (QT <= 8) dl_attn_two_pass<8>(QKV, T, h, j, g, bq, o, l);
+            else dl_attn_two_pass<16>(QKV, T, h, j, g, bq, o, l);
         } else {
         // operands of key tile 0, then one tile of look-ahead
         float4 ak = z4;
@@ -237,22 +263,22 @@ __global__ __launch_bounds__(DL_TILE_THREADS) void k_decoder_stage_b(int T, int 
     DL_STAMP(17);
     // tgt += out_proj(O)
     const float* xg = X + (size_t)t0 * DL_D;
-    dl_tile_gemm<false>(&sO[0][0], DL_LD, nvalid, DL_D, pr.opw, pr.opb, DL_D, wave, nw, lane,
-                        [&](int r, int c, float v) { sX[r][c] = v; }, xg, DL_D);
+    dl_tile_gemm_w<false>(&sO[0][0], DL_LD, nvalid, DL_D, DL_D, wave, nw, lane, w_op,
+                          [&](int r, int c, float v) { sX[r][c] = v; }, xg, DL_D);
     __syncthreads();
     DL_STAMP(18);
     float* xo = X + (size_t)t0 * DL_D;
     for (int i = threadIdx.x; i < nvalid * DL_D; i += DL_TILE_THREADS) xo[i] = sX[i >> 6][i & 63];
     float* tg = TGT2 + (size_t)t0 * DL_D;
-    dl_tile_layernorm(sX, nvalid, pr.n2w, pr.n2b, wave, nw, lane, [&](int r, int c, float v) {
+    dl_tile_layernorm_p(sX, nvalid, n2w, n2b, wave, nw, lane, [&](int r, int c, float v) {
         sT[r][c] = v;
         tg[r * DL_D + c] = v;
     });
     __syncthreads();
     DL_STAMP(19);
     float* q1 = q1_out + ((size_t)b * T + t0) * DL_D;
-    dl_tile_gemm<false>(&sT[0][0], DL_LD, nvalid, DL_D, pr.w1w, pr.w1b, DL_D, wave, nw, lane,
-                        [&](int r, int c, float v) { q1[r * DL_D + c] = v; });
+    dl_tile_gemm_w<false>(&sT[0][0], DL_LD, nvalid, DL_D, DL_D, wave, nw, lane, w_w1,
+                          [&](int r, int c, float v) { q1[r * DL_D + c] = v; });
     DL_STAMP(20);
 }
 
