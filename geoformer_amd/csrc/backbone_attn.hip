@@ -91,11 +91,84 @@ __device__ __forceinline__ void bt_tile_gemm(const float* A, int lda, int nvalid
     }
 }
 
+// The same product with its weight operands already in registers (decoder_layer.h, DlW: why): bt_w_load requests NT column
+// tiles per wave x KC 16-channel steps + bias ahead of the phase, bt_tile_gemm_w consumes them.  Same arithmetic and order.
+template <int NT, int KC>
+struct BtW {
+    float4 b[NT][KC];
+    float bias[NT];
+};
+template <int NT, int KC>
+__device__ __forceinline__ void bt_w_load(BtW<NT, KC>& w, const float* __restrict__ W, const float* __restrict__ bias, int N,
+                                          int K, int wave, int nwaves, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int ct = wave + t * nwaves;
+        const bool on = ct < (N >> 4);
+        const float* wb = W + (size_t)((on ? ct : 0) * 16 + j) * K + 4 * g;
+        w.bias[t] = on ? bias[ct * 16 + j] : 0.f;
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++)
+            w.b[t][kc] = (on && kc < (K >> 4)) ? *reinterpret_cast<const float4*>(wb + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <bool RELU, int NT, int KC, typename Epi>
+__device__ __forceinline__ void bt_tile_gemm_w(const float* A, int lda, int nvalid, int K, int N, int wave, int nwaves, int lane,
+                                               const BtW<NT, KC>& w, Epi epi, const float* __restrict__ addend = nullptr,
+                                               int add_ld = 0) {
+    const int j = lane & 15, g = lane >> 4;
+    const float* xa = A + (size_t)j * lda + 4 * g;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int ct = wave + t * nwaves;
+        if (ct >= (N >> 4)) break;
+        const int col = ct * 16 + j;
+        float ad[4] = {0.f, 0.f, 0.f, 0.f};
+        if (addend) {
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (4 * g + i < nvalid) ad[i] = addend[(size_t)(4 * g + i) * add_ld + col];
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+            if (kc < (K >> 4)) {
+                float4 a = j < nvalid ? *reinterpret_cast<const float4*>(xa + kc * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = mfma4(a, w.b[t][kc], acc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * g + i;
+            if (r >= nvalid) continue;
+            float v = acc[i] + w.bias[t];
+            if (RELU) v = fmaxf(v, 0.f);
+            if (addend) v += ad[i];
+            epi(r, col, v);
+        }
+    }
+}
+
 // Norm (transformer.py:62-76) of the rows of an LDS tile: one wave per row, two channels per lane
+struct BtNormP {  // a lane's two channels of a norm's alpha / bias (loaded ahead of the phase)
+    float a0, a1, b0, b1;
+};
+__device__ __forceinline__ BtNormP bt_norm_load(const float* __restrict__ alpha, const float* __restrict__ beta, int lane) {
+    return BtNormP{alpha[2 * lane], alpha[2 * lane + 1], beta[2 * lane], beta[2 * lane + 1]};
+}
+template <typename Out>
+__device__ __forceinline__ void bt_tile_norm_p(const float (*S)[BT_LD], int nvalid, BtNormP np, int wave, int nwaves, int lane,
+                                               Out out);
 template <typename Out>
 __device__ __forceinline__ void bt_tile_norm(const float (*S)[BT_LD], int nvalid, const float* __restrict__ alpha,
                                              const float* __restrict__ beta, int wave, int nwaves, int lane, Out out) {
-    const float a0 = alpha[2 * lane], a1 = alpha[2 * lane + 1], b0 = beta[2 * lane], b1 = beta[2 * lane + 1];
+    bt_tile_norm_p(S, nvalid, bt_norm_load(alpha, beta, lane), wave, nwaves, lane, out);
+}
+template <typename Out>
+__device__ __forceinline__ void bt_tile_norm_p(const float (*S)[BT_LD], int nvalid, BtNormP np, int wave, int nwaves, int lane,
+                                               Out out) {
+    const float a0 = np.a0, a1 = np.a1, b0 = np.b0, b1 = np.b1;
     for (int r = wave; r < nvalid; r += nwaves) {
         const float2 v = *reinterpret_cast<const float2*>(&S[r][2 * lane]);
         const float s = gf_wave_sum(v.x + v.y);  // (the __shfl_xor butterfly without the LDS crossbar: common.h)
@@ -134,6 +207,25 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_pre(const float* __restrict__
     float* X = scratch + (size_t)s0 * BT_SCRATCH_PER_TOKEN;
     float* QKV = X + (size_t)T * BT_D;
     const int* xyz = coords + (size_t)s0 * 4;
+    // every phase's weights, biases and norm parameters requested now (bt_w_load: why)
+    constexpr int KCI = 8;  // input widths up to 128 channels
+    BtW<1, KCI> w_b;
+    BtW<1, BT_D / 16> w_q, w_k, w_v;
+    bt_w_load(w_b, P.bw, P.bb, BT_D, c, wave, nw, lane);
+    const BtNormP np1 = bt_norm_load(P.L[0].n1a, P.L[0].n1b, lane);
+    bt_w_load(w_q, P.L[0].qw, P.L[0].qb, BT_D, BT_D, wave, nw, lane);
+    bt_w_load(w_k, P.L[0].kw, P.L[0].kb, BT_D, BT_D, wave, nw, lane);
+    bt_w_load(w_v, P.L[0].vw, P.L[0].vb, BT_D, BT_D, wave, nw, lane);
+    // (... and what the first product's epilogue reads: the positional layer's column of this lane, its rows' coordinates)
+    const int pcol = wave * 16 + (lane & 15);  // the one column tile of this wave (BT_D / 16 = nw tiles)
+    const float pw0 = P.pw[pcol * 3], pw1 = P.pw[pcol * 3 + 1], pw2 = P.pw[pcol * 3 + 2], pbc = P.pb[pcol];
+    int tzr[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int rr = min(t0 + 4 * (lane >> 4) + i, T - 1);
+#pragma unroll
+        for (int a = 0; a < 3; a++) tzr[i][a] = xyz[(size_t)rr * 4 + 1 + a];
+    }
     if (threadIdx.x < 3) psum[threadIdx.x] = 0;
     __syncthreads();
     {
@@ -155,24 +247,43 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_pre(const float* __restrict__
     }
     __syncthreads();
     const float ft = (float)T;
-    const int* tz = xyz + (size_t)t0 * 4;
-    bt_tile_gemm<false>(feats + ((size_t)s0 + t0) * c, c, nvalid, c, P.bw, P.bb, BT_D, wave, nw, lane,
-                        [&](int r, int col, float v) {
-                            const float r0 = (float)(T * tz[r * 4 + 1] - psum[0]) / ft;
-                            const float r1 = (float)(T * tz[r * 4 + 2] - psum[1]) / ft;
-                            const float r2 = (float)(T * tz[r * 4 + 3] - psum[2]) / ft;
-                            const float pe = fmaf(P.pw[col * 3 + 2], r2, fmaf(P.pw[col * 3 + 1], r1, P.pw[col * 3] * r0));
-                            sX[r][col] = v + (pe + P.pb[col]);
-                        });
+    static_assert(BT_D / 16 == BT_THREADS / 64, "k_bt_pre: one column tile of the first product per wave");
+    if (c <= KCI * 16) {
+        bt_tile_gemm_w<false>(feats + ((size_t)s0 + t0) * c, c, nvalid, c, BT_D, wave, nw, lane, w_b,
+                              [&](int r, int col, float v) {
+                                  const int i = r & 3;  // (r = 4 (lane >> 4) + i)
+                                  const float r0 = (float)(T * tzr[i][0] - psum[0]) / ft;
+                                  const float r1 = (float)(T * tzr[i][1] - psum[1]) / ft;
+                                  const float r2 = (float)(T * tzr[i][2] - psum[2]) / ft;
+                                  const float pe = fmaf(pw2, r2, fmaf(pw1, r1, pw0 * r0));
+                                  sX[r][col] = v + (pe + pbc);
+                              });
+    } else {
+        const int* tz = xyz + (size_t)t0 * 4;
+        bt_tile_gemm<false>(feats + ((size_t)s0 + t0) * c, c, nvalid, c, P.bw, P.bb, BT_D, wave, nw, lane,
+                            [&](int r, int col, float v) {
+                                const float r0 = (float)(T * tz[r * 4 + 1] - psum[0]) / ft;
+                                const float r1 = (float)(T * tz[r * 4 + 2] - psum[1]) / ft;
+                                const float r2 = (float)(T * tz[r * 4 + 3] - psum[2]) / ft;
+                                const float pe = fmaf(P.pw[col * 3 + 2], r2, fmaf(P.pw[col * 3 + 1], r1, P.pw[col * 3] * r0));
+                                sX[r][col] = v + (pe + P.pb[col]);
+                            });
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < nvalid * BT_D; i += BT_THREADS)
         X[(size_t)(t0 + (i >> 7)) * BT_D + (i & 127)] = sX[i >> 7][i & 127];
-    bt_tile_norm(sX, nvalid, P.L[0].n1a, P.L[0].n1b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+    bt_tile_norm_p(sX, nvalid, np1, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
         sT[r][c2] = v0;
         sT[r][c2 + 1] = v1;
     });
     __syncthreads();
-    bt_tile_qkv(sT, nvalid, P.L[0], QKV + (size_t)t0 * (3 * BT_D), wave, nw, lane);
+    float* qkv_rows = QKV + (size_t)t0 * (3 * BT_D);
+    bt_tile_gemm_w<false>(&sT[0][0], BT_LD, nvalid, BT_D, BT_D, wave, nw, lane, w_q,
+                          [&](int r, int cc, float v) { qkv_rows[(size_t)r * (3 * BT_D) + cc] = v; });
+    bt_tile_gemm_w<false>(&sT[0][0], BT_LD, nvalid, BT_D, BT_D, wave, nw, lane, w_k,
+                          [&](int r, int cc, float v) { qkv_rows[(size_t)r * (3 * BT_D) + BT_D + cc] = v; });
+    bt_tile_gemm_w<false>(&sT[0][0], BT_LD, nvalid, BT_D, BT_D, wave, nw, lane, w_v,
+                          [&](int r, int cc, float v) { qkv_rows[(size_t)r * (3 * BT_D) + 2 * BT_D + cc] = v; });
 }
 
 __global__ __launch_bounds__(BT_THREADS) void k_bt_layer(const int* __restrict__ scene_offsets,
@@ -193,6 +304,14 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_layer(const int* __restrict__
     float* Xo = scratch_out + (size_t)s0 * BT_SCRATCH_PER_TOKEN;
     float* QKVo = Xo + (size_t)T * BT_D;
     const BtLayer& L = P.L[li];
+    // the weights of the phases behind the self-attention, requested now; those of the last phase (next layer's q / k / v or
+    // the output layer: 96 registers) once the attention's own registers are free
+    BtW<1, BT_D / 16> w_o, w_f1;
+    BtW<1, BT_FF / 16> w_f2;
+    bt_w_load(w_o, L.ow, L.ob, BT_D, BT_D, wave, nw, lane);
+    const BtNormP np2 = bt_norm_load(L.n2a, L.n2b, lane);
+    bt_w_load(w_f1, L.f1w, L.f1b, BT_FF, BT_D, wave, nw, lane);
+    bt_w_load(w_f2, L.f2w, L.f2b, BT_D, BT_FF, wave, nw, lane);
     if (wave < BT_H) {
         // one wave per head: O[16 queries][32] over all keys of the scene
         const int h = wave;
@@ -271,42 +390,58 @@ __global__ __launch_bounds__(BT_THREADS) void k_bt_layer(const int* __restrict__
             sO[j][h * BT_DK + 16 + 4 * g + i] = o1[i] / l;
         }
     }
+    // (the last phase's operands: requested here, four phases ahead of their use)
+    const bool more = li + 1 < P.nl;
+    BtW<1, BT_D / 16> w_q, w_k, w_v;
+    const BtLayer& Ln = P.L[more ? li + 1 : li];
+    const BtNormP np3 = more ? bt_norm_load(Ln.n1a, Ln.n1b, lane) : bt_norm_load(P.na, P.nb, lane);
+    bt_w_load(w_q, more ? Ln.qw : P.aw, more ? Ln.qb : P.ab, more ? BT_D : c, BT_D, wave, nw, lane);
+    if (more) {
+        bt_w_load(w_k, Ln.kw, Ln.kb, BT_D, BT_D, wave, nw, lane);
+        bt_w_load(w_v, Ln.vw, Ln.vb, BT_D, BT_D, wave, nw, lane);
+    }
     __syncthreads();
     // x += out(O)
     const float* xg = X + (size_t)t0 * BT_D;
-    bt_tile_gemm<false>(&sO[0][0], BT_LD, nvalid, BT_D, L.ow, L.ob, BT_D, wave, nw, lane,
-                        [&](int r, int col, float v) { sX[r][col] = v; }, xg, BT_D);
+    bt_tile_gemm_w<false>(&sO[0][0], BT_LD, nvalid, BT_D, BT_D, wave, nw, lane, w_o,
+                          [&](int r, int col, float v) { sX[r][col] = v; }, xg, BT_D);
     __syncthreads();
-    bt_tile_norm(sX, nvalid, L.n2a, L.n2b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+    bt_tile_norm_p(sX, nvalid, np2, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
         sT[r][c2] = v0;
         sT[r][c2 + 1] = v1;
     });
     __syncthreads();
     // x += ff2(relu(ff1(.)));  the hidden tile reuses sO
-    bt_tile_gemm<true>(&sT[0][0], BT_LD, nvalid, BT_D, L.f1w, L.f1b, BT_FF, wave, nw, lane,
-                       [&](int r, int col, float v) { sO[r][col] = v; });
+    bt_tile_gemm_w<true>(&sT[0][0], BT_LD, nvalid, BT_D, BT_FF, wave, nw, lane, w_f1,
+                         [&](int r, int col, float v) { sO[r][col] = v; });
     __syncthreads();
-    bt_tile_gemm<false>(&sO[0][0], BT_LD, nvalid, BT_FF, L.f2w, L.f2b, BT_D, wave, nw, lane,
-                        [&](int r, int col, float v) { sX[r][col] += v; });
+    bt_tile_gemm_w<false>(&sO[0][0], BT_LD, nvalid, BT_FF, BT_D, wave, nw, lane, w_f2,
+                          [&](int r, int col, float v) { sX[r][col] += v; });
     __syncthreads();
-    if (li + 1 < P.nl) {
+    if (more) {
         for (int i = threadIdx.x; i < nvalid * BT_D; i += BT_THREADS)
             Xo[(size_t)(t0 + (i >> 7)) * BT_D + (i & 127)] = sX[i >> 7][i & 127];
-        bt_tile_norm(sX, nvalid, P.L[li + 1].n1a, P.L[li + 1].n1b, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+        bt_tile_norm_p(sX, nvalid, np3, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
             sT[r][c2] = v0;
             sT[r][c2 + 1] = v1;
         });
         __syncthreads();
-        bt_tile_qkv(sT, nvalid, P.L[li + 1], QKVo + (size_t)t0 * (3 * BT_D), wave, nw, lane);
+        float* qkv_rows = QKVo + (size_t)t0 * (3 * BT_D);
+        bt_tile_gemm_w<false>(&sT[0][0], BT_LD, nvalid, BT_D, BT_D, wave, nw, lane, w_q,
+                              [&](int r, int cc, float v) { qkv_rows[(size_t)r * (3 * BT_D) + cc] = v; });
+        bt_tile_gemm_w<false>(&sT[0][0], BT_LD, nvalid, BT_D, BT_D, wave, nw, lane, w_k,
+                              [&](int r, int cc, float v) { qkv_rows[(size_t)r * (3 * BT_D) + BT_D + cc] = v; });
+        bt_tile_gemm_w<false>(&sT[0][0], BT_LD, nvalid, BT_D, BT_D, wave, nw, lane, w_v,
+                              [&](int r, int cc, float v) { qkv_rows[(size_t)r * (3 * BT_D) + 2 * BT_D + cc] = v; });
     } else {
-        bt_tile_norm(sX, nvalid, P.na, P.nb, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
+        bt_tile_norm_p(sX, nvalid, np3, wave, nw, lane, [&](int r, int c2, float v0, float v1) {
             sT[r][c2] = v0;
             sT[r][c2 + 1] = v1;
         });
         __syncthreads();
         float* y = out + ((size_t)s0 + t0) * c;
-        bt_tile_gemm<false>(&sT[0][0], BT_LD, nvalid, BT_D, P.aw, P.ab, c, wave, nw, lane,
-                            [&](int r, int col, float v) { y[(size_t)r * c + col] = v; });
+        bt_tile_gemm_w<false>(&sT[0][0], BT_LD, nvalid, BT_D, c, wave, nw, lane, w_q,
+                              [&](int r, int col, float v) { y[(size_t)r * c + col] = v; });
     }
 }
 
@@ -331,9 +466,34 @@ extern "C" size_t gf_backbone_transformer_scratch_bytes(int M) {
 
 extern "C" int gf_backbone_transformer_num_params(int n_layers) { return 8 + 16 * n_layers; }
 
+// the tile tables alone (they need the scene offsets and nothing else): gf_unet_fwd builds them on its side stream with the
+// rulebooks, so that two small launches per transformer level are not in front of the transformer on the main stream
+int gf_backbone_transformer_tables(const int* scene_offsets, int n_scenes, int M, void* scratch, void* stream) {
+    GF_CHECK_ARG(scene_offsets && scratch && n_scenes >= 1 && n_scenes <= 4096 && M >= 1, "gf_backbone_transformer_tables: bad arguments");
+    float* sA = (float*)scratch;
+    float* sB = sA + (size_t)M * BT_SCRATCH_PER_TOKEN;
+    int* tile_scene = (int*)(sB + (size_t)M * BT_SCRATCH_PER_TOKEN);
+    const int max_tiles = M / 16 + n_scenes;
+    int* tile_first = tile_scene + (M / 16 + 4096 + 8);
+    hipLaunchKernelGGL(k_bt_tiles, dim3(1), dim3(64), 0, (hipStream_t)stream, scene_offsets, n_scenes, max_tiles, tile_scene,
+                       tile_first);
+    GF_CHECK_LAUNCH("gf_backbone_transformer_tables");
+    return GF_OK;
+}
+
+static int bt_forward(const float* feats, const int* coords, const int* scene_offsets, int n_scenes, int M, int c, int n_layers,
+                      const float* const* params, void* scratch, float* out, void* stream, bool tables_ready);
 extern "C" int gf_backbone_transformer(const float* feats, const int* coords, const int* scene_offsets, int n_scenes,
                                        int M, int c, int n_layers, const float* const* params, void* scratch,
                                        float* out, void* stream) {
+    return bt_forward(feats, coords, scene_offsets, n_scenes, M, c, n_layers, params, scratch, out, stream, false);
+}
+int gf_backbone_transformer_prepared(const float* feats, const int* coords, const int* scene_offsets, int n_scenes, int M, int c,
+                                     int n_layers, const float* const* params, void* scratch, float* out, void* stream) {
+    return bt_forward(feats, coords, scene_offsets, n_scenes, M, c, n_layers, params, scratch, out, stream, true);
+}
+static int bt_forward(const float* feats, const int* coords, const int* scene_offsets, int n_scenes, int M, int c, int n_layers,
+                      const float* const* params, void* scratch, float* out, void* stream, bool tables_ready) {
     GF_CHECK_ARG(c > 0 && c % 16 == 0, "gf_backbone_transformer: channel width %d must be a multiple of 16", c);
     GF_CHECK_ARG(n_layers >= 1 && n_layers <= BT_MAXL, "gf_backbone_transformer: 1..%d layers, got %d", BT_MAXL,
                  n_layers);
@@ -380,7 +540,8 @@ extern "C" int gf_backbone_transformer(const float* feats, const int* coords, co
     int* tile_scene = (int*)(sB + (size_t)M * BT_SCRATCH_PER_TOKEN);
     const int max_tiles = M / 16 + n_scenes;  // sum of ceil(T_s / 16) never exceeds this
     int* tile_first = tile_scene + (M / 16 + 4096 + 8);
-    hipLaunchKernelGGL(k_bt_tiles, dim3(1), dim3(64), 0, st, scene_offsets, n_scenes, max_tiles, tile_scene, tile_first);
+    if (!tables_ready)
+        hipLaunchKernelGGL(k_bt_tiles, dim3(1), dim3(64), 0, st, scene_offsets, n_scenes, max_tiles, tile_scene, tile_first);
     hipLaunchKernelGGL(k_bt_pre, dim3(max_tiles), dim3(BT_THREADS), 0, st, feats, coords, scene_offsets, tile_scene,
                        tile_first, c, P, sA);
     for (int l = 0; l < n_layers; l++) {

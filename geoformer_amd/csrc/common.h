@@ -219,3 +219,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total) {
     return off + inc - v;
 }
 
+// backbone_attn.hip, for unet_exec.hip: the transformer's tile tables built ahead (side stream), then the transformer without them
+int gf_backbone_transformer_tables(const int* scene_offsets, int n_scenes, int M, void* scratch, void* stream);
+int gf_backbone_transformer_prepared(const float* feats, const int* coords, const int* scene_offsets, int n_scenes, int M, int c,
+                                     int n_layers, const float* const* params, void* scratch, float* out, void* stream);

@@ -602,6 +602,7 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         return GF_OK;
     };
     bool blocks_done[GF_UNET_MAX_LEVELS] = {true};
+    bool tr_tables[GF_UNET_MAX_LEVELS + 1] = {false};
     auto down_conv = [&](int l) -> int {
         const GfUnetLevelParams& L = P->level[l];
         const long long* o = offs + l * 10;
@@ -670,12 +671,21 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         }
         UN_TRY(take_counts(2, nl));
         for (int l = 2; l <= nl; l++) UN_TRY(subm_tables(l, ss));
+        for (int l = 2; l <= nl; l++) carve(l);
+        // the voxel transformers' scene offsets and tile tables: functions of the levels' coordinates, built here with the
+        // rulebooks instead of as two small launches in front of every transformer on the main stream
+        for (int l = 2; l <= nl; l++)
+            if (P->level[l].tr_layers > 0 && M[l] > 0 && Bf[l].tr_offs) {
+                hipLaunchKernelGGL(k_scene_offsets, dim3(gf_div_up(M[l] + 1, 256)), dim3(256), 0, ss, lcoords[l], M[l], B,
+                                   Bf[l].tr_offs);
+                UN_TRY(gf_backbone_transformer_tables(Bf[l].tr_offs, B, M[l], Bf[l].tr_scratch, ss));
+                tr_tables[l] = true;
+            }
         if (forked) {
             GF_TRY(hipEventRecord(t_ev.rules, ss));
             GF_TRY(hipStreamWaitEvent(st, t_ev.rules, 0));
         }
         UN_TRY(build_flat0());
-        for (int l = 2; l <= nl; l++) carve(l);
     }
 
     if (nl <= 1) UN_TRY(build_flat0());
@@ -714,7 +724,11 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         if (L.tr_layers > 0) {
             GF_CHECK_ARG(l > 0, "gf_unet_fwd: the voxel transformer needs batch-major rows (levels below the first)");
             GF_CHECK_ARG(L.tr_params != nullptr, "gf_unet_fwd: level %d: transformer parameters missing", l);
-            if (M[l] > 0) {
+            if (M[l] > 0 && tr_tables[l]) {
+                UN_TRY(gf_backbone_transformer_prepared(cur, lcoords[l], Bf[l].tr_offs, B, M[l], L.C, L.tr_layers, L.tr_params,
+                                                        Bf[l].tr_scratch, Bf[l].tr, st));
+                cur = Bf[l].tr;
+            } else if (M[l] > 0) {
                 hipLaunchKernelGGL(k_scene_offsets, dim3(gf_div_up(M[l] + 1, 256)), dim3(256), 0, st, lcoords[l], M[l], B,
                                    Bf[l].tr_offs);
                 UN_TRY(gf_backbone_transformer(cur, lcoords[l], Bf[l].tr_offs, B, M[l], L.C, L.tr_layers, L.tr_params,
