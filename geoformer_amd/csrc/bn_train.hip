@@ -306,11 +306,8 @@ inline BnClGeom bncl_geom(int R, long long L) {
 }
 
 __device__ __forceinline__ float2 block_sum2(float a, float b, float2* s_w) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        a += __shfl_xor(a, d, 64);
-        b += __shfl_xor(b, d, 64);
-    }
+    a = gf_wave_sum(a);  // (the __shfl_xor butterfly without the LDS crossbar: common.h)
+    b = gf_wave_sum(b);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) s_w[w] = make_float2(a, b);
     __syncthreads();

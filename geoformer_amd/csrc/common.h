@@ -108,6 +108,15 @@ __device__ __forceinline__ int gf_wave_sum_i(int s) {
     s += gf_shfl_xor_i<1>(s);
     return s;
 }
+__device__ __forceinline__ float gf_wave_max(float m) {
+    m = fmaxf(m, gf_shfl_xor<32>(m));
+    m = fmaxf(m, gf_shfl_xor<16>(m));
+    m = fmaxf(m, gf_shfl_xor<8>(m));
+    m = fmaxf(m, gf_shfl_xor<4>(m));
+    m = fmaxf(m, gf_shfl_xor<2>(m));
+    m = fmaxf(m, gf_shfl_xor<1>(m));
+    return m;
+}
 // sum over the wave with the order of `for (d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d)`
 __device__ __forceinline__ float gf_wave_sum(float s) {
     s += gf_shfl_xor<32>(s);

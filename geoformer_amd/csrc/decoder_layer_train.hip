@@ -63,22 +63,15 @@ __device__ __forceinline__ void dl_tile_layernorm_bwd(const float (*X)[DL_LD], c
             continue;
         }
         const float v = X[r][lane];
-        float s = v;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+        const float s = gf_wave_sum(v);  // (the __shfl_xor butterflies without the LDS crossbar: common.h)
         const float dv = v - s / (float)DL_D;
-        float q = dv * dv;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) q += __shfl_xor(q, d, 64);
+        const float q = gf_wave_sum(dv * dv);
         const float rstd = 1.0f / sqrtf(q / (float)DL_D + 1e-5f);
         const float xh = dv * rstd;
         const float g = G[r][lane] * wl;
         float sg = g, sgx = g * xh;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            sg += __shfl_xor(sg, d, 64);
-            sgx += __shfl_xor(sgx, d, 64);
-        }
+        sg = gf_wave_sum(sg);
+        sgx = gf_wave_sum(sgx);
         out(r, lane, rstd * (g - sg / (float)DL_D - xh * (sgx / (float)DL_D)));
         XH[r][lane] = xh;
     }
@@ -167,8 +160,8 @@ __global__ __launch_bounds__(DT_THREADS) void k_dt_pre_b(const float* __restrict
 #pragma unroll
             for (int i = 0; i < 4; i++) sc[i] = (kt * 16 + 4 * g + i) < T ? s[i] * 0.25f : -INFINITY;  // 1/sqrt(16)
             float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, gf_shfl_xor<16>(mx));
+            mx = fmaxf(mx, gf_shfl_xor<32>(mx));
             const float mnew = fmaxf(m, mx);
             const float corr = expf(m - mnew);
             float p[4];
@@ -183,8 +176,8 @@ __global__ __launch_bounds__(DT_THREADS) void k_dt_pre_b(const float* __restrict
                 o = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], pd, o, 0, 0, 0);
             }
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l += gf_shfl_xor<16>(l);
+        l += gf_shfl_xor<32>(l);
 #pragma unroll
         for (int i = 0; i < 4; i++) sO[j][h * DL_DK + 4 * g + i] = o[i] / l;
         if (g == 0 && qrow < T) LSE[(row0 + j) * DL_H + h] = m + logf(l);

@@ -72,12 +72,9 @@ __global__ __launch_bounds__(PR_THREADS) void k_proposal_stats(const float* __re
             ss += in ? sv[e] : 0.f;
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        cnt += __shfl_xor(cnt, d, 64);
-        sp += __shfl_xor(sp, d, 64);
-        ss += __shfl_xor(ss, d, 64);
-    }
+    cnt = gf_wave_sum_i(cnt);  // (the __shfl_xor butterflies without the LDS crossbar: common.h)
+    sp = gf_wave_sum(sp);
+    ss = gf_wave_sum(ss);
     if (lane == 0) {
         r_cnt[wave] = cnt;
         r_prob[wave] = sp;
@@ -131,11 +128,8 @@ __global__ __launch_bounds__(PR_THREADS) void k_proposal_stats_fs(const float* _
             sp += in ? pr : 0.f;
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        cnt += __shfl_xor(cnt, d, 64);
-        sp += __shfl_xor(sp, d, 64);
-    }
+    cnt = gf_wave_sum_i(cnt);
+    sp = gf_wave_sum(sp);
     if (lane == 0) {
         r_cnt[wave] = cnt;
         r_prob[wave] = sp;
@@ -246,8 +240,7 @@ __global__ __launch_bounds__(256) void k_mask_intersections(const unsigned long 
     const unsigned long long *a = bits + (size_t)i * W2, *b = bits + (size_t)j * W2;
     int c = 0;
     for (int w = lane; w < W2; w += 64) c += __popcll(a[w] & b[w]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    c = gf_wave_sum_i(c);
     if (lane == 0) {
         inter[(size_t)i * n + j] = c;
         inter[(size_t)j * n + i] = c;
@@ -293,8 +286,7 @@ __global__ __launch_bounds__(256) void k_relpos_gather(const float* __restrict__
         geo_ctx[(size_t)q * nc + j] = v;
         m = fmaxf(m, v);
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    m = gf_wave_max(m);
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) row_max[q] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
@@ -304,8 +296,7 @@ __global__ __launch_bounds__(1024) void k_relpos_fix(float* __restrict__ row_max
     __shared__ float s_m[16];
     float m = -INFINITY;
     for (int q = threadIdx.x; q < nq; q += 1024) m = fmaxf(m, row_max[q]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    m = gf_wave_max(m);
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
     float all = s_m[0];
