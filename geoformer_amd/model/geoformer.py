@@ -186,6 +186,7 @@ class PendingProposals:
         self.done = torch.cuda.Event()
         self.done.record(self.stream)
         self.value = None
+        self.home = None  # the caller's stream when this object lives on a side stream (generate_proposal)
 
     def get(self):
         if self.value is None:
@@ -207,6 +208,16 @@ class PendingProposals:
                 with torch.cuda.stream(self.stream):
                     proposals = pointops.proposal_scatter(logits, sel[:n], fg_idxs, logit_thresh, num_points)
                 self.value = (cls[:n], sc[:n], proposals)
+                if self.home is not None:
+                    # the scatter ran on the side stream: whoever reads the result on the stream that is current now
+                    # waits for it there
+                    cur = torch.cuda.current_stream(logits.device)
+                    if cur.cuda_stream != self.stream.cuda_stream:
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                        cur.wait_event(ev)
+                        for t in self.value:
+                            t.record_stream(cur)
             self.args = None
         return self.value
 
@@ -1100,11 +1111,31 @@ class GeoFormer(nn.Module):
             else:
                 sem = sem_prob if sem_prob is not None else F.softmax(semantic_scores_, dim=1)
                 sem_t = sem[offs_[b]:offs_[b + 1]].t()
-            cls_pred, _, scores, final = pointops.proposal_stats(
-                logits, cls_logits[b].contiguous(), sem_t.contiguous(), logit_thresh, score_thresh, npoint_thresh,
-                min_class=4, class_major=True)
-            pending = PendingProposals(final, cls_pred, scores, logits, fg_idxs.contiguous(), logit_thresh, num_points,
-                                       knn_flags=knn_flags)
+            # Deferred proposals (a loop that collects scene i's after it has issued scene i+1): statistics, selection, the
+            # count's copy and later the membership scatter -- ~0.1 ms of small launches that nothing on the caller's stream
+            # waits for -- go to the third stream behind the mask head, so that the NEXT scene's backbone does not queue
+            # behind them.  (Not in a serving loop's last part: its lanes are balanced as they are.)
+            side = None
+            if defer and not pointops.co_resident():
+                main = torch.cuda.current_stream(logits.device)
+                side = _SIDE_STREAMS.get((logits.device, main.cuda_stream, "aux"))
+            cls_b, sem_c, fg_c = cls_logits[b].contiguous(), sem_t.contiguous(), fg_idxs.contiguous()
+            if side is not None:
+                ready = torch.cuda.Event()
+                ready.record(main)
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    cls_pred, _, scores, final = pointops.proposal_stats(logits, cls_b, sem_c, logit_thresh, score_thresh,
+                                                                         npoint_thresh, min_class=4, class_major=True)
+                    pending = PendingProposals(final, cls_pred, scores, logits, fg_c, logit_thresh, num_points,
+                                               knn_flags=knn_flags)
+                pending.home = main
+                for t in (logits, cls_b, sem_c, fg_c) + tuple(knn_flags):
+                    t.record_stream(side)
+                return pending
+            cls_pred, _, scores, final = pointops.proposal_stats(logits, cls_b, sem_c, logit_thresh, score_thresh,
+                                                                 npoint_thresh, min_class=4, class_major=True)
+            pending = PendingProposals(final, cls_pred, scores, logits, fg_c, logit_thresh, num_points, knn_flags=knn_flags)
             return pending if defer else pending.get()
         sem = sem_prob if sem_prob is not None and not isinstance(sem_prob, tuple) else F.softmax(semantic_scores_, dim=1)
         num_points = int(batch_offsets[b + 1] - batch_offsets[b])
