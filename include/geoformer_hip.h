@@ -73,8 +73,9 @@ int gf_host_legacy_choice(uint32_t* key, int32_t* pos, long long n, long long k,
 int gf_host_legacy_prefetch(const uint32_t* key, int pos, long long nwords);
 /* The draw and what geoformer.py:575-579 does with it, from the host's side in ONE call (the device idles between the
  * arrival of the foreground count and the first sampling launch): the same draw as 32-bit indices into the caller's PINNED
- * buffer `pinned` (pinned_cap entries, >= k; with >= n the shuffle runs in place there), one asynchronous copy to
- * d_idx32[k], one launch that writes d_idx64[k] (the model's `sampling_indices`) and xyz_dst[k,3] = xyz_src[idx] (n rows).
+ * buffer `pinned` (pinned_cap entries, >= k; with >= n the shuffle runs in place there) and ONE launch that reads them
+ * there (device-visible host memory) and writes d_idx32[k], d_idx64[k] (the model's `sampling_indices`) and
+ * xyz_dst[k,3] = xyz_src[idx] (n rows).
  * key / pos: the generator's state, advanced in place.  The pinned buffer may be rewritten once the copy has left it
  * (stream order).  fps_m > 0: gf_furthest_point_sampling(xyz_dst, 1, k, fps_m, fps_idx, fps_scratch) is queued behind the
  * gather in the same call (geoformer.py:580-581 / pointnet2_utils.furthest_point_sample on the drawn points). */
