@@ -36,6 +36,48 @@ __global__ void k_concat2(const float4* __restrict__ a, const float4* __restrict
     out[i] = c < c4 ? a[(size_t)r * c4 + c] : b[(size_t)r * c4 + (c - c4)];
 }
 
+// The skip concatenation AND the tail block's 1x1x1 identity branch in one launch (round 6): cat[r] = (a[r], b[r]) and
+// idn[r] = W_i^T cat[r], W_i in the packed K = 1 layout of gf_conv_pack_weights (2C -> C).  One wave per (16-row group,
+// 16-column block): it reads the group's rows of a and b once -- 2C / 16 float4 per lane, all in flight together with the
+// weight operands --, the wave of column block 0 also writes them out as the concatenated rows, and the product runs
+// transposed like every convolution here (A = weights, B = rows: lane (r, q) ends with four consecutive output channels of
+// row r).  Replaces k_concat2 + a K = 1 gf_conv_fwd launch: one dependent launch less per tail block (six per forward).
+#define IDC_MAXCH 16  // 2C / 16 <= 16: widths up to C = 128
+__global__ __launch_bounds__(256) void k_concat2_idn(const float* __restrict__ a, const float* __restrict__ b, int M, int C,
+                                                     const float4* __restrict__ Wp, float* __restrict__ cat,
+                                                     float* __restrict__ idn) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int ncb = C >> 4, nch = C >> 3, nc1 = C >> 4;  // column blocks, input chunks (2C / 16), chunks that come from a
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ngroups = (M + 15) >> 4;
+    if (item >= ngroups * ncb) return;
+    const int g = item / ncb, cb = item - g * ncb;
+    const int row = g * 16 + r;
+    const int rc = row < M ? row : M - 1;
+    float4 x[IDC_MAXCH], w[IDC_MAXCH];
+#pragma unroll
+    for (int ch = 0; ch < IDC_MAXCH; ch++) {
+        if (ch < nch) {
+            const float* src = ch < nc1 ? a + (size_t)rc * C + ch * 16 + 4 * q : b + (size_t)rc * C + (ch - nc1) * 16 + 4 * q;
+            x[ch] = *reinterpret_cast<const float4*>(src);
+            w[ch] = Wp[(size_t)(ch * ncb + cb) * 64 + lane];
+        }
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < IDC_MAXCH; ch++) {
+        if (ch < nch) {
+            if (cb == 0 && row < M) *reinterpret_cast<float4*>(cat + (size_t)row * 2 * C + ch * 16 + 4 * q) = x[ch];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ch].x, x[ch].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ch].y, x[ch].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ch].z, x[ch].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ch].w, x[ch].w, acc, 0, 0, 0);
+        }
+    }
+    if (row < M) *reinterpret_cast<float4*>(idn + (size_t)row * C + cb * 16 + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 // scene_offsets[b] = first row of batch b (rows in batch-major order: every level below the first)
 __global__ void k_scene_offsets(const int32_t* __restrict__ coords, int M, int B, int32_t* __restrict__ offs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -505,6 +547,7 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         const float *s, *t;
         float* buf;
     };
+    bool idn_made = false;  // the next resblock's identity branch is in Bf[l].idn already (k_concat2_idn)
     auto resblock = [&](const GfResBlockParams& rb, int l, int cin, const float* x, float* outp, const float* osc,
                         const float* osh, const float* x_act = nullptr, const NextAct* next = nullptr) -> int {
         const int C = P->level[l].C;
@@ -513,11 +556,12 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         GF_CHECK_ARG((rb.wpi != nullptr) == (cin != C), "gf_unet_fwd: level %d: identity-branch weights must exist iff the widths differ", l);
         GF_CHECK_ARG(!(next && osc), "gf_unet_fwd: a block has one epilogue activation");
         int r;
-        if (rb.wpi) {
+        if (rb.wpi && !idn_made) {
             r = conv(l, 3, x, rb.wpi, nullptr, nullptr, nullptr, 1, M[l], M[l], 0, cin, C, nullptr, nullptr, nullptr, nullptr,
                      nullptr, Bf[l].idn);
             if (r != GF_OK) return r;
         }
+        idn_made = false;
         if (x_act)
             r = conv(l, 1, x_act, rb.wp0, t.nbr, t.gmask, t.steps, 27, M[l], M[l], t.ld, cin, C, nullptr, nullptr, nullptr, rb.s1,
                      rb.t1, Bf[l].tmp);
@@ -708,7 +752,22 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
             // BN + ReLU + SparseInverseConv3d: the one-hot `up` table of the chain; rows without a coarse cell stay zero
             UN_TRY(conv(l, 5, Bf[l + 1].o2, L.up_wp, cws + o[7], (const uint32_t*)(cws + o[9]), nullptr, 8, M[l + 1], M[l],
                         caps[l], P->level[l + 1].C, L.C, L.up_s, L.up_t, nullptr, nullptr, nullptr, Bf[l].up));
-            if (M[l] > 0) {
+            if (M[l] > 0 && L.tail[0].wpi && L.C % 16 == 0 && L.C / 8 <= IDC_MAXCH) {
+                // concatenation + the tail block's identity branch in one launch; the probe books it as that convolution
+                Probe& pb = t_probe;
+                const bool rec = pb.mode == 2;
+                ProbeRec pr{l, 3, 1, 2 * L.C, L.C, M[l], M[l], 0, -1, rec ? pb.ev() : nullptr, rec ? pb.ev() : nullptr, nullptr,
+                            nullptr};
+                if (rec) GF_TRY(hipEventRecord(pr.a, st));
+                const int items = ((M[l] + 15) / 16) * (L.C / 16);
+                hipLaunchKernelGGL(k_concat2_idn, dim3(gf_div_up(items, 4)), dim3(256), 0, st, Bf[l].o1, Bf[l].up, M[l], L.C,
+                                   (const float4*)L.tail[0].wpi, Bf[l].cat, Bf[l].idn);
+                if (rec) {
+                    GF_TRY(hipEventRecord(pr.b, st));
+                    pb.recs.push_back(pr);
+                }
+                idn_made = true;
+            } else if (M[l] > 0) {
                 const int c4 = L.C / 4, n = M[l] * 2 * c4;
                 hipLaunchKernelGGL(k_concat2, dim3(gf_div_up(n, 256)), dim3(256), 0, st, (const float4*)Bf[l].o1,
                                    (const float4*)Bf[l].up, M[l], c4, (float4*)Bf[l].cat);
