@@ -316,7 +316,8 @@ extern "C" int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, con
 // been resident all along -- every rulebook launch goes to the side stream behind those events (and behind the end of
 // this thread's previous call, which read the same workspace), NOT behind whatever `stream` still has queued: in a loop
 // of forwards they run under the previous scene's latency-bound sampling / BFS stretch and this scene's convolutions
-// start on finished tables.  Same launches, same results as gf_unet_fwd; needs a side stream (else: gf_unet_fwd).
+// start on finished tables.  `feats` is read there too (the zero-padded input rows): same events, or made on the side
+// stream.  Same launches, same results as gf_unet_fwd; needs a side stream (else: gf_unet_fwd).
 extern "C" int gf_unet_fwd_ahead(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y,
                                  int Z, void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream,
                                  void* side_stream, void* const* input_events, int n_input) {
@@ -421,6 +422,16 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         if (caps[l] >= kFlatMinRows) T[l].flat = a.take<int32_t>(gf_rules_flat_words(27, caps[l]));
     }
 
+    // feature buffers are carved after the counts are known for the levels below the first; level 1 now
+    int M[GF_UNET_MAX_LEVELS];
+    M[0] = M0;
+    LevelBufs Bf[GF_UNET_MAX_LEVELS];
+    auto carve = [&](int l) {
+        carve_level(a, Bf[l], (size_t)r16(M[l]), (size_t)P->level[l].C, P->level[l].tr_layers > 0, B);
+    };
+    carve(0);
+    float* x16 = a.take<float>((size_t)ld0 * 16);
+
     int rc;
 #define UN_TRY(call)                  \
     do {                              \
@@ -440,6 +451,8 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
         // chain behind them: with nothing of a previous scene to hide under (a loop that waits for every scene's results) the
         // chain's ~0.11 ms would otherwise sit in front of the first convolution instead of beside the first level's
         UN_TRY(fork_side());
+        // (the zero-padded input rows too: the voxel features were made on this stream -- GeoFormer._inputs_ahead)
+        hipLaunchKernelGGL(k_pad_channels, dim3(gf_div_up(M0 * 16, 256)), dim3(256), 0, ss, feats, M0, P->cin, 16, x16);
         UN_TRY(gf_index_build(coords, M0, nullptr, B, X, Y, Z, bitmap0, prefix0, perm0, iscratch, ss));
         UN_TRY(gf_rules_subm3(coords, M0, nullptr, X, Y, Z, bitmap0, prefix0, perm0, T[0].nbr, ld0, T[0].gmask, T[0].steps, ss));
         GF_TRY(hipEventRecord(t_ev.tbl0, ss));
@@ -475,15 +488,6 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
     };
     if (forked && !ahead) GF_TRY(hipEventRecord(t_ev.tbl0, st));
 
-    // feature buffers are carved after the counts are known for the levels below the first; level 1 now
-    int M[GF_UNET_MAX_LEVELS];
-    M[0] = M0;
-    LevelBufs Bf[GF_UNET_MAX_LEVELS];
-    auto carve = [&](int l) {
-        carve_level(a, Bf[l], (size_t)r16(M[l]), (size_t)P->level[l].C, P->level[l].tr_layers > 0, B);
-    };
-    carve(0);
-    float* x16 = a.take<float>((size_t)ld0 * 16);
 
     // every convolution of the call goes through here (kind: 0 input, 1 / 2 first / second conv of a block, 3 its
     // 1x1x1 identity branch, 4 strided, 5 inverse); the dev probe, when armed, brackets the launch with two events.
@@ -583,7 +587,7 @@ static int unet_fwd_impl(const GfUnetParams* P, const float* feats, const int32_
     for (int e = 0; e < n_gate; e++) GF_TRY(hipStreamWaitEvent(st, (hipEvent_t)gate_events[e], 0));
     {
         const int n = M0 * 16;
-        hipLaunchKernelGGL(k_pad_channels, dim3(gf_div_up(n, 256)), dim3(256), 0, st, feats, M0, P->cin, 16, x16);
+        if (!ahead) hipLaunchKernelGGL(k_pad_channels, dim3(gf_div_up(n, 256)), dim3(256), 0, st, feats, M0, P->cin, 16, x16);
         const GfResBlockParams& b0 = P->level[0].blocks[0];
         if (dual0)
             UN_TRY(conv(0, 0, x16, P->input_wp, T[0].nbr, T[0].gmask, T[0].steps, 27, M0, M0, ld0, 16, 16, nullptr, nullptr, nullptr,

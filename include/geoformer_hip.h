@@ -329,7 +329,8 @@ int gf_unet_fwd_phased(const GfUnetParams* P, const float* feats, const int32_t*
  * resident all along); every rulebook launch goes to side_stream behind those events and behind the end of this host
  * thread's previous gf_unet_fwd* call (which read the same workspace) -- not behind what `stream` still has queued.  In a
  * loop of forwards they then run under the previous scene's sampling / BFS stretch (test.py:52-96 calls the model scene
- * after scene).  `feats` and everything else keep `stream`'s order.  Same launches and results; side_stream NULL: gf_unet_fwd. */
+ * after scene).  `feats` is read on side_stream as well (the zero-padded input rows are made there): it waits for the same
+ * events, or was produced on side_stream itself.  Same launches and results; side_stream NULL: gf_unet_fwd. */
 int gf_unet_fwd_ahead(const GfUnetParams* P, const float* feats, const int32_t* coords, int M0, int B, int X, int Y, int Z,
                       void* ws, size_t ws_bytes, int32_t* host_counts, float* out, void* stream, void* side_stream,
                       void* const* input_events, int n_input);
