@@ -87,6 +87,20 @@ if os.path.exists(_CONV_SRC):
     if PMC_TRAFFIC.get("kernel_source_sha256") != _sha:
         PMC_TRAFFIC = {"bytes": None, "source": "stale: " + str(PMC_TRAFFIC.get("source")) + " was collected on another "
                        "version of csrc/spconv_conv.hip -- re-run tools/pmc_conv.sh"}
+# the same for the whole conv family of a forward (tools/pmc_conv_family.sh): quoted while the hash of the three sources it
+# covers matches
+PMC_FAMILY = {"bytes_per_forward": None, "source": "no profiles/pmc_conv_family_latest.json"}
+_PMC_FAMILY_FILE = os.path.join(ROOT, "profiles", "pmc_conv_family_latest.json")
+if os.path.exists(_PMC_FAMILY_FILE):
+    import hashlib
+
+    PMC_FAMILY = json.load(open(_PMC_FAMILY_FILE))
+    _srcs = [os.path.join(ROOT, "geoformer_amd", "csrc", f) for f in ("spconv_conv.hip", "spconv_lw.hip", "unet_exec.hip")]
+    if all(os.path.exists(f) for f in _srcs):
+        _sha = hashlib.sha256(b"".join(open(f, "rb").read() for f in _srcs)).hexdigest()
+        if PMC_FAMILY.get("kernel_source_sha256") != _sha:
+            PMC_FAMILY = {"bytes_per_forward": None, "source": "stale: " + str(PMC_FAMILY.get("source"))[:120] + " ... was "
+                          "collected on another version of the conv sources -- re-run tools/pmc_conv_family.sh"}
 # average duration of the same launches in the committed rocprofv3 kernel trace of `bench.py` (tools/bench_trace.sh
 # writes it): {"us_per_launch": ..., "source": ...}
 ROCPROF_FILE = os.path.join(ROOT, "profiles", "rocprof_conv_l1_latest.json")
@@ -1203,8 +1217,11 @@ def main():
             # binding roofline" -- with the level-1 16 -> 16 launch (the family's best kernel, 2-3 % of device time) beside it
             res["roofline"] = {
                 "bound": "hbm", "achieved": fam["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fam["frac"],
-                "traffic": None,
-                "traffic_note": "no PMC pass covers all 71 launches; level1_16to16.traffic is the level-1 launch's",
+                "traffic": PMC_FAMILY.get("bytes_per_forward"),
+                "traffic_note": "HBM-side bytes of the family PER FORWARD, like achieved (2 FETCH_SIZE + WRITE_SIZE in KiB over "
+                                "every k_conv_* launch and k_concat2_idn: " + str(PMC_FAMILY.get("source"))[:200] + ")",
+                "actual_hbm_frac": (round(PMC_FAMILY["bytes_per_forward"] / (fam["us_per_forward"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                                    if PMC_FAMILY.get("bytes_per_forward") else None),
                 "kernel": "the sparse-convolution family: all 71 launches of a forward (k_conv_g16p / k_conv_lw / k_conv_os / "
                           "k_conv_flat / k_conv_pair), sum of SURVEY 8(d) algorithmic bytes / sum of launch durations "
                           "(events around every launch, untimed extra passes: roofline_convs)",
