@@ -15,10 +15,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#ifdef DRAW_TIMING
-#include <stdio.h>
-#include <time.h>
-#endif
 
 #include "common.h"
 
@@ -257,9 +253,6 @@ static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long 
     uint32_t* J = t_ds.J;
     // 32-bit working set: half the cache footprint (the caller's own buffer when it takes 32-bit indices and has the room)
     uint32_t* x = (out32 && cap32 >= n) ? (uint32_t*)out32 : t_ds.x;
-#ifdef DRAW_TIMING
-    struct timespec ts0, ts1, ts2, ts3; clock_gettime(CLOCK_MONOTONIC, &ts0);
-#endif
     // pass 1: the swap partner of every position, top down: Jq[q] belongs to position n - 1 - q
 #ifdef GF_DRAW_AVX2
     static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
@@ -318,9 +311,6 @@ static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long 
             pos = (int)(more - (adv - 1) * MT_N);
         }
     }
-#ifdef DRAW_TIMING
-    clock_gettime(CLOCK_MONOTONIC, &ts1);
-#endif
     // pass 2: the swaps
     for (long long t = 0; t < n; t++) x[t] = (uint32_t)t;
     for (long long p = n - 1, s = 0; p >= 1; p--, s++) {
@@ -330,18 +320,9 @@ static int legacy_choice_impl(uint32_t* key, int32_t* pos_io, long long n, long 
         x[j] = x[p];
         x[p] = tmp;
     }
-#ifdef DRAW_TIMING
-    clock_gettime(CLOCK_MONOTONIC, &ts2);
-#endif
     if (out)
         for (long long t = 0; t < k; t++) out[t] = (long long)x[t];
     if (out32 && (uint32_t*)out32 != x) memcpy(out32, x, (size_t)k * sizeof(int32_t));
-#ifdef DRAW_TIMING
-    clock_gettime(CLOCK_MONOTONIC, &ts3);
-    { static int cnt = 0; if ((cnt++ % 50) == 0) fprintf(stderr, "draw n=%lld pass1 %.1f us pass2 %.1f us out %.1f us\n", n,
-        (ts1.tv_sec - ts0.tv_sec) * 1e6 + (ts1.tv_nsec - ts0.tv_nsec) * 1e-3, (ts2.tv_sec - ts1.tv_sec) * 1e6 + (ts2.tv_nsec - ts1.tv_nsec) * 1e-3,
-        (ts3.tv_sec - ts2.tv_sec) * 1e6 + (ts3.tv_nsec - ts2.tv_nsec) * 1e-3); }
-#endif
     *pos_io = pos;
     return GF_OK;
 }
