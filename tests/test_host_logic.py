@@ -167,3 +167,29 @@ def test_dropout_keep_reference_is_the_hash_the_header_states():
                                           torch.arange(64).view(1, -1).expand(4096, 64))
     assert abs(float((big == 0).float().mean()) - 0.1) < 0.005
     assert float(pointops.dropout_keep_reference(7, 0.0, 3, torch.arange(8), torch.arange(8)).min()) == 1.0
+
+
+def test_host_wait_word_returns_the_stored_value_or_times_out(lib):
+    """gf_host_wait_word (the host side of gf_fg_select's polled count): a word that already differs from `pending` comes
+    back at once; one that never changes comes back as `pending` after the time-out; a word another thread stores to
+    ends the wait."""
+    import ctypes
+    import threading
+    import time
+
+    w = (ctypes.c_int32 * 1)(42)
+    assert lib.gf_host_wait_word(ctypes.addressof(w), -1, 1_000_000) == 42
+    w[0] = -1
+    t0 = time.perf_counter()
+    assert lib.gf_host_wait_word(ctypes.addressof(w), -1, 20_000) == -1
+    assert 0.015 < time.perf_counter() - t0 < 1.0
+
+    def store():
+        time.sleep(0.01)
+        w[0] = 7
+
+    th = threading.Thread(target=store)
+    th.start()
+    assert lib.gf_host_wait_word(ctypes.addressof(w), -1, 5_000_000) == 7
+    th.join()
+    assert lib.gf_host_wait_word(None, -1, 10) == -1
