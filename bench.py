@@ -104,6 +104,22 @@ if os.path.exists(_PMC_FAMILY_FILE):
 # average duration of the same launches in the committed rocprofv3 kernel trace of `bench.py` (tools/bench_trace.sh
 # writes it): {"us_per_launch": ..., "source": ...}
 ROCPROF_FILE = os.path.join(ROOT, "profiles", "rocprof_conv_l1_latest.json")
+ROCPROF_FAMILY_FILE = os.path.join(ROOT, "profiles", "rocprof_conv_family_latest.json")
+
+
+def _family_rocprof(fam):
+    """The committed rocprofv3 kernel trace's figure for the same 71 launches (summed KERNEL durations per forward) beside
+    the live one (events around every launch: they also see the dependent-dispatch gap in front of each launch, ~3 us x 71).
+    `frac` stays on the slower, live figure."""
+    if not os.path.exists(ROCPROF_FAMILY_FILE):
+        return {}
+    rp = json.load(open(ROCPROF_FAMILY_FILE))
+    us = float(rp["us_per_forward"])
+    return {"frac_by_launch_events": fam["frac"], "rocprof_us_per_forward": us,
+            "frac_by_rocprof_trace": round(fam["algorithmic_bytes_per_forward"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "rocprof_source": rp.get("source"),
+            "frac_note": "frac = the slower of the two: events recorded around every launch inside bench.py (they include the "
+                         "dependent-dispatch gap in front of a launch) against the kernels' own durations in the committed trace"}
 
 
 def build_model(device, nfg_frac=0.4, probe_batch=None, bias_shift=None, cfg_name="test_geoformer_scannet.yaml"):
@@ -1222,6 +1238,7 @@ def main():
                                 "every k_conv_* launch and k_concat2_idn: " + str(PMC_FAMILY.get("source"))[:200] + ")",
                 "actual_hbm_frac": (round(PMC_FAMILY["bytes_per_forward"] / (fam["us_per_forward"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                                     if PMC_FAMILY.get("bytes_per_forward") else None),
+                **_family_rocprof(fam),
                 "kernel": "the sparse-convolution family: all 71 launches of a forward (k_conv_g16p / k_conv_lw / k_conv_os / "
                           "k_conv_flat / k_conv_pair), sum of SURVEY 8(d) algorithmic bytes / sum of launch durations "
                           "(events around every launch, untimed extra passes: roofline_convs)",

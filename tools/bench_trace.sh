@@ -21,6 +21,16 @@ if conv:
                "source": "profiles/<round>_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of bench.py (tools/bench_trace.sh), "
                          "call-weighted mean of the level-1 16->16 launches of the residual blocks (k_conv_g16p<1, false, *>)"},
               open('$R/gpurun_out/$tag/rocprof_conv_l1.json','w'), indent=1)
+fam = ('k_conv_g16p', 'k_conv_lw', 'k_conv_os', 'k_conv_flat', 'k_conv_pair', 'k_concat2_idn')
+nf = [int(r['Calls']) for r in rows if 'k_voxelize_fp' in r['Name']]
+if nf:
+    import json
+    ftot = sum(float(r['TotalDurationNs']) for r in rows if any(k in r['Name'] for k in fam))
+    fcalls = sum(int(r['Calls']) for r in rows if any(k in r['Name'] for k in fam))
+    json.dump({"us_per_forward": round(ftot / nf[0] / 1e3, 1), "launches_per_forward": round(fcalls / nf[0], 2), "forwards": nf[0],
+               "source": "profiles/<round>_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of bench.py (tools/bench_trace.sh), summed "
+                         "kernel durations of every k_conv_* launch and k_concat2_idn per forward (forwards = k_voxelize_fp calls)"},
+              open('$R/gpurun_out/$tag/rocprof_conv_family.json', 'w'), indent=1)
 for r in rows[:int('${2:-28}')]:
     print(f"{r['Name'][:64]:64s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:8.2f} min {float(r['MinNs'])/1e3:7.2f} total {float(r['TotalDurationNs'])/1e6:7.3f} ms {float(r['Percentage']):5.1f}%")
 PY

@@ -9,5 +9,5 @@ python tools/summarize_trace.py $(ls gpurun_out/${tag}_t/prof/*/*kernel_trace.cs
 python tools/trace_span.py $(ls gpurun_out/${tag}_t/prof/*/*kernel_trace.csv) k_voxelize_fp 25 10 > gpurun_out/$tag/forward_timeline.txt 2>&1
 python tools/trace_span.py $(ls gpurun_out/${tag}_t/prof/*/*kernel_trace.csv) k_voxelize_fp 0 10 > gpurun_out/$tag/forward_all_kernels.txt 2>&1
 cp gpurun_out/${tag}_t/prof/*/*kernel_stats.csv gpurun_out/$tag/bench_kernel_stats.csv
-cp gpurun_out/${tag}_t/rocprof_conv_l1.json gpurun_out/$tag/
+cp gpurun_out/${tag}_t/rocprof_conv_l1.json gpurun_out/${tag}_t/rocprof_conv_family.json gpurun_out/$tag/
 rm -rf gpurun_out/${tag}_t/prof
